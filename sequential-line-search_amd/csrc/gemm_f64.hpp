@@ -1,0 +1,172 @@
+// fp64 MFMA GEMM building block for gfx950 (MI355X / CDNA4).
+//
+// One workgroup (256 threads = 4 waves, 2x2) computes a 128x128 tile of
+//     C[m][n] (+)= sum_k opA[m][k] * opB[n][k]
+// with v_mfma_f64_16x16x4_f64.  Each wave owns a 64x64 sub-tile = 4x4 MFMA
+// tiles (128 accumulator VGPRs).  Operand tiles are staged global -> regs ->
+// LDS in BK=16 slabs, double buffered, one barrier per slab (64 MFMAs per wave
+// between barriers).
+//
+// Both operands are "M x K" style matrices; each may be stored either
+//   M-contiguous ("MC"):  elem(m,k) = P[m + k*ld]   (column-major M x K)
+//   K-contiguous ("KC"):  elem(m,k) = P[k + m*ld]   (column-major K x M)
+// so NT / NN / TN / TT products of column-major matrices are all covered
+// without a transposing copy.  LDS images:
+//   MC: [16 k][144]  (128 + 16 pad doubles: row stride 1152 B == 128 mod 256 ->
+//        the two 16-lane k-rows of a ds_read_b64 half-wave hit disjoint banks)
+//   KC: [128 m][18]  (16 + 2 pad doubles: m*18 mod 32 distinct even numbers)
+// both 18432 B, conflict-free for the MFMA fragment reads.
+//
+// The MFMA is issued as D = Bfrag x Afrag so that the 16 lanes sharing
+// lane>>4 hold 16 consecutive m (the memory-contiguous direction of C):
+//   acc[i][j][r] = C[m = 16 i + (lane & 15)][n = 16 j + (lane >> 4) + 4 r]
+// (f64 16x16x4 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg).
+//
+// All dimensions are multiples of the tile (callers pad).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace slsk {
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+constexpr int GEMM_BM = 128;
+constexpr int GEMM_BN = 128;
+constexpr int GEMM_BK = 16;
+constexpr int GEMM_THREADS = 256;
+constexpr int GEMM_LDS_MC_LD = 144;                       // doubles per k-row (MC image)
+constexpr int GEMM_LDS_KC_LD = 18;                        // doubles per m-row (KC image)
+constexpr int GEMM_LDS_TILE = 16 * 144;                   // doubles per operand slab (= 128*18)
+constexpr int GEMM_LDS_BYTES = 4 * GEMM_LDS_TILE * 8;     // A,B x 2 buffers = 73728 B
+
+struct Acc {
+    d4_t v[4][4];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
+    }
+};
+
+// Staging registers for one 128x16 operand slab: 8 doubles per thread.
+struct Stage {
+    d2_t r[4];
+};
+
+template <bool KC>
+__device__ __forceinline__ void stage_load(Stage& s, const double* __restrict__ P, long ld, int k0, int tid) {
+    // P points at (m0, k = 0) of the operand panel.
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i;
+        if (!KC) {
+            const int k = idx >> 6, m2 = idx & 63;
+            s.r[i] = *reinterpret_cast<const d2_t*>(P + (long)(2 * m2) + (long)(k0 + k) * ld);
+        } else {
+            const int m = idx >> 3, k2 = idx & 7;
+            s.r[i] = *reinterpret_cast<const d2_t*>(P + (long)(k0 + 2 * k2) + (long)m * ld);
+        }
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void stage_store(const Stage& s, double* lds, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i;
+        if (!KC) {
+            const int k = idx >> 6, m2 = idx & 63;
+            *reinterpret_cast<d2_t*>(lds + k * GEMM_LDS_MC_LD + 2 * m2) = s.r[i];
+        } else {
+            const int m = idx >> 3, k2 = idx & 7;
+            *reinterpret_cast<d2_t*>(lds + m * GEMM_LDS_KC_LD + 2 * k2) = s.r[i];
+        }
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ double frag_read(const double* lds, int mbase, int kk, int lane) {
+    // fragment element (row = mbase + (lane & 15), k = 4 kk + (lane >> 4))
+    if (!KC)
+        return lds[(4 * kk + (lane >> 4)) * GEMM_LDS_MC_LD + mbase + (lane & 15)];
+    else
+        return lds[(mbase + (lane & 15)) * GEMM_LDS_KC_LD + 4 * kk + (lane >> 4)];
+}
+
+// Accumulate acc += opA[m0.., kb..ke) * opB[n0.., kb..ke)^T.
+// A, B point at row m0 / n0, k = 0 of their panels.  kb, ke multiples of 16.
+// `lds` is the 73728-byte, 16-byte aligned dynamic LDS block.
+template <bool A_KC, bool B_KC>
+__device__ __forceinline__ void gemm_tile(Acc& acc, const double* __restrict__ A, long lda,
+                                          const double* __restrict__ B, long ldb, int kb, int ke, double* lds) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = (wave & 1) * 64;   // wave's m offset inside the tile
+    const int wn = (wave >> 1) * 64;  // wave's n offset
+    if (kb >= ke) return;
+
+    double* ldsA[2] = {lds, lds + 2 * GEMM_LDS_TILE};
+    double* ldsB[2] = {lds + GEMM_LDS_TILE, lds + 3 * GEMM_LDS_TILE};
+
+    Stage sa, sb;
+    stage_load<A_KC>(sa, A, lda, kb, tid);
+    stage_load<B_KC>(sb, B, ldb, kb, tid);
+    stage_store<A_KC>(sa, ldsA[0], tid);
+    stage_store<B_KC>(sb, ldsB[0], tid);
+    __syncthreads();
+
+    int buf = 0;
+    for (int k0 = kb; k0 < ke; k0 += GEMM_BK) {
+        const bool more = (k0 + GEMM_BK) < ke;
+        if (more) {
+            stage_load<A_KC>(sa, A, lda, k0 + GEMM_BK, tid);
+            stage_load<B_KC>(sb, B, ldb, k0 + GEMM_BK, tid);
+        }
+        const double* la = ldsA[buf];
+        const double* lb = ldsB[buf];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            double af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = frag_read<A_KC>(la, wm + 16 * i, kk, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = frag_read<B_KC>(lb, wn + 16 * j, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc.v[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc.v[i][j], 0, 0, 0);
+        }
+        if (more) {
+            stage_store<A_KC>(sa, ldsA[buf ^ 1], tid);
+            stage_store<B_KC>(sb, ldsB[buf ^ 1], tid);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+}
+
+// Coordinates of accumulator element (i, j, r) inside the 128x128 tile.
+__device__ __forceinline__ int acc_m(int i) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    return (wave & 1) * 64 + 16 * i + (lane & 15);
+}
+__device__ __forceinline__ int acc_n(int j, int r) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    return (wave >> 1) * 64 + 16 * j + (lane >> 4) + 4 * r;
+}
+
+// XCD-aware tile order.  Workgroup b runs on XCD b % 8 (observed, speed only).
+// Give each XCD a contiguous run of the linear tile order so that the 64 tiles
+// resident on one XCD share operand panels in its private L2.
+__device__ __forceinline__ int xcd_remap(int b, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = b & 7, within = b >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + within;
+}
+
+}  // namespace slsk
