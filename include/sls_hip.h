@@ -1,0 +1,134 @@
+/*
+ * sls_hip.h -- C ABI of the MI355X-native GP regression + acquisition-maximisation
+ * hot path (drop-in for the compute behind sequential-line-search's Regressor /
+ * GaussianProcessRegressor / PreferenceRegressor / acquisition_func surface).
+ *
+ * The reference has no FFI layer: its "operator API" is the C++
+ * public surface itself.  Each entry point below names the reference function(s)
+ * whose arithmetic it replaces (paths relative to the reference tree).  The C++
+ * classes in include/sequential-line-search/ and the tests bind exactly these.
+ *
+ * Conventions
+ *   - plain C types only; every matrix is column-major double (Eigen::MatrixXd
+ *     layout).  X is D x N: one data point per column, D contiguous doubles.
+ *   - theta = (a, l_1..l_D)  (kernel_hyperparams), b = noise level.
+ *   - pointers are HOST pointers unless the parameter name ends in _dev.
+ *   - return 0 on success, <0 on error; sls_last_error() describes the last
+ *     failure of the calling thread.  There is NO CPU fallback: every entry point
+ *     runs hand-written gfx950 kernels and fails if no GPU is present.
+ *   - a context owns one HIP stream; handles are safe for concurrent const use
+ *     from one context's stream order (the reference shares one const regressor
+ *     across worker threads, src/acquisition-function.cpp:125-144).
+ */
+#ifndef SLS_HIP_H
+#define SLS_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* include/sequential-line-search/kernel-type.hpp:8-12 */
+#define SLS_KERNEL_ARD_SQUARED_EXPONENTIAL 0
+#define SLS_KERNEL_ARD_MATERN52 1
+/* include/sequential-line-search/acquisition-function.hpp:11-15 */
+#define SLS_ACQ_EXPECTED_IMPROVEMENT 0
+#define SLS_ACQ_GP_UCB 1
+
+#define SLS_OK 0
+#define SLS_ERR_INVALID (-1)
+#define SLS_ERR_HIP (-2)
+#define SLS_ERR_NOT_SPD (-3)
+#define SLS_ERR_NO_DEVICE (-4)
+
+typedef struct sls_ctx sls_ctx;
+typedef struct sls_gp sls_gp;
+
+const char* sls_last_error(void);
+int sls_version(void);
+
+/* ---- context ------------------------------------------------------------ */
+int sls_ctx_create(int device, sls_ctx** out);
+int sls_ctx_destroy(sls_ctx* ctx);
+/* Run on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL restores the own stream. */
+int sls_ctx_set_stream(sls_ctx* ctx, void* hip_stream);
+int sls_ctx_synchronize(sls_ctx* ctx);
+/* Upper bound on candidates evaluated per device pass (workspace = 3 * chunk * N_pad doubles). Default 16384. */
+int sls_ctx_set_candidate_chunk(sls_ctx* ctx, int chunk);
+
+/* ---- free functions of src/regressor.cpp --------------------------------- */
+/* CalcLargeKY (src/regressor.cpp:61-71); b = 0 gives CalcLargeKF (:73-89).  K_out is N x N. */
+int sls_gram(sls_ctx* ctx, const double* X, int D, int N, const double* theta, double b, int kernel, double* K_out);
+/* CalcSmallK (src/regressor.cpp:45-59) for M query points at once: Ks_out is N x M, column m = k(Xs[:,m], X). */
+int sls_gram_cross(sls_ctx* ctx, const double* X, int D, int N, const double* Xs, int M, const double* theta, int kernel,
+                   double* Ks_out);
+
+/* ---- dense factorisation (Eigen::LLT / MatrixXd::inverse stand-ins) ------ */
+/* Eigen::LLT<MatrixXd>(K) (src/preference-regressor.cpp:162,290): A (N x N, symmetric, lower read) -> lower factor L
+ * (upper zeroed).  SLS_ERR_NOT_SPD if a pivot is not positive. */
+int sls_potrf(sls_ctx* ctx, double* A, int N);
+/* LLT::solve (src/preference-regressor.cpp:165,296,309,320,329): B (N x nrhs) <- (L L^T)^-1 B. */
+int sls_potrs(sls_ctx* ctx, const double* L, int N, double* B, int nrhs);
+/* K^-1 from its Cholesky factor (replaces m_K_y.inverse(), src/gaussian-process-regressor.cpp:159,211,231). */
+int sls_potri(sls_ctx* ctx, const double* L, int N, double* Ainv);
+
+/* ---- GP handle ----------------------------------------------------------- */
+/* GaussianProcessRegressor(X, y, kernel_hyperparams, noise, kernel_type) (src/gaussian-process-regressor.cpp:214-232) and the
+ * post-MAP state of PreferenceRegressor (src/preference-regressor.cpp:289-290): builds K_y, its Cholesky factor, K_y^-1,
+ * alpha = K_y^-1 y and the hoisted PredictMaximumPointFromData (src/regressor.cpp:29-43) on the device. */
+int sls_gp_create(sls_ctx* ctx, const double* X, int D, int N, const double* y, const double* theta, double b, int kernel,
+                  sls_gp** out);
+int sls_gp_destroy(sls_gp* gp);
+
+#define SLS_GP_K_Y 0        /* N x N  m_K_y / m_K          (gaussian-process-regressor.hpp:31, preference-regressor.hpp:57) */
+#define SLS_GP_K_Y_INV 1    /* N x N  m_K_y_inv            (gaussian-process-regressor.hpp:32) */
+#define SLS_GP_CHOL_L 2     /* N x N  m_K_llt.matrixL()    (preference-regressor.hpp:60) */
+#define SLS_GP_ALPHA 3      /* N      K_y^-1 y */
+#define SLS_GP_MU_DATA 4    /* N      PredictMu at every data point (regressor.cpp:34-37) */
+int sls_gp_get_matrix(sls_gp* gp, int what, double* out);
+/* best_index / x_best: PredictMaximumPointFromData (src/regressor.cpp:29-43); mu_best = PredictMu(x_best);
+ * logdet = CalcLogDetOfSymmetricPositiveDefiniteMatrix(K_y).  Any out pointer may be NULL. */
+int sls_gp_get_summary(sls_gp* gp, int* best_index, double* mu_best, double* logdet);
+
+/* PredictMu / PredictSigma for M points (gaussian-process-regressor.cpp:234-255, preference-regressor.cpp:293-313). */
+int sls_gp_predict(sls_gp* gp, const double* Xs, int M, double* mu, double* sigma);
+/* PredictMuDerivative / PredictSigmaDerivative (:257-272 / :315-330) for M points: dmu, dsigma are D x M. */
+int sls_gp_predict_grad(sls_gp* gp, const double* Xs, int M, double* dmu, double* dsigma);
+/* acquisition_func::CalcAcquisitionValue / CalcAcquisitionValueDerivative (src/acquisition-function.cpp:170-230)
+ * for M points; grad (D x M) may be NULL. */
+int sls_acq_eval(sls_gp* gp, int acq_type, double ucb_h, const double* Xs, int M, double* val, double* grad);
+
+/* ---- multi-start maximiser ------------------------------------------------ */
+/* FindGlobalSolution, parallelised multi-start branch (src/acquisition-function.cpp:121-153): S bounded L-BFGS runs
+ * on [0,1]^D from the explicit starts (D x S), n_local objective evaluations each, all S advanced in lock step on the
+ * device; returns the first maximum over the end points (Eigen maxCoeff semantics).
+ * idx_out is the winning start's index plus start_index_offset (so that ranks sharding one global start set report
+ * global indices).  x_stars (D x S) / y_stars (S) may be NULL. */
+typedef struct sls_lbfgs_opts {
+    int history;        /* L-BFGS memory m (1..8), default 6 */
+    double c1;          /* Armijo constant, default 1e-4 */
+    double shrink;      /* backtracking factor, default 0.5 */
+    double gtol;        /* projected-gradient inf-norm stop, default 0 */
+    int max_backtracks; /* default 20 */
+} sls_lbfgs_opts;
+void sls_lbfgs_default_opts(sls_lbfgs_opts* o);
+int sls_acq_maximize(sls_gp* gp, int acq_type, double ucb_h, const double* starts, int S, int n_local,
+                     const sls_lbfgs_opts* opts, long start_index_offset, double* x_out, double* val_out, long* idx_out,
+                     double* x_stars, double* y_stars);
+/* Same, with the starts already resident in HBM (D x S column-major device buffer) -- the timed path of bench.py. */
+int sls_acq_maximize_dev(sls_gp* gp, int acq_type, double ucb_h, const double* starts_dev, int S, int n_local,
+                         const sls_lbfgs_opts* opts, long start_index_offset, double* x_out, double* val_out,
+                         long* idx_out);
+/* Re-fit an existing handle in place from device-resident X (D x N), y (N): the timed "GP fit" of bench.py. */
+int sls_gp_refit_dev(sls_gp* gp, const double* X_dev, const double* y_dev);
+
+/* ---- instrumentation ------------------------------------------------------ */
+/* Per-kernel accumulated device time (ms, HIP events on the context's stream) and launch counts since the last reset.
+ * Names: "gram", "potrf", "trtri", "lauum", "cross_gram", "acq_gemm", "grad_gemm", "finalize", "lbfgs". */
+int sls_prof_enable(sls_ctx* ctx, int on);
+int sls_prof_reset(sls_ctx* ctx);
+int sls_prof_get(sls_ctx* ctx, const char* name, double* total_ms, long* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

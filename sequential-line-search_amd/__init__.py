@@ -1,0 +1,232 @@
+"""sequential-line-search_amd -- MI355X-native GP regression + acquisition maximisation.
+
+This module is a thin ctypes binding of the C ABI in include/sls_hip.h (libsls_hip.so, hand-written
+gfx950 HIP kernels).  It exists for the tests and bench.py; the product host layer is the C++ classes
+under include/sequential-line-search/ + host/.  There is NO CPU fallback here: if the shared library is
+missing or no GPU is present every call raises.
+
+Array convention = the reference's Eigen layout: X has shape (D, N), one data point per column.
+"""
+import ctypes as C
+import os
+import weakref
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsls_hip.so")
+
+KERNEL_SE, KERNEL_MATERN52 = 0, 1
+ACQ_EI, ACQ_UCB = 0, 1
+GP_K_Y, GP_K_Y_INV, GP_CHOL_L, GP_ALPHA, GP_MU_DATA = 0, 1, 2, 3, 4
+
+_dp = C.POINTER(C.c_double)
+_lib = None
+
+
+class SlsError(RuntimeError):
+    pass
+
+
+class LbfgsOpts(C.Structure):
+    _fields_ = [("history", C.c_int), ("c1", C.c_double), ("shrink", C.c_double), ("gtol", C.c_double),
+                ("max_backtracks", C.c_int)]
+
+
+def lib():
+    """Load libsls_hip.so (raises if it has not been built -- see __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SlsError(f"{LIB_PATH} is missing: build it with `make -C sequential-line-search_amd/csrc` "
+                           "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.sls_last_error.restype = C.c_char_p
+    return _lib
+
+
+EXPORTS = [
+    "sls_last_error", "sls_version", "sls_ctx_create", "sls_ctx_destroy", "sls_ctx_set_stream", "sls_ctx_synchronize",
+    "sls_ctx_set_candidate_chunk", "sls_gram", "sls_gram_cross", "sls_potrf", "sls_potrs", "sls_potri", "sls_gp_create",
+    "sls_gp_destroy", "sls_gp_get_matrix", "sls_gp_get_summary", "sls_gp_predict", "sls_gp_predict_grad", "sls_acq_eval",
+    "sls_lbfgs_default_opts", "sls_acq_maximize", "sls_acq_maximize_dev", "sls_gp_refit_dev", "sls_prof_enable",
+    "sls_prof_reset", "sls_prof_get",
+]
+
+
+def _ck(rc):
+    if rc != 0:
+        raise SlsError(f"libsls_hip error {rc}: {lib().sls_last_error().decode()}")
+
+
+def _f(a):
+    return np.asfortranarray(np.asarray(a, dtype=np.float64))
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+class Context:
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        self._gps = []
+        _ck(lib().sls_ctx_create(int(device), C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            for ref in self._gps:          # handles must not outlive their context
+                gp = ref()
+                if gp is not None:
+                    gp.close()
+            self._gps = []
+            lib().sls_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        _ck(lib().sls_ctx_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        _ck(lib().sls_ctx_synchronize(self.h))
+
+    def set_candidate_chunk(self, chunk):
+        _ck(lib().sls_ctx_set_candidate_chunk(self.h, int(chunk)))
+
+    def prof_enable(self, on=True):
+        _ck(lib().sls_prof_enable(self.h, int(on)))
+
+    def prof_reset(self):
+        _ck(lib().sls_prof_reset(self.h))
+
+    def prof_get(self, name):
+        ms, n = C.c_double(), C.c_long()
+        _ck(lib().sls_prof_get(self.h, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    # ---- free functions (src/regressor.cpp) ----
+    def gram(self, X, theta, b, kernel):
+        X, theta = _f(X), _f(theta)
+        D, N = X.shape
+        K = np.empty((N, N), order="F")
+        _ck(lib().sls_gram(self.h, _p(X), D, N, _p(theta), C.c_double(b), int(kernel), _p(K)))
+        return K
+
+    def gram_cross(self, X, Xs, theta, kernel):
+        X, Xs, theta = _f(X), _f(Xs), _f(theta)
+        D, N = X.shape
+        M = Xs.shape[1]
+        Ks = np.empty((N, M), order="F")
+        _ck(lib().sls_gram_cross(self.h, _p(X), D, N, _p(Xs), M, _p(theta), int(kernel), _p(Ks)))
+        return Ks
+
+    def potrf(self, A):
+        A = _f(A).copy(order="F")
+        _ck(lib().sls_potrf(self.h, _p(A), A.shape[0]))
+        return A
+
+    def potrs(self, L, B):
+        L = _f(L)
+        B = _f(B).copy(order="F")
+        nrhs = 1 if B.ndim == 1 else B.shape[1]
+        _ck(lib().sls_potrs(self.h, _p(L), L.shape[0], _p(B), nrhs))
+        return B
+
+    def potri(self, L):
+        L = _f(L)
+        out = np.empty_like(L, order="F")
+        _ck(lib().sls_potri(self.h, _p(L), L.shape[0], _p(out)))
+        return out
+
+
+class GP:
+    """Device-resident GP state (GaussianProcessRegressor with fixed hyper-parameters / PreferenceRegressor post-MAP)."""
+
+    def __init__(self, ctx, X, y, theta, b, kernel=KERNEL_MATERN52):
+        self.ctx = ctx
+        X, y, theta = _f(X), _f(y), _f(theta)
+        self.D, self.N = X.shape
+        assert y.shape == (self.N,) and theta.shape == (self.D + 1,)
+        self.h = C.c_void_p()
+        _ck(lib().sls_gp_create(ctx.h, _p(X), self.D, self.N, _p(y), _p(theta), C.c_double(b), int(kernel), C.byref(self.h)))
+        ctx._gps.append(weakref.ref(self))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().sls_gp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def matrix(self, what):
+        out = np.empty((self.N, self.N), order="F") if what in (GP_K_Y, GP_K_Y_INV, GP_CHOL_L) else np.empty(self.N)
+        _ck(lib().sls_gp_get_matrix(self.h, int(what), _p(out)))
+        return out
+
+    def summary(self):
+        bi, mb, ld = C.c_int(), C.c_double(), C.c_double()
+        _ck(lib().sls_gp_get_summary(self.h, C.byref(bi), C.byref(mb), C.byref(ld)))
+        return dict(best_index=bi.value, mu_best=mb.value, logdet=ld.value)
+
+    def predict(self, Xs):
+        Xs = _f(Xs)
+        M = Xs.shape[1]
+        mu, sg = np.empty(M), np.empty(M)
+        _ck(lib().sls_gp_predict(self.h, _p(Xs), M, _p(mu), _p(sg)))
+        return mu, sg
+
+    def predict_grad(self, Xs):
+        Xs = _f(Xs)
+        M = Xs.shape[1]
+        dm, ds = np.empty((self.D, M), order="F"), np.empty((self.D, M), order="F")
+        _ck(lib().sls_gp_predict_grad(self.h, _p(Xs), M, _p(dm), _p(ds)))
+        return dm, ds
+
+    def acq_eval(self, Xs, acq=ACQ_EI, ucb_h=1.0, want_grad=True):
+        Xs = _f(Xs)
+        M = Xs.shape[1]
+        val = np.empty(M)
+        grad = np.empty((self.D, M), order="F") if want_grad else None
+        _ck(lib().sls_acq_eval(self.h, int(acq), C.c_double(ucb_h), _p(Xs), M, _p(val), _p(grad) if want_grad else None))
+        return (val, grad) if want_grad else val
+
+    def acq_maximize(self, starts, n_local, acq=ACQ_EI, ucb_h=1.0, offset=0, want_all=True, opts=None):
+        starts = _f(starts)
+        S = starts.shape[1]
+        x, val, idx = np.empty(self.D), C.c_double(), C.c_long()
+        xs = np.empty((self.D, S), order="F") if want_all else None
+        ys = np.empty(S) if want_all else None
+        _ck(lib().sls_acq_maximize(self.h, int(acq), C.c_double(ucb_h), _p(starts), S, int(n_local),
+                                   C.byref(opts) if opts is not None else None, C.c_long(offset), _p(x), C.byref(val),
+                                   C.byref(idx), _p(xs) if want_all else None, _p(ys) if want_all else None))
+        return dict(index=idx.value, x=x, value=val.value, x_stars=xs, y_stars=ys)
+
+    def acq_maximize_dev(self, starts_dev_ptr, S, n_local, acq=ACQ_EI, ucb_h=1.0, offset=0, opts=None):
+        x, val, idx = np.empty(self.D), C.c_double(), C.c_long()
+        _ck(lib().sls_acq_maximize_dev(self.h, int(acq), C.c_double(ucb_h), C.c_void_p(starts_dev_ptr), int(S), int(n_local),
+                                       C.byref(opts) if opts is not None else None, C.c_long(offset), _p(x), C.byref(val),
+                                       C.byref(idx)))
+        return dict(index=idx.value, x=x, value=val.value)
+
+    def refit_dev(self, X_dev_ptr, y_dev_ptr):
+        _ck(lib().sls_gp_refit_dev(self.h, C.c_void_p(X_dev_ptr), C.c_void_p(y_dev_ptr)))
+
+
+def merge_rank_results(results):
+    """Global argmax over per-rank (value, global_index, x) triples: highest value, ties -> lowest global index
+    (Eigen maxCoeff 'first maximum', src/acquisition-function.cpp:146-153).  `results` is an iterable of
+    (value, index, x) with x a length-D array."""
+    best = None
+    for v, i, x in results:
+        if best is None or v > best[0] or (v == best[0] and i < best[1]):
+            best = (float(v), int(i), np.asarray(x, dtype=np.float64))
+    return best

@@ -1,0 +1,685 @@
+// C-ABI of libsls_hip (include/sls_hip.h): host orchestration of the gfx950 kernels.  No CPU fallback.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+using namespace slsk;
+
+namespace slsk {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace slsk
+
+// ---- context --------------------------------------------------------------------------------------------
+hipEvent_t sls_ctx::get_event() {
+    if (!event_pool.empty()) {
+        hipEvent_t e = event_pool.back();
+        event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    SLS_HIP(hipEventCreate(&e));
+    return e;
+}
+void sls_ctx::prof_begin(const char*, hipEvent_t& e0) {
+    e0 = get_event();
+    SLS_HIP(hipEventRecord(e0, stream));
+}
+void sls_ctx::prof_end(const char* name, hipEvent_t e0) {
+    hipEvent_t e1 = get_event();
+    (void)hipEventRecord(e1, stream);
+    ProfEntry& pe = prof[name];
+    pe.pending.emplace_back(e0, e1);
+    pe.launches += 1;
+}
+void sls_ctx::prof_collect() {
+    for (auto& kv : prof) {
+        for (auto& pr : kv.second.pending) {
+            (void)hipEventSynchronize(pr.second);
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, pr.first, pr.second);
+            kv.second.ms += ms;
+            event_pool.push_back(pr.first);
+            event_pool.push_back(pr.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+
+#define SLS_TRY try {
+#define SLS_CATCH                                   \
+    }                                               \
+    catch (const slsk::HipFail& f) { return f.code; } \
+    catch (const std::exception& e) {               \
+        slsk::set_error("exception: %s", e.what()); \
+        return SLS_ERR_INVALID;                     \
+    }                                               \
+    return SLS_OK;
+
+extern "C" const char* sls_last_error(void) { return slsk::g_err; }
+extern "C" int sls_version(void) { return 100; }
+
+extern "C" int sls_ctx_create(int device, sls_ctx** out) {
+    SLS_TRY
+    SLS_REQUIRE(out != nullptr, "sls_ctx_create: out is NULL");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) {
+        set_error("sls_ctx_create: no HIP device available (%s); this library has no CPU fallback",
+                  e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+        return SLS_ERR_NO_DEVICE;
+    }
+    SLS_REQUIRE(device >= 0 && device < ndev, "sls_ctx_create: device %d out of range (%d devices)", device, ndev);
+    SLS_HIP(hipSetDevice(device));
+    std::unique_ptr<sls_ctx> c(new sls_ctx());
+    c->device = device;
+    SLS_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    SLS_HIP(hipMalloc((void**)&c->d_info, 64));
+    *out = c.release();
+    SLS_CATCH
+}
+
+extern "C" int sls_ctx_destroy(sls_ctx* ctx) {
+    if (!ctx) return SLS_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->prof_collect();
+    for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->d_info) (void)hipFree(ctx->d_info);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return SLS_OK;
+}
+
+extern "C" int sls_ctx_set_stream(sls_ctx* ctx, void* hip_stream) {
+    SLS_TRY
+    SLS_REQUIRE(ctx, "ctx is NULL");
+    SLS_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    SLS_CATCH
+}
+extern "C" int sls_ctx_synchronize(sls_ctx* ctx) {
+    SLS_TRY
+    SLS_REQUIRE(ctx, "ctx is NULL");
+    SLS_HIP(hipStreamSynchronize(ctx->stream));
+    SLS_CATCH
+}
+extern "C" int sls_ctx_set_candidate_chunk(sls_ctx* ctx, int chunk) {
+    SLS_TRY
+    SLS_REQUIRE(ctx && chunk >= 128, "candidate chunk must be >= 128");
+    ctx->cand_chunk = round_up(chunk, 128);
+    SLS_CATCH
+}
+extern "C" int sls_prof_enable(sls_ctx* ctx, int on) {
+    if (!ctx) return SLS_ERR_INVALID;
+    ctx->prof_on = on != 0;
+    return SLS_OK;
+}
+extern "C" int sls_prof_reset(sls_ctx* ctx) {
+    if (!ctx) return SLS_ERR_INVALID;
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->prof_collect();
+    ctx->prof.clear();
+    return SLS_OK;
+}
+extern "C" int sls_prof_get(sls_ctx* ctx, const char* name, double* total_ms, long* launches) {
+    if (!ctx || !name) return SLS_ERR_INVALID;
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->prof_collect();
+    auto it = ctx->prof.find(name);
+    if (total_ms) *total_ms = it == ctx->prof.end() ? 0.0 : it->second.ms;
+    if (launches) *launches = it == ctx->prof.end() ? 0 : it->second.launches;
+    return SLS_OK;
+}
+
+// ---- helpers --------------------------------------------------------------------------------------------
+static void h2d(sls_ctx* c, double* dst, const double* src, size_t n) {
+    SLS_HIP(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+}
+static void d2h(sls_ctx* c, double* dst, const double* src, size_t n) {
+    SLS_HIP(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+}
+static void sync(sls_ctx* c) { SLS_HIP(hipStreamSynchronize(c->stream)); }
+
+static void check_theta(const double* theta, int D) {
+    SLS_REQUIRE(theta != nullptr, "theta is NULL");
+    SLS_REQUIRE(theta[0] > 0.0, "theta[0] (signal variance) must be positive");
+    for (int d = 0; d < D; ++d) SLS_REQUIRE(theta[1 + d] > 0.0, "length scale %d must be positive", d);
+}
+
+// copies a padded (ld = Np) device matrix region [N x N] into a dense host N x N
+static void d2h_matrix(sls_ctx* c, double* dst, const double* src, int N, int Np) {
+    SLS_HIP(hipMemcpy2DAsync(dst, (size_t)N * 8, src, (size_t)Np * 8, (size_t)N * 8, N, hipMemcpyDeviceToHost, c->stream));
+}
+static void h2d_matrix(sls_ctx* c, double* dst, const double* src, int N, int Np) {
+    SLS_HIP(hipMemcpy2DAsync(dst, (size_t)Np * 8, src, (size_t)N * 8, (size_t)N * 8, N, hipMemcpyHostToDevice, c->stream));
+}
+
+// ---- GP handle --------------------------------------------------------------------------------------------
+struct sls_gp {
+    sls_ctx* ctx = nullptr;
+    int D = 0, N = 0, Np = 0, Dp = 0, Dcols = 0, kernel = 0;
+    double a = 0, b = 0;
+    std::vector<double> theta, Xh, yh;
+    DBuf X, y, inv_ell, XT, XaT, nx, L, Linv, Kinv, alpha, tvec, mu_data, scal;
+    long* d_idx = nullptr;
+    int best_index = 0;
+    double mu_best = 0, logdet = 0;
+    // evaluation workspace (grown on demand)
+    DBuf Ks, Cs, P, parts, Gs, Gm, XsT, ns, raw, outv, outg, outm, outs;
+    int ws_chunk = 0;
+    // L-BFGS state
+    DBuf lb_x, lb_g, lb_dir, lb_xt, lb_scr, lb_S, lb_Y, lb_rho, lb_f, lb_t, lb_val, lb_grad;
+    int* lb_int = nullptr;
+    int lb_Sp = 0, lb_m = 0;
+    ~sls_gp() {
+        if (d_idx) (void)hipFree(d_idx);
+        if (lb_int) (void)hipFree(lb_int);
+    }
+};
+
+static void gp_fit_device(sls_gp* g) {
+    sls_ctx* c = g->ctx;
+    const int N = g->N, Np = g->Np, D = g->D;
+    KernelSpec ks{g->kernel, g->a};
+    {
+        ProfScope ps(c, "gram");
+        launch_prep_points(c->stream, g->X.p, D, N, g->inv_ell.p, g->XT.p, Np, Np, g->Dcols, g->nx.p);
+        launch_gram_sym(c->stream, g->XT.p, Np, g->Dp, g->nx.p, Np, N, ks, g->b, g->L.p, true);
+    }
+    SLS_HIP(hipMemsetAsync(c->d_info, 0, 64, c->stream));
+    launch_fill(c->stream, g->Linv.p, (long)Np * Np, 0.0);
+    {
+        ProfScope ps(c, "potrf");
+        launch_potrf(c->stream, g->L.p, Np, g->Linv.p, c->d_info);
+    }
+    {
+        ProfScope ps(c, "trtri");
+        launch_trtri(c->stream, g->L.p, Np, g->Linv.p, g->Kinv.p);
+    }
+    {
+        ProfScope ps(c, "lauum");
+        launch_lauum(c->stream, g->Linv.p, Np, g->Kinv.p);
+    }
+    // alpha = Linv^T (Linv y);  mu at the data points = y - b alpha;  x_best = first argmax  (regressor.cpp:29-43 hoisted)
+    launch_gemv_n(c->stream, g->Linv.p, Np, g->y.p, g->tvec.p);
+    launch_gemv_t(c->stream, g->Linv.p, Np, g->tvec.p, g->alpha.p);
+    launch_scale_rows(c->stream, g->XT.p, g->alpha.p, g->XaT.p, Np, Np, g->Dcols);
+    launch_mu_data(c->stream, g->y.p, g->alpha.p, g->b, N, g->mu_data.p);
+    launch_argmax(c->stream, g->mu_data.p, N, g->scal.p, g->d_idx);
+    launch_logdet(c->stream, g->L.p, Np, N, g->scal.p + 1);
+}
+
+static void gp_fetch_summary(sls_gp* g) {
+    sls_ctx* c = g->ctx;
+    int info[16] = {0};
+    double sc[2];
+    long idx = 0;
+    SLS_HIP(hipMemcpyAsync(info, c->d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    SLS_HIP(hipMemcpyAsync(sc, g->scal.p, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    SLS_HIP(hipMemcpyAsync(&idx, g->d_idx, sizeof(long), hipMemcpyDeviceToHost, c->stream));
+    sync(c);
+    if (info[0] != 0) {
+        set_error("Cholesky failed: K_y is not positive definite (pivot %d)", info[0] - 1);
+        throw HipFail{SLS_ERR_NOT_SPD};
+    }
+    g->best_index = (int)idx;
+    g->mu_best = sc[0];
+    g->logdet = sc[1];
+}
+
+extern "C" int sls_gp_create(sls_ctx* ctx, const double* X, int D, int N, const double* y, const double* theta, double b,
+                             int kernel, sls_gp** out) {
+    SLS_TRY
+    SLS_REQUIRE(ctx && out, "sls_gp_create: NULL argument");
+    SLS_REQUIRE(D >= 1 && N >= 1, "sls_gp_create: need D >= 1 and N >= 1 (got D=%d N=%d)", D, N);
+    SLS_REQUIRE(X && y, "sls_gp_create: X / y is NULL");
+    SLS_REQUIRE(kernel == SLS_KERNEL_ARD_SQUARED_EXPONENTIAL || kernel == SLS_KERNEL_ARD_MATERN52, "unknown kernel %d", kernel);
+    SLS_REQUIRE(b >= 0.0, "noise level must be >= 0");
+    check_theta(theta, D);
+    SLS_HIP(hipSetDevice(ctx->device));
+    std::unique_ptr<sls_gp> g(new sls_gp());
+    g->ctx = ctx; g->D = D; g->N = N; g->kernel = kernel; g->a = theta[0]; g->b = b;
+    g->Np = round_up(N, 128); g->Dp = round_up(D, 16); g->Dcols = round_up(D, 128);
+    g->theta.assign(theta, theta + D + 1);
+    g->Xh.assign(X, X + (size_t)D * N);
+    g->yh.assign(y, y + N);
+    const size_t Np = g->Np;
+    g->X.ensure((size_t)D * N); g->y.ensure(Np); g->inv_ell.ensure(g->Dcols);
+    g->XT.ensure(Np * g->Dcols); g->XaT.ensure(Np * g->Dcols); g->nx.ensure(Np);
+    g->L.ensure(Np * Np); g->Linv.ensure(Np * Np); g->Kinv.ensure(Np * Np);
+    g->alpha.ensure(Np); g->tvec.ensure(Np); g->mu_data.ensure(Np); g->scal.ensure(8);
+    SLS_HIP(hipMalloc((void**)&g->d_idx, 64));
+    std::vector<double> il(g->Dcols, 0.0), ypad(Np, 0.0);
+    for (int d = 0; d < D; ++d) il[d] = 1.0 / theta[1 + d];
+    std::copy(y, y + N, ypad.begin());
+    h2d(ctx, g->X.p, X, (size_t)D * N);
+    h2d(ctx, g->y.p, ypad.data(), Np);
+    h2d(ctx, g->inv_ell.p, il.data(), g->Dcols);
+    sync(ctx);   // host staging vectors go out of scope
+    gp_fit_device(g.get());
+    gp_fetch_summary(g.get());
+    *out = g.release();
+    SLS_CATCH
+}
+
+extern "C" int sls_gp_refit_dev(sls_gp* g, const double* X_dev, const double* y_dev) {
+    SLS_TRY
+    SLS_REQUIRE(g && X_dev && y_dev, "sls_gp_refit_dev: NULL argument");
+    sls_ctx* c = g->ctx;
+    SLS_HIP(hipMemcpyAsync(g->X.p, X_dev, (size_t)g->D * g->N * 8, hipMemcpyDeviceToDevice, c->stream));
+    SLS_HIP(hipMemcpyAsync(g->y.p, y_dev, (size_t)g->N * 8, hipMemcpyDeviceToDevice, c->stream));
+    gp_fit_device(g);
+    gp_fetch_summary(g);
+    SLS_CATCH
+}
+
+extern "C" int sls_gp_destroy(sls_gp* gp) {
+    if (!gp) return SLS_OK;
+    (void)hipStreamSynchronize(gp->ctx->stream);
+    delete gp;
+    return SLS_OK;
+}
+
+extern "C" int sls_gp_get_summary(sls_gp* g, int* best_index, double* mu_best, double* logdet) {
+    if (!g) return SLS_ERR_INVALID;
+    if (best_index) *best_index = g->best_index;
+    if (mu_best) *mu_best = g->mu_best;
+    if (logdet) *logdet = g->logdet;
+    return SLS_OK;
+}
+
+extern "C" int sls_gp_get_matrix(sls_gp* g, int what, double* out) {
+    SLS_TRY
+    SLS_REQUIRE(g && out, "sls_gp_get_matrix: NULL argument");
+    sls_ctx* c = g->ctx;
+    const int N = g->N, Np = g->Np;
+    switch (what) {
+        case SLS_GP_K_Y: {
+            // m_K_y is not kept resident (the Cholesky factor overwrites it): rebuild the full symmetric matrix
+            DBuf K;
+            K.ensure((size_t)Np * Np);
+            launch_gram_sym(c->stream, g->XT.p, Np, g->Dp, g->nx.p, Np, N, KernelSpec{g->kernel, g->a}, g->b, K.p, false);
+            d2h_matrix(c, out, K.p, N, Np);
+            sync(c);
+            break;
+        }
+        case SLS_GP_K_Y_INV: d2h_matrix(c, out, g->Kinv.p, N, Np); sync(c); break;
+        case SLS_GP_CHOL_L: {
+            DBuf T;
+            T.ensure((size_t)Np * Np);
+            SLS_HIP(hipMemcpyAsync(T.p, g->L.p, (size_t)Np * Np * 8, hipMemcpyDeviceToDevice, c->stream));
+            launch_zero_upper(c->stream, T.p, Np);
+            d2h_matrix(c, out, T.p, N, Np);
+            sync(c);
+            break;
+        }
+        case SLS_GP_ALPHA: d2h(c, out, g->alpha.p, N); sync(c); break;
+        case SLS_GP_MU_DATA: d2h(c, out, g->mu_data.p, N); sync(c); break;
+        default: SLS_REQUIRE(false, "sls_gp_get_matrix: unknown selector %d", what);
+    }
+    SLS_CATCH
+}
+
+// ---- batched evaluation -------------------------------------------------------------------------------------
+static void ensure_eval_ws(sls_gp* g, int chunk) {
+    if (chunk <= g->ws_chunk) return;
+    const size_t Np = g->Np, C = chunk;
+    const size_t nbt = Np / 128;
+    g->Ks.ensure(C * Np);
+    if (g->kernel == SLS_KERNEL_ARD_MATERN52) g->Cs.ensure(C * Np);
+    g->P.ensure(C * Np);
+    g->parts.ensure(4 * nbt * C);
+    g->Gs.ensure(C * g->Dcols);
+    g->Gm.ensure(C * g->Dcols);
+    g->XsT.ensure(C * g->Dcols);
+    g->ns.ensure(C);
+    g->ws_chunk = chunk;
+}
+
+struct EvalOut {
+    // candidate-major device outputs with leading dimension ldo (full candidate count, padded); any may be NULL
+    long ldo = 0;
+    double *mu = nullptr, *sigma = nullptr, *dmu = nullptr, *dsigma = nullptr, *val = nullptr, *grad = nullptr;
+    int acq = SLS_ACQ_EXPECTED_IMPROVEMENT;
+    double ucb_h = 1.0;
+};
+
+// xr: raw candidate coordinates, candidate-major xr[n + d*ldr], S candidates.
+static void eval_candidates(sls_gp* g, const double* xr, long ldr, int S, const EvalOut& o) {
+    sls_ctx* c = g->ctx;
+    const int Np = g->Np, N = g->N, D = g->D;
+    const bool want_grad = o.dmu || o.dsigma || o.grad;
+    const int chunk_max = std::min(round_up(S, 128), c->cand_chunk);
+    ensure_eval_ws(g, chunk_max);
+    const int nbt = Np / 128;
+    KernelSpec ks{g->kernel, g->a};
+    for (int s0 = 0; s0 < S; s0 += chunk_max) {
+        const int sc = std::min(chunk_max, S - s0);
+        const int Sp = round_up(sc, 128);
+        const long ldk = Sp;
+        double* Cs = (g->kernel == SLS_KERNEL_ARD_MATERN52) ? g->Cs.p : g->Ks.p;
+        double* mu_part = g->parts.p;
+        double* ca_part = mu_part + (size_t)nbt * ldk;
+        double* kw_part = ca_part + (size_t)nbt * ldk;
+        double* cw_part = kw_part + (size_t)nbt * ldk;
+        {
+            ProfScope ps(c, "cross_gram");
+            launch_prep_cands(c->stream, xr + s0, ldr, D, sc, g->inv_ell.p, g->XsT.p, ldk, Sp, g->Dcols, g->ns.p);
+            launch_cross_gram(c->stream, g->XsT.p, ldk, g->ns.p, Sp, g->XT.p, Np, g->nx.p, Np, N, g->Dp, ks, g->alpha.p, g->Ks.p, Cs,
+                              ldk, mu_part, ca_part);
+        }
+        {
+            ProfScope ps(c, "acq_gemm");
+            launch_acq_gemm(c->stream, g->Ks.p, Cs, ldk, Sp, g->Kinv.p, Np, g->P.p, kw_part, cw_part);
+        }
+        if (want_grad) {
+            ProfScope ps(c, "grad_gemm");
+            launch_grad_gemm(c->stream, g->P.p, Cs, ldk, Sp, g->XT.p, g->XaT.p, Np, Np, g->Dcols, g->Gs.p, g->Gm.p);
+        }
+        {
+            ProfScope ps(c, "finalize");
+            FinalizeArgs f;
+            f.S = sc; f.D = D; f.nbt = nbt; f.ldk = ldk;
+            f.mu_part = mu_part; f.ca_part = ca_part; f.kw_part = kw_part; f.cw_part = cw_part;
+            f.Gs = g->Gs.p; f.Gm = g->Gm.p; f.XsT = g->XsT.p; f.inv_ell = g->inv_ell.p;
+            f.a = g->a; f.mu_best = g->mu_best; f.ucb_h = o.ucb_h; f.acq = o.acq;
+            f.ldo = o.ldo;
+            f.mu = o.mu ? o.mu + s0 : nullptr;
+            f.sigma = o.sigma ? o.sigma + s0 : nullptr;
+            f.dmu = o.dmu ? o.dmu + s0 : nullptr;
+            f.dsigma = o.dsigma ? o.dsigma + s0 : nullptr;
+            f.val = o.val ? o.val + s0 : nullptr;
+            f.grad = o.grad ? o.grad + s0 : nullptr;
+            launch_finalize(c->stream, f);
+        }
+    }
+}
+
+// host D x M column-major -> device candidate-major raw coordinates (clamping is NOT applied here)
+static void upload_candidates(sls_gp* g, const double* Xs, int M, DBuf& raw, int Mp) {
+    sls_ctx* c = g->ctx;
+    const int D = g->D;
+    std::vector<double> t((size_t)Mp * D, 0.5);
+    for (int m = 0; m < M; ++m)
+        for (int d = 0; d < D; ++d) t[(size_t)m + (size_t)d * Mp] = Xs[d + (size_t)m * D];
+    raw.ensure((size_t)Mp * D);
+    h2d(c, raw.p, t.data(), (size_t)Mp * D);
+    sync(c);
+}
+
+static void download_cm(sls_gp* g, const double* dev, int M, int Mp, int rows, double* host /* rows x M col-major or M */) {
+    sls_ctx* c = g->ctx;
+    std::vector<double> t((size_t)Mp * rows);
+    d2h(c, t.data(), dev, (size_t)Mp * rows);
+    sync(c);
+    if (rows == 1) {
+        std::copy(t.begin(), t.begin() + M, host);
+    } else {
+        for (int m = 0; m < M; ++m)
+            for (int d = 0; d < rows; ++d) host[d + (size_t)m * rows] = t[(size_t)m + (size_t)d * Mp];
+    }
+}
+
+extern "C" int sls_gp_predict(sls_gp* g, const double* Xs, int M, double* mu, double* sigma) {
+    SLS_TRY
+    SLS_REQUIRE(g && Xs && M >= 0, "sls_gp_predict: bad argument");
+    if (M == 0) return SLS_OK;
+    const int Mp = round_up(M, 128);
+    upload_candidates(g, Xs, M, g->raw, Mp);
+    g->outm.ensure(Mp); g->outs.ensure(Mp);
+    EvalOut o;
+    o.ldo = Mp; o.mu = g->outm.p; o.sigma = g->outs.p;
+    eval_candidates(g, g->raw.p, Mp, M, o);
+    if (mu) download_cm(g, g->outm.p, M, Mp, 1, mu);
+    if (sigma) download_cm(g, g->outs.p, M, Mp, 1, sigma);
+    SLS_CATCH
+}
+
+extern "C" int sls_gp_predict_grad(sls_gp* g, const double* Xs, int M, double* dmu, double* dsigma) {
+    SLS_TRY
+    SLS_REQUIRE(g && Xs && M >= 0, "sls_gp_predict_grad: bad argument");
+    if (M == 0) return SLS_OK;
+    const int Mp = round_up(M, 128), D = g->D;
+    upload_candidates(g, Xs, M, g->raw, Mp);
+    g->outv.ensure((size_t)Mp * D); g->outg.ensure((size_t)Mp * D);
+    EvalOut o;
+    o.ldo = Mp; o.dmu = g->outv.p; o.dsigma = g->outg.p;
+    eval_candidates(g, g->raw.p, Mp, M, o);
+    if (dmu) download_cm(g, g->outv.p, M, Mp, D, dmu);
+    if (dsigma) download_cm(g, g->outg.p, M, Mp, D, dsigma);
+    SLS_CATCH
+}
+
+extern "C" int sls_acq_eval(sls_gp* g, int acq_type, double ucb_h, const double* Xs, int M, double* val, double* grad) {
+    SLS_TRY
+    SLS_REQUIRE(g && Xs && M >= 0, "sls_acq_eval: bad argument");
+    SLS_REQUIRE(acq_type == SLS_ACQ_EXPECTED_IMPROVEMENT || acq_type == SLS_ACQ_GP_UCB, "unknown acquisition type %d", acq_type);
+    if (M == 0) return SLS_OK;
+    const int Mp = round_up(M, 128), D = g->D;
+    upload_candidates(g, Xs, M, g->raw, Mp);
+    g->outm.ensure(Mp);
+    if (grad) g->outg.ensure((size_t)Mp * D);
+    EvalOut o;
+    o.ldo = Mp; o.val = g->outm.p; o.grad = grad ? g->outg.p : nullptr; o.acq = acq_type; o.ucb_h = ucb_h;
+    eval_candidates(g, g->raw.p, Mp, M, o);
+    if (val) download_cm(g, g->outm.p, M, Mp, 1, val);
+    if (grad) download_cm(g, g->outg.p, M, Mp, D, grad);
+    SLS_CATCH
+}
+
+// ---- multi-start maximiser -------------------------------------------------------------------------------------
+extern "C" void sls_lbfgs_default_opts(sls_lbfgs_opts* o) {
+    o->history = 6; o->c1 = 1e-4; o->shrink = 0.5; o->gtol = 0.0; o->max_backtracks = 20;
+}
+
+static void ensure_lbfgs(sls_gp* g, int Sp, int m) {
+    if (Sp <= g->lb_Sp && m <= g->lb_m) return;
+    const size_t D = g->D, S = Sp;
+    g->lb_x.ensure(S * D); g->lb_g.ensure(S * D); g->lb_dir.ensure(S * D); g->lb_xt.ensure(S * D); g->lb_scr.ensure(S * D);
+    g->lb_S.ensure(S * D * m); g->lb_Y.ensure(S * D * m); g->lb_rho.ensure(S * m);
+    g->lb_f.ensure(S); g->lb_t.ensure(S); g->lb_val.ensure(S); g->lb_grad.ensure(S * D);
+    if (g->lb_int) (void)hipFree(g->lb_int);
+    SLS_HIP(hipMalloc((void**)&g->lb_int, S * 4 * sizeof(int)));
+    g->lb_Sp = Sp; g->lb_m = m;
+}
+
+static void maximize_impl(sls_gp* g, int acq_type, double ucb_h, const double* starts_dev, int S, int n_local,
+                          const sls_lbfgs_opts* opts_in, long off, double* x_out, double* val_out, long* idx_out,
+                          double* x_stars, double* y_stars) {
+    sls_ctx* c = g->ctx;
+    SLS_REQUIRE(S >= 1 && n_local >= 1, "sls_acq_maximize: need S >= 1 and n_local >= 1");
+    SLS_REQUIRE(acq_type == SLS_ACQ_EXPECTED_IMPROVEMENT || acq_type == SLS_ACQ_GP_UCB, "unknown acquisition type %d", acq_type);
+    sls_lbfgs_opts o;
+    if (opts_in) o = *opts_in; else sls_lbfgs_default_opts(&o);
+    SLS_REQUIRE(o.history >= 1 && o.history <= 8, "L-BFGS history must be in 1..8");
+    const int Sp = round_up(S, 128), D = g->D;
+    ensure_lbfgs(g, Sp, o.history);
+    LbfgsState st;
+    st.S = S; st.D = D; st.m = o.history; st.ld = Sp;
+    st.x = g->lb_x.p; st.g = g->lb_g.p; st.dir = g->lb_dir.p; st.xt = g->lb_xt.p; st.scr = g->lb_scr.p;
+    st.Sh = g->lb_S.p; st.Yh = g->lb_Y.p; st.rho = g->lb_rho.p; st.f = g->lb_f.p; st.t = g->lb_t.p;
+    st.hlen = g->lb_int; st.hpos = g->lb_int + Sp; st.nbt = g->lb_int + 2 * Sp; st.done = g->lb_int + 3 * Sp;
+    st.c1 = o.c1; st.shrink = o.shrink; st.gtol = o.gtol; st.max_backtracks = o.max_backtracks;
+    launch_clamp_starts(c->stream, starts_dev, D, S, st.xt, Sp, Sp);
+    EvalOut eo;
+    eo.ldo = Sp; eo.val = g->lb_val.p; eo.grad = g->lb_grad.p; eo.acq = acq_type; eo.ucb_h = ucb_h;
+    for (int ev = 0; ev < n_local; ++ev) {
+        eval_candidates(g, st.xt, Sp, S, eo);
+        ProfScope ps(c, "lbfgs");
+        launch_lbfgs_step(c->stream, st, g->lb_val.p, g->lb_grad.p, ev == 0);
+    }
+    launch_argmax_neg(c->stream, st.f, S, g->scal.p + 2, g->d_idx + 1);
+    double bv = 0;
+    long bi = 0;
+    SLS_HIP(hipMemcpyAsync(&bv, g->scal.p + 2, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    SLS_HIP(hipMemcpyAsync(&bi, g->d_idx + 1, sizeof(long), hipMemcpyDeviceToHost, c->stream));
+    sync(c);
+    if (val_out) *val_out = bv;
+    if (idx_out) *idx_out = bi + off;
+    if (x_out) {
+        SLS_HIP(hipMemcpy2DAsync(x_out, 8, st.x + bi, (size_t)Sp * 8, 8, D, hipMemcpyDeviceToHost, c->stream));
+        sync(c);
+    }
+    if (x_stars) download_cm(g, st.x, S, Sp, D, x_stars);
+    if (y_stars) {
+        download_cm(g, st.f, S, Sp, 1, y_stars);
+        for (int i = 0; i < S; ++i) y_stars[i] = -y_stars[i];
+    }
+}
+
+extern "C" int sls_acq_maximize(sls_gp* g, int acq_type, double ucb_h, const double* starts, int S, int n_local,
+                                const sls_lbfgs_opts* opts, long start_index_offset, double* x_out, double* val_out,
+                                long* idx_out, double* x_stars, double* y_stars) {
+    SLS_TRY
+    SLS_REQUIRE(g && starts, "sls_acq_maximize: NULL argument");
+    SLS_REQUIRE(S >= 1, "sls_acq_maximize: need S >= 1");
+    sls_ctx* c = g->ctx;
+    DBuf sd;
+    sd.ensure((size_t)g->D * S);
+    h2d(c, sd.p, starts, (size_t)g->D * S);
+    maximize_impl(g, acq_type, ucb_h, sd.p, S, n_local, opts, start_index_offset, x_out, val_out, idx_out, x_stars, y_stars);
+    SLS_CATCH
+}
+
+extern "C" int sls_acq_maximize_dev(sls_gp* g, int acq_type, double ucb_h, const double* starts_dev, int S, int n_local,
+                                    const sls_lbfgs_opts* opts, long start_index_offset, double* x_out, double* val_out,
+                                    long* idx_out) {
+    SLS_TRY
+    SLS_REQUIRE(g && starts_dev, "sls_acq_maximize_dev: NULL argument");
+    maximize_impl(g, acq_type, ucb_h, starts_dev, S, n_local, opts, start_index_offset, x_out, val_out, idx_out, nullptr, nullptr);
+    SLS_CATCH
+}
+
+// ---- free functions ----------------------------------------------------------------------------------------------
+extern "C" int sls_gram(sls_ctx* c, const double* X, int D, int N, const double* theta, double b, int kernel, double* K_out) {
+    SLS_TRY
+    SLS_REQUIRE(c && X && K_out && D >= 1 && N >= 1, "sls_gram: bad argument");
+    check_theta(theta, D);
+    SLS_HIP(hipSetDevice(c->device));
+    const int Np = round_up(N, 128), Dp = round_up(D, 16);
+    DBuf Xd, il, XT, nx, K;
+    Xd.ensure((size_t)D * N); il.ensure(Dp); XT.ensure((size_t)Np * Dp); nx.ensure(Np); K.ensure((size_t)Np * Np);
+    std::vector<double> ilh(Dp, 0.0);
+    for (int d = 0; d < D; ++d) ilh[d] = 1.0 / theta[1 + d];
+    h2d(c, Xd.p, X, (size_t)D * N);
+    h2d(c, il.p, ilh.data(), Dp);
+    launch_prep_points(c->stream, Xd.p, D, N, il.p, XT.p, Np, Np, Dp, nx.p);
+    launch_gram_sym(c->stream, XT.p, Np, Dp, nx.p, Np, N, KernelSpec{kernel, theta[0]}, b, K.p, false);
+    d2h_matrix(c, K_out, K.p, N, Np);
+    sync(c);
+    SLS_CATCH
+}
+
+extern "C" int sls_gram_cross(sls_ctx* c, const double* X, int D, int N, const double* Xs, int M, const double* theta, int kernel,
+                              double* Ks_out) {
+    SLS_TRY
+    SLS_REQUIRE(c && X && Xs && Ks_out && D >= 1 && N >= 1 && M >= 1, "sls_gram_cross: bad argument");
+    check_theta(theta, D);
+    SLS_HIP(hipSetDevice(c->device));
+    const int Np = round_up(N, 128), Mp = round_up(M, 128), Dp = round_up(D, 16);
+    DBuf Xd, Xsd, il, XT, XsT, nx, ns, Ks, Cs;
+    Xd.ensure((size_t)D * N); Xsd.ensure((size_t)D * M); il.ensure(Dp);
+    XT.ensure((size_t)Np * Dp); XsT.ensure((size_t)Mp * Dp); nx.ensure(Np); ns.ensure(Mp);
+    Ks.ensure((size_t)Mp * Np);
+    const bool matern = kernel == SLS_KERNEL_ARD_MATERN52;
+    if (matern) Cs.ensure((size_t)Mp * Np);
+    std::vector<double> ilh(Dp, 0.0);
+    for (int d = 0; d < D; ++d) ilh[d] = 1.0 / theta[1 + d];
+    h2d(c, Xd.p, X, (size_t)D * N);
+    h2d(c, Xsd.p, Xs, (size_t)D * M);
+    h2d(c, il.p, ilh.data(), Dp);
+    launch_prep_points(c->stream, Xd.p, D, N, il.p, XT.p, Np, Np, Dp, nx.p);
+    launch_prep_points(c->stream, Xsd.p, D, M, il.p, XsT.p, Mp, Mp, Dp, ns.p);
+    launch_cross_gram(c->stream, XsT.p, Mp, ns.p, Mp, XT.p, Np, nx.p, Np, N, Dp, KernelSpec{kernel, theta[0]}, nullptr, Ks.p,
+                      matern ? Cs.p : Ks.p, Mp, nullptr, nullptr);
+    // device image is candidate-major [m + i*Mp]; the API returns N x M column-major (column m = k(xs_m, X))
+    std::vector<double> t((size_t)Mp * Np);
+    d2h(c, t.data(), Ks.p, (size_t)Mp * Np);
+    sync(c);
+    for (int m = 0; m < M; ++m)
+        for (int i = 0; i < N; ++i) Ks_out[i + (size_t)m * N] = t[(size_t)m + (size_t)i * Mp];
+    SLS_CATCH
+}
+
+static void upload_padded_spd(sls_ctx* c, DBuf& A, const double* src, int N, int Np) {
+    A.ensure((size_t)Np * Np);
+    launch_fill(c->stream, A.p, (long)Np * Np, 0.0);
+    h2d_matrix(c, A.p, src, N, Np);
+    if (Np > N) {
+        std::vector<double> ones(Np - N, 1.0);
+        SLS_HIP(hipMemcpy2DAsync(A.p + (size_t)N * (Np + 1), (size_t)(Np + 1) * 8, ones.data(), 8, 8, Np - N,
+                                 hipMemcpyHostToDevice, c->stream));
+        sync(c);
+    }
+}
+
+extern "C" int sls_potrf(sls_ctx* c, double* A, int N) {
+    SLS_TRY
+    SLS_REQUIRE(c && A && N >= 1, "sls_potrf: bad argument");
+    SLS_HIP(hipSetDevice(c->device));
+    const int Np = round_up(N, 128);
+    DBuf Ad, Li;
+    upload_padded_spd(c, Ad, A, N, Np);
+    Li.ensure((size_t)Np * Np);
+    SLS_HIP(hipMemsetAsync(c->d_info, 0, 64, c->stream));
+    launch_potrf(c->stream, Ad.p, Np, Li.p, c->d_info);
+    launch_zero_upper(c->stream, Ad.p, Np);
+    int info = 0;
+    SLS_HIP(hipMemcpyAsync(&info, c->d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    d2h_matrix(c, A, Ad.p, N, Np);
+    sync(c);
+    if (info != 0) {
+        set_error("sls_potrf: matrix is not positive definite (pivot %d)", info - 1);
+        return SLS_ERR_NOT_SPD;
+    }
+    SLS_CATCH
+}
+
+extern "C" int sls_potrs(sls_ctx* c, const double* L, int N, double* B, int nrhs) {
+    SLS_TRY
+    SLS_REQUIRE(c && L && B && N >= 1 && nrhs >= 1, "sls_potrs: bad argument");
+    SLS_HIP(hipSetDevice(c->device));
+    const int Np = round_up(N, 128), Rp = round_up(nrhs, 128);
+    DBuf Ld, Li, Bd;
+    upload_padded_spd(c, Ld, L, N, Np);
+    launch_zero_upper(c->stream, Ld.p, Np);
+    Li.ensure((size_t)Np * Np);
+    launch_diag_inverse(c->stream, Ld.p, Np, Li.p);
+    Bd.ensure((size_t)Np * Rp);
+    launch_fill(c->stream, Bd.p, (long)Np * Rp, 0.0);
+    SLS_HIP(hipMemcpy2DAsync(Bd.p, (size_t)Np * 8, B, (size_t)N * 8, (size_t)N * 8, nrhs, hipMemcpyHostToDevice, c->stream));
+    launch_potrs(c->stream, Ld.p, Li.p, Np, Bd.p, Rp);
+    SLS_HIP(hipMemcpy2DAsync(B, (size_t)N * 8, Bd.p, (size_t)Np * 8, (size_t)N * 8, nrhs, hipMemcpyDeviceToHost, c->stream));
+    sync(c);
+    SLS_CATCH
+}
+
+extern "C" int sls_potri(sls_ctx* c, const double* L, int N, double* Ainv) {
+    SLS_TRY
+    SLS_REQUIRE(c && L && Ainv && N >= 1, "sls_potri: bad argument");
+    SLS_HIP(hipSetDevice(c->device));
+    const int Np = round_up(N, 128);
+    DBuf Ld, Li, Ki;
+    upload_padded_spd(c, Ld, L, N, Np);
+    launch_zero_upper(c->stream, Ld.p, Np);
+    Li.ensure((size_t)Np * Np);
+    Ki.ensure((size_t)Np * Np);
+    launch_fill(c->stream, Li.p, (long)Np * Np, 0.0);
+    launch_diag_inverse(c->stream, Ld.p, Np, Li.p);
+    launch_trtri(c->stream, Ld.p, Np, Li.p, Ki.p);
+    launch_lauum(c->stream, Li.p, Np, Ki.p);
+    d2h_matrix(c, Ainv, Ki.p, N, Np);
+    sync(c);
+    SLS_CATCH
+}

@@ -1,0 +1,100 @@
+// Shared host-side plumbing of libsls_hip: context, error handling, device buffers, per-kernel event timing.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/sls_hip.h"
+
+namespace slsk {
+
+void set_error(const char* fmt, ...);
+
+struct HipFail {
+    int code;
+};
+
+#define SLS_HIP(x)                                                                                 \
+    do {                                                                                           \
+        hipError_t e_ = (x);                                                                       \
+        if (e_ != hipSuccess) {                                                                    \
+            slsk::set_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+            throw slsk::HipFail{SLS_ERR_HIP};                                                      \
+        }                                                                                          \
+    } while (0)
+
+#define SLS_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            slsk::set_error(__VA_ARGS__);      \
+            throw slsk::HipFail{SLS_ERR_INVALID}; \
+        }                                      \
+    } while (0)
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// Owning device buffer of doubles (or raw bytes).
+struct DBuf {
+    double* p = nullptr;
+    size_t n = 0;  // doubles
+    DBuf() = default;
+    DBuf(const DBuf&) = delete;
+    DBuf& operator=(const DBuf&) = delete;
+    ~DBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    void ensure(size_t doubles) {
+        if (doubles <= n && p) return;
+        release();
+        SLS_HIP(hipMalloc((void**)&p, doubles * sizeof(double)));
+        n = doubles;
+    }
+};
+
+struct ProfEntry {
+    double ms = 0;
+    long launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+}  // namespace slsk
+
+struct sls_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    int cand_chunk = 16384;
+    bool prof_on = false;
+    std::map<std::string, slsk::ProfEntry> prof;
+    std::vector<hipEvent_t> event_pool;
+    // scratch
+    slsk::DBuf scratch;   // generic host<->device staging
+    int* d_info = nullptr;  // device int[4]: potrf info etc.
+
+    hipEvent_t get_event();
+    void prof_begin(const char* name, hipEvent_t& e0);
+    void prof_end(const char* name, hipEvent_t e0);
+    void prof_collect();
+};
+
+namespace slsk {
+// RAII kernel-timing scope: records HIP events on the context's stream when profiling is enabled.
+struct ProfScope {
+    sls_ctx* c;
+    const char* name;
+    hipEvent_t e0 = nullptr;
+    ProfScope(sls_ctx* c_, const char* n) : c(c_), name(n) {
+        if (c->prof_on) c->prof_begin(name, e0);
+    }
+    ~ProfScope() {
+        if (c->prof_on) c->prof_end(name, e0);
+    }
+};
+}  // namespace slsk

@@ -1,0 +1,95 @@
+// Launch wrappers of the hand-written gfx950 kernels (definitions in kernels_*.hip).
+//
+// Device-side data layout: every matrix keeps its LONG dimension contiguous.
+//   training points   XtT [i + d*Np]      scaled + centred  x~ = (x - 0.5) / l_d, zero padded (Np = ceil128(N))
+//   candidates        XsT [n + d*Sp]      same transform, n = candidate index         (Sp = ceil128(S))
+//   K, L, Linv, Kinv  [i + j*Np]          column-major Np x Np, identity-padded
+//   K*, C*, P         [n + i*Sp]          candidate-major: row i (training point) is contiguous over candidates
+//   G_mu, G_sigma     [n + d*Sp]
+// Padding to the 128-wide GEMM tile keeps every kernel free of edge code.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace slsk {
+
+struct KernelSpec {
+    int kernel;   // SLS_KERNEL_*
+    double a;     // signal variance theta[0]
+};
+
+// ---- kernels_gram.hip -------------------------------------------------------
+// X (D x M column-major, device) -> XT[i + d*ld] = (X[d,i]-0.5)*inv_ell[d] for i<M,d<D, 0 elsewhere (i<Mp, d<Dcols); norms[i].
+void launch_prep_points(hipStream_t s, const double* X, int D, int M, const double* inv_ell, double* XT, long ld, int Mp,
+                        int Dcols, double* norms);
+// same from candidate-major raw coordinates xr[n + d*ldr]
+void launch_prep_cands(hipStream_t s, const double* xr, long ldr, int D, int M, const double* inv_ell, double* XT, long ld,
+                       int Mp, int Dcols, double* norms);
+// XaT[i + d*ld] = alpha[i] * XT[i + d*ld]
+void launch_scale_rows(hipStream_t s, const double* XT, const double* alpha, double* XaT, long ld, int Np, int Dcols);
+// K[i + j*Np] = k(x_i, x_j) (+ b on the diagonal); identity in the padding.  lower_only: skip tiles above the diagonal.
+void launch_gram_sym(hipStream_t s, const double* XT, long ld, int Dp, const double* nx, int Np, int N, KernelSpec ks, double b,
+                     double* K, bool lower_only);
+// Ks[n + i*ldk] = k(xs_n, x_i), Cs likewise with the derivative weight c (Matern; Cs == Ks for SE);
+// mu_part[t*ldk + n] = sum_{i in tile t} alpha_i k, ca_part likewise with c.  alpha may be NULL (no partials).
+void launch_cross_gram(hipStream_t s, const double* XsT, long lds_, const double* ns, int Sp, const double* XT, long ld,
+                       const double* nx, int Np, int N, int Dp, KernelSpec ks, const double* alpha, double* Ks, double* Cs,
+                       long ldk, double* mu_part, double* ca_part);
+
+// ---- kernels_acq.hip ---------------------------------------------------------
+// P[n + i*ldk] = Cs * (Kinv Ks)  and the partial column sums kw_part (Ks.*W), cw_part (Cs.*W) per 128-row tile of i.
+void launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk, int Sp, const double* Kinv, int Np, double* P,
+                     double* kw_part, double* cw_part);
+// Gs[n + d*ldk] = sum_i P[n,i] XT[i,d] ;  Gm[n + d*ldk] = sum_i Cs[n,i] XaT[i,d]   (d < Dcols)
+void launch_grad_gemm(hipStream_t s, const double* P, const double* Cs, long ldk, int Sp, const double* XT, const double* XaT,
+                      long ld, int Np, int Dcols, double* Gs, double* Gm);
+struct FinalizeArgs {
+    int S, D, nbt;            // candidates in this chunk, dims, number of 128-row tiles of i
+    long ldk;                 // candidate leading dimension of this chunk
+    const double *mu_part, *ca_part, *kw_part, *cw_part, *Gs, *Gm, *XsT, *inv_ell;
+    double a, mu_best, ucb_h;
+    int acq;                  // SLS_ACQ_* (used when val/grad requested)
+    // outputs (any may be NULL); all candidate-major with leading dimension ldo, offset already applied
+    long ldo;
+    double *mu, *sigma, *dmu, *dsigma, *val, *grad;
+};
+void launch_finalize(hipStream_t s, const FinalizeArgs& a);
+
+struct LbfgsState {
+    int S, D, m;
+    long ld;                  // Sp
+    double *x, *g, *dir, *xt, *scr;   // [n + d*ld]
+    double *Sh, *Yh;          // [h][d][n]
+    double *rho;              // [h][n]
+    double *f, *t;            // [n]
+    int *hlen, *hpos, *nbt, *done;    // [n]
+    double c1, shrink, gtol;
+    int max_backtracks;
+};
+// first: (val, grad) are the objective at the starts; otherwise at the trial points xt.  Writes the next trial points.
+void launch_lbfgs_step(hipStream_t s, const LbfgsState& st, const double* val, const double* grad, bool first);
+void launch_clamp_starts(hipStream_t s, const double* starts /*D x S col-major*/, int D, int S, double* xt, long ld, int Sp);
+// first maximum of y[n] = -f[n]: out[0] = value, idx_out[0] = index
+void launch_argmax_neg(hipStream_t s, const double* f, int S, double* out_val, long* out_idx);
+void launch_argmax(hipStream_t s, const double* y, int n, double* out_val, long* out_idx);
+
+// ---- kernels_chol.hip ---------------------------------------------------------
+// In-place lower Cholesky of the Np x Np matrix A (ld = Np); Linv receives the 128x128 diagonal-block inverses
+// (rest of Linv untouched).  info (device int) gets 1 + index of the first non-positive pivot, or stays 0.
+void launch_potrf(hipStream_t s, double* A, int Np, double* Linv, int* info);
+// Linv <- L^-1 (lower) given L and the diagonal-block inverses already in Linv; tmp is an Np x Np scratch.
+void launch_trtri(hipStream_t s, const double* L, int Np, double* Linv, double* tmp);
+// diagonal-block inverses only (for potrs / potri on a caller-supplied factor)
+void launch_diag_inverse(hipStream_t s, const double* L, int Np, double* Linv);
+// Kinv <- Linv^T Linv (full symmetric)
+void launch_lauum(hipStream_t s, const double* Linv, int Np, double* Kinv);
+// B (Np x Rp, ld = Np, Rp multiple of 128) <- (L L^T)^-1 B using the block inverses in Linv's diagonal
+void launch_potrs(hipStream_t s, const double* L, const double* Linv, int Np, double* B, int Rp);
+void launch_gemv_n(hipStream_t s, const double* A, int Np, const double* x, double* y);   // y = A x
+void launch_gemv_t(hipStream_t s, const double* A, int Np, const double* x, double* y);   // y = A^T x
+void launch_zero_upper(hipStream_t s, double* A, int Np);
+void launch_fill(hipStream_t s, double* p, long n, double v);
+// mu_data[i] = y[i] - b*alpha[i] (i<N); out: first argmax + value; logdet = 2 sum log L_ii (i<N)
+void launch_mu_data(hipStream_t s, const double* y, const double* alpha, double b, int N, double* mu_data);
+void launch_logdet(hipStream_t s, const double* L, int Np, int N, double* out);
+
+}  // namespace slsk

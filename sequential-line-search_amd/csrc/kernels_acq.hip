@@ -1,0 +1,421 @@
+// Acquisition hot loop: batched  w = K^-1 k  for every candidate (the dominant fp64 MFMA GEMM), the gradient
+// contractions, the EI / GP-UCB finalisation and the lock-step bounded L-BFGS update.
+//
+// Replaces, for S candidates at once, the per-point call chain
+//   objective (src/acquisition-function.cpp:38-56) -> CalcAcquisitionValue(:170-198) / ...Derivative(:200-230)
+//   -> PredictMu/Sigma/MuDerivative/SigmaDerivative (gaussian-process-regressor.cpp:234-272,
+//      preference-regressor.cpp:293-330) -> CalcSmallK / CalcSmallKSmallXDerivative (regressor.cpp:45-59,91-108)
+// and the multi-start loop (src/acquisition-function.cpp:121-153).
+#include "gemm_f64.hpp"
+#include "kernels.hpp"
+#include "../../include/sls_hip.h"
+
+namespace slsk {
+
+// ---------------------------------------------------------------------------------------------------------
+// acq_gemm: tile = 128 candidates (m) x 128 rows of K^-1 (n').  acc = W = (K^-1 K*)^T tile.
+// Epilogue: P = C* .* W stored candidate-major; per-tile partial sums over n' of K*.*W and C*.*W.
+// ---------------------------------------------------------------------------------------------------------
+template <bool MATERN>
+__global__ __launch_bounds__(256, 2) void acq_gemm_kernel(const double* __restrict__ Ks, const double* __restrict__ Cs, long ldk,
+                                                          int Sp, const double* __restrict__ Kinv, int Np,
+                                                          double* __restrict__ P, double* __restrict__ kw_part,
+                                                          double* __restrict__ cw_part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* lds = reinterpret_cast<double*>(smem);
+    const int ntm = Sp / GEMM_BM, ntn = Np / GEMM_BN;
+    // grouped order: 8 candidate tiles x all K^-1 row tiles, so the 64 tiles resident on one XCD share panels in L2
+    int t = xcd_remap(blockIdx.x, ntm * ntn);
+    const int GM = 8;
+    const int gsz = GM * ntn;
+    const int g = t / gsz, w = t % gsz;
+    const int gm = min(GM, ntm - g * GM);
+    const int tm = g * GM + (w % gm), tn = w / gm;
+    const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+    Acc acc;
+    acc.zero();
+    gemm_tile<false, false>(acc, Ks + m0, ldk, Kinv + n0, (long)Np, 0, Np, lds);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double skw[4], scw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long gm_ = m0 + acc_m(i);
+        double pk = 0.0, pc = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long off = gm_ + (long)(n0 + acc_n(j, r)) * ldk;
+                const double wv = acc.v[i][j][r];
+                const double k = Ks[off];
+                const double c = MATERN ? Cs[off] : k;
+                const double p = c * wv;
+                P[off] = p;
+                pc += p;
+                if (MATERN) pk += k * wv;
+            }
+        scw[i] = pc;
+        skw[i] = MATERN ? pk : pc;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        skw[i] += __shfl_xor(skw[i], 16);
+        skw[i] += __shfl_xor(skw[i], 32);
+        scw[i] += __shfl_xor(scw[i], 16);
+        scw[i] += __shfl_xor(scw[i], 32);
+    }
+    double* red = lds;
+    if (lane < 16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ml = (wave & 1) * 64 + 16 * i + lane;
+            red[((wave >> 1) * 2 + 0) * 128 + ml] = skw[i];
+            red[((wave >> 1) * 2 + 1) * 128 + ml] = scw[i];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int ml = threadIdx.x;
+        kw_part[(long)tn * ldk + m0 + ml] = red[0 * 128 + ml] + red[2 * 128 + ml];
+        cw_part[(long)tn * ldk + m0 + ml] = red[1 * 128 + ml] + red[3 * 128 + ml];
+    }
+}
+
+void launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk, int Sp, const double* Kinv, int Np, double* P,
+                     double* kw_part, double* cw_part) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)acq_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)acq_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        attr = true;
+    }
+    const int nt = (Sp / GEMM_BM) * (Np / GEMM_BN);
+    if (Cs != Ks)
+        hipLaunchKernelGGL(acq_gemm_kernel<true>, dim3(nt), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, Ks, Cs, ldk, Sp, Kinv, Np, P,
+                           kw_part, cw_part);
+    else
+        hipLaunchKernelGGL(acq_gemm_kernel<false>, dim3(nt), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, Ks, Cs, ldk, Sp, Kinv, Np, P,
+                           kw_part, cw_part);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// grad_gemm: z = 0: Gs = P * X~ ; z = 1: Gm = C* * (alpha .* X~).  Tile = 128 candidates x 128 dims.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void grad_gemm_kernel(const double* __restrict__ P, const double* __restrict__ Cs, long ldk,
+                                                           int Sp, const double* __restrict__ XT, const double* __restrict__ XaT,
+                                                           long ld, int Np, int Dcols, double* __restrict__ Gs,
+                                                           double* __restrict__ Gm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* lds = reinterpret_cast<double*>(smem);
+    const int ntm = Sp / GEMM_BM;
+    const int tm = blockIdx.x % ntm, tn = blockIdx.x / ntm;
+    const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+    const double* A = blockIdx.y == 0 ? P : Cs;
+    const double* B = blockIdx.y == 0 ? XT : XaT;
+    double* C = blockIdx.y == 0 ? Gs : Gm;
+    Acc acc;
+    acc.zero();
+    // B operand: elem(n' = d, k = i) = B[i + d*ld]  -> K-contiguous
+    gemm_tile<false, true>(acc, A + m0, ldk, B + (long)n0 * ld, ld, 0, Np, lds);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) C[(long)(m0 + acc_m(i)) + (long)(n0 + acc_n(j, r)) * ldk] = acc.v[i][j][r];
+}
+
+void launch_grad_gemm(hipStream_t s, const double* P, const double* Cs, long ldk, int Sp, const double* XT, const double* XaT,
+                      long ld, int Np, int Dcols, double* Gs, double* Gm) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)grad_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        attr = true;
+    }
+    const int nt = (Sp / GEMM_BM) * (Dcols / GEMM_BN);
+    hipLaunchKernelGGL(grad_gemm_kernel, dim3(nt, 2), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, P, Cs, ldk, Sp, XT, XaT, ld, Np, Dcols,
+                       Gs, Gm);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// finalize: one thread per candidate.  mathtoolbox EI / GP-UCB on the reduced sums.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs p) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= p.S) return;
+    double mu = 0.0, ca = 0.0, kw = 0.0, cw = 0.0;
+    for (int t = 0; t < p.nbt; ++t) {
+        mu += p.mu_part[(long)t * p.ldk + n];
+        ca += p.ca_part[(long)t * p.ldk + n];
+        kw += p.kw_part[(long)t * p.ldk + n];
+        cw += p.cw_part[(long)t * p.ldk + n];
+    }
+    const double s2 = p.a - kw;
+    const double sigma = s2 < 0.0 ? 0.0 : sqrt(s2);   // gaussian-process-regressor.cpp:253-254
+    if (p.mu) p.mu[n] = mu;
+    if (p.sigma) p.sigma[n] = sigma;
+    const bool need_g = p.dmu || p.dsigma || p.grad;
+    double Phi = 0.0, phi = 0.0;
+    bool bad = false;
+    if (p.val || p.grad) {
+        if (p.acq == SLS_ACQ_EXPECTED_IMPROVEMENT) {
+            const double diff = mu - p.mu_best;
+            const double u = diff / sigma;
+            Phi = 0.5 * erfc(-u * 0.70710678118654752440);
+            phi = exp(-0.5 * u * u) * 0.39894228040143267794;
+            const double ei = diff * Phi + sigma * phi;
+            bad = (sigma < 1e-10) || isnan(ei);
+            if (p.val) p.val[n] = bad ? 0.0 : ei;
+        } else {
+            if (p.val) p.val[n] = mu + p.ucb_h * sigma;
+        }
+    }
+    if (!need_g) return;
+    const double inv_sigma = 1.0 / sigma;
+    if (p.grad && p.acq == SLS_ACQ_EXPECTED_IMPROVEMENT) {
+        // NaN anywhere in the gradient -> zero vector (mathtoolbox guard); needs a scan before the write
+        for (int d = 0; d < p.D && !bad; ++d) {
+            const double xt = p.XsT[n + (long)d * p.ldk];
+            const double il = p.inv_ell[d];
+            const double dm = -il * (xt * ca - p.Gm[n + (long)d * p.ldk]);
+            const double ds = inv_sigma * il * (xt * cw - p.Gs[n + (long)d * p.ldk]);
+            if (isnan(Phi * dm + phi * ds)) bad = true;
+        }
+    }
+    for (int d = 0; d < p.D; ++d) {
+        const double xt = p.XsT[n + (long)d * p.ldk];
+        const double il = p.inv_ell[d];
+        const double dm = -il * (xt * ca - p.Gm[n + (long)d * p.ldk]);                 // PredictMuDerivative
+        const double ds = inv_sigma * il * (xt * cw - p.Gs[n + (long)d * p.ldk]);      // PredictSigmaDerivative
+        if (p.dmu) p.dmu[n + (long)d * p.ldo] = dm;
+        if (p.dsigma) p.dsigma[n + (long)d * p.ldo] = ds;
+        if (p.grad) {
+            double g;
+            if (p.acq == SLS_ACQ_EXPECTED_IMPROVEMENT) g = bad ? 0.0 : Phi * dm + phi * ds;
+            else g = dm + p.ucb_h * ds;
+            p.grad[n + (long)d * p.ldo] = g;
+        }
+    }
+}
+
+void launch_finalize(hipStream_t s, const FinalizeArgs& a) {
+    hipLaunchKernelGGL(finalize_kernel, dim3((a.S + 255) / 256), dim3(256), 0, s, a);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Lock-step bounded L-BFGS (the oracle's slso_acq_maximize is the same algorithm, statement by
+// statement).  One thread per start; every per-start vector is candidate-major so all accesses coalesce.
+// Minimises phi = -acq on [0,1]^D.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void clamp_starts_kernel(const double* __restrict__ starts, int D, int S, double* __restrict__ xt,
+                                                           long ld, int Sp) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= Sp) return;
+    for (int d = 0; d < D; ++d) {
+        double v = 0.5;
+        if (n < S) {
+            v = starts[d + (long)n * D];
+            v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+        }
+        xt[n + (long)d * ld] = v;
+    }
+}
+void launch_clamp_starts(hipStream_t s, const double* starts, int D, int S, double* xt, long ld, int Sp) {
+    hipLaunchKernelGGL(clamp_starts_kernel, dim3((Sp + 255) / 256), dim3(256), 0, s, starts, D, S, xt, ld, Sp);
+}
+
+__global__ __launch_bounds__(256) void lbfgs_step_kernel(LbfgsState st, const double* __restrict__ val,
+                                                         const double* __restrict__ grad, int first) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= st.S) return;
+    const long ld = st.ld;
+    const int D = st.D, m = st.m;
+    bool need_dir = false;
+    if (first) {
+        st.f[n] = -val[n];
+        for (int d = 0; d < D; ++d) {
+            st.x[n + d * ld] = st.xt[n + d * ld];
+            st.g[n + d * ld] = -grad[n + d * ld];
+        }
+        st.hlen[n] = 0; st.hpos[n] = 0; st.nbt[n] = 0; st.done[n] = 0; st.t[n] = 1.0;
+        need_dir = true;
+    } else {
+        if (st.done[n]) return;
+        const double ft = -val[n];
+        double gs = 0.0, ss = 0.0;
+        for (int d = 0; d < D; ++d) {
+            const double sd = st.xt[n + d * ld] - st.x[n + d * ld];
+            gs += st.g[n + d * ld] * sd;
+            ss += sd * sd;
+        }
+        if (ss == 0.0) { st.done[n] = 1; return; }
+        if (ft <= st.f[n] + st.c1 * gs) {
+            double sy = 0.0, yy = 0.0;
+            const int idx = st.hpos[n];
+            double* Sh = st.Sh + (long)idx * D * ld;
+            double* Yh = st.Yh + (long)idx * D * ld;
+            for (int d = 0; d < D; ++d) {
+                const double sd = st.xt[n + d * ld] - st.x[n + d * ld];
+                const double yd = -grad[n + d * ld] - st.g[n + d * ld];
+                Sh[n + d * ld] = sd;
+                Yh[n + d * ld] = yd;
+                sy += sd * yd;
+                yy += yd * yd;
+            }
+            if (sy > 1e-10 * yy && sy > 0.0) {
+                st.rho[(long)idx * ld + n] = 1.0 / sy;
+                st.hpos[n] = (idx + 1) % m;
+                if (st.hlen[n] < m) st.hlen[n] += 1;
+            }
+            for (int d = 0; d < D; ++d) {
+                st.x[n + d * ld] = st.xt[n + d * ld];
+                st.g[n + d * ld] = -grad[n + d * ld];
+            }
+            st.f[n] = ft;
+            need_dir = true;
+        } else {
+            st.t[n] *= st.shrink;
+            const int nb = st.nbt[n] + 1;
+            st.nbt[n] = nb;
+            if (nb > st.max_backtracks) { st.done[n] = 1; }
+        }
+    }
+    bool done = st.done[n] != 0;
+    if (!done && need_dir) {
+        // projected gradient -> scr (pg), two-loop recursion in dir
+        double pgmax = 0.0, pgn2 = 0.0;
+        for (int d = 0; d < D; ++d) {
+            double v = st.g[n + d * ld];
+            const double xv = st.x[n + d * ld];
+            if ((xv <= 0.0 && v > 0.0) || (xv >= 1.0 && v < 0.0)) v = 0.0;
+            st.scr[n + d * ld] = v;
+            st.dir[n + d * ld] = v;
+            pgmax = fmax(pgmax, fabs(v));
+            pgn2 += v * v;
+        }
+        if (!(pgmax > st.gtol)) {
+            done = true;
+        } else {
+            int hlen = st.hlen[n];
+            const int hpos = st.hpos[n];
+            double al[8];
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                al[h] = 0.0;
+                if (h < hlen) {
+                    const int idx = (hpos - 1 - h + 2 * m) % m;
+                    const double* Sh = st.Sh + (long)idx * D * ld;
+                    const double* Yh = st.Yh + (long)idx * D * ld;
+                    double dot = 0.0;
+                    for (int d = 0; d < D; ++d) dot += Sh[n + d * ld] * st.dir[n + d * ld];
+                    al[h] = st.rho[(long)idx * ld + n] * dot;
+                    for (int d = 0; d < D; ++d) st.dir[n + d * ld] -= al[h] * Yh[n + d * ld];
+                }
+            }
+            double gamma;
+            if (hlen > 0) {
+                const int idx = (hpos - 1 + m) % m;
+                const double* Sh = st.Sh + (long)idx * D * ld;
+                const double* Yh = st.Yh + (long)idx * D * ld;
+                double sy = 0.0, yy = 0.0;
+                for (int d = 0; d < D; ++d) {
+                    sy += Sh[n + d * ld] * Yh[n + d * ld];
+                    yy += Yh[n + d * ld] * Yh[n + d * ld];
+                }
+                gamma = sy / yy;
+            } else {
+                const double nn = sqrt(pgn2);
+                gamma = 1.0 / (nn > 1.0 ? nn : 1.0);
+            }
+            for (int d = 0; d < D; ++d) st.dir[n + d * ld] *= gamma;
+#pragma unroll
+            for (int h = 7; h >= 0; --h) {
+                if (h < hlen) {
+                    const int idx = (hpos - 1 - h + 2 * m) % m;
+                    const double* Sh = st.Sh + (long)idx * D * ld;
+                    const double* Yh = st.Yh + (long)idx * D * ld;
+                    double dot = 0.0;
+                    for (int d = 0; d < D; ++d) dot += Yh[n + d * ld] * st.dir[n + d * ld];
+                    const double beta = st.rho[(long)idx * ld + n] * dot;
+                    for (int d = 0; d < D; ++d) st.dir[n + d * ld] += Sh[n + d * ld] * (al[h] - beta);
+                }
+            }
+            double gd = 0.0;
+            for (int d = 0; d < D; ++d) {
+                const double pg = st.scr[n + d * ld];
+                const double dv = (pg == 0.0) ? 0.0 : -st.dir[n + d * ld];
+                st.dir[n + d * ld] = dv;
+                gd += pg * dv;
+            }
+            if (!(gd < 0.0)) {
+                st.hlen[n] = 0;
+                const double nn = sqrt(pgn2);
+                gamma = 1.0 / (nn > 1.0 ? nn : 1.0);
+                gd = 0.0;
+                for (int d = 0; d < D; ++d) {
+                    const double pg = st.scr[n + d * ld];
+                    const double dv = -gamma * pg;
+                    st.dir[n + d * ld] = dv;
+                    gd += pg * dv;
+                }
+                if (!(gd < 0.0)) done = true;
+            }
+            if (!done) { st.t[n] = 1.0; st.nbt[n] = 0; }
+        }
+        if (done) st.done[n] = 1;
+    }
+    // propose the next trial point
+    const double t = st.t[n];
+    for (int d = 0; d < D; ++d) {
+        double v = st.x[n + d * ld];
+        if (!done) {
+            v = v + t * st.dir[n + d * ld];
+            v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+        }
+        st.xt[n + d * ld] = v;
+    }
+}
+
+void launch_lbfgs_step(hipStream_t s, const LbfgsState& st, const double* val, const double* grad, bool first) {
+    hipLaunchKernelGGL(lbfgs_step_kernel, dim3((st.S + 255) / 256), dim3(256), 0, s, st, val, grad, (int)first);
+}
+
+// first maximum (Eigen maxCoeff semantics, src/acquisition-function.cpp:146-153)
+template <bool NEG>
+__global__ __launch_bounds__(1024) void argmax_kernel(const double* __restrict__ y, int n, double* out_val, long* out_idx) {
+    __shared__ double sv[1024];
+    __shared__ int si[1024];
+    double bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const double v = NEG ? -y[i] : y[i];
+        if (v > bv) { bv = v; bi = i; }   // strictly greater: keeps the earliest index within this thread
+    }
+    sv[threadIdx.x] = bv;
+    si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            const double ov = sv[threadIdx.x + s];
+            const int oi = si[threadIdx.x + s];
+            if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) {
+                sv[threadIdx.x] = ov;
+                si[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        // all -inf / NaN: Eigen's maxCoeff returns index 0
+        out_val[0] = (si[0] == 0x7fffffff) ? (NEG ? -y[0] : y[0]) : sv[0];
+        out_idx[0] = (si[0] == 0x7fffffff) ? 0 : si[0];
+    }
+}
+void launch_argmax_neg(hipStream_t s, const double* f, int S, double* out_val, long* out_idx) {
+    hipLaunchKernelGGL(argmax_kernel<true>, dim3(1), dim3(1024), 0, s, f, S, out_val, out_idx);
+}
+void launch_argmax(hipStream_t s, const double* y, int n, double* out_val, long* out_idx) {
+    hipLaunchKernelGGL(argmax_kernel<false>, dim3(1), dim3(1024), 0, s, y, n, out_val, out_idx);
+}
+
+}  // namespace slsk

@@ -1,0 +1,422 @@
+// Dense SPD factorisation on the fp64 MFMA tile: blocked Cholesky (Eigen::LLT stand-in,
+// src/preference-regressor.cpp:162,290), triangular inverse and K^-1 = L^-T L^-1 (replaces MatrixXd::inverse(),
+// src/gaussian-process-regressor.cpp:159,211,231), block triangular solves (LLT::solve), GEMV helpers.
+//
+// Right-looking, NB = 128:
+//   chol_diag   one workgroup factors the 128x128 diagonal block in registers (8x8 per thread, column broadcast
+//               through LDS, one barrier per column) and also produces its inverse T_jj (forward substitution on I);
+//   panel       L_ij = A_ij T_jj^T            (MFMA GEMM, in place)
+//   syrk        A_ik -= L_ij L_kj^T, i>=k>j   (MFMA GEMM, lower tiles only)
+// Triangular inverse: recursive doubling over block pairs, X21 = -X22 (L21 X11), every level two batched GEMMs.
+#include "gemm_f64.hpp"
+#include "kernels.hpp"
+
+namespace slsk {
+
+constexpr int NB = 128;
+
+// ---------------------------------------------------------------------------------------------------------
+// generic tile GEMM with triangular k-ranges:  C = alpha * opA opB^T + beta * C
+// ---------------------------------------------------------------------------------------------------------
+struct GemmDesc {
+    const double* A; long lda; long strideA;   // batch strides in elements
+    const double* B; long ldb; long strideB;
+    double* C; long ldc; long strideC;
+    int mt, nt;        // tile grid
+    int K;             // full k extent (multiple of 16)
+    double alpha, beta;
+    int tri;           // 1: only tiles tm >= tn
+    int kmode;         // 0: [0,K)  1: [128 tn, K)  2: [0, 128 (tm+1))  3: [128 max(tm,tn), K)
+    int vb_stride, vb_off, vb_limit;   // tile row valid iff batch*vb_stride + vb_off + tm < vb_limit
+};
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void tri_gemm_kernel(GemmDesc g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* lds = reinterpret_cast<double*>(smem);
+    const int tm = blockIdx.x % g.mt, tn = blockIdx.x / g.mt;
+    const int batch = blockIdx.y;
+    if (g.tri && tn > tm) return;
+    if (batch * g.vb_stride + g.vb_off + tm >= g.vb_limit) return;
+    const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+    int kb = 0, ke = g.K;
+    if (g.kmode == 1) kb = NB * tn;
+    else if (g.kmode == 2) ke = min(g.K, NB * (tm + 1));
+    else if (g.kmode == 3) kb = NB * max(tm, tn);
+    const double* A = g.A + batch * g.strideA;
+    const double* B = g.B + batch * g.strideB;
+    double* C = g.C + batch * g.strideC;
+    const double* Ap = A_KC ? A + (long)m0 * g.lda : A + m0;
+    const double* Bp = B_KC ? B + (long)n0 * g.ldb : B + n0;
+    Acc acc;
+    acc.zero();
+    gemm_tile<A_KC, B_KC>(acc, Ap, g.lda, Bp, g.ldb, kb, ke, lds);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double* c = C + (long)(m0 + acc_m(i)) + (long)(n0 + acc_n(j, r)) * g.ldc;
+                double v = g.alpha * acc.v[i][j][r];
+                if (g.beta != 0.0) v += g.beta * *c;
+                *c = v;
+            }
+}
+
+template <bool A_KC, bool B_KC>
+static void launch_tri_gemm(hipStream_t s, const GemmDesc& g, int batches) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)tri_gemm_kernel<A_KC, B_KC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  GEMM_LDS_BYTES);
+        attr = true;
+    }
+    if (g.mt <= 0 || g.nt <= 0 || batches <= 0) return;
+    hipLaunchKernelGGL((tri_gemm_kernel<A_KC, B_KC>), dim3(g.mt * g.nt, batches), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, g);
+}
+
+static GemmDesc mkdesc(const double* A, long lda, const double* B, long ldb, double* C, long ldc, int mt, int nt, int K,
+                       double alpha, double beta) {
+    GemmDesc g;
+    g.A = A; g.lda = lda; g.strideA = 0;
+    g.B = B; g.ldb = ldb; g.strideB = 0;
+    g.C = C; g.ldc = ldc; g.strideC = 0;
+    g.mt = mt; g.nt = nt; g.K = K; g.alpha = alpha; g.beta = beta;
+    g.tri = 0; g.kmode = 0; g.vb_stride = 0; g.vb_off = 0; g.vb_limit = 1 << 30;
+    return g;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// diagonal block: Cholesky + inverse, one workgroup of 256 threads, thread (ti, tj) owns the 8x8 block
+// rows 8 ti.., cols 8 tj.. (only ti >= tj work).  LDS: Ls[128*128] (column-major image of L) + broadcast buffers.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int DIAG_LDS_BYTES = (128 * 128 + 2 * 128 + 2 * 128) * 8;
+
+template <bool FACTOR>
+__global__ __launch_bounds__(256) void chol_diag_kernel(double* __restrict__ A, long lda, double* __restrict__ Tout, long ldt,
+                                                        int* __restrict__ info, int global_off) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* Ls = reinterpret_cast<double*>(smem);          // [i + 128 j]
+    double* colbuf = Ls + 128 * 128;                       // [2][128]
+    double* rowbuf = colbuf + 2 * 128;                     // [2][128]
+    const int tid = threadIdx.x;
+    const int ti = tid & 15, tj = tid >> 4;
+    const bool active = ti >= tj;
+
+    if (FACTOR) {
+        double a[8][8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) a[r][c] = active ? A[(long)(8 * ti + r) + (long)(8 * tj + c) * lda] : 0.0;
+        int cur = 0;
+        for (int kb = 0; kb < 16; ++kb) {
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) {
+                const int k = 8 * kb + kc;
+                double* cb = colbuf + cur * 128;
+                if (tj == kb && active) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) cb[8 * ti + r] = a[r][kc];
+                }
+                __syncthreads();
+                const double dkk = cb[k];
+                if (!(dkk > 0.0) && tid == 0) {
+                    if (atomicCAS(info, 0, global_off + k + 1) == 0) {}
+                }
+                const double lkk = sqrt(dkk);
+                const double inv = 1.0 / lkk;
+                if (active && tj >= kb) {
+                    double li[8], lj[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) li[r] = cb[8 * ti + r] * inv;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) lj[c] = cb[8 * tj + c] * inv;
+                    if (tj == kb) {
+                        // finalise column k of L (rows >= k)
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            const int i = 8 * ti + r;
+                            if (i > k) a[r][kc] = li[r];
+                            else if (i == k) a[r][kc] = lkk;
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        if (tj > kb || c > kc) {
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) a[r][c] -= li[r] * lj[c];
+                        }
+                    }
+                }
+                cur ^= 1;
+            }
+        }
+        // write L (lower; strict upper of the diagonal block zeroed) to LDS image and global
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int i = 8 * ti + r, j = 8 * tj + c;
+                const double v = (i >= j) ? a[r][c] : 0.0;
+                Ls[i + 128 * j] = v;
+                A[(long)i + (long)j * lda] = v;
+            }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int i = 8 * ti + r, j = 8 * tj + c;
+                Ls[i + 128 * j] = (i >= j) ? A[(long)i + (long)j * lda] : 0.0;
+            }
+    }
+    __syncthreads();
+
+    // inverse by forward substitution on the identity: B = I; for k: T[k,:] = B[k,:]/L_kk; B[i,:] -= L[i,k] T[k,:]
+    double b[8][8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) b[r][c] = (ti == tj && r == c) ? 1.0 : 0.0;
+    int cur = 0;
+    for (int kb = 0; kb < 16; ++kb) {
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+            const int k = 8 * kb + kc;
+            double* rb = rowbuf + cur * 128;
+            if (ti == kb) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) rb[8 * tj + c] = b[kc][c];
+            }
+            __syncthreads();
+            const double inv = 1.0 / Ls[k + 128 * k];
+            double tk[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) tk[c] = rb[8 * tj + c] * inv;
+            if (ti == kb) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) b[kc][c] = tk[c];
+            }
+            if (ti >= kb) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    if (ti > kb || r > kc) {
+                        const double lik = Ls[8 * ti + r + 128 * k];
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) b[r][c] -= lik * tk[c];
+                    }
+                }
+            }
+            cur ^= 1;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int i = 8 * ti + r, j = 8 * tj + c;
+            Tout[(long)i + (long)j * ldt] = (i >= j) ? b[r][c] : 0.0;
+        }
+}
+
+static void diag_attr() {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)chol_diag_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)chol_diag_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES);
+        attr = true;
+    }
+}
+
+void launch_potrf(hipStream_t s, double* A, int Np, double* Linv, int* info) {
+    diag_attr();
+    const int nb = Np / NB;
+    const long ld = Np;
+    for (int j = 0; j < nb; ++j) {
+        double* Ajj = A + (long)j * NB * (ld + 1);
+        double* Tjj = Linv + (long)j * NB * (ld + 1);
+        hipLaunchKernelGGL(chol_diag_kernel<true>, dim3(1), dim3(256), DIAG_LDS_BYTES, s, Ajj, ld, Tjj, ld, info, j * NB);
+        const int rem = nb - j - 1;
+        if (rem <= 0) break;
+        double* Apan = Ajj + NB;   // rows below the diagonal block, same columns
+        // panel: L_ij = A_ij T_jj^T   (B operand elem(n,k) = T[n + k ld], M-contiguous)
+        GemmDesc p = mkdesc(Apan, ld, Tjj, ld, Apan, ld, rem, 1, NB, 1.0, 0.0);
+        launch_tri_gemm<false, false>(s, p, 1);
+        // trailing update: A_ik -= L_ij L_kj^T for i >= k > j
+        double* Atr = Ajj + (long)NB * (ld + 1);
+        GemmDesc u = mkdesc(Apan, ld, Apan, ld, Atr, ld, rem, rem, NB, -1.0, 1.0);
+        u.tri = 1;
+        launch_tri_gemm<false, false>(s, u, 1);
+    }
+}
+
+void launch_diag_inverse(hipStream_t s, const double* L, int Np, double* Linv) {
+    diag_attr();
+    const int nb = Np / NB;
+    const long ld = Np;
+    for (int j = 0; j < nb; ++j) {
+        // FACTOR = false never writes A
+        hipLaunchKernelGGL(chol_diag_kernel<false>, dim3(1), dim3(256), DIAG_LDS_BYTES, s,
+                           const_cast<double*>(L) + (long)j * NB * (ld + 1), ld, Linv + (long)j * NB * (ld + 1), ld, nullptr, 0);
+    }
+}
+
+// Linv (diagonal blocks already inverted) <- full lower-triangular inverse.  Level with half-size h blocks:
+// pair p = blocks [2hp, 2hp+h) | [2hp+h, min(2hp+2h, nb));  tmp = L21 X11 ; X21 = -X22 tmp.
+void launch_trtri(hipStream_t s, const double* L, int Np, double* Linv, double* tmp) {
+    const int nb = Np / NB;
+    const long ld = Np;
+    for (int h = 1; h < nb; h *= 2) {
+        const int pairs = (nb + 2 * h - 1) / (2 * h);
+        const long pstride = (long)2 * h * NB * (ld + 1);
+        const long off21 = (long)h * NB;   // rows of the second half, columns of the first
+        // tmp21 = L21 * X11 : A = L21 (M-contig), B elem(n,k) = X11[k + n ld] (K-contig), k >= 128 tn
+        GemmDesc g1 = mkdesc(L + off21, ld, Linv, ld, tmp + off21, ld, h, h, h * NB, 1.0, 0.0);
+        g1.strideA = g1.strideB = g1.strideC = pstride;
+        g1.kmode = 1;
+        g1.vb_stride = 2 * h; g1.vb_off = h; g1.vb_limit = nb;
+        launch_tri_gemm<false, true>(s, g1, pairs);
+        // X21 = -X22 * tmp21 : A = X22 (M-contig), B elem(n,k) = tmp21[k + n ld] (K-contig), k < 128 (tm+1)
+        GemmDesc g2 = mkdesc(Linv + (long)h * NB * (ld + 1), ld, tmp + off21, ld, Linv + off21, ld, h, h, h * NB, -1.0, 0.0);
+        g2.strideA = g2.strideB = g2.strideC = pstride;
+        g2.kmode = 2;
+        g2.vb_stride = 2 * h; g2.vb_off = h; g2.vb_limit = nb;
+        launch_tri_gemm<false, true>(s, g2, pairs);
+    }
+}
+
+__global__ __launch_bounds__(256) void symmetrize_kernel(double* __restrict__ A, int Np) {
+    // copy the lower triangle into the upper one through a 32x33 LDS tile (both sides coalesced)
+    __shared__ double tile[32][33];
+    const int bi = blockIdx.x, bj = blockIdx.y;
+    if (bj > bi) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int r = ty; r < 32; r += 8) tile[r][tx] = A[(long)(32 * bi + tx) + (long)(32 * bj + r) * Np];   // tile[c][r_in]
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int gi = 32 * bj + tx, gj = 32 * bi + r;   // transposed position
+        if (gi < gj) A[(long)gi + (long)gj * Np] = tile[tx][r];
+    }
+}
+
+void launch_lauum(hipStream_t s, const double* Linv, int Np, double* Kinv) {
+    const int nb = Np / NB;
+    const long ld = Np;
+    // lower tiles of X^T X: A elem(m,k) = X[k + m ld], B elem(n,k) = X[k + n ld], k >= 128 max(tm,tn)
+    GemmDesc g = mkdesc(Linv, ld, Linv, ld, Kinv, ld, nb, nb, Np, 1.0, 0.0);
+    g.tri = 1;
+    g.kmode = 3;
+    launch_tri_gemm<true, true>(s, g, 1);
+    hipLaunchKernelGGL(symmetrize_kernel, dim3(Np / 32, Np / 32), dim3(256), 0, s, Kinv, Np);
+}
+
+// B <- (L L^T)^-1 B, B is Np x Rp (ld = Np).  Block forward / backward substitution, each step two tile GEMMs.
+void launch_potrs(hipStream_t s, const double* L, const double* Linv, int Np, double* B, int Rp) {
+    const int nb = Np / NB, rt = Rp / NB;
+    const long ld = Np;
+    for (int j = 0; j < nb; ++j) {   // forward: X_j = T_jj B_j ; B_i -= L_ij X_j (i > j)
+        const double* Tjj = Linv + (long)j * NB * (ld + 1);
+        double* Bj = B + (long)j * NB;
+        GemmDesc a = mkdesc(Tjj, ld, Bj, ld, Bj, ld, 1, rt, NB, 1.0, 0.0);   // B operand elem(n,k) = Bj[k + n ld]: K-contig
+        launch_tri_gemm<false, true>(s, a, 1);
+        const int rem = nb - j - 1;
+        if (rem > 0) {
+            GemmDesc u = mkdesc(L + (long)j * NB * (ld + 1) + NB, ld, Bj, ld, Bj + NB, ld, rem, rt, NB, -1.0, 1.0);
+            launch_tri_gemm<false, true>(s, u, 1);
+        }
+    }
+    for (int j = nb - 1; j >= 0; --j) {   // backward: X_j = T_jj^T B_j ; B_i -= L_ji^T X_j (i < j)
+        const double* Tjj = Linv + (long)j * NB * (ld + 1);
+        double* Bj = B + (long)j * NB;
+        GemmDesc a = mkdesc(Tjj, ld, Bj, ld, Bj, ld, 1, rt, NB, 1.0, 0.0);   // A elem(m,k) = T[k + m ld]: K-contig
+        launch_tri_gemm<true, true>(s, a, 1);
+        if (j > 0) {
+            // rows i < j: A elem(m,k) = L[(j NB + k) + m ld] over block row j of L, columns 0.. j NB
+            GemmDesc u = mkdesc(L + (long)j * NB, ld, Bj, ld, B, ld, j, rt, NB, -1.0, 1.0);
+            launch_tri_gemm<true, true>(s, u, 1);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemv_n_kernel(const double* __restrict__ A, int Np, const double* __restrict__ x,
+                                                     double* __restrict__ y) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Np) return;
+    double s = 0.0;
+    for (int j = 0; j < Np; ++j) s += A[(long)i + (long)j * Np] * x[j];
+    y[i] = s;
+}
+void launch_gemv_n(hipStream_t s, const double* A, int Np, const double* x, double* y) {
+    hipLaunchKernelGGL(gemv_n_kernel, dim3((Np + 255) / 256), dim3(256), 0, s, A, Np, x, y);
+}
+
+// y_j = sum_i A[i,j] x_i : one wave per column, wave-shuffle reduction
+__global__ __launch_bounds__(256) void gemv_t_kernel(const double* __restrict__ A, int Np, const double* __restrict__ x,
+                                                     double* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= Np) return;
+    double s = 0.0;
+    for (int i = lane; i < Np; i += 64) s += A[(long)i + (long)j * Np] * x[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) y[j] = s;
+}
+void launch_gemv_t(hipStream_t s, const double* A, int Np, const double* x, double* y) {
+    hipLaunchKernelGGL(gemv_t_kernel, dim3((Np + 3) / 4), dim3(256), 0, s, A, Np, x, y);
+}
+
+__global__ __launch_bounds__(256) void zero_upper_kernel(double* __restrict__ A, int Np) {
+    const long idx = blockIdx.x * 256L + threadIdx.x;
+    if (idx >= (long)Np * Np) return;
+    const int i = idx % Np, j = idx / Np;
+    if (i < j) A[idx] = 0.0;
+}
+void launch_zero_upper(hipStream_t s, double* A, int Np) {
+    const long n = (long)Np * Np;
+    hipLaunchKernelGGL(zero_upper_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, A, Np);
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(double* __restrict__ p, long n, double v) {
+    long i = blockIdx.x * 256L + threadIdx.x;
+    const long stride = gridDim.x * 256L;
+    for (; i < n; i += stride) p[i] = v;
+}
+void launch_fill(hipStream_t s, double* p, long n, double v) {
+    if (n <= 0) return;
+    long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, n, v);
+}
+
+__global__ __launch_bounds__(256) void mu_data_kernel(const double* __restrict__ y, const double* __restrict__ alpha, double b,
+                                                      int N, double* __restrict__ mu_data) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < N) mu_data[i] = y[i] - b * alpha[i];
+}
+void launch_mu_data(hipStream_t s, const double* y, const double* alpha, double b, int N, double* mu_data) {
+    hipLaunchKernelGGL(mu_data_kernel, dim3((N + 255) / 256), dim3(256), 0, s, y, alpha, b, N, mu_data);
+}
+
+__global__ __launch_bounds__(256) void logdet_kernel(const double* __restrict__ L, int Np, int N, double* __restrict__ out) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < N; i += 256) s += log(L[(long)i * (Np + 1)]);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = 2.0 * red[0];
+}
+void launch_logdet(hipStream_t s, const double* L, int Np, int N, double* out) {
+    hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(256), 0, s, L, Np, N, out);
+}
+
+}  // namespace slsk

@@ -1,0 +1,205 @@
+// Gram-matrix kernels: CalcLargeKF/KY (src/regressor.cpp:61-89) and batched CalcSmallK (src/regressor.cpp:45-59),
+// ARD squared-exponential and ARD Matern-5/2 (mathtoolbox kernel functions).
+//
+// q_ij = |x~_i|^2 + |x~_j|^2 - 2 x~_i . x~_j with x~ = (x - 0.5)/l; the dot products run on the fp64 MFMA tile
+// (gemm_f64.hpp), the transcendental epilogue on the VALU, and the result tile is written once, coalesced
+// (HBM-write bound: 8 N^2 bytes).
+#include "gemm_f64.hpp"
+#include "kernels.hpp"
+#include "../../include/sls_hip.h"
+
+namespace slsk {
+
+// k and the first-argument-derivative weight c (dk/dx_d = -c (x_d - x'_d) / l_d^2)
+__device__ __forceinline__ void kernel_kc(int kernel, double a, double q, double& k, double& c) {
+    if (kernel == SLS_KERNEL_ARD_SQUARED_EXPONENTIAL) {
+        k = a * exp(-0.5 * q);
+        c = k;
+    } else {
+        const double s = sqrt(5.0 * q);
+        const double e = exp(-s);
+        k = a * (1.0 + s + (5.0 / 3.0) * q) * e;
+        c = a * (5.0 / 3.0) * (1.0 + s) * e;
+    }
+}
+
+template <bool CAND_MAJOR>
+__global__ __launch_bounds__(256) void prep_kernel(const double* __restrict__ X, long ldr, int D, int M,
+                                                   const double* __restrict__ inv_ell, double* __restrict__ XT, long ld, int Mp,
+                                                   int Dcols, double* __restrict__ norms) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Mp) return;
+    double s = 0.0;
+    if (i < M) {
+        for (int d = 0; d < D; ++d) {
+            const double raw = CAND_MAJOR ? X[i + (long)d * ldr] : X[d + (long)i * D];
+            const double v = (raw - 0.5) * inv_ell[d];
+            XT[i + (long)d * ld] = v;
+            s += v * v;
+        }
+        for (int d = D; d < Dcols; ++d) XT[i + (long)d * ld] = 0.0;
+    } else {
+        for (int d = 0; d < Dcols; ++d) XT[i + (long)d * ld] = 0.0;
+    }
+    norms[i] = s;
+}
+
+void launch_prep_points(hipStream_t s, const double* X, int D, int M, const double* inv_ell, double* XT, long ld, int Mp,
+                        int Dcols, double* norms) {
+    hipLaunchKernelGGL(prep_kernel<false>, dim3((Mp + 255) / 256), dim3(256), 0, s, X, 0L, D, M, inv_ell, XT, ld, Mp, Dcols,
+                       norms);
+}
+void launch_prep_cands(hipStream_t s, const double* xr, long ldr, int D, int M, const double* inv_ell, double* XT, long ld,
+                       int Mp, int Dcols, double* norms) {
+    hipLaunchKernelGGL(prep_kernel<true>, dim3((Mp + 255) / 256), dim3(256), 0, s, xr, ldr, D, M, inv_ell, XT, ld, Mp, Dcols,
+                       norms);
+}
+
+__global__ __launch_bounds__(256) void scale_rows_kernel(const double* __restrict__ XT, const double* __restrict__ alpha,
+                                                         double* __restrict__ XaT, long ld, int Np, int Dcols) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Np) return;
+    const double al = alpha[i];
+    for (int d = 0; d < Dcols; ++d) XaT[i + (long)d * ld] = al * XT[i + (long)d * ld];
+}
+void launch_scale_rows(hipStream_t s, const double* XT, const double* alpha, double* XaT, long ld, int Np, int Dcols) {
+    hipLaunchKernelGGL(scale_rows_kernel, dim3((Np + 255) / 256), dim3(256), 0, s, XT, alpha, XaT, ld, Np, Dcols);
+}
+
+__global__ __launch_bounds__(256, 2) void gram_sym_kernel(const double* __restrict__ XT, long ld, int Dp,
+                                                          const double* __restrict__ nx, int Np, int N, int kernel, double a,
+                                                          double b, double* __restrict__ K, int lower_only) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* lds = reinterpret_cast<double*>(smem);
+    const int nt = Np / GEMM_BM;
+    const int t = xcd_remap(blockIdx.x, nt * nt);
+    const int tm = t % nt, tn = t / nt;
+    if (lower_only && tn > tm) return;
+    const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+    Acc acc;
+    acc.zero();
+    gemm_tile<false, false>(acc, XT + m0, ld, XT + n0, ld, 0, Dp, lds);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gi = m0 + acc_m(i);
+        const double ni = nx[gi];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gj = n0 + acc_n(j, r);
+                double q = ni + nx[gj] - 2.0 * acc.v[i][j][r];
+                q = (q < 0.0 || gi == gj) ? 0.0 : q;
+                double k, c;
+                kernel_kc(kernel, a, q, k, c);
+                if (gi == gj) k += b;
+                if (gi >= N || gj >= N) k = (gi == gj) ? 1.0 : 0.0;
+                K[(long)gi + (long)gj * Np] = k;
+            }
+    }
+}
+
+void launch_gram_sym(hipStream_t s, const double* XT, long ld, int Dp, const double* nx, int Np, int N, KernelSpec ks, double b,
+                     double* K, bool lower_only) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gram_sym_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        attr = true;
+    }
+    const int nt = Np / GEMM_BM;
+    hipLaunchKernelGGL(gram_sym_kernel, dim3(nt * nt), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, XT, ld, Dp, nx, Np, N, ks.kernel,
+                       ks.a, b, K, (int)lower_only);
+}
+
+// One tile = 128 candidates (m) x 128 training points (n').  Writes K*, C* candidate-major and the per-tile partial
+// column sums of alpha_i k_in and alpha_i c_in (reduced deterministically by the finalize kernel).
+template <bool MATERN>
+__global__ __launch_bounds__(256, 2) void cross_gram_kernel(const double* __restrict__ XsT, long lds_, const double* __restrict__ ns,
+                                                            int Sp, const double* __restrict__ XT, long ld,
+                                                            const double* __restrict__ nx, int Np, int N, int Dp, double a,
+                                                            const double* __restrict__ alpha, double* __restrict__ Ks,
+                                                            double* __restrict__ Cs, long ldk, double* __restrict__ mu_part,
+                                                            double* __restrict__ ca_part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* lds = reinterpret_cast<double*>(smem);
+    const int ntm = Sp / GEMM_BM, ntn = Np / GEMM_BN;
+    const int t = xcd_remap(blockIdx.x, ntm * ntn);
+    const int tm = t % ntm, tn = t / ntm;
+    const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+    Acc acc;
+    acc.zero();
+    gemm_tile<false, false>(acc, XsT + m0, lds_, XT + n0, ld, 0, Dp, lds);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double smu[4], sca[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gm = m0 + acc_m(i);
+        const double nm = ns[gm];
+        double pm = 0.0, pc = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gi = n0 + acc_n(j, r);
+                double q = nm + nx[gi] - 2.0 * acc.v[i][j][r];
+                q = q < 0.0 ? 0.0 : q;
+                double k, c;
+                kernel_kc(MATERN ? SLS_KERNEL_ARD_MATERN52 : SLS_KERNEL_ARD_SQUARED_EXPONENTIAL, a, q, k, c);
+                if (gi >= N) { k = 0.0; c = 0.0; }
+                Ks[(long)gm + (long)gi * ldk] = k;
+                if (MATERN) Cs[(long)gm + (long)gi * ldk] = c;
+                if (alpha) {
+                    const double al = alpha[gi];
+                    pm += al * k;
+                    pc += al * c;
+                }
+            }
+        smu[i] = pm;
+        sca[i] = pc;
+    }
+    if (alpha) {
+        // reduce over the 4 lane groups (lane>>4), then over the two wave columns through LDS
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            smu[i] += __shfl_xor(smu[i], 16);
+            smu[i] += __shfl_xor(smu[i], 32);
+            sca[i] += __shfl_xor(sca[i], 16);
+            sca[i] += __shfl_xor(sca[i], 32);
+        }
+        double* red = lds;  // [2 wn][2 arrays][128]
+        if (lane < 16) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ml = (wave & 1) * 64 + 16 * i + lane;
+                red[((wave >> 1) * 2 + 0) * 128 + ml] = smu[i];
+                red[((wave >> 1) * 2 + 1) * 128 + ml] = sca[i];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int ml = threadIdx.x;
+            mu_part[(long)tn * ldk + m0 + ml] = red[0 * 128 + ml] + red[2 * 128 + ml];
+            ca_part[(long)tn * ldk + m0 + ml] = red[1 * 128 + ml] + red[3 * 128 + ml];
+        }
+    }
+}
+
+void launch_cross_gram(hipStream_t s, const double* XsT, long lds_, const double* ns, int Sp, const double* XT, long ld,
+                       const double* nx, int Np, int N, int Dp, KernelSpec ks, const double* alpha, double* Ks, double* Cs,
+                       long ldk, double* mu_part, double* ca_part) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)cross_gram_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)cross_gram_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        attr = true;
+    }
+    const int nt = (Sp / GEMM_BM) * (Np / GEMM_BN);
+    if (ks.kernel == SLS_KERNEL_ARD_MATERN52)
+        hipLaunchKernelGGL(cross_gram_kernel<true>, dim3(nt), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, XsT, lds_, ns, Sp, XT, ld, nx,
+                           Np, N, Dp, ks.a, alpha, Ks, Cs, ldk, mu_part, ca_part);
+    else
+        hipLaunchKernelGGL(cross_gram_kernel<false>, dim3(nt), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, XsT, lds_, ns, Sp, XT, ld, nx,
+                           Np, N, Dp, ks.a, alpha, Ks, Cs, ldk, mu_part, ca_part);
+}
+
+}  // namespace slsk

@@ -1,0 +1,46 @@
+"""CPU-side checks of the boundary: the C-ABI library loads and exports every symbol include/sls_hip.h declares,
+and refuses to run without a GPU (no silent CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from util import sls
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "sls_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(sls_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    g.build()
+    m = sls()
+    lib = m.lib()
+    names = declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"libsls_hip.so does not export {n}"
+    assert sorted(m.EXPORTS) == names
+    assert lib.sls_version() >= 100
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    m = sls()
+    with pytest.raises(m.SlsError) as e:
+        m.Context(0)
+    assert "no CPU fallback" in str(e.value) or "no HIP device" in str(e.value)
+
+
+def test_merge_rank_results_first_maximum():
+    m = sls()
+    best = m.merge_rank_results([(1.0, 7, [0.1]), (2.0, 40, [0.2]), (2.0, 12, [0.3]), (-1.0, 0, [0.4])])
+    assert best[0] == 2.0 and best[1] == 12 and best[2][0] == 0.3
