@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric: GP-fit + acquisition-maximisation step at N=8192, D=64 (config C4).
+
+One STEP = (a) GP fit on the device-resident design matrix: Gram (Matern-5/2) + Cholesky + K^-1 + alpha + mu+,
+           (b) multi-start EI maximisation: 65 536 random starts x 50 lock-step bounded L-BFGS evaluations,
+               i.e. 3 276 800 candidate evaluations (value + gradient), sharded over the ranks,
+           (c) one all-gather of (value, global index, x[D]) per rank and the first-maximum merge.
+value = candidate evaluations per second of the whole job (all ranks); ms_per_step is the step time.
+Strong scaling: the 65 536 starts are fixed and split over the ranks; every rank repeats the (cheap) fit.
+
+Launch: python bench.py [--gpus N --steps K --warmup W];  for N > 1 under torch.distributed.run (one rank per GPU).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X dense fp64 matrix peak: 256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz
+                               # (v_mfma_f64_16x16x4_f64 = 2048 FLOP / 64 clk / SIMD; MI355X_MICROARCH.md gives no
+                               #  fp64 row -- derived from the f32 row's 64 FLOP/clk/SIMD halved)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=2)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--n", type=int, default=8192, help="training points N")
+    p.add_argument("--d", type=int, default=64, help="dimensions D")
+    p.add_argument("--starts", type=int, default=65536, help="total multi-start count S (split over ranks)")
+    p.add_argument("--n-local", type=int, default=50, help="objective evaluations per start")
+    p.add_argument("--kernel", choices=["matern52", "se"], default="matern52")
+    p.add_argument("--chunk", type=int, default=16384, help="candidates per device pass")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    return p.parse_args()
+
+
+def synth(D, N, S):
+    """SURVEY.md 8(d) synthetic inputs (seeds 1234/1235/1236)."""
+    X = np.random.default_rng(1234).uniform(0.0, 1.0, (D, N))
+    y = np.exp(-np.sum((X - 0.4) ** 2, axis=0)) + 0.01 * np.random.default_rng(1235).normal(size=N)
+    theta = np.concatenate([[0.5], np.full(D, 0.5 * np.sqrt(max(D, 8) / 8.0))])
+    starts = np.random.default_rng(1236).uniform(0.0, 1.0, (D, S))
+    return np.asfortranarray(X), y, theta, 0.005, np.asfortranarray(starts)
+
+
+def cpu_baseline(args, kernel_id):
+    """The oracle ("port") timed on the host cores, on a bounded sample of the same workload."""
+    from oracle import oracle_py as orc
+    orc.build()
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    Ns = min(args.n, 2048)
+    Ss = 1024
+    evals = 3
+    X, y, theta, b, starts = synth(args.d, Ns, Ss)
+    t0 = time.perf_counter()
+    ref = orc.Regressor(X, y, theta, b, kernel=kernel_id)
+    t_fit = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ref.acq_maximize(starts, evals, n_threads=threads)
+    t_acq = time.perf_counter() - t0
+    rate_sample = Ss * evals / t_acq
+    scale = (Ns / args.n) ** 2          # per-evaluation cost is 2 N^2 + 6 N D flops
+    return {
+        "value": rate_sample * scale, "unit": "candidate-evals/s", "cores": threads, "kind": "port",
+        "sample": (f"oracle (hoisted mode, Cholesky inverse, blocked GEMV) at N={Ns}, D={args.d}: fit {t_fit:.2f} s, "
+                   f"{Ss} starts x {evals} evals in {t_acq:.2f} s = {rate_sample:.1f} evals/s; value is that rate scaled "
+                   f"by (N_sample/N)^2 = {scale:.4f} to N={args.n} (per-eval cost ~ 2N^2 flops); box has {cores} cores"),
+        "measured_rate_at_sample": rate_sample, "fit_seconds_at_sample": t_fit,
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    sls = importlib.import_module("sequential-line-search_amd")
+    kernel_id = sls.KERNEL_MATERN52 if args.kernel == "matern52" else sls.KERNEL_SE
+    D, N, S = args.d, args.n, args.starts
+    assert S % world == 0, "starts must divide over the ranks"
+    S_loc = S // world
+    lo = rank * S_loc
+
+    X, y, theta, b, starts = synth(D, N, S)
+    ctx = sls.Context(local_rank)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_candidate_chunk(args.chunk)
+    # inputs resident in HBM before the timed region
+    X_dev = torch.from_numpy(np.ascontiguousarray(X.T)).to(dev)               # (N, D) C-order == D x N column-major
+    y_dev = torch.from_numpy(y).to(dev)
+    starts_dev = torch.from_numpy(np.ascontiguousarray(starts[:, lo:lo + S_loc].T)).to(dev)
+    gp = sls.GP(ctx, X, y, theta, b, kernel_id)
+    gather = torch.empty((world, D + 2), dtype=torch.float64, device=dev)
+    mine = torch.empty(D + 2, dtype=torch.float64, device=dev)
+
+    def step():
+        gp.refit_dev(X_dev.data_ptr(), y_dev.data_ptr())
+        r = gp.acq_maximize_dev(starts_dev.data_ptr(), S_loc, args.n_local, sls.ACQ_EI, 1.0, offset=lo)
+        if world > 1:
+            mine.copy_(torch.from_numpy(np.concatenate([[r["value"], float(r["index"])], r["x"]])))
+            dist.all_gather_into_tensor(gather, mine)          # the single RCCL exchange of the step
+            g = gather.cpu().numpy()
+            v, i, x = sls.merge_rank_results((row[0], int(row[1]), row[2:]) for row in g)
+            return dict(value=v, index=i, x=x)
+        return r
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    names = ["gram", "potrf", "trtri", "lauum", "cross_gram", "acq_gemm", "grad_gemm", "finalize", "lbfgs"]
+    prof = {n: ctx.prof_get(n) for n in names}
+    ctx.prof_enable(False)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        evals = S * args.n_local
+        Np = (N + 127) // 128 * 128
+        gemm_ms, gemm_launches = prof["acq_gemm"]
+        chunk = min(args.chunk, (S_loc + 127) // 128 * 128)
+        # algorithmic flops of ONE acq_gemm launch: w = K^-1 k for `chunk` candidates = 2 N^2 flops per candidate
+        # (SURVEY.md 8(d) "EI value+grad, one candidate-eval": 2 N^2 of the 2 N^2 + 6 N D)
+        launches_per_eval = -(-S_loc // chunk)
+        cand_per_launch = S_loc / launches_per_eval
+        flops_per_launch = 2.0 * N * N * cand_per_launch
+        avg_ms = gemm_ms / max(gemm_launches, 1)
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_acq_gemm.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "candidate_evals_per_sec (GP-fit + multi-start EI acq-max step, N=8192 D=64)",
+            "value": evals / (ms_per_step * 1e-3), "unit": "candidate-evals/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C4: multi-start EI maximisation", "N": N, "D": D, "starts_total": S,
+                       "starts_per_gpu": S_loc, "n_local_evals": args.n_local, "kernel": args.kernel,
+                       "candidate_chunk": chunk, "parallelism": f"starts sharded over {world} GPU(s), one all-gather"},
+            "roofline": {"bound": "mfma", "kernel": "acq_gemm_kernel", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
+                         "avg_launch_ms": avg_ms, "launches": gemm_launches, "flops_per_launch": flops_per_launch},
+            "stage_ms_per_step": {n: prof[n][0] / args.steps for n in names},
+            "result": {"best_value": res["value"], "best_index": int(res["index"])},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, kernel_id)
+        print(json.dumps(out))
+    gp.close()
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
