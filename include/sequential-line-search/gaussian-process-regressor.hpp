@@ -1,0 +1,61 @@
+// GP regression on (X, y) (reference surface: include/sequential-line-search/gaussian-process-regressor.hpp:13-58).
+#ifndef SEQUENTIAL_LINE_SEARCH_GAUSSIAN_PROCESS_REGRESSOR_HPP
+#define SEQUENTIAL_LINE_SEARCH_GAUSSIAN_PROCESS_REGRESSOR_HPP
+
+#include <memory>
+#include <sequential-line-search/eigen-lite.hpp>
+#include <sequential-line-search/regressor.hpp>
+
+namespace sequential_line_search
+{
+    namespace device
+    {
+        struct GpHandle;
+    }
+
+    class GaussianProcessRegressor : public Regressor
+    {
+    public:
+        /// Hyper-parameters (a, b, r) come from MAP estimation of the log marginal likelihood with log-normal priors.
+        GaussianProcessRegressor(const Eigen::MatrixXd& X, const Eigen::VectorXd& y,
+                                 const KernelType kernel_type = KernelType::ArdMatern52Kernel);
+
+        /// Specified hyper-parameters are used as they are.
+        GaussianProcessRegressor(const Eigen::MatrixXd& X, const Eigen::VectorXd& y, const Eigen::VectorXd& kernel_hyperparams,
+                                 double noise_hyperparam, const KernelType kernel_type = KernelType::ArdMatern52Kernel);
+
+        double PredictMu(const Eigen::VectorXd& x) const override;
+        double PredictSigma(const Eigen::VectorXd& x) const override;
+
+        Eigen::VectorXd PredictMuDerivative(const Eigen::VectorXd& x) const override;
+        Eigen::VectorXd PredictSigmaDerivative(const Eigen::VectorXd& x) const override;
+
+        // Available after construction (copied back from the device; see s_materialize_matrices)
+        Eigen::MatrixXd m_K_y;
+        Eigen::MatrixXd m_K_y_inv;
+
+        /// Set false to skip the 2 x N^2 device->host copies of m_K_y / m_K_y_inv for large N.
+        static bool s_materialize_matrices;
+
+        const Eigen::MatrixXd& GetLargeX() const override { return m_X; }
+        const Eigen::VectorXd& GetSmallY() const override { return m_y; }
+
+        const Eigen::VectorXd& GetKernelHyperparams() const override { return m_kernel_hyperparams; }
+        double                 GetNoiseHyperparam() const override { return m_noise_hyperparam; }
+
+        sls_gp* GetDeviceHandle() const override;
+
+    private:
+        void PerformMapEstimation();
+        void BuildDeviceState();
+
+        Eigen::MatrixXd m_X;
+        Eigen::VectorXd m_y;
+        Eigen::VectorXd m_kernel_hyperparams;
+        double          m_noise_hyperparam;
+
+        std::shared_ptr<device::GpHandle> m_handle;
+    };
+} // namespace sequential_line_search
+
+#endif

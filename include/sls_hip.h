@@ -118,8 +118,43 @@ int sls_acq_maximize(sls_gp* gp, int acq_type, double ucb_h, const double* start
 int sls_acq_maximize_dev(sls_gp* gp, int acq_type, double ucb_h, const double* starts_dev, int S, int n_local,
                          const sls_lbfgs_opts* opts, long start_index_offset, double* x_out, double* val_out,
                          long* idx_out);
+/* objective_for_multiple_points (src/acquisition-function.cpp:63-110), the inner objective of FindNextPoints (:246-298):
+ * predictive mean (and mu+) from gp_mean, predictive deviation from gp_sigma (the variance-updated dummy regressor). */
+int sls_acq_eval_pair(sls_gp* gp_mean, sls_gp* gp_sigma, int acq_type, double ucb_h, const double* Xs, int M, double* val,
+                      double* grad);
+int sls_acq_maximize_pair(sls_gp* gp_mean, sls_gp* gp_sigma, int acq_type, double ucb_h, const double* starts, int S, int n_local,
+                          const sls_lbfgs_opts* opts, double* x_out, double* val_out, long* idx_out);
 /* Re-fit an existing handle in place from device-resident X (D x N), y (N): the timed "GP fit" of bench.py. */
 int sls_gp_refit_dev(sls_gp* gp, const double* X_dev, const double* y_dev);
+
+/* ---- MAP objectives (hyper-parameter / goodness-value estimation) -------------------------------- */
+/* Device state for repeated evaluations of the GP log-likelihood terms on a fixed design matrix X (D x N). */
+typedef struct sls_nll sls_nll;
+int sls_nll_create(sls_ctx* ctx, const double* X, int D, int N, int kernel, sls_nll** out);
+int sls_nll_destroy(sls_nll* h);
+/* Core of both MAP objectives, for K_y = K_f(theta) + b I and a vector y (N):
+ *   quad = y^T K_y^-1 y, logdet = log|K_y| (CalcLogDetOfSymmetricPositiveDefiniteMatrix), alpha = K_y^-1 y (may be NULL),
+ *   grad_theta[p] = 1/2 alpha^T (dK/dtheta_p) alpha - 1/2 tr(K_y^-1 dK/dtheta_p), p = 0..D  (may be NULL)
+ *   grad_b        = the same with dK/db = I                                              (may be NULL)
+ * i.e. calc_grad_theta / calc_grad_b (src/gaussian-process-regressor.cpp:66-106) and CalcObjectiveThetaDerivative /
+ * CalcObjectiveNoiseLevelDerivative (src/preference-regressor.cpp:53-115) without their prior terms, computed without
+ * the (D+1) x N x N tensor of CalcLargeKYThetaDerivative (src/regressor.cpp:110-134).  A repeated (theta, b) re-uses
+ * the cached factorisation (the reference's cached m_K / m_K_llt, src/preference-regressor.cpp:161-162,363-371). */
+int sls_nll_eval(sls_nll* h, const double* y, const double* theta, double b, double* quad, double* logdet, double* alpha,
+                 double* grad_theta, double* grad_b);
+/* objective(x, grad) of src/gaussian-process-regressor.cpp:141-193 with x = (a, b, r_1..r_D) and the file's fixed
+ * log-normal priors (:18-24).  grad (D + 2) may be NULL. */
+int sls_gp_nll_grad(sls_nll* h, const double* y, const double* x, double* value, double* grad);
+/* objective(x, grad) of src/preference-regressor.cpp:129-259.  x = (y_1..y_M [, a, b, r_1..r_D] if use_map_hyperparams);
+ * prefs_flat / pref_offsets: CSR image of std::vector<Preference> (n_prefs tuples, first index = preferred point).
+ * grad (same length as x) may be NULL.  BTL terms (include/sequential-line-search/utils.hpp:25-52) run on the host. */
+typedef struct sls_pref_cfg {
+    int use_map_hyperparams;
+    double default_a, default_r, default_b, prior_var, btl_scale;
+    int noiseless; /* SEQUENTIAL_LINE_SEARCH_USE_NOISELESS_FORMULATION (src/preference-regressor.cpp:48-50,139-143) */
+} sls_pref_cfg;
+int sls_pref_objective(sls_nll* h, const unsigned* prefs_flat, const int* pref_offsets, int n_prefs, const double* x,
+                       const sls_pref_cfg* cfg, double* value, double* grad);
 
 /* ---- instrumentation ------------------------------------------------------ */
 /* Per-kernel accumulated device time (ms, HIP events on the context's stream) and launch counts since the last reset.

@@ -50,7 +50,8 @@ EXPORTS = [
     "sls_ctx_set_candidate_chunk", "sls_gram", "sls_gram_cross", "sls_potrf", "sls_potrs", "sls_potri", "sls_gp_create",
     "sls_gp_destroy", "sls_gp_get_matrix", "sls_gp_get_summary", "sls_gp_predict", "sls_gp_predict_grad", "sls_acq_eval",
     "sls_lbfgs_default_opts", "sls_acq_maximize", "sls_acq_maximize_dev", "sls_gp_refit_dev", "sls_prof_enable",
-    "sls_prof_reset", "sls_prof_get",
+    "sls_prof_reset", "sls_prof_get", "sls_nll_create", "sls_nll_destroy", "sls_nll_eval", "sls_gp_nll_grad",
+    "sls_pref_objective", "sls_acq_eval_pair", "sls_acq_maximize_pair",
 ]
 
 
@@ -219,6 +220,64 @@ class GP:
 
     def refit_dev(self, X_dev_ptr, y_dev_ptr):
         _ck(lib().sls_gp_refit_dev(self.h, C.c_void_p(X_dev_ptr), C.c_void_p(y_dev_ptr)))
+
+
+class PrefCfg(C.Structure):
+    _fields_ = [("use_map_hyperparams", C.c_int), ("default_a", C.c_double), ("default_r", C.c_double),
+                ("default_b", C.c_double), ("prior_var", C.c_double), ("btl_scale", C.c_double), ("noiseless", C.c_int)]
+
+
+class Nll:
+    """Device state for the MAP objectives on a fixed design matrix (sls_nll_* / sls_gp_nll_grad / sls_pref_objective)."""
+
+    def __init__(self, ctx, X, kernel=KERNEL_MATERN52):
+        self.ctx = ctx
+        X = _f(X)
+        self.D, self.N = X.shape
+        self.h = C.c_void_p()
+        _ck(lib().sls_nll_create(ctx.h, _p(X), self.D, self.N, int(kernel), C.byref(self.h)))
+        ctx._gps.append(weakref.ref(self))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().sls_nll_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def eval(self, y, theta, b, want_grad=True):
+        y, theta = _f(y), _f(theta)
+        quad, logdet, gb = C.c_double(), C.c_double(), C.c_double()
+        alpha = np.empty(self.N)
+        gth = np.empty(self.D + 1)
+        _ck(lib().sls_nll_eval(self.h, _p(y), _p(theta), C.c_double(b), C.byref(quad), C.byref(logdet), _p(alpha),
+                               _p(gth) if want_grad else None, C.byref(gb) if want_grad else None))
+        return dict(quad=quad.value, logdet=logdet.value, alpha=alpha, grad_theta=gth if want_grad else None,
+                    grad_b=gb.value if want_grad else None)
+
+    def gp_objective(self, y, x, want_grad=True):
+        y, x = _f(y), _f(x)
+        val = C.c_double()
+        g = np.empty(self.D + 2) if want_grad else None
+        _ck(lib().sls_gp_nll_grad(self.h, _p(y), _p(x), C.byref(val), _p(g) if want_grad else None))
+        return (val.value, g) if want_grad else val.value
+
+    def pref_objective(self, prefs, x, use_map=False, a=0.5, r=0.5, b=0.005, prior_var=0.25, btl_scale=0.01,
+                       noiseless=False, want_grad=True):
+        x = _f(x)
+        flat = np.array([i for p in prefs for i in p], dtype=np.uint32)
+        offs = np.zeros(len(prefs) + 1, dtype=np.int32)
+        offs[1:] = np.cumsum([len(p) for p in prefs])
+        cfg = PrefCfg(int(use_map), a, r, b, prior_var, btl_scale, int(noiseless))
+        val = C.c_double()
+        g = np.empty(len(x)) if want_grad else None
+        _ck(lib().sls_pref_objective(self.h, flat.ctypes.data_as(C.POINTER(C.c_uint)), offs.ctypes.data_as(C.POINTER(C.c_int)),
+                                     len(prefs), _p(x), C.byref(cfg), C.byref(val), _p(g) if want_grad else None))
+        return (val.value, g) if want_grad else val.value
 
 
 def merge_rank_results(results):

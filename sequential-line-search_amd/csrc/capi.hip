@@ -179,6 +179,7 @@ struct sls_gp {
     DBuf Ks, Cs, P, parts, Gs, Gm, XsT, ns, raw, outv, outg, outm, outs;
     int ws_chunk = 0;
     // L-BFGS state
+    DBuf pair_mu, pair_sg, pair_dmu, pair_dsg;
     DBuf lb_x, lb_g, lb_dir, lb_xt, lb_scr, lb_S, lb_Y, lb_rho, lb_f, lb_t, lb_val, lb_grad;
     int* lb_int = nullptr;
     int lb_Sp = 0, lb_m = 0;
@@ -494,7 +495,29 @@ static void ensure_lbfgs(sls_gp* g, int Sp, int m) {
     g->lb_Sp = Sp; g->lb_m = m;
 }
 
-static void maximize_impl(sls_gp* g, int acq_type, double ucb_h, const double* starts_dev, int S, int n_local,
+// value (+ gradient) of the acquisition at candidate-major points xr; gs != nullptr: sigma / dsigma come from gs
+// (objective_for_multiple_points, src/acquisition-function.cpp:63-110)
+static void eval_acq(sls_gp* g, sls_gp* gs, const double* xr, long ldr, int S, int acq_type, double ucb_h, double* val,
+                     double* grad, long ldo) {
+    if (!gs) {
+        EvalOut eo;
+        eo.ldo = ldo; eo.val = val; eo.grad = grad; eo.acq = acq_type; eo.ucb_h = ucb_h;
+        eval_candidates(g, xr, ldr, S, eo);
+        return;
+    }
+    const size_t D = g->D;
+    g->pair_mu.ensure(ldo); g->pair_sg.ensure(ldo);
+    if (grad) { g->pair_dmu.ensure(ldo * D); g->pair_dsg.ensure(ldo * D); }
+    EvalOut a, b;
+    a.ldo = ldo; a.mu = g->pair_mu.p; a.dmu = grad ? g->pair_dmu.p : nullptr;
+    b.ldo = ldo; b.sigma = g->pair_sg.p; b.dsigma = grad ? g->pair_dsg.p : nullptr;
+    eval_candidates(g, xr, ldr, S, a);
+    eval_candidates(gs, xr, ldr, S, b);
+    launch_combine(g->ctx->stream, S, (int)D, ldo, g->pair_mu.p, g->pair_sg.p, g->pair_dmu.p, g->pair_dsg.p, acq_type, g->mu_best,
+                   ucb_h, val, grad);
+}
+
+static void maximize_impl(sls_gp* g, sls_gp* gs, int acq_type, double ucb_h, const double* starts_dev, int S, int n_local,
                           const sls_lbfgs_opts* opts_in, long off, double* x_out, double* val_out, long* idx_out,
                           double* x_stars, double* y_stars) {
     sls_ctx* c = g->ctx;
@@ -512,10 +535,8 @@ static void maximize_impl(sls_gp* g, int acq_type, double ucb_h, const double* s
     st.hlen = g->lb_int; st.hpos = g->lb_int + Sp; st.nbt = g->lb_int + 2 * Sp; st.done = g->lb_int + 3 * Sp;
     st.c1 = o.c1; st.shrink = o.shrink; st.gtol = o.gtol; st.max_backtracks = o.max_backtracks;
     launch_clamp_starts(c->stream, starts_dev, D, S, st.xt, Sp, Sp);
-    EvalOut eo;
-    eo.ldo = Sp; eo.val = g->lb_val.p; eo.grad = g->lb_grad.p; eo.acq = acq_type; eo.ucb_h = ucb_h;
     for (int ev = 0; ev < n_local; ++ev) {
-        eval_candidates(g, st.xt, Sp, S, eo);
+        eval_acq(g, gs, st.xt, Sp, S, acq_type, ucb_h, g->lb_val.p, g->lb_grad.p, Sp);
         ProfScope ps(c, "lbfgs");
         launch_lbfgs_step(c->stream, st, g->lb_val.p, g->lb_grad.p, ev == 0);
     }
@@ -548,7 +569,43 @@ extern "C" int sls_acq_maximize(sls_gp* g, int acq_type, double ucb_h, const dou
     DBuf sd;
     sd.ensure((size_t)g->D * S);
     h2d(c, sd.p, starts, (size_t)g->D * S);
-    maximize_impl(g, acq_type, ucb_h, sd.p, S, n_local, opts, start_index_offset, x_out, val_out, idx_out, x_stars, y_stars);
+    maximize_impl(g, nullptr, acq_type, ucb_h, sd.p, S, n_local, opts, start_index_offset, x_out, val_out, idx_out, x_stars,
+                  y_stars);
+    SLS_CATCH
+}
+
+static void check_pair(sls_gp* g, sls_gp* gs) {
+    SLS_REQUIRE(g && gs, "NULL handle");
+    SLS_REQUIRE(g->ctx == gs->ctx && g->D == gs->D, "the two regressors must share the context and the dimensionality");
+}
+
+extern "C" int sls_acq_maximize_pair(sls_gp* g, sls_gp* gs, int acq_type, double ucb_h, const double* starts, int S, int n_local,
+                                     const sls_lbfgs_opts* opts, double* x_out, double* val_out, long* idx_out) {
+    SLS_TRY
+    check_pair(g, gs);
+    SLS_REQUIRE(starts && S >= 1, "sls_acq_maximize_pair: bad argument");
+    sls_ctx* c = g->ctx;
+    DBuf sd;
+    sd.ensure((size_t)g->D * S);
+    h2d(c, sd.p, starts, (size_t)g->D * S);
+    maximize_impl(g, gs, acq_type, ucb_h, sd.p, S, n_local, opts, 0, x_out, val_out, idx_out, nullptr, nullptr);
+    SLS_CATCH
+}
+
+extern "C" int sls_acq_eval_pair(sls_gp* g, sls_gp* gs, int acq_type, double ucb_h, const double* Xs, int M, double* val,
+                                 double* grad) {
+    SLS_TRY
+    check_pair(g, gs);
+    SLS_REQUIRE(Xs && M >= 0, "sls_acq_eval_pair: bad argument");
+    SLS_REQUIRE(acq_type == SLS_ACQ_EXPECTED_IMPROVEMENT || acq_type == SLS_ACQ_GP_UCB, "unknown acquisition type %d", acq_type);
+    if (M == 0) return SLS_OK;
+    const int Mp = round_up(M, 128), D = g->D;
+    upload_candidates(g, Xs, M, g->raw, Mp);
+    g->outm.ensure(Mp);
+    if (grad) g->outg.ensure((size_t)Mp * D);
+    eval_acq(g, gs, g->raw.p, Mp, M, acq_type, ucb_h, g->outm.p, grad ? g->outg.p : nullptr, Mp);
+    if (val) download_cm(g, g->outm.p, M, Mp, 1, val);
+    if (grad) download_cm(g, g->outg.p, M, Mp, D, grad);
     SLS_CATCH
 }
 
@@ -557,7 +614,8 @@ extern "C" int sls_acq_maximize_dev(sls_gp* g, int acq_type, double ucb_h, const
                                     long* idx_out) {
     SLS_TRY
     SLS_REQUIRE(g && starts_dev, "sls_acq_maximize_dev: NULL argument");
-    maximize_impl(g, acq_type, ucb_h, starts_dev, S, n_local, opts, start_index_offset, x_out, val_out, idx_out, nullptr, nullptr);
+    maximize_impl(g, nullptr, acq_type, ucb_h, starts_dev, S, n_local, opts, start_index_offset, x_out, val_out, idx_out, nullptr,
+                  nullptr);
     SLS_CATCH
 }
 

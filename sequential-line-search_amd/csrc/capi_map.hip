@@ -1,0 +1,245 @@
+// C-ABI: MAP objectives (GP marginal likelihood, preference objective).  Device: Gram + Cholesky + K^-1 + fused
+// gradient contraction; host: the O(D) prior terms and the O(#preferences) Bradley-Terry-Luce terms.
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+using namespace slsk;
+
+#define SLS_TRY try {
+#define SLS_CATCH                                   \
+    }                                               \
+    catch (const slsk::HipFail& f) { return f.code; } \
+    catch (const std::exception& e) {               \
+        slsk::set_error("exception: %s", e.what()); \
+        return SLS_ERR_INVALID;                     \
+    }                                               \
+    return SLS_OK;
+
+struct sls_nll {
+    sls_ctx* ctx = nullptr;
+    int D = 0, N = 0, Np = 0, Dp = 0, Dcols = 0, kernel = 0;
+    DBuf X, y, inv_ell, XT, nx, L, Linv, Kinv, alpha, tvec, G, Y, svec, ones, parts, scal, gl;
+    std::vector<double> cached_theta;
+    double cached_b = -1.0;
+    bool have_factor = false;
+    double logdet = 0.0;
+};
+
+extern "C" int sls_nll_create(sls_ctx* ctx, const double* X, int D, int N, int kernel, sls_nll** out) {
+    SLS_TRY
+    SLS_REQUIRE(ctx && X && out && D >= 1 && N >= 1, "sls_nll_create: bad argument");
+    SLS_REQUIRE(kernel == SLS_KERNEL_ARD_SQUARED_EXPONENTIAL || kernel == SLS_KERNEL_ARD_MATERN52, "unknown kernel %d", kernel);
+    SLS_HIP(hipSetDevice(ctx->device));
+    std::unique_ptr<sls_nll> h(new sls_nll());
+    h->ctx = ctx; h->D = D; h->N = N; h->kernel = kernel;
+    h->Np = round_up(N, 128); h->Dp = round_up(D, 16); h->Dcols = round_up(D, 128);
+    const size_t Np = h->Np;
+    h->X.ensure((size_t)D * N); h->y.ensure(Np); h->inv_ell.ensure(h->Dcols);
+    h->XT.ensure(Np * h->Dcols); h->nx.ensure(Np);
+    h->L.ensure(Np * Np); h->Linv.ensure(Np * Np); h->Kinv.ensure(Np * Np);
+    h->alpha.ensure(Np); h->tvec.ensure(Np); h->svec.ensure(Np); h->ones.ensure(Np);
+    h->scal.ensure(8); h->gl.ensure(h->Dcols);
+    SLS_HIP(hipMemcpyAsync(h->X.p, X, (size_t)D * N * 8, hipMemcpyHostToDevice, ctx->stream));
+    launch_fill(ctx->stream, h->ones.p, Np, 1.0);
+    launch_fill(ctx->stream, h->y.p, Np, 0.0);
+    SLS_HIP(hipStreamSynchronize(ctx->stream));
+    *out = h.release();
+    SLS_CATCH
+}
+
+extern "C" int sls_nll_destroy(sls_nll* h) {
+    if (!h) return SLS_OK;
+    (void)hipStreamSynchronize(h->ctx->stream);
+    delete h;
+    return SLS_OK;
+}
+
+static void nll_factor(sls_nll* h, const double* theta, double b) {
+    sls_ctx* c = h->ctx;
+    const int D = h->D, N = h->N, Np = h->Np;
+    if (h->have_factor && h->cached_b == b && (int)h->cached_theta.size() == D + 1 &&
+        std::memcmp(h->cached_theta.data(), theta, sizeof(double) * (D + 1)) == 0)
+        return;
+    h->have_factor = false;
+    SLS_REQUIRE(theta[0] > 0.0, "signal variance must be positive");
+    std::vector<double> il(h->Dcols, 0.0);
+    for (int d = 0; d < D; ++d) {
+        SLS_REQUIRE(theta[1 + d] > 0.0, "length scale %d must be positive", d);
+        il[d] = 1.0 / theta[1 + d];
+    }
+    SLS_HIP(hipMemcpyAsync(h->inv_ell.p, il.data(), h->Dcols * 8, hipMemcpyHostToDevice, c->stream));
+    SLS_HIP(hipStreamSynchronize(c->stream));
+    KernelSpec ks{h->kernel, theta[0]};
+    launch_prep_points(c->stream, h->X.p, D, N, h->inv_ell.p, h->XT.p, Np, Np, h->Dcols, h->nx.p);
+    launch_gram_sym(c->stream, h->XT.p, Np, h->Dp, h->nx.p, Np, N, ks, b, h->L.p, true);
+    SLS_HIP(hipMemsetAsync(c->d_info, 0, 64, c->stream));
+    launch_fill(c->stream, h->Linv.p, (long)Np * Np, 0.0);
+    launch_potrf(c->stream, h->L.p, Np, h->Linv.p, c->d_info);
+    launch_trtri(c->stream, h->L.p, Np, h->Linv.p, h->Kinv.p);
+    launch_lauum(c->stream, h->Linv.p, Np, h->Kinv.p);
+    launch_logdet(c->stream, h->L.p, Np, N, h->scal.p + 4);
+    int info = 0;
+    SLS_HIP(hipMemcpyAsync(&info, c->d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    SLS_HIP(hipMemcpyAsync(&h->logdet, h->scal.p + 4, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    SLS_HIP(hipStreamSynchronize(c->stream));
+    if (info != 0) {
+        set_error("sls_nll_eval: K_y is not positive definite (pivot %d)", info - 1);
+        throw HipFail{SLS_ERR_NOT_SPD};
+    }
+    h->cached_theta.assign(theta, theta + D + 1);
+    h->cached_b = b;
+    h->have_factor = true;
+}
+
+static void nll_eval_impl(sls_nll* h, const double* y, const double* theta, double b, double* quad, double* logdet,
+                          double* alpha, double* grad_theta, double* grad_b) {
+    sls_ctx* c = h->ctx;
+    const int D = h->D, N = h->N, Np = h->Np;
+    SLS_REQUIRE(y && theta, "sls_nll_eval: NULL argument");
+    SLS_REQUIRE(b >= 0.0, "noise level must be >= 0");
+    nll_factor(h, theta, b);
+    SLS_HIP(hipMemcpyAsync(h->y.p, y, (size_t)N * 8, hipMemcpyHostToDevice, c->stream));
+    launch_gemv_n(c->stream, h->Linv.p, Np, h->y.p, h->tvec.p);
+    launch_gemv_t(c->stream, h->Linv.p, Np, h->tvec.p, h->alpha.p);
+    const bool want_grad = grad_theta || grad_b;
+    const int nt = Np / 128;
+    if (want_grad) {
+        h->G.ensure((size_t)Np * Np);
+        h->Y.ensure((size_t)Np * h->Dcols);
+        h->parts.ensure((size_t)nt * nt);
+        launch_nll_weight(c->stream, h->XT.p, Np, h->Dp, h->nx.p, Np, N, KernelSpec{h->kernel, theta[0]}, h->alpha.p, h->Kinv.p,
+                          h->G.p, h->parts.p);
+    } else {
+        h->parts.ensure(1);
+    }
+    launch_nll_scalars(c->stream, h->parts.p, want_grad ? nt * nt : 0, h->alpha.p, h->y.p, h->Kinv.p, Np, N, h->scal.p);
+    std::vector<double> gl(D, 0.0);
+    if (grad_theta) {
+        launch_gemv_n(c->stream, h->G.p, Np, h->ones.p, h->svec.p);
+        launch_gemm_plain(c->stream, h->G.p, Np, false, h->XT.p, Np, true, h->Y.p, Np, nt, h->Dcols / 128, Np, 1.0, 0.0);
+        launch_lengthscale_grad(c->stream, h->XT.p, h->Y.p, h->svec.p, h->inv_ell.p, Np, N, D, h->gl.p);
+        SLS_HIP(hipMemcpyAsync(gl.data(), h->gl.p, (size_t)D * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    double sc[3];
+    SLS_HIP(hipMemcpyAsync(sc, h->scal.p, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (alpha) SLS_HIP(hipMemcpyAsync(alpha, h->alpha.p, (size_t)N * 8, hipMemcpyDeviceToHost, c->stream));
+    SLS_HIP(hipStreamSynchronize(c->stream));
+    if (quad) *quad = sc[2];
+    if (logdet) *logdet = h->logdet;
+    if (grad_b) *grad_b = sc[1];
+    if (grad_theta) {
+        grad_theta[0] = sc[0] / theta[0];
+        for (int d = 0; d < D; ++d) grad_theta[1 + d] = gl[d];
+    }
+}
+
+extern "C" int sls_nll_eval(sls_nll* h, const double* y, const double* theta, double b, double* quad, double* logdet,
+                            double* alpha, double* grad_theta, double* grad_b) {
+    SLS_TRY
+    SLS_REQUIRE(h, "sls_nll_eval: NULL handle");
+    nll_eval_impl(h, y, theta, b, quad, logdet, alpha, grad_theta, grad_b);
+    SLS_CATCH
+}
+
+// mathtoolbox::GetLogOfLogNormalDist / ...Derivative
+static double log_lognormal(double x, double mu, double s2) {
+    const double lx = std::log(x);
+    return -lx - 0.5 * std::log(2.0 * M_PI * s2) - (lx - mu) * (lx - mu) / (2.0 * s2);
+}
+static double log_lognormal_d(double x, double mu, double s2) { return (mu - s2 - std::log(x)) / (s2 * x); }
+
+extern "C" int sls_gp_nll_grad(sls_nll* h, const double* y, const double* x, double* value, double* grad) {
+    SLS_TRY
+    SLS_REQUIRE(h && y && x, "sls_gp_nll_grad: NULL argument");
+    const int D = h->D, N = h->N;
+    // priors: src/gaussian-process-regressor.cpp:18-24
+    const double a_mu = std::log(0.5), a_s2 = 0.5, b_mu = std::log(1e-4), b_s2 = 0.5, r_mu = std::log(0.5), r_s2 = 0.5;
+    const double a = x[0], b = x[1];
+    std::vector<double> theta(D + 1), gth(D + 1);
+    theta[0] = a;
+    for (int d = 0; d < D; ++d) theta[1 + d] = x[2 + d];
+    double quad = 0, logdet = 0, gb = 0;
+    nll_eval_impl(h, y, theta.data(), b, &quad, &logdet, nullptr, grad ? gth.data() : nullptr, grad ? &gb : nullptr);
+    double reg = log_lognormal(a, a_mu, a_s2) + log_lognormal(b, b_mu, b_s2);
+    for (int d = 0; d < D; ++d) reg += log_lognormal(x[2 + d], r_mu, r_s2);
+    if (value) *value = -0.5 * quad - 0.5 * logdet - 0.5 * N * std::log(2.0 * M_PI) + reg;   // :174-192
+    if (grad) {
+        grad[0] = gth[0] + log_lognormal_d(a, a_mu, a_s2);                                   // calc_grad :120-124
+        grad[1] = gb + log_lognormal_d(b, b_mu, b_s2);
+        for (int d = 0; d < D; ++d) grad[2 + d] = gth[1 + d] + log_lognormal_d(x[2 + d], r_mu, r_s2);
+    }
+    SLS_CATCH
+}
+
+// utils::CalcBtl / CalcBtlDerivative (include/sequential-line-search/utils.hpp:25-52), no max-subtraction like the reference
+static double btl(const double* f, int n, double s) {
+    double sum = 0.0;
+    for (int i = 0; i < n; ++i) sum += std::exp(f[i] / s);
+    return std::exp(f[0] / s) / sum;
+}
+static void btl_derivative(const double* f, int n, double s, double* d) {
+    const double v = btl(f, n, s);
+    const double tmp = -v * v / s;
+    double sum = 0.0;
+    for (int i = 1; i < n; ++i) sum += std::exp((f[i] - f[0]) / s);
+    d[0] = tmp * (-sum);
+    for (int i = 1; i < n; ++i) d[i] = tmp * std::exp((f[i] - f[0]) / s);
+}
+
+extern "C" int sls_pref_objective(sls_nll* h, const unsigned* prefs_flat, const int* pref_offsets, int n_prefs, const double* x,
+                                  const sls_pref_cfg* cfg, double* value, double* grad) {
+    SLS_TRY
+    SLS_REQUIRE(h && x && cfg && (n_prefs == 0 || (prefs_flat && pref_offsets)), "sls_pref_objective: NULL argument");
+    const int D = h->D, M = h->N;
+    const bool use_map = cfg->use_map_hyperparams != 0;
+    const double a = use_map ? x[M + 0] : cfg->default_a;
+    const double b = cfg->noiseless ? 0.0 : (use_map ? x[M + 1] : cfg->default_b);
+    std::vector<double> theta(D + 1), gth(D + 1), alpha(M);
+    theta[0] = a;
+    for (int d = 0; d < D; ++d) theta[1 + d] = use_map ? x[M + 2 + d] : cfg->default_r;
+    double obj = 0.0;
+    std::vector<double> ftmp, dtmp;
+    for (int p = 0; p < n_prefs; ++p) {   // :151-154
+        const int o = pref_offsets[p], n = pref_offsets[p + 1] - o;
+        ftmp.resize(n);
+        for (int i = 0; i < n; ++i) {
+            SLS_REQUIRE(prefs_flat[o + i] < (unsigned)M, "preference index %u out of range", prefs_flat[o + i]);
+            ftmp[i] = x[prefs_flat[o + i]];
+        }
+        obj += std::log(btl(ftmp.data(), n, cfg->btl_scale));
+    }
+    double quad = 0, logdet = 0, gb = 0;
+    const bool gtheta = grad && use_map;
+    nll_eval_impl(h, x, theta.data(), b, &quad, &logdet, alpha.data(), gtheta ? gth.data() : nullptr, gtheta ? &gb : nullptr);
+    obj += -0.5 * quad - 0.5 * logdet - 0.5 * M * std::log(2.0 * M_PI);   // :165-170
+    if (use_map) {   // :175-192
+        obj += log_lognormal(a, std::log(cfg->default_a), cfg->prior_var);
+        if (!cfg->noiseless) obj += log_lognormal(b, std::log(cfg->default_b), cfg->prior_var);
+        for (int d = 0; d < D; ++d) obj += log_lognormal(theta[1 + d], std::log(cfg->default_r), cfg->prior_var);
+    }
+    if (value) *value = obj;
+    if (grad) {
+        for (int i = 0; i < M; ++i) grad[i] = 0.0;
+        for (int p = 0; p < n_prefs; ++p) {   // :202-216
+            const int o = pref_offsets[p], n = pref_offsets[p + 1] - o;
+            ftmp.resize(n);
+            dtmp.resize(n);
+            for (int i = 0; i < n; ++i) ftmp[i] = x[prefs_flat[o + i]];
+            const double v = btl(ftmp.data(), n, cfg->btl_scale);
+            btl_derivative(ftmp.data(), n, cfg->btl_scale, dtmp.data());
+            for (int i = 0; i < n; ++i) grad[prefs_flat[o + i]] += dtmp[i] / v;
+        }
+        for (int i = 0; i < M; ++i) grad[i] += -alpha[i];   // :219
+        if (use_map) {
+            grad[M + 0] = gth[0] + log_lognormal_d(a, std::log(cfg->default_a), cfg->prior_var);
+            grad[M + 1] = cfg->noiseless ? 0.0 : gb + log_lognormal_d(b, std::log(cfg->default_b), cfg->prior_var);   // :237-238
+            for (int d = 0; d < D; ++d)
+                grad[M + 2 + d] = gth[1 + d] + log_lognormal_d(theta[1 + d], std::log(cfg->default_r), cfg->prior_var);
+        }
+    }
+    SLS_CATCH
+}

@@ -54,6 +54,11 @@ struct FinalizeArgs {
 };
 void launch_finalize(hipStream_t s, const FinalizeArgs& a);
 
+// acquisition value / gradient from separately predicted mean and deviation (objective_for_multiple_points,
+// src/acquisition-function.cpp:63-110): all arrays candidate-major with leading dimension ld
+void launch_combine(hipStream_t s, int S, int D, long ld, const double* mu, const double* sigma, const double* dmu,
+                    const double* dsigma, int acq, double mu_best, double ucb_h, double* val, double* grad);
+
 struct LbfgsState {
     int S, D, m;
     long ld;                  // Sp
@@ -91,5 +96,22 @@ void launch_fill(hipStream_t s, double* p, long n, double v);
 // mu_data[i] = y[i] - b*alpha[i] (i<N); out: first argmax + value; logdet = 2 sum log L_ii (i<N)
 void launch_mu_data(hipStream_t s, const double* y, const double* alpha, double b, int N, double* mu_data);
 void launch_logdet(hipStream_t s, const double* L, int Np, int N, double* out);
+
+// generic C = alpha * opA opB^T + beta * C on full 128-tiles (mt x nt tiles, K multiple of 16)
+void launch_gemm_plain(hipStream_t s, const double* A, long lda, bool a_kc, const double* B, long ldb, bool b_kc, double* C,
+                       long ldc, int mt, int nt, int K, double alpha, double beta);
+
+// ---- kernels_map.hip -----------------------------------------------------------
+// MAP-gradient weights (replaces the (D+1) x N x N tensor of CalcLargeKYThetaDerivative, src/regressor.cpp:110-134):
+// G[j + k*Np] = 1/2 (alpha_j alpha_k - Kinv_jk) c_jk  (0 in the padding);  wk_part[tile] = sum over the tile of
+// 1/2 (alpha_j alpha_k - Kinv_jk) kf_jk  (kf = kernel value without noise).  ntiles = (Np/128)^2 partials.
+void launch_nll_weight(hipStream_t s, const double* XT, long ld, int Dp, const double* nx, int Np, int N, KernelSpec ks,
+                       const double* alpha, const double* Kinv, double* G, double* wk_part);
+// out[0] = sum_t part[t] (fixed order);  out[1] = 1/2 (alpha.alpha - tr Kinv);  out[2] = y.alpha
+void launch_nll_scalars(hipStream_t s, const double* part, int nparts, const double* alpha, const double* y,
+                        const double* Kinv, int Np, int N, double* out);
+// gl[p] = 2 * inv_ell[p] * sum_j XT[j,p] * (XT[j,p] * s_j - Y[j,p]),  p < D
+void launch_lengthscale_grad(hipStream_t s, const double* XT, const double* Y, const double* svec, const double* inv_ell,
+                             long ld, int N, int D, double* gl);
 
 }  // namespace slsk

@@ -202,6 +202,38 @@ void launch_finalize(hipStream_t s, const FinalizeArgs& a) {
     hipLaunchKernelGGL(finalize_kernel, dim3((a.S + 255) / 256), dim3(256), 0, s, a);
 }
 
+__global__ __launch_bounds__(256) void combine_kernel(int S, int D, long ld, const double* __restrict__ mu,
+                                                     const double* __restrict__ sigma, const double* __restrict__ dmu,
+                                                     const double* __restrict__ dsigma, int acq, double mu_best, double ucb_h,
+                                                     double* __restrict__ val, double* __restrict__ grad) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= S) return;
+    const double m = mu[n], sg = sigma[n];
+    if (acq == SLS_ACQ_EXPECTED_IMPROVEMENT) {
+        const double diff = m - mu_best;
+        const double u = diff / sg;
+        const double Phi = 0.5 * erfc(-u * 0.70710678118654752440);
+        const double phi = exp(-0.5 * u * u) * 0.39894228040143267794;
+        const double ei = diff * Phi + sg * phi;
+        bool bad = (sg < 1e-10) || isnan(ei);
+        val[n] = bad ? 0.0 : ei;
+        if (grad) {
+            for (int d = 0; d < D && !bad; ++d)
+                if (isnan(Phi * dmu[n + d * ld] + phi * dsigma[n + d * ld])) bad = true;
+            for (int d = 0; d < D; ++d) grad[n + d * ld] = bad ? 0.0 : Phi * dmu[n + d * ld] + phi * dsigma[n + d * ld];
+        }
+    } else {
+        val[n] = m + ucb_h * sg;
+        if (grad)
+            for (int d = 0; d < D; ++d) grad[n + d * ld] = dmu[n + d * ld] + ucb_h * dsigma[n + d * ld];
+    }
+}
+void launch_combine(hipStream_t s, int S, int D, long ld, const double* mu, const double* sigma, const double* dmu,
+                    const double* dsigma, int acq, double mu_best, double ucb_h, double* val, double* grad) {
+    hipLaunchKernelGGL(combine_kernel, dim3((S + 255) / 256), dim3(256), 0, s, S, D, ld, mu, sigma, dmu, dsigma, acq, mu_best,
+                       ucb_h, val, grad);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Lock-step bounded L-BFGS (the oracle's slso_acq_maximize is the same algorithm, statement by
 // statement).  One thread per start; every per-start vector is candidate-major so all accesses coalesce.

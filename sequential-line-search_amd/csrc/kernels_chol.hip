@@ -87,6 +87,15 @@ static GemmDesc mkdesc(const double* A, long lda, const double* B, long ldb, dou
     return g;
 }
 
+void launch_gemm_plain(hipStream_t s, const double* A, long lda, bool a_kc, const double* B, long ldb, bool b_kc, double* C,
+                       long ldc, int mt, int nt, int K, double alpha, double beta) {
+    GemmDesc g = mkdesc(A, lda, B, ldb, C, ldc, mt, nt, K, alpha, beta);
+    if (!a_kc && !b_kc) launch_tri_gemm<false, false>(s, g, 1);
+    else if (!a_kc && b_kc) launch_tri_gemm<false, true>(s, g, 1);
+    else if (a_kc && b_kc) launch_tri_gemm<true, true>(s, g, 1);
+    else launch_tri_gemm<true, false>(s, g, 1);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // diagonal block: Cholesky + inverse, one workgroup of 256 threads, thread (ti, tj) owns the 8x8 block
 // rows 8 ti.., cols 8 tj.. (only ti >= tj work).  LDS: Ls[128*128] (column-major image of L) + broadcast buffers.

@@ -1,0 +1,169 @@
+#include "device.hpp"
+
+#include <cmath>
+#include <cstdlib>
+#include <mutex>
+
+namespace sequential_line_search
+{
+    namespace device
+    {
+        void Check(int rc, const char* what)
+        {
+            if (rc != 0) throw std::runtime_error(std::string(what) + ": " + sls_last_error());
+        }
+
+        sls_ctx* Context()
+        {
+            static sls_ctx*   ctx = nullptr;
+            static std::mutex mtx;
+            std::lock_guard<std::mutex> lock(mtx);
+            if (!ctx)
+            {
+                const char* env = std::getenv("SLS_DEVICE");
+                Check(sls_ctx_create(env ? std::atoi(env) : 0, &ctx), "sls_ctx_create");
+            }
+            return ctx;
+        }
+
+        GpHandle::GpHandle(const Eigen::MatrixXd& X, const Eigen::VectorXd& y, const Eigen::VectorXd& theta, double b, int kernel)
+        {
+            Check(sls_gp_create(Context(), X.data(), static_cast<int>(X.rows()), static_cast<int>(X.cols()), y.data(), theta.data(), b,
+                                kernel, &h),
+                  "sls_gp_create");
+        }
+        GpHandle::~GpHandle() { sls_gp_destroy(h); }
+
+        NllHandle::NllHandle(const Eigen::MatrixXd& X, int kernel)
+        {
+            Check(sls_nll_create(Context(), X.data(), static_cast<int>(X.rows()), static_cast<int>(X.cols()), kernel, &h),
+                  "sls_nll_create");
+        }
+        NllHandle::~NllHandle() { sls_nll_destroy(h); }
+    } // namespace device
+
+    namespace optim
+    {
+        std::vector<double> MaximizeBounded(const Objective& f, std::vector<double> x, const std::vector<double>& lo,
+                                            const std::vector<double>& hi, int max_evals, double* best_value)
+        {
+            const size_t n = x.size();
+            const int    m = 8;
+            auto clampv = [&](std::vector<double>& v) {
+                for (size_t i = 0; i < n; ++i) v[i] = std::min(hi[i], std::max(lo[i], v[i]));
+            };
+            clampv(x);
+            std::vector<double> g(n), gt(n), xt(n), d(n), pg(n);
+            // minimise phi = -f
+            int    evals = 0;
+            double fx    = -f(x, &g);
+            ++evals;
+            for (auto& v : g) v = -v;
+            std::vector<std::vector<double>> S, Y;
+            std::vector<double>              rho;
+            while (evals < max_evals)
+            {
+                double pgmax = 0.0, pgn2 = 0.0;
+                for (size_t i = 0; i < n; ++i)
+                {
+                    double v = g[i];
+                    if ((x[i] <= lo[i] && v > 0.0) || (x[i] >= hi[i] && v < 0.0)) v = 0.0;
+                    pg[i] = v;
+                    pgmax = std::max(pgmax, std::fabs(v));
+                    pgn2 += v * v;
+                }
+                if (!(pgmax > 0.0)) break;
+                d = pg;
+                std::vector<double> al(S.size());
+                for (int h = static_cast<int>(S.size()) - 1; h >= 0; --h)
+                {
+                    double dot = 0.0;
+                    for (size_t i = 0; i < n; ++i) dot += S[h][i] * d[i];
+                    al[h] = rho[h] * dot;
+                    for (size_t i = 0; i < n; ++i) d[i] -= al[h] * Y[h][i];
+                }
+                double gamma = 1.0 / std::max(1.0, std::sqrt(pgn2));
+                if (!S.empty())
+                {
+                    double sy = 0.0, yy = 0.0;
+                    for (size_t i = 0; i < n; ++i)
+                    {
+                        sy += S.back()[i] * Y.back()[i];
+                        yy += Y.back()[i] * Y.back()[i];
+                    }
+                    gamma = sy / yy;
+                }
+                for (auto& v : d) v *= gamma;
+                for (size_t h = 0; h < S.size(); ++h)
+                {
+                    double dot = 0.0;
+                    for (size_t i = 0; i < n; ++i) dot += Y[h][i] * d[i];
+                    const double beta = rho[h] * dot;
+                    for (size_t i = 0; i < n; ++i) d[i] += S[h][i] * (al[h] - beta);
+                }
+                double gd = 0.0;
+                for (size_t i = 0; i < n; ++i)
+                {
+                    d[i] = (pg[i] == 0.0) ? 0.0 : -d[i];
+                    gd += pg[i] * d[i];
+                }
+                if (!(gd < 0.0))
+                {
+                    S.clear(); Y.clear(); rho.clear();
+                    gamma = 1.0 / std::max(1.0, std::sqrt(pgn2));
+                    gd    = 0.0;
+                    for (size_t i = 0; i < n; ++i)
+                    {
+                        d[i] = -gamma * pg[i];
+                        gd += pg[i] * d[i];
+                    }
+                    if (!(gd < 0.0)) break;
+                }
+                double t        = 1.0;
+                bool   accepted = false;
+                for (int bt = 0; bt <= 30 && evals < max_evals; ++bt)
+                {
+                    for (size_t i = 0; i < n; ++i) xt[i] = x[i] + t * d[i];
+                    clampv(xt);
+                    double ss = 0.0, gs = 0.0;
+                    for (size_t i = 0; i < n; ++i)
+                    {
+                        ss += (xt[i] - x[i]) * (xt[i] - x[i]);
+                        gs += g[i] * (xt[i] - x[i]);
+                    }
+                    if (ss == 0.0) break;
+                    const double ft = -f(xt, &gt);
+                    ++evals;
+                    for (auto& v : gt) v = -v;
+                    if (std::isfinite(ft) && ft <= fx + 1e-4 * gs)
+                    {
+                        std::vector<double> s(n), y(n);
+                        double              sy = 0.0, yy = 0.0;
+                        for (size_t i = 0; i < n; ++i)
+                        {
+                            s[i] = xt[i] - x[i];
+                            y[i] = gt[i] - g[i];
+                            sy += s[i] * y[i];
+                            yy += y[i] * y[i];
+                        }
+                        if (sy > 1e-10 * yy && sy > 0.0)
+                        {
+                            if (static_cast<int>(S.size()) == m)
+                            {
+                                S.erase(S.begin()); Y.erase(Y.begin()); rho.erase(rho.begin());
+                            }
+                            S.push_back(s); Y.push_back(y); rho.push_back(1.0 / sy);
+                        }
+                        x = xt; g = gt; fx = ft;
+                        accepted = true;
+                        break;
+                    }
+                    t *= 0.5;
+                }
+                if (!accepted) break;
+            }
+            if (best_value) *best_value = -fx;
+            return x;
+        }
+    } // namespace optim
+} // namespace sequential_line_search

@@ -1,0 +1,52 @@
+// Host-side RAII over the C ABI (include/sls_hip.h): process-wide context, GP and MAP-objective handles.
+#pragma once
+#include <sls_hip.h>
+
+#include <sequential-line-search/eigen-lite.hpp>
+#include <functional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace sequential_line_search
+{
+    namespace device
+    {
+        /// Throws std::runtime_error carrying sls_last_error() when rc != 0 (the reference never returns error codes; a
+        /// missing GPU or a non-SPD matrix must not be silent).
+        void Check(int rc, const char* what);
+
+        /// Lazily created context on device $SLS_DEVICE (default 0).
+        sls_ctx* Context();
+
+        struct GpHandle
+        {
+            sls_gp* h = nullptr;
+            GpHandle(const Eigen::MatrixXd& X, const Eigen::VectorXd& y, const Eigen::VectorXd& theta, double b, int kernel);
+            ~GpHandle();
+            GpHandle(const GpHandle&)            = delete;
+            GpHandle& operator=(const GpHandle&) = delete;
+        };
+
+        struct NllHandle
+        {
+            sls_nll* h = nullptr;
+            NllHandle(const Eigen::MatrixXd& X, int kernel);
+            ~NllHandle();
+            NllHandle(const NllHandle&)            = delete;
+            NllHandle& operator=(const NllHandle&) = delete;
+        };
+    } // namespace device
+
+    namespace optim
+    {
+        /// value = f(x), and the gradient into `grad` when grad != nullptr.
+        using Objective = std::function<double(const std::vector<double>& x, std::vector<double>* grad)>;
+
+        /// Bounded L-BFGS MAXIMISER (projected gradient, Armijo backtracking, m = 8), at most max_evals objective
+        /// evaluations.  Stand-in for nloptutil::solve(..., LD_LBFGS / LD_TNEWTON, ..., is_max = true, max_evals):
+        /// NLopt is not available, so iterates differ from the reference while the optimum is the same.
+        std::vector<double> MaximizeBounded(const Objective& f, std::vector<double> x0, const std::vector<double>& lower,
+                                            const std::vector<double>& upper, int max_evals, double* best_value = nullptr);
+    } // namespace optim
+} // namespace sequential_line_search

@@ -1,0 +1,124 @@
+// GaussianProcessRegressor over the C ABI (reference: src/gaussian-process-regressor.cpp).
+#include <cmath>
+#include <sequential-line-search/gaussian-process-regressor.hpp>
+
+#include "device.hpp"
+
+using Eigen::MatrixXd;
+using Eigen::VectorXd;
+
+namespace sequential_line_search
+{
+    bool GaussianProcessRegressor::s_materialize_matrices = true;
+
+    namespace
+    {
+        int KernelId(KernelType t) { return t == KernelType::ArdSquaredExponentialKernel ? SLS_KERNEL_ARD_SQUARED_EXPONENTIAL : SLS_KERNEL_ARD_MATERN52; }
+    }
+
+    // reference: src/gaussian-process-regressor.cpp:198-212
+    GaussianProcessRegressor::GaussianProcessRegressor(const MatrixXd& X, const VectorXd& y, const KernelType kernel_type)
+        : Regressor(kernel_type), m_X(X), m_y(y), m_noise_hyperparam(0.0)
+    {
+        if (X.rows() == 0) return;   // inert object, like the reference
+        PerformMapEstimation();
+        BuildDeviceState();
+    }
+
+    // reference: src/gaussian-process-regressor.cpp:214-232
+    GaussianProcessRegressor::GaussianProcessRegressor(const MatrixXd& X, const VectorXd& y, const VectorXd& kernel_hyperparams,
+                                                       double noise_hyperparam, const KernelType kernel_type)
+        : Regressor(kernel_type), m_X(X), m_y(y), m_kernel_hyperparams(kernel_hyperparams), m_noise_hyperparam(noise_hyperparam)
+    {
+        if (X.rows() == 0) return;
+        BuildDeviceState();
+    }
+
+    void GaussianProcessRegressor::BuildDeviceState()
+    {
+        m_handle = std::make_shared<device::GpHandle>(m_X, m_y, m_kernel_hyperparams, m_noise_hyperparam, KernelId(m_kernel_type));
+        if (s_materialize_matrices)
+        {
+            const long N = m_X.cols();
+            m_K_y        = MatrixXd(N, N);
+            m_K_y_inv    = MatrixXd(N, N);
+            device::Check(sls_gp_get_matrix(m_handle->h, SLS_GP_K_Y, m_K_y.data()), "sls_gp_get_matrix(K_y)");
+            device::Check(sls_gp_get_matrix(m_handle->h, SLS_GP_K_Y_INV, m_K_y_inv.data()), "sls_gp_get_matrix(K_y_inv)");
+        }
+    }
+
+    sls_gp* GaussianProcessRegressor::GetDeviceHandle() const { return m_handle ? m_handle->h : nullptr; }
+
+    // reference: src/gaussian-process-regressor.cpp:234-272 -- single-point forms of the batched device evaluation
+    double GaussianProcessRegressor::PredictMu(const VectorXd& x) const
+    {
+        double mu = 0.0;
+        device::Check(sls_gp_predict(m_handle->h, x.data(), 1, &mu, nullptr), "sls_gp_predict");
+        return mu;
+    }
+    double GaussianProcessRegressor::PredictSigma(const VectorXd& x) const
+    {
+        double sigma = 0.0;
+        device::Check(sls_gp_predict(m_handle->h, x.data(), 1, nullptr, &sigma), "sls_gp_predict");
+        return sigma;
+    }
+    VectorXd GaussianProcessRegressor::PredictMuDerivative(const VectorXd& x) const
+    {
+        VectorXd g(x.size());
+        device::Check(sls_gp_predict_grad(m_handle->h, x.data(), 1, g.data(), nullptr), "sls_gp_predict_grad");
+        return g;
+    }
+    VectorXd GaussianProcessRegressor::PredictSigmaDerivative(const VectorXd& x) const
+    {
+        VectorXd g(x.size());
+        device::Check(sls_gp_predict_grad(m_handle->h, x.data(), 1, nullptr, g.data()), "sls_gp_predict_grad");
+        return g;
+    }
+
+    // reference: src/gaussian-process-regressor.cpp:274-299.  Objective + gradient on the device (sls_gp_nll_grad);
+    // the reference's DIRECT(300) -> TNEWTON(1000) drivers are replaced by a coarse log-grid scan + bounded L-BFGS in
+    // log-parameters (same bounds [1e-8, 50]; NLopt is unavailable, iterates are not comparable, the optimum is).
+    void GaussianProcessRegressor::PerformMapEstimation()
+    {
+        const int         D = static_cast<int>(m_X.rows());
+        device::NllHandle nll(m_X, KernelId(m_kernel_type));
+        const double      lo = std::log(1e-8), hi = std::log(5e+01);
+
+        auto objective = [&](const std::vector<double>& z, std::vector<double>* grad) -> double {
+            std::vector<double> x(z.size()), g(z.size());
+            for (size_t i = 0; i < z.size(); ++i) x[i] = std::exp(z[i]);
+            double    v  = 0.0;
+            const int rc = sls_gp_nll_grad(nll.h, m_y.data(), x.data(), &v, grad ? g.data() : nullptr);
+            if (rc == SLS_ERR_NOT_SPD) return -HUGE_VAL;   // numerically singular K_y: reject the trial point
+            device::Check(rc, "sls_gp_nll_grad");
+            if (grad)
+            {
+                grad->resize(z.size());
+                for (size_t i = 0; i < z.size(); ++i) (*grad)[i] = g[i] * x[i];   // d/d log x
+            }
+            return v;
+        };
+
+        // global phase: prior medians (the reference's x_ini) and an isotropic log grid
+        std::vector<double> best(D + 2);
+        best[0] = std::log(0.5); best[1] = std::log(1e-4);
+        for (int d = 0; d < D; ++d) best[2 + d] = std::log(0.5);
+        double best_v = objective(best, nullptr);
+        for (double a : {0.1, 0.5, 2.0})
+            for (double b : {1e-5, 1e-3, 1e-1})
+                for (double r : {0.05, 0.15, 0.5, 1.5})
+                {
+                    std::vector<double> z(D + 2, std::log(r));
+                    z[0] = std::log(a); z[1] = std::log(b);
+                    const double v = objective(z, nullptr);
+                    if (v > best_v) { best_v = v; best = z; }
+                }
+        const std::vector<double> lower(D + 2, lo), upper(D + 2, hi);
+        const std::vector<double> z = optim::MaximizeBounded(objective, best, lower, upper, 200);
+
+        m_kernel_hyperparams    = VectorXd(D + 1);
+        m_kernel_hyperparams(0) = std::exp(z[0]);
+        m_noise_hyperparam      = std::exp(z[1]);
+        for (int d = 0; d < D; ++d) m_kernel_hyperparams(1 + d) = std::exp(z[2 + d]);
+    }
+} // namespace sequential_line_search

@@ -199,3 +199,73 @@ def test_invalid_arguments(ctx):
         m.GP(ctx, np.zeros((2, 3)), np.zeros(3), [0.5, -1.0, 0.5], 0.01)
     with pytest.raises(m.SlsError):
         m.GP(ctx, np.zeros((2, 3)), np.zeros(3), [0.5, 0.5, 0.5], 0.01, kernel=7)
+
+
+# ---- MAP objectives ------------------------------------------------------------
+
+def test_gp_map_objective_against_mpmath_and_oracle(ctx, oracle, fixtures):
+    for c in fixtures["gp_map"]:                      # independent 50-digit values
+        h = sls().Nll(ctx, np.array(c["X"]), c["kernel"])
+        v, g = h.gp_objective(c["y"], c["x"])
+        close(v, c["value"], rtol=1e-9)
+        close(g, c["grad"], rtol=1e-6, atol=1e-7)
+        close(h.gp_objective(c["y"], c["x"], want_grad=False), v, rtol=0)
+        h.close()
+    for kernel in (0, 1):                             # the reference's tensor + trace formulation, larger N
+        D, N = 7, 200
+        X, y, theta, b = synth_problem(oracle, D, N)
+        x = np.concatenate([[0.6, 0.01], np.linspace(0.35, 0.8, D)])
+        vo, go = oracle.gp_map_objective(kernel, X, y, x, as_written=True)
+        h = sls().Nll(ctx, X, kernel)
+        v, g = h.gp_objective(y, x)
+        close(v, vo, rtol=1e-9)
+        close(g, go, rtol=RTOL, atol=1e-6 * np.abs(go).max())
+        h.close()
+
+
+@pytest.mark.parametrize("kernel", [0, 1])
+@pytest.mark.parametrize("use_map", [False, True])
+def test_preference_objective(ctx, oracle, fixtures, kernel, use_map):
+    for c in fixtures["pref_objective"]:
+        if c["kernel"] != kernel or c["use_map"] != use_map:
+            continue
+        h = sls().Nll(ctx, np.array(c["X"]), kernel)
+        v, g = h.pref_objective(c["prefs"], c["x"], use_map=use_map)
+        close(v, c["value"], rtol=1e-9)
+        close(g, c["grad"], rtol=1e-6, atol=1e-6)
+        h.close()
+    # sequential-line-search style data: M points, one preference tuple per "slider" observation
+    rng = np.random.default_rng(7)
+    D, M = 6, 45
+    X = rng.uniform(0, 1, (D, M))
+    prefs = [[3 * i, 3 * i + 1, 3 * i + 2] for i in range(M // 3)]
+    yv = rng.normal(0, 0.02, M)
+    x = np.concatenate([yv, [0.45, 0.004], rng.uniform(0.4, 0.6, D)]) if use_map else yv
+    vo, go = oracle.pref_objective(kernel, X, prefs, x, use_map=use_map)
+    h = sls().Nll(ctx, X, kernel)
+    v, g = h.pref_objective(prefs, x, use_map=use_map)
+    close(v, vo, rtol=1e-9)
+    close(g, go, rtol=RTOL, atol=1e-6 * np.abs(go).max())
+    # cached factorisation path (same theta, new y) must agree with a fresh handle
+    x2 = x.copy(); x2[:M] += 0.001
+    v2, g2 = h.pref_objective(prefs, x2, use_map=use_map)
+    vo2, go2 = oracle.pref_objective(kernel, X, prefs, x2, use_map=use_map)
+    close(v2, vo2, rtol=1e-9)
+    close(g2, go2, rtol=RTOL, atol=1e-6 * np.abs(go2).max())
+    h.close()
+
+
+def test_nll_core_terms(ctx, oracle):
+    D, N = 5, 150
+    X, y, theta, b = synth_problem(oracle, D, N)
+    K = oracle.calc_large_ky(1, X, theta, b)
+    L, _ = oracle.cholesky(K)
+    h = sls().Nll(ctx, X, 1)
+    r = h.eval(y, theta, b)
+    al = oracle.chol_solve(L, y)
+    close(r["alpha"], al, rtol=1e-7, atol=1e-9)
+    close(r["quad"], y @ al, rtol=1e-9)
+    close(r["logdet"], oracle.logdet_from_chol(L), rtol=1e-10)
+    Kinv = oracle.spd_inverse_from_chol(L)
+    close(r["grad_b"], 0.5 * (al @ al - np.trace(Kinv)), rtol=1e-7)
+    h.close()
