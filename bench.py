@@ -99,9 +99,8 @@ def main():
     sls = importlib.import_module("sequential-line-search_amd")
     kernel_id = sls.KERNEL_MATERN52 if args.kernel == "matern52" else sls.KERNEL_SE
     D, N, S = args.d, args.n, args.starts
-    assert S % world == 0, "starts must divide over the ranks"
-    S_loc = S // world
-    lo = rank * S_loc
+    lo, hi = sls.shard_range(S, rank, world)
+    S_loc = hi - lo
 
     X, y, theta, b, starts = synth(D, N, S)
     ctx = sls.Context(local_rank)
@@ -112,17 +111,12 @@ def main():
     y_dev = torch.from_numpy(y).to(dev)
     starts_dev = torch.from_numpy(np.ascontiguousarray(starts[:, lo:lo + S_loc].T)).to(dev)
     gp = sls.GP(ctx, X, y, theta, b, kernel_id)
-    gather = torch.empty((world, D + 2), dtype=torch.float64, device=dev)
-    mine = torch.empty(D + 2, dtype=torch.float64, device=dev)
 
     def step():
         gp.refit_dev(X_dev.data_ptr(), y_dev.data_ptr())
         r = gp.acq_maximize_dev(starts_dev.data_ptr(), S_loc, args.n_local, sls.ACQ_EI, 1.0, offset=lo)
         if world > 1:
-            mine.copy_(torch.from_numpy(np.concatenate([[r["value"], float(r["index"])], r["x"]])))
-            dist.all_gather_into_tensor(gather, mine)          # the single RCCL exchange of the step
-            g = gather.cpu().numpy()
-            v, i, x = sls.merge_rank_results((row[0], int(row[1]), row[2:]) for row in g)
+            v, i, x = sls.exchange_best(r["value"], r["index"], r["x"], device=dev)   # the single RCCL exchange of the step
             return dict(value=v, index=i, x=x)
         return r
 

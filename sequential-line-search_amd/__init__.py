@@ -289,3 +289,27 @@ def merge_rank_results(results):
         if best is None or v > best[0] or (v == best[0] and i < best[1]):
             best = (float(v), int(i), np.asarray(x, dtype=np.float64))
     return best
+
+
+def shard_range(n_starts, rank, world):
+    """Contiguous slice [lo, hi) of the global start set owned by `rank` (the last ranks get the remainder-free part)."""
+    base, rem = divmod(int(n_starts), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def exchange_best(value, index, x, device=None, group=None):
+    """The single collective of a multi-GPU maximisation: all-gather (value, global index, x[D]) over the ranks of a
+    torch.distributed group (RCCL on GPUs, gloo on CPU) and take the first maximum on every rank.
+    Returns (value, index, x) -- identical on all ranks.  The global index travels as float64 (exact below 2**53)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    x = np.asarray(x, dtype=np.float64)
+    mine = torch.from_numpy(np.concatenate([[float(value), float(index)], x]))
+    if device is not None:
+        mine = mine.to(device)
+    gathered = torch.empty(world * mine.numel(), dtype=torch.float64, device=mine.device)
+    dist.all_gather_into_tensor(gathered, mine, group=group)
+    g = gathered.cpu().numpy().reshape(world, mine.numel())
+    return merge_rank_results((row[0], int(row[1]), row[2:]) for row in g)
