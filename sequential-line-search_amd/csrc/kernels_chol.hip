@@ -97,137 +97,227 @@ void launch_gemm_plain(hipStream_t s, const double* A, long lda, bool a_kc, cons
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// diagonal block: Cholesky + inverse, one workgroup of 256 threads, thread (ti, tj) owns the 8x8 block
-// rows 8 ti.., cols 8 tj.. (only ti >= tj work).  LDS: Ls[128*128] (column-major image of L) + broadcast buffers.
+// Diagonal block: Cholesky + inverse of one 128x128 block by ONE workgroup (4 waves), matrix resident in LDS.
+//   LDS: As[128 x 144] (column-major, ld 144 -> MFMA fragment reads conflict-free) + Ts[8][16 x 16] = exactly 160 KiB.
+//   Phase 1 (factor), per 16-column panel:  wave 0 factors the 16x16 diagonal tile in registers (lane = row, pivots and
+//     columns broadcast with wave shuffles) and inverts it; all waves then form the panel L = A T16^T and the trailing
+//     update A_ij -= L_i L_j^T with v_mfma_f64_16x16x4 on 16x16 tiles read straight from LDS.
+//   Phase 2 (inverse, in place, right-to-left block columns):  X[:,j] = -(X[:,j+1:] L[j+1:,j]) T_j, again MFMA tiles.
+// The serial chain is 128 pivot steps of ~one sqrt + one shuffle each instead of 256 barrier-separated steps.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int DIAG_LDS_BYTES = (128 * 128 + 2 * 128 + 2 * 128) * 8;
+constexpr int DL = 144;
+constexpr int DIAG_LDS_BYTES = (128 * DL + 8 * 256) * 8;   // 163840
+
+__device__ __forceinline__ d4_t mfma16(double bfrag, double afrag, d4_t acc) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(bfrag, afrag, acc, 0, 0, 0);
+}
+
+// value of lane k (compile-time constant after unrolling) in every lane: v_readlane into SGPRs, a few cycles instead of the
+// ~100-cycle ds_bpermute behind __shfl -- this broadcast sits on the serial pivot chain
+__device__ __forceinline__ double bcast(double x, int k) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), k);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), k);
+    return __hiloint2double(hi, lo);
+}
+
+// 16x16 diagonal tile at (c0, c0): optional in-register Cholesky, then inverse.  Executed by one full wave; lane & 15 = row.
+// 1/sqrt(d) to full fp64 accuracy: hardware v_rsq_f64 seed (~2^-26) + two Newton steps on the residual (the
+// correctly-rounded sqrt()/division pair of the math library costs ~350 dependent cycles on the pivot chain, this ~80)
+__device__ __forceinline__ double rsqrt_nr(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double e = fma(-d * y, y, 1.0);          // 1 - d y^2
+        y = fma(y * e, fma(0.375, e, 0.5), y);          // y (1 + e/2 + 3 e^2/8)
+    }
+    return y;
+}
+
+template <bool FACTOR>
+__device__ __forceinline__ void diag16(double* As, double* Tk, int c0, int lane, int* info, int global_off) {
+    const int row = lane & 15;
+    double a[16], b[16], dinv[16];
+    double own_inv = 1.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a[j] = As[c0 + row + (c0 + j) * DL];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const double d = bcast(a[k], k);
+        if (FACTOR) {
+            if (!(d > 0.0) && lane == 0 && info) atomicCAS(info, 0, global_off + c0 + k + 1);
+            const double inv = rsqrt_nr(d);
+            dinv[k] = inv;
+            const double lik = a[k] * inv;   // lane k: d * rsqrt(d) = L_kk; rows < k hold unused upper-triangle values
+            a[k] = lik;
+#pragma unroll
+            for (int j = k + 1; j < 16; ++j) a[j] -= lik * bcast(lik, j);
+        } else {
+            dinv[k] = 1.0 / d;
+        }
+        own_inv = (row == k) ? dinv[k] : own_inv;
+    }
+    // inverse: B = I; for k: t_k = B[k,:] / L_kk; B[i,:] -= L[i,k] t_k (i > k).  Row k of B is final before step k, so the
+    // scaling of lane k's own row is deferred to the end (no per-element select on the chain).
+#pragma unroll
+    for (int j = 0; j < 16; ++j) b[j] = (row == j) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const double ck = (row > k) ? a[k] : 0.0;
+#pragma unroll
+        for (int j = 0; j <= k; ++j) b[j] = fma(-ck, bcast(b[j], k) * dinv[k], b[j]);
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (FACTOR) As[c0 + row + (c0 + j) * DL] = (j <= row) ? a[j] : 0.0;
+            Tk[row + 16 * j] = (j <= row) ? b[j] * own_inv : 0.0;
+        }
+    }
+}
 
 template <bool FACTOR>
 __global__ __launch_bounds__(256) void chol_diag_kernel(double* __restrict__ A, long lda, double* __restrict__ Tout, long ldt,
                                                         int* __restrict__ info, int global_off) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* Ls = reinterpret_cast<double*>(smem);          // [i + 128 j]
-    double* colbuf = Ls + 128 * 128;                       // [2][128]
-    double* rowbuf = colbuf + 2 * 128;                     // [2][128]
-    const int tid = threadIdx.x;
-    const int ti = tid & 15, tj = tid >> 4;
-    const bool active = ti >= tj;
+    double* As = reinterpret_cast<double*>(smem);   // [i + j*DL]
+    double* Ts = As + 128 * DL;                     // [tile][i + 16 j]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fl = lane & 15, fk = lane >> 4;       // fragment index / k sub-index
 
-    if (FACTOR) {
-        double a[8][8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-#pragma unroll
-            for (int r = 0; r < 8; ++r) a[r][c] = active ? A[(long)(8 * ti + r) + (long)(8 * tj + c) * lda] : 0.0;
-        int cur = 0;
-        for (int kb = 0; kb < 16; ++kb) {
-#pragma unroll
-            for (int kc = 0; kc < 8; ++kc) {
-                const int k = 8 * kb + kc;
-                double* cb = colbuf + cur * 128;
-                if (tj == kb && active) {
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) cb[8 * ti + r] = a[r][kc];
-                }
-                __syncthreads();
-                const double dkk = cb[k];
-                if (!(dkk > 0.0) && tid == 0) {
-                    if (atomicCAS(info, 0, global_off + k + 1) == 0) {}
-                }
-                const double lkk = sqrt(dkk);
-                const double inv = 1.0 / lkk;
-                if (active && tj >= kb) {
-                    double li[8], lj[8];
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) li[r] = cb[8 * ti + r] * inv;
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) lj[c] = cb[8 * tj + c] * inv;
-                    if (tj == kb) {
-                        // finalise column k of L (rows >= k)
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) {
-                            const int i = 8 * ti + r;
-                            if (i > k) a[r][kc] = li[r];
-                            else if (i == k) a[r][kc] = lkk;
-                        }
-                    }
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        if (tj > kb || c > kc) {
-#pragma unroll
-                            for (int r = 0; r < 8; ++r) a[r][c] -= li[r] * lj[c];
-                        }
-                    }
-                }
-                cur ^= 1;
-            }
+#ifdef SLS_DIAG_TIMING
+#define DIAG_STAMP(slot) do { if (tid == 0 && info) ((long long*)info)[slot] = clock64(); } while (0)
+#else
+#define DIAG_STAMP(slot) do {} while (0)
+#endif
+    DIAG_STAMP(1);
+    {   // thread -> (row pair, column): 64 threads cover one column with 16-byte loads, 4 columns per pass
+        const int i2 = 2 * (tid & 63), jc = tid >> 6;
+#pragma unroll 8
+        for (int p = 0; p < 32; ++p) {
+            const int j = 4 * p + jc;
+            d2_t v = *reinterpret_cast<const d2_t*>(A + (long)i2 + (long)j * lda);
+            if ((i2 >> 4) < (j >> 4)) v = d2_t{0.0, 0.0};
+            *reinterpret_cast<d2_t*>(As + i2 + j * DL) = v;
         }
-        // write L (lower; strict upper of the diagonal block zeroed) to LDS image and global
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int i = 8 * ti + r, j = 8 * tj + c;
-                const double v = (i >= j) ? a[r][c] : 0.0;
-                Ls[i + 128 * j] = v;
-                A[(long)i + (long)j * lda] = v;
-            }
-    } else {
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int i = 8 * ti + r, j = 8 * tj + c;
-                Ls[i + 128 * j] = (i >= j) ? A[(long)i + (long)j * lda] : 0.0;
-            }
     }
     __syncthreads();
+    DIAG_STAMP(2);
 
-    // inverse by forward substitution on the identity: B = I; for k: T[k,:] = B[k,:]/L_kk; B[i,:] -= L[i,k] T[k,:]
-    double b[8][8];
+    // ---------------- phase 1: factor (FACTOR) / diagonal-tile inverses only (!FACTOR) ----------------
+    for (int kb = 0; kb < 8; ++kb) {
+        const int c0 = 16 * kb;
+#ifdef SLS_DIAG_TIMING
+        long long t_a = clock64();
+#endif
+        if (wave == 0) diag16<FACTOR>(As, Ts + 256 * kb, c0, lane, info, global_off);
+        if (!FACTOR) continue;
+        __syncthreads();
+#ifdef SLS_DIAG_TIMING
+        if (tid == 0 && kb == 0 && info) ((long long*)info)[7] = clock64() - t_a;
+#endif
+        const double* Tk = Ts + 256 * kb;
+        // panel: L_r = A_r T16^T for tile rows r > kb
+        for (int r = kb + 1 + wave; r < 8; r += 4) {
+            d4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int c = 0; c < 8; ++c)
-#pragma unroll
-        for (int r = 0; r < 8; ++r) b[r][c] = (ti == tj && r == c) ? 1.0 : 0.0;
-    int cur = 0;
-    for (int kb = 0; kb < 16; ++kb) {
-#pragma unroll
-        for (int kc = 0; kc < 8; ++kc) {
-            const int k = 8 * kb + kc;
-            double* rb = rowbuf + cur * 128;
-            if (ti == kb) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) rb[8 * tj + c] = b[kc][c];
+            for (int kk = 0; kk < 4; ++kk) {
+                const int k = 4 * kk + fk;
+                const double af = As[(c0 + k) * DL + 16 * r + fl];   // A_r[m = fl][k]
+                const double bf = Tk[fl + 16 * k];                    // T[n = fl][k]
+                acc = mfma16(bf, af, acc);
             }
-            __syncthreads();
-            const double inv = 1.0 / Ls[k + 128 * k];
-            double tk[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) tk[c] = rb[8 * tj + c] * inv;
-            if (ti == kb) {
+            for (int q = 0; q < 4; ++q) As[(c0 + fk + 4 * q) * DL + 16 * r + fl] = acc[q];
+        }
+        __syncthreads();
+        // trailing update: A_ij -= L_i L_j^T for 7 >= i >= j > kb, tiles dealt round-robin to the waves
+        int t = 0;
+        for (int j = kb + 1; j < 8; ++j)
+            for (int i = j; i < 8; ++i, ++t) {
+                if ((t & 3) != wave) continue;
+                d4_t acc;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) b[kc][c] = tk[c];
-            }
-            if (ti >= kb) {
+                for (int q = 0; q < 4; ++q) acc[q] = As[(16 * j + fk + 4 * q) * DL + 16 * i + fl];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    if (ti > kb || r > kc) {
-                        const double lik = Ls[8 * ti + r + 128 * k];
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) b[r][c] -= lik * tk[c];
-                    }
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int k = c0 + 4 * kk + fk;
+                    const double af = -As[k * DL + 16 * i + fl];
+                    const double bf = As[k * DL + 16 * j + fl];
+                    acc = mfma16(bf, af, acc);
                 }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) As[(16 * j + fk + 4 * q) * DL + 16 * i + fl] = acc[q];
             }
-            cur ^= 1;
+        __syncthreads();
+    }
+    __syncthreads();
+    DIAG_STAMP(3);
+    if (FACTOR) {
+        const int i2 = 2 * (tid & 63), jc = tid >> 6;
+#pragma unroll 8
+        for (int p = 0; p < 32; ++p) {
+            const int j = 4 * p + jc;
+            d2_t v = *reinterpret_cast<const d2_t*>(As + i2 + j * DL);
+            if (i2 < j) v[0] = 0.0;
+            if (i2 + 1 < j) v[1] = 0.0;
+            *reinterpret_cast<d2_t*>(A + (long)i2 + (long)j * lda) = v;
         }
     }
+    DIAG_STAMP(4);
+
+    // ---------------- phase 2: in-place inverse of the strictly-lower tiles, block columns right to left ----------------
+    for (int j = 6; j >= 0; --j) {
+        d4_t acc[2];
+        int nt = 0;
+        for (int i = j + 1 + wave; i < 8; i += 4, ++nt) {
+            d4_t c = {0.0, 0.0, 0.0, 0.0};
+            for (int k = j + 1; k <= i; ++k) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c)
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int i = 8 * ti + r, j = 8 * tj + c;
-            Tout[(long)i + (long)j * ldt] = (i >= j) ? b[r][c] : 0.0;
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int kq = 4 * kk + fk;
+                    // X[i][k] (row m = fl, col kq): inverted tile in As for k < i, diagonal inverse in Ts for k == i
+                    const double af = (k == i) ? Ts[256 * i + fl + 16 * kq] : As[(16 * k + kq) * DL + 16 * i + fl];
+                    const double bf = As[(16 * j + fl) * DL + 16 * k + kq];   // L[k][j] (row kq, col n = fl)
+                    c = mfma16(bf, af, c);
+                }
+            }
+            acc[nt] = c;
         }
+        __syncthreads();
+        nt = 0;
+        for (int i = j + 1 + wave; i < 8; i += 4, ++nt) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) As[(16 * j + fk + 4 * q) * DL + 16 * i + fl] = acc[nt][q];
+        }
+        __syncthreads();
+        for (int i = j + 1 + wave; i < 8; i += 4) {
+            d4_t c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int kq = 4 * kk + fk;
+                const double af = -As[(16 * j + kq) * DL + 16 * i + fl];   // -(tile)[m = fl][kq]
+                const double bf = Ts[256 * j + kq + 16 * fl];              // T_j[kq][n = fl]
+                c = mfma16(bf, af, c);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) As[(16 * j + fk + 4 * q) * DL + 16 * i + fl] = c[q];
+        }
+        __syncthreads();
+    }
+    DIAG_STAMP(5);
+    {
+        const int i2 = 2 * (tid & 63), jc = tid >> 6;
+        const int ti = i2 >> 4;
+#pragma unroll 8
+        for (int p = 0; p < 32; ++p) {
+            const int j = 4 * p + jc, tj = j >> 4;
+            d2_t v = {0.0, 0.0};
+            if (ti > tj) v = *reinterpret_cast<const d2_t*>(As + i2 + j * DL);
+            else if (ti == tj) v = *reinterpret_cast<const d2_t*>(Ts + 256 * ti + (i2 & 15) + 16 * (j & 15));
+            *reinterpret_cast<d2_t*>(Tout + (long)i2 + (long)j * ldt) = v;
+        }
+    }
+    DIAG_STAMP(6);
 }
 
 static void diag_attr() {
@@ -352,16 +442,39 @@ void launch_potrs(hipStream_t s, const double* L, const double* Linv, int Np, do
 // ---------------------------------------------------------------------------------------------------------
 // small helpers
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gemv_n_kernel(const double* __restrict__ A, int Np, const double* __restrict__ x,
-                                                     double* __restrict__ y) {
+// y = A x (A column-major Np x Np): columns split into chunks over blockIdx.y so that the whole chip streams the matrix;
+// the per-chunk partials are summed in a fixed order by a second tiny kernel (deterministic).
+__global__ __launch_bounds__(256) void gemv_n_partial_kernel(const double* __restrict__ A, int Np, const double* __restrict__ x,
+                                                             double* __restrict__ part, int cols_per_chunk) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Np) return;
+    const int j0 = blockIdx.y * cols_per_chunk;
+    double s = 0.0;
+#pragma unroll 4
+    for (int j = j0; j < j0 + cols_per_chunk; ++j) s += A[(long)i + (long)j * Np] * x[j];
+    part[(long)blockIdx.y * Np + i] = s;
+}
+__global__ __launch_bounds__(256) void gemv_n_reduce_kernel(const double* __restrict__ part, int Np, int chunks,
+                                                            double* __restrict__ y) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= Np) return;
     double s = 0.0;
-    for (int j = 0; j < Np; ++j) s += A[(long)i + (long)j * Np] * x[j];
+    for (int c = 0; c < chunks; ++c) s += part[(long)c * Np + i];
     y[i] = s;
 }
 void launch_gemv_n(hipStream_t s, const double* A, int Np, const double* x, double* y) {
-    hipLaunchKernelGGL(gemv_n_kernel, dim3((Np + 255) / 256), dim3(256), 0, s, A, Np, x, y);
+    // scratch for the partials: thread-safe enough for one context per process / stream-ordered reuse
+    static double* part = nullptr;
+    static size_t part_n = 0;
+    const int chunks = Np / 128;                 // 128 columns per chunk
+    const size_t need = (size_t)chunks * Np;
+    if (need > part_n) {
+        if (part) (void)hipFree(part);
+        (void)hipMalloc((void**)&part, need * sizeof(double));
+        part_n = need;
+    }
+    hipLaunchKernelGGL(gemv_n_partial_kernel, dim3((Np + 255) / 256, chunks), dim3(256), 0, s, A, Np, x, part, 128);
+    hipLaunchKernelGGL(gemv_n_reduce_kernel, dim3((Np + 255) / 256), dim3(256), 0, s, part, Np, chunks, y);
 }
 
 // y_j = sum_i A[i,j] x_i : one wave per column, wave-shuffle reduction

@@ -1,5 +1,5 @@
 import sys, numpy as np
-sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.join(R, "tests")); sys.path.insert(0, R)
 from util import sls, synth_problem, synth_candidates
 from oracle import oracle_py as oracle
 D, N, S, n_local = 5, 120, 96, 25
