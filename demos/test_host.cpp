@@ -6,6 +6,7 @@
 #include <sequential-line-search/gaussian-process-regressor.hpp>
 #include <sequential-line-search/preference-data-manager.hpp>
 #include <sequential-line-search/preference-regressor.hpp>
+#include <sequential-line-search/preferential-bayesian-optimizer.hpp>
 #include <sequential-line-search/sequential-line-search.hpp>
 #include <sequential-line-search/slider.hpp>
 #include <sequential-line-search/utils.hpp>
@@ -206,6 +207,35 @@ int main()
         const auto pts = acquisition_func::FindNextPoints(fixed, 3, 32, 20);
         EXPECT(pts.size() == 3);
         EXPECT((pts[0] - pts[1]).norm() > 1e-3 && (pts[1] - pts[2]).norm() > 1e-3);   // variance update pushes the batch apart
+    }
+    // ---- preferential Bayesian optimisation (pairwise comparison) on the bump objective ----
+    {
+        const int D = 3;
+        utils::SetRandomSeed(11);
+        PreferentialBayesianOptimizer pbo(D, false);
+        pbo.SetHyperparams(0.5, 0.5, 0.001, 0.1, 0.01);
+        auto objective = [](const VectorXd& x) {
+            double qd = 0.0;
+            for (long i = 0; i < x.size(); ++i) qd += (x(i) - 0.4) * (x(i) - 0.4);
+            return std::exp(-qd);
+        };
+        double first = -1.0, last = -1.0;
+        for (int it = 0; it < 10; ++it)
+        {
+            const auto& opts = pbo.GetCurrentOptions();
+            EXPECT(opts.size() == 2);
+            const int choice = objective(opts[0]) >= objective(opts[1]) ? 0 : 1;
+            pbo.SubmitFeedbackData(choice);
+            pbo.DetermineNextQuery(64, 20);
+            const double v = objective(pbo.GetMaximizer());
+            if (it == 0) first = v;
+            last = v;
+            for (const VectorXd& o : pbo.GetCurrentOptions())
+                for (long d = 0; d < o.size(); ++d) EXPECT(o(d) >= 0.0 && o(d) <= 1.0);
+        }
+        std::cout << "PBO D=3: objective at maximiser " << first << " -> " << last << std::endl;
+        EXPECT(last >= first - 1e-9);
+        EXPECT(pbo.GetRawDataPoints().cols() >= 10);
     }
     std::cout << (g_fail ? "HOST TESTS FAILED" : "HOST TESTS PASSED") << std::endl;
     return g_fail ? 1 : 0;
