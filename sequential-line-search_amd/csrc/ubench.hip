@@ -122,27 +122,29 @@ static void check_small() {
 }
 
 template <bool A_KC, bool B_KC>
-static void bench_gemm(int M, int N, int K, int group_m, int reps) {
+static void bench_gemm(int M, int N, int K, int group_m, int reps, int pad = 0) {
     double *dA, *dB, *dC;
-    CK(hipMalloc(&dA, (size_t)M * K * 8));
-    CK(hipMalloc(&dB, (size_t)N * K * 8));
-    CK(hipMalloc(&dC, (size_t)M * N * 8));
+    const long lda = (A_KC ? K : M) + pad, ldb = (B_KC ? K : N) + pad, ldc = M + pad;
+    CK(hipMalloc(&dA, (size_t)lda * (A_KC ? M : K) * 8));
+    CK(hipMalloc(&dB, (size_t)ldb * (B_KC ? N : K) * 8));
+    CK(hipMalloc(&dC, (size_t)ldc * N * 8));
     // random fill (uniform [-0.5,0.5)) -- never bench on zeros (DVFS)
     {
         std::vector<double> h((size_t)1 << 22);
         for (auto& v : h) v = frand();
-        for (size_t off = 0; off < (size_t)M * K; off += h.size())
-            CK(hipMemcpy(dA + off, h.data(), std::min(h.size(), (size_t)M * K - off) * 8, hipMemcpyHostToDevice));
-        for (size_t off = 0; off < (size_t)N * K; off += h.size())
-            CK(hipMemcpy(dB + off, h.data(), std::min(h.size(), (size_t)N * K - off) * 8, hipMemcpyHostToDevice));
+        const size_t na = (size_t)lda * (A_KC ? M : K), nb = (size_t)ldb * (B_KC ? N : K);
+        for (size_t off = 0; off < na; off += h.size())
+            CK(hipMemcpy(dA + off, h.data(), std::min(h.size(), na - off) * 8, hipMemcpyHostToDevice));
+        for (size_t off = 0; off < nb; off += h.size())
+            CK(hipMemcpy(dB + off, h.data(), std::min(h.size(), nb - off) * 8, hipMemcpyHostToDevice));
     }
     const int nt = (M / 128) * (N / 128);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     auto launch = [&]() {
-        hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC>), dim3(nt), dim3(256), GEMM_LDS_BYTES, 0, dA,
-                           (long)(A_KC ? K : M), dB, (long)(B_KC ? K : N), dC, (long)M, M, N, K, group_m);
+        hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC>), dim3(nt), dim3(256), GEMM_LDS_BYTES, 0, dA, lda, dB, ldb, dC, ldc, M, N, K,
+                           group_m);
     };
     launch();
     CK(hipDeviceSynchronize());
@@ -153,8 +155,8 @@ static void bench_gemm(int M, int N, int K, int group_m, int reps) {
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
     ms /= reps;
-    printf("gemm A_KC=%d B_KC=%d M=%d N=%d K=%d group_m=%d: %.3f ms  %.2f TFLOP/s\n", (int)A_KC, (int)B_KC, M, N, K,
-           group_m, ms, 2.0 * M * N * K / ms * 1e-9);
+    printf("gemm A_KC=%d B_KC=%d M=%d N=%d K=%d group_m=%d pad=%d: %.3f ms  %.2f TFLOP/s\n", (int)A_KC, (int)B_KC, M, N, K,
+           group_m, pad, ms, 2.0 * M * N * K / ms * 1e-9);
     CK(hipFree(dA));
     CK(hipFree(dB));
     CK(hipFree(dC));
@@ -219,6 +221,10 @@ int main(int argc, char** argv) {
     bench_gemm<false, false>(8192, 8192, 8192, 8, 3);
     bench_gemm<true, true>(8192, 8192, 8192, 8, 3);
     bench_gemm<false, false>(16384, 8192, 8192, 8, 2);   // acquisition main GEMM, 16k candidates
+    bench_gemm<false, false>(16384, 8192, 8192, 8, 2, 16);
+    bench_gemm<false, false>(16384, 8192, 8192, 8, 2, 32);
+    bench_gemm<false, false>(16384, 8192, 8192, 8, 2, 144);
+    bench_gemm<false, false>(16384, 8192, 8192, 16, 2, 16);
     bench_gemm<false, false>(16384, 8192, 8192, 4, 2);
     bench_gemm<false, false>(16384, 8192, 8192, 16, 2);
     bench_gemm<false, false>(2048, 2048, 2048, 8, 5);
