@@ -97,34 +97,42 @@ __device__ __forceinline__ double frag_read(const double* lds, int mbase, int kk
 
 // Accumulate acc += opA[m0.., kb..ke) * opB[n0.., kb..ke)^T.
 // A, B point at row m0 / n0, k = 0 of their panels.  kb, ke multiples of 16.
+// The k loop starts at slab `kfirst` (kb <= kfirst < ke, multiple of 16) and wraps around at ke: tiles that share an
+// operand panel are started a slab apart so that their global loads of one slab do not miss the L2 simultaneously.
 // `lds` is the 73728-byte, 16-byte aligned dynamic LDS block.
 template <bool A_KC, bool B_KC>
 __device__ __forceinline__ void gemm_tile(Acc& acc, const double* __restrict__ A, long lda,
-                                          const double* __restrict__ B, long ldb, int kb, int ke, double* lds) {
+                                          const double* __restrict__ B, long ldb, int kb, int ke, double* lds,
+                                          int kfirst = -1) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = (wave & 1) * 64;   // wave's m offset inside the tile
     const int wn = (wave >> 1) * 64;  // wave's n offset
     if (kb >= ke) return;
+    if (kfirst < kb || kfirst >= ke) kfirst = kb;
 
     // NOTE: LDS buffers are selected by integer offset from the one LDS base pointer.  Selecting between
     // pointers (double* buf[2]) makes hipcc lose the LDS address space and emit flat_load/flat_store, whose
     // s_waitcnt vmcnt(0) then drains the global prefetch before every MFMA group (measured: 72 % -> MFMA busy).
     // layout: [A0 | B0 | A1 | B1], each GEMM_LDS_TILE doubles
     Stage sa, sb;
-    stage_load<A_KC>(sa, A, lda, kb, tid);
-    stage_load<B_KC>(sb, B, ldb, kb, tid);
+    stage_load<A_KC>(sa, A, lda, kfirst, tid);
+    stage_load<B_KC>(sb, B, ldb, kfirst, tid);
     stage_store<A_KC>(sa, lds, tid);
     stage_store<B_KC>(sb, lds + GEMM_LDS_TILE, tid);
     __syncthreads();
 
     int cur = 0;   // offset (doubles) of the buffer pair being consumed
-    for (int k0 = kb; k0 < ke; k0 += GEMM_BK) {
-        const bool more = (k0 + GEMM_BK) < ke;
+    int knext = kfirst;
+    const int nslab = (ke - kb) / GEMM_BK;
+    for (int s = 0; s < nslab; ++s) {
+        const bool more = (s + 1) < nslab;
+        knext += GEMM_BK;
+        if (knext >= ke) knext = kb;
         if (more) {
-            stage_load<A_KC>(sa, A, lda, k0 + GEMM_BK, tid);
-            stage_load<B_KC>(sb, B, ldb, k0 + GEMM_BK, tid);
+            stage_load<A_KC>(sa, A, lda, knext, tid);
+            stage_load<B_KC>(sb, B, ldb, knext, tid);
         }
         const double* la = lds + cur;
         const double* lb = lds + cur + GEMM_LDS_TILE;

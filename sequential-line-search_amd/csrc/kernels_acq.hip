@@ -34,7 +34,12 @@ __global__ __launch_bounds__(256, 2) void acq_gemm_kernel(const double* __restri
     const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
     Acc acc;
     acc.zero();
-    gemm_tile<false, false>(acc, Ks + m0, ldk, Kinv + n0, (long)Np, 0, Np, lds);
+    // Staggered k start.  The 8 tiles of an XCD's resident 8x8 group that share an operand panel otherwise request every
+    // slab within the same microsecond; the L2 does not merge those misses (hit rate 0.34-0.43, 40-46 GB of fabric reads
+    // per launch).  Starting tile (tm, tn) (tm&7 + tn&7) slabs into the k loop (and wrapping) makes the sharers arrive one
+    // slab-time apart: hit rate 0.67, fabric reads halved, same kernel time (gemm_probe, PMC TCC_HIT/MISS, FETCH_SIZE).
+    const int ks = (Np >= 2048) ? ((tm & 7) + (tn & 7)) * GEMM_BK : 0;
+    gemm_tile<false, false>(acc, Ks + m0, ldk, Kinv + n0, (long)Np, 0, Np, lds, ks);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double skw[4], scw[4];
 #pragma unroll

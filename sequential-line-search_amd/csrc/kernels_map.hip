@@ -13,7 +13,7 @@
 namespace slsk {
 
 template <bool MATERN>
-__global__ __launch_bounds__(256, 2) void nll_weight_kernel(const double* __restrict__ XT, long ld, int Dp,
+__global__ __launch_bounds__(256) void nll_weight_kernel(const double* __restrict__ XT, long ld, int Dp,
                                                             const double* __restrict__ nx, int Np, int N, double a,
                                                             const double* __restrict__ alpha, const double* __restrict__ Kinv,
                                                             double* __restrict__ G, double* __restrict__ wk_part) {

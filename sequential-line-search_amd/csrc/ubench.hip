@@ -13,6 +13,9 @@
 #include "gemm_f64.hpp"
 
 using namespace slsk;
+#ifndef STAGGER
+#define STAGGER 1
+#endif
 
 #define CK(x)                                                                      \
     do {                                                                           \
@@ -68,16 +71,23 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const double* __restrict__
     const int ntm = M / GEMM_BM, ntn = N / GEMM_BN;
     int t = xcd_remap(blockIdx.x, ntm * ntn);
     // grouped order: group_m m-tiles x all n-tiles, n-major inside the group
-    const int gsz = group_m * ntn;
+    const int gmm = group_m < 0 ? -group_m : group_m;
+    const int gsz = gmm * ntn;
     const int g = t / gsz, w = t % gsz;
-    const int gm = min(group_m, ntm - g * group_m);
-    const int tm = g * group_m + (w % gm), tn = w / gm;
+    const int gm = min(gmm, ntm - g * gmm);
+    const int tm = g * gmm + (w % gm), tn = w / gm;
     const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
     const double* Ap = A_KC ? A + (long)m0 * lda : A + m0;
     const double* Bp = B_KC ? B + (long)n0 * ldb : B + n0;
     Acc acc;
     acc.zero();
-    gemm_tile<A_KC, B_KC>(acc, Ap, lda, Bp, ldb, 0, K, lds);
+    if (group_m < 0) {
+        // staggered k start: the tiles sharing an operand panel on one XCD request a given slab one slab-time apart
+        const int ks = (((tm & 7) + (tn & 7)) * GEMM_BK * STAGGER) % K;
+        gemm_tile<A_KC, B_KC>(acc, Ap, lda, Bp, ldb, 0, K, lds, ks);
+    } else {
+        gemm_tile<A_KC, B_KC>(acc, Ap, lda, Bp, ldb, 0, K, lds);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
