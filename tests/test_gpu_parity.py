@@ -269,3 +269,130 @@ def test_nll_core_terms(ctx, oracle):
     Kinv = oracle.spd_inverse_from_chol(L)
     close(r["grad_b"], 0.5 * (al @ al - np.trace(Kinv)), rtol=1e-7)
     h.close()
+
+
+# ---- edge cases (empty / ragged / maximum sizes / duplicates) ----------------------------------------------
+
+def test_single_data_point_and_single_candidate(ctx, oracle):
+    X = np.array([[0.3], [0.7]])
+    y = np.array([1.25])
+    theta = np.array([0.5, 0.4, 0.6])
+    for kernel in (0, 1):
+        gp = sls().GP(ctx, X, y, theta, 0.01, kernel)
+        ref = oracle.Regressor(X, y, theta, 0.01, kernel=kernel)
+        xs = np.array([[0.31], [0.65]])
+        close(gp.predict(xs)[0], ref.predict_batch(xs)[0], rtol=1e-10)
+        close(gp.predict(xs)[1], ref.predict_batch(xs)[1], rtol=1e-8)
+        v, g = gp.acq_eval(xs, 1, 1.5)
+        vo, go = ref.acq_eval_batch(xs, 1, 1.5)
+        close(v, vo, rtol=1e-9)
+        close(g, go, rtol=1e-7, atol=1e-12)
+        assert gp.summary()["best_index"] == 0
+        r = gp.acq_maximize(xs, 5, 1, 1.5)
+        assert r["index"] == 0 and r["x"].shape == (2,)
+        gp.close()
+
+
+def test_duplicate_and_near_duplicate_training_points(ctx, oracle):
+    """The reference merges points closer than 1e-4 only in the data manager; the regressors must still cope with exact
+    duplicates (K_y stays SPD through the noise term)."""
+    D, N = 3, 40
+    X, y, theta, b = synth_problem(oracle, D, N)
+    X[:, 7] = X[:, 3]
+    X[:, 9] = X[:, 3] + 1e-9
+    y[7] = y[3]
+    for kernel in (0, 1):
+        gp = sls().GP(ctx, X, y, theta, b, kernel)
+        ref = oracle.Regressor(X, y, theta, b, kernel=kernel)
+        Xs = synth_candidates(oracle, D, 50)
+        Xs[:, 0] = X[:, 3]
+        close(gp.predict(Xs)[0], ref.predict_batch(Xs)[0], rtol=1e-6, atol=1e-8)
+        close(gp.predict(Xs)[1], ref.predict_batch(Xs)[1], rtol=1e-5, atol=1e-8)
+        gp.close()
+
+
+def test_noiseless_formulation_b_zero(ctx, oracle):
+    """SEQUENTIAL_LINE_SEARCH_USE_NOISELESS_FORMULATION: b = 0, well-separated points -> interpolation, sigma(x_i) ~ 0."""
+    D, N = 2, 25
+    g = np.linspace(0.05, 0.95, 5)
+    X = np.array([[a, c] for a in g for c in g]).T.copy()
+    y = np.sin(3 * X[0]) * np.cos(2 * X[1])
+    theta = np.array([0.5, 0.15, 0.15])
+    gp = sls().GP(ctx, X, y, theta, 0.0, 1)
+    mu, sg = gp.predict(X)
+    close(mu, y, rtol=1e-7, atol=1e-8)
+    assert np.all(sg < 1e-4)
+    ei, dei = gp.acq_eval(X)               # EI and its gradient are finite (zero) where sigma < 1e-10 or tiny
+    assert np.all(np.isfinite(ei)) and np.all(ei >= 0)
+    ref = oracle.Regressor(X, y, theta, 0.0, kernel=1)
+    Xs = synth_candidates(oracle, D, 40)
+    close(gp.predict(Xs)[0], ref.predict_batch(Xs)[0], rtol=1e-6, atol=1e-8)
+    gp.close()
+
+
+def test_candidates_outside_the_unit_box_and_ragged_counts(ctx, oracle):
+    D, N = 4, 33
+    X, y, theta, b = synth_problem(oracle, D, N)
+    gp = sls().GP(ctx, X, y, theta, b, 1)
+    ref = oracle.Regressor(X, y, theta, b, kernel=1)
+    for M in (1, 127, 128, 129, 257):
+        Xs = synth_candidates(oracle, D, M, seed=M) * 1.6 - 0.3      # predictions are defined on all of R^D
+        close(gp.predict(Xs)[0], ref.predict_batch(Xs)[0], rtol=1e-6, atol=1e-9)
+        v, g = gp.acq_eval(Xs)
+        vo, go = ref.acq_eval_batch(Xs)
+        close(v, vo, rtol=1e-6, atol=1e-12)
+        close(g, go, rtol=1e-6, atol=1e-9 * max(np.abs(go).max(), 1e-30))
+    # the maximiser clamps its starts to the box first (reference bounds [0,1]^D, acquisition-function.cpp:118-119)
+    starts = synth_candidates(oracle, D, 30) * 1.6 - 0.3
+    r, ro = gp.acq_maximize(starts, 8), ref.acq_maximize(starts, 8)
+    assert np.all((r["x_stars"] >= 0) & (r["x_stars"] <= 1))
+    close(r["value"], ro["value"], rtol=1e-6)
+    gp.close()
+
+
+def test_high_dimension_and_ard(ctx, oracle):
+    D, N, M = 128, 150, 64
+    X, y, theta, b = synth_problem(oracle, D, N)
+    theta[1:] *= np.linspace(0.5, 2.0, D)
+    for kernel in (0, 1):
+        gp = sls().GP(ctx, X, y, theta, b, kernel)
+        ref = oracle.Regressor(X, y, theta, b, kernel=kernel)
+        Xs = synth_candidates(oracle, D, M)
+        v, g = gp.acq_eval(Xs, 1, 2.0)
+        vo, go = ref.acq_eval_batch(Xs, 1, 2.0)
+        close(v, vo, rtol=1e-6)
+        close(g, go, rtol=1e-6, atol=1e-8 * np.abs(go).max())
+        gp.close()
+
+
+def test_expected_improvement_flat_region_is_exactly_zero(ctx, oracle):
+    """Far from the data with a short length scale EI underflows to 0 with a zero gradient; such starts stop at once
+    and the maximiser returns them unchanged (value 0), like the oracle."""
+    X = np.array([[0.1, 0.12, 0.15]])
+    y = np.array([1.0, 3.0, 2.0])
+    theta = np.array([1e-3, 0.01])
+    gp = sls().GP(ctx, X, y, theta, 1e-6, 0)
+    ref = oracle.Regressor(X, y, theta, 1e-6, kernel=0)
+    xs = np.array([[0.9, 0.95, 0.5]])
+    v, g = gp.acq_eval(xs)
+    vo, go = ref.acq_eval_batch(xs)
+    assert np.array_equal(v, vo) and np.all(v == 0.0) and np.all(g == 0.0) and np.all(go == 0.0)
+    r, ro = gp.acq_maximize(xs, 10), ref.acq_maximize(xs, 10)
+    assert np.array_equal(r["x_stars"], xs) and r["value"] == 0.0 and ro["value"] == 0.0 and r["index"] == ro["index"] == 0
+    gp.close()
+
+
+def test_lbfgs_options_and_single_evaluation(ctx, oracle):
+    D, N, S = 3, 30, 40
+    X, y, theta, b = synth_problem(oracle, D, N)
+    starts = synth_candidates(oracle, D, S)
+    gp = sls().GP(ctx, X, y, theta, b, 1)
+    v0 = gp.acq_eval(starts, want_grad=False)
+    r1 = gp.acq_maximize(starts, 1)                      # n_local = 1: the starts themselves
+    assert np.array_equal(r1["y_stars"], v0) and r1["index"] == int(np.argmax(v0))
+    opts = sls().LbfgsOpts(3, 1e-4, 0.5, 0.0, 20)        # shorter memory: still monotone and inside the box
+    r = gp.acq_maximize(starts, 12, opts=opts)
+    assert np.all(r["y_stars"] >= v0 - 1e-15)
+    with pytest.raises(sls().SlsError):
+        gp.acq_maximize(starts, 5, opts=sls().LbfgsOpts(9, 1e-4, 0.5, 0.0, 20))
+    gp.close()
