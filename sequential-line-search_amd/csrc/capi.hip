@@ -1,6 +1,7 @@
 // C-ABI of libsls_hip (include/sls_hip.h): host orchestration of the gfx950 kernels.  No CPU fallback.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -535,10 +536,38 @@ static void maximize_impl(sls_gp* g, sls_gp* gs, int acq_type, double ucb_h, con
     st.hlen = g->lb_int; st.hpos = g->lb_int + Sp; st.nbt = g->lb_int + 2 * Sp; st.done = g->lb_int + 3 * Sp;
     st.c1 = o.c1; st.shrink = o.shrink; st.gtol = o.gtol; st.max_backtracks = o.max_backtracks;
     launch_clamp_starts(c->stream, starts_dev, D, S, st.xt, Sp, Sp);
-    for (int ev = 0; ev < n_local; ++ev) {
+    // Round 0 runs eagerly (it also performs every lazy allocation / attribute set-up).  The remaining rounds are one
+    // fixed kernel sequence with constant arguments and can be captured once into a hipGraph and replayed
+    // (SLS_USE_GRAPH=1).  Measured on MI355X at the launch-bound sizes of the reference's demos (D=32 N=90 S=10, 320
+    // rounds: eager 55.1 ms, graph 56.6 ms; tools/time_small.py) replay does not help: the 7 single-tile kernels of a
+    // round take ~25 us each on the device, far above the ~3 us host launch cost -- so eager launch is the default.
+    auto round = [&](bool first) {
         eval_acq(g, gs, st.xt, Sp, S, acq_type, ucb_h, g->lb_val.p, g->lb_grad.p, Sp);
         ProfScope ps(c, "lbfgs");
-        launch_lbfgs_step(c->stream, st, g->lb_val.p, g->lb_grad.p, ev == 0);
+        launch_lbfgs_step(c->stream, st, g->lb_val.p, g->lb_grad.p, first);
+    };
+    round(true);
+    const char* genv = getenv("SLS_USE_GRAPH");
+    const bool use_graph = n_local > 3 && !c->prof_on && genv && atoi(genv) != 0;
+    if (use_graph) {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        SLS_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        try {
+            round(false);
+        } catch (...) {
+            (void)hipStreamEndCapture(c->stream, &graph);
+            if (graph) (void)hipGraphDestroy(graph);
+            throw;
+        }
+        SLS_HIP(hipStreamEndCapture(c->stream, &graph));
+        SLS_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        for (int ev = 1; ev < n_local; ++ev) SLS_HIP(hipGraphLaunch(exec, c->stream));
+        SLS_HIP(hipStreamSynchronize(c->stream));
+        (void)hipGraphExecDestroy(exec);
+        (void)hipGraphDestroy(graph);
+    } else {
+        for (int ev = 1; ev < n_local; ++ev) round(false);
     }
     launch_argmax_neg(c->stream, st.f, S, g->scal.p + 2, g->d_idx + 1);
     double bv = 0;
