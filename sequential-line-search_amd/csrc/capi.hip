@@ -387,7 +387,7 @@ static void eval_candidates(sls_gp* g, const double* xr, long ldr, int S, const 
         }
         if (want_grad) {
             ProfScope ps(c, "grad_gemm");
-            launch_grad_gemm(c->stream, g->P.p, Cs, ldk, Sp, g->XT.p, g->XaT.p, Np, Np, g->Dcols, g->Gs.p, g->Gm.p);
+            launch_grad_gemm(c->stream, g->P.p, Cs, ldk, Sp, g->XT.p, g->XaT.p, Np, Np, D <= 64 ? -g->Dcols : g->Dcols, g->Gs.p, g->Gm.p);
         }
         {
             ProfScope ps(c, "finalize");

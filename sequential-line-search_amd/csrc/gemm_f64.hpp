@@ -159,6 +159,85 @@ __device__ __forceinline__ void gemm_tile(Acc& acc, const double* __restrict__ A
     }
 }
 
+// 128 x 64 output tile (A M-contiguous, B K-contiguous), for products whose second dimension is small (the gradient
+// contractions have n' = D <= 64 for the headline configuration; a 128-wide tile would waste half of its MFMAs).
+// 4 waves stacked along m: wave w owns rows 32 w .. 32 w + 31 (2 A fragments) x all 64 columns (4 B fragments).
+// LDS per buffer: A slab [16][144] + B slab [64][18] doubles; two buffers = 55296 B -> 2-3 workgroups per CU.
+constexpr int GEMM_N64_LDS_B = 64 * GEMM_LDS_KC_LD;                       // 1152 doubles
+constexpr int GEMM_N64_LDS_BUF = GEMM_LDS_TILE + GEMM_N64_LDS_B;          // 3456 doubles
+constexpr int GEMM_N64_LDS_BYTES = 2 * GEMM_N64_LDS_BUF * 8;              // 55296 B
+
+struct Acc64 {
+    d4_t v[2][4];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
+    }
+};
+
+__device__ __forceinline__ void gemm_tile_n64(Acc64& acc, const double* __restrict__ A, long lda,
+                                              const double* __restrict__ B, long ldb, int kb, int ke, double* lds) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wm = (tid >> 6) * 32;
+    if (kb >= ke) return;
+    Stage sa;
+    d2_t sbr[2];
+    auto load_b = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;          // 512 x 16-byte pieces: n' = idx / 8, k pair = idx % 8
+            const int n = idx >> 3, k2 = idx & 7;
+            sbr[i] = *reinterpret_cast<const d2_t*>(B + (long)(k0 + 2 * k2) + (long)n * ldb);
+        }
+    };
+    auto store_b = [&](double* l) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            const int n = idx >> 3, k2 = idx & 7;
+            *reinterpret_cast<d2_t*>(l + n * GEMM_LDS_KC_LD + 2 * k2) = sbr[i];
+        }
+    };
+    stage_load<false>(sa, A, lda, kb, tid);
+    load_b(kb);
+    stage_store<false>(sa, lds, tid);
+    store_b(lds + GEMM_LDS_TILE);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = kb; k0 < ke; k0 += GEMM_BK) {
+        const bool more = (k0 + GEMM_BK) < ke;
+        if (more) {
+            stage_load<false>(sa, A, lda, k0 + GEMM_BK, tid);
+            load_b(k0 + GEMM_BK);
+        }
+        const double* la = lds + cur;
+        const double* lb = lds + cur + GEMM_LDS_TILE;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            double af[2], bf[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = frag_read<false>(la, wm + 16 * i, kk, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = frag_read<true>(lb, 16 * j, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc.v[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc.v[i][j], 0, 0, 0);
+        }
+        const int nxt = cur ^ GEMM_N64_LDS_BUF;
+        if (more) {
+            stage_store<false>(sa, lds + nxt, tid);
+            store_b(lds + nxt + GEMM_LDS_TILE);
+        }
+        __syncthreads();
+        cur = nxt;
+    }
+}
+
 // Coordinates of accumulator element (i, j, r) inside the 128x128 tile.
 __device__ __forceinline__ int acc_m(int i) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -130,12 +130,41 @@ __global__ __launch_bounds__(256, 2) void grad_gemm_kernel(const double* __restr
             for (int r = 0; r < 4; ++r) C[(long)(m0 + acc_m(i)) + (long)(n0 + acc_n(j, r)) * ldk] = acc.v[i][j][r];
 }
 
+// D <= 64: 128 x 64 tiles (no wasted MFMA columns), 3 workgroups per CU
+__global__ __launch_bounds__(256, 3) void grad_gemm64_kernel(const double* __restrict__ P, const double* __restrict__ Cs, long ldk,
+                                                             int Sp, const double* __restrict__ XT, const double* __restrict__ XaT,
+                                                             long ld, int Np, double* __restrict__ Gs, double* __restrict__ Gm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* lds = reinterpret_cast<double*>(smem);
+    const int m0 = blockIdx.x * GEMM_BM;
+    const double* A = blockIdx.y == 0 ? P : Cs;
+    const double* B = blockIdx.y == 0 ? XT : XaT;
+    double* C = blockIdx.y == 0 ? Gs : Gm;
+    Acc64 acc;
+    acc.zero();
+    gemm_tile_n64(acc, A + m0, ldk, B, ld, 0, Np, lds);
+    const int lane = threadIdx.x & 63, wm = (threadIdx.x >> 6) * 32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                C[(long)(m0 + wm + 16 * i + (lane & 15)) + (long)(16 * j + (lane >> 4) + 4 * r) * ldk] = acc.v[i][j][r];
+}
+
 void launch_grad_gemm(hipStream_t s, const double* P, const double* Cs, long ldk, int Sp, const double* XT, const double* XaT,
                       long ld, int Np, int Dcols, double* Gs, double* Gm) {
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)grad_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)grad_gemm64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_N64_LDS_BYTES);
         attr = true;
+    }
+    if (Dcols < 0) {   // caller signals D <= 64 by passing -Dcols
+        hipLaunchKernelGGL(grad_gemm64_kernel, dim3(Sp / GEMM_BM, 2), dim3(GEMM_THREADS), GEMM_N64_LDS_BYTES, s, P, Cs, ldk, Sp, XT,
+                           XaT, ld, Np, Gs, Gm);
+        return;
     }
     const int nt = (Sp / GEMM_BM) * (Dcols / GEMM_BN);
     hipLaunchKernelGGL(grad_gemm_kernel, dim3(nt, 2), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, P, Cs, ldk, Sp, XT, XaT, ld, Np, Dcols,
