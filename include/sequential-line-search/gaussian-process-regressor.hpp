@@ -45,6 +45,10 @@ namespace sequential_line_search
 
         sls_gp* GetDeviceHandle() const override;
 
+        /// Extension: add one observation without refitting (O(N^2) update on the device; hyper-parameters unchanged).
+        /// m_K_y / m_K_y_inv are refreshed only if s_materialize_matrices is set.
+        void AppendPoint(const Eigen::VectorXd& x, double y);
+
     private:
         void PerformMapEstimation();
         void BuildDeviceState();

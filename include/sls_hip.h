@@ -78,6 +78,10 @@ int sls_potri(sls_ctx* ctx, const double* L, int N, double* Ainv);
 int sls_gp_create(sls_ctx* ctx, const double* X, int D, int N, const double* y, const double* theta, double b, int kernel,
                   sls_gp** out);
 int sls_gp_destroy(sls_gp* gp);
+/* Append one observation (x, y) to a fitted handle in O(N^2) (Schur-complement update of K_y^-1, one new row of the
+ * Cholesky factor): what FindNextPoints needs after every accepted point instead of re-building the dummy regressor
+ * (src/acquisition-function.cpp:280-293). */
+int sls_gp_append_point(sls_gp* gp, const double* x, double y);
 
 #define SLS_GP_K_Y 0        /* N x N  m_K_y / m_K          (gaussian-process-regressor.hpp:31, preference-regressor.hpp:57) */
 #define SLS_GP_K_Y_INV 1    /* N x N  m_K_y_inv            (gaussian-process-regressor.hpp:32) */

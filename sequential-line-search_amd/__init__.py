@@ -51,7 +51,7 @@ EXPORTS = [
     "sls_gp_destroy", "sls_gp_get_matrix", "sls_gp_get_summary", "sls_gp_predict", "sls_gp_predict_grad", "sls_acq_eval",
     "sls_lbfgs_default_opts", "sls_acq_maximize", "sls_acq_maximize_dev", "sls_gp_refit_dev", "sls_prof_enable",
     "sls_prof_reset", "sls_prof_get", "sls_nll_create", "sls_nll_destroy", "sls_nll_eval", "sls_gp_nll_grad",
-    "sls_pref_objective", "sls_acq_eval_pair", "sls_acq_maximize_pair",
+    "sls_pref_objective", "sls_acq_eval_pair", "sls_acq_maximize_pair", "sls_gp_append_point",
 ]
 
 
@@ -167,6 +167,12 @@ class GP:
             self.close()
         except Exception:
             pass
+
+    def append_point(self, x, y):
+        x = _f(x)
+        assert x.shape == (self.D,)
+        _ck(lib().sls_gp_append_point(self.h, _p(x), C.c_double(y)))
+        self.N += 1
 
     def matrix(self, what):
         out = np.empty((self.N, self.N), order="F") if what in (GP_K_Y, GP_K_Y_INV, GP_CHOL_L) else np.empty(self.N)

@@ -240,6 +240,30 @@ static void gp_fetch_summary(sls_gp* g) {
     g->logdet = sc[1];
 }
 
+// (re)size every per-handle buffer for the host copies g->Xh / g->yh, upload and fit
+static void gp_setup(sls_gp* g) {
+    sls_ctx* ctx = g->ctx;
+    const int D = g->D, N = (int)g->yh.size();
+    g->N = N;
+    g->Np = round_up(N, 128); g->Dp = round_up(D, 16); g->Dcols = round_up(D, 128);
+    const size_t Np = g->Np;
+    g->X.ensure((size_t)D * N); g->y.ensure(Np); g->inv_ell.ensure(g->Dcols);
+    g->XT.ensure(Np * g->Dcols); g->XaT.ensure(Np * g->Dcols); g->nx.ensure(Np);
+    g->L.ensure(Np * Np); g->Linv.ensure(Np * Np); g->Kinv.ensure(Np * Np);
+    g->alpha.ensure(Np); g->tvec.ensure(Np); g->mu_data.ensure(Np); g->scal.ensure(8);
+    g->ws_chunk = 0;   // the evaluation workspace depends on Np
+    if (!g->d_idx) SLS_HIP(hipMalloc((void**)&g->d_idx, 64));
+    std::vector<double> il(g->Dcols, 0.0), ypad(Np, 0.0);
+    for (int d = 0; d < D; ++d) il[d] = 1.0 / g->theta[1 + d];
+    std::copy(g->yh.begin(), g->yh.end(), ypad.begin());
+    h2d(ctx, g->X.p, g->Xh.data(), (size_t)D * N);
+    h2d(ctx, g->y.p, ypad.data(), Np);
+    h2d(ctx, g->inv_ell.p, il.data(), g->Dcols);
+    sync(ctx);   // host staging vectors go out of scope
+    gp_fit_device(g);
+    gp_fetch_summary(g);
+}
+
 extern "C" int sls_gp_create(sls_ctx* ctx, const double* X, int D, int N, const double* y, const double* theta, double b,
                              int kernel, sls_gp** out) {
     SLS_TRY
@@ -251,26 +275,11 @@ extern "C" int sls_gp_create(sls_ctx* ctx, const double* X, int D, int N, const 
     check_theta(theta, D);
     SLS_HIP(hipSetDevice(ctx->device));
     std::unique_ptr<sls_gp> g(new sls_gp());
-    g->ctx = ctx; g->D = D; g->N = N; g->kernel = kernel; g->a = theta[0]; g->b = b;
-    g->Np = round_up(N, 128); g->Dp = round_up(D, 16); g->Dcols = round_up(D, 128);
+    g->ctx = ctx; g->D = D; g->kernel = kernel; g->a = theta[0]; g->b = b;
     g->theta.assign(theta, theta + D + 1);
     g->Xh.assign(X, X + (size_t)D * N);
     g->yh.assign(y, y + N);
-    const size_t Np = g->Np;
-    g->X.ensure((size_t)D * N); g->y.ensure(Np); g->inv_ell.ensure(g->Dcols);
-    g->XT.ensure(Np * g->Dcols); g->XaT.ensure(Np * g->Dcols); g->nx.ensure(Np);
-    g->L.ensure(Np * Np); g->Linv.ensure(Np * Np); g->Kinv.ensure(Np * Np);
-    g->alpha.ensure(Np); g->tvec.ensure(Np); g->mu_data.ensure(Np); g->scal.ensure(8);
-    SLS_HIP(hipMalloc((void**)&g->d_idx, 64));
-    std::vector<double> il(g->Dcols, 0.0), ypad(Np, 0.0);
-    for (int d = 0; d < D; ++d) il[d] = 1.0 / theta[1 + d];
-    std::copy(y, y + N, ypad.begin());
-    h2d(ctx, g->X.p, X, (size_t)D * N);
-    h2d(ctx, g->y.p, ypad.data(), Np);
-    h2d(ctx, g->inv_ell.p, il.data(), g->Dcols);
-    sync(ctx);   // host staging vectors go out of scope
-    gp_fit_device(g.get());
-    gp_fetch_summary(g.get());
+    gp_setup(g.get());
     *out = g.release();
     SLS_CATCH
 }
@@ -770,3 +779,56 @@ extern "C" int sls_potri(sls_ctx* c, const double* L, int N, double* Ainv) {
     sync(c);
     SLS_CATCH
 }
+
+// Grow the fitted state by one observation in O(N^2): Schur-complement update of K^-1, one new row of L and L^-1,
+// alpha, mu at the data points, arg max and log-determinant.  Replaces the full refit of the dummy regressor in
+// FindNextPoints (src/acquisition-function.cpp:280-293).  When N is a multiple of 128 the padded buffers are full and
+// the handle is rebuilt from scratch on the device instead (same results).
+extern "C" int sls_gp_append_point(sls_gp* g, const double* x, double y_new) {
+    SLS_TRY
+    SLS_REQUIRE(g && x, "sls_gp_append_point: NULL argument");
+    sls_ctx* c = g->ctx;
+    const int D = g->D, N = g->N, Np = g->Np;
+    g->Xh.insert(g->Xh.end(), x, x + D);
+    g->yh.push_back(y_new);
+    if (N % 128 == 0) {
+        gp_setup(g);   // buffers full: re-size with one more 128-block and refit on the device
+        return SLS_OK;
+    }
+    // candidate-major upload of the single point, cross covariances k = k(X, x) through the regular evaluation kernels
+    upload_candidates(g, x, 1, g->raw, 128);
+    ensure_eval_ws(g, 128);
+    g->outv.ensure(4 * (size_t)Np + 8);
+    double* kvec = g->outv.p;            // k (Np, strided copy of Ks row 0)
+    double* uvec = kvec + Np;
+    double* lvec = uvec + Np;
+    double* tmp = lvec + Np;
+    double* scal = tmp + Np;
+    KernelSpec ks{g->kernel, g->a};
+    launch_prep_cands(c->stream, g->raw.p, 128, D, 1, g->inv_ell.p, g->XsT.p, 128, 128, g->Dcols, g->ns.p);
+    double* Cs = (g->kernel == SLS_KERNEL_ARD_MATERN52) ? g->Cs.p : g->Ks.p;
+    launch_cross_gram(c->stream, g->XsT.p, 128, g->ns.p, 128, g->XT.p, Np, g->nx.p, Np, N, g->Dp, ks, nullptr, g->Ks.p, Cs, 128,
+                      nullptr, nullptr);
+    // Ks[n + i*128], n = 0 -> stride-128 gather into a dense vector (padding rows i >= N are 0)
+    SLS_HIP(hipMemcpy2DAsync(kvec, 8, g->Ks.p, 128 * 8, 8, Np, hipMemcpyDeviceToDevice, c->stream));
+    launch_gemv_n(c->stream, g->Kinv.p, Np, kvec, uvec);     // u = K^-1 k   (padding: identity block x 0 = 0)
+    launch_gemv_n(c->stream, g->Linv.p, Np, kvec, lvec);     // l = L^-1 k
+    launch_append_dots(c->stream, kvec, uvec, lvec, g->y.p, N, scal);
+    const double kappa = g->a + g->b;
+    launch_append_update(c->stream, g->Kinv.p, g->L.p, g->Linv.p, g->alpha.p, Np, N, uvec, lvec, scal, kappa, y_new);
+    // new training point joins X, y, the scaled copies and the hoisted quantities
+    SLS_HIP(hipMemcpyAsync(g->y.p + N, &g->yh[N], 8, hipMemcpyHostToDevice, c->stream));
+    g->X.ensure((size_t)D * (N + 1));   // may reallocate: refill from the host copy
+    SLS_HIP(hipMemcpyAsync(g->X.p, g->Xh.data(), (size_t)D * (N + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    g->N = N + 1;
+    launch_prep_points(c->stream, g->X.p, D, N + 1, g->inv_ell.p, g->XT.p, Np, Np, g->Dcols, g->nx.p);
+    launch_scale_rows(c->stream, g->XT.p, g->alpha.p, g->XaT.p, Np, Np, g->Dcols);
+    launch_mu_data(c->stream, g->y.p, g->alpha.p, g->b, N + 1, g->mu_data.p);
+    launch_argmax(c->stream, g->mu_data.p, N + 1, g->scal.p, g->d_idx);
+    launch_logdet(c->stream, g->L.p, Np, N + 1, g->scal.p + 1);
+    SLS_HIP(hipMemsetAsync(c->d_info, 0, 64, c->stream));
+    gp_fetch_summary(g);
+    SLS_REQUIRE(std::isfinite(g->logdet), "sls_gp_append_point: the extended K_y is not positive definite");
+    SLS_CATCH
+}
+

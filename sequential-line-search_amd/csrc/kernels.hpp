@@ -97,6 +97,14 @@ void launch_fill(hipStream_t s, double* p, long n, double v);
 void launch_mu_data(hipStream_t s, const double* y, const double* alpha, double b, int N, double* mu_data);
 void launch_logdet(hipStream_t s, const double* L, int Np, int N, double* out);
 
+// ---- rank-1 growth of the fitted state by one data point (kernels_chol.hip) ----
+// scal_out[0] = k.u, scal_out[1] = l.l, scal_out[2] = u.y  (fixed-order block reductions)
+void launch_append_dots(hipStream_t s, const double* k, const double* u, const double* l, const double* y, int N, double* scal_out);
+// Kinv(0:N,0:N) += u u^T / s ; Kinv(N,0:N) = Kinv(0:N,N) = -u / s ; Kinv(N,N) = 1/s ;
+// L(N,0:N) = l ; L(N,N) = lam ; Linv(N,0:N) = -u / lam ; Linv(N,N) = 1/lam ; alpha(0:N) += u (uy - eta)/s ; alpha(N) = (eta - uy)/s
+void launch_append_update(hipStream_t s, double* Kinv, double* L, double* Linv, double* alpha, int Np, int N, const double* u,
+                          const double* l, const double* scal /* k.u, l.l, u.y on device */, double kappa, double eta);
+
 // generic C = alpha * opA opB^T + beta * C on full 128-tiles (mt x nt tiles, K multiple of 16)
 void launch_gemm_plain(hipStream_t s, const double* A, long lda, bool a_kc, const double* B, long ldb, bool b_kc, double* C,
                        long ldc, int mt, int nt, int K, double alpha, double beta);

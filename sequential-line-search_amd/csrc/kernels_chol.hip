@@ -493,6 +493,63 @@ void launch_gemv_t(hipStream_t s, const double* A, int Np, const double* x, doub
     hipLaunchKernelGGL(gemv_t_kernel, dim3((Np + 3) / 4), dim3(256), 0, s, A, Np, x, y);
 }
 
+__device__ __forceinline__ double block_sum256(double v, double* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void append_dots_kernel(const double* __restrict__ k, const double* __restrict__ u,
+                                                          const double* __restrict__ l, const double* __restrict__ y, int N,
+                                                          double* __restrict__ out) {
+    __shared__ double red[4];
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        a += k[i] * u[i];
+        b += l[i] * l[i];
+        c += u[i] * y[i];
+    }
+    const double ta = block_sum256(a, red), tb = block_sum256(b, red), tc = block_sum256(c, red);
+    if (threadIdx.x == 0) { out[0] = ta; out[1] = tb; out[2] = tc; }
+}
+void launch_append_dots(hipStream_t s, const double* k, const double* u, const double* l, const double* y, int N, double* scal_out) {
+    hipLaunchKernelGGL(append_dots_kernel, dim3(1), dim3(256), 0, s, k, u, l, y, N, scal_out);
+}
+__global__ __launch_bounds__(256) void append_update_kernel(double* __restrict__ Kinv, double* __restrict__ L, double* __restrict__ Linv,
+                                                            double* __restrict__ alpha, int Np, int N, const double* __restrict__ u,
+                                                            const double* __restrict__ l, const double* __restrict__ scal, double kappa,
+                                                            double eta) {
+    // Schur complement s = kappa - k.K^-1 k (from the inverse) and lam^2 = kappa - l.l (from the factor) are the same number
+    const double sch = kappa - scal[0];
+    const double lam = sqrt(kappa - scal[1]);
+    const double uy = scal[2];
+    const int i = blockIdx.x * 256 + threadIdx.x;   // row
+    const int j = blockIdx.y;                       // column, 0..N
+    if (i > N) return;
+    if (j < N && i < N) {
+        Kinv[(long)i + (long)j * Np] += u[i] * u[j] / sch;
+    } else if (j == N) {
+        Kinv[(long)i + (long)N * Np] = (i < N) ? -u[i] / sch : 1.0 / sch;
+        if (i < N) {
+            Kinv[(long)N + (long)i * Np] = -u[i] / sch;
+            L[(long)N + (long)i * Np] = l[i];
+            Linv[(long)N + (long)i * Np] = -u[i] / lam;
+            alpha[i] += u[i] * (uy - eta) / sch;
+        } else {
+            L[(long)N * (Np + 1)] = lam;
+            Linv[(long)N * (Np + 1)] = 1.0 / lam;
+            alpha[N] = (eta - uy) / sch;
+        }
+    }
+}
+void launch_append_update(hipStream_t s, double* Kinv, double* L, double* Linv, double* alpha, int Np, int N, const double* u,
+                          const double* l, const double* scal, double kappa, double eta) {
+    hipLaunchKernelGGL(append_update_kernel, dim3((N + 1 + 255) / 256, N + 1), dim3(256), 0, s, Kinv, L, Linv, alpha, Np, N, u, l, scal,
+                       kappa, eta);
+}
+
 __global__ __launch_bounds__(256) void zero_upper_kernel(double* __restrict__ A, int Np) {
     const long idx = blockIdx.x * 256L + threadIdx.x;
     if (idx >= (long)Np * Np) return;

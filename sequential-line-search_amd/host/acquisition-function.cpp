@@ -162,13 +162,10 @@ namespace sequential_line_search
             points.push_back(x_star);
             if (points.size() != num_points)
             {
-                // append the new point; its value is irrelevant for the variance (:286-289 uses PredictMu)
-                const MatrixXd new_X = eig::AppendCol(temp->GetLargeX(), x_star);
-                const VectorXd old_y = temp->GetSmallY();
-                VectorXd       new_y(old_y.size() + 1);
-                for (long k = 0; k < old_y.size(); ++k) new_y(k) = old_y(k);
-                new_y(old_y.size()) = temp->PredictMu(x_star);
-                temp = std::make_shared<GaussianProcessRegressor>(new_X, new_y, theta, regressor.GetNoiseHyperparam());
+                // append the new point to the dummy regressor; its value is irrelevant for the variance (the reference
+                // uses PredictMu, :286-289).  The reference rebuilds the regressor (:293); here the fitted state grows by a
+                // rank-1 update on the device.
+                temp->AppendPoint(x_star, temp->PredictMu(x_star));
             }
         }
         GaussianProcessRegressor::s_materialize_matrices = keep;

@@ -47,6 +47,24 @@ namespace sequential_line_search
         }
     }
 
+    void GaussianProcessRegressor::AppendPoint(const VectorXd& x, double y)
+    {
+        device::Check(sls_gp_append_point(m_handle->h, x.data(), y), "sls_gp_append_point");
+        m_X = eig::AppendCol(m_X, x);
+        VectorXd yn(m_y.size() + 1);
+        for (long i = 0; i < m_y.size(); ++i) yn(i) = m_y(i);
+        yn(m_y.size()) = y;
+        m_y            = yn;
+        if (s_materialize_matrices)
+        {
+            const long N = m_X.cols();
+            m_K_y        = MatrixXd(N, N);
+            m_K_y_inv    = MatrixXd(N, N);
+            device::Check(sls_gp_get_matrix(m_handle->h, SLS_GP_K_Y, m_K_y.data()), "sls_gp_get_matrix(K_y)");
+            device::Check(sls_gp_get_matrix(m_handle->h, SLS_GP_K_Y_INV, m_K_y_inv.data()), "sls_gp_get_matrix(K_y_inv)");
+        }
+    }
+
     sls_gp* GaussianProcessRegressor::GetDeviceHandle() const { return m_handle ? m_handle->h : nullptr; }
 
     // reference: src/gaussian-process-regressor.cpp:234-272 -- single-point forms of the batched device evaluation

@@ -396,3 +396,31 @@ def test_lbfgs_options_and_single_evaluation(ctx, oracle):
     with pytest.raises(sls().SlsError):
         gp.acq_maximize(starts, 5, opts=sls().LbfgsOpts(9, 1e-4, 0.5, 0.0, 20))
     gp.close()
+
+
+@pytest.mark.parametrize("kernel", [0, 1])
+@pytest.mark.parametrize("N0", [5, 126, 128, 200])
+def test_append_point_equals_refit(ctx, oracle, kernel, N0):
+    """sls_gp_append_point (rank-1 growth, used by FindNextPoints) against a fresh fit on the extended data; N0 = 126 / 128
+    cross the 128-padding boundary (in-place update vs buffer growth)."""
+    D, extra = 3, 4
+    X, y, theta, b = synth_problem(oracle, D, N0 + extra)
+    gp = sls().GP(ctx, X[:, :N0], y[:N0], theta, b, kernel)
+    for i in range(N0, N0 + extra):
+        gp.append_point(X[:, i], y[i])
+    ref = sls().GP(ctx, X, y, theta, b, kernel)
+    m = sls()
+    Ki, Kr = gp.matrix(m.GP_K_Y_INV), ref.matrix(m.GP_K_Y_INV)
+    assert relerr(Ki, Kr, floor=np.abs(Kr).max()) < 1e-9
+    close(gp.matrix(m.GP_CHOL_L), ref.matrix(m.GP_CHOL_L), rtol=1e-8, atol=1e-10)
+    close(gp.matrix(m.GP_ALPHA), ref.matrix(m.GP_ALPHA), rtol=1e-6, atol=1e-7 * np.abs(y).max())
+    sa, sb = gp.summary(), ref.summary()
+    assert sa["best_index"] == sb["best_index"]
+    close(sa["logdet"], sb["logdet"], rtol=1e-10)
+    close(sa["mu_best"], sb["mu_best"], rtol=1e-8)
+    Xs = synth_candidates(oracle, D, 33)
+    for a_, b_ in zip(gp.acq_eval(Xs), ref.acq_eval(Xs)):
+        close(a_, b_, rtol=1e-6, atol=1e-9 * max(np.abs(b_).max(), 1e-30))
+    oref = oracle.Regressor(X, y, theta, b, kernel=kernel)
+    close(gp.predict(Xs)[1], oref.predict_batch(Xs)[1], rtol=1e-6, atol=1e-9)
+    gp.close(); ref.close()
