@@ -204,6 +204,15 @@ int main()
         const VectorXd k  = CalcSmallK(x, X, fixed.GetKernelHyperparams(), fixed.GetKernel());
         for (int i = 0; i < 9; ++i) mu += k(i) * b(i);
         EXPECT(std::abs(mu - fixed.PredictMu(x)) < 1e-9);   // PredictMu = k^T K_llt.solve(y) (src/preference-regressor.cpp:293-297)
+        // DampData round trip (X.csv / D.csv) -> identical regressor
+        fixed.DampData("/tmp", "slshost_");
+        const MatrixXd X2 = utils::ImportMatrixFromCsv("/tmp/slshost_X.csv");
+        const auto     D2 = utils::ImportPreferencesFromCsv("/tmp/slshost_D.csv");
+        EXPECT(X2.rows() == X.rows() && X2.cols() == X.cols() && D2.size() == prefs.size());
+        std::vector<Preference> prefs2;
+        for (const auto& p : D2) prefs2.push_back(Preference(p));
+        PreferenceRegressor reloaded(X2, prefs2, false);
+        EXPECT(std::abs(reloaded.PredictMu(x) - fixed.PredictMu(x)) < 1e-12);
         const auto pts = acquisition_func::FindNextPoints(fixed, 3, 32, 20);
         EXPECT(pts.size() == 3);
         EXPECT((pts[0] - pts[1]).norm() > 1e-3 && (pts[1] - pts[2]).norm() > 1e-3);   // variance update pushes the batch apart

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <sequential-line-search/eigen-lite.hpp>
 #include <string>
+#include <vector>
 
 namespace sequential_line_search
 {
@@ -42,6 +43,13 @@ namespace sequential_line_search
         }
 
         void ExportMatrixToCsv(const std::string& file_path, const Eigen::MatrixXd& X);
+
+        /// Reads a matrix written by ExportMatrixToCsv (comma separated, one matrix row per line).  The reference only
+        /// writes its state (DampData); this loader makes the dump usable for resuming a session.
+        Eigen::MatrixXd ImportMatrixFromCsv(const std::string& file_path);
+
+        /// Reads the preference tuples of DampData's D.csv (one comma separated index tuple per line).
+        std::vector<std::vector<unsigned>> ImportPreferencesFromCsv(const std::string& file_path);
     } // namespace utils
 } // namespace sequential_line_search
 
