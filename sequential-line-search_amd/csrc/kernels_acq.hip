@@ -178,6 +178,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs p) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= p.S) return;
     double mu = 0.0, ca = 0.0, kw = 0.0, cw = 0.0;
+    #pragma unroll 8
     for (int t = 0; t < p.nbt; ++t) {
         mu += p.mu_part[(long)t * p.ldk + n];
         ca += p.ca_part[(long)t * p.ldk + n];
@@ -216,6 +217,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs p) {
             if (isnan(Phi * dm + phi * ds)) bad = true;
         }
     }
+    #pragma unroll 4
     for (int d = 0; d < p.D; ++d) {
         const double xt = p.XsT[n + (long)d * p.ldk];
         const double il = p.inv_ell[d];
@@ -299,6 +301,7 @@ __global__ __launch_bounds__(256) void lbfgs_step_kernel(LbfgsState st, const do
     bool need_dir = false;
     if (first) {
         st.f[n] = -val[n];
+        #pragma unroll 8
         for (int d = 0; d < D; ++d) {
             st.x[n + d * ld] = st.xt[n + d * ld];
             st.g[n + d * ld] = -grad[n + d * ld];
@@ -309,6 +312,7 @@ __global__ __launch_bounds__(256) void lbfgs_step_kernel(LbfgsState st, const do
         if (st.done[n]) return;
         const double ft = -val[n];
         double gs = 0.0, ss = 0.0;
+        #pragma unroll 8
         for (int d = 0; d < D; ++d) {
             const double sd = st.xt[n + d * ld] - st.x[n + d * ld];
             gs += st.g[n + d * ld] * sd;
@@ -320,6 +324,7 @@ __global__ __launch_bounds__(256) void lbfgs_step_kernel(LbfgsState st, const do
             const int idx = st.hpos[n];
             double* Sh = st.Sh + (long)idx * D * ld;
             double* Yh = st.Yh + (long)idx * D * ld;
+            #pragma unroll 8
             for (int d = 0; d < D; ++d) {
                 const double sd = st.xt[n + d * ld] - st.x[n + d * ld];
                 const double yd = -grad[n + d * ld] - st.g[n + d * ld];
@@ -333,6 +338,7 @@ __global__ __launch_bounds__(256) void lbfgs_step_kernel(LbfgsState st, const do
                 st.hpos[n] = (idx + 1) % m;
                 if (st.hlen[n] < m) st.hlen[n] += 1;
             }
+            #pragma unroll 8
             for (int d = 0; d < D; ++d) {
                 st.x[n + d * ld] = st.xt[n + d * ld];
                 st.g[n + d * ld] = -grad[n + d * ld];
@@ -350,6 +356,7 @@ __global__ __launch_bounds__(256) void lbfgs_step_kernel(LbfgsState st, const do
     if (!done && need_dir) {
         // projected gradient -> scr (pg), two-loop recursion in dir
         double pgmax = 0.0, pgn2 = 0.0;
+        #pragma unroll 8
         for (int d = 0; d < D; ++d) {
             double v = st.g[n + d * ld];
             const double xv = st.x[n + d * ld];
@@ -373,8 +380,10 @@ __global__ __launch_bounds__(256) void lbfgs_step_kernel(LbfgsState st, const do
                     const double* Sh = st.Sh + (long)idx * D * ld;
                     const double* Yh = st.Yh + (long)idx * D * ld;
                     double dot = 0.0;
+                    #pragma unroll 8
                     for (int d = 0; d < D; ++d) dot += Sh[n + d * ld] * st.dir[n + d * ld];
                     al[h] = st.rho[(long)idx * ld + n] * dot;
+                    #pragma unroll 8
                     for (int d = 0; d < D; ++d) st.dir[n + d * ld] -= al[h] * Yh[n + d * ld];
                 }
             }
@@ -384,6 +393,7 @@ __global__ __launch_bounds__(256) void lbfgs_step_kernel(LbfgsState st, const do
                 const double* Sh = st.Sh + (long)idx * D * ld;
                 const double* Yh = st.Yh + (long)idx * D * ld;
                 double sy = 0.0, yy = 0.0;
+                #pragma unroll 8
                 for (int d = 0; d < D; ++d) {
                     sy += Sh[n + d * ld] * Yh[n + d * ld];
                     yy += Yh[n + d * ld] * Yh[n + d * ld];
@@ -393,6 +403,7 @@ __global__ __launch_bounds__(256) void lbfgs_step_kernel(LbfgsState st, const do
                 const double nn = sqrt(pgn2);
                 gamma = 1.0 / (nn > 1.0 ? nn : 1.0);
             }
+            #pragma unroll 8
             for (int d = 0; d < D; ++d) st.dir[n + d * ld] *= gamma;
 #pragma unroll
             for (int h = 7; h >= 0; --h) {
@@ -401,12 +412,15 @@ __global__ __launch_bounds__(256) void lbfgs_step_kernel(LbfgsState st, const do
                     const double* Sh = st.Sh + (long)idx * D * ld;
                     const double* Yh = st.Yh + (long)idx * D * ld;
                     double dot = 0.0;
+                    #pragma unroll 8
                     for (int d = 0; d < D; ++d) dot += Yh[n + d * ld] * st.dir[n + d * ld];
                     const double beta = st.rho[(long)idx * ld + n] * dot;
+                    #pragma unroll 8
                     for (int d = 0; d < D; ++d) st.dir[n + d * ld] += Sh[n + d * ld] * (al[h] - beta);
                 }
             }
             double gd = 0.0;
+            #pragma unroll 8
             for (int d = 0; d < D; ++d) {
                 const double pg = st.scr[n + d * ld];
                 const double dv = (pg == 0.0) ? 0.0 : -st.dir[n + d * ld];
@@ -418,6 +432,7 @@ __global__ __launch_bounds__(256) void lbfgs_step_kernel(LbfgsState st, const do
                 const double nn = sqrt(pgn2);
                 gamma = 1.0 / (nn > 1.0 ? nn : 1.0);
                 gd = 0.0;
+                #pragma unroll 8
                 for (int d = 0; d < D; ++d) {
                     const double pg = st.scr[n + d * ld];
                     const double dv = -gamma * pg;
@@ -432,6 +447,7 @@ __global__ __launch_bounds__(256) void lbfgs_step_kernel(LbfgsState st, const do
     }
     // propose the next trial point
     const double t = st.t[n];
+    #pragma unroll 8
     for (int d = 0; d < D; ++d) {
         double v = st.x[n + d * ld];
         if (!done) {

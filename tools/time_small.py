@@ -9,12 +9,12 @@ for (D, N, S, nl) in ((32, 90, 10, 320), (8, 30, 10, 80), (1, 20, 100, 50)):
     starts = synth_candidates(oracle, D, S)
     gp = m.GP(ctx, X, y, theta, b, 1)
     res = {}
-    for flag in ("0", "1"):
+    for flag in os.environ.get("SLS_TIME_FLAGS", "0,1").split(","):
         os.environ["SLS_USE_GRAPH"] = flag
         gp.acq_maximize(starts, nl)
         t0 = time.perf_counter()
         for _ in range(3): r = gp.acq_maximize(starts, nl)
         res[flag] = ((time.perf_counter() - t0) / 3 * 1e3, r)
-    same = np.array_equal(res["0"][1]["x_stars"], res["1"][1]["x_stars"]) and np.array_equal(res["0"][1]["y_stars"], res["1"][1]["y_stars"])
-    print(f"D={D} N={N} S={S} n_local={nl}: eager {res['0'][0]:.2f} ms  graph {res['1'][0]:.2f} ms  identical={same}")
+    same = all(np.array_equal(res[k][1]["x_stars"], res["0"][1]["x_stars"]) for k in res)
+    print(f"D={D} N={N} S={S} n_local={nl}: " + "  ".join(f"{k}:{v[0]:.2f}ms" for k, v in res.items()) + f"  identical={same}")
     gp.close()
