@@ -172,7 +172,7 @@ struct sls_gp {
     int D = 0, N = 0, Np = 0, Dp = 0, Dcols = 0, kernel = 0;
     double a = 0, b = 0;
     std::vector<double> theta, Xh, yh;
-    DBuf X, y, inv_ell, XT, XaT, nx, L, Linv, Kinv, alpha, tvec, mu_data, scal;
+    DBuf X, y, inv_ell, XT, XaT, nx, L, Linv, Kinv, alpha, tvec, mu_data, scal, gemv_part;
     long* d_idx = nullptr;
     int best_index = 0;
     double mu_best = 0, logdet = 0;
@@ -214,7 +214,7 @@ static void gp_fit_device(sls_gp* g) {
         launch_lauum(c->stream, g->Linv.p, Np, g->Kinv.p);
     }
     // alpha = Linv^T (Linv y);  mu at the data points = y - b alpha;  x_best = first argmax  (regressor.cpp:29-43 hoisted)
-    launch_gemv_n(c->stream, g->Linv.p, Np, g->y.p, g->tvec.p);
+    launch_gemv_n(c->stream, g->Linv.p, Np, g->y.p, g->tvec.p, g->gemv_part.p);
     launch_gemv_t(c->stream, g->Linv.p, Np, g->tvec.p, g->alpha.p);
     launch_scale_rows(c->stream, g->XT.p, g->alpha.p, g->XaT.p, Np, Np, g->Dcols);
     launch_mu_data(c->stream, g->y.p, g->alpha.p, g->b, N, g->mu_data.p);
@@ -251,6 +251,7 @@ static void gp_setup(sls_gp* g) {
     g->XT.ensure(Np * g->Dcols); g->XaT.ensure(Np * g->Dcols); g->nx.ensure(Np);
     g->L.ensure(Np * Np); g->Linv.ensure(Np * Np); g->Kinv.ensure(Np * Np);
     g->alpha.ensure(Np); g->tvec.ensure(Np); g->mu_data.ensure(Np); g->scal.ensure(8);
+    g->gemv_part.ensure((Np / 128) * Np);
     g->ws_chunk = 0;   // the evaluation workspace depends on Np
     if (!g->d_idx) SLS_HIP(hipMalloc((void**)&g->d_idx, 64));
     std::vector<double> il(g->Dcols, 0.0), ypad(Np, 0.0);
@@ -286,6 +287,7 @@ extern "C" int sls_gp_create(sls_ctx* ctx, const double* X, int D, int N, const 
 
 extern "C" int sls_gp_refit_dev(sls_gp* g, const double* X_dev, const double* y_dev) {
     SLS_TRY
+    if (g) (void)hipSetDevice(g->ctx->device);   // the handle's device, whatever the caller's current device is
     SLS_REQUIRE(g && X_dev && y_dev, "sls_gp_refit_dev: NULL argument");
     sls_ctx* c = g->ctx;
     SLS_HIP(hipMemcpyAsync(g->X.p, X_dev, (size_t)g->D * g->N * 8, hipMemcpyDeviceToDevice, c->stream));
@@ -312,6 +314,7 @@ extern "C" int sls_gp_get_summary(sls_gp* g, int* best_index, double* mu_best, d
 
 extern "C" int sls_gp_get_matrix(sls_gp* g, int what, double* out) {
     SLS_TRY
+    if (g) (void)hipSetDevice(g->ctx->device);   // the handle's device, whatever the caller's current device is
     SLS_REQUIRE(g && out, "sls_gp_get_matrix: NULL argument");
     sls_ctx* c = g->ctx;
     const int N = g->N, Np = g->Np;
@@ -444,6 +447,7 @@ static void download_cm(sls_gp* g, const double* dev, int M, int Mp, int rows, d
 
 extern "C" int sls_gp_predict(sls_gp* g, const double* Xs, int M, double* mu, double* sigma) {
     SLS_TRY
+    if (g) (void)hipSetDevice(g->ctx->device);   // the handle's device, whatever the caller's current device is
     SLS_REQUIRE(g && Xs && M >= 0, "sls_gp_predict: bad argument");
     if (M == 0) return SLS_OK;
     const int Mp = round_up(M, 128);
@@ -459,6 +463,7 @@ extern "C" int sls_gp_predict(sls_gp* g, const double* Xs, int M, double* mu, do
 
 extern "C" int sls_gp_predict_grad(sls_gp* g, const double* Xs, int M, double* dmu, double* dsigma) {
     SLS_TRY
+    if (g) (void)hipSetDevice(g->ctx->device);   // the handle's device, whatever the caller's current device is
     SLS_REQUIRE(g && Xs && M >= 0, "sls_gp_predict_grad: bad argument");
     if (M == 0) return SLS_OK;
     const int Mp = round_up(M, 128), D = g->D;
@@ -474,6 +479,7 @@ extern "C" int sls_gp_predict_grad(sls_gp* g, const double* Xs, int M, double* d
 
 extern "C" int sls_acq_eval(sls_gp* g, int acq_type, double ucb_h, const double* Xs, int M, double* val, double* grad) {
     SLS_TRY
+    if (g) (void)hipSetDevice(g->ctx->device);   // the handle's device, whatever the caller's current device is
     SLS_REQUIRE(g && Xs && M >= 0, "sls_acq_eval: bad argument");
     SLS_REQUIRE(acq_type == SLS_ACQ_EXPECTED_IMPROVEMENT || acq_type == SLS_ACQ_GP_UCB, "unknown acquisition type %d", acq_type);
     if (M == 0) return SLS_OK;
@@ -601,6 +607,7 @@ extern "C" int sls_acq_maximize(sls_gp* g, int acq_type, double ucb_h, const dou
                                 const sls_lbfgs_opts* opts, long start_index_offset, double* x_out, double* val_out,
                                 long* idx_out, double* x_stars, double* y_stars) {
     SLS_TRY
+    if (g) (void)hipSetDevice(g->ctx->device);   // the handle's device, whatever the caller's current device is
     SLS_REQUIRE(g && starts, "sls_acq_maximize: NULL argument");
     SLS_REQUIRE(S >= 1, "sls_acq_maximize: need S >= 1");
     sls_ctx* c = g->ctx;
@@ -620,6 +627,7 @@ static void check_pair(sls_gp* g, sls_gp* gs) {
 extern "C" int sls_acq_maximize_pair(sls_gp* g, sls_gp* gs, int acq_type, double ucb_h, const double* starts, int S, int n_local,
                                      const sls_lbfgs_opts* opts, double* x_out, double* val_out, long* idx_out) {
     SLS_TRY
+    if (g) (void)hipSetDevice(g->ctx->device);   // the handle's device, whatever the caller's current device is
     check_pair(g, gs);
     SLS_REQUIRE(starts && S >= 1, "sls_acq_maximize_pair: bad argument");
     sls_ctx* c = g->ctx;
@@ -633,6 +641,7 @@ extern "C" int sls_acq_maximize_pair(sls_gp* g, sls_gp* gs, int acq_type, double
 extern "C" int sls_acq_eval_pair(sls_gp* g, sls_gp* gs, int acq_type, double ucb_h, const double* Xs, int M, double* val,
                                  double* grad) {
     SLS_TRY
+    if (g) (void)hipSetDevice(g->ctx->device);   // the handle's device, whatever the caller's current device is
     check_pair(g, gs);
     SLS_REQUIRE(Xs && M >= 0, "sls_acq_eval_pair: bad argument");
     SLS_REQUIRE(acq_type == SLS_ACQ_EXPECTED_IMPROVEMENT || acq_type == SLS_ACQ_GP_UCB, "unknown acquisition type %d", acq_type);
@@ -651,6 +660,7 @@ extern "C" int sls_acq_maximize_dev(sls_gp* g, int acq_type, double ucb_h, const
                                     const sls_lbfgs_opts* opts, long start_index_offset, double* x_out, double* val_out,
                                     long* idx_out) {
     SLS_TRY
+    if (g) (void)hipSetDevice(g->ctx->device);   // the handle's device, whatever the caller's current device is
     SLS_REQUIRE(g && starts_dev, "sls_acq_maximize_dev: NULL argument");
     maximize_impl(g, nullptr, acq_type, ucb_h, starts_dev, S, n_local, opts, start_index_offset, x_out, val_out, idx_out, nullptr,
                   nullptr);
@@ -786,6 +796,7 @@ extern "C" int sls_potri(sls_ctx* c, const double* L, int N, double* Ainv) {
 // the handle is rebuilt from scratch on the device instead (same results).
 extern "C" int sls_gp_append_point(sls_gp* g, const double* x, double y_new) {
     SLS_TRY
+    if (g) (void)hipSetDevice(g->ctx->device);   // the handle's device, whatever the caller's current device is
     SLS_REQUIRE(g && x, "sls_gp_append_point: NULL argument");
     sls_ctx* c = g->ctx;
     const int D = g->D, N = g->N, Np = g->Np;
@@ -811,8 +822,8 @@ extern "C" int sls_gp_append_point(sls_gp* g, const double* x, double y_new) {
                       nullptr, nullptr);
     // Ks[n + i*128], n = 0 -> stride-128 gather into a dense vector (padding rows i >= N are 0)
     SLS_HIP(hipMemcpy2DAsync(kvec, 8, g->Ks.p, 128 * 8, 8, Np, hipMemcpyDeviceToDevice, c->stream));
-    launch_gemv_n(c->stream, g->Kinv.p, Np, kvec, uvec);     // u = K^-1 k   (padding: identity block x 0 = 0)
-    launch_gemv_n(c->stream, g->Linv.p, Np, kvec, lvec);     // l = L^-1 k
+    launch_gemv_n(c->stream, g->Kinv.p, Np, kvec, uvec, g->gemv_part.p);     // u = K^-1 k   (padding: identity block x 0 = 0)
+    launch_gemv_n(c->stream, g->Linv.p, Np, kvec, lvec, g->gemv_part.p);     // l = L^-1 k
     launch_append_dots(c->stream, kvec, uvec, lvec, g->y.p, N, scal);
     const double kappa = g->a + g->b;
     launch_append_update(c->stream, g->Kinv.p, g->L.p, g->Linv.p, g->alpha.p, Np, N, uvec, lvec, scal, kappa, y_new);

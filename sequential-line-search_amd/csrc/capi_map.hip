@@ -22,7 +22,7 @@ using namespace slsk;
 struct sls_nll {
     sls_ctx* ctx = nullptr;
     int D = 0, N = 0, Np = 0, Dp = 0, Dcols = 0, kernel = 0;
-    DBuf X, y, inv_ell, XT, nx, L, Linv, Kinv, alpha, tvec, G, Y, svec, ones, parts, scal, gl;
+    DBuf X, y, inv_ell, XT, nx, L, Linv, Kinv, alpha, tvec, G, Y, svec, ones, parts, scal, gl, gemv_part;
     std::vector<double> cached_theta;
     double cached_b = -1.0;
     bool have_factor = false;
@@ -42,7 +42,7 @@ extern "C" int sls_nll_create(sls_ctx* ctx, const double* X, int D, int N, int k
     h->XT.ensure(Np * h->Dcols); h->nx.ensure(Np);
     h->L.ensure(Np * Np); h->Linv.ensure(Np * Np); h->Kinv.ensure(Np * Np);
     h->alpha.ensure(Np); h->tvec.ensure(Np); h->svec.ensure(Np); h->ones.ensure(Np);
-    h->scal.ensure(8); h->gl.ensure(h->Dcols);
+    h->scal.ensure(8); h->gl.ensure(h->Dcols); h->gemv_part.ensure((Np / 128) * Np);
     SLS_HIP(hipMemcpyAsync(h->X.p, X, (size_t)D * N * 8, hipMemcpyHostToDevice, ctx->stream));
     launch_fill(ctx->stream, h->ones.p, Np, 1.0);
     launch_fill(ctx->stream, h->y.p, Np, 0.0);
@@ -103,7 +103,7 @@ static void nll_eval_impl(sls_nll* h, const double* y, const double* theta, doub
     SLS_REQUIRE(b >= 0.0, "noise level must be >= 0");
     nll_factor(h, theta, b);
     SLS_HIP(hipMemcpyAsync(h->y.p, y, (size_t)N * 8, hipMemcpyHostToDevice, c->stream));
-    launch_gemv_n(c->stream, h->Linv.p, Np, h->y.p, h->tvec.p);
+    launch_gemv_n(c->stream, h->Linv.p, Np, h->y.p, h->tvec.p, h->gemv_part.p);
     launch_gemv_t(c->stream, h->Linv.p, Np, h->tvec.p, h->alpha.p);
     const bool want_grad = grad_theta || grad_b;
     const int nt = Np / 128;
@@ -119,7 +119,7 @@ static void nll_eval_impl(sls_nll* h, const double* y, const double* theta, doub
     launch_nll_scalars(c->stream, h->parts.p, want_grad ? nt * nt : 0, h->alpha.p, h->y.p, h->Kinv.p, Np, N, h->scal.p);
     std::vector<double> gl(D, 0.0);
     if (grad_theta) {
-        launch_gemv_n(c->stream, h->G.p, Np, h->ones.p, h->svec.p);
+        launch_gemv_n(c->stream, h->G.p, Np, h->ones.p, h->svec.p, h->gemv_part.p);
         launch_gemm_plain(c->stream, h->G.p, Np, false, h->XT.p, Np, true, h->Y.p, Np, nt, h->Dcols / 128, Np, 1.0, 0.0);
         launch_lengthscale_grad(c->stream, h->XT.p, h->Y.p, h->svec.p, h->inv_ell.p, Np, N, D, h->gl.p);
         SLS_HIP(hipMemcpyAsync(gl.data(), h->gl.p, (size_t)D * 8, hipMemcpyDeviceToHost, c->stream));
@@ -140,6 +140,7 @@ static void nll_eval_impl(sls_nll* h, const double* y, const double* theta, doub
 extern "C" int sls_nll_eval(sls_nll* h, const double* y, const double* theta, double b, double* quad, double* logdet,
                             double* alpha, double* grad_theta, double* grad_b) {
     SLS_TRY
+    if (h) (void)hipSetDevice(h->ctx->device);   // the handle's device, whatever the caller's current device is
     SLS_REQUIRE(h, "sls_nll_eval: NULL handle");
     nll_eval_impl(h, y, theta, b, quad, logdet, alpha, grad_theta, grad_b);
     SLS_CATCH
@@ -154,6 +155,7 @@ static double log_lognormal_d(double x, double mu, double s2) { return (mu - s2 
 
 extern "C" int sls_gp_nll_grad(sls_nll* h, const double* y, const double* x, double* value, double* grad) {
     SLS_TRY
+    if (h) (void)hipSetDevice(h->ctx->device);   // the handle's device, whatever the caller's current device is
     SLS_REQUIRE(h && y && x, "sls_gp_nll_grad: NULL argument");
     const int D = h->D, N = h->N;
     // priors: src/gaussian-process-regressor.cpp:18-24
@@ -193,6 +195,7 @@ static void btl_derivative(const double* f, int n, double s, double* d) {
 extern "C" int sls_pref_objective(sls_nll* h, const unsigned* prefs_flat, const int* pref_offsets, int n_prefs, const double* x,
                                   const sls_pref_cfg* cfg, double* value, double* grad) {
     SLS_TRY
+    if (h) (void)hipSetDevice(h->ctx->device);   // the handle's device, whatever the caller's current device is
     SLS_REQUIRE(h && x && cfg && (n_prefs == 0 || (prefs_flat && pref_offsets)), "sls_pref_objective: NULL argument");
     const int D = h->D, M = h->N;
     const bool use_map = cfg->use_map_hyperparams != 0;

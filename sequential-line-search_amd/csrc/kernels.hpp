@@ -89,7 +89,8 @@ void launch_diag_inverse(hipStream_t s, const double* L, int Np, double* Linv);
 void launch_lauum(hipStream_t s, const double* Linv, int Np, double* Kinv);
 // B (Np x Rp, ld = Np, Rp multiple of 128) <- (L L^T)^-1 B using the block inverses in Linv's diagonal
 void launch_potrs(hipStream_t s, const double* L, const double* Linv, int Np, double* B, int Rp);
-void launch_gemv_n(hipStream_t s, const double* A, int Np, const double* x, double* y);   // y = A x
+// y = A x; `part` is a caller-owned scratch of (Np/128) * Np doubles (per-chunk partial sums, reduced in fixed order)
+void launch_gemv_n(hipStream_t s, const double* A, int Np, const double* x, double* y, double* part);
 void launch_gemv_t(hipStream_t s, const double* A, int Np, const double* x, double* y);   // y = A^T x
 void launch_zero_upper(hipStream_t s, double* A, int Np);
 void launch_fill(hipStream_t s, double* p, long n, double v);

@@ -462,17 +462,8 @@ __global__ __launch_bounds__(256) void gemv_n_reduce_kernel(const double* __rest
     for (int c = 0; c < chunks; ++c) s += part[(long)c * Np + i];
     y[i] = s;
 }
-void launch_gemv_n(hipStream_t s, const double* A, int Np, const double* x, double* y) {
-    // scratch for the partials: thread-safe enough for one context per process / stream-ordered reuse
-    static double* part = nullptr;
-    static size_t part_n = 0;
+void launch_gemv_n(hipStream_t s, const double* A, int Np, const double* x, double* y, double* part) {
     const int chunks = Np / 128;                 // 128 columns per chunk
-    const size_t need = (size_t)chunks * Np;
-    if (need > part_n) {
-        if (part) (void)hipFree(part);
-        (void)hipMalloc((void**)&part, need * sizeof(double));
-        part_n = need;
-    }
     hipLaunchKernelGGL(gemv_n_partial_kernel, dim3((Np + 255) / 256, chunks), dim3(256), 0, s, A, Np, x, part, 128);
     hipLaunchKernelGGL(gemv_n_reduce_kernel, dim3((Np + 255) / 256), dim3(256), 0, s, part, Np, chunks, y);
 }
