@@ -6,6 +6,8 @@
 //   -> PredictMu/Sigma/MuDerivative/SigmaDerivative (gaussian-process-regressor.cpp:234-272,
 //      preference-regressor.cpp:293-330) -> CalcSmallK / CalcSmallKSmallXDerivative (regressor.cpp:45-59,91-108)
 // and the multi-start loop (src/acquisition-function.cpp:121-153).
+#include <cstdlib>
+
 #include "gemm_f64.hpp"
 #include "kernels.hpp"
 #include "../../include/sls_hip.h"
@@ -20,7 +22,7 @@ template <bool MATERN>
 __global__ __launch_bounds__(256, 2) void acq_gemm_kernel(const double* __restrict__ Ks, const double* __restrict__ Cs, long ldk,
                                                           int Sp, const double* __restrict__ Kinv, int Np,
                                                           double* __restrict__ P, double* __restrict__ kw_part,
-                                                          double* __restrict__ cw_part) {
+                                                          double* __restrict__ cw_part, int stagger) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
     const int ntm = Sp / GEMM_BM, ntn = Np / GEMM_BN;
@@ -38,7 +40,7 @@ __global__ __launch_bounds__(256, 2) void acq_gemm_kernel(const double* __restri
     // slab within the same microsecond; the L2 does not merge those misses (hit rate 0.34-0.43, 40-46 GB of fabric reads
     // per launch).  Starting tile (tm, tn) (tm&7 + tn&7) slabs into the k loop (and wrapping) makes the sharers arrive one
     // slab-time apart: hit rate 0.67, fabric reads halved, same kernel time (gemm_probe, PMC TCC_HIT/MISS, FETCH_SIZE).
-    const int ks = (Np >= 2048) ? ((tm & 7) + (tn & 7)) * GEMM_BK : 0;
+    const int ks = stagger ? ((tm & 7) + (tn & 7)) * GEMM_BK : 0;
     gemm_tile<false, false>(acc, Ks + m0, ldk, Kinv + n0, (long)Np, 0, Np, lds, ks);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double skw[4], scw[4];
@@ -95,12 +97,18 @@ void launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk
         attr = true;
     }
     const int nt = (Sp / GEMM_BM) * (Np / GEMM_BN);
+    static int stagger_env = -1;
+    if (stagger_env < 0) {
+        const char* e = getenv("SLS_STAGGER");
+        stagger_env = e ? atoi(e) : 1;
+    }
+    const int stagger = (stagger_env && Np >= 2048) ? 1 : 0;
     if (Cs != Ks)
         hipLaunchKernelGGL(acq_gemm_kernel<true>, dim3(nt), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, Ks, Cs, ldk, Sp, Kinv, Np, P,
-                           kw_part, cw_part);
+                           kw_part, cw_part, stagger);
     else
         hipLaunchKernelGGL(acq_gemm_kernel<false>, dim3(nt), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, Ks, Cs, ldk, Sp, Kinv, Np, P,
-                           kw_part, cw_part);
+                           kw_part, cw_part, stagger);
 }
 
 // ---------------------------------------------------------------------------------------------------------
