@@ -79,6 +79,25 @@ def cpu_baseline(args, kernel_id):
     }
 
 
+def stage_rooflines(prof, N, D, Np, cand, matern):
+    """Secondary kernels against their own bound (algorithmic bytes / flops of DESIGN.md 4 per launch group)."""
+    def per_launch_ms(name):
+        ms, n = prof[name]
+        return ms / n if n else float("nan")
+    out = {}
+    t = per_launch_ms("cross_gram")          # writes K* (and C*): 8 N S_c bytes each; HBM-write bound
+    out["cross_gram"] = {"bound": "hbm", "achieved_GBps": (2 if matern else 1) * 8.0 * N * cand / (t * 1e-3) / 1e9, "peak_GBps": 8000.0}
+    t = per_launch_ms("grad_gemm")           # reads P and C*: 16 N S_c bytes; 4 N D S_c flops
+    out["grad_gemm"] = {"bound": "hbm", "achieved_GBps": 16.0 * N * cand / (t * 1e-3) / 1e9, "peak_GBps": 8000.0,
+                        "achieved_TFLOPs": 4.0 * N * D * cand / (t * 1e-3) / 1e12}
+    t = per_launch_ms("gram")                # writes the lower triangle of K_y: 4 N^2 bytes
+    out["gram"] = {"bound": "hbm", "achieved_GBps": 4.0 * N * N / (t * 1e-3) / 1e9, "peak_GBps": 8000.0}
+    for name, flops in (("potrf", N ** 3 / 3.0), ("trtri", 2.0 * N ** 3 / 3.0), ("lauum", N ** 3 / 3.0)):
+        t = per_launch_ms(name)
+        out[name] = {"bound": "mfma", "achieved_TFLOPs": flops / (t * 1e-3) / 1e12, "peak_TFLOPs": PEAK_FP64_MFMA_TFLOPS}
+    return out
+
+
 def main():
     args = parse()
     import torch
@@ -176,6 +195,7 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches": gemm_launches, "flops_per_launch": flops_per_launch},
             "stage_ms_per_step": {n: prof[n][0] / args.steps for n in names},
+            "stage_rooflines": stage_rooflines(prof, N, D, Np, cand_per_launch, args.kernel == "matern52"),
             "result": {"best_value": res["value"], "best_index": int(res["index"])},
         }
         if world == 1 and not args.no_cpu_baseline:
