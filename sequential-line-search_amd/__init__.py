@@ -217,6 +217,23 @@ class GP:
                                    C.byref(idx), _p(xs) if want_all else None, _p(ys) if want_all else None))
         return dict(index=idx.value, x=x, value=val.value, x_stars=xs, y_stars=ys)
 
+    def acq_eval_pair(self, sigma_gp, Xs, acq=ACQ_EI, ucb_h=1.0, want_grad=True):
+        """objective_for_multiple_points: mean (and mu+) from this handle, deviation from `sigma_gp`."""
+        Xs = _f(Xs)
+        M = Xs.shape[1]
+        val = np.empty(M)
+        grad = np.empty((self.D, M), order="F") if want_grad else None
+        _ck(lib().sls_acq_eval_pair(self.h, sigma_gp.h, int(acq), C.c_double(ucb_h), _p(Xs), M, _p(val),
+                                    _p(grad) if want_grad else None))
+        return (val, grad) if want_grad else val
+
+    def acq_maximize_pair(self, sigma_gp, starts, n_local, acq=ACQ_EI, ucb_h=1.0):
+        starts = _f(starts)
+        x, val, idx = np.empty(self.D), C.c_double(), C.c_long()
+        _ck(lib().sls_acq_maximize_pair(self.h, sigma_gp.h, int(acq), C.c_double(ucb_h), _p(starts), starts.shape[1], int(n_local),
+                                        None, _p(x), C.byref(val), C.byref(idx)))
+        return dict(index=idx.value, x=x, value=val.value)
+
     def acq_maximize_dev(self, starts_dev_ptr, S, n_local, acq=ACQ_EI, ucb_h=1.0, offset=0, opts=None):
         x, val, idx = np.empty(self.D), C.c_double(), C.c_long()
         _ck(lib().sls_acq_maximize_dev(self.h, int(acq), C.c_double(ucb_h), C.c_void_p(starts_dev_ptr), int(S), int(n_local),

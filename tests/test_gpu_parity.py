@@ -424,3 +424,41 @@ def test_append_point_equals_refit(ctx, oracle, kernel, N0):
     oref = oracle.Regressor(X, y, theta, b, kernel=kernel)
     close(gp.predict(Xs)[1], oref.predict_batch(Xs)[1], rtol=1e-6, atol=1e-9)
     gp.close(); ref.close()
+
+
+@pytest.mark.parametrize("acq", [0, 1])
+def test_pair_objective_of_find_next_points(ctx, oracle, acq):
+    """objective_for_multiple_points (src/acquisition-function.cpp:63-110): mu, mu+ from the original regressor, sigma from
+    the variance-updated dummy regressor.  Composed here from two oracle regressors with the mathtoolbox EI formula."""
+    from scipy.special import erfc
+    D, N = 3, 35
+    X, y, theta, b = synth_problem(oracle, D, N)
+    extra = synth_candidates(oracle, D, 2, seed=99)
+    X2 = np.concatenate([X, extra], axis=1)
+    y2 = np.concatenate([y, [0.3, 0.1]])
+    g1 = sls().GP(ctx, X, y, theta, b, 1)
+    g2 = sls().GP(ctx, X2, y2, theta, b, 1)
+    r1 = oracle.Regressor(X, y, theta, b, kernel=1)
+    r2 = oracle.Regressor(X2, y2, theta, b, kernel=1)
+    Xs = synth_candidates(oracle, D, 70)
+    mu, _ = r1.predict_batch(Xs)
+    _, sg = r2.predict_batch(Xs)
+    dmu, _ = r1.predict_grad_batch(Xs)
+    _, dsg = r2.predict_grad_batch(Xs)
+    if acq == 0:
+        mu_best = r1.predict_batch(r1.predict_maximum_point_from_data()[1][:, None])[0][0]
+        u = (mu - mu_best) / sg
+        Phi, phi = 0.5 * erfc(-u / np.sqrt(2)), np.exp(-0.5 * u * u) / np.sqrt(2 * np.pi)
+        vo, go = (mu - mu_best) * Phi + sg * phi, Phi * dmu + phi * dsg
+    else:
+        vo, go = mu + 1.7 * sg, dmu + 1.7 * dsg
+    v, g = g1.acq_eval_pair(g2, Xs, acq, 1.7)
+    close(v, vo, rtol=RTOL, atol=1e-12)
+    close(g, go, rtol=RTOL, atol=1e-9 * np.abs(go).max())
+    # near the appended points the dummy regressor's deviation collapses, so the pair objective avoids them
+    ve = g1.acq_eval_pair(g2, extra, acq, 1.7, want_grad=False)
+    vs = g1.acq_eval(extra, acq, 1.7, want_grad=False)
+    assert np.all(ve < vs)
+    r = g1.acq_maximize_pair(g2, Xs[:, :32], 10, acq, 1.7)
+    assert r["value"] >= v[:32].max() - 1e-15
+    g1.close(); g2.close()
