@@ -79,6 +79,14 @@ def cpu_baseline(args, kernel_id):
     }
 
 
+def baseline_metric():
+    """BASELINE.json's metric string, verbatim (value = its candidate-evals/sec part, ms_per_step = its step-time part)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:
+        return "GP-fit+acq-max step time (ms) and candidate-evals/sec at N=8192 D=64"
+
+
 def stage_rooflines(prof, N, D, Np, cand, matern):
     """Secondary kernels against their own bound (algorithmic bytes / flops of DESIGN.md 4 per launch group)."""
     def per_launch_ms(name):
@@ -184,7 +192,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "candidate_evals_per_sec (GP-fit + multi-start EI acq-max step, N=8192 D=64)",
+            "metric": baseline_metric(),
             "value": evals / (ms_per_step * 1e-3), "unit": "candidate-evals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
