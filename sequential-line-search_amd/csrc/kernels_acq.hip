@@ -485,7 +485,7 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const double* __restrict__
     si[threadIdx.x] = bi;
     __syncthreads();
     for (int s = 512; s > 0; s >>= 1) {
-        if (threadIdx.x < s) {
+        if ((int)threadIdx.x < s) {
             const double ov = sv[threadIdx.x + s];
             const int oi = si[threadIdx.x + s];
             if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) {

@@ -580,7 +580,7 @@ __global__ __launch_bounds__(256) void logdet_kernel(const double* __restrict__ 
     red[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
     if (threadIdx.x == 0) out[0] = 2.0 * red[0];
