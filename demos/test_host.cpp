@@ -2,6 +2,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <iostream>
+#include <thread>
 #include <sequential-line-search/acquisition-function.hpp>
 #include <sequential-line-search/gaussian-process-regressor.hpp>
 #include <sequential-line-search/preference-data-manager.hpp>
@@ -110,6 +111,29 @@ int main()
         // empty regressor: acquisition value 0 (src/acquisition-function.cpp:176-179)
         GaussianProcessRegressor empty(MatrixXd(0, 0), VectorXd(0));
         EXPECT(acquisition_func::CalcAcquisitionValue(empty, VectorXd::Constant(1, 0.3), AcquisitionFuncType::ExpectedImprovement) == 0.0);
+    }
+    // ---- the reference calls the const predictors from many worker threads on ONE regressor
+    //      (src/acquisition-function.cpp:125-144): concurrent calls must give the sequential answers ----
+    {
+        const int      D = 3, N = 50, T = 8, M = 40;
+        const MatrixXd X = RandomPoints(D, N);
+        VectorXd       y(N), theta(D + 1);
+        for (int i = 0; i < N; ++i) y(i) = std::cos(2.0 * X(0, i)) - X(1, i);
+        theta(0) = 0.5; theta(1) = 0.4; theta(2) = 0.5; theta(3) = 0.6;
+        GaussianProcessRegressor gp(X, y, theta, 0.01);
+        const MatrixXd           Q = RandomPoints(D, T * M);
+        std::vector<double>      seq(T * M), par(T * M);
+        for (int i = 0; i < T * M; ++i) seq[i] = acquisition_func::CalcAcquisitionValue(gp, eig::Col(Q, i), AcquisitionFuncType::ExpectedImprovement) + gp.PredictSigma(eig::Col(Q, i));
+        std::vector<std::thread> workers;
+        for (int t = 0; t < T; ++t)
+            workers.emplace_back([&, t]() {
+                for (int i = t * M; i < (t + 1) * M; ++i)
+                    par[i] = acquisition_func::CalcAcquisitionValue(gp, eig::Col(Q, i), AcquisitionFuncType::ExpectedImprovement) + gp.PredictSigma(eig::Col(Q, i));
+            });
+        for (auto& w : workers) w.join();
+        bool same = true;
+        for (int i = 0; i < T * M; ++i) same = same && (seq[i] == par[i]);
+        EXPECT(same);
     }
     // ---- GP MAP: 1-D BO reaches the known optimum of 1 - 1.5 x sin(13 x) ----
     {

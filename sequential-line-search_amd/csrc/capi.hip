@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 
 #include "common.hpp"
 #include "kernels.hpp"
@@ -104,6 +105,8 @@ extern "C" int sls_ctx_destroy(sls_ctx* ctx) {
 
 extern "C" int sls_ctx_set_stream(sls_ctx* ctx, void* hip_stream) {
     SLS_TRY
+    std::unique_lock<std::recursive_mutex> lock_;
+    if (ctx) lock_ = std::unique_lock<std::recursive_mutex>(ctx->mtx);
     SLS_REQUIRE(ctx, "ctx is NULL");
     SLS_HIP(hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
@@ -111,6 +114,8 @@ extern "C" int sls_ctx_set_stream(sls_ctx* ctx, void* hip_stream) {
 }
 extern "C" int sls_ctx_synchronize(sls_ctx* ctx) {
     SLS_TRY
+    std::unique_lock<std::recursive_mutex> lock_;
+    if (ctx) lock_ = std::unique_lock<std::recursive_mutex>(ctx->mtx);
     SLS_REQUIRE(ctx, "ctx is NULL");
     SLS_HIP(hipStreamSynchronize(ctx->stream));
     SLS_CATCH
@@ -268,6 +273,8 @@ static void gp_setup(sls_gp* g) {
 extern "C" int sls_gp_create(sls_ctx* ctx, const double* X, int D, int N, const double* y, const double* theta, double b,
                              int kernel, sls_gp** out) {
     SLS_TRY
+    std::unique_lock<std::recursive_mutex> lock_;
+    if (ctx) lock_ = std::unique_lock<std::recursive_mutex>(ctx->mtx);
     SLS_REQUIRE(ctx && out, "sls_gp_create: NULL argument");
     SLS_REQUIRE(D >= 1 && N >= 1, "sls_gp_create: need D >= 1 and N >= 1 (got D=%d N=%d)", D, N);
     SLS_REQUIRE(X && y, "sls_gp_create: X / y is NULL");
@@ -287,7 +294,11 @@ extern "C" int sls_gp_create(sls_ctx* ctx, const double* X, int D, int N, const 
 
 extern "C" int sls_gp_refit_dev(sls_gp* g, const double* X_dev, const double* y_dev) {
     SLS_TRY
-    if (g) (void)hipSetDevice(g->ctx->device);   // the handle's device, whatever the caller's current device is
+    std::unique_lock<std::recursive_mutex> lock_;
+    if (g) {
+        lock_ = std::unique_lock<std::recursive_mutex>(g->ctx->mtx);
+        (void)hipSetDevice(g->ctx->device);   // the handle's device, whatever the caller's current device is
+    }
     SLS_REQUIRE(g && X_dev && y_dev, "sls_gp_refit_dev: NULL argument");
     sls_ctx* c = g->ctx;
     SLS_HIP(hipMemcpyAsync(g->X.p, X_dev, (size_t)g->D * g->N * 8, hipMemcpyDeviceToDevice, c->stream));
@@ -314,7 +325,11 @@ extern "C" int sls_gp_get_summary(sls_gp* g, int* best_index, double* mu_best, d
 
 extern "C" int sls_gp_get_matrix(sls_gp* g, int what, double* out) {
     SLS_TRY
-    if (g) (void)hipSetDevice(g->ctx->device);   // the handle's device, whatever the caller's current device is
+    std::unique_lock<std::recursive_mutex> lock_;
+    if (g) {
+        lock_ = std::unique_lock<std::recursive_mutex>(g->ctx->mtx);
+        (void)hipSetDevice(g->ctx->device);   // the handle's device, whatever the caller's current device is
+    }
     SLS_REQUIRE(g && out, "sls_gp_get_matrix: NULL argument");
     sls_ctx* c = g->ctx;
     const int N = g->N, Np = g->Np;
@@ -447,7 +462,11 @@ static void download_cm(sls_gp* g, const double* dev, int M, int Mp, int rows, d
 
 extern "C" int sls_gp_predict(sls_gp* g, const double* Xs, int M, double* mu, double* sigma) {
     SLS_TRY
-    if (g) (void)hipSetDevice(g->ctx->device);   // the handle's device, whatever the caller's current device is
+    std::unique_lock<std::recursive_mutex> lock_;
+    if (g) {
+        lock_ = std::unique_lock<std::recursive_mutex>(g->ctx->mtx);
+        (void)hipSetDevice(g->ctx->device);   // the handle's device, whatever the caller's current device is
+    }
     SLS_REQUIRE(g && Xs && M >= 0, "sls_gp_predict: bad argument");
     if (M == 0) return SLS_OK;
     const int Mp = round_up(M, 128);
@@ -463,7 +482,11 @@ extern "C" int sls_gp_predict(sls_gp* g, const double* Xs, int M, double* mu, do
 
 extern "C" int sls_gp_predict_grad(sls_gp* g, const double* Xs, int M, double* dmu, double* dsigma) {
     SLS_TRY
-    if (g) (void)hipSetDevice(g->ctx->device);   // the handle's device, whatever the caller's current device is
+    std::unique_lock<std::recursive_mutex> lock_;
+    if (g) {
+        lock_ = std::unique_lock<std::recursive_mutex>(g->ctx->mtx);
+        (void)hipSetDevice(g->ctx->device);   // the handle's device, whatever the caller's current device is
+    }
     SLS_REQUIRE(g && Xs && M >= 0, "sls_gp_predict_grad: bad argument");
     if (M == 0) return SLS_OK;
     const int Mp = round_up(M, 128), D = g->D;
@@ -479,7 +502,11 @@ extern "C" int sls_gp_predict_grad(sls_gp* g, const double* Xs, int M, double* d
 
 extern "C" int sls_acq_eval(sls_gp* g, int acq_type, double ucb_h, const double* Xs, int M, double* val, double* grad) {
     SLS_TRY
-    if (g) (void)hipSetDevice(g->ctx->device);   // the handle's device, whatever the caller's current device is
+    std::unique_lock<std::recursive_mutex> lock_;
+    if (g) {
+        lock_ = std::unique_lock<std::recursive_mutex>(g->ctx->mtx);
+        (void)hipSetDevice(g->ctx->device);   // the handle's device, whatever the caller's current device is
+    }
     SLS_REQUIRE(g && Xs && M >= 0, "sls_acq_eval: bad argument");
     SLS_REQUIRE(acq_type == SLS_ACQ_EXPECTED_IMPROVEMENT || acq_type == SLS_ACQ_GP_UCB, "unknown acquisition type %d", acq_type);
     if (M == 0) return SLS_OK;
@@ -607,7 +634,11 @@ extern "C" int sls_acq_maximize(sls_gp* g, int acq_type, double ucb_h, const dou
                                 const sls_lbfgs_opts* opts, long start_index_offset, double* x_out, double* val_out,
                                 long* idx_out, double* x_stars, double* y_stars) {
     SLS_TRY
-    if (g) (void)hipSetDevice(g->ctx->device);   // the handle's device, whatever the caller's current device is
+    std::unique_lock<std::recursive_mutex> lock_;
+    if (g) {
+        lock_ = std::unique_lock<std::recursive_mutex>(g->ctx->mtx);
+        (void)hipSetDevice(g->ctx->device);   // the handle's device, whatever the caller's current device is
+    }
     SLS_REQUIRE(g && starts, "sls_acq_maximize: NULL argument");
     SLS_REQUIRE(S >= 1, "sls_acq_maximize: need S >= 1");
     sls_ctx* c = g->ctx;
@@ -627,7 +658,11 @@ static void check_pair(sls_gp* g, sls_gp* gs) {
 extern "C" int sls_acq_maximize_pair(sls_gp* g, sls_gp* gs, int acq_type, double ucb_h, const double* starts, int S, int n_local,
                                      const sls_lbfgs_opts* opts, double* x_out, double* val_out, long* idx_out) {
     SLS_TRY
-    if (g) (void)hipSetDevice(g->ctx->device);   // the handle's device, whatever the caller's current device is
+    std::unique_lock<std::recursive_mutex> lock_;
+    if (g) {
+        lock_ = std::unique_lock<std::recursive_mutex>(g->ctx->mtx);
+        (void)hipSetDevice(g->ctx->device);   // the handle's device, whatever the caller's current device is
+    }
     check_pair(g, gs);
     SLS_REQUIRE(starts && S >= 1, "sls_acq_maximize_pair: bad argument");
     sls_ctx* c = g->ctx;
@@ -641,7 +676,11 @@ extern "C" int sls_acq_maximize_pair(sls_gp* g, sls_gp* gs, int acq_type, double
 extern "C" int sls_acq_eval_pair(sls_gp* g, sls_gp* gs, int acq_type, double ucb_h, const double* Xs, int M, double* val,
                                  double* grad) {
     SLS_TRY
-    if (g) (void)hipSetDevice(g->ctx->device);   // the handle's device, whatever the caller's current device is
+    std::unique_lock<std::recursive_mutex> lock_;
+    if (g) {
+        lock_ = std::unique_lock<std::recursive_mutex>(g->ctx->mtx);
+        (void)hipSetDevice(g->ctx->device);   // the handle's device, whatever the caller's current device is
+    }
     check_pair(g, gs);
     SLS_REQUIRE(Xs && M >= 0, "sls_acq_eval_pair: bad argument");
     SLS_REQUIRE(acq_type == SLS_ACQ_EXPECTED_IMPROVEMENT || acq_type == SLS_ACQ_GP_UCB, "unknown acquisition type %d", acq_type);
@@ -660,7 +699,11 @@ extern "C" int sls_acq_maximize_dev(sls_gp* g, int acq_type, double ucb_h, const
                                     const sls_lbfgs_opts* opts, long start_index_offset, double* x_out, double* val_out,
                                     long* idx_out) {
     SLS_TRY
-    if (g) (void)hipSetDevice(g->ctx->device);   // the handle's device, whatever the caller's current device is
+    std::unique_lock<std::recursive_mutex> lock_;
+    if (g) {
+        lock_ = std::unique_lock<std::recursive_mutex>(g->ctx->mtx);
+        (void)hipSetDevice(g->ctx->device);   // the handle's device, whatever the caller's current device is
+    }
     SLS_REQUIRE(g && starts_dev, "sls_acq_maximize_dev: NULL argument");
     maximize_impl(g, nullptr, acq_type, ucb_h, starts_dev, S, n_local, opts, start_index_offset, x_out, val_out, idx_out, nullptr,
                   nullptr);
@@ -670,6 +713,8 @@ extern "C" int sls_acq_maximize_dev(sls_gp* g, int acq_type, double ucb_h, const
 // ---- free functions ----------------------------------------------------------------------------------------------
 extern "C" int sls_gram(sls_ctx* c, const double* X, int D, int N, const double* theta, double b, int kernel, double* K_out) {
     SLS_TRY
+    std::unique_lock<std::recursive_mutex> lock_;
+    if (c) lock_ = std::unique_lock<std::recursive_mutex>(c->mtx);
     SLS_REQUIRE(c && X && K_out && D >= 1 && N >= 1, "sls_gram: bad argument");
     check_theta(theta, D);
     SLS_HIP(hipSetDevice(c->device));
@@ -690,6 +735,8 @@ extern "C" int sls_gram(sls_ctx* c, const double* X, int D, int N, const double*
 extern "C" int sls_gram_cross(sls_ctx* c, const double* X, int D, int N, const double* Xs, int M, const double* theta, int kernel,
                               double* Ks_out) {
     SLS_TRY
+    std::unique_lock<std::recursive_mutex> lock_;
+    if (c) lock_ = std::unique_lock<std::recursive_mutex>(c->mtx);
     SLS_REQUIRE(c && X && Xs && Ks_out && D >= 1 && N >= 1 && M >= 1, "sls_gram_cross: bad argument");
     check_theta(theta, D);
     SLS_HIP(hipSetDevice(c->device));
@@ -732,6 +779,8 @@ static void upload_padded_spd(sls_ctx* c, DBuf& A, const double* src, int N, int
 
 extern "C" int sls_potrf(sls_ctx* c, double* A, int N) {
     SLS_TRY
+    std::unique_lock<std::recursive_mutex> lock_;
+    if (c) lock_ = std::unique_lock<std::recursive_mutex>(c->mtx);
     SLS_REQUIRE(c && A && N >= 1, "sls_potrf: bad argument");
     SLS_HIP(hipSetDevice(c->device));
     const int Np = round_up(N, 128);
@@ -754,6 +803,8 @@ extern "C" int sls_potrf(sls_ctx* c, double* A, int N) {
 
 extern "C" int sls_potrs(sls_ctx* c, const double* L, int N, double* B, int nrhs) {
     SLS_TRY
+    std::unique_lock<std::recursive_mutex> lock_;
+    if (c) lock_ = std::unique_lock<std::recursive_mutex>(c->mtx);
     SLS_REQUIRE(c && L && B && N >= 1 && nrhs >= 1, "sls_potrs: bad argument");
     SLS_HIP(hipSetDevice(c->device));
     const int Np = round_up(N, 128), Rp = round_up(nrhs, 128);
@@ -773,6 +824,8 @@ extern "C" int sls_potrs(sls_ctx* c, const double* L, int N, double* B, int nrhs
 
 extern "C" int sls_potri(sls_ctx* c, const double* L, int N, double* Ainv) {
     SLS_TRY
+    std::unique_lock<std::recursive_mutex> lock_;
+    if (c) lock_ = std::unique_lock<std::recursive_mutex>(c->mtx);
     SLS_REQUIRE(c && L && Ainv && N >= 1, "sls_potri: bad argument");
     SLS_HIP(hipSetDevice(c->device));
     const int Np = round_up(N, 128);
@@ -796,7 +849,11 @@ extern "C" int sls_potri(sls_ctx* c, const double* L, int N, double* Ainv) {
 // the handle is rebuilt from scratch on the device instead (same results).
 extern "C" int sls_gp_append_point(sls_gp* g, const double* x, double y_new) {
     SLS_TRY
-    if (g) (void)hipSetDevice(g->ctx->device);   // the handle's device, whatever the caller's current device is
+    std::unique_lock<std::recursive_mutex> lock_;
+    if (g) {
+        lock_ = std::unique_lock<std::recursive_mutex>(g->ctx->mtx);
+        (void)hipSetDevice(g->ctx->device);   // the handle's device, whatever the caller's current device is
+    }
     SLS_REQUIRE(g && x, "sls_gp_append_point: NULL argument");
     sls_ctx* c = g->ctx;
     const int D = g->D, N = g->N, Np = g->Np;

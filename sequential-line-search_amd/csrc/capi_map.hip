@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <mutex>
 
 #include "common.hpp"
 #include "kernels.hpp"
@@ -31,6 +32,8 @@ struct sls_nll {
 
 extern "C" int sls_nll_create(sls_ctx* ctx, const double* X, int D, int N, int kernel, sls_nll** out) {
     SLS_TRY
+    std::unique_lock<std::recursive_mutex> lock_;
+    if (ctx) lock_ = std::unique_lock<std::recursive_mutex>(ctx->mtx);
     SLS_REQUIRE(ctx && X && out && D >= 1 && N >= 1, "sls_nll_create: bad argument");
     SLS_REQUIRE(kernel == SLS_KERNEL_ARD_SQUARED_EXPONENTIAL || kernel == SLS_KERNEL_ARD_MATERN52, "unknown kernel %d", kernel);
     SLS_HIP(hipSetDevice(ctx->device));
@@ -140,7 +143,11 @@ static void nll_eval_impl(sls_nll* h, const double* y, const double* theta, doub
 extern "C" int sls_nll_eval(sls_nll* h, const double* y, const double* theta, double b, double* quad, double* logdet,
                             double* alpha, double* grad_theta, double* grad_b) {
     SLS_TRY
-    if (h) (void)hipSetDevice(h->ctx->device);   // the handle's device, whatever the caller's current device is
+    std::unique_lock<std::recursive_mutex> lock_;
+    if (h) {
+        lock_ = std::unique_lock<std::recursive_mutex>(h->ctx->mtx);
+        (void)hipSetDevice(h->ctx->device);   // the handle's device, whatever the caller's current device is
+    }
     SLS_REQUIRE(h, "sls_nll_eval: NULL handle");
     nll_eval_impl(h, y, theta, b, quad, logdet, alpha, grad_theta, grad_b);
     SLS_CATCH
@@ -155,7 +162,11 @@ static double log_lognormal_d(double x, double mu, double s2) { return (mu - s2 
 
 extern "C" int sls_gp_nll_grad(sls_nll* h, const double* y, const double* x, double* value, double* grad) {
     SLS_TRY
-    if (h) (void)hipSetDevice(h->ctx->device);   // the handle's device, whatever the caller's current device is
+    std::unique_lock<std::recursive_mutex> lock_;
+    if (h) {
+        lock_ = std::unique_lock<std::recursive_mutex>(h->ctx->mtx);
+        (void)hipSetDevice(h->ctx->device);   // the handle's device, whatever the caller's current device is
+    }
     SLS_REQUIRE(h && y && x, "sls_gp_nll_grad: NULL argument");
     const int D = h->D, N = h->N;
     // priors: src/gaussian-process-regressor.cpp:18-24
@@ -195,7 +206,11 @@ static void btl_derivative(const double* f, int n, double s, double* d) {
 extern "C" int sls_pref_objective(sls_nll* h, const unsigned* prefs_flat, const int* pref_offsets, int n_prefs, const double* x,
                                   const sls_pref_cfg* cfg, double* value, double* grad) {
     SLS_TRY
-    if (h) (void)hipSetDevice(h->ctx->device);   // the handle's device, whatever the caller's current device is
+    std::unique_lock<std::recursive_mutex> lock_;
+    if (h) {
+        lock_ = std::unique_lock<std::recursive_mutex>(h->ctx->mtx);
+        (void)hipSetDevice(h->ctx->device);   // the handle's device, whatever the caller's current device is
+    }
     SLS_REQUIRE(h && x && cfg && (n_prefs == 0 || (prefs_flat && pref_offsets)), "sls_pref_objective: NULL argument");
     const int D = h->D, M = h->N;
     const bool use_map = cfg->use_map_hyperparams != 0;

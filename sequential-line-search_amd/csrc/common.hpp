@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -67,6 +68,9 @@ struct ProfEntry {
 }  // namespace slsk
 
 struct sls_ctx {
+    // One stream, one info word, one profiling table per context: every entry point that touches the device takes this
+    // lock, so a context (and all handles created from it) may be used from several host threads, one call at a time.
+    std::recursive_mutex mtx;
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
