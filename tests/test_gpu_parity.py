@@ -462,3 +462,28 @@ def test_pair_objective_of_find_next_points(ctx, oracle, acq):
     r = g1.acq_maximize_pair(g2, Xs[:, :32], 10, acq, 1.7)
     assert r["value"] >= v[:32].max() - 1e-15
     g1.close(); g2.close()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_randomised_configurations(ctx, oracle, seed):
+    """Random problem shapes / hyper-parameters (ragged sizes, anisotropic length scales, noise from 1e-6 to 1e-1)."""
+    rng = np.random.default_rng(1000 + seed)
+    D = int(rng.integers(1, 40)); N = int(rng.integers(2, 400)); M = int(rng.integers(1, 300)); kernel = int(rng.integers(0, 2))
+    X = rng.uniform(0, 1, (D, N))
+    y = np.sin(X.sum(axis=0) * rng.uniform(1, 4)) + 0.05 * rng.normal(size=N)
+    theta = np.concatenate([[rng.uniform(0.1, 2.0)], rng.uniform(0.2, 1.5, D) * np.sqrt(max(D, 4) / 4.0)])
+    b = float(10 ** rng.uniform(-6, -1))
+    Xs = rng.uniform(-0.1, 1.1, (D, M))
+    gp = sls().GP(ctx, X, y, theta, b, kernel)
+    ref = oracle.Regressor(X, y, theta, b, kernel=kernel)
+    mu, sg = gp.predict(Xs); muo, sgo = ref.predict_batch(Xs)
+    scale = max(np.abs(muo).max(), 1e-30)
+    close(mu, muo, rtol=RTOL, atol=1e-6 * scale)
+    close(sg, sgo, rtol=1e-5, atol=1e-7 * np.sqrt(theta[0]))       # sigma^2 = a - k.K^-1 k cancels to ~b: kappa * eps floor
+    for acq, h in ((0, 1.0), (1, 0.7)):
+        v, g = gp.acq_eval(Xs, acq, h); vo, go = ref.acq_eval_batch(Xs, acq, h)
+        close(v, vo, rtol=1e-5, atol=1e-7 * max(np.abs(vo).max(), 1e-30))
+        finite = np.isfinite(go)
+        assert np.array_equal(np.isfinite(g), finite)
+        close(g[finite], go[finite], rtol=1e-4, atol=1e-6 * max(np.abs(go[finite]).max(), 1e-30))
+    gp.close()

@@ -1,0 +1,52 @@
+"""All five BASELINE.json configs on one MI355X (C4 itself is bench.py): wall-clock timings -> profiles/r01_configs.json."""
+import json, os, re, subprocess, sys, time
+import numpy as np
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.join(R, "tests")); sys.path.insert(0, R)
+from util import sls, synth_problem, synth_candidates
+from oracle import oracle_py as oracle
+m = sls(); ctx = m.Context(0)
+BIN = os.path.join(R, "sequential-line-search_amd", "bin")
+out = {}
+
+def wall(f, reps=3):
+    f(); ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps): f()
+    ctx.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+# C1: bayesian_optimization_1d, 20 iterations (GP MAP fit + EI maximisation per iteration)
+t0 = time.perf_counter()
+p = subprocess.run([os.path.join(BIN, "bayesian_optimization_1d"), "1", "20", "1"], capture_output=True, text=True)
+mm = re.search(r"maximizer ([-\d.e]+) maximum ([-\d.e]+)", p.stdout)
+out["C1_bayesian_optimization_1d_20_iterations"] = {"wall_s": time.perf_counter() - t0, "maximizer": float(mm.group(1)), "maximum": float(mm.group(2)),
+                                                    "true_optimum": [0.852733, 2.273928]}
+# C2: N=2048, D=16, ARD-SE: Gram + Cholesky (+ inverse, alpha) + 4096-point predict
+D, N, M = 16, 2048, 4096
+X, y, theta, b = synth_problem(oracle, D, N); Xs = synth_candidates(oracle, D, M)
+gp = m.GP(ctx, X, y, theta, b, 0)
+out["C2_gp_fit_predict_N2048_D16_M4096"] = {"fit_ms_wall_incl_upload": wall(lambda: m.GP(ctx, X, y, theta, b, 0).close()),
+                                            "predict_ms_wall_incl_pcie": wall(lambda: gp.predict(Xs))}
+t0 = time.perf_counter(); ref = oracle.Regressor(X, y, theta, b, kernel=0); t1 = time.perf_counter(); ref.predict_batch(Xs); t2 = time.perf_counter()
+out["C2_gp_fit_predict_N2048_D16_M4096"]["cpu_oracle_fit_s"] = t1 - t0
+out["C2_gp_fit_predict_N2048_D16_M4096"]["cpu_oracle_predict_s"] = t2 - t1
+gp.close()
+# C3: sequential_line_search_nd D=32, 30 iterations (PreferenceRegressor MAP + EI acquisition per step)
+p = subprocess.run([os.path.join(BIN, "sequential_line_search_nd"), "32", "30", "1"], capture_output=True, text=True)
+ms = [float(v) for v in re.findall(r" ms ([-\d.e]+)", p.stdout)]
+res = [float(v) for v in re.findall(r"residual ([-\d.e]+)", p.stdout)]
+out["C3_sequential_line_search_nd_D32_30_iterations"] = {"ms_per_submit_mean": float(np.mean(ms)), "ms_per_submit_max": float(np.max(ms)),
+                                                         "residual_first": res[0], "residual_last": res[-1]}
+# C5: Matern-5/2 MAP objective + gradient, N=4096, D=128
+D, N = 128, 4096
+X, y, theta, b = synth_problem(oracle, D, N)
+h = m.Nll(ctx, X, 1)
+x = np.concatenate([[0.5, 0.005], np.full(D, theta[1])])
+k = [0]
+def ev():
+    k[0] += 1
+    xx = x.copy(); xx[2] *= (1 + 1e-3 * k[0])
+    h.gp_objective(y, xx)
+out["C5_map_objective_gradient_N4096_D128"] = {"ms_per_evaluation": wall(ev)}
+json.dump(out, open(os.path.join(R, "gpurun_out", "configs.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
