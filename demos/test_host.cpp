@@ -136,25 +136,34 @@ int main()
         EXPECT(same);
     }
     // ---- GP MAP: 1-D BO reaches the known optimum of 1 - 1.5 x sin(13 x) ----
+    // EI with a zero-mean GP can stall in the local optimum x = 0.378 (f = 1.555) for some start sets -- the model is the
+    // reference's; with few points the MAP length scale is long and the model over-confident) -- so the known-answer check
+    // runs 40 iterations over several seeds: most runs must reach the global optimum, none may end below f(0) = 1.
     {
-        utils::SetRandomSeed(1);   // BO with a zero-mean GP can stall in the local optimum x = 0.378 for some start sets
-        MatrixXd X(1, 0);
-        VectorXd y(0);
-        std::shared_ptr<GaussianProcessRegressor> gp;
-        for (int it = 0; it < 20; ++it)
+        int reached = 0;
+        for (int seed = 1; seed <= 6; ++seed)
         {
-            const VectorXd x = (it == 0) ? utils::GenerateRandomVector(1) : acquisition_func::FindNextPoint(*gp);
-            X                = eig::AppendCol(X, x);
-            VectorXd yn(y.size() + 1);
-            for (long i = 0; i < y.size(); ++i) yn(i) = y(i);
-            yn(y.size()) = 1.0 - 1.5 * x(0) * std::sin(13.0 * x(0));
-            y            = yn;
-            gp           = std::make_shared<GaussianProcessRegressor>(X, y);
+            utils::SetRandomSeed(seed);
+            MatrixXd X(1, 0);
+            VectorXd y(0);
+            std::shared_ptr<GaussianProcessRegressor> gp;
+            for (int it = 0; it < 40; ++it)
+            {
+                const VectorXd x = (it == 0) ? utils::GenerateRandomVector(1) : acquisition_func::FindNextPoint(*gp);
+                X                = eig::AppendCol(X, x);
+                VectorXd yn(y.size() + 1);
+                for (long i = 0; i < y.size(); ++i) yn(i) = y(i);
+                yn(y.size()) = 1.0 - 1.5 * x(0) * std::sin(13.0 * x(0));
+                y            = yn;
+                gp           = std::make_shared<GaussianProcessRegressor>(X, y);
+            }
+            const VectorXd xb = gp->PredictMaximumPointFromData();
+            const double   mb = gp->PredictMu(xb);
+            std::cout << "1-D BO seed " << seed << ": x_max " << xb(0) << "  mu " << mb << "  (true 0.852733 / 2.273928)" << std::endl;
+            if (std::abs(xb(0) - 0.852733) < 2e-2 && std::abs(mb - 2.273928) < 2e-2) ++reached;
+            EXPECT(mb > 0.99);   // never worse than the boundary value f(0) = 1
         }
-        const VectorXd xb = gp->PredictMaximumPointFromData();
-        std::cout << "1-D BO: x_max " << xb(0) << "  mu " << gp->PredictMu(xb) << "  (true 0.852733 / 2.273928)" << std::endl;
-        EXPECT(std::abs(xb(0) - 0.852733) < 2e-2);
-        EXPECT(std::abs(gp->PredictMu(xb) - 2.273928) < 2e-2);
+        EXPECT(reached >= 4);   // 40 iterations: measured 6 of 6 (7 of 8 over seeds 1..8); 20 iterations reach it for ~40 % of the seeds
     }
     // ---- data manager: merge semantics of src/preference-data-manager.cpp ----
     {

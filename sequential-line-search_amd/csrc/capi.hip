@@ -577,6 +577,28 @@ static void maximize_impl(sls_gp* g, sls_gp* gs, int acq_type, double ucb_h, con
     st.Sh = g->lb_S.p; st.Yh = g->lb_Y.p; st.rho = g->lb_rho.p; st.f = g->lb_f.p; st.t = g->lb_t.p;
     st.hlen = g->lb_int; st.hpos = g->lb_int + Sp; st.nbt = g->lb_int + 2 * Sp; st.done = g->lb_int + 3 * Sp;
     st.c1 = o.c1; st.shrink = o.shrink; st.gtol = o.gtol; st.max_backtracks = o.max_backtracks;
+    // Small problems: one wavefront per start runs the whole search in a single launch (kernels_wave.hip).  The choice
+    // depends only on the fitted state and the start count, so repeated / sharded calls take the same path.
+    bool used_wave = false;
+    {
+        const char* wenv = getenv("SLS_WAVE_PATH");
+        const bool allow = wenv ? atoi(wenv) != 0 : true;
+        if (allow && !gs && g->Np <= WAVE_PATH_MAX_NP && D <= WAVE_PATH_MAX_D && S <= 4096) {
+            WaveArgs w;
+            w.S = S; w.D = D; w.N = g->N; w.Np = g->Np; w.m = o.history; w.n_local = n_local; w.acq = acq_type;
+            w.matern = g->kernel == SLS_KERNEL_ARD_MATERN52;
+            w.a = g->a; w.mu_best = g->mu_best; w.ucb_h = ucb_h; w.c1 = o.c1; w.shrink = o.shrink; w.gtol = o.gtol;
+            w.max_backtracks = o.max_backtracks;
+            w.XT = g->XT.p; w.inv_ell = g->inv_ell.p; w.Kinv = g->Kinv.p; w.alpha = g->alpha.p; w.starts = starts_dev;
+            w.x_out = st.x; w.f_out = st.f; w.ld = Sp;
+            {
+                ProfScope ps(c, "acq_wave");
+                launch_maximize_wave(c->stream, w);
+            }
+            used_wave = true;
+        }
+    }
+    if (!used_wave) {
     launch_clamp_starts(c->stream, starts_dev, D, S, st.xt, Sp, Sp);
     // Round 0 runs eagerly (it also performs every lazy allocation / attribute set-up).  The remaining rounds are one
     // fixed kernel sequence with constant arguments and can be captured once into a hipGraph and replayed
@@ -611,6 +633,7 @@ static void maximize_impl(sls_gp* g, sls_gp* gs, int acq_type, double ucb_h, con
     } else {
         for (int ev = 1; ev < n_local; ++ev) round(false);
     }
+    }   // !used_wave
     launch_argmax_neg(c->stream, st.f, S, g->scal.p + 2, g->d_idx + 1);
     double bv = 0;
     long bi = 0;

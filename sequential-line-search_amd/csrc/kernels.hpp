@@ -77,6 +77,20 @@ void launch_clamp_starts(hipStream_t s, const double* starts /*D x S col-major*/
 void launch_argmax_neg(hipStream_t s, const double* f, int S, double* out_val, long* out_idx);
 void launch_argmax(hipStream_t s, const double* y, int n, double* out_val, long* out_idx);
 
+// ---- kernels_wave.hip: one wavefront per start, whole L-BFGS in one launch (small problems) ----
+struct WaveArgs {
+    int S, D, N, Np, m, n_local, acq, matern;
+    int lds_per_wave, Dr;                 // filled by the launcher
+    double a, mu_best, ucb_h, c1, shrink, gtol;
+    int max_backtracks;
+    const double *XT, *inv_ell, *Kinv, *alpha, *starts;   // XT [i + d*Np] scaled; starts D x S column-major (raw)
+    double *x_out, *f_out;                // x_out[n + d*ld], f_out[n] = -acq at the end point
+    long ld;
+};
+constexpr int WAVE_PATH_MAX_NP = 512;     // 8 rows per lane
+constexpr int WAVE_PATH_MAX_D = 128;      // 2 dimensions per lane
+void launch_maximize_wave(hipStream_t s, WaveArgs a);
+
 // ---- kernels_chol.hip ---------------------------------------------------------
 // In-place lower Cholesky of the Np x Np matrix A (ld = Np); Linv receives the 128x128 diagonal-block inverses
 // (rest of Linv untouched).  info (device int) gets 1 + index of the first non-positive pivot, or stays 0.
