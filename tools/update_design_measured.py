@@ -17,7 +17,7 @@ new = f'''| quantity (C4: N=8192, D=64, Matern-5/2, 65 536 starts x 50 evals, 1 
 | other stages per step (ms) | cross_gram {st["cross_gram"]:.0f} ({sr.get("cross_gram", {}).get("achieved_GBps", 0)/1e3:.1f} TB/s written, transcendental-bound), grad_gemm {st["grad_gemm"]:.0f} ({sr.get("grad_gemm", {}).get("achieved_GBps", 0)/1e3:.1f} TB/s read), lbfgs {st["lbfgs"]:.0f}, finalize {st["finalize"]:.0f}; fit: gram {st["gram"]:.2f}, potrf {st["potrf"]:.1f} ({sr.get("potrf", {}).get("achieved_TFLOPs", 0):.0f} TFLOP/s, latency-bound diagonal chain), trtri {st["trtri"]:.1f} ({sr.get("trtri", {}).get("achieved_TFLOPs", 0):.0f} TFLOP/s), lauum {st["lauum"]:.1f} ({sr.get("lauum", {}).get("achieved_TFLOPs", 0):.0f} TFLOP/s) |
 | C2 (N=2048, D=16, SE): fit / 4096-point predict | 3.9 ms / 0.9 ms wall incl. PCIe |
 | C5 (N=4096, D=128, Matern): MAP objective + gradient | 8.2 ms per evaluation |
-| C3 (`sequential_line_search_nd 32 30`) | 50-70 ms per `SubmitFeedbackData` (single-tile kernels, ~20 us each: device-latency bound at N <= 90) |
+| C3 (`sequential_line_search_nd 32 30`) | 16 ms per `SubmitFeedbackData` on average (61 ms before the per-start wavefront kernel); C1 (`bayesian_optimization_1d 1 20`): 0.93 s for 20 iterations, dominated by ~240 launch-bound MAP evaluations per fit |
 | parity vs the oracle (`profiles/r01_parity_report.md`) | max relative error 1e-16 .. 3e-11 on mu, sigma, gradients, EI, UCB; chosen maximiser 7e-9 |
 
 '''
