@@ -435,6 +435,25 @@ static void eval_candidates(sls_gp* g, const double* xr, long ldr, int S, const 
     }
 }
 
+// Small problems: one wavefront per query point (kernels_wave.hip, evaluation-only mode) instead of the tiled pipeline.
+// Xs_dev: D x M column-major device copy of the query points; outputs as in EvalOut.
+static bool eval_small(sls_gp* g, const double* Xs_dev, int M, const EvalOut& o) {
+    const char* wenv = getenv("SLS_WAVE_PATH");
+    const bool allow = wenv ? atoi(wenv) != 0 : true;
+    if (!allow || g->Np > WAVE_PATH_MAX_NP || g->D > WAVE_PATH_MAX_D || M > 4096) return false;
+    sls_ctx* c = g->ctx;
+    WaveArgs w;
+    w.S = M; w.D = g->D; w.N = g->N; w.Np = g->Np; w.m = 1; w.n_local = 0; w.acq = o.acq;
+    w.matern = g->kernel == SLS_KERNEL_ARD_MATERN52;
+    w.a = g->a; w.mu_best = g->mu_best; w.ucb_h = o.ucb_h; w.c1 = 0; w.shrink = 0; w.gtol = 0; w.max_backtracks = 0;
+    w.XT = g->XT.p; w.inv_ell = g->inv_ell.p; w.Kinv = g->Kinv.p; w.alpha = g->alpha.p; w.starts = Xs_dev;
+    w.x_out = nullptr; w.f_out = nullptr; w.ld = o.ldo;
+    w.ev_mu = o.mu; w.ev_sigma = o.sigma; w.ev_dmu = o.dmu; w.ev_dsigma = o.dsigma; w.ev_val = o.val; w.ev_grad = o.grad;
+    ProfScope ps(c, "acq_wave");
+    launch_maximize_wave(c->stream, w);
+    return true;
+}
+
 // host D x M column-major -> device candidate-major raw coordinates (clamping is NOT applied here)
 static void upload_candidates(sls_gp* g, const double* Xs, int M, DBuf& raw, int Mp) {
     sls_ctx* c = g->ctx;
@@ -445,6 +464,20 @@ static void upload_candidates(sls_gp* g, const double* Xs, int M, DBuf& raw, int
     raw.ensure((size_t)Mp * D);
     h2d(c, raw.p, t.data(), (size_t)Mp * D);
     sync(c);
+}
+
+// evaluate M host-supplied query points (D x M column-major) into the candidate-major device outputs of `o`
+static void eval_host_points(sls_gp* g, const double* Xs, int M, int Mp, const EvalOut& o) {
+    sls_ctx* c = g->ctx;
+    const char* wenv = getenv("SLS_WAVE_PATH");
+    const bool allow = wenv ? atoi(wenv) != 0 : true;
+    if (allow && g->Np <= WAVE_PATH_MAX_NP && g->D <= WAVE_PATH_MAX_D && M <= 4096) {
+        g->raw.ensure((size_t)g->D * M);
+        h2d(c, g->raw.p, Xs, (size_t)g->D * M);
+        if (eval_small(g, g->raw.p, M, o)) return;
+    }
+    upload_candidates(g, Xs, M, g->raw, Mp);
+    eval_candidates(g, g->raw.p, Mp, M, o);
 }
 
 static void download_cm(sls_gp* g, const double* dev, int M, int Mp, int rows, double* host /* rows x M col-major or M */) {
@@ -470,11 +503,10 @@ extern "C" int sls_gp_predict(sls_gp* g, const double* Xs, int M, double* mu, do
     SLS_REQUIRE(g && Xs && M >= 0, "sls_gp_predict: bad argument");
     if (M == 0) return SLS_OK;
     const int Mp = round_up(M, 128);
-    upload_candidates(g, Xs, M, g->raw, Mp);
     g->outm.ensure(Mp); g->outs.ensure(Mp);
     EvalOut o;
     o.ldo = Mp; o.mu = g->outm.p; o.sigma = g->outs.p;
-    eval_candidates(g, g->raw.p, Mp, M, o);
+    eval_host_points(g, Xs, M, Mp, o);
     if (mu) download_cm(g, g->outm.p, M, Mp, 1, mu);
     if (sigma) download_cm(g, g->outs.p, M, Mp, 1, sigma);
     SLS_CATCH
@@ -490,11 +522,10 @@ extern "C" int sls_gp_predict_grad(sls_gp* g, const double* Xs, int M, double* d
     SLS_REQUIRE(g && Xs && M >= 0, "sls_gp_predict_grad: bad argument");
     if (M == 0) return SLS_OK;
     const int Mp = round_up(M, 128), D = g->D;
-    upload_candidates(g, Xs, M, g->raw, Mp);
     g->outv.ensure((size_t)Mp * D); g->outg.ensure((size_t)Mp * D);
     EvalOut o;
     o.ldo = Mp; o.dmu = g->outv.p; o.dsigma = g->outg.p;
-    eval_candidates(g, g->raw.p, Mp, M, o);
+    eval_host_points(g, Xs, M, Mp, o);
     if (dmu) download_cm(g, g->outv.p, M, Mp, D, dmu);
     if (dsigma) download_cm(g, g->outg.p, M, Mp, D, dsigma);
     SLS_CATCH
@@ -511,12 +542,11 @@ extern "C" int sls_acq_eval(sls_gp* g, int acq_type, double ucb_h, const double*
     SLS_REQUIRE(acq_type == SLS_ACQ_EXPECTED_IMPROVEMENT || acq_type == SLS_ACQ_GP_UCB, "unknown acquisition type %d", acq_type);
     if (M == 0) return SLS_OK;
     const int Mp = round_up(M, 128), D = g->D;
-    upload_candidates(g, Xs, M, g->raw, Mp);
     g->outm.ensure(Mp);
     if (grad) g->outg.ensure((size_t)Mp * D);
     EvalOut o;
     o.ldo = Mp; o.val = g->outm.p; o.grad = grad ? g->outg.p : nullptr; o.acq = acq_type; o.ucb_h = ucb_h;
-    eval_candidates(g, g->raw.p, Mp, M, o);
+    eval_host_points(g, Xs, M, Mp, o);
     if (val) download_cm(g, g->outm.p, M, Mp, 1, val);
     if (grad) download_cm(g, g->outg.p, M, Mp, D, grad);
     SLS_CATCH
@@ -591,6 +621,7 @@ static void maximize_impl(sls_gp* g, sls_gp* gs, int acq_type, double ucb_h, con
             w.max_backtracks = o.max_backtracks;
             w.XT = g->XT.p; w.inv_ell = g->inv_ell.p; w.Kinv = g->Kinv.p; w.alpha = g->alpha.p; w.starts = starts_dev;
             w.x_out = st.x; w.f_out = st.f; w.ld = Sp;
+            w.ev_mu = w.ev_sigma = w.ev_dmu = w.ev_dsigma = w.ev_val = w.ev_grad = nullptr;
             {
                 ProfScope ps(c, "acq_wave");
                 launch_maximize_wave(c->stream, w);

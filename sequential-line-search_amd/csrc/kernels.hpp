@@ -86,6 +86,8 @@ struct WaveArgs {
     const double *XT, *inv_ell, *Kinv, *alpha, *starts;   // XT [i + d*Np] scaled; starts D x S column-major (raw)
     double *x_out, *f_out;                // x_out[n + d*ld], f_out[n] = -acq at the end point
     long ld;
+    // evaluation-only mode (n_local == 0): `starts` holds the M query points; any of these may be NULL
+    double *ev_mu, *ev_sigma, *ev_dmu, *ev_dsigma, *ev_val, *ev_grad;
 };
 constexpr int WAVE_PATH_MAX_NP = 512;     // 8 rows per lane
 constexpr int WAVE_PATH_MAX_D = 128;      // 2 dimensions per lane

@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
     const bool has0 = d0 < D, has1 = d1 < D;
 
     // ---- objective: value and gradient of the acquisition function at xq (lanes over d) ----
+    double last_mu = 0.0, last_sigma = 0.0, last_dm[2] = {0.0, 0.0}, last_ds[2] = {0.0, 0.0};   // predictive parts of the last call
     auto evaluate = [&](const double xq0, const double xq1, double& val, double& gr0, double& gr1) {
         if (has0) xs[d0] = (xq0 - 0.5) * p.inv_ell[d0];
         if (has1) xs[d1] = (xq1 - 0.5) * p.inv_ell[d1];
@@ -133,6 +134,8 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
                 ds[e] = inv_sigma * il * (xs[d] * cw - gs);
             }
         }
+        last_mu = mu; last_sigma = sigma;
+        last_dm[0] = dm[0]; last_dm[1] = dm[1]; last_ds[0] = ds[0]; last_ds[1] = ds[1];
         if (p.acq == SLS_ACQ_EXPECTED_IMPROVEMENT) {
             const double diff = mu - p.mu_best;
             const double u = diff / sigma;
@@ -156,10 +159,33 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
 
     auto clamp01 = [](double v) { return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); };
 
+    double val, gr0, gr1;
+    if (p.n_local == 0) {
+        // evaluation-only mode (sls_gp_predict / sls_gp_predict_grad / sls_acq_eval on small problems): the point is used
+        // as given (predictions are defined outside [0,1]^D too); outputs are candidate-major with leading dimension ld
+        const double q0 = has0 ? p.starts[d0 + (long)n * D] : 0.0, q1 = has1 ? p.starts[d1 + (long)n * D] : 0.0;
+        evaluate(q0, q1, val, gr0, gr1);
+        if (live) {
+            if (lane == 0) {
+                if (p.ev_mu) p.ev_mu[n] = last_mu;
+                if (p.ev_sigma) p.ev_sigma[n] = last_sigma;
+                if (p.ev_val) p.ev_val[n] = val;
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int d = lane + 64 * e;
+                if (d < D) {
+                    if (p.ev_dmu) p.ev_dmu[n + (long)d * p.ld] = last_dm[e];
+                    if (p.ev_dsigma) p.ev_dsigma[n + (long)d * p.ld] = last_ds[e];
+                    if (p.ev_grad) p.ev_grad[n + (long)d * p.ld] = e == 0 ? gr0 : gr1;
+                }
+            }
+        }
+        return;
+    }
     // ---- start ----
     double x0 = has0 ? clamp01(p.starts[d0 + (long)n * D]) : 0.0;
     double x1 = has1 ? clamp01(p.starts[d1 + (long)n * D]) : 0.0;
-    double val, gr0, gr1;
     evaluate(x0, x1, val, gr0, gr1);
     double f = -val, g0 = -gr0, g1 = -gr1;       // minimise phi = -acq
     double dir0 = 0.0, dir1 = 0.0, t = 1.0;

@@ -19,6 +19,14 @@ def ctx():
     c.close()
 
 
+@pytest.fixture(params=["wave", "tiled"])
+def path(request, monkeypatch):
+    """Small problems take the per-point wavefront kernels (kernels_wave.hip) by default; SLS_WAVE_PATH=0 forces the tiled
+    MFMA pipeline that large problems use.  Tests that request this fixture run on both."""
+    monkeypatch.setenv("SLS_WAVE_PATH", "1" if request.param == "wave" else "0")
+    return request.param
+
+
 def close(a, b, rtol=RTOL, atol=0.0):
     np.testing.assert_allclose(np.asarray(a, dtype=float), np.asarray(b, dtype=float), rtol=rtol, atol=atol)
 
@@ -66,7 +74,7 @@ def test_potrf_rejects_indefinite(ctx):
 
 @pytest.mark.parametrize("kernel", [0, 1])
 @pytest.mark.parametrize("D,N,M", [(1, 9, 33), (4, 60, 25), (8, 300, 200), (16, 512, 130)])
-def test_gp_posterior_and_acquisition(ctx, oracle, kernel, D, N, M):
+def test_gp_posterior_and_acquisition(ctx, oracle, kernel, D, N, M, path):
     X, y, theta, b = synth_problem(oracle, D, N)
     Xs = synth_candidates(oracle, D, M)
     Xs[:, 0] = X[:, N // 2]                         # a candidate exactly on a data point (sigma^2 ~ b)
@@ -100,7 +108,7 @@ def test_gp_posterior_and_acquisition(ctx, oracle, kernel, D, N, M):
     gp.close()
 
 
-def test_gp_against_mpmath_fixtures(ctx, fixtures):
+def test_gp_against_mpmath_fixtures(ctx, fixtures, path):
     """The HIP path directly against the independent 50-digit answers (not via the oracle)."""
     for c in fixtures["gp_pipelines"]:
         X, Xs = np.array(c["X"]), np.array(c["Xs"])
@@ -122,7 +130,8 @@ def test_gp_against_mpmath_fixtures(ctx, fixtures):
         gp.close()
 
 
-def test_chunked_evaluation_matches_single_pass(ctx, oracle):
+def test_chunked_evaluation_matches_single_pass(ctx, oracle, monkeypatch):
+    monkeypatch.setenv("SLS_WAVE_PATH", "0")          # the chunk loop belongs to the tiled pipeline
     X, y, theta, b = synth_problem(oracle, 6, 200)
     Xs = synth_candidates(oracle, 6, 700)
     gp = sls().GP(ctx, X, y, theta, b, 1)
@@ -136,7 +145,7 @@ def test_chunked_evaluation_matches_single_pass(ctx, oracle):
 
 @pytest.mark.parametrize("kernel", [0, 1])
 @pytest.mark.parametrize("acq", [0, 1])
-def test_multistart_maximizer_matches_oracle(ctx, oracle, kernel, acq):
+def test_multistart_maximizer_matches_oracle(ctx, oracle, kernel, acq, path):
     D, N, S, n_local = 5, 120, 96, 25
     X, y, theta, b = synth_problem(oracle, D, N)
     starts = synth_candidates(oracle, D, S)
@@ -273,7 +282,7 @@ def test_nll_core_terms(ctx, oracle):
 
 # ---- edge cases (empty / ragged / maximum sizes / duplicates) ----------------------------------------------
 
-def test_single_data_point_and_single_candidate(ctx, oracle):
+def test_single_data_point_and_single_candidate(ctx, oracle, path):
     X = np.array([[0.3], [0.7]])
     y = np.array([1.25])
     theta = np.array([0.5, 0.4, 0.6])
@@ -330,7 +339,7 @@ def test_noiseless_formulation_b_zero(ctx, oracle):
     gp.close()
 
 
-def test_candidates_outside_the_unit_box_and_ragged_counts(ctx, oracle):
+def test_candidates_outside_the_unit_box_and_ragged_counts(ctx, oracle, path):
     D, N = 4, 33
     X, y, theta, b = synth_problem(oracle, D, N)
     gp = sls().GP(ctx, X, y, theta, b, 1)
@@ -350,7 +359,7 @@ def test_candidates_outside_the_unit_box_and_ragged_counts(ctx, oracle):
     gp.close()
 
 
-def test_high_dimension_and_ard(ctx, oracle):
+def test_high_dimension_and_ard(ctx, oracle, path):
     D, N, M = 128, 150, 64
     X, y, theta, b = synth_problem(oracle, D, N)
     theta[1:] *= np.linspace(0.5, 2.0, D)
@@ -468,7 +477,7 @@ def test_pair_objective_of_find_next_points(ctx, oracle, acq):
 
 
 @pytest.mark.parametrize("seed", range(10))
-def test_randomised_configurations(ctx, oracle, seed):
+def test_randomised_configurations(ctx, oracle, seed, path):
     """Random problem shapes / hyper-parameters (ragged sizes, anisotropic length scales, noise from 1e-6 to 1e-1)."""
     rng = np.random.default_rng(1000 + seed)
     D = int(rng.integers(1, 40)); N = int(rng.integers(2, 400)); M = int(rng.integers(1, 300)); kernel = int(rng.integers(0, 2))
