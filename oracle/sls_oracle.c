@@ -363,8 +363,14 @@ void slso_regressor_free(slso_regressor* r) {
 static void apply_Kinv_as_written(const slso_regressor* r, const double* v, double* out) {
     const int N = r->N;
     if (r->reg_type == SLSO_REG_GPR && r->Kinv) {
-        /* m_K_y_inv * v in the row form Eigen evaluates: (K_inv v)_i = sum_k K_inv(i,k) v_k */
-        for (int i = 0; i < N; ++i) { double s = 0.0; for (int k = 0; k < N; ++k) s += r->Kinv[i + (long)k * N] * v[k]; out[i] = s; }
+        /* m_K_y_inv * v as a column-major GEMV (column axpy sweeps, the traversal Eigen's product kernel uses; a
+           row-wise dot form would stride by N and mis-state the reference's CPU cost) */
+        for (int i = 0; i < N; ++i) out[i] = 0.0;
+        for (int k = 0; k < N; ++k) {
+            const double vk = v[k];
+            const double* col = r->Kinv + (long)k * N;
+            for (int i = 0; i < N; ++i) out[i] += col[i] * vk;
+        }
     } else {
         memcpy(out, v, sizeof(double) * (size_t)N);
         slso_chol_solve(r->L, N, out, 1);          /* m_K_llt.solve(v) */
