@@ -32,13 +32,16 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=2)
     p.add_argument("--warmup", type=int, default=1)
-    p.add_argument("--n", type=int, default=8192, help="training points N")
-    p.add_argument("--d", type=int, default=64, help="dimensions D")
+    p.add_argument("--n", "--num-train", dest="n", type=int, default=8192, help="training points N")
+    p.add_argument("--d", "--dims", dest="d", type=int, default=64, help="dimensions D")
     p.add_argument("--starts", type=int, default=65536, help="total multi-start count S (split over ranks)")
     p.add_argument("--n-local", type=int, default=50, help="objective evaluations per start")
     p.add_argument("--kernel", choices=["matern52", "se"], default="matern52")
     p.add_argument("--chunk", type=int, default=16384, help="candidates per device pass")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                   help="collective backend; gloo + --same-device exercises the N>1 path on a 1-GPU box (tests only)")
+    p.add_argument("--same-device", action="store_true", help="all ranks use GPU 0 (tests only; never a bench line)")
     return p.parse_args()
 
 
@@ -117,11 +120,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    xdev = dev if args.backend == "nccl" else None      # gloo exchanges host tensors
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     sls = importlib.import_module("sequential-line-search_amd")
     kernel_id = sls.KERNEL_MATERN52 if args.kernel == "matern52" else sls.KERNEL_SE
@@ -143,7 +152,7 @@ def main():
         gp.refit_dev(X_dev.data_ptr(), y_dev.data_ptr())
         r = gp.acq_maximize_dev(starts_dev.data_ptr(), S_loc, args.n_local, sls.ACQ_EI, 1.0, offset=lo)
         if world > 1:
-            v, i, x = sls.exchange_best(r["value"], r["index"], r["x"], device=dev)   # the single RCCL exchange of the step
+            v, i, x = sls.exchange_best(r["value"], r["index"], r["x"], device=xdev)   # the single RCCL exchange of the step
             return dict(value=v, index=i, x=x)
         return r
 
@@ -164,7 +173,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=xdev if xdev is not None else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     names = ["gram", "potrf", "trtri", "lauum", "cross_gram", "acq_gemm", "grad_gemm", "finalize", "lbfgs"]
@@ -186,7 +195,7 @@ def main():
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_acq_gemm.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and chunk == 16384 and (N, D) == (8192, 64):   # the PMC pass measured this launch shape
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:
@@ -204,8 +213,10 @@ def main():
                          "avg_launch_ms": avg_ms, "launches": gemm_launches, "flops_per_launch": flops_per_launch},
             "stage_ms_per_step": {n: prof[n][0] / args.steps for n in names},
             "stage_rooflines": stage_rooflines(prof, N, D, Np, cand_per_launch, args.kernel == "matern52"),
-            "result": {"best_value": res["value"], "best_index": int(res["index"])},
+            "result": {"best_value": res["value"], "best_index": int(res["index"]), "best_x": [float(v) for v in res["x"]]},
         }
+        if args.same_device or args.backend != "nccl":
+            out["config"]["test_mode"] = "ranks share GPU 0 over gloo: not a bench line"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, kernel_id)
         print(json.dumps(out))

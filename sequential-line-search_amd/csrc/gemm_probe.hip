@@ -1,4 +1,4 @@
-// tiny probe for PMC / variant runs: gemm_probe M N K mode  (mode 0: plain, 1: staggered k start).  A 2-slab-deep register prefetch was tried and spills (256 VGPRs, 22 TFLOP/s).
+// tiny probe for PMC / variant runs: gemm_probe M N K mode  (mode 0: plain, 1: k start staggered by (tm&7)+(tn&7) slabs, 2: (tm+tn)&7, 3: 2((tm+tn)&7), 4: 2((tm&7)+(tn&7))).  A 2-slab-deep register prefetch was tried and spills (256 VGPRs, 22 TFLOP/s).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -19,9 +19,12 @@ __global__ __launch_bounds__(256, 2) void probe_kernel(const double* __restrict_
     const int m0 = tm * 128, n0 = tn * 128;
     Acc acc;
     acc.zero();
-    const int ks = ((tm & 7) + (tn & 7)) * GEMM_BK;
+    int ks = ((tm & 7) + (tn & 7)) * GEMM_BK;
+    if (MODE == 2) ks = ((tm + tn) & 7) * GEMM_BK;
+    if (MODE == 3) ks = ((tm + tn) & 7) * 2 * GEMM_BK;
+    if (MODE == 4) ks = ((tm & 7) + (tn & 7)) * 2 * GEMM_BK;
     if (MODE == 0) gemm_tile<false, false>(acc, A + m0, lda, B + n0, ldb, 0, K, lds);
-    if (MODE == 1) gemm_tile<false, false>(acc, A + m0, lda, B + n0, ldb, 0, K, lds, ks);
+    else gemm_tile<false, false>(acc, A + m0, lda, B + n0, ldb, 0, K, lds, ks);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -54,5 +57,8 @@ int main(int argc, char** argv) {
     for (size_t off = 0; off < (size_t)N * K; off += h.size()) hipMemcpy(dB + off, h.data(), std::min(h.size(), (size_t)N * K - off) * 8, hipMemcpyHostToDevice);
     if (mode == 0) run<0>(M, N, K, dA, dB, dC);
     if (mode == 1) run<1>(M, N, K, dA, dB, dC);
+    if (mode == 2) run<2>(M, N, K, dA, dB, dC);
+    if (mode == 3) run<3>(M, N, K, dA, dB, dC);
+    if (mode == 4) run<4>(M, N, K, dA, dB, dC);
     return 0;
 }

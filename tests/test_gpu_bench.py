@@ -1,0 +1,48 @@
+"""bench.py contract and its N>1 code path, on the 1-GPU box.
+
+Two ranks are launched through torch.distributed.run exactly as the driver does, but share GPU 0 and exchange over gloo
+(RCCL refuses two ranks on one device). Everything else -- sharding of the starts, per-rank maximisation with the global
+start offset, the single exchange, the first-maximum merge, max-over-ranks timing, the JSON line -- is the bench's own code.
+The merged winner must equal the single-rank answer over all starts.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# long option names: torch.distributed.run would prefix-match "--n" / "--d" against its own options
+SMALL = ["--num-train", "640", "--dims", "8", "--starts", "3000", "--n-local", "8", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline"]
+
+
+def run(cmd):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_line_contract_and_two_rank_merge():
+    one = run([sys.executable, "bench.py", "--gpus", "1"] + SMALL)
+    for k in REQUIRED:
+        assert k in one, k
+    assert one["n_gpus"] == 1 and one["dtype"] == "f64" and one["scaling"] == "strong" and one["vs_baseline"] is None
+    assert one["unit"] == "candidate-evals/s" and one["value"] > 0 and one["higher_is_better"] is True
+    r = one["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert "workload" in one["config"]
+
+    two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", "29617", "bench.py", "--gpus", "2", "--backend", "gloo", "--same-device"] + SMALL)
+    assert two["n_gpus"] == 2 and two["config"]["starts_per_gpu"] == 1500 and "test_mode" in two["config"]
+    assert two["result"]["best_index"] == one["result"]["best_index"]
+    assert two["result"]["best_value"] == one["result"]["best_value"]
+    np.testing.assert_array_equal(two["result"]["best_x"], one["result"]["best_x"])

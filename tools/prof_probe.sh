@@ -17,7 +17,7 @@ per = defaultdict(float); last = 0
 for f in glob.glob("$OUT/p$i/*.db"):
     c = sqlite3.connect(f)
     for disp, kn, cn, val, st, en in c.execute("select dispatch_id,kernel_name,counter_name,value,start,end from counters_collection"):
-        if "gemm_kernel" not in kn: continue
+        if "gemm_kernel" not in kn and "probe_kernel" not in kn: continue
         per[(disp, cn)] += val; per[(disp, "dur")] = (en - st) / 1e6; last = max(last, disp)
 if True:
     print("$cfg".ljust(28), "ms %.2f" % per[(last, "dur")], "FETCH_GB(raw) %.2f" % (per[(last, "FETCH_SIZE")] * 1024 / 1e9),
