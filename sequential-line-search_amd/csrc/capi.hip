@@ -86,7 +86,7 @@ extern "C" int sls_ctx_create(int device, sls_ctx** out) {
     c->device = device;
     SLS_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
-    SLS_HIP(hipMalloc((void**)&c->d_info, 64));
+    SLS_HIP(hipMalloc((void**)&c->d_info, 256));   // ints 0..15: potrf info / timing; ints 32..39: acq_gemm generation gates
     *out = c.release();
     SLS_CATCH
 }
@@ -410,7 +410,7 @@ static void eval_candidates(sls_gp* g, const double* xr, long ldr, int S, const 
         }
         {
             ProfScope ps(c, "acq_gemm");
-            launch_acq_gemm(c->stream, g->Ks.p, Cs, ldk, Sp, g->Kinv.p, Np, g->P.p, kw_part, cw_part);
+            launch_acq_gemm(c->stream, g->Ks.p, Cs, ldk, Sp, g->Kinv.p, Np, g->P.p, kw_part, cw_part, c->d_info + 32);
         }
         if (want_grad) {
             ProfScope ps(c, "grad_gemm");

@@ -19,15 +19,10 @@ namespace slsk {
 // Epilogue: P = C* .* W stored candidate-major; per-tile partial sums over n' of K*.*W and C*.*W.
 // ---------------------------------------------------------------------------------------------------------
 template <bool MATERN>
-__global__ __launch_bounds__(256, 2) void acq_gemm_kernel(const double* __restrict__ Ks, const double* __restrict__ Cs, long ldk,
-                                                          int Sp, const double* __restrict__ Kinv, int Np,
-                                                          double* __restrict__ P, double* __restrict__ kw_part,
-                                                          double* __restrict__ cw_part, int stagger) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* lds = reinterpret_cast<double*>(smem);
-    const int ntm = Sp / GEMM_BM, ntn = Np / GEMM_BN;
+__device__ __forceinline__ void acq_tile(int t, int ntm, int ntn, const double* __restrict__ Ks, const double* __restrict__ Cs,
+                                         long ldk, const double* __restrict__ Kinv, int Np, double* __restrict__ P,
+                                         double* __restrict__ kw_part, double* __restrict__ cw_part, int stagger, double* lds) {
     // grouped order: 8 candidate tiles x all K^-1 row tiles, so the 64 tiles resident on one XCD share panels in L2
-    int t = xcd_remap(blockIdx.x, ntm * ntn);
     const int GM = 8;
     const int gsz = GM * ntn;
     const int g = t / gsz, w = t % gsz;
@@ -36,10 +31,9 @@ __global__ __launch_bounds__(256, 2) void acq_gemm_kernel(const double* __restri
     const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
     Acc acc;
     acc.zero();
-    // Staggered k start.  The 8 tiles of an XCD's resident 8x8 group that share an operand panel otherwise request every
-    // slab within the same microsecond; the L2 does not merge those misses (hit rate 0.34-0.43, 40-46 GB of fabric reads
-    // per launch).  Starting tile (tm, tn) (tm&7 + tn&7) slabs into the k loop (and wrapping) makes the sharers arrive one
-    // slab-time apart: hit rate 0.67, fabric reads halved, same kernel time (gemm_probe, PMC TCC_HIT/MISS, FETCH_SIZE).
+    // Staggered k start: tile (tm, tn) begins (tm&7 + tn&7) slabs into the k loop and wraps, so the 8 co-resident sharers of
+    // a panel do not all miss on the same slab in the same microsecond.  Measured effect is build-dependent (round-start
+    // build: hit rate 0.34-0.43 -> 0.67; current build 0.85 with or without), kernel time unchanged; kept on.
     const int ks = stagger ? ((tm & 7) + (tn & 7)) * GEMM_BK : 0;
     gemm_tile<false, false>(acc, Ks + m0, ldk, Kinv + n0, (long)Np, 0, Np, lds, ks);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -88,8 +82,52 @@ __global__ __launch_bounds__(256, 2) void acq_gemm_kernel(const double* __restri
     }
 }
 
+// One tile per workgroup (sync == nullptr, the default), or the persistent form (SLS_PERSIST=1): gridDim.x = 8 * slots
+// workgroups, all resident (slots = 2 per CU x 32 CUs per XCD), workgroup b = slot b>>3 of XCD b&7.  Generation i of XCD x
+// is the 64-tile chunk x + 8 i (an 8 x 8 block of tiles sharing 16 operand panels); the 64 slots of an XCD start each
+// generation together, gated by a per-XCD counter of finished tiles.  Panel sharing through the 4 MB L2 only works while
+// the co-resident sharers of a panel are within ~16 slabs of each other in k; the gate enforces that (PMC: hit rate
+// 0.84-0.85, 19-20 GB per launch in every run) where the ungated form depends on how far the tiles of an XCD drift apart
+// (0.66-0.85, 20-48 GB observed across builds with an identical k loop).  The gate costs ~1.6 % kernel time: both
+// workgroups of a CU then run their epilogues at the same moment instead of hiding them behind each other's MFMA loop,
+// so it is off by default.  The wait is a bounded spin: the gate is a locality hint, not a correctness requirement, and
+// an unexpected residency pattern cannot hang the device.
+template <bool MATERN>
+__global__ __launch_bounds__(256, 2) void acq_gemm_kernel(const double* __restrict__ Ks, const double* __restrict__ Cs, long ldk,
+                                                          int Sp, const double* __restrict__ Kinv, int Np,
+                                                          double* __restrict__ P, double* __restrict__ kw_part,
+                                                          double* __restrict__ cw_part, int stagger, int* __restrict__ sync) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* lds = reinterpret_cast<double*>(smem);
+    const int ntm = Sp / GEMM_BM, ntn = Np / GEMM_BN;
+    const int ntiles = ntm * ntn;
+    if (sync == nullptr) {
+        acq_tile<MATERN>(xcd_remap(blockIdx.x, ntiles), ntm, ntn, Ks, Cs, ldk, Kinv, Np, P, kw_part, cw_part, stagger, lds);
+        return;
+    }
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    const int nchunks = (ntiles + slots - 1) / slots;
+    int gen = 0;
+    for (int c = xcd; c < nchunks; c += 8, ++gen) {
+        if (gen > 0) {
+            if (threadIdx.x == 0) {
+                const int target = slots * gen;
+                const long long t0 = wall_clock64();
+                while (__hip_atomic_load(sync + xcd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target &&
+                       wall_clock64() - t0 < 20000)   // 100 MHz counter: give up after 200 us
+                    __builtin_amdgcn_s_sleep(16);
+            }
+            __syncthreads();
+        }
+        const int t = c * slots + slot;
+        if (t < ntiles) acq_tile<MATERN>(t, ntm, ntn, Ks, Cs, ldk, Kinv, Np, P, kw_part, cw_part, stagger, lds);
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(sync + xcd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 void launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk, int Sp, const double* Kinv, int Np, double* P,
-                     double* kw_part, double* cw_part) {
+                     double* kw_part, double* cw_part, int* sync) {
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)acq_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
@@ -102,13 +140,27 @@ void launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk
         const char* e = getenv("SLS_STAGGER");
         stagger_env = e ? atoi(e) : 1;
     }
-    const int stagger = (stagger_env && Np >= 2048) ? 1 : 0;
+    static int persist_env = -1;
+    if (persist_env < 0) {
+        const char* e = getenv("SLS_PERSIST");
+        persist_env = e ? atoi(e) : 0;
+    }
+    // persistent, generation-gated form when there are at least two generations of tiles (MI355X: 256 CUs x 2 = 512 slots)
+    const bool persist = persist_env && sync && nt >= 1024 && Np >= 2048;
+    const int stagger = (stagger_env == 1 && !persist && Np >= 2048) || stagger_env == 2 ? 1 : 0;
+    int* sy = nullptr;
+    int grid = nt;
+    if (persist) {
+        (void)hipMemsetAsync(sync, 0, 8 * sizeof(int), s);
+        sy = sync;
+        grid = 512;
+    }
     if (Cs != Ks)
-        hipLaunchKernelGGL(acq_gemm_kernel<true>, dim3(nt), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, Ks, Cs, ldk, Sp, Kinv, Np, P,
-                           kw_part, cw_part, stagger);
+        hipLaunchKernelGGL(acq_gemm_kernel<true>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, Ks, Cs, ldk, Sp, Kinv, Np, P,
+                           kw_part, cw_part, stagger, sy);
     else
-        hipLaunchKernelGGL(acq_gemm_kernel<false>, dim3(nt), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, Ks, Cs, ldk, Sp, Kinv, Np, P,
-                           kw_part, cw_part, stagger);
+        hipLaunchKernelGGL(acq_gemm_kernel<false>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, Ks, Cs, ldk, Sp, Kinv, Np, P,
+                           kw_part, cw_part, stagger, sy);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -1,14 +1,17 @@
 #!/bin/bash
-# A/B of the staggered k start inside the real acq_gemm_kernel: FETCH_SIZE and TCC hit/miss passes, SLS_STAGGER=0 and 1.
+# A/B of tile scheduling variants inside the real acq_gemm_kernel: FETCH_SIZE and TCC hit/miss passes.
+# usage: prof_stagger.sh "SLS_PERSIST=0 SLS_STAGGER=1" "SLS_PERSIST=1 SLS_STAGGER=0" ...
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_stagger
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp
 BENCH="python $R/bench.py --steps 1 --warmup 0 --n-local 3 --no-cpu-baseline"
-for st in 0 1; do
-  SLS_STAGGER=$st timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/s$st -o pmcf -- $BENCH > $OUT/log_f$st.txt 2>&1
-  SLS_STAGGER=$st timeout 200 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d $OUT/s$st -o pmch -- $BENCH > $OUT/log_h$st.txt 2>&1
+i=0
+for cfg in "$@"; do
+  i=$((i+1)); st=$i
+  env $cfg timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/s$st -o pmcf -- $BENCH > $OUT/log_f$st.txt 2>&1
+  env $cfg timeout 200 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d $OUT/s$st -o pmch -- $BENCH > $OUT/log_h$st.txt 2>&1
   python - <<PY
 import sqlite3, glob
 from collections import defaultdict
@@ -23,7 +26,7 @@ for f in glob.glob("$OUT/s$st/*.db"):
     per["dur"] += list(dur.values())
 import statistics as S
 m = lambda k: S.mean(per[k]) if per[k] else float("nan")
-print("SLS_STAGGER=$st launches", len(per["FETCH_SIZE"]), "ms %.2f" % m("dur"), "FETCH_GB(raw) %.2f (x2 = %.1f GB)" % (m("FETCH_SIZE") * 1024 / 1e9, 2 * m("FETCH_SIZE") * 1024 / 1e9),
+print("$cfg launches", len(per["FETCH_SIZE"]), "ms %.2f" % m("dur"), "FETCH_GB(raw) %.2f (x2 = %.1f GB)" % (m("FETCH_SIZE") * 1024 / 1e9, 2 * m("FETCH_SIZE") * 1024 / 1e9),
       "hitrate %.3f" % (m("TCC_HIT_sum") / (m("TCC_HIT_sum") + m("TCC_MISS_sum"))),
       "min/max FETCH raw GB %.1f/%.1f" % (min(per["FETCH_SIZE"]) * 1024 / 1e9, max(per["FETCH_SIZE"]) * 1024 / 1e9))
 PY
