@@ -3,8 +3,8 @@
 // src/gaussian-process-regressor.cpp:159,211,231), block triangular solves (LLT::solve), GEMV helpers.
 //
 // Right-looking, NB = 128:
-//   chol_diag   one workgroup factors the 128x128 diagonal block in registers (8x8 per thread, column broadcast
-//               through LDS, one barrier per column) and also produces its inverse T_jj (forward substitution on I);
+//   chol_diag   one workgroup factors the 128x128 diagonal block resident in LDS (16-column steps: register Cholesky of the
+//               16x16 tile on one wave, MFMA panel + trailing update) and produces its inverse T_jj on the way;
 //   panel       L_ij = A_ij T_jj^T            (MFMA GEMM, in place)
 //   syrk        A_ik -= L_ij L_kj^T, i>=k>j   (MFMA GEMM, lower tiles only)
 // Triangular inverse: recursive doubling over block pairs, X21 = -X22 (L21 X11), every level two batched GEMMs.
@@ -62,6 +62,51 @@ __global__ __launch_bounds__(256, 2) void tri_gemm_kernel(GemmDesc g) {
                 if (g.beta != 0.0) v += g.beta * *c;
                 *c = v;
             }
+}
+
+// Same product on 128 x 64 tiles (A M-contiguous, B K-contiguous only): twice as many workgroups for the levels of the
+// triangular inverse whose 128 x 128 tiling leaves most of the 512 workgroup slots empty (each tile is a long serial k loop,
+// so the level time is the time of ONE tile; halving the tile halves it).  g.nt still counts 128-wide block columns.
+__global__ __launch_bounds__(256, 2) void tri_gemm64_kernel(GemmDesc g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* lds = reinterpret_cast<double*>(smem);
+    const int tm = blockIdx.x % g.mt, tn64 = blockIdx.x / g.mt, tn = tn64 >> 1;
+    const int batch = blockIdx.y;
+    if (g.tri && tn > tm) return;
+    if (batch * g.vb_stride + g.vb_off + tm >= g.vb_limit) return;
+    const int m0 = tm * GEMM_BM, n0 = tn64 * 64;
+    int kb = 0, ke = g.K;
+    if (g.kmode == 1) kb = NB * tn;
+    else if (g.kmode == 2) ke = min(g.K, NB * (tm + 1));
+    else if (g.kmode == 3) kb = NB * max(tm, tn);
+    const double* A = g.A + batch * g.strideA + m0;
+    const double* B = g.B + batch * g.strideB + (long)n0 * g.ldb;
+    double* C = g.C + batch * g.strideC;
+    Acc64 acc;
+    acc.zero();
+    gemm_tile_n64(acc, A, g.lda, B, g.ldb, kb, ke, lds);
+    const int lane = threadIdx.x & 63, wm = (threadIdx.x >> 6) * 32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double* c = C + (long)(m0 + wm + 16 * i + (lane & 15)) + (long)(n0 + 16 * j + (lane >> 4) + 4 * r) * g.ldc;
+                double v = g.alpha * acc.v[i][j][r];
+                if (g.beta != 0.0) v += g.beta * *c;
+                *c = v;
+            }
+}
+
+static void launch_tri_gemm64(hipStream_t s, const GemmDesc& g, int batches) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)tri_gemm64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_N64_LDS_BYTES);
+        attr = true;
+    }
+    if (g.mt <= 0 || g.nt <= 0 || batches <= 0) return;
+    hipLaunchKernelGGL(tri_gemm64_kernel, dim3(g.mt * g.nt * 2, batches), dim3(GEMM_THREADS), GEMM_N64_LDS_BYTES, s, g);
 }
 
 template <bool A_KC, bool B_KC>
@@ -459,13 +504,16 @@ void launch_trtri(hipStream_t s, const double* L, int Np, double* Linv, double* 
         g1.strideA = g1.strideB = g1.strideC = pstride;
         g1.kmode = 1;
         g1.vb_stride = 2 * h; g1.vb_off = h; g1.vb_limit = nb;
-        launch_tri_gemm<false, true>(s, g1, pairs);
+        const bool narrow = (long)h * h * pairs <= 512;   // fewer 128 x 128 tiles than workgroup slots
+        if (narrow) launch_tri_gemm64(s, g1, pairs);
+        else launch_tri_gemm<false, true>(s, g1, pairs);
         // X21 = -X22 * tmp21 : A = X22 (M-contig), B elem(n,k) = tmp21[k + n ld] (K-contig), k < 128 (tm+1)
         GemmDesc g2 = mkdesc(Linv + (long)h * NB * (ld + 1), ld, tmp + off21, ld, Linv + off21, ld, h, h, h * NB, -1.0, 0.0);
         g2.strideA = g2.strideB = g2.strideC = pstride;
         g2.kmode = 2;
         g2.vb_stride = 2 * h; g2.vb_off = h; g2.vb_limit = nb;
-        launch_tri_gemm<false, true>(s, g2, pairs);
+        if (narrow) launch_tri_gemm64(s, g2, pairs);
+        else launch_tri_gemm<false, true>(s, g2, pairs);
     }
 }
 
