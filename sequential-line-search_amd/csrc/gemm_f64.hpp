@@ -159,7 +159,7 @@ __device__ __forceinline__ void gemm_tile(Acc& acc, const double* __restrict__ A
     }
 }
 
-// 128 x 64 output tile (A M-contiguous, B K-contiguous), for products whose second dimension is small (the gradient
+// 128 x 64 output tile (A M- or K-contiguous, B K-contiguous), for products whose second dimension is small (the gradient
 // contractions have n' = D <= 64 for the headline configuration; a 128-wide tile would waste half of its MFMAs).
 // 4 waves stacked along m: wave w owns rows 32 w .. 32 w + 31 (2 A fragments) x all 64 columns (4 B fragments).
 // LDS per buffer: A slab [16][144] + B slab [64][18] doubles; two buffers = 55296 B -> 2-3 workgroups per CU.
@@ -177,6 +177,7 @@ struct Acc64 {
     }
 };
 
+template <bool A_KC = false>
 __device__ __forceinline__ void gemm_tile_n64(Acc64& acc, const double* __restrict__ A, long lda,
                                               const double* __restrict__ B, long ldb, int kb, int ke, double* lds) {
     const int tid = threadIdx.x;
@@ -201,16 +202,16 @@ __device__ __forceinline__ void gemm_tile_n64(Acc64& acc, const double* __restri
             *reinterpret_cast<d2_t*>(l + n * GEMM_LDS_KC_LD + 2 * k2) = sbr[i];
         }
     };
-    stage_load<false>(sa, A, lda, kb, tid);
+    stage_load<A_KC>(sa, A, lda, kb, tid);
     load_b(kb);
-    stage_store<false>(sa, lds, tid);
+    stage_store<A_KC>(sa, lds, tid);
     store_b(lds + GEMM_LDS_TILE);
     __syncthreads();
     int cur = 0;
     for (int k0 = kb; k0 < ke; k0 += GEMM_BK) {
         const bool more = (k0 + GEMM_BK) < ke;
         if (more) {
-            stage_load<false>(sa, A, lda, k0 + GEMM_BK, tid);
+            stage_load<A_KC>(sa, A, lda, k0 + GEMM_BK, tid);
             load_b(k0 + GEMM_BK);
         }
         const double* la = lds + cur;
@@ -219,7 +220,7 @@ __device__ __forceinline__ void gemm_tile_n64(Acc64& acc, const double* __restri
         for (int kk = 0; kk < 4; ++kk) {
             double af[2], bf[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = frag_read<false>(la, wm + 16 * i, kk, lane);
+            for (int i = 0; i < 2; ++i) af[i] = frag_read<A_KC>(la, wm + 16 * i, kk, lane);
 #pragma unroll
             for (int j = 0; j < 4; ++j) bf[j] = frag_read<true>(lb, 16 * j, kk, lane);
 #pragma unroll
@@ -230,7 +231,7 @@ __device__ __forceinline__ void gemm_tile_n64(Acc64& acc, const double* __restri
         }
         const int nxt = cur ^ GEMM_N64_LDS_BUF;
         if (more) {
-            stage_store<false>(sa, lds + nxt, tid);
+            stage_store<A_KC>(sa, lds + nxt, tid);
             store_b(lds + nxt + GEMM_LDS_TILE);
         }
         __syncthreads();

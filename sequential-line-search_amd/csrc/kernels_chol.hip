@@ -8,6 +8,8 @@
 //   panel       L_ij = A_ij T_jj^T            (MFMA GEMM, in place)
 //   syrk        A_ik -= L_ij L_kj^T, i>=k>j   (MFMA GEMM, lower tiles only)
 // Triangular inverse: recursive doubling over block pairs, X21 = -X22 (L21 X11), every level two batched GEMMs.
+#include <cstdlib>
+
 #include "gemm_f64.hpp"
 #include "kernels.hpp"
 
@@ -64,9 +66,10 @@ __global__ __launch_bounds__(256, 2) void tri_gemm_kernel(GemmDesc g) {
             }
 }
 
-// Same product on 128 x 64 tiles (A M-contiguous, B K-contiguous only): twice as many workgroups for the levels of the
+// Same product on 128 x 64 tiles (B K-contiguous only): twice as many workgroups for the levels of the
 // triangular inverse whose 128 x 128 tiling leaves most of the 512 workgroup slots empty (each tile is a long serial k loop,
 // so the level time is the time of ONE tile; halving the tile halves it).  g.nt still counts 128-wide block columns.
+template <bool A_KC>
 __global__ __launch_bounds__(256, 2) void tri_gemm64_kernel(GemmDesc g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
@@ -79,12 +82,12 @@ __global__ __launch_bounds__(256, 2) void tri_gemm64_kernel(GemmDesc g) {
     if (g.kmode == 1) kb = NB * tn;
     else if (g.kmode == 2) ke = min(g.K, NB * (tm + 1));
     else if (g.kmode == 3) kb = NB * max(tm, tn);
-    const double* A = g.A + batch * g.strideA + m0;
+    const double* A = g.A + batch * g.strideA + (A_KC ? (long)m0 * g.lda : (long)m0);
     const double* B = g.B + batch * g.strideB + (long)n0 * g.ldb;
     double* C = g.C + batch * g.strideC;
     Acc64 acc;
     acc.zero();
-    gemm_tile_n64(acc, A, g.lda, B, g.ldb, kb, ke, lds);
+    gemm_tile_n64<A_KC>(acc, A, g.lda, B, g.ldb, kb, ke, lds);
     const int lane = threadIdx.x & 63, wm = (threadIdx.x >> 6) * 32;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -99,14 +102,15 @@ __global__ __launch_bounds__(256, 2) void tri_gemm64_kernel(GemmDesc g) {
             }
 }
 
+template <bool A_KC>
 static void launch_tri_gemm64(hipStream_t s, const GemmDesc& g, int batches) {
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)tri_gemm64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_N64_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)tri_gemm64_kernel<A_KC>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_N64_LDS_BYTES);
         attr = true;
     }
     if (g.mt <= 0 || g.nt <= 0 || batches <= 0) return;
-    hipLaunchKernelGGL(tri_gemm64_kernel, dim3(g.mt * g.nt * 2, batches), dim3(GEMM_THREADS), GEMM_N64_LDS_BYTES, s, g);
+    hipLaunchKernelGGL(tri_gemm64_kernel<A_KC>, dim3(g.mt * g.nt * 2, batches), dim3(GEMM_THREADS), GEMM_N64_LDS_BYTES, s, g);
 }
 
 template <bool A_KC, bool B_KC>
@@ -505,14 +509,14 @@ void launch_trtri(hipStream_t s, const double* L, int Np, double* Linv, double* 
         g1.kmode = 1;
         g1.vb_stride = 2 * h; g1.vb_off = h; g1.vb_limit = nb;
         const bool narrow = (long)h * h * pairs <= 512;   // fewer 128 x 128 tiles than workgroup slots
-        if (narrow) launch_tri_gemm64(s, g1, pairs);
+        if (narrow) launch_tri_gemm64<false>(s, g1, pairs);
         else launch_tri_gemm<false, true>(s, g1, pairs);
         // X21 = -X22 * tmp21 : A = X22 (M-contig), B elem(n,k) = tmp21[k + n ld] (K-contig), k < 128 (tm+1)
         GemmDesc g2 = mkdesc(Linv + (long)h * NB * (ld + 1), ld, tmp + off21, ld, Linv + off21, ld, h, h, h * NB, -1.0, 0.0);
         g2.strideA = g2.strideB = g2.strideC = pstride;
         g2.kmode = 2;
         g2.vb_stride = 2 * h; g2.vb_off = h; g2.vb_limit = nb;
-        if (narrow) launch_tri_gemm64(s, g2, pairs);
+        if (narrow) launch_tri_gemm64<false>(s, g2, pairs);
         else launch_tri_gemm<false, true>(s, g2, pairs);
     }
 }
@@ -538,7 +542,15 @@ void launch_lauum(hipStream_t s, const double* Linv, int Np, double* Kinv) {
     GemmDesc g = mkdesc(Linv, ld, Linv, ld, Kinv, ld, nb, nb, Np, 1.0, 0.0);
     g.tri = 1;
     g.kmode = 3;
-    launch_tri_gemm<true, true>(s, g, 1);
+    // small matrices leave most workgroup slots empty: 128 x 64 tiles double the count (SLS_LAUUM_N64=0/1 overrides)
+    static int n64_env = -2;
+    if (n64_env == -2) {
+        const char* e = getenv("SLS_LAUUM_N64");
+        n64_env = e ? atoi(e) : -1;
+    }
+    const bool narrow = n64_env >= 0 ? n64_env != 0 : nb <= 8;   // measured: N=1024 0.16 -> 0.09 ms, N=4096 0.84 -> 1.0 ms
+    if (narrow) launch_tri_gemm64<true>(s, g, 1);
+    else launch_tri_gemm<true, true>(s, g, 1);
     hipLaunchKernelGGL(symmetrize_kernel, dim3(Np / 32, Np / 32), dim3(256), 0, s, Kinv, Np);
 }
 
