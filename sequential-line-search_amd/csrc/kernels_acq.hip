@@ -135,16 +135,12 @@ void launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk
         attr = true;
     }
     const int nt = (Sp / GEMM_BM) * (Np / GEMM_BN);
-    static int stagger_env = -1;
-    if (stagger_env < 0) {
-        const char* e = getenv("SLS_STAGGER");
-        stagger_env = e ? atoi(e) : 1;
-    }
-    static int persist_env = -1;
-    if (persist_env < 0) {
-        const char* e = getenv("SLS_PERSIST");
-        persist_env = e ? atoi(e) : 0;
-    }
+    // SLS_STAGGER (0 off, 1 default: on unless gated, 2 always) and SLS_PERSIST (0 default, 1 gated form) are read per
+    // call so that tests and A/B runs can switch within one process
+    const char* es = getenv("SLS_STAGGER");
+    const char* ep = getenv("SLS_PERSIST");
+    const int stagger_env = es ? atoi(es) : 1;
+    const int persist_env = ep ? atoi(ep) : 0;
     // persistent, generation-gated form when there are at least two generations of tiles (MI355X: 256 CUs x 2 = 512 slots)
     const bool persist = persist_env && sync && nt >= 1024 && Np >= 2048;
     const int stagger = (stagger_env == 1 && !persist && Np >= 2048) || stagger_env == 2 ? 1 : 0;

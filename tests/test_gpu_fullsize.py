@@ -115,3 +115,37 @@ def test_c5_size_map_gradient(ctx, oracle):
     np.testing.assert_allclose(r["quad"], y @ r["alpha"], rtol=1e-10)
     gp.close()
     h.close()
+
+
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_acq_gemm_scheduling_variants_agree(ctx, oracle, kernel, monkeypatch):
+    """The tile-scheduling variants of acq_gemm_kernel (staggered k start on/off, persistent generation-gated form) only
+    change the ORDER in which tiles run and where each tile starts its (wrapped) k loop.  Values and gradients must agree
+    to rounding with the default and with the oracle at a size where the gated form is active
+    (N = 2048 -> 16 row tiles, 8192 candidates -> 64 column tiles = 1024 tiles = two generations)."""
+    D, N, M = 16, 2048, 8192
+    X, y, theta, b = synth_problem(oracle, D, N)
+    Xs = synth_candidates(oracle, D, M)
+    gp = sls().GP(ctx, X, y, theta, b, kernel)
+    ctx.set_candidate_chunk(16384)
+    monkeypatch.setenv("SLS_WAVE_PATH", "0")
+    base = None
+    for env in ({"SLS_PERSIST": "0", "SLS_STAGGER": "1"}, {"SLS_PERSIST": "0", "SLS_STAGGER": "0"},
+                {"SLS_PERSIST": "1", "SLS_STAGGER": "0"}, {"SLS_PERSIST": "1", "SLS_STAGGER": "2"}):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        val, grad = gp.acq_eval(Xs)
+        mu, sg = gp.predict(Xs)
+        if base is None:
+            base = (val, grad, mu, sg)
+            ref = oracle.Regressor(X, y, theta, b, kernel=kernel)
+            v_o, g_o = ref.acq_eval_batch(Xs[:, :256])
+            np.testing.assert_allclose(val[:256], v_o, rtol=1e-6, atol=1e-9 * np.abs(v_o).max())
+            np.testing.assert_allclose(grad[:, :256], g_o, rtol=1e-6, atol=1e-7 * np.abs(g_o).max())
+        else:
+            # a different k start changes the summation order inside a tile: agreement to a few ulp of the sums
+            np.testing.assert_allclose(mu, base[2], rtol=1e-11, atol=1e-12)
+            np.testing.assert_allclose(sg, base[3], rtol=1e-9, atol=1e-11)
+            np.testing.assert_allclose(val, base[0], rtol=1e-8, atol=1e-11 * np.abs(base[0]).max())
+            np.testing.assert_allclose(grad, base[1], rtol=1e-7, atol=1e-9 * np.abs(base[1]).max())
+    gp.close()
