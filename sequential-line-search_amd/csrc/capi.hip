@@ -384,6 +384,12 @@ struct EvalOut {
     double ucb_h = 1.0;
 };
 
+// value-only evaluations take the triangular L^-1 contraction (half the flops); SLS_TRI_PREDICT=0 forces the K^-1 form
+static bool tri_predict() {
+    const char* e = getenv("SLS_TRI_PREDICT");
+    return !e || atoi(e) != 0;
+}
+
 // xr: raw candidate coordinates, candidate-major xr[n + d*ldr], S candidates.
 static void eval_candidates(sls_gp* g, const double* xr, long ldr, int S, const EvalOut& o) {
     sls_ctx* c = g->ctx;
@@ -409,8 +415,11 @@ static void eval_candidates(sls_gp* g, const double* xr, long ldr, int S, const 
                               ldk, mu_part, ca_part);
         }
         {
-            ProfScope ps(c, "acq_gemm");
-            launch_acq_gemm(c->stream, g->Ks.p, Cs, ldk, Sp, g->Kinv.p, Np, g->P.p, kw_part, cw_part, c->d_info + 32);
+            ProfScope ps(c, want_grad ? "acq_gemm" : "var_gemm");
+            if (want_grad || !tri_predict())
+                launch_acq_gemm(c->stream, g->Ks.p, Cs, ldk, Sp, g->Kinv.p, Np, g->P.p, kw_part, cw_part, c->d_info + 32);
+            else
+                launch_var_gemm(c->stream, g->Ks.p, ldk, Sp, g->Linv.p, Np, kw_part, cw_part);
         }
         if (want_grad) {
             ProfScope ps(c, "grad_gemm");

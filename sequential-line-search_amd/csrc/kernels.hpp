@@ -39,6 +39,9 @@ void launch_cross_gram(hipStream_t s, const double* XsT, long lds_, const double
 // P[n + i*ldk] = Cs * (Kinv Ks)  and the partial column sums kw_part (Ks.*W), cw_part (Cs.*W) per 128-row tile of i.
 void launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk, int Sp, const double* Kinv, int Np, double* P,
                      double* kw_part, double* cw_part, int* sync = nullptr);
+// kw_part = per-tile partial sums of (Linv Ks)^2 (triangular contraction), cw_part = 0: the no-gradient form of acq_gemm
+void launch_var_gemm(hipStream_t s, const double* Ks, long ldk, int Sp, const double* Linv, int Np, double* kw_part,
+                     double* cw_part);
 // Gs[n + d*ldk] = sum_i P[n,i] XT[i,d] ;  Gm[n + d*ldk] = sum_i Cs[n,i] XaT[i,d]   (d < Dcols)
 void launch_grad_gemm(hipStream_t s, const double* P, const double* Cs, long ldk, int Sp, const double* XT, const double* XaT,
                       long ld, int Np, int Dcols, double* Gs, double* Gm);

@@ -160,6 +160,93 @@ void launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// var_gemm: prediction without gradients.  sigma^2 = a - |L^-1 k*|^2 needs only V = L^-1 K* with the TRIANGULAR factor:
+// tile (128 candidates, 128 rows n' of L^-1) contracts k < 128 (tn + 1) only, i.e. N^2 flops per candidate instead of the
+// 2 N^2 of the K^-1 form (SURVEY.md 8d "Batched predict": N^2 M*).  Epilogue: per-tile partial sums of v^2 into kw_part
+// (finalize then forms a - sum as for the K^-1 path); no P, no C* traffic.  Long tiles (large tn) are issued first.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void var_tile(int tm, int tn, const double* __restrict__ Ks, long ldk, const double* __restrict__ Linv,
+                                         int Np, double* __restrict__ kw_part, double* __restrict__ cw_part, double* lds) {
+    const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+    Acc acc;
+    acc.zero();
+    gemm_tile<false, false>(acc, Ks + m0, ldk, Linv + n0, (long)Np, 0, GEMM_BN * (tn + 1), lds);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double sv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        double p = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p = fma(acc.v[i][j][r], acc.v[i][j][r], p);
+        p += __shfl_xor(p, 16);
+        p += __shfl_xor(p, 32);
+        sv[i] = p;
+    }
+    __syncthreads();   // the k loop's last LDS reads are done before the buffer is reused
+    double* red = lds;
+    if (lane < 16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[(wave >> 1) * 128 + (wave & 1) * 64 + 16 * i + lane] = sv[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int ml = threadIdx.x;
+        kw_part[(long)tn * ldk + m0 + ml] = red[ml] + red[128 + ml];
+        cw_part[(long)tn * ldk + m0 + ml] = 0.0;
+    }
+    __syncthreads();
+}
+
+// pair == 0: one tile per workgroup, long tiles (large tn) first.  pair == 1 (fewer than two rounds of tiles): workgroup
+// (tm, p) runs tiles tn = ntn-1-p and tn = p back to back, so every workgroup contracts 128 (ntn + 1) columns in total;
+// with one tile each the launch would last as long as its longest tile, i.e. as long as the K^-1 form.
+__global__ __launch_bounds__(256, 2) void var_gemm_kernel(const double* __restrict__ Ks, long ldk, int Sp,
+                                                          const double* __restrict__ Linv, int Np,
+                                                          double* __restrict__ kw_part, double* __restrict__ cw_part, int pair) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* lds = reinterpret_cast<double*>(smem);
+    const int ntm = Sp / GEMM_BM, ntn = Np / GEMM_BN;
+    if (!pair) {
+        const int T = ntm * ntn;
+        int tm = blockIdx.x % ntm, tn = ntn - 1 - blockIdx.x / ntm;
+        if ((ntm & 7) == 0 && (ntn & 7) == 0) {
+            // 8 x 8 tile groups (64 workgroups resident on one XCD share 16 operand panels through its L2), groups ordered
+            // longest first and dealt round-robin to the XCDs: a contiguous range per XCD would hand all the long tiles
+            // (large tn) to XCD 0 and the launch would last almost as long as the untriangular product.
+            const int t = xcd_remap(blockIdx.x, T);
+            const int per = T >> 3;
+            const int x = t / per, l = t - x * per;
+            const int gid = (l >> 6) * 8 + x, w = l & 63;
+            const int ngm = ntm >> 3;
+            tn = ntn - 1 - (8 * (gid / ngm) + (w >> 3));
+            tm = 8 * (gid % ngm) + (w & 7);
+        }
+        var_tile(tm, tn, Ks, ldk, Linv, Np, kw_part, cw_part, lds);
+        return;
+    }
+    const int tm = blockIdx.x % ntm, p = blockIdx.x / ntm;
+    const int hi = ntn - 1 - p;
+    var_tile(tm, hi, Ks, ldk, Linv, Np, kw_part, cw_part, lds);
+    if (p < hi) var_tile(tm, p, Ks, ldk, Linv, Np, kw_part, cw_part, lds);
+}
+
+void launch_var_gemm(hipStream_t s, const double* Ks, long ldk, int Sp, const double* Linv, int Np, double* kw_part,
+                     double* cw_part) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)var_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        attr = true;
+    }
+    const int ntm = Sp / GEMM_BM, ntn = Np / GEMM_BN;
+    const int pair = (ntm * ntn < 1024 && ntn > 1) ? 1 : 0;
+    const int grid = pair ? ntm * ((ntn + 1) / 2) : ntm * ntn;
+    hipLaunchKernelGGL(var_gemm_kernel, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, Ks, ldk, Sp, Linv, Np, kw_part, cw_part,
+                       pair);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // grad_gemm: z = 0: Gs = P * X~ ; z = 1: Gm = C* * (alpha .* X~).  Tile = 128 candidates x 128 dims.
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void grad_gemm_kernel(const double* __restrict__ P, const double* __restrict__ Cs, long ldk,
