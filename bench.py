@@ -37,7 +37,8 @@ def parse():
     p.add_argument("--starts", type=int, default=65536, help="total multi-start count S (split over ranks)")
     p.add_argument("--n-local", type=int, default=50, help="objective evaluations per start")
     p.add_argument("--kernel", choices=["matern52", "se"], default="matern52")
-    p.add_argument("--chunk", type=int, default=16384, help="candidates per device pass")
+    p.add_argument("--chunk", type=int, default=65536,
+                   help="candidates per device pass (K*, C*, P workspaces: 3 x chunk x N x 8 B = 12.9 GB at the default)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                    help="collective backend; gloo + --same-device exercises the N>1 path on a 1-GPU box (tests only)")
@@ -195,9 +196,11 @@ def main():
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_acq_gemm.json")
-        if os.path.exists(pmc) and chunk == 16384 and (N, D) == (8192, 64):   # the PMC pass measured this launch shape
+        if os.path.exists(pmc) and (N, D) == (8192, 64):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                pj = json.load(open(pmc))
+                if pj.get("candidates_per_launch") == int(cand_per_launch):   # the PMC pass measured this launch shape
+                    traffic = pj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
