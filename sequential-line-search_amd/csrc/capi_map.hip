@@ -1,6 +1,7 @@
 // C-ABI: MAP objectives (GP marginal likelihood, preference objective).  Device: Gram + Cholesky + K^-1 + fused
 // gradient contraction; host: the O(D) prior terms and the O(#preferences) Bradley-Terry-Luce terms.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -23,7 +24,7 @@ using namespace slsk;
 struct sls_nll {
     sls_ctx* ctx = nullptr;
     int D = 0, N = 0, Np = 0, Dp = 0, Dcols = 0, kernel = 0;
-    DBuf X, y, inv_ell, XT, nx, L, Linv, Kinv, alpha, tvec, G, Y, svec, ones, parts, scal, gl, gemv_part;
+    DBuf X, y, inv_ell, XT, nx, L, Linv, Kinv, alpha, tvec, G, Y, svec, ones, parts, scal, gl, gemv_part, small_in, small_out;
     std::vector<double> cached_theta;
     double cached_b = -1.0;
     bool have_factor = false;
@@ -98,12 +99,60 @@ static void nll_factor(sls_nll* h, const double* theta, double b) {
     h->have_factor = true;
 }
 
+// N <= 128: the whole evaluation is one single-workgroup launch (kernels_small.hip); SLS_NLL_SMALL=0 forces the tiled path
+static bool nll_small_ok(const sls_nll* h, bool want_theta_grad) {
+    if (h->N > NLL_SMALL_MAX_N) return false;
+    if (want_theta_grad && h->D > NLL_SMALL_MAX_GRAD_D) return false;
+    const char* e = getenv("SLS_NLL_SMALL");
+    return !e || atoi(e) != 0;
+}
+
+static void nll_small_eval(sls_nll* h, const double* y, const double* theta, double b, double* quad, double* logdet,
+                           double* alpha, double* grad_theta, double* grad_b) {
+    sls_ctx* c = h->ctx;
+    const int D = h->D, N = h->N;
+    SLS_REQUIRE(theta[0] > 0.0, "signal variance must be positive");
+    for (int d = 0; d < D; ++d) SLS_REQUIRE(theta[1 + d] > 0.0, "length scale %d must be positive", d);
+    const bool want_grad = grad_theta || grad_b;
+    std::vector<double> in(2 + D + N);
+    in[0] = theta[0]; in[1] = b;
+    for (int d = 0; d < D; ++d) in[2 + d] = theta[1 + d];
+    for (int i = 0; i < N; ++i) in[2 + D + i] = y[i];
+    h->small_in.ensure(in.size());
+    h->small_out.ensure(160);
+    SLS_HIP(hipMemcpyAsync(h->small_in.p, in.data(), in.size() * 8, hipMemcpyHostToDevice, c->stream));
+    SLS_HIP(hipMemsetAsync(c->d_info, 0, 64, c->stream));
+    launch_nll_small(c->stream, h->kernel, h->X.p, D, N, h->small_in.p, want_grad, c->d_info, h->small_out.p);
+    double out[160];
+    const int nout = alpha ? 32 + N : 32;
+    SLS_HIP(hipMemcpyAsync(out, h->small_out.p, nout * 8, hipMemcpyDeviceToHost, c->stream));
+    SLS_HIP(hipStreamSynchronize(c->stream));
+    if (out[4] != 0.0) {
+        set_error("sls_nll_eval: K_y is not positive definite (pivot %d)", (int)out[4] - 1);
+        throw HipFail{SLS_ERR_NOT_SPD};
+    }
+    h->have_factor = false;   // the tiled path's cached factor (L, Linv, Kinv buffers) was not refreshed
+    h->logdet = out[3];
+    if (quad) *quad = out[2];
+    if (logdet) *logdet = out[3];
+    if (grad_b) *grad_b = out[1];
+    if (grad_theta) {
+        grad_theta[0] = out[0] / theta[0];
+        for (int d = 0; d < D; ++d) grad_theta[1 + d] = out[8 + d];
+    }
+    if (alpha) std::memcpy(alpha, out + 32, sizeof(double) * N);
+}
+
 static void nll_eval_impl(sls_nll* h, const double* y, const double* theta, double b, double* quad, double* logdet,
                           double* alpha, double* grad_theta, double* grad_b) {
     sls_ctx* c = h->ctx;
     const int D = h->D, N = h->N, Np = h->Np;
     SLS_REQUIRE(y && theta, "sls_nll_eval: NULL argument");
     SLS_REQUIRE(b >= 0.0, "noise level must be >= 0");
+    if (nll_small_ok(h, grad_theta != nullptr)) {
+        nll_small_eval(h, y, theta, b, quad, logdet, alpha, grad_theta, grad_b);
+        return;
+    }
     nll_factor(h, theta, b);
     SLS_HIP(hipMemcpyAsync(h->y.p, y, (size_t)N * 8, hipMemcpyHostToDevice, c->stream));
     launch_gemv_n(c->stream, h->Linv.p, Np, h->y.p, h->tvec.p, h->gemv_part.p);

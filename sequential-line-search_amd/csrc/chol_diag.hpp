@@ -1,0 +1,257 @@
+// LDS-resident Cholesky + triangular inverse of a (<=) 128x128 SPD block: device code shared by chol_diag_kernel
+// (kernels_chol.hip) and the fused small-problem MAP kernel (kernels_small.hip).
+#pragma once
+#include "gemm_f64.hpp"
+
+namespace slsk {
+
+#ifdef SLS_DIAG_TIMING
+#define DIAG_STAMP(slot) do { if (threadIdx.x == 0 && info) ((long long*)info)[slot] = clock64(); } while (0)
+#define DIAG_STAMP_T(t_, slot) do { if (threadIdx.x == (t_) && info) ((long long*)info)[slot] = clock64(); } while (0)
+#else
+#define DIAG_STAMP_T(t_, slot) do {} while (0)
+#define DIAG_STAMP(slot) do {} while (0)
+#endif
+
+// ---------------------------------------------------------------------------------------------------------
+// Diagonal block: Cholesky + inverse of one 128x128 block by ONE workgroup (4 waves), matrix resident in LDS.
+//   LDS: As[128 x 144] (column-major, ld 144 -> MFMA fragment reads conflict-free) + Ts[8][16 x 16] = exactly 160 KiB.
+//   Phase 1 (factor), per 16-column panel:  wave 0 factors the 16x16 diagonal tile in registers (lane = row, pivots and
+//     columns broadcast with wave shuffles) and inverts it; all waves then form the panel L = A T16^T and the trailing
+//     update A_ij -= L_i L_j^T with v_mfma_f64_16x16x4 on 16x16 tiles read straight from LDS.
+//   The inverse is built block row by block row WHILE wave 0 is busy with the next diagonal tile: waves 1-3 form
+//     S = L[kb][:kb] Linv[:kb][:kb] during the pivot chain of step kb and T[kb][j] = -T16 S joins the panel phase; the tiles
+//     go to the unused strictly-upper part of As (as Linv^T), so no LDS beyond the matrix itself is needed.
+// The serial chain is 128 pivot steps of ~one rsqrt + one readlane each instead of 256 barrier-separated steps.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int DL = 144;
+constexpr int DIAG_LDS_BYTES = (128 * DL + 8 * 256) * 8;   // 163840
+
+__device__ __forceinline__ d4_t mfma16(double bfrag, double afrag, d4_t acc) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(bfrag, afrag, acc, 0, 0, 0);
+}
+
+// value of lane k of each 16-lane row in every lane of that row: one v_mov_b64_dpp row_newbcast:k (the only DPP control
+// gfx90a+ allows on 64-bit operands).  The diagonal-tile code keeps row i of the tile in lanes i, 16+i, 32+i, 48+i, so
+// this is a wave-wide broadcast; it sits on the serial pivot chain, where the alternatives cost two v_readlane + SGPR
+// pressure (the unrolled code spilled 146 SGPRs) or a ~100-cycle ds_bpermute.  k is a constant after unrolling.
+__device__ __forceinline__ double bcast(double x, int k) {
+    const long v = __builtin_bit_cast(long, x);
+    long r = v;
+    switch (k) {
+#define SLS_BC(K) case K: r = __builtin_amdgcn_update_dpp(0L, v, 0x150 + K, 0xf, 0xf, true); break;
+        SLS_BC(0) SLS_BC(1) SLS_BC(2) SLS_BC(3) SLS_BC(4) SLS_BC(5) SLS_BC(6) SLS_BC(7)
+        SLS_BC(8) SLS_BC(9) SLS_BC(10) SLS_BC(11) SLS_BC(12) SLS_BC(13) SLS_BC(14) SLS_BC(15)
+#undef SLS_BC
+        default: break;
+    }
+    return __builtin_bit_cast(double, r);
+}
+
+// 16x16 diagonal tile at (c0, c0): optional in-register Cholesky, then inverse.  Executed by one full wave; lane & 15 = row.
+// 1/sqrt(d) to full fp64 accuracy: hardware v_rsq_f64 seed (measured max rel. error 5.2e-8) + one third-order Newton step
+// on the residual (-> 1.4e-16, identical to a second step; diag_timing.hip).  The correctly-rounded sqrt()/division pair
+// of the math library costs ~350 dependent cycles on the pivot chain.
+__device__ __forceinline__ double rsqrt_nr(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    const double e = fma(-d * y, y, 1.0);          // 1 - d y^2
+    y = fma(y * e, fma(0.375, e, 0.5), y);          // y (1 + e/2 + 3 e^2/8)
+    return y;
+}
+
+// workgroup barrier that waits for this wave's LDS traffic only (not for outstanding global stores)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <bool FACTOR>
+__device__ __forceinline__ void diag16(double* As, double* Tk, int c0, int lane, int* info, int global_off) {
+    const int row = lane & 15;
+    double a[16], dinv[16];
+    double own_inv = 1.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a[j] = As[c0 + row + (c0 + j) * DL];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const double d = bcast(a[k], k);
+        if (FACTOR) {
+            if (!(d > 0.0) && lane == 0 && info) atomicCAS(info, 0, global_off + c0 + k + 1);
+            const double inv = rsqrt_nr(d);
+            dinv[k] = inv;
+            const double lik = a[k] * inv;   // lane k: d * rsqrt(d) = L_kk; rows < k hold unused upper-triangle values
+            a[k] = lik;
+#pragma unroll
+            for (int j = k + 1; j < 16; ++j) a[j] -= lik * bcast(lik, j);
+        } else {
+            dinv[k] = 1.0 / d;
+        }
+        own_inv = (row == k) ? dinv[k] : own_inv;
+    }
+    // inverse: B = I; for k: B[i,:] -= (L[i,k] / L_kk) B[k,:] (i > k); finally B[i,:] /= L_ii.  Row k of B is final before step
+    // k, so its scaling waits until the end (no select on the chain).  The columns of B are independent and are dealt to
+    // the four 16-lane rows of the wave: lane (row, g) keeps columns g, g+4, g+8, g+12, the broadcast of row k stays inside
+    // each 16-lane row, and step k costs k/4 + 1 broadcast + fma pairs instead of k + 1 (columns > k see B[k,j] = 0).
+    const int g = lane >> 4;
+    double bq[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bq[r] = (row == 4 * r + g) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const double ck = (row > k) ? a[k] * dinv[k] : 0.0;
+#pragma unroll
+        for (int r = 0; r <= k / 4; ++r) bq[r] = fma(-ck, bcast(bq[r], k), bq[r]);
+    }
+    if (FACTOR && lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) As[c0 + row + (c0 + j) * DL] = (j <= row) ? a[j] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int col = 4 * r + g;
+        Tk[row + 16 * col] = (col <= row) ? bq[r] * own_inv : 0.0;
+    }
+}
+
+// Linv^T tiles in the strictly-upper part of As -> natural strictly-lower positions: the 28 tiles are dealt 7 per wave
+// (tile t -> wave t & 3) with compile-time coordinates (one branch on the wave id instead of 28), reads before writes.
+// Each 16-lane group walks a wrapped diagonal of the tile (column fl, row fl + fk + 4q), so both the row-major reads and
+// the column-major writes touch 16 different banks (a straight transpose makes one side a 16-way conflict).
+template <int W>
+__device__ __forceinline__ void transpose_inverse_tiles(double* As, int fl, int fk) {
+    double tv[7][4];
+#pragma unroll
+    for (int n = 0; n < 7; ++n) {
+        const int t = 4 * n + W;
+        const int ti = t < 1 ? 1 : t < 3 ? 2 : t < 6 ? 3 : t < 10 ? 4 : t < 15 ? 5 : t < 21 ? 6 : 7;
+        const int tj = t - ti * (ti - 1) / 2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tv[n][q] = As[(16 * ti + ((fl + fk + 4 * q) & 15)) * DL + 16 * tj + fl];
+    }
+#pragma unroll
+    for (int n = 0; n < 7; ++n) {
+        const int t = 4 * n + W;
+        const int ti = t < 1 ? 1 : t < 3 ? 2 : t < 6 ? 3 : t < 10 ? 4 : t < 15 ? 5 : t < 21 ? 6 : 7;
+        const int tj = t - ti * (ti - 1) / 2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) As[(16 * tj + fl) * DL + 16 * ti + ((fl + fk + 4 * q) & 15)] = tv[n][q];
+    }
+}
+
+// The 16-column steps of the LDS-resident factorisation + inverse (see chol_diag_kernel), restricted to the leading nb16
+// 16x16 block rows/columns (nb16 = 8: the whole 128x128 block; smaller for the fused small-problem kernels, whose
+// identity padding needs no work).  On return (after the caller's barrier) the lower triangle of As holds L, the
+// strictly-upper tiles hold Linv^T and Ts the inverses of the diagonal tiles.
+template <bool FACTOR>
+__device__ __forceinline__ void chol_diag_steps(double* As, double* Ts, int* __restrict__ info, int global_off, int nb16) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fl = lane & 15, fk = lane >> 4;
+    // Per 16-column step kb (three barrier-separated phases; the strictly-upper tiles of As, unused by the factorisation,
+    // receive the inverse: slot (j, kb) holds T[kb][j] transposed, i.e. the upper triangle of As becomes Linv^T):
+    //   A  wave 0: Cholesky + inverse of the 16x16 diagonal tile (serial pivot chain, the critical path);
+    //      waves 1-3, meanwhile: S[kb][j] = sum_{j <= k < kb} L[kb][k] T[k][j] for j < kb  (block row kb of -T16^-1 Linv)
+    //   B  T[kb][j] = -T16 S[kb][j]  and (FACTOR) the panel L_r = A_r T16^T, r > kb: 7 tiles over the 4 waves
+    //   C  (FACTOR) trailing update A_ij -= L_i L_j^T, 7 >= i >= j > kb
+    for (int kb = 0; kb < nb16; ++kb) {
+        const int c0 = 16 * kb;
+#ifdef SLS_DIAG_TIMING
+        long long t_a = clock64();
+#endif
+        DIAG_STAMP_T(0, 16 + 8 * kb + 0);
+        if (wave == 0) {
+            diag16<FACTOR>(As, Ts + 256 * kb, c0, lane, info, global_off);
+            DIAG_STAMP_T(0, 16 + 8 * kb + 1);
+        } else {
+            // tile j costs kb - j MFMA groups: waves 1..3 take j = {0, 5, 6}, {1, 4}, {2, 3} (10 / 9 / 9 groups at kb = 7)
+            const int js[3] = {wave - 1, 6 - wave, wave == 1 ? 6 : 8};
+            for (int n = 0; n < 3; ++n) {
+                const int j = js[n];
+                if (j >= kb) continue;
+                d4_t c = {0.0, 0.0, 0.0, 0.0};
+                for (int k = j; k < kb; ++k) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const int kq = 4 * kk + fk;
+                        const double af = As[(16 * k + kq) * DL + c0 + fl];   // L[kb][k] (row m = fl, col kq)
+                        // T[k][j] (row kq, col n = fl): diagonal inverse in Ts for k == j, transposed upper slot otherwise
+                        const double bf = (k == j) ? Ts[256 * j + kq + 16 * fl] : As[(16 * k + kq) * DL + 16 * j + fl];
+                        c = mfma16(af, bf, c);   // operands swapped: lane holds S (m = fk + 4q, n = fl), stores run along n
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) As[(c0 + fk + 4 * q) * DL + 16 * j + fl] = c[q];   // S -> slot (j, kb)
+            }
+            DIAG_STAMP_T(64, 16 + 8 * kb + 5);
+        }
+        __syncthreads();
+        DIAG_STAMP_T(0, 16 + 8 * kb + 2);
+#ifdef SLS_DIAG_TIMING
+        if (tid == 0 && kb == 0 && info) ((long long*)info)[7] = clock64() - t_a;
+#endif
+        const double* Tk = Ts + 256 * kb;
+        for (int t = wave; t < nb16 - 1; t += 4) {
+            if (t < kb) {
+                const int j = t;
+                d4_t c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int kq = 4 * kk + fk;
+                    const double af = -Tk[fl + 16 * kq];                        // -T16 (row m = fl, col kq)
+                    const double bf = As[(c0 + kq) * DL + 16 * j + fl];         // S (row kq, col n = fl)
+                    c = mfma16(af, bf, c);   // swapped as for S
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) As[(c0 + fk + 4 * q) * DL + 16 * j + fl] = c[q];
+            } else if (FACTOR) {
+                const int r = t + 1;   // panel: L_r = A_r T16^T
+                d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int k = 4 * kk + fk;
+                    const double af = As[(c0 + k) * DL + 16 * r + fl];   // A_r[m = fl][k]
+                    const double bf = Tk[fl + 16 * k];                    // T[n = fl][k]
+                    acc = mfma16(bf, af, acc);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) As[(c0 + fk + 4 * q) * DL + 16 * r + fl] = acc[q];
+            }
+        }
+        __syncthreads();
+        DIAG_STAMP_T(0, 16 + 8 * kb + 3);
+        if (!FACTOR) continue;
+        // trailing update: A_ij -= L_i L_j^T for 7 >= i >= j > kb.  Wave 0 takes only the next diagonal tile and runs straight
+        // on into its pivot chain (no barrier here: nobody else touches that tile); waves 1-3 share the other tiles and then
+        // the S tiles of the next step, all hidden behind the chain.
+        auto update_tile = [&](int i, int j) {
+            d4_t acc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = As[(16 * j + fk + 4 * q) * DL + 16 * i + fl];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int k = c0 + 4 * kk + fk;
+                const double af = -As[k * DL + 16 * i + fl];
+                const double bf = As[k * DL + 16 * j + fl];
+                acc = mfma16(bf, af, acc);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) As[(16 * j + fk + 4 * q) * DL + 16 * i + fl] = acc[q];
+        };
+        if (wave == 0) {
+            if (kb < nb16 - 1) update_tile(kb + 1, kb + 1);
+        } else {
+            // tiles in column-major order after the first, (i, j) advanced 3 at a time
+            int i = kb + 1, j = kb + 1;
+            auto advance = [&](int n) {
+                for (; n > 0; --n) {
+                    if (++i == nb16) { ++j; i = j; }
+                }
+            };
+            advance(wave);
+            while (j < nb16) {
+                update_tile(i, j);
+                advance(3);
+            }
+        }
+        DIAG_STAMP_T(0, 16 + 8 * kb + 4);
+        DIAG_STAMP_T(64, 16 + 8 * kb + 6);
+    }
+}
+
+}  // namespace slsk

@@ -213,7 +213,14 @@ def test_invalid_arguments(ctx):
 
 # ---- MAP objectives ------------------------------------------------------------
 
-def test_gp_map_objective_against_mpmath_and_oracle(ctx, oracle, fixtures):
+@pytest.fixture(params=["small", "tiled"])
+def nllpath(request, monkeypatch):
+    """N <= 128 evaluations run the fused single-launch kernel (kernels_small.hip) unless SLS_NLL_SMALL=0: both paths must pass."""
+    monkeypatch.setenv("SLS_NLL_SMALL", "1" if request.param == "small" else "0")
+    return request.param
+
+
+def test_gp_map_objective_against_mpmath_and_oracle(ctx, oracle, fixtures, nllpath):
     for c in fixtures["gp_map"]:                      # independent 50-digit values
         h = sls().Nll(ctx, np.array(c["X"]), c["kernel"])
         v, g = h.gp_objective(c["y"], c["x"])
@@ -235,7 +242,7 @@ def test_gp_map_objective_against_mpmath_and_oracle(ctx, oracle, fixtures):
 
 @pytest.mark.parametrize("kernel", [0, 1])
 @pytest.mark.parametrize("use_map", [False, True])
-def test_preference_objective(ctx, oracle, fixtures, kernel, use_map):
+def test_preference_objective(ctx, oracle, fixtures, kernel, use_map, nllpath):
     for c in fixtures["pref_objective"]:
         if c["kernel"] != kernel or c["use_map"] != use_map:
             continue
@@ -279,6 +286,37 @@ def test_nll_core_terms(ctx, oracle):
     Kinv = oracle.spd_inverse_from_chol(L)
     close(r["grad_b"], 0.5 * (al @ al - np.trace(Kinv)), rtol=1e-7)
     h.close()
+
+
+@pytest.mark.parametrize("kernel", [0, 1])
+@pytest.mark.parametrize("D,N", [(1, 1), (1, 5), (2, 16), (3, 17), (16, 64), (5, 100), (4, 128), (32, 90)])
+def test_fused_small_objective_matches_tiled_and_oracle(ctx, oracle, kernel, D, N, monkeypatch):
+    """kernels_small.hip (whole evaluation in one workgroup) against the tiled pipeline and the oracle, over the 16-block
+    boundaries of its LDS factorisation (N = 16, 17, 128) and with D above its gradient limit (D = 32: no theta gradient)."""
+    X, y, theta, b = synth_problem(oracle, D, N)
+    K = oracle.calc_large_ky(kernel, X, theta, b)
+    L, _ = oracle.cholesky(K)
+    al = oracle.chol_solve(L, y)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SLS_NLL_SMALL", flag)
+        h = sls().Nll(ctx, X, kernel)
+        r = h.eval(y, theta, b, want_grad=(D <= 16))
+        close(r["alpha"], al, rtol=1e-7, atol=1e-9 * max(np.abs(al).max(), 1e-30))
+        close(r["quad"], y @ al, rtol=1e-9)
+        close(r["logdet"], oracle.logdet_from_chol(L), rtol=1e-10, atol=1e-12)
+        if D <= 16:
+            x = np.concatenate([[theta[0], b], theta[1:]])
+            vo, go = oracle.gp_map_objective(kernel, X, y, x)
+            v, g = h.gp_objective(y, x)
+            close(v, vo, rtol=1e-9, atol=1e-10)
+            close(g, go, rtol=RTOL, atol=1e-6 * max(np.abs(go).max(), 1e-30))
+            res[flag] = (r["quad"], r["logdet"], r["grad_b"], r["grad_theta"], v, g)
+        else:
+            res[flag] = (r["quad"], r["logdet"])
+        h.close()
+    for u, w in zip(res["1"], res["0"]):
+        close(u, w, rtol=1e-7, atol=1e-9 * max(np.abs(np.asarray(w)).max(), 1e-30))
 
 
 # ---- edge cases (SURVEY.md 8c: empty / ragged / maximum sizes / duplicates) ----------------------------------------------
