@@ -114,15 +114,26 @@ static void nll_small_eval(sls_nll* h, const double* y, const double* theta, dou
     SLS_REQUIRE(theta[0] > 0.0, "signal variance must be positive");
     for (int d = 0; d < D; ++d) SLS_REQUIRE(theta[1 + d] > 0.0, "length scale %d must be positive", d);
     const bool want_grad = grad_theta || grad_b;
-    std::vector<double> in(2 + D + N);
-    in[0] = theta[0]; in[1] = b;
-    for (int d = 0; d < D; ++d) in[2 + d] = theta[1 + d];
-    for (int i = 0; i < N; ++i) in[2 + D + i] = y[i];
-    h->small_in.ensure(in.size());
+    NllSmallArgs args;
+    args.X = h->X.p; args.D = D; args.N = N; args.want_grad = want_grad ? 1 : 0;
+    args.info = c->d_info;
     h->small_out.ensure(160);
-    SLS_HIP(hipMemcpyAsync(h->small_in.p, in.data(), in.size() * 8, hipMemcpyHostToDevice, c->stream));
-    SLS_HIP(hipMemsetAsync(c->d_info, 0, 64, c->stream));
-    launch_nll_small(c->stream, h->kernel, h->X.p, D, N, h->small_in.p, want_grad, c->d_info, h->small_out.p);
+    args.out = h->small_out.p;
+    args.in_dev = nullptr;
+    if (D <= NLL_SMALL_MAX_GRAD_D) {
+        args.a = theta[0]; args.b = b;
+        for (int d = 0; d < D; ++d) args.ell[d] = theta[1 + d];
+        std::memcpy(args.y, y, sizeof(double) * N);
+    } else {
+        std::vector<double> in(2 + D + N);
+        in[0] = theta[0]; in[1] = b;
+        for (int d = 0; d < D; ++d) in[2 + d] = theta[1 + d];
+        for (int i = 0; i < N; ++i) in[2 + D + i] = y[i];
+        h->small_in.ensure(in.size());
+        SLS_HIP(hipMemcpyAsync(h->small_in.p, in.data(), in.size() * 8, hipMemcpyHostToDevice, c->stream));   // pageable: staged before return
+        args.in_dev = h->small_in.p;
+    }
+    launch_nll_small(c->stream, h->kernel, args);
     double out[160];
     const int nout = alpha ? 32 + N : 32;
     SLS_HIP(hipMemcpyAsync(out, h->small_out.p, nout * 8, hipMemcpyDeviceToHost, c->stream));

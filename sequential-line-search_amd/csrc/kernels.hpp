@@ -36,13 +36,23 @@ void launch_cross_gram(hipStream_t s, const double* XsT, long lds_, const double
                        long ldk, double* mu_part, double* ca_part);
 
 // ---- kernels_small.hip ---------------------------------------------------------
-// Whole MAP-objective evaluation for N <= 128 in one single-workgroup launch.  in = [a, b, l_1..l_D, y_1..y_N] (device),
-// out (device, 160 doubles): [0] sum W.*K_f, [1] d/db, [2] y^T alpha, [3] logdet, [4] potrf info, [8..8+D) d/dl (only if
-// want_grad and D <= NLL_SMALL_MAX_GRAD_D), [32..32+N) alpha.  X: raw D x N column-major design matrix (device).
+// Whole MAP-objective evaluation for N <= 128 in one single-workgroup launch.  Inputs a, b, l_1..l_D, y_1..y_N travel in
+// the kernel argument block (D <= 16) or in in_dev = [a, b, l.., y..] (device).  out (device, 160 doubles):
+// [0] sum W.*K_f, [1] d/db, [2] y^T alpha, [3] logdet, [4] potrf info, [8..8+D) d/dl (only if want_grad and
+// D <= NLL_SMALL_MAX_GRAD_D), [32..32+N) alpha.  X: raw D x N column-major design matrix (device).
 constexpr int NLL_SMALL_MAX_N = 128;
 constexpr int NLL_SMALL_MAX_GRAD_D = 16;
-void launch_nll_small(hipStream_t s, int kernel, const double* X, int D, int N, const double* in, bool want_grad, int* info,
-                      double* out);
+struct NllSmallArgs {
+    const double* X;
+    int D, N, want_grad;
+    int* info;
+    double* out;
+    const double* in_dev;
+    double a, b;
+    double ell[NLL_SMALL_MAX_GRAD_D];
+    double y[NLL_SMALL_MAX_N];
+};
+void launch_nll_small(hipStream_t s, int kernel, const NllSmallArgs& args);
 
 // ---- kernels_acq.hip ---------------------------------------------------------
 // P[n + i*ldk] = Cs * (Kinv Ks)  and the partial column sums kw_part (Ks.*W), cw_part (Cs.*W) per 128-row tile of i.

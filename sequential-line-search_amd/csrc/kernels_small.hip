@@ -32,19 +32,23 @@ __device__ __forceinline__ double small_block_sum(double v, double* As) {
 
 // scratch map: [0,128) alpha, [128,256) y, [256,384) 1/l, [1024,1028) reduction slots
 template <bool MATERN>
-__global__ __launch_bounds__(256) void nll_small_kernel(const double* __restrict__ X, int D, int N, const double* __restrict__ in,
-                                                        int want_grad, int* __restrict__ info, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void nll_small_kernel(const NllSmallArgs args) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* As = reinterpret_cast<double*>(smem);
     double* Ts = As + 128 * DL;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fl = lane & 15, fk = lane >> 4;
+    const double* __restrict__ X = args.X;
+    double* __restrict__ out = args.out;
+    int* __restrict__ info = args.info;
+    const int D = args.D, N = args.N, want_grad = args.want_grad;
     const int nb16 = (N + 15) >> 4, Nb = 16 * nb16;
-    const double a = in[0], b = in[1];
-    const double* ell = in + 2;
-    const double* y = in + 2 + D;
-    for (int d = tid; d < D; d += 256) small_scratch(As, 256 + d) = 1.0 / ell[d];
-    for (int i = tid; i < 128; i += 256) small_scratch(As, 128 + i) = i < N ? y[i] : 0.0;
+    // hyper-parameters and targets travel in the kernel argument block (no upload); D > 16 falls back to a device buffer
+    const double a = args.in_dev ? args.in_dev[0] : args.a, b = args.in_dev ? args.in_dev[1] : args.b;
+    for (int d = tid; d < D; d += 256) small_scratch(As, 256 + d) = 1.0 / (args.in_dev ? args.in_dev[2 + d] : args.ell[d]);
+    for (int i = tid; i < 128; i += 256)
+        small_scratch(As, 128 + i) = i < N ? (args.in_dev ? args.in_dev[2 + D + i] : args.y[i]) : 0.0;
+    if (tid == 0) *info = 0;
     __syncthreads();
 
     auto pair_q = [&](int i, int j) {
@@ -192,8 +196,7 @@ __global__ __launch_bounds__(256) void nll_small_kernel(const double* __restrict
     }
 }
 
-void launch_nll_small(hipStream_t s, int kernel, const double* X, int D, int N, const double* in, bool want_grad, int* info,
-                      double* out) {
+void launch_nll_small(hipStream_t s, int kernel, const NllSmallArgs& args) {
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)nll_small_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES);
@@ -201,9 +204,9 @@ void launch_nll_small(hipStream_t s, int kernel, const double* X, int D, int N, 
         attr = true;
     }
     if (kernel == SLS_KERNEL_ARD_MATERN52)
-        hipLaunchKernelGGL(nll_small_kernel<true>, dim3(1), dim3(256), DIAG_LDS_BYTES, s, X, D, N, in, want_grad ? 1 : 0, info, out);
+        hipLaunchKernelGGL(nll_small_kernel<true>, dim3(1), dim3(256), DIAG_LDS_BYTES, s, args);
     else
-        hipLaunchKernelGGL(nll_small_kernel<false>, dim3(1), dim3(256), DIAG_LDS_BYTES, s, X, D, N, in, want_grad ? 1 : 0, info, out);
+        hipLaunchKernelGGL(nll_small_kernel<false>, dim3(1), dim3(256), DIAG_LDS_BYTES, s, args);
 }
 
 }  // namespace slsk
