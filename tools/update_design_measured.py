@@ -30,7 +30,7 @@ new = f'''| quantity (C4: N=8192, D=64, Matern-5/2, 65 536 starts x 50 evals, 1 
 | other stages per step (ms) | cross_gram {st["cross_gram"]:.0f} ({sr.get("cross_gram", {}).get("achieved_GBps", 0)/1e3:.1f} TB/s written, transcendental-bound), grad_gemm {st["grad_gemm"]:.0f} ({sr.get("grad_gemm", {}).get("achieved_GBps", 0)/1e3:.1f} TB/s read), lbfgs {st["lbfgs"]:.0f}, finalize {st["finalize"]:.0f}; fit: gram {st["gram"]:.2f}, potrf {st["potrf"]:.1f} ({sr.get("potrf", {}).get("achieved_TFLOPs", 0):.0f} TFLOP/s, latency-bound diagonal chain), trtri {st["trtri"]:.1f} ({sr.get("trtri", {}).get("achieved_TFLOPs", 0):.0f} TFLOP/s), lauum {st["lauum"]:.1f} ({sr.get("lauum", {}).get("achieved_TFLOPs", 0):.0f} TFLOP/s) |
 | C2 (N=2048, D=16, SE): fit / 4096-point predict | {c2["fit_ms_wall_incl_upload"]:.1f} ms / {c2["predict_ms_wall_incl_pcie"]:.2f} ms wall incl. PCIe (oracle on the host: {c2["cpu_oracle_fit_s"]:.1f} s / {c2["cpu_oracle_predict_s"]:.2f} s) |
 | C5 (N=4096, D=128, Matern): MAP objective + gradient | {c5["ms_per_evaluation"]:.1f} ms per evaluation (8.2 ms before the diagonal-block kernel rewrite and the 128x64 trtri tiles) |
-| C3 (`sequential_line_search_nd 32 30`) | {c3["ms_per_submit_mean"]:.0f} ms per `SubmitFeedbackData` on average (61 ms before the per-start wavefront kernel); C1 (`bayesian_optimization_1d 1 20`): {c1["wall_s"]:.2f} s for 20 iterations, dominated by ~240 launch-bound MAP evaluations per fit |
+| C3 (`sequential_line_search_nd 32 30`) | {c3["ms_per_submit_mean"]:.0f} ms per `SubmitFeedbackData` on average (first call included; ~11 ms steady state; 61 ms before the per-start wavefront kernel); C1 (`bayesian_optimization_1d 1 20`): {c1["wall_s"]:.2f} s for 20 iterations (0.93 s with the ~20-launch tiled MAP evaluation, before `nll_small_kernel`) |
 | parity vs the oracle (`profiles/r01_parity_report.md`) | max relative error 1e-16 .. 3e-11 on mu, sigma, gradients, EI, UCB; 4e-11 on EI; chosen maximiser x within 1.1e-8 |
 
 '''
