@@ -95,6 +95,12 @@ __device__ __forceinline__ double frag_read(const double* lds, int mbase, int kk
         return lds[(mbase + (lane & 15)) * GEMM_LDS_KC_LD + 4 * kk + (lane >> 4)];
 }
 
+// 64 lanes x 16 B from global memory straight into 1024 contiguous LDS bytes at l (wave-uniform): global_load_lds_dwordx4
+__device__ __forceinline__ void slab_row_to_lds(const double* g, double* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0,
+                                     0);
+}
+
 // Accumulate acc += opA[m0.., kb..ke) * opB[n0.., kb..ke)^T.
 // A, B point at row m0 / n0, k = 0 of their panels.  kb, ke multiples of 16.
 // The k loop starts at slab `kfirst` (kb <= kfirst < ke, multiple of 16) and wraps around at ke: tiles that share an
@@ -116,11 +122,32 @@ __device__ __forceinline__ void gemm_tile(Acc& acc, const double* __restrict__ A
     // pointers (double* buf[2]) makes hipcc lose the LDS address space and emit flat_load/flat_store, whose
     // s_waitcnt vmcnt(0) then drains the global prefetch before every MFMA group (measured: 72 % -> MFMA busy).
     // layout: [A0 | B0 | A1 | B1], each GEMM_LDS_TILE doubles
+    // Both operands M-contiguous: a k-row of a slab is 128 contiguous doubles = 64 lanes x 16 B, exactly what one
+    // global_load_lds_dwordx4 (LDS-direct load, gfx950) deposits at LDS base + 16 B * lane.  The slab then never passes
+    // through VGPRs: no staging registers (-32 VGPRs), no ds_write, no vmcnt -> ds_write dependency in the MFMA stream
+    // (gemm_probe_lds: 70.0 -> 71.2 TFLOP/s at 16384 x 8192 x 8192, 50 -> 56 TFLOP/s at 2048^3).  Wave w brings rows
+    // 4w .. 4w+3 of both operands; the loads of slab s+1 are issued at the top of slab s and must have landed
+    // (s_waitcnt vmcnt(0)) before the barrier that publishes the buffer.
+    constexpr bool DIRECT = !A_KC && !B_KC;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto issue_direct = [&](int k0, int bufoff) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * wave_u + r;
+            slab_row_to_lds(A + 2 * lane + (long)(k0 + row) * lda, lds + bufoff + row * GEMM_LDS_MC_LD);
+            slab_row_to_lds(B + 2 * lane + (long)(k0 + row) * ldb, lds + bufoff + GEMM_LDS_TILE + row * GEMM_LDS_MC_LD);
+        }
+    };
     Stage sa, sb;
-    stage_load<A_KC>(sa, A, lda, kfirst, tid);
-    stage_load<B_KC>(sb, B, ldb, kfirst, tid);
-    stage_store<A_KC>(sa, lds, tid);
-    stage_store<B_KC>(sb, lds + GEMM_LDS_TILE, tid);
+    if (DIRECT) {
+        issue_direct(kfirst, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        stage_load<A_KC>(sa, A, lda, kfirst, tid);
+        stage_load<B_KC>(sb, B, ldb, kfirst, tid);
+        stage_store<A_KC>(sa, lds, tid);
+        stage_store<B_KC>(sb, lds + GEMM_LDS_TILE, tid);
+    }
     __syncthreads();
 
     int cur = 0;   // offset (doubles) of the buffer pair being consumed
@@ -131,8 +158,12 @@ __device__ __forceinline__ void gemm_tile(Acc& acc, const double* __restrict__ A
         knext += GEMM_BK;
         if (knext >= ke) knext = kb;
         if (more) {
-            stage_load<A_KC>(sa, A, lda, knext, tid);
-            stage_load<B_KC>(sb, B, ldb, knext, tid);
+            if (DIRECT) {
+                issue_direct(knext, cur ^ (2 * GEMM_LDS_TILE));
+            } else {
+                stage_load<A_KC>(sa, A, lda, knext, tid);
+                stage_load<B_KC>(sb, B, ldb, knext, tid);
+            }
         }
         const double* la = lds + cur;
         const double* lb = lds + cur + GEMM_LDS_TILE;
@@ -150,7 +181,9 @@ __device__ __forceinline__ void gemm_tile(Acc& acc, const double* __restrict__ A
                     acc.v[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc.v[i][j], 0, 0, 0);
         }
         const int nxt = cur ^ (2 * GEMM_LDS_TILE);
-        if (more) {
+        if (DIRECT) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (more) {
             stage_store<A_KC>(sa, lds + nxt, tid);
             stage_store<B_KC>(sb, lds + nxt + GEMM_LDS_TILE, tid);
         }
