@@ -82,16 +82,16 @@ __device__ __forceinline__ void acq_tile(int t, int ntm, int ntn, const double* 
     }
 }
 
-// One tile per workgroup (sync == nullptr, the default), or the persistent form (SLS_PERSIST=1): gridDim.x = 8 * slots
-// workgroups, all resident (slots = 2 per CU x 32 CUs per XCD), workgroup b = slot b>>3 of XCD b&7.  Generation i of XCD x
-// is the 64-tile chunk x + 8 i (an 8 x 8 block of tiles sharing 16 operand panels); the 64 slots of an XCD start each
-// generation together, gated by a per-XCD counter of finished tiles.  Panel sharing through the 4 MB L2 only works while
-// the co-resident sharers of a panel are within ~16 slabs of each other in k; the gate enforces that (PMC: hit rate
-// 0.84-0.85, 19-20 GB per launch in every run) where the ungated form depends on how far the tiles of an XCD drift apart
-// (0.66-0.85, 20-48 GB observed across builds with an identical k loop).  The gate costs ~1.6 % kernel time: both
-// workgroups of a CU then run their epilogues at the same moment instead of hiding them behind each other's MFMA loop,
-// so it is off by default.  The wait is a bounded spin: the gate is a locality hint, not a correctness requirement, and
-// an unexpected residency pattern cannot hang the device.
+// The persistent, generation-gated form (default) or one tile per workgroup (sync == nullptr, SLS_PERSIST=0).
+// Persistent: gridDim.x = 8 * slots workgroups, all resident (slots = 2 per CU x 32 CUs per XCD), workgroup b = slot b>>3 of
+// XCD b&7.  Generation i of XCD x is the 64-tile chunk x + 8 i (an 8 x 8 block of tiles sharing 16 operand panels); the 64
+// slots of an XCD start each generation together, gated by a per-XCD counter of finished tiles.  Panel sharing through the
+// 4 MB L2 only works while the co-resident sharers of a panel are within ~16 slabs of each other in k; the gate enforces
+// that (PMC: hit rate 0.85, 82 GB of fabric reads per 65 536-candidate launch in every run) where the ungated form depends
+// on how far the tiles of an XCD drift apart (hit rates 0.37-0.85, 80-350 GB observed across builds with an identical k
+// loop; 0.44 / 314 GB with the LDS-direct loads).  The gate costs ~1 % kernel time: both workgroups of a CU then run their
+// epilogues at the same moment instead of hiding them behind each other's MFMA loop.  The wait is a bounded spin: the
+// gate is a locality hint, not a correctness requirement, and an unexpected residency pattern cannot hang the device.
 template <bool MATERN>
 __global__ __launch_bounds__(256, 2) void acq_gemm_kernel(const double* __restrict__ Ks, const double* __restrict__ Cs, long ldk,
                                                           int Sp, const double* __restrict__ Kinv, int Np,
@@ -135,12 +135,12 @@ void launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk
         attr = true;
     }
     const int nt = (Sp / GEMM_BM) * (Np / GEMM_BN);
-    // SLS_STAGGER (0 off, 1 default: on unless gated, 2 always) and SLS_PERSIST (0 default, 1 gated form) are read per
+    // SLS_STAGGER (0 off, 1 default: on unless gated, 2 always) and SLS_PERSIST (1 default: gated form, 0 one tile per workgroup) are read per
     // call so that tests and A/B runs can switch within one process
     const char* es = getenv("SLS_STAGGER");
     const char* ep = getenv("SLS_PERSIST");
     const int stagger_env = es ? atoi(es) : 1;
-    const int persist_env = ep ? atoi(ep) : 0;
+    const int persist_env = ep ? atoi(ep) : 1;
     // persistent, generation-gated form when there are at least two generations of tiles (MI355X: 256 CUs x 2 = 512 slots)
     const bool persist = persist_env && sync && nt >= 1024 && Np >= 2048;
     const int stagger = (stagger_env == 1 && !persist && Np >= 2048) || stagger_env == 2 ? 1 : 0;
