@@ -235,16 +235,29 @@ __device__ __forceinline__ void gemm_tile_n64(Acc64& acc, const double* __restri
             *reinterpret_cast<d2_t*>(l + n * GEMM_LDS_KC_LD + 2 * k2) = sbr[i];
         }
     };
-    stage_load<A_KC>(sa, A, lda, kb, tid);
+    // M-contiguous A (the streamed operand of the gradient contractions): LDS-direct loads as in gemm_tile
+    constexpr bool DIRECT_A = !A_KC;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto issue_a = [&](int k0, int bufoff) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * wave_u + r;
+            slab_row_to_lds(A + 2 * lane + (long)(k0 + row) * lda, lds + bufoff + row * GEMM_LDS_MC_LD);
+        }
+    };
+    if (DIRECT_A) issue_a(kb, 0);
+    else stage_load<A_KC>(sa, A, lda, kb, tid);
     load_b(kb);
-    stage_store<A_KC>(sa, lds, tid);
+    if (DIRECT_A) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else stage_store<A_KC>(sa, lds, tid);
     store_b(lds + GEMM_LDS_TILE);
     __syncthreads();
     int cur = 0;
     for (int k0 = kb; k0 < ke; k0 += GEMM_BK) {
         const bool more = (k0 + GEMM_BK) < ke;
         if (more) {
-            stage_load<A_KC>(sa, A, lda, k0 + GEMM_BK, tid);
+            if (DIRECT_A) issue_a(k0 + GEMM_BK, cur ^ GEMM_N64_LDS_BUF);
+            else stage_load<A_KC>(sa, A, lda, k0 + GEMM_BK, tid);
             load_b(k0 + GEMM_BK);
         }
         const double* la = lds + cur;
@@ -264,9 +277,10 @@ __device__ __forceinline__ void gemm_tile_n64(Acc64& acc, const double* __restri
         }
         const int nxt = cur ^ GEMM_N64_LDS_BUF;
         if (more) {
-            stage_store<A_KC>(sa, lds + nxt, tid);
+            if (!DIRECT_A) stage_store<A_KC>(sa, lds + nxt, tid);
             store_b(lds + nxt + GEMM_LDS_TILE);
         }
+        if (DIRECT_A) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         cur = nxt;
     }
