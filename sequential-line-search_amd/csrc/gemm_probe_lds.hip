@@ -56,11 +56,7 @@ __global__ __launch_bounds__(256, 2) void probe_lds_kernel(const double* __restr
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
 #ifdef SPREAD
-            if (more) {
-                const int row = 4 * wave + kk;
-                row_to_lds(Ap + (long)(k0 + GEMM_BK + row) * lda, lds + nxt + row * GEMM_LDS_MC_LD);
-                row_to_lds(Bp + (long)(k0 + GEMM_BK + row) * ldb, lds + nxt + GEMM_LDS_TILE + row * GEMM_LDS_MC_LD);
-            }
+            if (more && kk == SPREAD) issue(k0 + GEMM_BK, lds + nxt);
 #endif
             double af[4], bf[4];
 #pragma unroll
