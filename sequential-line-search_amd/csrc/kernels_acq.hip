@@ -87,16 +87,18 @@ __device__ __forceinline__ void acq_tile(int t, int ntm, int ntn, const double* 
 // XCD b&7.  Generation i of XCD x is the 64-tile chunk x + 8 i (an 8 x 8 block of tiles sharing 16 operand panels); the 64
 // slots of an XCD start each generation together, gated by a per-XCD counter of finished tiles.  Panel sharing through the
 // 4 MB L2 only works while the co-resident sharers of a panel are within ~16 slabs of each other in k; the gate enforces
-// that (PMC: hit rate 0.85, 82 GB of fabric reads per 65 536-candidate launch in every run) where the ungated form depends
-// on how far the tiles of an XCD drift apart (hit rates 0.37-0.85, 80-350 GB observed across builds with an identical k
-// loop; 0.44 / 314 GB with the LDS-direct loads).  The gate costs ~1 % kernel time: both workgroups of a CU then run their
-// epilogues at the same moment instead of hiding them behind each other's MFMA loop.  The wait is a bounded spin: the
+// that (PMC: hit rate 0.80-0.86 in every run) where the ungated form depends on how far the tiles of an XCD drift apart
+// (hit rates 0.37-0.85, 80-350 GB per 65 536-candidate launch observed across builds with an identical k loop; 0.42 / 333 GB
+// with the LDS-direct loads).  One gate per XCD costs ~1 % kernel time: both workgroups of a CU then run their epilogues
+// at the same moment instead of hiding them behind each other's MFMA loop; two phase-shifted gate groups (below) recover
+// it.  The wait is a bounded spin: the
 // gate is a locality hint, not a correctness requirement, and an unexpected residency pattern cannot hang the device.
 template <bool MATERN>
 __global__ __launch_bounds__(256, 2) void acq_gemm_kernel(const double* __restrict__ Ks, const double* __restrict__ Cs, long ldk,
                                                           int Sp, const double* __restrict__ Kinv, int Np,
                                                           double* __restrict__ P, double* __restrict__ kw_part,
-                                                          double* __restrict__ cw_part, int stagger, int* __restrict__ sync) {
+                                                          double* __restrict__ cw_part, int stagger, int* __restrict__ sync,
+                                                          int phase) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
     const int ntm = Sp / GEMM_BM, ntn = Np / GEMM_BN;
@@ -107,13 +109,28 @@ __global__ __launch_bounds__(256, 2) void acq_gemm_kernel(const double* __restri
     }
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
     const int nchunks = (ntiles + slots - 1) / slots;
+    // Slots s and s + slots/2 of an XCD share a CU (cu_probe.hip: all 256 pairs).  With `phase` the two halves are gated
+    // separately and the upper half starts `phase` ticks (100 MHz) late, so the two workgroups of a CU never run their
+    // epilogues at the same moment (one tile's epilogue hides behind the other's MFMA loop again) while sharers of a
+    // panel stay a few slabs apart, inside the L2 window.
+    const int half = slots >> 1;
+    const int grp = phase > 0 ? (slot >= half ? 1 : 0) : 0;
+    int* gate = sync + 2 * xcd + grp;
+    const int per_gen = phase > 0 ? half : slots;
+    if (grp == 1) {
+        if (threadIdx.x == 0) {
+            const long long t0 = wall_clock64();
+            while (wall_clock64() - t0 < phase) __builtin_amdgcn_s_sleep(16);
+        }
+        __syncthreads();
+    }
     int gen = 0;
     for (int c = xcd; c < nchunks; c += 8, ++gen) {
         if (gen > 0) {
             if (threadIdx.x == 0) {
-                const int target = slots * gen;
+                const int target = per_gen * gen;
                 const long long t0 = wall_clock64();
-                while (__hip_atomic_load(sync + xcd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target &&
+                while (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target &&
                        wall_clock64() - t0 < 20000)   // 100 MHz counter: give up after 200 us
                     __builtin_amdgcn_s_sleep(16);
             }
@@ -122,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void acq_gemm_kernel(const double* __restri
         const int t = c * slots + slot;
         if (t < ntiles) acq_tile<MATERN>(t, ntm, ntn, Ks, Cs, ldk, Kinv, Np, P, kw_part, cw_part, stagger, lds);
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(sync + xcd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(gate, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -141,22 +158,27 @@ void launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk
     const char* ep = getenv("SLS_PERSIST");
     const int stagger_env = es ? atoi(es) : 1;
     const int persist_env = ep ? atoi(ep) : 1;
+    // SLS_GATE_PHASE: start offset (ticks of the 100 MHz clock) between the two gate groups of an XCD; 0: one gate per XCD.
+    // Measured per 65 536-candidate launch: phase 0 124.8 ms / 77 GB (hit rate 0.856); phase 2000..8000 123.2-123.3 ms /
+    // 112 GB (0.795: each group of 8 x 4 tiles shares 12 panels); ungated 124.9 ms / 333 GB (0.42).
+    const char* eph = getenv("SLS_GATE_PHASE");
+    const int phase = eph ? atoi(eph) : 2000;
     // persistent, generation-gated form when there are at least two generations of tiles (MI355X: 256 CUs x 2 = 512 slots)
     const bool persist = persist_env && sync && nt >= 1024 && Np >= 2048;
     const int stagger = (stagger_env == 1 && !persist && Np >= 2048) || stagger_env == 2 ? 1 : 0;
     int* sy = nullptr;
     int grid = nt;
     if (persist) {
-        (void)hipMemsetAsync(sync, 0, 8 * sizeof(int), s);
+        (void)hipMemsetAsync(sync, 0, 16 * sizeof(int), s);
         sy = sync;
         grid = 512;
     }
     if (Cs != Ks)
         hipLaunchKernelGGL(acq_gemm_kernel<true>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, Ks, Cs, ldk, Sp, Kinv, Np, P,
-                           kw_part, cw_part, stagger, sy);
+                           kw_part, cw_part, stagger, sy, phase);
     else
         hipLaunchKernelGGL(acq_gemm_kernel<false>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, Ks, Cs, ldk, Sp, Kinv, Np, P,
-                           kw_part, cw_part, stagger, sy);
+                           kw_part, cw_part, stagger, sy, phase);
 }
 
 // ---------------------------------------------------------------------------------------------------------
