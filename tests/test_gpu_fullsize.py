@@ -153,3 +153,24 @@ def test_acq_gemm_scheduling_variants_agree(ctx, oracle, kernel, monkeypatch):
             np.testing.assert_allclose(val, base[0], rtol=1e-8, atol=1e-11 * np.abs(base[0]).max())
             np.testing.assert_allclose(grad, base[1], rtol=1e-7, atol=1e-9 * np.abs(base[1]).max())
     gp.close()
+
+
+def test_beyond_headline_size_n16384(ctx, oracle):
+    """Twice the headline N (N = 16 384: 2 GB per N x N matrix, 128 block steps of the Cholesky, 7 trtri levels): the
+    size-independent posterior identities must still hold; the predictions here take the triangular var_gemm path on its
+    XCD-grouped tile order (128 x 8 tile groups) and the value+gradient path the gated acq_gemm with 16 generations."""
+    D, N = 32, 16384
+    X, y, theta, b = synth_problem(oracle, D, N)
+    gp = sls().GP(ctx, X, y, theta, b, 1)
+    _posterior_identities(gp, X, y, theta, b, n_check=1024)
+    Xs = synth_candidates(oracle, D, 2048)
+    v, g = gp.acq_eval(Xs)
+    v0 = gp.acq_eval(Xs, want_grad=False)
+    np.testing.assert_allclose(v0, v, rtol=1e-6, atol=1e-9 * np.abs(v).max())
+    h = 1e-6
+    d = np.random.default_rng(3).normal(size=(D, 1)); d /= np.linalg.norm(d)
+    pick = np.argsort(-v)[:8]
+    fp = gp.acq_eval(Xs[:, pick] + h * d, want_grad=False)
+    fm = gp.acq_eval(Xs[:, pick] - h * d, want_grad=False)
+    np.testing.assert_allclose((fp - fm) / (2 * h), (g[:, pick] * d).sum(axis=0), rtol=2e-4, atol=1e-7 * np.abs(g).max())
+    gp.close()
