@@ -1,5 +1,6 @@
 // Host-logic checks that need no GPU (run by tests/test_host_logic_cpu.py): data manager merge semantics, slider
 // enlargement, BTL helpers, the bounded L-BFGS driver, CSV round trip, kernel scalar forms, error behaviour without a device.
+#include <fstream>
 #include <cmath>
 #include <iostream>
 #include <sequential-line-search/gaussian-process-regressor.hpp>
@@ -126,6 +127,13 @@ int main(int argc, char** argv)
             for (int i = 0; i < 3; ++i) EXPECT(X(i, j) >= 0.0 && X(i, j) <= 1.0);
         utils::SetRandomSeed(5);
         EXPECT((utils::GenerateRandomVector(3) - eig::Col(X, 0)).norm() == 0.0);   // seeded stream is reproducible
+        {   // a ragged file is rejected, not read out of bounds
+            std::ofstream f("/tmp/sls_cpu_ragged.csv");
+            f << "1,2\n3,4,5\n";
+        }
+        bool threw = false;
+        try { utils::ImportMatrixFromCsv("/tmp/sls_cpu_ragged.csv"); } catch (const std::runtime_error&) { threw = true; }
+        EXPECT(threw);
     }
     // ---- kernel scalar forms: derivative consistency, Matern finite at coincident points ----
     {

@@ -2,6 +2,7 @@
 #ifndef SEQUENTIAL_LINE_SEARCH_GAUSSIAN_PROCESS_REGRESSOR_HPP
 #define SEQUENTIAL_LINE_SEARCH_GAUSSIAN_PROCESS_REGRESSOR_HPP
 
+#include <atomic>
 #include <memory>
 #include <sequential-line-search/eigen-lite.hpp>
 #include <sequential-line-search/regressor.hpp>
@@ -20,9 +21,11 @@ namespace sequential_line_search
         GaussianProcessRegressor(const Eigen::MatrixXd& X, const Eigen::VectorXd& y,
                                  const KernelType kernel_type = KernelType::ArdMatern52Kernel);
 
-        /// Specified hyper-parameters are used as they are.
+        /// Specified hyper-parameters are used as they are.  `materialize_matrices = false` (extension) skips the
+        /// 2 x N^2 device->host copies of m_K_y / m_K_y_inv for THIS object (large N, or internal helper regressors).
         GaussianProcessRegressor(const Eigen::MatrixXd& X, const Eigen::VectorXd& y, const Eigen::VectorXd& kernel_hyperparams,
-                                 double noise_hyperparam, const KernelType kernel_type = KernelType::ArdMatern52Kernel);
+                                 double noise_hyperparam, const KernelType kernel_type = KernelType::ArdMatern52Kernel,
+                                 bool materialize_matrices = true);
 
         double PredictMu(const Eigen::VectorXd& x) const override;
         double PredictSigma(const Eigen::VectorXd& x) const override;
@@ -30,12 +33,13 @@ namespace sequential_line_search
         Eigen::VectorXd PredictMuDerivative(const Eigen::VectorXd& x) const override;
         Eigen::VectorXd PredictSigmaDerivative(const Eigen::VectorXd& x) const override;
 
-        // Available after construction (copied back from the device; see s_materialize_matrices)
+        // Available after construction (copied back from the device unless materialisation is switched off)
         Eigen::MatrixXd m_K_y;
         Eigen::MatrixXd m_K_y_inv;
 
-        /// Set false to skip the 2 x N^2 device->host copies of m_K_y / m_K_y_inv for large N.
-        static bool s_materialize_matrices;
+        /// Process-wide default for objects constructed afterwards (atomic; read once per construction): set false to skip
+        /// the 2 x N^2 device->host copies of m_K_y / m_K_y_inv for large N.  Library code never writes it.
+        static std::atomic<bool> s_materialize_matrices;
 
         const Eigen::MatrixXd& GetLargeX() const override { return m_X; }
         const Eigen::VectorXd& GetSmallY() const override { return m_y; }
@@ -46,7 +50,7 @@ namespace sequential_line_search
         sls_gp* GetDeviceHandle() const override;
 
         /// Extension: add one observation without refitting (O(N^2) update on the device; hyper-parameters unchanged).
-        /// m_K_y / m_K_y_inv are refreshed only if s_materialize_matrices is set.
+        /// m_K_y / m_K_y_inv are refreshed only if this object materialises them.
         void AppendPoint(const Eigen::VectorXd& x, double y);
 
     private:
@@ -57,6 +61,7 @@ namespace sequential_line_search
         Eigen::VectorXd m_y;
         Eigen::VectorXd m_kernel_hyperparams;
         double          m_noise_hyperparam;
+        bool            m_materialize = true;
 
         std::shared_ptr<device::GpHandle> m_handle;
     };

@@ -122,17 +122,21 @@ extern "C" int sls_ctx_synchronize(sls_ctx* ctx) {
 }
 extern "C" int sls_ctx_set_candidate_chunk(sls_ctx* ctx, int chunk) {
     SLS_TRY
+    std::unique_lock<std::recursive_mutex> lock_;
+    if (ctx) lock_ = std::unique_lock<std::recursive_mutex>(ctx->mtx);
     SLS_REQUIRE(ctx && chunk >= 128, "candidate chunk must be >= 128");
     ctx->cand_chunk = round_up(chunk, 128);
     SLS_CATCH
 }
 extern "C" int sls_prof_enable(sls_ctx* ctx, int on) {
     if (!ctx) return SLS_ERR_INVALID;
+    std::unique_lock<std::recursive_mutex> lock_(ctx->mtx);
     ctx->prof_on = on != 0;
     return SLS_OK;
 }
 extern "C" int sls_prof_reset(sls_ctx* ctx) {
     if (!ctx) return SLS_ERR_INVALID;
+    std::unique_lock<std::recursive_mutex> lock_(ctx->mtx);
     (void)hipStreamSynchronize(ctx->stream);
     ctx->prof_collect();
     ctx->prof.clear();
@@ -140,6 +144,7 @@ extern "C" int sls_prof_reset(sls_ctx* ctx) {
 }
 extern "C" int sls_prof_get(sls_ctx* ctx, const char* name, double* total_ms, long* launches) {
     if (!ctx || !name) return SLS_ERR_INVALID;
+    std::unique_lock<std::recursive_mutex> lock_(ctx->mtx);
     (void)hipStreamSynchronize(ctx->stream);
     ctx->prof_collect();
     auto it = ctx->prof.find(name);
@@ -177,6 +182,7 @@ struct sls_gp {
     int D = 0, N = 0, Np = 0, Dp = 0, Dcols = 0, kernel = 0;
     double a = 0, b = 0;
     std::vector<double> theta, Xh, yh;
+    bool host_stale = false;   // sls_gp_refit_dev replaced the device X / y: Xh / yh are refreshed before their next use
     DBuf X, y, inv_ell, XT, XaT, nx, L, Linv, Kinv, alpha, tvec, mu_data, scal, gemv_part;
     long* d_idx = nullptr;
     int best_index = 0;
@@ -303,6 +309,7 @@ extern "C" int sls_gp_refit_dev(sls_gp* g, const double* X_dev, const double* y_
     sls_ctx* c = g->ctx;
     SLS_HIP(hipMemcpyAsync(g->X.p, X_dev, (size_t)g->D * g->N * 8, hipMemcpyDeviceToDevice, c->stream));
     SLS_HIP(hipMemcpyAsync(g->y.p, y_dev, (size_t)g->N * 8, hipMemcpyDeviceToDevice, c->stream));
+    g->host_stale = true;
     gp_fit_device(g);
     gp_fetch_summary(g);
     SLS_CATCH
@@ -317,6 +324,7 @@ extern "C" int sls_gp_destroy(sls_gp* gp) {
 
 extern "C" int sls_gp_get_summary(sls_gp* g, int* best_index, double* mu_best, double* logdet) {
     if (!g) return SLS_ERR_INVALID;
+    std::unique_lock<std::recursive_mutex> lock_(g->ctx->mtx);
     if (best_index) *best_index = g->best_index;
     if (mu_best) *mu_best = g->mu_best;
     if (logdet) *logdet = g->logdet;
@@ -920,6 +928,12 @@ extern "C" int sls_gp_append_point(sls_gp* g, const double* x, double y_new) {
     SLS_REQUIRE(g && x, "sls_gp_append_point: NULL argument");
     sls_ctx* c = g->ctx;
     const int D = g->D, N = g->N, Np = g->Np;
+    if (g->host_stale) {   // the device copies are authoritative after sls_gp_refit_dev
+        d2h(c, g->Xh.data(), g->X.p, (size_t)D * N);
+        d2h(c, g->yh.data(), g->y.p, (size_t)N);
+        sync(c);
+        g->host_stale = false;
+    }
     g->Xh.insert(g->Xh.end(), x, x + D);
     g->yh.push_back(y_new);
     if (N % 128 == 0) {

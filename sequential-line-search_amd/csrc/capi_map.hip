@@ -120,17 +120,18 @@ static void nll_small_eval(sls_nll* h, const double* y, const double* theta, dou
     h->small_out.ensure(160);
     args.out = h->small_out.p;
     args.in_dev = nullptr;
+    std::vector<double> in;   // staging for the D > 16 upload: must outlive the stream synchronisation below
     if (D <= NLL_SMALL_MAX_GRAD_D) {
         args.a = theta[0]; args.b = b;
         for (int d = 0; d < D; ++d) args.ell[d] = theta[1 + d];
         std::memcpy(args.y, y, sizeof(double) * N);
     } else {
-        std::vector<double> in(2 + D + N);
+        in.resize(2 + D + N);
         in[0] = theta[0]; in[1] = b;
         for (int d = 0; d < D; ++d) in[2 + d] = theta[1 + d];
         for (int i = 0; i < N; ++i) in[2 + D + i] = y[i];
         h->small_in.ensure(in.size());
-        SLS_HIP(hipMemcpyAsync(h->small_in.p, in.data(), in.size() * 8, hipMemcpyHostToDevice, c->stream));   // pageable: staged before return
+        SLS_HIP(hipMemcpyAsync(h->small_in.p, in.data(), in.size() * 8, hipMemcpyHostToDevice, c->stream));
         args.in_dev = h->small_in.p;
     }
     launch_nll_small(c->stream, h->kernel, args);

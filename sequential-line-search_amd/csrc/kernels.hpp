@@ -10,7 +10,22 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 namespace slsk {
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is per (device, function): one process may drive several GPUs (sls_multi),
+// so the opt-in is recorded per current device, under a lock (launch wrappers run on one host thread per device).
+inline void ensure_dyn_lds(const void* fn, int bytes) {
+    static std::mutex mtx;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mtx);
+    if (done.insert({dev, fn}).second) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
 
 struct KernelSpec {
     int kernel;   // SLS_KERNEL_*

@@ -145,12 +145,8 @@ __global__ __launch_bounds__(256, 2) void acq_gemm_kernel(const double* __restri
 
 void launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk, int Sp, const double* Kinv, int Np, double* P,
                      double* kw_part, double* cw_part, int* sync) {
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)acq_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)acq_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-        attr = true;
-    }
+    ensure_dyn_lds((const void*)acq_gemm_kernel<false>, GEMM_LDS_BYTES);
+    ensure_dyn_lds((const void*)acq_gemm_kernel<true>, GEMM_LDS_BYTES);
     const int nt = (Sp / GEMM_BM) * (Np / GEMM_BN);
     // SLS_STAGGER (0 off, 1 default: on unless gated, 2 always) and SLS_PERSIST (1 default: gated form, 0 one tile per workgroup) are read per
     // call so that tests and A/B runs can switch within one process
@@ -256,11 +252,7 @@ __global__ __launch_bounds__(256, 2) void var_gemm_kernel(const double* __restri
 
 void launch_var_gemm(hipStream_t s, const double* Ks, long ldk, int Sp, const double* Linv, int Np, double* kw_part,
                      double* cw_part) {
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)var_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-        attr = true;
-    }
+    ensure_dyn_lds((const void*)var_gemm_kernel, GEMM_LDS_BYTES);
     const int ntm = Sp / GEMM_BM, ntn = Np / GEMM_BN;
     const int pair = (ntm * ntn < 1024 && ntn > 1) ? 1 : 0;
     const int grid = pair ? ntm * ((ntn + 1) / 2) : ntm * ntn;
@@ -320,12 +312,8 @@ __global__ __launch_bounds__(256, 3) void grad_gemm64_kernel(const double* __res
 
 void launch_grad_gemm(hipStream_t s, const double* P, const double* Cs, long ldk, int Sp, const double* XT, const double* XaT,
                       long ld, int Np, int Dcols, double* Gs, double* Gm) {
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)grad_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)grad_gemm64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_N64_LDS_BYTES);
-        attr = true;
-    }
+    ensure_dyn_lds((const void*)grad_gemm_kernel, GEMM_LDS_BYTES);
+    ensure_dyn_lds((const void*)grad_gemm64_kernel, GEMM_N64_LDS_BYTES);
     if (Dcols < 0) {   // caller signals D <= 64 by passing -Dcols
         hipLaunchKernelGGL(grad_gemm64_kernel, dim3(Sp / GEMM_BM, 2), dim3(GEMM_THREADS), GEMM_N64_LDS_BYTES, s, P, Cs, ldk, Sp, XT,
                            XaT, ld, Np, Gs, Gm);

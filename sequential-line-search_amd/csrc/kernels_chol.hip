@@ -105,23 +105,14 @@ __global__ __launch_bounds__(256, 2) void tri_gemm64_kernel(GemmDesc g) {
 
 template <bool A_KC>
 static void launch_tri_gemm64(hipStream_t s, const GemmDesc& g, int batches) {
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)tri_gemm64_kernel<A_KC>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_N64_LDS_BYTES);
-        attr = true;
-    }
+    ensure_dyn_lds((const void*)tri_gemm64_kernel<A_KC>, GEMM_N64_LDS_BYTES);
     if (g.mt <= 0 || g.nt <= 0 || batches <= 0) return;
     hipLaunchKernelGGL(tri_gemm64_kernel<A_KC>, dim3(g.mt * g.nt * 2, batches), dim3(GEMM_THREADS), GEMM_N64_LDS_BYTES, s, g);
 }
 
 template <bool A_KC, bool B_KC>
 static void launch_tri_gemm(hipStream_t s, const GemmDesc& g, int batches) {
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)tri_gemm_kernel<A_KC, B_KC>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  GEMM_LDS_BYTES);
-        attr = true;
-    }
+    ensure_dyn_lds((const void*)tri_gemm_kernel<A_KC, B_KC>, GEMM_LDS_BYTES);
     if (g.mt <= 0 || g.nt <= 0 || batches <= 0) return;
     hipLaunchKernelGGL((tri_gemm_kernel<A_KC, B_KC>), dim3(g.mt * g.nt, batches), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, g);
 }
@@ -217,12 +208,8 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double* __restrict__ A, 
 }
 
 static void diag_attr() {
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)chol_diag_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)chol_diag_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES);
-        attr = true;
-    }
+    ensure_dyn_lds((const void*)chol_diag_kernel<true>, DIAG_LDS_BYTES);
+    ensure_dyn_lds((const void*)chol_diag_kernel<false>, DIAG_LDS_BYTES);
 }
 
 void launch_potrf(hipStream_t s, double* A, int Np, double* Linv, int* info) {

@@ -101,11 +101,7 @@ __global__ __launch_bounds__(256, 2) void gram_sym_kernel(const double* __restri
 
 void launch_gram_sym(hipStream_t s, const double* XT, long ld, int Dp, const double* nx, int Np, int N, KernelSpec ks, double b,
                      double* K, bool lower_only) {
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gram_sym_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-        attr = true;
-    }
+    ensure_dyn_lds((const void*)gram_sym_kernel, GEMM_LDS_BYTES);
     const int nt = Np / GEMM_BM;
     hipLaunchKernelGGL(gram_sym_kernel, dim3(nt * nt), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, XT, ld, Dp, nx, Np, N, ks.kernel,
                        ks.a, b, K, (int)lower_only);
@@ -187,12 +183,8 @@ __global__ __launch_bounds__(256, 2) void cross_gram_kernel(const double* __rest
 void launch_cross_gram(hipStream_t s, const double* XsT, long lds_, const double* ns, int Sp, const double* XT, long ld,
                        const double* nx, int Np, int N, int Dp, KernelSpec ks, const double* alpha, double* Ks, double* Cs,
                        long ldk, double* mu_part, double* ca_part) {
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)cross_gram_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)cross_gram_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-        attr = true;
-    }
+    ensure_dyn_lds((const void*)cross_gram_kernel<false>, GEMM_LDS_BYTES);
+    ensure_dyn_lds((const void*)cross_gram_kernel<true>, GEMM_LDS_BYTES);
     const int nt = (Sp / GEMM_BM) * (Np / GEMM_BN);
     if (ks.kernel == SLS_KERNEL_ARD_MATERN52)
         hipLaunchKernelGGL(cross_gram_kernel<true>, dim3(nt), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, XsT, lds_, ns, Sp, XT, ld, nx,

@@ -64,12 +64,8 @@ __global__ __launch_bounds__(256) void nll_weight_kernel(const double* __restric
 
 void launch_nll_weight(hipStream_t s, const double* XT, long ld, int Dp, const double* nx, int Np, int N, KernelSpec ks,
                        const double* alpha, const double* Kinv, double* G, double* wk_part) {
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)nll_weight_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)nll_weight_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-        attr = true;
-    }
+    ensure_dyn_lds((const void*)nll_weight_kernel<false>, GEMM_LDS_BYTES);
+    ensure_dyn_lds((const void*)nll_weight_kernel<true>, GEMM_LDS_BYTES);
     const int nt = Np / GEMM_BM;
     if (ks.kernel == SLS_KERNEL_ARD_MATERN52)
         hipLaunchKernelGGL(nll_weight_kernel<true>, dim3(nt * nt), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, XT, ld, Dp, nx, Np, N, ks.a,

@@ -197,12 +197,8 @@ __global__ __launch_bounds__(256) void nll_small_kernel(const NllSmallArgs args)
 }
 
 void launch_nll_small(hipStream_t s, int kernel, const NllSmallArgs& args) {
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)nll_small_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)nll_small_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES);
-        attr = true;
-    }
+    ensure_dyn_lds((const void*)nll_small_kernel<false>, DIAG_LDS_BYTES);
+    ensure_dyn_lds((const void*)nll_small_kernel<true>, DIAG_LDS_BYTES);
     if (kernel == SLS_KERNEL_ARD_MATERN52)
         hipLaunchKernelGGL(nll_small_kernel<true>, dim3(1), dim3(256), DIAG_LDS_BYTES, s, args);
     else

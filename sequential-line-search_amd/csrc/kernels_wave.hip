@@ -307,11 +307,7 @@ size_t wave_lds_bytes(int D, int Np, int m, int* lds_per_wave, int* Dr) {
 
 void launch_maximize_wave(hipStream_t s, WaveArgs a) {
     const size_t bytes = wave_lds_bytes(a.D, a.Np, a.m, &a.lds_per_wave, &a.Dr);
-    static size_t attr_bytes = 0;
-    if (bytes > attr_bytes) {
-        (void)hipFuncSetAttribute((const void*)maximize_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        attr_bytes = bytes;
-    }
+    ensure_dyn_lds((const void*)maximize_wave_kernel, 160 * 1024);   // opt in to the CU's whole LDS once per device
     hipLaunchKernelGGL(maximize_wave_kernel, dim3((a.S + 3) / 4), dim3(256), bytes, s, a);
 }
 

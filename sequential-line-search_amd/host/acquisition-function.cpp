@@ -144,10 +144,10 @@ namespace sequential_line_search
 
         // Dummy regressor that only tracks the variance.  Like the reference (:261-262, :293) it is built with the
         // DEFAULT kernel type (Matern-5/2), not the regressor's own -- reproduced on purpose.
-        const bool keep = GaussianProcessRegressor::s_materialize_matrices;
-        GaussianProcessRegressor::s_materialize_matrices = false;
+        // It never exposes m_K_y / m_K_y_inv, so it is built without the host copies (per-object flag: no global state).
         std::shared_ptr<GaussianProcessRegressor> temp = std::make_shared<GaussianProcessRegressor>(
-            regressor.GetLargeX(), regressor.GetSmallY(), theta, regressor.GetNoiseHyperparam());
+            regressor.GetLargeX(), regressor.GetSmallY(), theta, regressor.GetNoiseHyperparam(), KernelType::ArdMatern52Kernel,
+            /*materialize_matrices=*/false);
 
         for (unsigned i = 0; i < num_points; ++i)
         {
@@ -168,7 +168,6 @@ namespace sequential_line_search
                 temp->AppendPoint(x_star, temp->PredictMu(x_star));
             }
         }
-        GaussianProcessRegressor::s_materialize_matrices = keep;
         return points;
     }
 } // namespace sequential_line_search

@@ -9,7 +9,7 @@ using Eigen::VectorXd;
 
 namespace sequential_line_search
 {
-    bool GaussianProcessRegressor::s_materialize_matrices = true;
+    std::atomic<bool> GaussianProcessRegressor::s_materialize_matrices{true};
 
     namespace
     {
@@ -18,7 +18,7 @@ namespace sequential_line_search
 
     // reference: src/gaussian-process-regressor.cpp:198-212
     GaussianProcessRegressor::GaussianProcessRegressor(const MatrixXd& X, const VectorXd& y, const KernelType kernel_type)
-        : Regressor(kernel_type), m_X(X), m_y(y), m_noise_hyperparam(0.0)
+        : Regressor(kernel_type), m_X(X), m_y(y), m_noise_hyperparam(0.0), m_materialize(s_materialize_matrices.load())
     {
         if (X.rows() == 0) return;   // inert object, like the reference
         PerformMapEstimation();
@@ -27,8 +27,10 @@ namespace sequential_line_search
 
     // reference: src/gaussian-process-regressor.cpp:214-232
     GaussianProcessRegressor::GaussianProcessRegressor(const MatrixXd& X, const VectorXd& y, const VectorXd& kernel_hyperparams,
-                                                       double noise_hyperparam, const KernelType kernel_type)
-        : Regressor(kernel_type), m_X(X), m_y(y), m_kernel_hyperparams(kernel_hyperparams), m_noise_hyperparam(noise_hyperparam)
+                                                       double noise_hyperparam, const KernelType kernel_type,
+                                                       bool materialize_matrices)
+        : Regressor(kernel_type), m_X(X), m_y(y), m_kernel_hyperparams(kernel_hyperparams), m_noise_hyperparam(noise_hyperparam),
+          m_materialize(materialize_matrices && s_materialize_matrices.load())
     {
         if (X.rows() == 0) return;
         BuildDeviceState();
@@ -37,7 +39,7 @@ namespace sequential_line_search
     void GaussianProcessRegressor::BuildDeviceState()
     {
         m_handle = std::make_shared<device::GpHandle>(m_X, m_y, m_kernel_hyperparams, m_noise_hyperparam, KernelId(m_kernel_type));
-        if (s_materialize_matrices)
+        if (m_materialize)
         {
             const long N = m_X.cols();
             m_K_y        = MatrixXd(N, N);
@@ -55,7 +57,7 @@ namespace sequential_line_search
         for (long i = 0; i < m_y.size(); ++i) yn(i) = m_y(i);
         yn(m_y.size()) = y;
         m_y            = yn;
-        if (s_materialize_matrices)
+        if (m_materialize)
         {
             const long N = m_X.cols();
             m_K_y        = MatrixXd(N, N);

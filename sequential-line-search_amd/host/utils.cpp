@@ -1,3 +1,4 @@
+#include <stdexcept>
 #include <cstdlib>
 #include <fstream>
 #include <iomanip>
@@ -58,7 +59,11 @@ namespace sequential_line_search
             const auto      rows = ReadCsvRows(file_path);
             Eigen::MatrixXd X(static_cast<long>(rows.size()), rows.empty() ? 0 : static_cast<long>(rows[0].size()));
             for (size_t i = 0; i < rows.size(); ++i)
+            {
+                if (rows[i].size() != rows[0].size())
+                    throw std::runtime_error("ImportMatrixFromCsv: ragged row " + std::to_string(i) + " in " + file_path);
                 for (size_t j = 0; j < rows[i].size(); ++j) X(static_cast<long>(i), static_cast<long>(j)) = rows[i][j];
+            }
             return X;
         }
 

@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_mfma
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp
-timeout 120 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 -d $OUT -o pmc -- $R/sequential-line-search_amd/csrc/mfma_probe > $OUT/log.txt 2>&1
+timeout 120 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 -d $OUT -o pmc -- $R/tools/probes/bin/mfma_probe > $OUT/log.txt 2>&1
 python - <<PY
 import sqlite3, glob
 from collections import defaultdict

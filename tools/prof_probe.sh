@@ -8,8 +8,8 @@ cd /tmp
 i=0
 for cfg in "$@"; do
   i=$((i+1))
-  timeout 40 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/p$i -o pmcf -- $R/sequential-line-search_amd/csrc/gemm_probe $cfg > $OUT/log$i.txt 2>&1
-  timeout 40 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d $OUT/p$i -o pmch -- $R/sequential-line-search_amd/csrc/gemm_probe $cfg >> $OUT/log$i.txt 2>&1
+  timeout 40 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/p$i -o pmcf -- $R/tools/probes/bin/gemm_probe $cfg > $OUT/log$i.txt 2>&1
+  timeout 40 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d $OUT/p$i -o pmch -- $R/tools/probes/bin/gemm_probe $cfg >> $OUT/log$i.txt 2>&1
   python - <<PY
 import sqlite3, glob
 from collections import defaultdict

@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_ubench
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp
-rocprofv3 --kernel-trace --pmc FETCH_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/f -o pmc -- $R/sequential-line-search_amd/csrc/ubench > $OUT/log.txt 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/f -o pmc -- $R/tools/probes/bin/ubench > $OUT/log.txt 2>&1
 python - <<PY
 import sqlite3
 c = sqlite3.connect("$OUT/f/pmc_results.db")
