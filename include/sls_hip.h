@@ -16,9 +16,14 @@
  *   - return 0 on success, <0 on error; sls_last_error() describes the last
  *     failure of the calling thread.  There is NO CPU fallback: every entry point
  *     runs hand-written gfx950 kernels and fails if no GPU is present.
- *   - a context owns one HIP stream; handles are safe for concurrent const use
- *     from one context's stream order (the reference shares one const regressor
- *     across worker threads, src/acquisition-function.cpp:125-144).
+ *   - a context owns one HIP stream and one lock: EVERY entry point that takes a
+ *     context or a handle created from it holds that (recursive) lock for the whole
+ *     call, so a context and its handles may be shared by any number of host threads
+ *     -- the reference shares one const regressor across hardware_concurrency worker
+ *     threads (src/acquisition-function.cpp:125-144) -- but their calls are SERIALISED
+ *     in arrival order, not run concurrently.  Parallelism comes from batching (M
+ *     points / S starts per call), not from concurrent callers; use one context per
+ *     thread (or sls_multi, one per GPU) for independent streams of work.
  */
 #ifndef SLS_HIP_H
 #define SLS_HIP_H
@@ -118,6 +123,15 @@ void sls_lbfgs_default_opts(sls_lbfgs_opts* o);
 int sls_acq_maximize(sls_gp* gp, int acq_type, double ucb_h, const double* starts, int S, int n_local,
                      const sls_lbfgs_opts* opts, long start_index_offset, double* x_out, double* val_out, long* idx_out,
                      double* x_stars, double* y_stars);
+/* Statistics of the last sls_acq_maximize* call on this handle.  The starts advance in lock step over an ACTIVE SET: a start
+ * that can no longer move (stationary projected gradient, null step, exhausted backtracking) is finished and leaves the
+ * batch -- NLopt's max_evals is a cap per start, not a quota (src/acquisition-function.cpp:128-129).
+ *   evals_issued  objective evaluations actually performed (sum over rounds of the live starts)
+ *   evals_cap     S * n_local
+ *   rounds        lock-step rounds executed (<= n_local)
+ *   live_at_end   starts still moving when the cap was reached
+ * Any out pointer may be NULL.  (The single-launch wavefront path for small problems reports evals_issued = evals_cap.) */
+int sls_acq_last_stats(sls_gp* gp, long* evals_issued, long* evals_cap, int* rounds, int* live_at_end);
 /* Same, with the starts already resident in HBM (D x S column-major device buffer) -- the timed path of bench.py. */
 int sls_acq_maximize_dev(sls_gp* gp, int acq_type, double ucb_h, const double* starts_dev, int S, int n_local,
                          const sls_lbfgs_opts* opts, long start_index_offset, double* x_out, double* val_out,

@@ -652,10 +652,15 @@ static int lb_direction(lb_state* s, int D, int m, double gtol) {
     return 1;
 }
 
-int slso_acq_maximize(const slso_regressor* r, int acq, double ucb_h, const double* starts, int S, int n_local,
-                      const slso_lbfgs_opts* opts_in, double* x_out, double* val_out, double* x_stars, double* y_stars,
-                      int n_threads) {
+/* diag_margin / diag_eval (S each, may be NULL): per start, the smallest relative distance of an Armijo test from its
+   threshold, |ft - (f + c1 g.s)| / max(|f|, |ft|), over the run, and the evaluation at which it occurred.  A start whose
+   margin is at rounding level may take the other branch on an implementation that sums in a different order (the HIP
+   path): tests use this to tell such rounding-induced flips from real disagreements. */
+static int acq_maximize_impl(const slso_regressor* r, int acq, double ucb_h, const double* starts, int S, int n_local,
+                             const slso_lbfgs_opts* opts_in, double* x_out, double* val_out, double* x_stars, double* y_stars,
+                             int n_threads, double* diag_margin, int* diag_eval) {
     const int D = r->D;
+    if (diag_margin) for (int i = 0; i < S; ++i) { diag_margin[i] = INFINITY; if (diag_eval) diag_eval[i] = -1; }
     slso_lbfgs_opts o;
     if (opts_in) o = *opts_in; else slso_lbfgs_default_opts(&o);
     const int m = o.history > 64 ? 64 : o.history;
@@ -706,6 +711,11 @@ int slso_acq_maximize(const slso_regressor* r, int acq, double ucb_h, const doub
             double gs = 0.0, ss = 0.0;
             for (int d = 0; d < D; ++d) { const double sd = s->xt[d] - s->x[d]; gs += s->g[d] * sd; ss += sd * sd; }
             if (ss == 0.0) { s->done = 1; continue; }
+            if (diag_margin) {
+                const double sc = fmax(fabs(s->f), fabs(ft));
+                const double mg = fabs(ft - (s->f + o.c1 * gs)) / (sc > 0.0 ? sc : 1.0);
+                if (mg < diag_margin[i]) { diag_margin[i] = mg; if (diag_eval) diag_eval[i] = ev + 1; }
+            }
             if (ft <= s->f + o.c1 * gs) {
                 double sy = 0.0, yy = 0.0;
                 const int idx = s->hpos;
@@ -743,6 +753,18 @@ int slso_acq_maximize(const slso_regressor* r, int acq, double ucb_h, const doub
     for (int i = 0; i < S; ++i) { lb_state* s = &st[i]; free(s->x); free(s->g); free(s->d); free(s->xt); free(s->S); free(s->Y); free(s->rho); }
     free(st); free(XT); free(val); free(grad);
     return best;
+}
+
+int slso_acq_maximize(const slso_regressor* r, int acq, double ucb_h, const double* starts, int S, int n_local,
+                      const slso_lbfgs_opts* opts_in, double* x_out, double* val_out, double* x_stars, double* y_stars,
+                      int n_threads) {
+    return acq_maximize_impl(r, acq, ucb_h, starts, S, n_local, opts_in, x_out, val_out, x_stars, y_stars, n_threads, NULL, NULL);
+}
+int slso_acq_maximize_diag(const slso_regressor* r, int acq, double ucb_h, const double* starts, int S, int n_local,
+                           const slso_lbfgs_opts* opts_in, double* x_out, double* val_out, double* x_stars, double* y_stars,
+                           int n_threads, double* armijo_margin, int* armijo_eval) {
+    return acq_maximize_impl(r, acq, ucb_h, starts, S, n_local, opts_in, x_out, val_out, x_stars, y_stars, n_threads,
+                             armijo_margin, armijo_eval);
 }
 
 /* ------------------------------------------------------------------------- */

@@ -116,6 +116,12 @@ void slso_lbfgs_default_opts(slso_lbfgs_opts* o);
 int  slso_acq_maximize(const slso_regressor* r, int acq, double ucb_h, const double* starts, int S, int n_local,
                        const slso_lbfgs_opts* opts, double* x_out /*D*/, double* val_out, double* x_stars, double* y_stars,
                        int n_threads);
+/* Same run, plus per-start diagnostics (S each, may be NULL): the smallest relative distance of any Armijo test from its
+ * threshold and the evaluation at which it occurred -- starts whose margin is at rounding level may legitimately take the
+ * other branch on an implementation with a different summation order. */
+int  slso_acq_maximize_diag(const slso_regressor* r, int acq, double ucb_h, const double* starts, int S, int n_local,
+                            const slso_lbfgs_opts* opts, double* x_out, double* val_out, double* x_stars, double* y_stars,
+                            int n_threads, double* armijo_margin, int* armijo_eval);
 
 /* ---- GP marginal likelihood MAP objective (gaussian-process-regressor.cpp:141-193, 66-127) ----
  * x = (a, b, r_1..r_D); returns log p; grad (D+2) may be NULL.

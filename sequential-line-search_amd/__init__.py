@@ -51,7 +51,7 @@ EXPORTS = [
     "sls_gp_destroy", "sls_gp_get_matrix", "sls_gp_get_summary", "sls_gp_predict", "sls_gp_predict_grad", "sls_acq_eval",
     "sls_lbfgs_default_opts", "sls_acq_maximize", "sls_acq_maximize_dev", "sls_gp_refit_dev", "sls_prof_enable",
     "sls_prof_reset", "sls_prof_get", "sls_nll_create", "sls_nll_destroy", "sls_nll_eval", "sls_gp_nll_grad",
-    "sls_pref_objective", "sls_acq_eval_pair", "sls_acq_maximize_pair", "sls_gp_append_point",
+    "sls_pref_objective", "sls_acq_eval_pair", "sls_acq_maximize_pair", "sls_gp_append_point", "sls_acq_last_stats",
 ]
 
 
@@ -240,6 +240,12 @@ class GP:
                                        C.byref(opts) if opts is not None else None, C.c_long(offset), _p(x), C.byref(val),
                                        C.byref(idx)))
         return dict(index=idx.value, x=x, value=val.value)
+
+    def last_stats(self):
+        """Evaluation counts of the last acq_maximize* call (sls_acq_last_stats)."""
+        issued, cap, rounds, live = C.c_long(), C.c_long(), C.c_int(), C.c_int()
+        _ck(lib().sls_acq_last_stats(self.h, C.byref(issued), C.byref(cap), C.byref(rounds), C.byref(live)))
+        return dict(evals_issued=issued.value, evals_cap=cap.value, rounds=rounds.value, live_at_end=live.value)
 
     def refit_dev(self, X_dev_ptr, y_dev_ptr):
         _ck(lib().sls_gp_refit_dev(self.h, C.c_void_p(X_dev_ptr), C.c_void_p(y_dev_ptr)))

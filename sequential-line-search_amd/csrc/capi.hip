@@ -192,9 +192,12 @@ struct sls_gp {
     int ws_chunk = 0;
     // L-BFGS state
     DBuf pair_mu, pair_sg, pair_dmu, pair_dsg;
-    DBuf lb_x, lb_g, lb_dir, lb_xt, lb_scr, lb_S, lb_Y, lb_rho, lb_f, lb_t, lb_val, lb_grad;
-    int* lb_int = nullptr;
+    DBuf lb_x, lb_g, lb_dir, lb_xt, lb_scr, lb_S, lb_Y, lb_rho, lb_f, lb_t, lb_val, lb_grad, lb_xc;
+    int* lb_int = nullptr;    // hlen | hpos | nbt | done | live list A | live list B | live count (+ padding)
     int lb_Sp = 0, lb_m = 0;
+    // statistics of the last sls_acq_maximize* call on this handle (sls_acq_last_stats)
+    long stat_issued = 0, stat_cap = 0;
+    int stat_rounds = 0, stat_live_end = 0;
     ~sls_gp() {
         if (d_idx) (void)hipFree(d_idx);
         if (lb_int) (void)hipFree(lb_int);
@@ -579,9 +582,10 @@ static void ensure_lbfgs(sls_gp* g, int Sp, int m) {
     const size_t D = g->D, S = Sp;
     g->lb_x.ensure(S * D); g->lb_g.ensure(S * D); g->lb_dir.ensure(S * D); g->lb_xt.ensure(S * D); g->lb_scr.ensure(S * D);
     g->lb_S.ensure(S * D * m); g->lb_Y.ensure(S * D * m); g->lb_rho.ensure(S * m);
-    g->lb_f.ensure(S); g->lb_t.ensure(S); g->lb_val.ensure(S); g->lb_grad.ensure(S * D);
+    g->lb_f.ensure(S); g->lb_t.ensure(S); g->lb_val.ensure(S); g->lb_grad.ensure(S * D); g->lb_xc.ensure(S * D);
     if (g->lb_int) (void)hipFree(g->lb_int);
-    SLS_HIP(hipMalloc((void**)&g->lb_int, S * 4 * sizeof(int)));
+    g->lb_int = nullptr;
+    SLS_HIP(hipMalloc((void**)&g->lb_int, (S * 6 + 64) * sizeof(int)));
     g->lb_Sp = Sp; g->lb_m = m;
 }
 
@@ -618,7 +622,9 @@ static void maximize_impl(sls_gp* g, sls_gp* gs, int acq_type, double ucb_h, con
     SLS_REQUIRE(o.history >= 1 && o.history <= 8, "L-BFGS history must be in 1..8");
     const int Sp = round_up(S, 128), D = g->D;
     ensure_lbfgs(g, Sp, o.history);
+    g->stat_issued = 0; g->stat_cap = (long)S * n_local; g->stat_rounds = 0; g->stat_live_end = 0;
     LbfgsState st;
+    st.live = nullptr; st.nlive = S; st.ldv = Sp;
     st.S = S; st.D = D; st.m = o.history; st.ld = Sp;
     st.x = g->lb_x.p; st.g = g->lb_g.p; st.dir = g->lb_dir.p; st.xt = g->lb_xt.p; st.scr = g->lb_scr.p;
     st.Sh = g->lb_S.p; st.Yh = g->lb_Y.p; st.rho = g->lb_rho.p; st.f = g->lb_f.p; st.t = g->lb_t.p;
@@ -643,44 +649,52 @@ static void maximize_impl(sls_gp* g, sls_gp* gs, int acq_type, double ucb_h, con
                 ProfScope ps(c, "acq_wave");
                 launch_maximize_wave(c->stream, w);
             }
+            g->stat_issued = g->stat_cap;   // the per-start wavefront kernel keeps no count; upper bound
+            g->stat_rounds = n_local;
             used_wave = true;
         }
     }
     if (!used_wave) {
-    launch_clamp_starts(c->stream, starts_dev, D, S, st.xt, Sp, Sp);
-    // Round 0 runs eagerly (it also performs every lazy allocation / attribute set-up).  The remaining rounds are one
-    // fixed kernel sequence with constant arguments and can be captured once into a hipGraph and replayed
-    // (SLS_USE_GRAPH=1).  Measured on MI355X at the launch-bound sizes of the reference's demos (D=32 N=90 S=10, 320
-    // rounds: eager 55.1 ms, graph 56.6 ms; tools/time_small.py) replay does not help: the 7 single-tile kernels of a
-    // round take ~25 us each on the device, far above the ~3 us host launch cost -- so eager launch is the default.
-    auto round = [&](bool first) {
-        eval_acq(g, gs, st.xt, Sp, S, acq_type, ucb_h, g->lb_val.p, g->lb_grad.p, Sp);
-        ProfScope ps(c, "lbfgs");
-        launch_lbfgs_step(c->stream, st, g->lb_val.p, g->lb_grad.p, first);
-    };
-    round(true);
-    const char* genv = getenv("SLS_USE_GRAPH");
-    const bool use_graph = n_local > 3 && !c->prof_on && genv && atoi(genv) != 0;
-    if (use_graph) {
-        hipGraph_t graph = nullptr;
-        hipGraphExec_t exec = nullptr;
-        SLS_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-        try {
-            round(false);
-        } catch (...) {
-            (void)hipStreamEndCapture(c->stream, &graph);
-            if (graph) (void)hipGraphDestroy(graph);
-            throw;
+        // Lock-step rounds over the ACTIVE SET.  NLopt's max_evals is a cap per start, not a quota
+        // (src/acquisition-function.cpp:128-129): a start that can no longer move (stationary projected gradient, null
+        // step, exhausted backtracking) is finished.  After every round the starts still moving are compacted, in
+        // increasing order, into dense 128-wide tiles, so cross_gram / acq_gemm / grad_gemm only see live columns.  A
+        // candidate's arithmetic does not depend on the column it occupies, so every start ends with the same bits as
+        // in the uncompacted schedule (SLS_COMPACT=0: every start is re-evaluated every round; tests compare the two).
+        const char* cenv = getenv("SLS_COMPACT");
+        const bool compact = cenv ? atoi(cenv) != 0 : true;
+        int* live_a = g->lb_int + 4 * (size_t)Sp;
+        int* live_b = live_a + Sp;
+        int* d_count = live_b + Sp;
+        launch_clamp_starts(c->stream, starts_dev, D, S, st.xt, Sp, Sp);
+        const double* trial = st.xt;      // candidate-major trial points of this round, leading dimension Sp
+        const int* live = nullptr;        // identity
+        int nlive = S;
+        st.ldv = Sp;
+        for (int ev = 0; ev < n_local && nlive > 0; ++ev) {
+            eval_acq(g, gs, trial, Sp, nlive, acq_type, ucb_h, g->lb_val.p, g->lb_grad.p, Sp);
+            g->stat_issued += nlive;
+            g->stat_rounds += 1;
+            {
+                ProfScope ps(c, "lbfgs");
+                st.live = live; st.nlive = nlive;
+                launch_lbfgs_step(c->stream, st, g->lb_val.p, g->lb_grad.p, ev == 0);
+                if (compact && ev + 1 < n_local) {
+                    int* live_next = (live == live_a) ? live_b : live_a;
+                    launch_compact_live(c->stream, live, nlive, st.done, live_next, d_count);
+                    launch_gather_trials(c->stream, st.xt, Sp, D, live_next, d_count, nlive, g->lb_xc.p, Sp);
+                    live = live_next;
+                    trial = g->lb_xc.p;
+                }
+            }
+            if (compact && ev + 1 < n_local) {
+                int cnt = 0;
+                SLS_HIP(hipMemcpyAsync(&cnt, d_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                sync(c);
+                nlive = cnt;
+            }
         }
-        SLS_HIP(hipStreamEndCapture(c->stream, &graph));
-        SLS_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-        for (int ev = 1; ev < n_local; ++ev) SLS_HIP(hipGraphLaunch(exec, c->stream));
-        SLS_HIP(hipStreamSynchronize(c->stream));
-        (void)hipGraphExecDestroy(exec);
-        (void)hipGraphDestroy(graph);
-    } else {
-        for (int ev = 1; ev < n_local; ++ev) round(false);
-    }
+        g->stat_live_end = nlive;
     }   // !used_wave
     launch_argmax_neg(c->stream, st.f, S, g->scal.p + 2, g->d_idx + 1);
     double bv = 0;
@@ -699,6 +713,16 @@ static void maximize_impl(sls_gp* g, sls_gp* gs, int acq_type, double ucb_h, con
         download_cm(g, st.f, S, Sp, 1, y_stars);
         for (int i = 0; i < S; ++i) y_stars[i] = -y_stars[i];
     }
+}
+
+extern "C" int sls_acq_last_stats(sls_gp* g, long* evals_issued, long* evals_cap, int* rounds, int* live_at_end) {
+    if (!g) return SLS_ERR_INVALID;
+    std::unique_lock<std::recursive_mutex> lock_(g->ctx->mtx);
+    if (evals_issued) *evals_issued = g->stat_issued;
+    if (evals_cap) *evals_cap = g->stat_cap;
+    if (rounds) *rounds = g->stat_rounds;
+    if (live_at_end) *live_at_end = g->stat_live_end;
+    return SLS_OK;
 }
 
 extern "C" int sls_acq_maximize(sls_gp* g, int acq_type, double ucb_h, const double* starts, int S, int n_local,

@@ -106,9 +106,21 @@ struct LbfgsState {
     int *hlen, *hpos, *nbt, *done;    // [n]
     double c1, shrink, gtol;
     int max_backtracks;
+    // Active set: this round evaluated `nlive` trial points; column j of (val, grad) belongs to start live[j]
+    // (live == nullptr: identity, nlive == S).  ldv = leading dimension of grad.
+    const int* live;
+    int nlive;
+    long ldv;
 };
-// first: (val, grad) are the objective at the starts; otherwise at the trial points xt.  Writes the next trial points.
+// first: (val, grad) are the objective at the starts; otherwise at the trial points xt.  Writes the next trial points into
+// xt (start-indexed) and marks starts that can no longer move (null step, exhausted backtracking, stationary) as done.
 void launch_lbfgs_step(hipStream_t s, const LbfgsState& st, const double* val, const double* grad, bool first);
+// Stable compaction of the starts that are still moving: live_out[0..count) = { n in live_in (or 0..n_in) : !done[n] } in
+// increasing order, count -> *count_out (device); then xc[j + d*ldc] = xt[live_out[j] + d*ld] (padding columns up to the
+// next multiple of 128 are filled with 0.5 so that the tile kernels read finite numbers).
+void launch_compact_live(hipStream_t s, const int* live_in, int n_in, const int* done, int* live_out, int* count_out);
+void launch_gather_trials(hipStream_t s, const double* xt, long ld, int D, const int* live, const int* count_dev, int n_max,
+                          double* xc, long ldc);
 void launch_clamp_starts(hipStream_t s, const double* starts /*D x S col-major*/, int D, int S, double* xt, long ld, int Sp);
 // first maximum of y[n] = -f[n]: out[0] = value, idx_out[0] = index
 void launch_argmax_neg(hipStream_t s, const double* f, int S, double* out_val, long* out_idx);

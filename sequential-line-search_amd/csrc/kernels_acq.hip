@@ -31,10 +31,11 @@ __device__ __forceinline__ void acq_tile(int t, int ntm, int ntn, const double* 
     const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
     Acc acc;
     acc.zero();
-    // Staggered k start: tile (tm, tn) begins (tm&7 + tn&7) slabs into the k loop and wraps, so the 8 co-resident sharers of
-    // a panel do not all miss on the same slab in the same microsecond.  Measured effect is build-dependent (round-start
-    // build: hit rate 0.34-0.43 -> 0.67; current build 0.85 with or without), kernel time unchanged; kept on.
-    const int ks = stagger ? ((tm & 7) + (tn & 7)) * GEMM_BK : 0;
+    // Optional staggered k start (SLS_STAGGER=1): tile (tm, tn) begins (tn & 15) slabs into the k loop and wraps, so the
+    // sharers of a K* panel do not all miss on the same slab in the same microsecond.  The offset depends on tn ONLY: the
+    // summation order of a candidate's row must not depend on which tile position (tm) the candidate occupies, or the
+    // active-set compaction of the maximiser would change its bits.  Measured effect on time: none; off by default.
+    const int ks = stagger ? (tn & 15) * GEMM_BK : 0;
     gemm_tile<false, false>(acc, Ks + m0, ldk, Kinv + n0, (long)Np, 0, Np, lds, ks);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double skw[4], scw[4];
@@ -148,11 +149,11 @@ void launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk
     ensure_dyn_lds((const void*)acq_gemm_kernel<false>, GEMM_LDS_BYTES);
     ensure_dyn_lds((const void*)acq_gemm_kernel<true>, GEMM_LDS_BYTES);
     const int nt = (Sp / GEMM_BM) * (Np / GEMM_BN);
-    // SLS_STAGGER (0 off, 1 default: on unless gated, 2 always) and SLS_PERSIST (1 default: gated form, 0 one tile per workgroup) are read per
-    // call so that tests and A/B runs can switch within one process
+    // SLS_STAGGER (0 default: plain k loop, 1: staggered by tn) and SLS_PERSIST (1 default: gated form, 0 one tile per
+    // workgroup) are read per call so that tests and A/B runs can switch within one process
     const char* es = getenv("SLS_STAGGER");
     const char* ep = getenv("SLS_PERSIST");
-    const int stagger_env = es ? atoi(es) : 1;
+    const int stagger_env = es ? atoi(es) : 0;
     const int persist_env = ep ? atoi(ep) : 1;
     // SLS_GATE_PHASE: start offset (ticks of the 100 MHz clock) between the two gate groups of an XCD; 0: one gate per XCD.
     // Measured per 65 536-candidate launch: phase 0 124.8 ms / 77 GB (hit rate 0.856); phase 2000..8000 123.2-123.3 ms /
@@ -161,7 +162,7 @@ void launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk
     const int phase = eph ? atoi(eph) : 2000;
     // persistent, generation-gated form when there are at least two generations of tiles (MI355X: 256 CUs x 2 = 512 slots)
     const bool persist = persist_env && sync && nt >= 1024 && Np >= 2048;
-    const int stagger = (stagger_env == 1 && !persist && Np >= 2048) || stagger_env == 2 ? 1 : 0;
+    const int stagger = stagger_env != 0 ? 1 : 0;
     int* sy = nullptr;
     int grid = nt;
     if (persist) {
@@ -447,23 +448,24 @@ void launch_clamp_starts(hipStream_t s, const double* starts, int D, int S, doub
 
 __global__ __launch_bounds__(256) void lbfgs_step_kernel(LbfgsState st, const double* __restrict__ val,
                                                          const double* __restrict__ grad, int first) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= st.S) return;
-    const long ld = st.ld;
+    const int j = blockIdx.x * 256 + threadIdx.x;   // column of (val, grad)
+    if (j >= st.nlive) return;
+    const int n = st.live ? st.live[j] : j;          // the start it belongs to
+    const long ld = st.ld, ldv = st.ldv;
     const int D = st.D, m = st.m;
     bool need_dir = false;
     if (first) {
-        st.f[n] = -val[n];
+        st.f[n] = -val[j];
         #pragma unroll 8
         for (int d = 0; d < D; ++d) {
             st.x[n + d * ld] = st.xt[n + d * ld];
-            st.g[n + d * ld] = -grad[n + d * ld];
+            st.g[n + d * ld] = -grad[j + d * ldv];
         }
         st.hlen[n] = 0; st.hpos[n] = 0; st.nbt[n] = 0; st.done[n] = 0; st.t[n] = 1.0;
         need_dir = true;
     } else {
         if (st.done[n]) return;
-        const double ft = -val[n];
+        const double ft = -val[j];
         double gs = 0.0, ss = 0.0;
         #pragma unroll 8
         for (int d = 0; d < D; ++d) {
@@ -480,7 +482,7 @@ __global__ __launch_bounds__(256) void lbfgs_step_kernel(LbfgsState st, const do
             #pragma unroll 8
             for (int d = 0; d < D; ++d) {
                 const double sd = st.xt[n + d * ld] - st.x[n + d * ld];
-                const double yd = -grad[n + d * ld] - st.g[n + d * ld];
+                const double yd = -grad[j + d * ldv] - st.g[n + d * ld];
                 Sh[n + d * ld] = sd;
                 Yh[n + d * ld] = yd;
                 sy += sd * yd;
@@ -494,7 +496,7 @@ __global__ __launch_bounds__(256) void lbfgs_step_kernel(LbfgsState st, const do
             #pragma unroll 8
             for (int d = 0; d < D; ++d) {
                 st.x[n + d * ld] = st.xt[n + d * ld];
-                st.g[n + d * ld] = -grad[n + d * ld];
+                st.g[n + d * ld] = -grad[j + d * ldv];
             }
             st.f[n] = ft;
             need_dir = true;
@@ -598,21 +600,80 @@ __global__ __launch_bounds__(256) void lbfgs_step_kernel(LbfgsState st, const do
         }
         if (done) st.done[n] = 1;
     }
-    // propose the next trial point
+    // propose the next trial point.  A trial that coincides with x (the step vanished in the clamp / in rounding) would be
+    // evaluated once and then stop the start with x, f unchanged ("ss == 0" above): it is retired here, one evaluation
+    // earlier, with the same end state.
     const double t = st.t[n];
+    bool moved = false;
     #pragma unroll 8
     for (int d = 0; d < D; ++d) {
-        double v = st.x[n + d * ld];
+        const double xv = st.x[n + d * ld];
+        double v = xv;
         if (!done) {
             v = v + t * st.dir[n + d * ld];
             v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+            moved = moved || (v != xv);
         }
         st.xt[n + d * ld] = v;
     }
+    if (!done && !moved) st.done[n] = 1;
 }
 
 void launch_lbfgs_step(hipStream_t s, const LbfgsState& st, const double* val, const double* grad, bool first) {
-    hipLaunchKernelGGL(lbfgs_step_kernel, dim3((st.S + 255) / 256), dim3(256), 0, s, st, val, grad, (int)first);
+    if (st.nlive <= 0) return;
+    hipLaunchKernelGGL(lbfgs_step_kernel, dim3((st.nlive + 255) / 256), dim3(256), 0, s, st, val, grad, (int)first);
+}
+
+// One workgroup: thread t owns the contiguous segment [t*per, (t+1)*per) of the input list, counts its survivors, an
+// exclusive scan over the 1024 counts gives its output offset (stable, increasing order).
+__global__ __launch_bounds__(1024) void compact_live_kernel(const int* __restrict__ live_in, int n_in, const int* __restrict__ done,
+                                                            int* __restrict__ live_out, int* __restrict__ count_out) {
+    __shared__ int cnt[1024];
+    const int t = threadIdx.x;
+    const int per = (n_in + 1023) / 1024;
+    const int lo = min(t * per, n_in), hi = min(lo + per, n_in);
+    int c = 0;
+    for (int i = lo; i < hi; ++i) {
+        const int n = live_in ? live_in[i] : i;
+        c += done[n] ? 0 : 1;
+    }
+    cnt[t] = c;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {   // inclusive Hillis-Steele scan
+        const int v = t >= o ? cnt[t - o] : 0;
+        __syncthreads();
+        cnt[t] += v;
+        __syncthreads();
+    }
+    int pos = cnt[t] - c;
+    for (int i = lo; i < hi; ++i) {
+        const int n = live_in ? live_in[i] : i;
+        if (!done[n]) live_out[pos++] = n;
+    }
+    if (t == 1023) count_out[0] = cnt[1023];
+}
+void launch_compact_live(hipStream_t s, const int* live_in, int n_in, const int* done, int* live_out, int* count_out) {
+    hipLaunchKernelGGL(compact_live_kernel, dim3(1), dim3(1024), 0, s, live_in, n_in, done, live_out, count_out);
+}
+
+__global__ __launch_bounds__(256) void gather_trials_kernel(const double* __restrict__ xt, long ld, int D, const int* __restrict__ live,
+                                                            const int* __restrict__ count_dev, double* __restrict__ xc, long ldc) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int cnt = count_dev[0];
+    const int cntp = (cnt + 127) & ~127;
+    if (j >= cntp) return;
+    if (j < cnt) {
+        const int n = live[j];
+        for (int d = 0; d < D; ++d) xc[j + d * ldc] = xt[n + d * ld];
+    } else {
+        for (int d = 0; d < D; ++d) xc[j + d * ldc] = 0.5;
+    }
+}
+void launch_gather_trials(hipStream_t s, const double* xt, long ld, int D, const int* live, const int* count_dev, int n_max,
+                          double* xc, long ldc) {
+    if (n_max <= 0) return;
+    const int np = (n_max + 127) & ~127;
+    hipLaunchKernelGGL(gather_trials_kernel, dim3((np + 255) / 256), dim3(256), 0, s, xt, ld, D, live, count_dev, xc, ldc);
 }
 
 // first maximum (Eigen maxCoeff semantics, src/acquisition-function.cpp:146-153)

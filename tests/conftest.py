@@ -24,3 +24,17 @@ def oracle():
     from oracle import oracle_py
     oracle_py.build()
     return oracle_py
+
+
+@pytest.fixture(scope="session")
+def scipy_cases():
+    """tests/golden/scipy_pipelines.npz (make_scipy_fixtures.py): GP pipelines at N = 130 .. 2048 from scipy/LAPACK + numpy,
+    as a dict  case name -> dict of arrays."""
+    import numpy as np
+    z = np.load(os.path.join(ROOT, "tests", "golden", "scipy_pipelines.npz"))
+    cases = {}
+    for name in z["cases"]:
+        name = str(name)
+        cases[name] = {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith(name + "/")}
+    cases["_ucb_h"] = float(z["ucb_h"])
+    return cases

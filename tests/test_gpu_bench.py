@@ -39,6 +39,12 @@ def test_bench_line_contract_and_two_rank_merge():
     r = one["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert "workload" in one["config"]
+    c = one["config"]
+    assert 0 < c["evals_issued_per_step"] <= c["evals_cap_per_step"] == 3000 * 8
+    assert abs(one["value"] - c["evals_issued_per_step"] / (one["ms_per_step"] * 1e-3)) < 1e-6 * one["value"]
+    for name, st in one["stage_rooflines"].items():          # a fraction above 1 is an accounting error, not evidence
+        assert 0 < st["frac"] < 1, (name, st)
+    assert "fit_pipeline" in one["stage_rooflines"] and "traffic_source" in r
 
     two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                "127.0.0.1", "--master-port", "29617", "bench.py", "--gpus", "2", "--backend", "gloo", "--same-device"] + SMALL)

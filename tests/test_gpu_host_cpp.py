@@ -3,6 +3,7 @@ import os
 import re
 import subprocess
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -43,6 +44,17 @@ def test_sequential_line_search_nd_demo():
     res = [float(x) for x in re.findall(r"residual ([-\d.e]+)", out)]
     assert len(res) == 10
     assert res[-1] < res[0] and res[-1] < 0.35, res
+
+
+def test_sequential_line_search_nd_c3_size():
+    """BASELINE config C3: sequential_line_search_nd at D = 32, 30 iterations -- full PreferenceRegressor MAP + EI acquisition
+    per step through the C++ facade.  The synthetic user picks the best point of every slider, so the residual to the
+    optimum 0.4*1 cannot grow by more than the slider's resolution and must trend down over the run."""
+    out = run("sequential_line_search_nd", 32, 30, 1, timeout=900)
+    res = [float(x) for x in re.findall(r"residual ([-\d.e]+)", out)]
+    assert len(res) == 30
+    assert res[-1] < res[0] and min(res[-5:]) < 0.8 * res[0], res
+    assert all(np.isfinite(res))
 
 
 def test_python_binding_runs_reference_recipe():
