@@ -159,13 +159,12 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    xdev = dev if args.backend == "nccl" else None      # gloo exchanges host tensors
+    xdev = None                                          # the rendezvous group exchanges host tensors
     if world > 1:
+        # torch.distributed is the RENDEZVOUS only (gloo: barrier, the 128-byte RCCL id, the max-over-ranks clock); the
+        # data-path collective of a step is the ncclAllGather inside libsls_hip (sls_comm_allgather_best)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     sls = importlib.import_module("sequential-line-search_amd")
     kernel_id = sls.KERNEL_MATERN52 if args.kernel == "matern52" else sls.KERNEL_SE
@@ -183,12 +182,37 @@ def main():
     starts_dev = torch.from_numpy(np.ascontiguousarray(starts[:, lo:lo + S_loc].T)).to(dev)
     gp = sls.GP(ctx, X, y, theta, b, kernel_id)
 
+    comm, exchange = None, "none (1 GPU)"
+    if world > 1:
+        if args.backend == "nccl" and not args.same_device:
+            uid = [sls.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            err = ""
+            try:
+                comm = sls.Comm(ctx, uid[0], rank, world)
+            except sls.SlsError as e:                    # keep the measurement alive, say so in the JSON line
+                err = str(e)
+            ok = torch.tensor([1.0 if comm is not None else 0.0], dtype=torch.float64)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if ok.item() < 1.0:
+                if comm is not None:
+                    comm.close()
+                comm = None
+                exchange = f"torch.distributed gloo all_gather (RCCL communicator unavailable on some rank: {err or 'see other ranks'})"
+            else:
+                exchange = "ncclAllGather inside libsls_hip (sls_comm_allgather_best), RCCL over xGMI"
+        else:
+            exchange = "torch.distributed gloo all_gather (test mode)"
+
     def step():
         gp.refit_dev(X_dev.data_ptr(), y_dev.data_ptr())
         r = gp.acq_maximize_dev(starts_dev.data_ptr(), S_loc, args.n_local, sls.ACQ_EI, 1.0, offset=lo)
         issued[0] += gp.last_stats()["evals_issued"]
-        if world > 1:
-            v, i, x = sls.exchange_best(r["value"], r["index"], r["x"], device=xdev)   # the single RCCL exchange of the step
+        if world > 1:                                   # the single exchange of the step
+            if comm is not None:
+                v, i, x = comm.allgather_best(r["value"], r["index"], r["x"])
+            else:
+                v, i, x = sls.exchange_best(r["value"], r["index"], r["x"], device=xdev)
             return dict(value=v, index=i, x=x)
         return r
 
@@ -257,7 +281,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C4: multi-start EI maximisation", "N": N, "D": D, "starts_total": S,
                        "starts_per_gpu": S_loc, "n_local_evals": args.n_local, "kernel": args.kernel,
-                       "candidate_chunk": chunk, "parallelism": f"starts sharded over {world} GPU(s), one all-gather",
+                       "candidate_chunk": chunk, "parallelism": f"starts sharded over {world} GPU(s), one all-gather", "exchange": exchange,
                        "evals_cap_per_step": evals_cap, "evals_issued_per_step": evals_issued,
                        "evals_semantics": "n_local is a cap per start (NLopt max_evals); finished starts leave the batch"},
             "roofline": {"bound": "mfma", "kernel": "acq_gemm_kernel", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS,
@@ -275,6 +299,8 @@ def main():
             # the oracle run is not thrown away: the same inputs go through the HIP path and the two are diffed
             out["parity"], out["parity_max_rel"] = parity_vs_oracle(sls, ctx, kernel_id, oracle_out)
         print(json.dumps(out))
+    if comm is not None:
+        comm.close()
     gp.close()
     ctx.close()
     if world > 1:

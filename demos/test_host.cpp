@@ -4,6 +4,7 @@
 #include <iostream>
 #include <thread>
 #include <sequential-line-search/acquisition-function.hpp>
+#include <sequential-line-search/device.hpp>
 #include <sequential-line-search/gaussian-process-regressor.hpp>
 #include <sequential-line-search/preference-data-manager.hpp>
 #include <sequential-line-search/preference-regressor.hpp>
@@ -107,6 +108,13 @@ int main()
             const VectorXd v0 = acquisition_func::CalcAcquisitionValues(gp, starts, AcquisitionFuncType::ExpectedImprovement);
             EXPECT(vmax >= v0.maxCoeff() - 1e-15);
             for (int d = 0; d < D; ++d) EXPECT(xs(d) >= 0.0 && xs(d) <= 1.0);
+            // multi-GPU path behind the same call: three logical shards on device 0 (replicated fit, starts split 22/21/21,
+            // per-shard winners merged by first maximum) must return the single-device winner bit for bit
+            device::SetDevices({0, 0, 0});
+            double         vmulti = 0.0;
+            const VectorXd xm = acquisition_func::FindNextPointFromStarts(gp, starts, 30, AcquisitionFuncType::ExpectedImprovement, 1.0, &vmulti);
+            device::SetDevices({0});
+            EXPECT(vmulti == vmax && (xm - xs).norm() == 0.0);
         }
         // empty regressor: acquisition value 0 (src/acquisition-function.cpp:176-179)
         GaussianProcessRegressor empty(MatrixXd(0, 0), VectorXd(0));

@@ -145,6 +145,43 @@ int sls_acq_maximize_pair(sls_gp* gp_mean, sls_gp* gp_sigma, int acq_type, doubl
 /* Re-fit an existing handle in place from device-resident X (D x N), y (N): the timed "GP fit" of bench.py. */
 int sls_gp_refit_dev(sls_gp* gp, const double* X_dev, const double* y_dev);
 
+/* ---- multi-GPU maximisation ------------------------------------------------------------------------------
+ * FindGlobalSolution's multi-start loop (src/acquisition-function.cpp:121-153) shards over its starts: the iterations share
+ * only the const regressor (:125-141).  Every GPU holds a replica of the fitted state, runs a contiguous slice of the starts
+ * with the global index offset, and contributes (value, global index, x[D]) to ONE ncclAllGather (RCCL over xGMI); the
+ * first maximum (highest value, ties -> lowest global index: Eigen maxCoeff, :146-153) is taken on the gathered records.
+ * RCCL is dlopen'ed on first use; single-GPU callers never load it. */
+
+/* (1) one process, n devices, one host thread per device.  `devices` may name a GPU more than once (logical shards on one
+ * device, used by tests on a 1-GPU box): RCCL allows one rank per GPU, so the records are then merged on the host;
+ * sls_multi_exchange() says which exchange is in use ("ncclAllGather" or "host merge: <why>"). */
+typedef struct sls_multi sls_multi;
+typedef struct sls_multi_gp sls_multi_gp;
+int sls_multi_create(const int* devices, int n, sls_multi** out);
+int sls_multi_destroy(sls_multi* m);
+int sls_multi_size(const sls_multi* m);
+const char* sls_multi_exchange(const sls_multi* m);
+sls_ctx* sls_multi_ctx(sls_multi* m, int shard);
+/* sls_gp_create on every device (concurrently). */
+int sls_multi_gp_create(sls_multi* m, const double* X, int D, int N, const double* y, const double* theta, double b, int kernel,
+                        sls_multi_gp** out);
+int sls_multi_gp_destroy(sls_multi_gp* g);
+sls_gp* sls_multi_gp_shard(sls_multi_gp* g, int shard);
+/* sls_acq_maximize over all devices: starts (D x S, host) are split into contiguous slices; idx_out is the global start
+ * index of the winner; evals_issued (may be NULL) sums the shards' sls_acq_last_stats. */
+int sls_multi_acq_maximize(sls_multi_gp* g, int acq_type, double ucb_h, const double* starts, int S, int n_local,
+                           const sls_lbfgs_opts* opts, double* x_out, double* val_out, long* idx_out, long* evals_issued);
+
+/* (2) one process per GPU (torch.distributed.run / mpirun).  Rank 0 calls sls_comm_unique_id and distributes the 128 bytes
+ * (any side channel); every rank then calls sls_comm_create on its context.  sls_comm_allgather_best is the single exchange
+ * of a step: this rank's (value, global index, x[D]) in, the global first maximum out -- identical on every rank. */
+typedef struct sls_comm sls_comm;
+int sls_comm_unique_id(char* out128);
+int sls_comm_create(sls_ctx* ctx, const char* id128, int rank, int world, sls_comm** out);
+int sls_comm_destroy(sls_comm* c);
+int sls_comm_allgather_best(sls_comm* c, double value, long index, const double* x, int D, double* value_out, long* index_out,
+                            double* x_out);
+
 /* ---- MAP objectives (hyper-parameter / goodness-value estimation) -------------------------------- */
 /* Device state for repeated evaluations of the GP log-likelihood terms on a fixed design matrix X (D x N). */
 typedef struct sls_nll sls_nll;

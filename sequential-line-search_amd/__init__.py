@@ -52,6 +52,9 @@ EXPORTS = [
     "sls_lbfgs_default_opts", "sls_acq_maximize", "sls_acq_maximize_dev", "sls_gp_refit_dev", "sls_prof_enable",
     "sls_prof_reset", "sls_prof_get", "sls_nll_create", "sls_nll_destroy", "sls_nll_eval", "sls_gp_nll_grad",
     "sls_pref_objective", "sls_acq_eval_pair", "sls_acq_maximize_pair", "sls_gp_append_point", "sls_acq_last_stats",
+    "sls_multi_create", "sls_multi_destroy", "sls_multi_size", "sls_multi_exchange", "sls_multi_ctx", "sls_multi_gp_create",
+    "sls_multi_gp_destroy", "sls_multi_gp_shard", "sls_multi_acq_maximize", "sls_comm_unique_id", "sls_comm_create",
+    "sls_comm_destroy", "sls_comm_allgather_best",
 ]
 
 
@@ -307,6 +310,93 @@ class Nll:
         _ck(lib().sls_pref_objective(self.h, flat.ctypes.data_as(C.POINTER(C.c_uint)), offs.ctypes.data_as(C.POINTER(C.c_int)),
                                      len(prefs), _p(x), C.byref(cfg), C.byref(val), _p(g) if want_grad else None))
         return (val.value, g) if want_grad else val.value
+
+
+class Multi:
+    """One process driving several GPUs (sls_multi_*): replicated fit, starts sharded, one ncclAllGather."""
+
+    def __init__(self, devices):
+        self.devices = [int(d) for d in devices]
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        self.h = C.c_void_p()
+        _ck(lib().sls_multi_create(arr, len(self.devices), C.byref(self.h)))
+        lib().sls_multi_exchange.restype = C.c_char_p
+        self._gps = []
+
+    @property
+    def exchange(self):
+        return lib().sls_multi_exchange(self.h).decode()
+
+    def close(self):
+        if getattr(self, "h", None):
+            for ref in self._gps:
+                gp = ref()
+                if gp is not None:
+                    gp.close()
+            self._gps = []
+            lib().sls_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiGP:
+    def __init__(self, multi, X, y, theta, b, kernel=KERNEL_MATERN52):
+        X, y, theta = _f(X), _f(y), _f(theta)
+        self.D, self.N = X.shape
+        self.h = C.c_void_p()
+        _ck(lib().sls_multi_gp_create(multi.h, _p(X), self.D, self.N, _p(y), _p(theta), C.c_double(b), int(kernel), C.byref(self.h)))
+        multi._gps.append(weakref.ref(self))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().sls_multi_gp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def acq_maximize(self, starts, n_local, acq=ACQ_EI, ucb_h=1.0, opts=None):
+        starts = _f(starts)
+        x, val, idx, issued = np.empty(self.D), C.c_double(), C.c_long(), C.c_long()
+        _ck(lib().sls_multi_acq_maximize(self.h, int(acq), C.c_double(ucb_h), _p(starts), starts.shape[1], int(n_local),
+                                         C.byref(opts) if opts is not None else None, _p(x), C.byref(val), C.byref(idx),
+                                         C.byref(issued)))
+        return dict(index=idx.value, x=x, value=val.value, evals_issued=issued.value)
+
+
+class Comm:
+    """One process per GPU: RCCL communicator inside the library (sls_comm_*).  `unique_id()` on rank 0, distribute the 128
+    bytes, then Comm(ctx, id, rank, world) on every rank."""
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        _ck(lib().sls_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, ctx, uid, rank, world):
+        assert len(uid) == 128
+        self.h = C.c_void_p()
+        _ck(lib().sls_comm_create(ctx.h, uid, int(rank), int(world), C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().sls_comm_destroy(self.h)
+            self.h = None
+
+    def allgather_best(self, value, index, x):
+        x = _f(x)
+        xo, vo, io = np.empty_like(x), C.c_double(), C.c_long()
+        _ck(lib().sls_comm_allgather_best(self.h, C.c_double(value), C.c_long(index), _p(x), len(x), C.byref(vo), C.byref(io), _p(xo)))
+        return vo.value, io.value, xo
 
 
 def merge_rank_results(results):

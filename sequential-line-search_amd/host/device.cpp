@@ -26,6 +26,83 @@ namespace sequential_line_search
             return ctx;
         }
 
+        namespace
+        {
+            std::mutex        g_multi_mtx;
+            std::vector<int>  g_devices;
+            bool              g_devices_set = false;
+            sls_multi*        g_multi       = nullptr;
+            std::vector<int>  g_multi_devices;
+
+            void LoadDevicesFromEnv()
+            {
+                if (g_devices_set) return;
+                g_devices_set = true;
+                g_devices.clear();
+                if (const char* env = std::getenv("SLS_DEVICES"))
+                {
+                    std::string tok;
+                    for (const char* p = env;; ++p)
+                    {
+                        if (*p == ',' || *p == '\0')
+                        {
+                            if (!tok.empty()) g_devices.push_back(std::atoi(tok.c_str()));
+                            tok.clear();
+                            if (*p == '\0') break;
+                        }
+                        else tok.push_back(*p);
+                    }
+                }
+                if (g_devices.empty())
+                {
+                    const char* env = std::getenv("SLS_DEVICE");
+                    g_devices.push_back(env ? std::atoi(env) : 0);
+                }
+            }
+        } // namespace
+
+        void SetDevices(const std::vector<int>& devices)
+        {
+            std::lock_guard<std::mutex> lock(g_multi_mtx);
+            if (devices.empty()) throw std::invalid_argument("device::SetDevices: empty device list");
+            g_devices     = devices;
+            g_devices_set = true;
+        }
+
+        const std::vector<int>& Devices()
+        {
+            std::lock_guard<std::mutex> lock(g_multi_mtx);
+            LoadDevicesFromEnv();
+            return g_devices;
+        }
+
+        sls_multi* Multi()
+        {
+            std::lock_guard<std::mutex> lock(g_multi_mtx);
+            LoadDevicesFromEnv();
+            if (g_devices.size() < 2) return nullptr;
+            if (g_multi && g_multi_devices != g_devices)
+            {
+                sls_multi_destroy(g_multi);
+                g_multi = nullptr;
+            }
+            if (!g_multi)
+            {
+                Check(sls_multi_create(g_devices.data(), static_cast<int>(g_devices.size()), &g_multi), "sls_multi_create");
+                g_multi_devices = g_devices;
+            }
+            return g_multi;
+        }
+
+        MultiGpHandle::MultiGpHandle(const Eigen::MatrixXd& X, const Eigen::VectorXd& y, const Eigen::VectorXd& theta, double b,
+                                     int kernel)
+        {
+            Check(sls_multi_gp_create(Multi(), X.data(), static_cast<int>(X.rows()), static_cast<int>(X.cols()), y.data(), theta.data(),
+                                      b, kernel, &h),
+                  "sls_multi_gp_create");
+        }
+        MultiGpHandle::~MultiGpHandle() { sls_multi_gp_destroy(h); }
+
         GpHandle::GpHandle(const Eigen::MatrixXd& X, const Eigen::VectorXd& y, const Eigen::VectorXd& theta, double b, int kernel)
         {
             Check(sls_gp_create(Context(), X.data(), static_cast<int>(X.rows()), static_cast<int>(X.cols()), y.data(), theta.data(), b,

@@ -2,6 +2,7 @@
 #pragma once
 #include <sls_hip.h>
 
+#include <sequential-line-search/device.hpp>
 #include <sequential-line-search/eigen-lite.hpp>
 #include <functional>
 #include <stdexcept>
@@ -18,6 +19,19 @@ namespace sequential_line_search
 
         /// Lazily created context on device $SLS_DEVICE (default 0).
         sls_ctx* Context();
+
+        // SetDevices / Devices: public, include/sequential-line-search/device.hpp
+        /// The process-wide multi-device handle for Devices() (nullptr when only one device is configured).
+        sls_multi* Multi();
+
+        struct MultiGpHandle
+        {
+            sls_multi_gp* h = nullptr;
+            MultiGpHandle(const Eigen::MatrixXd& X, const Eigen::VectorXd& y, const Eigen::VectorXd& theta, double b, int kernel);
+            ~MultiGpHandle();
+            MultiGpHandle(const MultiGpHandle&)            = delete;
+            MultiGpHandle& operator=(const MultiGpHandle&) = delete;
+        };
 
         struct GpHandle
         {
