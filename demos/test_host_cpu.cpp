@@ -111,6 +111,46 @@ int main(int argc, char** argv)
         const std::vector<double> xr = optim::MaximizeBounded(rosen, {-1.2, 1.0}, {-2, -2}, {2, 2}, 300);
         EXPECT(std::abs(xr[0] - 1.0) < 1e-4 && std::abs(xr[1] - 1.0) < 1e-4);
     }
+    // ---- DIRECT (host/direct.cpp): the global phase of the reference's default maximiser branch ----
+    {
+        int  calls = 0, points = 0, max_batch = 0;
+        auto counted = [&](auto fn) {
+            return [&, fn](const std::vector<std::vector<double>>& xs, std::vector<double>& v) {
+                ++calls; points += static_cast<int>(xs.size()); max_batch = std::max(max_batch, static_cast<int>(xs.size()));
+                v.resize(xs.size());
+                for (size_t k = 0; k < xs.size(); ++k) v[k] = fn(xs[k]);
+            };
+        };
+        // 1-D demo objective 1 - 1.5 x sin(13 x): global maximum 2.273928 at 0.852733, local one 1.555 at 0.378
+        double bv = 0.0; int used = 0;
+        auto x1 = optim::DirectMaximize(counted([](const std::vector<double>& x) { return 1.0 - 1.5 * x[0] * std::sin(13.0 * x[0]); }),
+                                        {0.0}, {1.0}, 60, &bv, &used);
+        EXPECT(std::abs(x1[0] - 0.852733) < 5e-3 && std::abs(bv - 2.273928) < 1e-3);
+        EXPECT(used <= 60 && used == points && calls < used);   // the budget is a cap; iterations are batched
+        // 2-D Branin (negated), rescaled box: three global minima with value 0.397887
+        calls = points = max_batch = 0;
+        auto branin = [](const std::vector<double>& x) {
+            const double a = 1.0, b = 5.1 / (4 * M_PI * M_PI), c = 5.0 / M_PI, r = 6.0, s = 10.0, t = 1.0 / (8 * M_PI);
+            const double u = x[1] - b * x[0] * x[0] + c * x[0] - r;
+            return -(a * u * u + s * (1 - t) * std::cos(x[0]) + s);
+        };
+        auto x2 = optim::DirectMaximize(counted(branin), {-5.0, 0.0}, {10.0, 15.0}, 400, &bv, &used);
+        EXPECT(std::abs(-bv - 0.397887) < 2e-3 && used <= 400);
+        EXPECT(max_batch >= 4);   // several potentially optimal rectangles per iteration share one batch
+        EXPECT(x2[0] >= -5.0 && x2[0] <= 10.0 && x2[1] >= 0.0 && x2[1] <= 15.0);
+        // 6-D: optimum off-centre, anisotropic; 50 D evaluations (the facade's heuristic) get close, never leave the box
+        auto quad = [](const std::vector<double>& x) {
+            double q = 0.0;
+            for (size_t i = 0; i < x.size(); ++i) q += (1.0 + i) * (x[i] - 0.3) * (x[i] - 0.3);
+            return std::exp(-q);
+        };
+        auto x6 = optim::DirectMaximize(counted(quad), std::vector<double>(6, 0.0), std::vector<double>(6, 1.0), 300, &bv, &used);
+        EXPECT(bv > 0.9 && used <= 300);
+        for (double v : x6) EXPECT(v >= 0.0 && v <= 1.0);
+        // a budget smaller than one full first iteration: the centre is returned, nothing is exceeded
+        auto xc = optim::DirectMaximize(counted(quad), std::vector<double>(6, 0.0), std::vector<double>(6, 1.0), 5, &bv, &used);
+        EXPECT(used == 1 && xc[0] == 0.5);
+    }
     // ---- CSV round trip ----
     {
         utils::SetRandomSeed(5);

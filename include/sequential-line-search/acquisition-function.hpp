@@ -16,8 +16,26 @@ namespace sequential_line_search
         GaussianProcessUpperConfidenceBound,
     };
 
+    /// How FindNextPoint / FindNextPoints search [0,1]^D (reference: the two branches of FindGlobalSolution,
+    /// src/acquisition-function.cpp:112-167, chosen there at COMPILE time by the CMake option
+    /// SEQUENTIAL_LINE_SEARCH_USE_PARALLELIZED_MULTI_START_SEARCH, default OFF):
+    ///   DirectThenLbfgs      DIRECT with num_global_search_iters evaluations, then one L-BFGS of num_local_search_iters
+    ///                        evaluations from its result (:155-165, the reference's default build);
+    ///   ParallelMultiStart   num_global_search_iters random starts, one L-BFGS each, best end point (:121-153).
+    /// Here the choice is a run-time setting.  Its initial value is ParallelMultiStart if this library was compiled with
+    /// -DSEQUENTIAL_LINE_SEARCH_USE_PARALLELIZED_MULTI_START_SEARCH, else DirectThenLbfgs; the environment variable
+    /// SLS_GLOBAL_SEARCH=direct|multistart overrides that, SetGlobalSearchStrategy overrides both.
+    enum class GlobalSearchStrategy
+    {
+        DirectThenLbfgs,
+        ParallelMultiStart,
+    };
+
     namespace acquisition_func
     {
+        void                 SetGlobalSearchStrategy(GlobalSearchStrategy strategy);
+        GlobalSearchStrategy GetGlobalSearchStrategy();
+
         /// Acquisition value at x (0 if the regressor holds no data).  `..._hyperparam` is the GP-UCB trade-off weight
         /// (ignored for EI).
         double CalcAcquisitionValue(const Regressor& regressor, const Eigen::VectorXd& x, const AcquisitionFuncType func_type,
@@ -32,15 +50,21 @@ namespace sequential_line_search
                                               const double gaussian_process_upper_confidence_bound_hyperparam = 1.0,
                                               Eigen::MatrixXd* grad = nullptr);
 
-        /// Maximiser of the acquisition function over [0,1]^D: `num_global_search_iters` random starts, each refined by a
-        /// bounded L-BFGS limited to `num_local_search_iters` objective evaluations, all starts advanced in lock step on the
-        /// GPU (the reference's SEQUENTIAL_LINE_SEARCH_USE_PARALLELIZED_MULTI_START_SEARCH branch).
+        /// Maximiser of the acquisition function over [0,1]^D by the current GlobalSearchStrategy.  DirectThenLbfgs: every
+        /// DIRECT iteration's sample points are one batched device evaluation.  ParallelMultiStart: all starts advance in
+        /// lock step on the GPU (sharded over device::Devices() when several are configured).
         Eigen::VectorXd FindNextPoint(const Regressor& regressor, const unsigned num_global_search_iters = 100,
                                       const unsigned            num_local_search_iters = 50,
                                       const AcquisitionFuncType func_type              = AcquisitionFuncType::ExpectedImprovement,
                                       const double              gaussian_process_upper_confidence_bound_hyperparam = 1.0);
 
-        /// Same from an explicit start set (D x S), for reproducible runs and multi-GPU sharding; returns also the value.
+        /// The DirectThenLbfgs branch, whatever the current strategy (deterministic: DIRECT draws no random numbers).
+        Eigen::VectorXd FindNextPointDirect(const Regressor& regressor, const unsigned num_global_search_iters,
+                                            const unsigned num_local_search_iters, const AcquisitionFuncType func_type,
+                                            const double gaussian_process_upper_confidence_bound_hyperparam, double* value = nullptr);
+
+        /// The ParallelMultiStart branch from an explicit start set (D x S), for reproducible runs and multi-GPU sharding;
+        /// returns also the value.
         Eigen::VectorXd FindNextPointFromStarts(const Regressor& regressor, const Eigen::MatrixXd& starts,
                                                 const unsigned num_local_search_iters, const AcquisitionFuncType func_type,
                                                 const double gaussian_process_upper_confidence_bound_hyperparam, double* value = nullptr);

@@ -11,6 +11,10 @@
 
 using namespace slsk;
 
+#ifndef SLS_POTRF_LOOKAHEAD_DEFAULT
+#define SLS_POTRF_LOOKAHEAD_DEFAULT 0
+#endif
+
 namespace slsk {
 static thread_local char g_err[512] = "";
 void set_error(const char* fmt, ...) {
@@ -57,6 +61,15 @@ void sls_ctx::prof_collect() {
     }
 }
 
+slsk::PotrfAux* sls_ctx::potrf_lookahead() {
+    // SLS_POTRF_LOOKAHEAD = f > 0: side stream whose CU mask leaves f CUs per XCD free; 0: single-stream schedule
+    const char* e = getenv("SLS_POTRF_LOOKAHEAD");
+    const int f = e ? atoi(e) : SLS_POTRF_LOOKAHEAD_DEFAULT;
+    if (f <= 0) return nullptr;
+    if (!potrf_aux.side) slsk::potrf_aux_create(&potrf_aux, f);
+    return &potrf_aux;
+}
+
 #define SLS_TRY try {
 #define SLS_CATCH                                   \
     }                                               \
@@ -97,6 +110,7 @@ extern "C" int sls_ctx_destroy(sls_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     ctx->prof_collect();
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+    slsk::potrf_aux_destroy(&ctx->potrf_aux);
     if (ctx->d_info) (void)hipFree(ctx->d_info);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -217,7 +231,7 @@ static void gp_fit_device(sls_gp* g) {
     launch_fill(c->stream, g->Linv.p, (long)Np * Np, 0.0);
     {
         ProfScope ps(c, "potrf");
-        launch_potrf(c->stream, g->L.p, Np, g->Linv.p, c->d_info);
+        launch_potrf(c->stream, g->L.p, Np, g->Linv.p, c->d_info, 0, c->potrf_lookahead());
     }
     {
         ProfScope ps(c, "trtri");
@@ -883,7 +897,7 @@ extern "C" int sls_potrf(sls_ctx* c, double* A, int N) {
     upload_padded_spd(c, Ad, A, N, Np);
     Li.ensure((size_t)Np * Np);
     SLS_HIP(hipMemsetAsync(c->d_info, 0, 64, c->stream));
-    launch_potrf(c->stream, Ad.p, Np, Li.p, c->d_info);
+    launch_potrf(c->stream, Ad.p, Np, Li.p, c->d_info, 0, c->potrf_lookahead());
     launch_zero_upper(c->stream, Ad.p, Np);
     int info = 0;
     SLS_HIP(hipMemcpyAsync(&info, c->d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/sls_hip.h"
+#include "kernels.hpp"
 
 namespace slsk {
 
@@ -81,6 +82,9 @@ struct sls_ctx {
     // scratch
     slsk::DBuf scratch;   // generic host<->device staging
     int* d_info = nullptr;  // device int[4]: potrf info etc.
+    // look-ahead schedule of the Cholesky factorisation: CU-masked side stream + events, created on first use
+    slsk::PotrfAux potrf_aux;
+    slsk::PotrfAux* potrf_lookahead();   // nullptr unless SLS_POTRF_LOOKAHEAD selects the two-stream schedule
 
     hipEvent_t get_event();
     void prof_begin(const char* name, hipEvent_t& e0);

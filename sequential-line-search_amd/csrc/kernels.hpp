@@ -145,7 +145,19 @@ void launch_maximize_wave(hipStream_t s, WaveArgs a);
 // ---- kernels_chol.hip ---------------------------------------------------------
 // In-place lower Cholesky of the Np x Np matrix A (ld = Np); Linv receives the 128x128 diagonal-block inverses
 // (rest of Linv untouched).  info (device int) gets 1 + index of the first non-positive pivot, or stays 0.
-void launch_potrf(hipStream_t s, double* A, int Np, double* Linv, int* info);
+// nbo: 128-columns per outer block (1 = one-level algorithm; default from potrf_default_nbo(Np)).  aux (optional): a side
+// stream + events for the look-ahead schedule (see kernels_chol.hip); nullptr = everything on s.
+struct PotrfAux {
+    static constexpr int NEV = 8;
+    hipStream_t side = nullptr;
+    hipEvent_t ev[NEV] = {};
+    hipEvent_t last_rest = nullptr;
+};
+int potrf_default_nbo(int Np);
+void launch_potrf(hipStream_t s, double* A, int Np, double* Linv, int* info, int nbo = 0, PotrfAux* aux = nullptr);
+// side stream restricted by a CU mask that leaves `free_per_xcd` CUs of each of the 8 XCDs to other streams (0: plain stream)
+void potrf_aux_create(PotrfAux* aux, int free_per_xcd);
+void potrf_aux_destroy(PotrfAux* aux);
 // Linv <- L^-1 (lower) given L and the diagonal-block inverses already in Linv; tmp is an Np x Np scratch.
 void launch_trtri(hipStream_t s, const double* L, int Np, double* Linv, double* tmp);
 // diagonal-block inverses only (for potrs / potri on a caller-supplied factor)

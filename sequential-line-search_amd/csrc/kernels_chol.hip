@@ -8,6 +8,7 @@
 //   panel       L_ij = A_ij T_jj^T            (MFMA GEMM, in place)
 //   syrk        A_ik -= L_ij L_kj^T, i>=k>j   (MFMA GEMM, lower tiles only)
 // Triangular inverse: recursive doubling over block pairs, X21 = -X22 (L21 X11), every level two batched GEMMs.
+#include <algorithm>
 #include <cstdlib>
 
 #include "chol_diag.hpp"
@@ -28,7 +29,8 @@ struct GemmDesc {
     int mt, nt;        // tile grid
     int K;             // full k extent (multiple of 16)
     double alpha, beta;
-    int tri;           // 1: only tiles tm >= tn
+    int tri;           // 1: only tiles tm >= tn + tri_off
+    int tri_off;
     int kmode;         // 0: [0,K)  1: [128 tn, K)  2: [0, 128 (tm+1))  3: [128 max(tm,tn), K)
     int vb_stride, vb_off, vb_limit;   // tile row valid iff batch*vb_stride + vb_off + tm < vb_limit
 };
@@ -39,7 +41,7 @@ __global__ __launch_bounds__(256, 2) void tri_gemm_kernel(GemmDesc g) {
     double* lds = reinterpret_cast<double*>(smem);
     const int tm = blockIdx.x % g.mt, tn = blockIdx.x / g.mt;
     const int batch = blockIdx.y;
-    if (g.tri && tn > tm) return;
+    if (g.tri && tn + g.tri_off > tm) return;
     if (batch * g.vb_stride + g.vb_off + tm >= g.vb_limit) return;
     const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
     int kb = 0, ke = g.K;
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void tri_gemm64_kernel(GemmDesc g) {
     double* lds = reinterpret_cast<double*>(smem);
     const int tm = blockIdx.x % g.mt, tn64 = blockIdx.x / g.mt, tn = tn64 >> 1;
     const int batch = blockIdx.y;
-    if (g.tri && tn > tm) return;
+    if (g.tri && tn + g.tri_off > tm) return;
     if (batch * g.vb_stride + g.vb_off + tm >= g.vb_limit) return;
     const int m0 = tm * GEMM_BM, n0 = tn64 * 64;
     int kb = 0, ke = g.K;
@@ -124,7 +126,7 @@ static GemmDesc mkdesc(const double* A, long lda, const double* B, long ldb, dou
     g.B = B; g.ldb = ldb; g.strideB = 0;
     g.C = C; g.ldc = ldc; g.strideC = 0;
     g.mt = mt; g.nt = nt; g.K = K; g.alpha = alpha; g.beta = beta;
-    g.tri = 0; g.kmode = 0; g.vb_stride = 0; g.vb_off = 0; g.vb_limit = 1 << 30;
+    g.tri = 0; g.tri_off = 0; g.kmode = 0; g.vb_stride = 0; g.vb_off = 0; g.vb_limit = 1 << 30;
     return g;
 }
 
@@ -212,25 +214,106 @@ static void diag_attr() {
     ensure_dyn_lds((const void*)chol_diag_kernel<false>, DIAG_LDS_BYTES);
 }
 
-void launch_potrf(hipStream_t s, double* A, int Np, double* Linv, int* info) {
+// Two-level right-looking factorisation.  Outer blocks of `nbo` 128-columns: inside an outer block every 128-step is
+//   diag (one workgroup, LDS-resident)  ->  panel L_ij = A_ij T_jj^T for ALL rows below  ->  update of the REMAINING columns
+//   of the outer block only (K = 128, at most nbo - 1 tile columns: a short launch),
+// and the rest of the trailing matrix is updated once per outer block with K = 128 nbo (nbo x fewer read-modify-write
+// sweeps over the trailing matrix and a k loop long enough to run at the GEMM rate; with nbo = 1 this is the plain
+// one-level algorithm).
+// Look-ahead (aux != nullptr, nbo > 1): the outer update is split into the columns of the NEXT outer block (main stream,
+// the only part the next inner factorisation needs) and the rest (side stream).  The side stream is created with a CU mask
+// that leaves a few CUs per XCD free, so the single-workgroup diagonal kernel -- which needs a whole CU's LDS -- always
+// finds one while the bulk update runs; without the mask it would wait for the bulk grid to drain.
+// CU-mask convention of the amdgpu driver on multi-XCC parts: mask bit i addresses XCC i % 8, and bit i / 8 of that XCC's
+// own (SE-interleaved) CU sequence.  Clearing bits >= 8 (32 - f) therefore frees f CUs on every XCD (tools/probes/potrf_bench
+// prints the CUs a masked stream really uses).
+void potrf_aux_create(PotrfAux* aux, int free_per_xcd) {
+    if (aux->side) return;
+    if (free_per_xcd > 0 && free_per_xcd < 32) {
+        uint32_t mask[8];
+        for (int w = 0; w < 8; ++w) mask[w] = 0;
+        for (int b = 0; b < 8 * (32 - free_per_xcd); ++b) mask[b >> 5] |= 1u << (b & 31);
+        if (hipExtStreamCreateWithCUMask(&aux->side, 8, mask) != hipSuccess) aux->side = nullptr;
+    }
+    if (!aux->side) (void)hipStreamCreateWithFlags(&aux->side, hipStreamNonBlocking);
+    for (int i = 0; i < PotrfAux::NEV; ++i) (void)hipEventCreateWithFlags(&aux->ev[i], hipEventDisableTiming);
+    aux->last_rest = nullptr;
+}
+void potrf_aux_destroy(PotrfAux* aux) {
+    if (!aux->side) return;
+    (void)hipStreamSynchronize(aux->side);
+    (void)hipStreamDestroy(aux->side);
+    for (int i = 0; i < PotrfAux::NEV; ++i) (void)hipEventDestroy(aux->ev[i]);
+    aux->side = nullptr;
+}
+
+int potrf_default_nbo(int Np) {
+    static int env = -2;
+    if (env == -2) {
+        const char* e = getenv("SLS_POTRF_NBO");
+        env = e ? atoi(e) : -1;
+    }
+    if (env >= 1) return env;
+    return Np >= 2048 ? 4 : 1;
+}
+
+void launch_potrf(hipStream_t s, double* A, int Np, double* Linv, int* info, int nbo, PotrfAux* aux) {
     diag_attr();
     const int nb = Np / NB;
     const long ld = Np;
-    for (int j = 0; j < nb; ++j) {
-        double* Ajj = A + (long)j * NB * (ld + 1);
-        double* Tjj = Linv + (long)j * NB * (ld + 1);
-        hipLaunchKernelGGL(chol_diag_kernel<true>, dim3(1), dim3(256), DIAG_LDS_BYTES, s, Ajj, ld, Tjj, ld, info, j * NB);
-        const int rem = nb - j - 1;
-        if (rem <= 0) break;
-        double* Apan = Ajj + NB;   // rows below the diagonal block, same columns
-        // panel: L_ij = A_ij T_jj^T   (B operand elem(n,k) = T[n + k ld], M-contiguous)
-        GemmDesc p = mkdesc(Apan, ld, Tjj, ld, Apan, ld, rem, 1, NB, 1.0, 0.0);
-        launch_tri_gemm<false, false>(s, p, 1);
-        // trailing update: A_ik -= L_ij L_kj^T for i >= k > j
-        double* Atr = Ajj + (long)NB * (ld + 1);
-        GemmDesc u = mkdesc(Apan, ld, Apan, ld, Atr, ld, rem, rem, NB, -1.0, 1.0);
+    if (nbo < 1) nbo = potrf_default_nbo(Np);
+    const bool look = aux && aux->side && nbo > 1 && nb > 2 * nbo;
+    auto syrk = [&](hipStream_t st, int kcol0, int ktiles, int row0, int col0, int ncols) {
+        // A[row0.., col0 .. col0+ncols) -= L[row0.., kcol0 .. kcol0+ktiles) L[col0.., same]^T on lower tiles (row >= col)
+        const int mt = nb - row0;
+        if (mt <= 0 || ncols <= 0) return;
+        const double* Ap = A + (long)row0 * NB + (long)kcol0 * NB * ld;
+        const double* Bp = A + (long)col0 * NB + (long)kcol0 * NB * ld;
+        double* Cp = A + (long)row0 * NB + (long)col0 * NB * ld;
+        GemmDesc u = mkdesc(Ap, ld, Bp, ld, Cp, ld, mt, ncols, ktiles * NB, -1.0, 1.0);
         u.tri = 1;
-        launch_tri_gemm<false, false>(s, u, 1);
+        u.tri_off = col0 - row0;     // tile (tm, tn) is on or below the diagonal iff row0 + tm >= col0 + tn
+        launch_tri_gemm<false, false>(st, u, 1);
+    };
+    int ev_i = 0;
+    for (int J0 = 0; J0 < nb; J0 += nbo) {
+        const int J1 = std::min(J0 + nbo, nb);      // outer block = tile columns [J0, J1)
+        for (int j = J0; j < J1; ++j) {
+            double* Ajj = A + (long)j * NB * (ld + 1);
+            double* Tjj = Linv + (long)j * NB * (ld + 1);
+            hipLaunchKernelGGL(chol_diag_kernel<true>, dim3(1), dim3(256), DIAG_LDS_BYTES, s, Ajj, ld, Tjj, ld, info, j * NB);
+            const int rem = nb - j - 1;
+            if (rem <= 0) break;
+            double* Apan = Ajj + NB;   // rows below the diagonal block, same columns
+            // panel: L_ij = A_ij T_jj^T   (B operand elem(n,k) = T[n + k ld], M-contiguous)
+            GemmDesc p = mkdesc(Apan, ld, Tjj, ld, Apan, ld, rem, 1, NB, 1.0, 0.0);
+            launch_tri_gemm<false, false>(s, p, 1);
+            // inner update: the remaining columns of this outer block
+            syrk(s, j, 1, j + 1, j + 1, J1 - (j + 1));
+        }
+        if (J1 >= nb) break;
+        const int kt = J1 - J0;
+        if (!look) {
+            syrk(s, J0, kt, J1, J1, nb - J1);   // nbo == 1: the inner update above had no columns, this is the whole update
+            continue;
+        }
+        // look-ahead: next outer block's columns on the main stream, the rest on the side stream
+        const int N1 = std::min(J1 + nbo, nb);
+        hipEvent_t panel_done = aux->ev[ev_i % PotrfAux::NEV];
+        hipEvent_t rest_done = aux->ev[(ev_i + 1) % PotrfAux::NEV];
+        ev_i += 2;
+        (void)hipEventRecord(panel_done, s);
+        (void)hipStreamWaitEvent(aux->side, panel_done, 0);
+        if (N1 < nb) syrk(aux->side, J0, kt, N1, N1, nb - N1);          // in order after the previous rest on the side stream
+        (void)hipEventRecord(rest_done, aux->side);
+        // the next block's columns were also written by the PREVIOUS rest update (side stream): order after it
+        if (aux->last_rest) (void)hipStreamWaitEvent(s, aux->last_rest, 0);
+        syrk(s, J0, kt, J1, J1, N1 - J1);
+        aux->last_rest = rest_done;
+    }
+    if (look) {
+        if (aux->last_rest) (void)hipStreamWaitEvent(s, aux->last_rest, 0);   // join: later work on s sees the whole factor
+        aux->last_rest = nullptr;
     }
 }
 

@@ -1,5 +1,9 @@
 // acquisition_func over the C ABI (reference: src/acquisition-function.cpp).
+#include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
+#include <string>
 #include <sequential-line-search/acquisition-function.hpp>
 #include <sequential-line-search/gaussian-process-regressor.hpp>
 #include <sequential-line-search/utils.hpp>
@@ -54,6 +58,22 @@ namespace sequential_line_search
             return starts;
         }
 
+        GlobalSearchStrategy InitialStrategy()
+        {
+            if (const char* env = std::getenv("SLS_GLOBAL_SEARCH"))
+            {
+                const std::string v(env);
+                if (v == "direct") return GlobalSearchStrategy::DirectThenLbfgs;
+                if (v == "multistart") return GlobalSearchStrategy::ParallelMultiStart;
+            }
+#ifdef SEQUENTIAL_LINE_SEARCH_USE_PARALLELIZED_MULTI_START_SEARCH
+            return GlobalSearchStrategy::ParallelMultiStart;
+#else
+            return GlobalSearchStrategy::DirectThenLbfgs;   // the reference's default build (CMakeLists.txt:33)
+#endif
+        }
+        std::atomic<int> g_strategy{-1};
+
         sls_gp* RequireHandle(const Regressor& r)
         {
             sls_gp* h = r.GetDeviceHandle();
@@ -63,6 +83,18 @@ namespace sequential_line_search
             return h;
         }
     } // namespace
+
+    void acquisition_func::SetGlobalSearchStrategy(GlobalSearchStrategy strategy) { g_strategy.store(static_cast<int>(strategy)); }
+    GlobalSearchStrategy acquisition_func::GetGlobalSearchStrategy()
+    {
+        int v = g_strategy.load();
+        if (v < 0)
+        {
+            v = static_cast<int>(InitialStrategy());
+            g_strategy.store(v);
+        }
+        return static_cast<GlobalSearchStrategy>(v);
+    }
 
     // reference: src/acquisition-function.cpp:170-198
     double acquisition_func::CalcAcquisitionValue(const Regressor& regressor, const VectorXd& x, const AcquisitionFuncType func_type,
@@ -138,12 +170,51 @@ namespace sequential_line_search
         return x;
     }
 
-    // reference: src/acquisition-function.cpp:232-244 + FindGlobalSolution :112-153 (parallelised multi-start branch)
+    // reference: src/acquisition-function.cpp:155-165 -- DIRECT (num_global_search_iters evaluations), then L-BFGS
+    // (num_local_search_iters evaluations) from its result.  Every DIRECT iteration is ONE batched device evaluation.
+    VectorXd acquisition_func::FindNextPointDirect(const Regressor& regressor, const unsigned num_global_search_iters,
+                                                   const unsigned num_local_search_iters, const AcquisitionFuncType func_type,
+                                                   const double hyperparam, double* value)
+    {
+        const unsigned num_dim = regressor.GetNumDims();
+        sls_gp*        h       = RequireHandle(regressor);
+        const optim::BatchObjective objective = [&](const std::vector<std::vector<double>>& xs, std::vector<double>& values) {
+            MatrixXd Xs(num_dim, static_cast<long>(xs.size()));
+            for (size_t m = 0; m < xs.size(); ++m)
+                for (unsigned d = 0; d < num_dim; ++d) Xs(d, static_cast<long>(m)) = xs[m][d];
+            values.resize(xs.size());
+            device::Check(sls_acq_eval(h, AcqId(func_type), hyperparam, Xs.data(), static_cast<int>(xs.size()), values.data(), nullptr),
+                          "sls_acq_eval");
+        };
+        const std::vector<double> lower(num_dim, 0.0), upper(num_dim, 1.0);
+        const std::vector<double> xg = optim::DirectMaximize(objective, lower, upper, static_cast<int>(num_global_search_iters));
+        MatrixXd start(num_dim, 1);
+        for (unsigned d = 0; d < num_dim; ++d) start(d, 0) = xg[d];
+        if (num_local_search_iters == 0)
+        {
+            VectorXd x(num_dim);
+            for (unsigned d = 0; d < num_dim; ++d) x(d) = xg[d];
+            if (value) *value = CalcAcquisitionValue(regressor, x, func_type, hyperparam);
+            return x;
+        }
+        VectorXd x(num_dim);
+        double   v   = 0.0;
+        long     idx = 0;
+        device::Check(sls_acq_maximize(h, AcqId(func_type), hyperparam, start.data(), 1, static_cast<int>(num_local_search_iters), nullptr,
+                                       0, x.data(), &v, &idx, nullptr, nullptr),
+                      "sls_acq_maximize");
+        if (value) *value = v;
+        return x;
+    }
+
+    // reference: src/acquisition-function.cpp:232-244 + FindGlobalSolution :112-167 (both branches, chosen at run time)
     VectorXd acquisition_func::FindNextPoint(const Regressor& regressor, const unsigned num_global_search_iters,
                                              const unsigned num_local_search_iters, const AcquisitionFuncType func_type,
                                              const double hyperparam)
     {
         const unsigned num_dim = regressor.GetNumDims();
+        if (GetGlobalSearchStrategy() == GlobalSearchStrategy::DirectThenLbfgs)
+            return FindNextPointDirect(regressor, num_global_search_iters, num_local_search_iters, func_type, hyperparam);
         return FindNextPointFromStarts(regressor, RandomStarts(num_dim, num_global_search_iters), num_local_search_iters, func_type,
                                        hyperparam);
     }
@@ -168,13 +239,34 @@ namespace sequential_line_search
 
         for (unsigned i = 0; i < num_points; ++i)
         {
-            const MatrixXd starts = RandomStarts(num_dim, num_global_search_iters);
-            VectorXd       x_star(num_dim);
-            double         v   = 0.0;
-            long           idx = 0;
+            // FindGlobalSolution on objective_for_multiple_points (:265-278): both branches, as in FindNextPoint
+            MatrixXd starts;
+            if (GetGlobalSearchStrategy() == GlobalSearchStrategy::DirectThenLbfgs)
+            {
+                const optim::BatchObjective objective = [&](const std::vector<std::vector<double>>& xs, std::vector<double>& values) {
+                    MatrixXd Xs(num_dim, static_cast<long>(xs.size()));
+                    for (size_t m = 0; m < xs.size(); ++m)
+                        for (unsigned d = 0; d < num_dim; ++d) Xs(d, static_cast<long>(m)) = xs[m][d];
+                    values.resize(xs.size());
+                    device::Check(sls_acq_eval_pair(mean_handle, temp->GetDeviceHandle(), AcqId(func_type), hyperparam, Xs.data(),
+                                                    static_cast<int>(xs.size()), values.data(), nullptr),
+                                  "sls_acq_eval_pair");
+                };
+                const std::vector<double> lower(num_dim, 0.0), upper(num_dim, 1.0);
+                const std::vector<double> xg = optim::DirectMaximize(objective, lower, upper, static_cast<int>(num_global_search_iters));
+                starts = MatrixXd(num_dim, 1);
+                for (unsigned d = 0; d < num_dim; ++d) starts(d, 0) = xg[d];
+            }
+            else
+            {
+                starts = RandomStarts(num_dim, num_global_search_iters);
+            }
+            VectorXd x_star(num_dim);
+            double   v   = 0.0;
+            long     idx = 0;
             device::Check(sls_acq_maximize_pair(mean_handle, temp->GetDeviceHandle(), AcqId(func_type), hyperparam, starts.data(),
-                                                static_cast<int>(starts.cols()), static_cast<int>(num_local_search_iters), nullptr,
-                                                x_star.data(), &v, &idx),
+                                                static_cast<int>(starts.cols()),
+                                                std::max(1, static_cast<int>(num_local_search_iters)), nullptr, x_star.data(), &v, &idx),
                           "sls_acq_maximize_pair");
             points.push_back(x_star);
             if (points.size() != num_points)

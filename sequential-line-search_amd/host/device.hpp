@@ -62,5 +62,14 @@ namespace sequential_line_search
         /// NLopt is not available, so iterates differ from the reference while the optimum is the same.
         std::vector<double> MaximizeBounded(const Objective& f, std::vector<double> x0, const std::vector<double>& lower,
                                             const std::vector<double>& upper, int max_evals, double* best_value = nullptr);
+
+        /// values[k] = f(xs[k]) for a whole batch of points (one device call per batch).
+        using BatchObjective = std::function<void(const std::vector<std::vector<double>>& xs, std::vector<double>& values)>;
+
+        /// DIRECT global MAXIMISER on the box [lower, upper] with at most max_evals objective evaluations (host/direct.cpp).
+        /// Stand-in for nloptutil::solve(x0, upper, lower, f, nlopt::GN_DIRECT, data, is_max = true, max_evals) -- DIRECT
+        /// ignores x0.  Returns the centre of the best rectangle.
+        std::vector<double> DirectMaximize(const BatchObjective& f, const std::vector<double>& lower, const std::vector<double>& upper,
+                                           int max_evals, double* best_value = nullptr, int* evals_used = nullptr);
     } // namespace optim
 } // namespace sequential_line_search

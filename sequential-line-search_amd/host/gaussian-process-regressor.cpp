@@ -96,8 +96,8 @@ namespace sequential_line_search
     }
 
     // reference: src/gaussian-process-regressor.cpp:274-299.  Objective + gradient on the device (sls_gp_nll_grad);
-    // the reference's DIRECT(300) -> TNEWTON(1000) drivers are replaced by a coarse log-grid scan + bounded L-BFGS in
-    // log-parameters (same bounds [1e-8, 50]; NLopt is unavailable, iterates are not comparable, the optimum is).
+    // drivers: DIRECT(300) as the reference (host/direct.cpp), then a bounded L-BFGS in log-parameters in place of
+    // TNEWTON(1000) (same bounds [1e-8, 50]; NLopt is unavailable, iterates are not comparable, the optimum is).
     void GaussianProcessRegressor::PerformMapEstimation()
     {
         const int         D = static_cast<int>(m_X.rows());
@@ -119,22 +119,29 @@ namespace sequential_line_search
             return v;
         };
 
-        // global phase: prior medians (the reference's x_ini) and an isotropic log grid
+        // global phase: DIRECT, 300 evaluations on the reference's box [1e-8, 50]^(D+2) in the reference's (linear)
+        // parameters (:291-294); DIRECT ignores x_ini.  The prior medians (the reference's x_ini) stay in the race.
+        const optim::BatchObjective batch = [&](const std::vector<std::vector<double>>& xs, std::vector<double>& values) {
+            values.resize(xs.size());
+            for (size_t k = 0; k < xs.size(); ++k)
+            {
+                std::vector<double> z(xs[k].size());
+                for (size_t i = 0; i < z.size(); ++i) z[i] = std::log(xs[k][i]);
+                values[k] = objective(z, nullptr);
+            }
+        };
+        const std::vector<double> lin_lower(D + 2, 1e-8), lin_upper(D + 2, 5e+01);
+        double                    direct_v = 0.0;
+        const std::vector<double> xg       = optim::DirectMaximize(batch, lin_lower, lin_upper, 300, &direct_v);
         std::vector<double> best(D + 2);
         best[0] = std::log(0.5); best[1] = std::log(1e-4);
         for (int d = 0; d < D; ++d) best[2 + d] = std::log(0.5);
-        double best_v = objective(best, nullptr);
-        for (double a : {0.1, 0.5, 2.0})
-            for (double b : {1e-5, 1e-3, 1e-1})
-                for (double r : {0.05, 0.15, 0.5, 1.5})
-                {
-                    std::vector<double> z(D + 2, std::log(r));
-                    z[0] = std::log(a); z[1] = std::log(b);
-                    const double v = objective(z, nullptr);
-                    if (v > best_v) { best_v = v; best = z; }
-                }
+        if (direct_v > objective(best, nullptr))
+            for (int i = 0; i < D + 2; ++i) best[i] = std::log(xg[i]);
+        // local phase: bounded quasi-Newton in log-parameters from the global phase's point (reference: TNEWTON, 1000
+        // evaluations, :295; same bounds)
         const std::vector<double> lower(D + 2, lo), upper(D + 2, hi);
-        const std::vector<double> z = optim::MaximizeBounded(objective, best, lower, upper, 200);
+        const std::vector<double> z = optim::MaximizeBounded(objective, best, lower, upper, 1000);
 
         m_kernel_hyperparams    = VectorXd(D + 1);
         m_kernel_hyperparams(0) = std::exp(z[0]);

@@ -59,12 +59,14 @@ namespace sequential_line_search
         m_btl_scale                    = btl_scale;
     }
 
-    // reference: src/sequential-line-search.cpp:65-79 (the acquisition maximiser is always the parallel multi-start one here,
-    // hence the "10 starts" branch of the heuristic)
+    // reference: src/sequential-line-search.cpp:65-79 -- the effort heuristic follows the maximiser branch in use: 10 starts
+    // for the parallel multi-start search, 50 D DIRECT evaluations otherwise; 10 D local evaluations either way
     void SequentialLineSearchOptimizer::SubmitFeedbackData(const double slider_position)
     {
-        const int num_dims = static_cast<int>(GetMaximizer().size());
-        SubmitFeedbackData(slider_position, 100, 10, 10 * num_dims);
+        const int  num_dims                = static_cast<int>(GetMaximizer().size());
+        const bool multi_start             = acquisition_func::GetGlobalSearchStrategy() == GlobalSearchStrategy::ParallelMultiStart;
+        const int  num_global_search_iters = multi_start ? 10 : 50 * num_dims;
+        SubmitFeedbackData(slider_position, 100, num_global_search_iters, 10 * num_dims);
     }
 
     // reference: src/sequential-line-search.cpp:81-123

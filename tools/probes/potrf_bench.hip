@@ -1,0 +1,113 @@
+// potrf schedule experiments (debug tool, not shipped): one-level vs two-level blocking, look-ahead on a CU-masked side
+// stream.  usage: potrf_bench [N ...]   env: none.  Prints ms per factorisation and the max deviation from the one-level L.
+#include "../../sequential-line-search_amd/csrc/kernels_chol.hip"
+#include <cmath>
+#include <cstdio>
+#include <set>
+#include <vector>
+
+__global__ void fill_spd(double* A, int Np) {
+    const long idx = blockIdx.x * 256L + threadIdx.x;
+    if (idx >= (long)Np * Np) return;
+    const int i = idx % Np, j = idx / Np;
+    const double d = (double)(i - j) / 40.0;
+    A[idx] = exp(-0.5 * d * d) * (1.0 + 0.3 * cos(0.01 * (i + j))) * 0.5 + (i == j ? 0.05 : 0.0);
+}
+__global__ void maxdiff_lower(const double* a, const double* b, int Np, double* out) {
+    __shared__ double red[256];
+    double m = 0.0;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < (long)Np * Np; idx += gridDim.x * 256L) {
+        const int i = idx % Np, j = idx / Np;
+        if (i >= j) m = fmax(m, fabs(a[idx] - b[idx]));
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256, 2) void where_kernel(int* out) {
+    if (threadIdx.x == 0) {
+        unsigned x, h;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(h));
+        out[blockIdx.x] = ((x & 0xf) << 16) | (h & 0xff00);
+    }
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < 5000) __builtin_amdgcn_s_sleep(32);
+}
+
+int main(int argc, char** argv) {
+    using namespace slsk;
+    std::vector<int> sizes;
+    for (int i = 1; i < argc; ++i) sizes.push_back(atoi(argv[i]));
+    if (sizes.empty()) sizes = {2048, 4096, 8192};
+    hipStream_t s;
+    hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    int* info; hipMalloc(&info, 4096);
+    // which CUs does a masked stream use?
+    for (int f : {0, 2, 4, 8}) {
+        PotrfAux aux;
+        potrf_aux_create(&aux, f);
+        int* d; hipMalloc(&d, 4096 * 4);
+        hipLaunchKernelGGL(where_kernel, dim3(2048), dim3(256), 0, aux.side, d);
+        hipStreamSynchronize(aux.side);
+        std::vector<int> h(2048); hipMemcpy(h.data(), d, 2048 * 4, hipMemcpyDeviceToHost);
+        std::set<int> cus; int per_xcd[8] = {0};
+        for (int v : h) cus.insert(v);
+        for (int v : cus) per_xcd[(v >> 16) & 7]++;
+        printf("mask free_per_xcd=%d: %zu distinct CUs used; per XCD:", f, cus.size());
+        for (int x = 0; x < 8; ++x) printf(" %d", per_xcd[x]);
+        printf("\n");
+        hipFree(d);
+        potrf_aux_destroy(&aux);
+    }
+    for (int Np : sizes) {
+        double *A0, *A, *Lref, *Linv, *red;
+        const size_t bytes = (size_t)Np * Np * 8;
+        hipMalloc(&A0, bytes); hipMalloc(&A, bytes); hipMalloc(&Lref, bytes); hipMalloc(&Linv, bytes); hipMalloc(&red, 1024 * 8);
+        hipLaunchKernelGGL(fill_spd, dim3((unsigned)(((long)Np * Np + 255) / 256)), dim3(256), 0, s, A0, Np);
+        hipMemsetAsync(Linv, 0, bytes, s);
+        auto run = [&](int nbo, PotrfAux* aux, const char* label, bool is_ref) {
+            float best = 1e30f;
+            for (int rep = 0; rep < 4; ++rep) {
+                hipMemcpyAsync(A, A0, bytes, hipMemcpyDeviceToDevice, s);
+                hipMemsetAsync(info, 0, 64, s);
+                hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+                hipEventRecord(e0, s);
+                launch_potrf(s, A, Np, Linv, info, nbo, aux);
+                hipEventRecord(e1, s); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                if (rep > 0 && ms < best) best = ms;
+                hipEventDestroy(e0); hipEventDestroy(e1);
+            }
+            int inf = 0; hipMemcpy(&inf, info, 4, hipMemcpyDeviceToHost);
+            double md = 0.0;
+            if (is_ref) hipMemcpyAsync(Lref, A, bytes, hipMemcpyDeviceToDevice, s);
+            else {
+                hipLaunchKernelGGL(maxdiff_lower, dim3(1024), dim3(256), 0, s, A, Lref, Np, red);
+                std::vector<double> h(1024); hipStreamSynchronize(s); hipMemcpy(h.data(), red, 1024 * 8, hipMemcpyDeviceToHost);
+                for (double v : h) md = fmax(md, v);
+            }
+            hipStreamSynchronize(s);
+            const double tf = (double)Np * Np * Np / 3.0 / (best * 1e-3) / 1e12;
+            printf("N=%5d %-34s %8.3f ms  %6.2f TFLOP/s  info=%d  max|L - L_ref|=%.2e\n", Np, label, best, tf, inf, md);
+        };
+        run(1, nullptr, "one-level (nbo=1)", true);
+        for (int nbo : {2, 4, 8}) {
+            char lab[96];
+            snprintf(lab, sizeof lab, "two-level nbo=%d", nbo);
+            run(nbo, nullptr, lab, false);
+        }
+        for (int f : {0, 2, 4, 8})
+            for (int nbo : {2, 4, 8}) {
+                PotrfAux aux;
+                potrf_aux_create(&aux, f);
+                char lab[96];
+                snprintf(lab, sizeof lab, "look-ahead nbo=%d free/xcd=%d", nbo, f);
+                run(nbo, &aux, lab, false);
+                potrf_aux_destroy(&aux);
+            }
+        hipFree(A0); hipFree(A); hipFree(Lref); hipFree(Linv); hipFree(red);
+    }
+    return 0;
+}
