@@ -21,6 +21,8 @@ def fixtures():
 
 @pytest.fixture(scope="session")
 def oracle():
+    # the oracle's OpenMP loops stop scaling (and on a 256-thread host slow down badly) past ~64 threads
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 64)))
     from oracle import oracle_py
     oracle_py.build()
     return oracle_py

@@ -23,19 +23,27 @@ def test_host_classes():
 
 
 def test_bayesian_optimization_1d_demo():
-    """BASELINE config C1: 20 iterations; true optimum x = 0.852733, f = 2.273928.  EI with the reference's
-    zero-mean GP and MAP hyper-parameters from a handful of points often still sits in the local optimum x = 0.378
-    (f = 1.555) after 20 iterations (40 iterations reach the global one for 7 of 8 seeds: demos/test_host.cpp), so the
-    20-iteration config is checked over eight seeds."""
-    reached = 0
-    for seed in range(1, 9):
-        out = run("bayesian_optimization_1d", 1, 20, seed)
-        m = re.search(r"maximizer ([-\d.e]+) maximum ([-\d.e]+)", out)
-        assert m, out
-        assert float(m.group(2)) > 0.99
-        if abs(float(m.group(1)) - 0.852733) < 2e-2 and abs(float(m.group(2)) - 2.273928) < 2e-2:
-            reached += 1
-    assert reached >= 2, reached
+    """BASELINE config C1: 20 iterations; true optimum x = 0.852733, f = 2.273928.  With the reference's
+    default maximiser branch (DIRECT -> L-BFGS, host/direct.cpp) and DIRECT(300) as the global phase of the GP-MAP fit,
+    6 of 8 seeds reach the global optimum in 20 iterations and 5 of 8 within the reference demo's 15
+    (profiles/r02_kat_1d.log; the parallel multi-start branch with its random starts: 3 of 8).  The misses sit in the local
+    optimum x = 0.378 (f = 1.555): EI with a zero-mean GP and MAP hyper-parameters from a handful of points is
+    over-confident there -- a property of the model, the reference's too."""
+    def scan(iters, strategy):
+        reached = 0
+        for seed in range(1, 9):
+            p = subprocess.run([os.path.join(BIN, "bayesian_optimization_1d"), "1", str(iters), str(seed)], capture_output=True,
+                               text=True, timeout=600, env=dict(os.environ, SLS_GLOBAL_SEARCH=strategy))
+            assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+            m = re.search(r"maximizer ([-\d.e]+) maximum ([-\d.e]+)", p.stdout)
+            assert m, p.stdout
+            assert float(m.group(2)) > 0.99                      # never below the boundary value f(0) = 1
+            if abs(float(m.group(1)) - 0.852733) < 2e-2 and abs(float(m.group(2)) - 2.273928) < 2e-2:
+                reached += 1
+        return reached
+    assert scan(20, "direct") >= 6
+    assert scan(15, "direct") >= 4
+    assert scan(20, "multistart") >= 2
 
 
 def test_sequential_line_search_nd_demo():

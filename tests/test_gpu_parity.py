@@ -5,7 +5,7 @@ Tolerance: BASELINE.json's north_star asks for 1e-6 relative in fp64; the assert
 import numpy as np
 import pytest
 
-from util import relerr, sls, synth_candidates, synth_problem
+from util import assert_starts_agree, relerr, sls, synth_candidates, synth_problem
 
 pytestmark = pytest.mark.gpu
 
@@ -191,11 +191,11 @@ def test_multistart_maximizer_matches_oracle(ctx, oracle, kernel, acq, path):
     starts = synth_candidates(oracle, D, S)
     ref = oracle.Regressor(X, y, theta, b, kernel=kernel)
     gp = sls().GP(ctx, X, y, theta, b, kernel)
-    ro = ref.acq_maximize(starts, n_local, acq, 2.0)
+    ro = ref.acq_maximize(starts, n_local, acq, 2.0, diag=True)
     rg = gp.acq_maximize(starts, n_local, acq, 2.0)
-    # every start follows the same trajectory (same algorithm, fp64 rounding apart)
-    agree = np.isclose(rg["y_stars"], ro["y_stars"], rtol=1e-6, atol=1e-12)
-    assert agree.mean() > 0.9, f"only {agree.mean():.2%} of the starts agree"
+    # every start follows the same trajectory (same algorithm, fp64 rounding apart); the rare exception is a start whose
+    # Armijo test sat at rounding level of its threshold
+    assert_starts_agree(rg, ro)
     # many starts converge to the same maximiser, so the winning INDEX is decided by the last bits; what must
     # agree is the chosen maximiser and its value (north_star: within 1e-6 relative), and the GPU's winner must
     # be one of the oracle's tied winners
@@ -244,10 +244,9 @@ def test_active_set_compaction_is_bit_identical(ctx, oracle, kernel, D, N, S, n_
     if not pair:
         assert sa["evals_issued"] < su["evals_issued"]      # the corner starts retire early
         # same end points as the oracle's all-starts-every-round loop
-        ro = oracle.Regressor(X, y, theta, b, kernel=kernel).acq_maximize(starts, n_local) if N <= 300 else None
+        ro = oracle.Regressor(X, y, theta, b, kernel=kernel).acq_maximize(starts, n_local, diag=True) if N <= 300 else None
         if ro is not None:
-            agree = np.isclose(a[0], ro["y_stars"], rtol=1e-6, atol=1e-12)
-            assert agree.mean() > 0.9
+            assert_starts_agree(dict(y_stars=a[0]), ro)
             close(a[2], ro["value"], rtol=RTOL)
     gp.close()
     if g2 is not None:
@@ -638,10 +637,10 @@ def test_wave_path_matches_tiled_path_and_oracle(ctx, oracle, kernel, D, N, S, m
         rw = gp.acq_maximize(starts, 15, acq, 1.5)
         monkeypatch.setenv("SLS_WAVE_PATH", "0")
         rt = gp.acq_maximize(starts, 15, acq, 1.5)
-        ro = oracle.Regressor(X, y, theta, b, kernel=kernel).acq_maximize(starts, 15, acq, 1.5)
+        ro = oracle.Regressor(X, y, theta, b, kernel=kernel).acq_maximize(starts, 15, acq, 1.5, diag=True)
+        assert_starts_agree(rw, ro, min_frac=0.9)
+        assert_starts_agree(rt, ro, min_frac=0.9)
         for other in (rt, ro):
-            agree = np.isclose(rw["y_stars"], other["y_stars"], rtol=1e-6, atol=1e-12)
-            assert agree.mean() >= 0.9, agree.mean()
             close(rw["value"], other["value"], rtol=RTOL)
             close(rw["x"], other["x"], rtol=RTOL, atol=1e-7)
         assert np.all((rw["x_stars"] >= 0) & (rw["x_stars"] <= 1))

@@ -8,6 +8,8 @@ algorithm because the two implementations sum in a different order -- not a disa
 
 usage: python tools/diverging_starts.py [D N S n_local]     (GPU box; writes gpurun_out/diverging_starts.json)"""
 import importlib
+import os as _os
+_os.environ.setdefault("OMP_NUM_THREADS", "64")   # the oracle stops scaling past ~64 threads
 import json
 import os
 import sys
