@@ -12,7 +12,7 @@
 using namespace slsk;
 
 #ifndef SLS_POTRF_LOOKAHEAD_DEFAULT
-#define SLS_POTRF_LOOKAHEAD_DEFAULT 0
+#define SLS_POTRF_LOOKAHEAD_DEFAULT 4
 #endif
 
 namespace slsk {
@@ -61,14 +61,31 @@ void sls_ctx::prof_collect() {
     }
 }
 
-slsk::PotrfAux* sls_ctx::potrf_lookahead() {
-    // SLS_POTRF_LOOKAHEAD = f > 0: side stream whose CU mask leaves f CUs per XCD free; 0: single-stream schedule
+slsk::PotrfAux* sls_ctx::potrf_lookahead(int Np) {
+    // SLS_POTRF_LOOKAHEAD = f > 0: side stream whose CU mask leaves f CUs per XCD free; 0: single-stream schedule.
+    // Only the two-level schedule (N >= 8192 by default) has an outer update to overlap.
     const char* e = getenv("SLS_POTRF_LOOKAHEAD");
     const int f = e ? atoi(e) : SLS_POTRF_LOOKAHEAD_DEFAULT;
-    if (f <= 0) return nullptr;
+    if (f <= 0 || slsk::potrf_default_nbo(Np) <= 1) return nullptr;
     if (!potrf_aux.side) slsk::potrf_aux_create(&potrf_aux, f);
     return &potrf_aux;
 }
+
+int* sls_ctx::potrf_sync(int Np) {
+    // sync words of the single-launch factorisation live behind the info words; nullptr (multi-launch schedule) if they
+    // would not fit (N > 60 000)
+    return 32 + 2 * (Np / 128) <= 960 ? d_info + 64 : nullptr;
+}
+
+namespace slsk {
+void check_potrf_abort(int abort_flag) {
+    if (abort_flag != 0) {
+        set_error("Cholesky factorisation aborted: a device-side wait of the persistent kernel expired (SLS_POTRF_MODE=0 "
+                  "selects the multi-launch schedule)");
+        throw HipFail{SLS_ERR_HIP};
+    }
+}
+}  // namespace slsk
 
 #define SLS_TRY try {
 #define SLS_CATCH                                   \
@@ -99,7 +116,7 @@ extern "C" int sls_ctx_create(int device, sls_ctx** out) {
     c->device = device;
     SLS_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
-    SLS_HIP(hipMalloc((void**)&c->d_info, 256));   // ints 0..15: potrf info / timing; ints 32..39: acq_gemm generation gates
+    SLS_HIP(hipMalloc((void**)&c->d_info, 4096));   // ints 0..15: potrf info ([0] pivot, [1] abort); 32..47: acq_gemm generation gates; 64..1023: sync words of the persistent potrf
     *out = c.release();
     SLS_CATCH
 }
@@ -231,7 +248,7 @@ static void gp_fit_device(sls_gp* g) {
     launch_fill(c->stream, g->Linv.p, (long)Np * Np, 0.0);
     {
         ProfScope ps(c, "potrf");
-        launch_potrf(c->stream, g->L.p, Np, g->Linv.p, c->d_info, 0, c->potrf_lookahead());
+        launch_potrf(c->stream, g->L.p, Np, g->Linv.p, c->d_info, 0, c->potrf_lookahead(Np), c->potrf_sync(Np));
     }
     {
         ProfScope ps(c, "trtri");
@@ -255,10 +272,11 @@ static void gp_fetch_summary(sls_gp* g) {
     int info[16] = {0};
     double sc[2];
     long idx = 0;
-    SLS_HIP(hipMemcpyAsync(info, c->d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    SLS_HIP(hipMemcpyAsync(info, c->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     SLS_HIP(hipMemcpyAsync(sc, g->scal.p, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     SLS_HIP(hipMemcpyAsync(&idx, g->d_idx, sizeof(long), hipMemcpyDeviceToHost, c->stream));
     sync(c);
+    check_potrf_abort(info[1]);
     if (info[0] != 0) {
         set_error("Cholesky failed: K_y is not positive definite (pivot %d)", info[0] - 1);
         throw HipFail{SLS_ERR_NOT_SPD};
@@ -897,12 +915,14 @@ extern "C" int sls_potrf(sls_ctx* c, double* A, int N) {
     upload_padded_spd(c, Ad, A, N, Np);
     Li.ensure((size_t)Np * Np);
     SLS_HIP(hipMemsetAsync(c->d_info, 0, 64, c->stream));
-    launch_potrf(c->stream, Ad.p, Np, Li.p, c->d_info, 0, c->potrf_lookahead());
+    launch_potrf(c->stream, Ad.p, Np, Li.p, c->d_info, 0, c->potrf_lookahead(Np), c->potrf_sync(Np));
     launch_zero_upper(c->stream, Ad.p, Np);
-    int info = 0;
-    SLS_HIP(hipMemcpyAsync(&info, c->d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    int info2[2] = {0, 0};
+    SLS_HIP(hipMemcpyAsync(info2, c->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     d2h_matrix(c, A, Ad.p, N, Np);
     sync(c);
+    check_potrf_abort(info2[1]);
+    const int info = info2[0];
     if (info != 0) {
         set_error("sls_potrf: matrix is not positive definite (pivot %d)", info - 1);
         return SLS_ERR_NOT_SPD;

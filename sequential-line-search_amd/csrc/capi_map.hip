@@ -82,14 +82,16 @@ static void nll_factor(sls_nll* h, const double* theta, double b) {
     launch_gram_sym(c->stream, h->XT.p, Np, h->Dp, h->nx.p, Np, N, ks, b, h->L.p, true);
     SLS_HIP(hipMemsetAsync(c->d_info, 0, 64, c->stream));
     launch_fill(c->stream, h->Linv.p, (long)Np * Np, 0.0);
-    launch_potrf(c->stream, h->L.p, Np, h->Linv.p, c->d_info, 0, c->potrf_lookahead());
+    launch_potrf(c->stream, h->L.p, Np, h->Linv.p, c->d_info, 0, c->potrf_lookahead(Np), c->potrf_sync(Np));
     launch_trtri(c->stream, h->L.p, Np, h->Linv.p, h->Kinv.p);
     launch_lauum(c->stream, h->Linv.p, Np, h->Kinv.p);
     launch_logdet(c->stream, h->L.p, Np, N, h->scal.p + 4);
-    int info = 0;
-    SLS_HIP(hipMemcpyAsync(&info, c->d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    int info2[2] = {0, 0};
+    SLS_HIP(hipMemcpyAsync(info2, c->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     SLS_HIP(hipMemcpyAsync(&h->logdet, h->scal.p + 4, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     SLS_HIP(hipStreamSynchronize(c->stream));
+    check_potrf_abort(info2[1]);
+    const int info = info2[0];
     if (info != 0) {
         set_error("sls_nll_eval: K_y is not positive definite (pivot %d)", info - 1);
         throw HipFail{SLS_ERR_NOT_SPD};

@@ -15,6 +15,7 @@
 namespace slsk {
 
 void set_error(const char* fmt, ...);
+void check_potrf_abort(int abort_flag);   // throws HipFail{SLS_ERR_HIP} if the persistent factorisation gave up
 
 struct HipFail {
     int code;
@@ -84,7 +85,8 @@ struct sls_ctx {
     int* d_info = nullptr;  // device int[4]: potrf info etc.
     // look-ahead schedule of the Cholesky factorisation: CU-masked side stream + events, created on first use
     slsk::PotrfAux potrf_aux;
-    slsk::PotrfAux* potrf_lookahead();   // nullptr unless SLS_POTRF_LOOKAHEAD selects the two-stream schedule
+    slsk::PotrfAux* potrf_lookahead(int Np);   // nullptr unless SLS_POTRF_LOOKAHEAD selects the two-stream schedule
+    int* potrf_sync(int Np);             // device sync words for launch_potrf_persistent
 
     hipEvent_t get_event();
     void prof_begin(const char* name, hipEvent_t& e0);

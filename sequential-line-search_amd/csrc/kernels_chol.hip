@@ -15,6 +15,10 @@
 #include "gemm_f64.hpp"
 #include "kernels.hpp"
 
+#ifndef SLS_POTRF_MODE_DEFAULT
+#define SLS_POTRF_MODE_DEFAULT 0
+#endif
+
 namespace slsk {
 
 constexpr int NB = 128;
@@ -139,10 +143,12 @@ void launch_gemm_plain(hipStream_t s, const double* A, long lda, bool a_kc, cons
     else launch_tri_gemm<true, false>(s, g, 1);
 }
 
+// Cholesky factor + inverse of ONE 128 x 128 diagonal block by the calling workgroup (256 threads, `smem` = DIAG_LDS_BYTES of
+// LDS): A (lower triangle read) -> L in place (FACTOR) and T = L^-1 into Tout.  Shared by the one-block launch
+// (chol_diag_kernel) and the single-launch persistent factorisation (potrf_persistent_kernel).
 template <bool FACTOR>
-__global__ __launch_bounds__(256) void chol_diag_kernel(double* __restrict__ A, long lda, double* __restrict__ Tout, long ldt,
-                                                        int* __restrict__ info, int global_off) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void diag_block(double* __restrict__ A, long lda, double* __restrict__ Tout, long ldt,
+                                           int* __restrict__ info, int global_off, char* smem) {
     double* As = reinterpret_cast<double*>(smem);   // [i + j*DL]
     double* Ts = As + 128 * DL;                     // [tile][i + 16 j]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR): the role branches below become scalar branches
@@ -209,9 +215,315 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double* __restrict__ A, 
     DIAG_STAMP(6);
 }
 
+template <bool FACTOR>
+__global__ __launch_bounds__(256) void chol_diag_kernel(double* __restrict__ A, long lda, double* __restrict__ Tout, long ldt,
+                                                        int* __restrict__ info, int global_off) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    diag_block<FACTOR>(A, lda, Tout, ldt, info, global_off, smem);
+}
+
 static void diag_attr() {
     ensure_dyn_lds((const void*)chol_diag_kernel<true>, DIAG_LDS_BYTES);
     ensure_dyn_lds((const void*)chol_diag_kernel<false>, DIAG_LDS_BYTES);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Single-launch factorisation: ONE persistent kernel runs all N/128 block steps.
+//
+// The multi-launch schedule below pays a dependent-launch gap for every kernel of every block step -- measured on MI355X:
+// 87 us per step at N = 2048 where the three kernels of a step hold ~40 us of work (tools/probes/potrf_bench) -- and the
+// diagonal block of step j+1 cannot start before the whole trailing update of step j has drained.  Here gridDim.x = number
+// of CUs workgroups (one per CU: every workgroup owns a whole CU's LDS so that any of them could factor a diagonal block)
+// stay resident for the whole factorisation and synchronise through device-scope counters:
+//   workgroup 0        factors the diagonal blocks.  It starts block j+1 as soon as the ONE trailing tile (j+1, j+1) has
+//                      been updated by step j (flag), i.e. concurrently with the rest of that update: the serial chain per
+//                      step is  panel tile -> first update tile -> diagonal block  instead of  3 launches + full update;
+//   workgroups 1..G-1  panel tiles L_ij = A_ij T_jj^T (after the flag "block j factored"), grid barrier, trailing tiles
+//                      A_ik -= L_ij L_kj^T dealt round-robin (tile (j+1, j+1) first), grid barrier.
+// Barriers and flags are release / acquire operations at agent scope (the 8 XCDs have private L2s); every wait is a bounded
+// spin (0.2 s) that raises an abort flag, so an unexpected residency pattern cannot hang the device -- the launcher's
+// caller sees SLS_ERR_HIP instead.  Arithmetic per tile is identical to the multi-launch schedule (same k order): the two
+// produce the same bits.
+// ---------------------------------------------------------------------------------------------------------
+struct PersistArgs {
+    double* A;
+    long ld;
+    int nb;
+    double* Linv;
+    int* info;        // [0] first non-positive pivot + 1, [1] abort
+    // [0] global barrier counter (counts XCD leaders), [1] set-up counter, [8 + x] workgroups resident on XCD x,
+    // [16 + x] arrivals on XCD x, [24 + x] "go" epoch of XCD x, [PK_FLAGS + j] tile (j, j) ready for factoring,
+    // [PK_FLAGS + nb + j] block j factored
+    int* sync;
+    int nbo;          // 128-columns per outer block of the two-level update (1: every step updates the whole trailing matrix)
+    long long timeout;
+    long long* trace;   // optional (probes): 16 wall-clock stamps per step, [0..7] workgroup 0, [8..15] workgroup 1
+};
+constexpr int PK_FLAGS = 32;
+#define PK_STAMP(slot) do { if (a.trace && threadIdx.x == 0) a.trace[16 * j + (slot)] = wall_clock64(); } while (0)
+
+// one lane: spin (RELAXED polls -- an acquire load at agent scope would invalidate the XCD's L2 on every poll) until
+// *p >= target; false = aborted / timed out
+__device__ __forceinline__ bool pk_spin(int* p, int target, int* abort_flag, long long timeout) {
+    const long long t0 = wall_clock64();
+    int n = 0;
+    while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        if ((++n & 63) == 0) {
+            if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+            if (wall_clock64() - t0 > timeout) {
+                __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return true;
+}
+// this CU's vector L1 only (the L2 is handled once per XCD by the barrier leader)
+__device__ __forceinline__ void pk_inv_l1() { asm volatile("buffer_inv sc0" ::: "memory"); }
+
+// Workgroup-level wait on a flag raised by pk_signal.  The diagonal-block code owns every byte of the 160 KB of LDS, so
+// there is no shared word for a broadcast: lane 0 of EVERY wave spins and hands its verdict to its own wave; the barrier
+// then orders the workgroup.  (A wave that gives up leaves the kernel; the others run into bounded waits of their own.)
+__device__ __forceinline__ bool pk_wait_flag(int* p, const PersistArgs& a) {
+    int ok = 1;
+    if ((threadIdx.x & 63) == 0) {
+        ok = pk_spin(p, 1, a.info + 1, a.timeout) ? 1 : 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    ok = __builtin_amdgcn_readfirstlane(ok);
+    __syncthreads();
+    return ok != 0;
+}
+// wait until the counter *p reaches `target` (the chain watching the workers' barrier counter)
+__device__ __forceinline__ bool pk_wait_count(int* p, int target, const PersistArgs& a) {
+    int ok = 1;
+    if ((threadIdx.x & 63) == 0) {
+        ok = pk_spin(p, target, a.info + 1, a.timeout) ? 1 : 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    ok = __builtin_amdgcn_readfirstlane(ok);
+    __syncthreads();
+    return ok != 0;
+}
+// publish this workgroup's stores (agent-scope release: the XCD's L2 is written back), then raise the flag
+__device__ __forceinline__ void pk_signal(int* p) {
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(p, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Grid barrier, hierarchical.  The 8 XCDs have private L2s, so an agent-scope release / acquire is an L2 write-back /
+// invalidate of the WHOLE XCD L2: with one release + acquire per WORKGROUP a barrier cost ~100 us (32 workgroups per XCD
+// each walking the same L2).  Here the workgroups of an XCD first meet on an XCD-local counter (their stores are already in
+// the shared L2 after the workgroup-scope barrier); the last one to arrive -- the XCD's leader for this barrier -- performs
+// the single release, joins the global barrier of leaders, performs the single acquire, and lets its XCD go.  The others only
+// drop their CU's L1.
+struct PkBarrier {
+    int xcc, xcd_size, n_xcd, epoch;
+};
+__device__ __forceinline__ bool pk_barrier(const PersistArgs& a, PkBarrier& bs, int* also_flag = nullptr) {
+    __syncthreads();
+    bs.epoch += 1;
+    int ok = 1;
+    if ((threadIdx.x & 63) == 0) {
+        int* arrive = a.sync + 16 + bs.xcc;
+        int* go = a.sync + 24 + bs.xcc;
+        if (threadIdx.x == 0) {
+            const int old = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old + 1 == bs.xcd_size * bs.epoch) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __hip_atomic_fetch_add(a.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = pk_spin(a.sync, bs.n_xcd * bs.epoch, a.info + 1, a.timeout) ? 1 : 0;
+                // a flag of the chain workgroup the next phase depends on: waited for HERE, by the 8 leaders, so that the one
+                // acquire below covers it and no worker needs an acquire (= an L2 invalidate) of its own
+                if (ok && also_flag) ok = pk_spin(also_flag, 1, a.info + 1, a.timeout) ? 1 : 0;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __hip_atomic_store(go, bs.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        ok = (ok && pk_spin(go, bs.epoch, a.info + 1, a.timeout)) ? 1 : 0;
+        pk_inv_l1();
+    }
+    ok = __builtin_amdgcn_readfirstlane(ok);
+    __syncthreads();
+    return ok != 0;
+}
+// who shares my XCD?  (flat, once per launch: atomics only)
+__device__ __forceinline__ bool pk_setup(const PersistArgs& a, PkBarrier& bs, bool is_worker) {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    bs.xcc = (int)(x & 7);
+    bs.epoch = 0;
+    int ok = 1, size = 0, nx = 0;
+    if ((threadIdx.x & 63) == 0) {
+        if (threadIdx.x == 0 && is_worker) {      // the chain workgroup takes no part in the workers' barriers
+            __hip_atomic_fetch_add(a.sync + 8 + bs.xcc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(a.sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        ok = pk_spin(a.sync + 1, (int)gridDim.x - 1, a.info + 1, a.timeout) ? 1 : 0;
+        for (int q = 0; q < 8; ++q) {
+            const int c = __hip_atomic_load(a.sync + 8 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            nx += c > 0 ? 1 : 0;
+            if (q == bs.xcc) size = c;
+        }
+    }
+    bs.xcd_size = __builtin_amdgcn_readfirstlane(size);
+    bs.n_xcd = __builtin_amdgcn_readfirstlane(nx);
+    ok = __builtin_amdgcn_readfirstlane(ok);
+    __syncthreads();
+    return ok != 0;
+}
+
+// 128 x 128 tile helpers on top of gemm_tile (operands in global memory / L2)
+__device__ __forceinline__ void pk_store_tile(double* C, long ld, const Acc& acc) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) C[(long)acc_m(i) + (long)acc_n(jj, r) * ld] = acc.v[i][jj][r];
+}
+__device__ __forceinline__ void pk_sub_tile(double* C, long ld, const Acc& acc) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double* c = C + (long)acc_m(i) + (long)acc_n(jj, r) * ld;
+                *c = *c - acc.v[i][jj][r];
+            }
+}
+// the workgroup's own global stores -> its own later loads: stores complete (barrier), this CU's L1 dropped
+__device__ __forceinline__ void pk_self_fence() {
+    __syncthreads();
+    pk_inv_l1();
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void potrf_persistent_kernel(PersistArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* lds = reinterpret_cast<double*>(smem);
+    const int G = gridDim.x, b = blockIdx.x, nb = a.nb, W = G - 1, w = b - 1, nbo = a.nbo;
+    const long ld = a.ld;
+    int* factored = a.sync + PK_FLAGS;            // [j]: L_jj, T_jj stored
+    int* sub = a.sync + PK_FLAGS + nb;            // [j]: L_{j+1,j} stored
+    PkBarrier bs;
+    if (!pk_setup(a, bs, b != 0)) return;
+    if (b == 0) {
+        // ---- the chain: diagonal block j, then ITS OWN sub-diagonal tile and next diagonal tile, no grid barrier ----
+        diag_block<true>(a.A, ld, a.Linv, ld, a.info, 0, smem);
+        pk_signal(factored);
+        for (int j = 0; j + 1 < nb; ++j) {
+            double* Ajj = a.A + (long)j * NB * (ld + 1);
+            double* Tjj = a.Linv + (long)j * NB * (ld + 1);
+            double* Asub = Ajj + NB;                           // tile (j+1, j)
+            double* Anext = Ajj + (long)NB * (ld + 1);         // tile (j+1, j+1)
+            PK_STAMP(0);
+            // tiles (j+1, j) and (j+1, j+1) carry the updates of steps < j once the workers have left step j-1
+            if (j > 0 && !pk_wait_count(a.sync, bs.n_xcd * (2 * j + 1), a)) return;   // workers arrived at B2 of step j-1
+            PK_STAMP(1);
+            pk_self_fence();                                   // T_jj, written by this workgroup a moment ago
+            Acc acc;
+            acc.zero();
+            gemm_tile<false, false>(acc, Asub, ld, Tjj, ld, 0, NB, lds);          // L_{j+1,j} = A_{j+1,j} T_jj^T
+            pk_store_tile(Asub, ld, acc);
+            pk_signal(sub + j);
+            PK_STAMP(2);
+            pk_inv_l1();
+            // A_{j+1,j+1} -= L_{j+1,k} L_{j+1,k}^T: k = j inside an outer block, all the block's columns at its last step
+            const int J0 = (j / nbo) * nbo;
+            const int kc0 = (j + 1 == min(J0 + nbo, nb)) ? J0 : j;
+            const double* Lr = a.A + (long)(j + 1) * NB + (long)kc0 * NB * ld;
+            acc.zero();
+            gemm_tile<false, false>(acc, Lr, ld, Lr, ld, 0, (j + 1 - kc0) * NB, lds);
+            pk_sub_tile(Anext, ld, acc);
+            pk_self_fence();
+            PK_STAMP(3);
+            diag_block<true>(Anext, ld, Tjj + (long)NB * (ld + 1), ld, a.info, (j + 1) * NB, smem);
+            pk_signal(factored + j + 1);
+            PK_STAMP(4);
+        }
+        return;
+    }
+    // ---- the workers: everything else.  Barrier epochs: B0 = 1, step j: B1 = 2j + 2, B2 = 2j + 3.  The chain's flags are
+    //      folded into the barriers that precede their first use (B0 / B2: block factored; B1: sub-diagonal tile stored) ----
+    if (!pk_barrier(a, bs, factored)) return;
+    for (int j = 0; j + 1 < nb; ++j) {
+        const int rem = nb - 1 - j;                            // block rows / columns below and right of block j
+        double* Ajj = a.A + (long)j * NB * (ld + 1);
+        double* Tjj = a.Linv + (long)j * NB * (ld + 1);
+        double* Apan = Ajj + NB;                               // block column j below the diagonal block
+        if (b == 1) PK_STAMP(8);
+        // panel tiles L_ij = A_ij T_jj^T for i >= j + 2 (tile t = 0, row j + 1, belongs to the chain), in place
+        for (int t = 1 + w; t < rem; t += W) {
+            double* Aij = Apan + (long)t * NB;
+            Acc acc;
+            acc.zero();
+            gemm_tile<false, false>(acc, Aij, ld, Tjj, ld, 0, NB, lds);
+            pk_store_tile(Aij, ld, acc);
+        }
+        if (b == 1) PK_STAMP(10);
+        if (!pk_barrier(a, bs, sub + j)) return;
+        if (b == 1) PK_STAMP(11);
+        // Trailing update, lower tiles in column-major order; tile t = 0 = (j+1, j+1) belongs to the chain.  Two-level: inside
+        // an outer block [J0, J1) step j only updates the block's own columns (K = 128); the block's LAST step updates
+        // everything beyond with all its columns at once (K = 128 (J1 - J0)): nbo x fewer read-modify-write sweeps over the
+        // trailing matrix.  nbo = 1: every step is a last step.
+        const int J0 = (j / nbo) * nbo, J1 = min(J0 + nbo, nb);
+        const bool outer = (j + 1 == J1);
+        const int kc0 = outer ? J0 : j;
+        const int K = (j + 1 - kc0) * NB;
+        const int ncols = outer ? rem : J1 - (j + 1);
+        const int ntile = ncols * rem - ncols * (ncols - 1) / 2;
+        const double* Lrow = a.A + (long)(j + 1) * NB + (long)kc0 * NB * ld;   // L[j+1.., kc0 .. j]
+        double* Atr = Ajj + (long)NB * (ld + 1);
+        for (int t = 1 + w; t < ntile; t += W) {
+            int tk = 0, off = 0;
+            while (t >= off + rem - tk) { off += rem - tk; ++tk; }
+            const int ti = tk + (t - off);
+            Acc acc;
+            acc.zero();
+            gemm_tile<false, false>(acc, Lrow + (long)ti * NB, ld, Lrow + (long)tk * NB, ld, 0, K, lds);
+            pk_sub_tile(Atr + (long)ti * NB + (long)tk * NB * ld, ld, acc);
+        }
+        if (b == 1) PK_STAMP(13);
+        if (!pk_barrier(a, bs, factored + j + 1)) return;
+        if (b == 1) PK_STAMP(14);
+    }
+}
+
+int potrf_persistent_nbo(int Np) {
+    const char* e = getenv("SLS_POTRF_PNBO");
+    if (e && atoi(e) >= 1) return atoi(e);
+    return Np >= 8192 ? 8 : 1;
+}
+
+int potrf_default_mode() {   // read per call: tests and A/B runs switch within one process
+    const char* e = getenv("SLS_POTRF_MODE");
+    return e ? atoi(e) : SLS_POTRF_MODE_DEFAULT;
+}
+
+// sync: >= 32 + 2 (Np / 128) ints of device scratch
+void launch_potrf_persistent(hipStream_t s, double* A, int Np, double* Linv, int* info, int* sync, long long* trace) {
+    ensure_dyn_lds((const void*)potrf_persistent_kernel, DIAG_LDS_BYTES);
+    const int nb = Np / NB;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0, v = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+        n_cu = v > 0 ? v : 64;
+    }
+    const int work = std::max(nb - 1, (nb - 1) * nb / 2);
+    const int G = std::max(2, std::min(n_cu, 1 + work));
+    (void)hipMemsetAsync(sync, 0, (size_t)(PK_FLAGS + 2 * nb) * sizeof(int), s);
+    PersistArgs a;
+    a.A = A; a.ld = Np; a.nb = nb; a.Linv = Linv; a.info = info; a.sync = sync;
+    a.timeout = 20000000LL;   // 0.2 s of the 100 MHz wall clock
+    a.trace = trace;
+    a.nbo = potrf_persistent_nbo(Np);
+    hipLaunchKernelGGL(potrf_persistent_kernel, dim3(G), dim3(256), DIAG_LDS_BYTES, s, a);
 }
 
 // Two-level right-looking factorisation.  Outer blocks of `nbo` 128-columns: inside an outer block every 128-step is
@@ -248,19 +560,19 @@ void potrf_aux_destroy(PotrfAux* aux) {
 }
 
 int potrf_default_nbo(int Np) {
-    static int env = -2;
-    if (env == -2) {
-        const char* e = getenv("SLS_POTRF_NBO");
-        env = e ? atoi(e) : -1;
-    }
-    if (env >= 1) return env;
-    return Np >= 2048 ? 4 : 1;
+    const char* e = getenv("SLS_POTRF_NBO");
+    if (e && atoi(e) >= 1) return atoi(e);
+    return Np >= 8192 ? 4 : 1;   // measured (tools/probes/potrf_bench): two-level pays from N = 8192 (10.4 -> 9.5 ms), not below
 }
 
-void launch_potrf(hipStream_t s, double* A, int Np, double* Linv, int* info, int nbo, PotrfAux* aux) {
+void launch_potrf(hipStream_t s, double* A, int Np, double* Linv, int* info, int nbo, PotrfAux* aux, int* persist_sync) {
     diag_attr();
     const int nb = Np / NB;
     const long ld = Np;
+    if (persist_sync && nb >= 3 && potrf_default_mode() == 1) {
+        launch_potrf_persistent(s, A, Np, Linv, info, persist_sync);
+        return;
+    }
     if (nbo < 1) nbo = potrf_default_nbo(Np);
     const bool look = aux && aux->side && nbo > 1 && nb > 2 * nbo;
     auto syrk = [&](hipStream_t st, int kcol0, int ktiles, int row0, int col0, int ncols) {

@@ -65,6 +65,39 @@ def test_cholesky_solve_inverse(ctx, oracle, N):
     assert np.array_equal(Ai, Ai.T)
 
 
+@pytest.mark.parametrize("N", [384, 1000, 2304])
+def test_potrf_schedules_agree(N, monkeypatch):
+    """The Cholesky schedules (kernels_chol.hip): multi-launch one-level (default below N = 8192), two-level with the outer
+    update on a CU-masked side stream (default from N = 8192; forced here by SLS_POTRF_NBO), and the single-launch persistent
+    kernel (SLS_POTRF_MODE=1, with and without its two-level update).  One-level multi-launch and one-level persistent run the
+    same arithmetic per tile: identical bits.  The two-level forms sum the outer update in one k loop: agreement to rounding.
+    Every variant must also reject an indefinite matrix (the persistent kernel reports through the same info word)."""
+    rng = np.random.default_rng(N)
+    B = rng.normal(size=(N, N))
+    A = B @ B.T / N + np.eye(N)
+    res = {}
+    for name, env in (("multi", {"SLS_POTRF_MODE": "0", "SLS_POTRF_NBO": "1"}),
+                      ("multi2", {"SLS_POTRF_MODE": "0", "SLS_POTRF_NBO": "2", "SLS_POTRF_LOOKAHEAD": "0"}),
+                      ("multi2look", {"SLS_POTRF_MODE": "0", "SLS_POTRF_NBO": "2", "SLS_POTRF_LOOKAHEAD": "4"}),
+                      ("persist1", {"SLS_POTRF_MODE": "1", "SLS_POTRF_PNBO": "1"}),
+                      ("persist4", {"SLS_POTRF_MODE": "1", "SLS_POTRF_PNBO": "4"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = sls().Context(0)          # a fresh context: the look-ahead side stream is created per context
+        res[name] = c.potrf(A)
+        bad = A.copy(); bad[N - 5, N - 5] = -1.0
+        with pytest.raises(sls().SlsError):
+            c.potrf(bad)
+        c.close()
+    L = np.linalg.cholesky(A)
+    for name, v in res.items():
+        close(v, L, rtol=1e-10, atol=1e-12)
+    assert np.array_equal(res["multi"], res["persist1"])
+    assert np.array_equal(res["multi2"], res["multi2look"])        # the side stream changes the schedule, not the arithmetic
+    close(res["persist4"], res["multi"], rtol=1e-12, atol=1e-13)
+    close(res["multi2"], res["multi"], rtol=1e-12, atol=1e-13)
+
+
 def test_potrf_rejects_indefinite(ctx):
     A = np.eye(200)
     A[150, 150] = -1.0

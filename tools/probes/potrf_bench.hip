@@ -38,14 +38,17 @@ __global__ __launch_bounds__(256, 2) void where_kernel(int* out) {
 
 int main(int argc, char** argv) {
     using namespace slsk;
+    setvbuf(stdout, nullptr, _IONBF, 0);
     std::vector<int> sizes;
     for (int i = 1; i < argc; ++i) sizes.push_back(atoi(argv[i]));
     if (sizes.empty()) sizes = {2048, 4096, 8192};
     hipStream_t s;
     hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
-    int* info; hipMalloc(&info, 4096);
+    int* info; hipMalloc(&info, 8192);
+    const bool quick = getenv("POTRF_BENCH_QUICK") != nullptr;
     // which CUs does a masked stream use?
     for (int f : {0, 2, 4, 8}) {
+        if (quick) break;
         PotrfAux aux;
         potrf_aux_create(&aux, f);
         int* d; hipMalloc(&d, 4096 * 4);
@@ -67,20 +70,21 @@ int main(int argc, char** argv) {
         hipMalloc(&A0, bytes); hipMalloc(&A, bytes); hipMalloc(&Lref, bytes); hipMalloc(&Linv, bytes); hipMalloc(&red, 1024 * 8);
         hipLaunchKernelGGL(fill_spd, dim3((unsigned)(((long)Np * Np + 255) / 256)), dim3(256), 0, s, A0, Np);
         hipMemsetAsync(Linv, 0, bytes, s);
-        auto run = [&](int nbo, PotrfAux* aux, const char* label, bool is_ref) {
+        auto run = [&](int nbo, PotrfAux* aux, const char* label, bool is_ref, bool persist = false) {
             float best = 1e30f;
             for (int rep = 0; rep < 4; ++rep) {
                 hipMemcpyAsync(A, A0, bytes, hipMemcpyDeviceToDevice, s);
                 hipMemsetAsync(info, 0, 64, s);
                 hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
                 hipEventRecord(e0, s);
-                launch_potrf(s, A, Np, Linv, info, nbo, aux);
+                launch_potrf(s, A, Np, Linv, info, nbo, aux, persist ? info + 64 : nullptr);
                 hipEventRecord(e1, s); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 if (rep > 0 && ms < best) best = ms;
                 hipEventDestroy(e0); hipEventDestroy(e1);
             }
-            int inf = 0; hipMemcpy(&inf, info, 4, hipMemcpyDeviceToHost);
+            int inf2[2] = {0, 0}; hipMemcpy(inf2, info, 8, hipMemcpyDeviceToHost);
+            const int inf = inf2[0] + 1000000 * inf2[1];
             double md = 0.0;
             if (is_ref) hipMemcpyAsync(Lref, A, bytes, hipMemcpyDeviceToDevice, s);
             else {
@@ -93,6 +97,26 @@ int main(int argc, char** argv) {
             printf("N=%5d %-34s %8.3f ms  %6.2f TFLOP/s  info=%d  max|L - L_ref|=%.2e\n", Np, label, best, tf, inf, md);
         };
         run(1, nullptr, "one-level (nbo=1)", true);
+        run(1, nullptr, "persistent single launch", false, true);
+        if (getenv("POTRF_BENCH_TRACE")) {
+            const int nb = Np / 128;
+            long long* tr; hipMalloc(&tr, (size_t)nb * 16 * 8); hipMemset(tr, 0, (size_t)nb * 16 * 8);
+            hipMemcpyAsync(A, A0, bytes, hipMemcpyDeviceToDevice, s);
+            hipMemsetAsync(info, 0, 64, s);
+            launch_potrf_persistent(s, A, Np, Linv, info, info + 64, tr);
+            hipStreamSynchronize(s);
+            std::vector<long long> h((size_t)nb * 16); hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost);
+            printf("trace N=%d (us, relative to the chain's step start): step | chain: workersDone gemm1+signal gemm2 diag+signal | worker 1: start - panelDone B1out - updDone B2out\n", Np);
+            for (int j = 0; j < nb - 1; ++j) {
+                const long long* g = h.data() + 16 * j; const double t0 = (double)g[0];
+                auto us = [&](long long v) { return v ? ((double)v - t0) / 100.0 : -1.0; };
+                if (j < 6 || j % 8 == 0 || j > nb - 4)
+                    printf("  %3d | %6.1f %6.1f %6.1f %6.1f %6.1f | %6.1f %6.1f %6.1f %6.1f %6.1f %6.1f %6.1f\n", j, us(g[1]), us(g[2]), us(g[3]), us(g[4]), -1.0,
+                           us(g[8]), us(g[9]), us(g[10]), us(g[11]), us(g[12]), us(g[13]), us(g[14]));
+            }
+            hipFree(tr);
+        }
+        if (quick) { hipFree(A0); hipFree(A); hipFree(Lref); hipFree(Linv); hipFree(red); continue; }
         for (int nbo : {2, 4, 8}) {
             char lab[96];
             snprintf(lab, sizeof lab, "two-level nbo=%d", nbo);
