@@ -200,6 +200,15 @@ class Regressor:
         idx = lib().slso_predict_maximum_point_from_data(self.h, _p(xb))
         return idx, xb
 
+    def best_index(self):
+        """Hoisted PredictMaximumPointFromData (arg max_i y_i - b alpha_i), O(1): for sizes where the as-written N x PredictMu
+        loop (O(N^3)) is out of reach."""
+        return int(lib().slso_regressor_best_index(self.h))
+
+    def mu_best(self):
+        lib().slso_regressor_mu_best.restype = C.c_double
+        return float(lib().slso_regressor_mu_best(self.h))
+
     def acq_value_as_written(self, x, acq=ACQ_EI, ucb_h=1.0):
         x = _f(x)
         return lib().slso_acq_value_as_written(self.h, _p(x), acq, C.c_double(ucb_h))

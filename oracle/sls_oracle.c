@@ -353,6 +353,10 @@ slso_regressor* slso_regressor_create(int reg_type, int kernel, const double* X,
     return r;
 }
 
+/* hoisted PredictMaximumPointFromData: index and mu(x_best) cached at creation (no O(N^3) loop) */
+int slso_regressor_best_index(const slso_regressor* r) { return r->best_index; }
+double slso_regressor_mu_best(const slso_regressor* r) { return r->mu_best; }
+
 void slso_regressor_free(slso_regressor* r) {
     if (!r) return;
     free(r->X); free(r->y); free(r->theta); free(r->K); free(r->Kinv); free(r->L); free(r->alpha); free(r->KinvC);

@@ -81,6 +81,8 @@ typedef struct slso_regressor {
 slso_regressor* slso_regressor_create(int reg_type, int kernel, const double* X, int D, int N, const double* y,
                                       const double* theta, double b);
 void slso_regressor_free(slso_regressor* r);
+int    slso_regressor_best_index(const slso_regressor* r);   /* hoisted arg max_i (y_i - b alpha_i): what regressor.cpp:29-43 returns */
+double slso_regressor_mu_best(const slso_regressor* r);
 
 /* as-written predictive quantities (O(N^2) .. O(D N^2) per call, like the reference) */
 double slso_predict_mu(const slso_regressor* r, const double* x);                        /* GPR :234-239 / PREF :293-297 */

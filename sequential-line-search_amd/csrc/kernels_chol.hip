@@ -10,6 +10,7 @@
 // Triangular inverse: recursive doubling over block pairs, X21 = -X22 (L21 X11), every level two batched GEMMs.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "chol_diag.hpp"
 #include "gemm_f64.hpp"
@@ -35,6 +36,8 @@ struct GemmDesc {
     double alpha, beta;
     int tri;           // 1: only tiles tm >= tn + tri_off
     int tri_off;
+    int order;         // tile issue order (longest k range first): 0 blockIdx = tm + tn*mt; 1 lower triangle row by row from
+                       // tm = 0 (grid = mt (mt + 1) / 2, kmode 3); 2 rows from tm = mt - 1 down (kmode 2)
     int kmode;         // 0: [0,K)  1: [128 tn, K)  2: [0, 128 (tm+1))  3: [128 max(tm,tn), K)
     int vb_stride, vb_off, vb_limit;   // tile row valid iff batch*vb_stride + vb_off + tm < vb_limit
 };
@@ -43,7 +46,17 @@ template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256, 2) void tri_gemm_kernel(GemmDesc g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
-    const int tm = blockIdx.x % g.mt, tn = blockIdx.x / g.mt;
+    int tm = blockIdx.x % g.mt, tn = blockIdx.x / g.mt;
+    if (g.order == 1) {          // row-major enumeration of the lower triangle: all tiles of row tm share one k length
+        int t = blockIdx.x;
+        tm = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+        while (tm * (tm + 1) / 2 > t) --tm;
+        while ((tm + 1) * (tm + 2) / 2 <= t) ++tm;
+        tn = t - tm * (tm + 1) / 2;
+    } else if (g.order == 2) {
+        tm = g.mt - 1 - blockIdx.x / g.nt;
+        tn = blockIdx.x % g.nt;
+    }
     const int batch = blockIdx.y;
     if (g.tri && tn + g.tri_off > tm) return;
     if (batch * g.vb_stride + g.vb_off + tm >= g.vb_limit) return;
@@ -120,7 +133,8 @@ template <bool A_KC, bool B_KC>
 static void launch_tri_gemm(hipStream_t s, const GemmDesc& g, int batches) {
     ensure_dyn_lds((const void*)tri_gemm_kernel<A_KC, B_KC>, GEMM_LDS_BYTES);
     if (g.mt <= 0 || g.nt <= 0 || batches <= 0) return;
-    hipLaunchKernelGGL((tri_gemm_kernel<A_KC, B_KC>), dim3(g.mt * g.nt, batches), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, g);
+    const int grid = g.order == 1 ? g.mt * (g.mt + 1) / 2 : g.mt * g.nt;
+    hipLaunchKernelGGL((tri_gemm_kernel<A_KC, B_KC>), dim3(grid, batches), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, g);
 }
 
 static GemmDesc mkdesc(const double* A, long lda, const double* B, long ldb, double* C, long ldc, int mt, int nt, int K,
@@ -130,7 +144,7 @@ static GemmDesc mkdesc(const double* A, long lda, const double* B, long ldb, dou
     g.B = B; g.ldb = ldb; g.strideB = 0;
     g.C = C; g.ldc = ldc; g.strideC = 0;
     g.mt = mt; g.nt = nt; g.K = K; g.alpha = alpha; g.beta = beta;
-    g.tri = 0; g.tri_off = 0; g.kmode = 0; g.vb_stride = 0; g.vb_off = 0; g.vb_limit = 1 << 30;
+    g.tri = 0; g.tri_off = 0; g.order = 0; g.kmode = 0; g.vb_stride = 0; g.vb_off = 0; g.vb_limit = 1 << 30;
     return g;
 }
 
@@ -401,6 +415,116 @@ __device__ __forceinline__ void pk_self_fence() {
     __syncthreads();
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The chain workgroup's two 128 x 128 x 128 products, restricted to the 16 x 16 blocks that matter:
+//   TRI  (panel tile):   C[m][n]  = sum_{k-block <= n-block} A[m][k] B[n][k]    B = T_jj is lower triangular
+//   !TRI (next diagonal): C[m][n] -= sum_k A[m][k] A[n][k]  for n-block <= m-block (the factorisation reads the lower half)
+// A full product is 512 MFMAs per wave = 13.6 us on ONE CU (128 FLOP/clk); both forms need 288.  Wave w owns the 16-row
+// blocks {w, 7 - w} and all column blocks, which balances either triangle exactly.  Skipped terms are exact zeros /
+// unused outputs and the k order is that of gemm_tile, so the results are bit-identical to the full products.
+// Operand slabs (16 k x 128, both M-contiguous) go global -> LDS with LDS-direct loads, all of them in flight early: the
+// workgroup owns 160 KB of LDS and the whole product is only 8 slabs (TRI: ring of 4 x (A, B); !TRI: all 8 A slabs).
+// ---------------------------------------------------------------------------------------------------------
+struct ChainAcc {
+    d4_t v[2][8];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int n = 0; n < 8; ++n) v[a][n] = d4_t{0.0, 0.0, 0.0, 0.0};
+    }
+};
+
+template <int N>
+__device__ __forceinline__ void chain_wait_vm() {
+    if (N >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (N >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (N >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (N >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (N >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <bool TRI>
+__device__ __forceinline__ void chain_gemm(ChainAcc& acc, const double* __restrict__ A, long lda, const double* __restrict__ B,
+                                           long ldb, double* lds) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int mi0 = wave, mi1 = 7 - wave;
+    constexpr int SLAB = GEMM_LDS_TILE;                 // doubles per operand slab image [16][144]
+    auto issue = [&](int s) {                            // wave w brings k-rows 4w .. 4w+3 of slab s
+        double* base = TRI ? lds + (s & 3) * 2 * SLAB : lds + s * SLAB;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * wave + r;
+            slab_row_to_lds(A + 2 * lane + (long)(16 * s + row) * lda, base + row * GEMM_LDS_MC_LD);
+            if (TRI) slab_row_to_lds(B + 2 * lane + (long)(16 * s + row) * ldb, base + SLAB + row * GEMM_LDS_MC_LD);
+        }
+    };
+    if (TRI) { issue(0); issue(1); issue(2); }
+    else {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) issue(s);
+    }
+    auto step = [&](auto S) {
+        constexpr int s = decltype(S)::value;
+        // slab s has landed when at most the loads issued after it are outstanding (8 per slab TRI, 4 otherwise)
+        if (TRI) chain_wait_vm<8 * (s <= 5 ? 2 : 7 - s)>();
+        else chain_wait_vm<4 * (7 - s)>();
+        __syncthreads();                                 // every wave's part of slab s is in LDS; slab s-1 is no longer read
+        if (TRI && s + 3 < 8) issue(s + 3);              // into the buffer of slab s - 1
+        const double* la = TRI ? lds + (s & 3) * 2 * SLAB : lds + s * SLAB;
+        const double* lb = TRI ? la + SLAB : la;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int krow = (4 * kk + (lane >> 4)) * GEMM_LDS_MC_LD + (lane & 15);
+            const double a0 = la[krow + 16 * mi0], a1 = la[krow + 16 * mi1];
+#pragma unroll
+            for (int nj = 0; nj < 8; ++nj) {
+                if (TRI) {
+                    if (nj >= s) {
+                        const double bf = lb[krow + 16 * nj];
+                        acc.v[0][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf, a0, acc.v[0][nj], 0, 0, 0);
+                        acc.v[1][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf, a1, acc.v[1][nj], 0, 0, 0);
+                    }
+                } else {
+                    if (nj <= mi1) {                     // mi1 >= mi0: the longer row
+                        const double bf = lb[krow + 16 * nj];
+                        if (nj <= mi0) acc.v[0][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf, a0, acc.v[0][nj], 0, 0, 0);
+                        acc.v[1][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf, a1, acc.v[1][nj], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    };
+    step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
+    step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+    step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
+    __syncthreads();                                     // LDS free for the next user
+}
+
+// element (a, nj, r) of a ChainAcc: row 16 mi + (lane & 15), column 16 nj + (lane >> 4) + 4 r
+template <bool TRI>
+__device__ __forceinline__ void chain_store(double* __restrict__ C, long ld, const ChainAcc& acc) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int mi = a == 0 ? wave : 7 - wave;
+#pragma unroll
+        for (int nj = 0; nj < 8; ++nj) {
+            if (!TRI && nj > mi) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double* c = C + (long)(16 * mi + (lane & 15)) + (long)(16 * nj + (lane >> 4) + 4 * r) * ld;
+                if (TRI) *c = acc.v[a][nj][r];
+                else *c = *c - acc.v[a][nj][r];
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void potrf_persistent_kernel(PersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
@@ -424,10 +548,12 @@ __global__ __launch_bounds__(256) void potrf_persistent_kernel(PersistArgs a) {
             if (j > 0 && !pk_wait_count(a.sync, bs.n_xcd * (2 * j + 1), a)) return;   // workers arrived at B2 of step j-1
             PK_STAMP(1);
             pk_self_fence();                                   // T_jj, written by this workgroup a moment ago
-            Acc acc;
-            acc.zero();
-            gemm_tile<false, false>(acc, Asub, ld, Tjj, ld, 0, NB, lds);          // L_{j+1,j} = A_{j+1,j} T_jj^T
-            pk_store_tile(Asub, ld, acc);
+            {
+                ChainAcc ca;
+                ca.zero();
+                chain_gemm<true>(ca, Asub, ld, Tjj, ld, lds);                     // L_{j+1,j} = A_{j+1,j} T_jj^T
+                chain_store<true>(Asub, ld, ca);
+            }
             pk_signal(sub + j);
             PK_STAMP(2);
             pk_inv_l1();
@@ -435,9 +561,17 @@ __global__ __launch_bounds__(256) void potrf_persistent_kernel(PersistArgs a) {
             const int J0 = (j / nbo) * nbo;
             const int kc0 = (j + 1 == min(J0 + nbo, nb)) ? J0 : j;
             const double* Lr = a.A + (long)(j + 1) * NB + (long)kc0 * NB * ld;
-            acc.zero();
-            gemm_tile<false, false>(acc, Lr, ld, Lr, ld, 0, (j + 1 - kc0) * NB, lds);
-            pk_sub_tile(Anext, ld, acc);
+            if (kc0 == j) {
+                ChainAcc ca;
+                ca.zero();
+                chain_gemm<false>(ca, Lr, ld, Lr, ld, lds);
+                chain_store<false>(Anext, ld, ca);
+            } else {
+                Acc acc;
+                acc.zero();
+                gemm_tile<false, false>(acc, Lr, ld, Lr, ld, 0, (j + 1 - kc0) * NB, lds);
+                pk_sub_tile(Anext, ld, acc);
+            }
             pk_self_fence();
             PK_STAMP(3);
             diag_block<true>(Anext, ld, Tjj + (long)NB * (ld + 1), ld, a.info, (j + 1) * NB, smem);
@@ -663,7 +797,10 @@ void launch_trtri(hipStream_t s, const double* L, int Np, double* Linv, double* 
         g2.kmode = 2;
         g2.vb_stride = 2 * h; g2.vb_off = h; g2.vb_limit = nb;
         if (narrow) launch_tri_gemm64<false>(s, g2, pairs);
-        else launch_tri_gemm<false, true>(s, g2, pairs);
+        else {
+            g2.order = 2;   // k < 128 (tm + 1): long rows first
+            launch_tri_gemm<false, true>(s, g2, pairs);
+        }
     }
 }
 
@@ -696,7 +833,10 @@ void launch_lauum(hipStream_t s, const double* Linv, int Np, double* Kinv) {
     }
     const bool narrow = n64_env >= 0 ? n64_env != 0 : nb <= 8;   // measured: N=1024 0.16 -> 0.09 ms, N=4096 0.84 -> 1.0 ms
     if (narrow) launch_tri_gemm64<true>(s, g, 1);
-    else launch_tri_gemm<true, true>(s, g, 1);
+    else {
+        g.order = 1;        // k >= 128 max(tm, tn) = 128 tm: rows from the top, longest k range first, no idle workgroups
+        launch_tri_gemm<true, true>(s, g, 1);
+    }
     hipLaunchKernelGGL(symmetrize_kernel, dim3(Np / 32, Np / 32), dim3(256), 0, s, Kinv, Np);
 }
 

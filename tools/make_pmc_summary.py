@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
-"""profiles/r01_pmc_by_kernel.json -> profiles/r01_pmc_acq_gemm.json (the `traffic` source of bench.py)."""
+"""<prefix>_pmc_by_kernel.json -> <prefix>_pmc_acq_gemm.json (the `traffic` source of bench.py).
+usage: tools/make_pmc_summary.py [prefix = profiles/r01]"""
 import json
-d = json.load(open("profiles/r01_pmc_by_kernel.json"))
+import sys
+PFX = sys.argv[1] if len(sys.argv) > 1 else "profiles/r01"
+d = json.load(open(PFX + "_pmc_by_kernel.json"))
 k = [x for x in d if x.startswith("acq_gemm_kernel")][0]
 c = d[k]
 fetch_kb, write_kb = c["FETCH_SIZE"]["mean"], c["WRITE_SIZE"]["mean"]
@@ -13,7 +16,7 @@ N = 8192
 cand = int(round(flops / (2.0 * N * N)))                     # candidates per launch (bench.py --chunk)
 out = {
     "kernel": k, "launches_profiled": c["FETCH_SIZE"]["n"],
-    "command": "rocprofv3 --kernel-trace --pmc <counters> -- python bench.py --steps 1 --warmup 1 --n-local 6 --no-cpu-baseline  (tools/prof_r01.sh; separate passes for FETCH_SIZE, WRITE_SIZE, SQ/GRBM)",
+    "command": "rocprofv3 --kernel-trace --pmc <counters> -- python bench.py --steps 1 --warmup 1 --n-local 6 --no-cpu-baseline  (tools/prof_r0N.sh; separate passes for FETCH_SIZE, WRITE_SIZE, SQ/GRBM; round 2: SLS_COMPACT=0 so that every dispatch has the full 65 536-candidate shape)",
     "avg_duration_ms": dur / 1e6,
     "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB_raw": write_kb,
     "fetch_bytes_corrected": fetch_kb * 1024 * 2, "write_bytes": write_kb * 1024,
@@ -24,5 +27,5 @@ out = {
     "mfma_flops_counted": flops, "effective_clock_GHz": gui / dur,
     "mfma_busy_fraction": mfma_busy / gui, "mfma_busy_cycles_per_instruction": c["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (flops / 2048),
 }
-json.dump(out, open("profiles/r01_pmc_acq_gemm.json", "w"), indent=1)
+json.dump(out, open(PFX + "_pmc_acq_gemm.json", "w"), indent=1)
 print({k2: out[k2] for k2 in ("avg_duration_ms", "FETCH_SIZE_KB_raw", "hbm_bytes_per_launch", "mfma_busy_fraction", "effective_clock_GHz")})

@@ -1,5 +1,7 @@
-"""All five BASELINE.json configs on one MI355X (C4 itself is bench.py): wall-clock timings -> profiles/r01_configs.json."""
+"""All five BASELINE.json configs on one MI355X (C4 itself is bench.py): wall-clock timings -> gpurun_out/configs.json
+(copied to profiles/r0N_configs.json)."""
 import json, os, re, subprocess, sys, time
+os.environ.setdefault("OMP_NUM_THREADS", "64")
 import numpy as np
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.join(R, "tests")); sys.path.insert(0, R)
 from util import sls, synth_problem, synth_candidates
