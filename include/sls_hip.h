@@ -60,6 +60,11 @@ int sls_ctx_synchronize(sls_ctx* ctx);
 /* Upper bound on candidates evaluated per device pass (workspace = 3 * chunk * N_pad doubles). Default 16384. */
 int sls_ctx_set_candidate_chunk(sls_ctx* ctx, int chunk);
 
+/* Device blocks released by handles and calls are cached per device (exact-size reuse; at most SLS_POOL_MB, default 16384,
+ * MB): re-creating a regressor of the same shape costs no hipMalloc.  This returns every cached block of `device` to the
+ * driver. */
+int sls_device_trim_cache(int device);
+
 /* ---- free functions of src/regressor.cpp --------------------------------- */
 /* CalcLargeKY (src/regressor.cpp:61-71); b = 0 gives CalcLargeKF (:73-89).  K_out is N x N. */
 int sls_gram(sls_ctx* ctx, const double* X, int D, int N, const double* theta, double b, int kernel, double* K_out);

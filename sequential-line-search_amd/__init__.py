@@ -54,7 +54,7 @@ EXPORTS = [
     "sls_pref_objective", "sls_acq_eval_pair", "sls_acq_maximize_pair", "sls_gp_append_point", "sls_acq_last_stats",
     "sls_multi_create", "sls_multi_destroy", "sls_multi_size", "sls_multi_exchange", "sls_multi_ctx", "sls_multi_gp_create",
     "sls_multi_gp_destroy", "sls_multi_gp_shard", "sls_multi_acq_maximize", "sls_comm_unique_id", "sls_comm_create",
-    "sls_comm_destroy", "sls_comm_allgather_best",
+    "sls_comm_destroy", "sls_comm_allgather_best", "sls_device_trim_cache",
 ]
 
 

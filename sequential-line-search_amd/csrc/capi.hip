@@ -3,6 +3,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <map>
 #include <memory>
 #include <mutex>
 
@@ -22,6 +24,106 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+}  // namespace slsk
+
+// ---- device block cache (common.hpp) -------------------------------------------------------------------------
+namespace slsk {
+namespace {
+struct Pool {
+    std::mutex mtx;
+    std::multimap<size_t, void*> free_blocks;
+    size_t cached = 0;
+    long synced_epoch = -1;
+};
+// bumped by every C-ABI entry point: "device work may have been queued since the last device-wide synchronisation"
+std::atomic<long> g_work_epoch{0};
+Pool& pool_of(int dev) {
+    static std::mutex m;
+    static std::map<int, std::unique_ptr<Pool>> pools;
+    std::lock_guard<std::mutex> lock(m);
+    auto& p = pools[dev];
+    if (!p) p.reset(new Pool());
+    return *p;
+}
+size_t pool_limit() {
+    const char* e = getenv("SLS_POOL_MB");
+    return (size_t)(e ? atol(e) : 16384) << 20;
+}
+}  // namespace
+
+void note_entry() { g_work_epoch.fetch_add(1); }
+
+void* pool_alloc(size_t bytes) {
+    if (bytes == 0) bytes = 8;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    Pool& P = pool_of(dev);
+    {
+        std::lock_guard<std::mutex> lock(P.mtx);
+        auto it = P.free_blocks.find(bytes);
+        if (it != P.free_blocks.end()) {
+            void* p = it->second;
+            P.free_blocks.erase(it);
+            P.cached -= bytes;
+            return p;
+        }
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {          // out of memory: give the cache back and try once more
+        pool_trim(dev);
+        e = hipMalloc(&p, bytes);
+    }
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        throw HipFail{SLS_ERR_HIP};
+    }
+    return p;
+}
+
+void pool_free(void* p, size_t bytes) {
+    if (!p) return;
+    if (bytes == 0) bytes = 8;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) == hipSuccess) dev = attr.device;   // freed from another thread / current device
+    Pool& P = pool_of(dev);
+    {
+        std::lock_guard<std::mutex> lock(P.mtx);
+        if (P.cached + bytes <= pool_limit()) {
+            // A cached block may be handed out again at once (to any stream): everything queued on it must have finished.
+            // hipFree would have synchronised implicitly; here ONE device-wide synchronisation covers all the blocks
+            // released after the same entry point (a handle's ~30 buffers cost one ~5 us call, normally on an idle device
+            // because handles and temporaries are released after their stream has been synchronised).
+            const long epoch = g_work_epoch.load();
+            if (P.synced_epoch != epoch) {
+                int cur = 0;
+                (void)hipGetDevice(&cur);
+                if (cur != dev) (void)hipSetDevice(dev);
+                (void)hipDeviceSynchronize();
+                if (cur != dev) (void)hipSetDevice(cur);
+                P.synced_epoch = epoch;
+            }
+            P.free_blocks.emplace(bytes, p);
+            P.cached += bytes;
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+
+void pool_trim(int device) {
+    Pool& P = pool_of(device);
+    std::vector<void*> blocks;
+    {
+        std::lock_guard<std::mutex> lock(P.mtx);
+        for (auto& kv : P.free_blocks) blocks.push_back(kv.second);
+        P.free_blocks.clear();
+        P.cached = 0;
+    }
+    for (void* b : blocks) (void)hipFree(b);
 }
 }  // namespace slsk
 
@@ -66,7 +168,8 @@ slsk::PotrfAux* sls_ctx::potrf_lookahead(int Np) {
     // Only the two-level schedule (N >= 8192 by default) has an outer update to overlap.
     const char* e = getenv("SLS_POTRF_LOOKAHEAD");
     const int f = e ? atoi(e) : SLS_POTRF_LOOKAHEAD_DEFAULT;
-    if (f <= 0 || slsk::potrf_default_nbo(Np) <= 1) return nullptr;
+    const int mode = slsk::potrf_default_mode(Np);
+    if (f <= 0 || mode == 1 || (mode == 0 && slsk::potrf_default_nbo(Np) <= 1)) return nullptr;
     if (!potrf_aux.side) slsk::potrf_aux_create(&potrf_aux, f);
     return &potrf_aux;
 }
@@ -74,20 +177,22 @@ slsk::PotrfAux* sls_ctx::potrf_lookahead(int Np) {
 int* sls_ctx::potrf_sync(int Np) {
     // sync words of the single-launch factorisation live behind the info words; nullptr (multi-launch schedule) if they
     // would not fit (N > 60 000)
-    return 32 + 2 * (Np / 128) <= 960 ? d_info + 64 : nullptr;
+    return (potrf_persistent_ok && 32 + 2 * (Np / 128) + Np / 128 + 2 <= 960) ? d_info + 64 : nullptr;
 }
 
 namespace slsk {
-void check_potrf_abort(int abort_flag) {
-    if (abort_flag != 0) {
-        set_error("Cholesky factorisation aborted: a device-side wait of the persistent kernel expired (SLS_POTRF_MODE=0 "
-                  "selects the multi-launch schedule)");
+bool potrf_gave_up(sls_ctx* c, int abort_flag, int attempt) {
+    if (abort_flag == 0) return false;
+    if (attempt > 0 || !c->potrf_persistent_ok) {
+        set_error("Cholesky factorisation aborted: a device-side wait expired");
         throw HipFail{SLS_ERR_HIP};
     }
+    c->potrf_persistent_ok = false;   // this context uses the multi-launch schedule from now on
+    return true;
 }
 }  // namespace slsk
 
-#define SLS_TRY try {
+#define SLS_TRY slsk::note_entry(); try {
 #define SLS_CATCH                                   \
     }                                               \
     catch (const slsk::HipFail& f) { return f.code; } \
@@ -131,6 +236,13 @@ extern "C" int sls_ctx_destroy(sls_ctx* ctx) {
     if (ctx->d_info) (void)hipFree(ctx->d_info);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
+    return SLS_OK;
+}
+
+extern "C" int sls_device_trim_cache(int device) {
+    slsk::note_entry();
+    (void)hipDeviceSynchronize();
+    slsk::pool_trim(device);
     return SLS_OK;
 }
 
@@ -267,7 +379,7 @@ static void gp_fit_device(sls_gp* g) {
     launch_logdet(c->stream, g->L.p, Np, N, g->scal.p + 1);
 }
 
-static void gp_fetch_summary(sls_gp* g) {
+static void gp_fetch_summary(sls_gp* g, int attempt = 0) {
     sls_ctx* c = g->ctx;
     int info[16] = {0};
     double sc[2];
@@ -276,7 +388,11 @@ static void gp_fetch_summary(sls_gp* g) {
     SLS_HIP(hipMemcpyAsync(sc, g->scal.p, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     SLS_HIP(hipMemcpyAsync(&idx, g->d_idx, sizeof(long), hipMemcpyDeviceToHost, c->stream));
     sync(c);
-    check_potrf_abort(info[1]);
+    if (potrf_gave_up(c, info[1], attempt)) {
+        gp_fit_device(g);            // once more, on the multi-launch schedule (the fit rebuilds K_y from X)
+        gp_fetch_summary(g, 1);
+        return;
+    }
     if (info[0] != 0) {
         set_error("Cholesky failed: K_y is not positive definite (pivot %d)", info[0] - 1);
         throw HipFail{SLS_ERR_NOT_SPD};
@@ -352,6 +468,8 @@ extern "C" int sls_gp_refit_dev(sls_gp* g, const double* X_dev, const double* y_
 
 extern "C" int sls_gp_destroy(sls_gp* gp) {
     if (!gp) return SLS_OK;
+    slsk::note_entry();
+    (void)hipSetDevice(gp->ctx->device);
     (void)hipStreamSynchronize(gp->ctx->stream);
     delete gp;
     return SLS_OK;
@@ -912,16 +1030,20 @@ extern "C" int sls_potrf(sls_ctx* c, double* A, int N) {
     SLS_HIP(hipSetDevice(c->device));
     const int Np = round_up(N, 128);
     DBuf Ad, Li;
-    upload_padded_spd(c, Ad, A, N, Np);
     Li.ensure((size_t)Np * Np);
-    SLS_HIP(hipMemsetAsync(c->d_info, 0, 64, c->stream));
-    launch_potrf(c->stream, Ad.p, Np, Li.p, c->d_info, 0, c->potrf_lookahead(Np), c->potrf_sync(Np));
-    launch_zero_upper(c->stream, Ad.p, Np);
     int info2[2] = {0, 0};
-    SLS_HIP(hipMemcpyAsync(info2, c->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    d2h_matrix(c, A, Ad.p, N, Np);
-    sync(c);
-    check_potrf_abort(info2[1]);
+    std::vector<double> out((size_t)N * N);
+    for (int attempt = 0;; ++attempt) {
+        upload_padded_spd(c, Ad, A, N, Np);
+        SLS_HIP(hipMemsetAsync(c->d_info, 0, 64, c->stream));
+        launch_potrf(c->stream, Ad.p, Np, Li.p, c->d_info, 0, c->potrf_lookahead(Np), c->potrf_sync(Np));
+        launch_zero_upper(c->stream, Ad.p, Np);
+        SLS_HIP(hipMemcpyAsync(info2, c->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        d2h_matrix(c, out.data(), Ad.p, N, Np);
+        sync(c);
+        if (!potrf_gave_up(c, info2[1], attempt)) break;
+    }
+    std::copy(out.begin(), out.end(), A);
     const int info = info2[0];
     if (info != 0) {
         set_error("sls_potrf: matrix is not positive definite (pivot %d)", info - 1);

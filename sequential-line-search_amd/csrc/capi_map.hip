@@ -11,7 +11,7 @@
 
 using namespace slsk;
 
-#define SLS_TRY try {
+#define SLS_TRY slsk::note_entry(); try {
 #define SLS_CATCH                                   \
     }                                               \
     catch (const slsk::HipFail& f) { return f.code; } \
@@ -57,6 +57,8 @@ extern "C" int sls_nll_create(sls_ctx* ctx, const double* X, int D, int N, int k
 
 extern "C" int sls_nll_destroy(sls_nll* h) {
     if (!h) return SLS_OK;
+    slsk::note_entry();
+    (void)hipSetDevice(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
     delete h;
     return SLS_OK;
@@ -78,19 +80,21 @@ static void nll_factor(sls_nll* h, const double* theta, double b) {
     SLS_HIP(hipMemcpyAsync(h->inv_ell.p, il.data(), h->Dcols * 8, hipMemcpyHostToDevice, c->stream));
     SLS_HIP(hipStreamSynchronize(c->stream));
     KernelSpec ks{h->kernel, theta[0]};
-    launch_prep_points(c->stream, h->X.p, D, N, h->inv_ell.p, h->XT.p, Np, Np, h->Dcols, h->nx.p);
-    launch_gram_sym(c->stream, h->XT.p, Np, h->Dp, h->nx.p, Np, N, ks, b, h->L.p, true);
-    SLS_HIP(hipMemsetAsync(c->d_info, 0, 64, c->stream));
-    launch_fill(c->stream, h->Linv.p, (long)Np * Np, 0.0);
-    launch_potrf(c->stream, h->L.p, Np, h->Linv.p, c->d_info, 0, c->potrf_lookahead(Np), c->potrf_sync(Np));
-    launch_trtri(c->stream, h->L.p, Np, h->Linv.p, h->Kinv.p);
-    launch_lauum(c->stream, h->Linv.p, Np, h->Kinv.p);
-    launch_logdet(c->stream, h->L.p, Np, N, h->scal.p + 4);
     int info2[2] = {0, 0};
-    SLS_HIP(hipMemcpyAsync(info2, c->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    SLS_HIP(hipMemcpyAsync(&h->logdet, h->scal.p + 4, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    SLS_HIP(hipStreamSynchronize(c->stream));
-    check_potrf_abort(info2[1]);
+    for (int attempt = 0;; ++attempt) {
+        launch_prep_points(c->stream, h->X.p, D, N, h->inv_ell.p, h->XT.p, Np, Np, h->Dcols, h->nx.p);
+        launch_gram_sym(c->stream, h->XT.p, Np, h->Dp, h->nx.p, Np, N, ks, b, h->L.p, true);
+        SLS_HIP(hipMemsetAsync(c->d_info, 0, 64, c->stream));
+        launch_fill(c->stream, h->Linv.p, (long)Np * Np, 0.0);
+        launch_potrf(c->stream, h->L.p, Np, h->Linv.p, c->d_info, 0, c->potrf_lookahead(Np), c->potrf_sync(Np));
+        launch_trtri(c->stream, h->L.p, Np, h->Linv.p, h->Kinv.p);
+        launch_lauum(c->stream, h->Linv.p, Np, h->Kinv.p);
+        launch_logdet(c->stream, h->L.p, Np, N, h->scal.p + 4);
+        SLS_HIP(hipMemcpyAsync(info2, c->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        SLS_HIP(hipMemcpyAsync(&h->logdet, h->scal.p + 4, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        SLS_HIP(hipStreamSynchronize(c->stream));
+        if (!potrf_gave_up(c, info2[1], attempt)) break;   // else: once more on the multi-launch schedule
+    }
     const int info = info2[0];
     if (info != 0) {
         set_error("sls_nll_eval: K_y is not positive definite (pivot %d)", info - 1);

@@ -15,7 +15,10 @@
 namespace slsk {
 
 void set_error(const char* fmt, ...);
-void check_potrf_abort(int abort_flag);   // throws HipFail{SLS_ERR_HIP} if the persistent factorisation gave up
+// true: the persistent factorisation gave up (a bounded device-side wait expired, e.g. another stream kept CUs busy so
+// that its workgroups were not all resident).  The context falls back to the multi-launch schedule for good and the
+// caller repeats the factorisation once; a second failure throws HipFail{SLS_ERR_HIP}.
+bool potrf_gave_up(sls_ctx* c, int abort_flag, int attempt);
 
 struct HipFail {
     int code;
@@ -40,6 +43,15 @@ struct HipFail {
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// Per-device cache of freed device blocks, keyed by exact size: hipMalloc / hipFree cost 50-300 us each and a GP handle owns
+// ~30 buffers, which made CREATING a handle at N = 2048 take longer than FITTING it (BASELINE config C2).  A regressor that
+// is rebuilt with the same shapes (every step of the reference's optimisers) gets its blocks back without touching the
+// driver.  At most SLS_POOL_MB (default 16384) MB stay cached per device; beyond that blocks go back to the driver.
+void note_entry();                           // every C-ABI entry point: device work may be queued from here on
+void* pool_alloc(size_t bytes);              // throws HipFail on failure
+void pool_free(void* p, size_t bytes);
+void pool_trim(int device);                  // return every cached block of `device` to the driver
+
 // Owning device buffer of doubles (or raw bytes).
 struct DBuf {
     double* p = nullptr;
@@ -49,14 +61,14 @@ struct DBuf {
     DBuf& operator=(const DBuf&) = delete;
     ~DBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) pool_free(p, n * sizeof(double));
         p = nullptr;
         n = 0;
     }
     void ensure(size_t doubles) {
         if (doubles <= n && p) return;
         release();
-        SLS_HIP(hipMalloc((void**)&p, doubles * sizeof(double)));
+        p = static_cast<double*>(pool_alloc(doubles * sizeof(double)));
         n = doubles;
     }
 };
@@ -86,7 +98,8 @@ struct sls_ctx {
     // look-ahead schedule of the Cholesky factorisation: CU-masked side stream + events, created on first use
     slsk::PotrfAux potrf_aux;
     slsk::PotrfAux* potrf_lookahead(int Np);   // nullptr unless SLS_POTRF_LOOKAHEAD selects the two-stream schedule
-    int* potrf_sync(int Np);             // device sync words for launch_potrf_persistent
+    int* potrf_sync(int Np);             // device sync words for launch_potrf_persistent (nullptr: multi-launch schedule)
+    bool potrf_persistent_ok = true;     // cleared when a persistent factorisation gave up (bounded wait expired)
 
     hipEvent_t get_event();
     void prof_begin(const char* name, hipEvent_t& e0);

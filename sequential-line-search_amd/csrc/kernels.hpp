@@ -158,9 +158,8 @@ void launch_potrf(hipStream_t s, double* A, int Np, double* Linv, int* info, int
                   int* persist_sync = nullptr);
 // The whole factorisation in ONE persistent launch (see kernels_chol.hip); sync = device scratch of >= 8 + 2 (Np/128) ints.
 // info[1] != 0 afterwards: a bounded wait expired (the kernel aborted; results undefined).  launch_potrf takes this path
-// when persist_sync != nullptr, Np >= 384 and SLS_POTRF_MODE=1 (opt-in: measured on MI355X it ties with the multi-launch
-// schedule -- both are bound by the same ~88 us per-step chain).
-int potrf_default_mode();
+// when persist_sync != nullptr, Np >= 384 and SLS_POTRF_MODE is 1 (default; 0 = multi-launch schedule).
+int potrf_default_mode(int Np);
 void launch_potrf_persistent(hipStream_t s, double* A, int Np, double* Linv, int* info, int* sync, long long* trace = nullptr);
 // side stream restricted by a CU mask that leaves `free_per_xcd` CUs of each of the 8 XCDs to other streams (0: plain stream)
 void potrf_aux_create(PotrfAux* aux, int free_per_xcd);

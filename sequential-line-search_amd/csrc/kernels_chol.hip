@@ -17,7 +17,7 @@
 #include "kernels.hpp"
 
 #ifndef SLS_POTRF_MODE_DEFAULT
-#define SLS_POTRF_MODE_DEFAULT 0
+#define SLS_POTRF_MODE_DEFAULT 1
 #endif
 
 namespace slsk {
@@ -270,6 +270,9 @@ struct PersistArgs {
     // [PK_FLAGS + nb + j] block j factored
     int* sync;
     int nbo;          // 128-columns per outer block of the two-level update (1: every step updates the whole trailing matrix)
+    int j0, j1;       // block steps [j0, j1) (j1 = nb: to the end, trailing updates included; j1 < nb: PANEL mode)
+    int k0;           // k0 < j0: first apply the block columns [k0, j0) to block column j0 (hybrid schedule, phase 0)
+    int* ext_flag;    // nullptr or a device word another stream raises when columns j0+1 .. have received [k0, j0)
     long long timeout;
     long long* trace;   // optional (probes): 16 wall-clock stamps per step, [0..7] workgroup 0, [8..15] workgroup 1
 };
@@ -335,7 +338,7 @@ __device__ __forceinline__ void pk_signal(int* p) {
 struct PkBarrier {
     int xcc, xcd_size, n_xcd, epoch;
 };
-__device__ __forceinline__ bool pk_barrier(const PersistArgs& a, PkBarrier& bs, int* also_flag = nullptr) {
+__device__ __forceinline__ bool pk_barrier(const PersistArgs& a, PkBarrier& bs, int* also_flag = nullptr, int* also_flag2 = nullptr) {
     __syncthreads();
     bs.epoch += 1;
     int ok = 1;
@@ -351,6 +354,7 @@ __device__ __forceinline__ bool pk_barrier(const PersistArgs& a, PkBarrier& bs, 
                 // a flag of the chain workgroup the next phase depends on: waited for HERE, by the 8 leaders, so that the one
                 // acquire below covers it and no worker needs an acquire (= an L2 invalidate) of its own
                 if (ok && also_flag) ok = pk_spin(also_flag, 1, a.info + 1, a.timeout) ? 1 : 0;
+                if (ok && also_flag2) ok = pk_spin(also_flag2, 1, a.info + 1, a.timeout) ? 1 : 0;
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 __hip_atomic_store(go, bs.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -386,6 +390,55 @@ __device__ __forceinline__ bool pk_setup(const PersistArgs& a, PkBarrier& bs, bo
     ok = __builtin_amdgcn_readfirstlane(ok);
     __syncthreads();
     return ok != 0;
+}
+
+// gemm_tile for a workgroup that owns the whole CU (160 KB of LDS, no co-resident workgroup to hide its waits): the same
+// 128 x 128 tile, wave quadrants, fragment layout and k order as gemm_tile<false, false> (=> identical bits), but the operand
+// slabs run through a ring of FOUR LDS stages with the LDS-direct loads issued three slabs ahead, so a slab's ~2 us load
+// latency is covered by the ~1.7 us of MFMA work of each of the three slabs in front of it (gemm_tile's two stages leave one
+// workgroup per CU waiting: measured 2.4 us per slab instead of 1.7).
+__device__ __forceinline__ void gemm_tile_deep(Acc& acc, const double* __restrict__ A, long lda, const double* __restrict__ B,
+                                               long ldb, int K, double* lds) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
+    constexpr int STAGE = 2 * GEMM_LDS_TILE;             // doubles per stage: A slab | B slab
+    const int nslab = K / GEMM_BK;
+    auto issue = [&](int s) {
+        double* base = lds + (s & 3) * STAGE;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * wave + r;
+            slab_row_to_lds(A + 2 * lane + (long)(GEMM_BK * s + row) * lda, base + row * GEMM_LDS_MC_LD);
+            slab_row_to_lds(B + 2 * lane + (long)(GEMM_BK * s + row) * ldb, base + GEMM_LDS_TILE + row * GEMM_LDS_MC_LD);
+        }
+    };
+    for (int s = 0; s < 3 && s < nslab; ++s) issue(s);
+    for (int s = 0; s < nslab; ++s) {
+        // slabs s+1, s+2 (8 loads each per wave) may still be in flight
+        const int later = min(2, nslab - 1 - s);
+        if (later == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                 // slab s complete in LDS; nobody reads slab s-1 any more
+        if (s + 3 < nslab) issue(s + 3);                 // into the stage slab s-1 occupied
+        const double* la = lds + (s & 3) * STAGE;
+        const double* lb = la + GEMM_LDS_TILE;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            double af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = frag_read<false>(la, wm + 16 * i, kk, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = frag_read<false>(lb, wn + 16 * j, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc.v[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc.v[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
 }
 
 // 128 x 128 tile helpers on top of gemm_tile (operands in global memory / L2)
@@ -525,27 +578,47 @@ __device__ __forceinline__ void chain_store(double* __restrict__ C, long ld, con
     }
 }
 
+// Steps [a.j0, a.j1) of the factorisation.  Whole matrix: j0 = 0, j1 = nb, two-level trailing updates inside the kernel.
+// PANEL mode (a.j1 < nb): the block columns [j0, j1) only -- diagonal blocks, all panel tiles below them, and the updates of
+// the panel's own columns; the update of everything beyond column j1 is left to the caller (launch_potrf_hybrid runs it as
+// a full-rate GEMM launch on a second stream while the next panel is being factored here).
 __global__ __launch_bounds__(256) void potrf_persistent_kernel(PersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
     const int G = gridDim.x, b = blockIdx.x, nb = a.nb, W = G - 1, w = b - 1, nbo = a.nbo;
+    const int j0 = a.j0, j1 = a.j1;
+    const bool panel = j1 < nb;
+    const int jlast = panel ? j1 - 1 : nb - 2;           // last step that has rows below it to work on
     const long ld = a.ld;
     int* factored = a.sync + PK_FLAGS;            // [j]: L_jj, T_jj stored
     int* sub = a.sync + PK_FLAGS + nb;            // [j]: L_{j+1,j} stored
     PkBarrier bs;
     if (!pk_setup(a, bs, b != 0)) return;
+    const bool phase0 = a.k0 < j0;
+    const double* Lprev = a.A + (long)j0 * NB + (long)a.k0 * NB * ld;   // L[j0.., k0 .. j0): the previous block's columns
+    const int Kprev = (j0 - a.k0) * NB;
     if (b == 0) {
         // ---- the chain: diagonal block j, then ITS OWN sub-diagonal tile and next diagonal tile, no grid barrier ----
-        diag_block<true>(a.A, ld, a.Linv, ld, a.info, 0, smem);
-        pk_signal(factored);
-        for (int j = 0; j + 1 < nb; ++j) {
+        if (phase0) {   // tile (j0, j0) -= L[j0, k0..j0) L[j0, k0..j0)^T
+            Acc acc;
+            acc.zero();
+            gemm_tile_deep(acc, Lprev, ld, Lprev, ld, Kprev, lds);
+            pk_sub_tile(a.A + (long)j0 * NB * (ld + 1), ld, acc);
+            pk_self_fence();
+        }
+        diag_block<true>(a.A + (long)j0 * NB * (ld + 1), ld, a.Linv + (long)j0 * NB * (ld + 1), ld, a.info, j0 * NB, smem);
+        pk_signal(factored + j0);
+        // in panel mode the diagonal block j1 belongs to the next launch: the chain stops one step earlier
+        const int jchain = panel ? j1 - 2 : nb - 2;
+        for (int j = j0; j <= jchain; ++j) {
             double* Ajj = a.A + (long)j * NB * (ld + 1);
             double* Tjj = a.Linv + (long)j * NB * (ld + 1);
             double* Asub = Ajj + NB;                           // tile (j+1, j)
             double* Anext = Ajj + (long)NB * (ld + 1);         // tile (j+1, j+1)
             PK_STAMP(0);
             // tiles (j+1, j) and (j+1, j+1) carry the updates of steps < j once the workers have left step j-1
-            if (j > 0 && !pk_wait_count(a.sync, bs.n_xcd * (2 * j + 1), a)) return;   // workers arrived at B2 of step j-1
+            // (for j = j0: at B0, i.e. past phase 0)
+            if (!pk_wait_count(a.sync, bs.n_xcd * (2 * (j - j0) + 1), a)) return;
             PK_STAMP(1);
             pk_self_fence();                                   // T_jj, written by this workgroup a moment ago
             {
@@ -556,10 +629,13 @@ __global__ __launch_bounds__(256) void potrf_persistent_kernel(PersistArgs a) {
             }
             pk_signal(sub + j);
             PK_STAMP(2);
+            // tile (j0+1, j0+1) also receives [k0, j0) from the other stream: that update must be in before this one
+            if (j == j0 && a.ext_flag && !pk_wait_flag(a.ext_flag, a)) return;
             pk_inv_l1();
             // A_{j+1,j+1} -= L_{j+1,k} L_{j+1,k}^T: k = j inside an outer block, all the block's columns at its last step
-            const int J0 = (j / nbo) * nbo;
-            const int kc0 = (j + 1 == min(J0 + nbo, nb)) ? J0 : j;
+            const int J0 = panel ? j0 : (j / nbo) * nbo;
+            const int J1 = panel ? j1 : min(J0 + nbo, nb);
+            const int kc0 = (j + 1 == J1) ? J0 : j;
             const double* Lr = a.A + (long)(j + 1) * NB + (long)kc0 * NB * ld;
             if (kc0 == j) {
                 ChainAcc ca;
@@ -569,7 +645,7 @@ __global__ __launch_bounds__(256) void potrf_persistent_kernel(PersistArgs a) {
             } else {
                 Acc acc;
                 acc.zero();
-                gemm_tile<false, false>(acc, Lr, ld, Lr, ld, 0, (j + 1 - kc0) * NB, lds);
+                gemm_tile_deep(acc, Lr, ld, Lr, ld, (j + 1 - kc0) * NB, lds);
                 pk_sub_tile(Anext, ld, acc);
             }
             pk_self_fence();
@@ -580,49 +656,62 @@ __global__ __launch_bounds__(256) void potrf_persistent_kernel(PersistArgs a) {
         }
         return;
     }
-    // ---- the workers: everything else.  Barrier epochs: B0 = 1, step j: B1 = 2j + 2, B2 = 2j + 3.  The chain's flags are
-    //      folded into the barriers that precede their first use (B0 / B2: block factored; B1: sub-diagonal tile stored) ----
-    if (!pk_barrier(a, bs, factored)) return;
-    for (int j = 0; j + 1 < nb; ++j) {
+    // ---- the workers: everything else.  Barrier epochs: B0 = 1, step j: B1 = 2 (j - j0) + 2, B2 = 2 (j - j0) + 3.  The
+    //      chain's flags are folded into the barriers that precede their first use (B0 / B2: block factored; B1:
+    //      sub-diagonal tile stored) ----
+    if (phase0) {   // block column j0 below the diagonal: A_{i,j0} -= L[i, k0..j0) L[j0, k0..j0)^T
+        double* Acol = a.A + (long)(j0 + 1) * NB + (long)j0 * NB * ld;
+        for (int t = w; t < nb - 1 - j0; t += W) {
+            Acc acc;
+            acc.zero();
+            gemm_tile_deep(acc, Lprev + (long)(t + 1) * NB, ld, Lprev, ld, Kprev, lds);
+            pk_sub_tile(Acol + (long)t * NB, ld, acc);
+        }
+    }
+    if (!pk_barrier(a, bs, factored + j0)) return;
+    for (int j = j0; j <= jlast; ++j) {
         const int rem = nb - 1 - j;                            // block rows / columns below and right of block j
         double* Ajj = a.A + (long)j * NB * (ld + 1);
         double* Tjj = a.Linv + (long)j * NB * (ld + 1);
         double* Apan = Ajj + NB;                               // block column j below the diagonal block
+        const bool chain_has_next = panel ? (j + 1 < j1) : true;   // the chain owns tiles (j+1, j) and (j+1, j+1)
         if (b == 1) PK_STAMP(8);
-        // panel tiles L_ij = A_ij T_jj^T for i >= j + 2 (tile t = 0, row j + 1, belongs to the chain), in place
-        for (int t = 1 + w; t < rem; t += W) {
+        // panel tiles L_ij = A_ij T_jj^T, in place (row j + 1 is the chain's while it continues with block j + 1)
+        for (int t = (chain_has_next ? 1 : 0) + w; t < rem; t += W) {
             double* Aij = Apan + (long)t * NB;
             Acc acc;
             acc.zero();
-            gemm_tile<false, false>(acc, Aij, ld, Tjj, ld, 0, NB, lds);
+            gemm_tile_deep(acc, Aij, ld, Tjj, ld, NB, lds);
             pk_store_tile(Aij, ld, acc);
         }
         if (b == 1) PK_STAMP(10);
-        if (!pk_barrier(a, bs, sub + j)) return;
+        if (!pk_barrier(a, bs, chain_has_next ? sub + j : nullptr, j == j0 ? a.ext_flag : nullptr)) return;
         if (b == 1) PK_STAMP(11);
         // Trailing update, lower tiles in column-major order; tile t = 0 = (j+1, j+1) belongs to the chain.  Two-level: inside
         // an outer block [J0, J1) step j only updates the block's own columns (K = 128); the block's LAST step updates
         // everything beyond with all its columns at once (K = 128 (J1 - J0)): nbo x fewer read-modify-write sweeps over the
-        // trailing matrix.  nbo = 1: every step is a last step.
-        const int J0 = (j / nbo) * nbo, J1 = min(J0 + nbo, nb);
+        // trailing matrix.  nbo = 1: every step is a last step.  Panel mode: one block, and no update beyond it.
+        const int J0 = panel ? j0 : (j / nbo) * nbo, J1 = panel ? j1 : min(J0 + nbo, nb);
         const bool outer = (j + 1 == J1);
-        const int kc0 = outer ? J0 : j;
-        const int K = (j + 1 - kc0) * NB;
-        const int ncols = outer ? rem : J1 - (j + 1);
-        const int ntile = ncols * rem - ncols * (ncols - 1) / 2;
-        const double* Lrow = a.A + (long)(j + 1) * NB + (long)kc0 * NB * ld;   // L[j+1.., kc0 .. j]
-        double* Atr = Ajj + (long)NB * (ld + 1);
-        for (int t = 1 + w; t < ntile; t += W) {
-            int tk = 0, off = 0;
-            while (t >= off + rem - tk) { off += rem - tk; ++tk; }
-            const int ti = tk + (t - off);
-            Acc acc;
-            acc.zero();
-            gemm_tile<false, false>(acc, Lrow + (long)ti * NB, ld, Lrow + (long)tk * NB, ld, 0, K, lds);
-            pk_sub_tile(Atr + (long)ti * NB + (long)tk * NB * ld, ld, acc);
+        if (!(panel && outer)) {
+            const int kc0 = outer ? J0 : j;
+            const int K = (j + 1 - kc0) * NB;
+            const int ncols = outer ? rem : J1 - (j + 1);
+            const int ntile = ncols * rem - ncols * (ncols - 1) / 2;
+            const double* Lrow = a.A + (long)(j + 1) * NB + (long)kc0 * NB * ld;   // L[j+1.., kc0 .. j]
+            double* Atr = Ajj + (long)NB * (ld + 1);
+            for (int t = 1 + w; t < ntile; t += W) {
+                int tk = 0, off = 0;
+                while (t >= off + rem - tk) { off += rem - tk; ++tk; }
+                const int ti = tk + (t - off);
+                Acc acc;
+                acc.zero();
+                gemm_tile_deep(acc, Lrow + (long)ti * NB, ld, Lrow + (long)tk * NB, ld, K, lds);
+                pk_sub_tile(Atr + (long)ti * NB + (long)tk * NB * ld, ld, acc);
+            }
         }
         if (b == 1) PK_STAMP(13);
-        if (!pk_barrier(a, bs, factored + j + 1)) return;
+        if (!pk_barrier(a, bs, chain_has_next ? factored + j + 1 : nullptr)) return;
         if (b == 1) PK_STAMP(14);
     }
 }
@@ -633,9 +722,19 @@ int potrf_persistent_nbo(int Np) {
     return Np >= 8192 ? 8 : 1;
 }
 
-int potrf_default_mode() {   // read per call: tests and A/B runs switch within one process
+// 0: multi-launch schedule, 1: single persistent launch (default), 2: hybrid (persistent panels + side-stream updates).
+// Measured on MI355X (tools/probes/potrf_bench, ms at N = 2048 / 4096 / 8192 / 16384): multi-launch 1.40 / 3.16 / 10.4 (8.8
+// two-level + look-ahead) / 56.4; persistent 1.11 / 2.72 / 8.56 / 39.3; hybrid (nbo 4) 1.67 / 3.62 / 9.18 / 41.7 -- the
+// hybrid's side-stream launches serialise behind each other more than they overlap with the panels, so it stays opt-in.
+// Read per call: tests and A/B runs switch within one process.
+int potrf_default_mode(int Np) {
+    (void)Np;
     const char* e = getenv("SLS_POTRF_MODE");
     return e ? atoi(e) : SLS_POTRF_MODE_DEFAULT;
+}
+int potrf_hybrid_nbo() {
+    const char* e = getenv("SLS_POTRF_HNBO");
+    return (e && atoi(e) >= 1) ? atoi(e) : 4;
 }
 
 // sync: >= 32 + 2 (Np / 128) ints of device scratch
@@ -657,6 +756,7 @@ void launch_potrf_persistent(hipStream_t s, double* A, int Np, double* Linv, int
     a.timeout = 20000000LL;   // 0.2 s of the 100 MHz wall clock
     a.trace = trace;
     a.nbo = potrf_persistent_nbo(Np);
+    a.j0 = 0; a.j1 = nb; a.k0 = 0; a.ext_flag = nullptr;
     hipLaunchKernelGGL(potrf_persistent_kernel, dim3(G), dim3(256), DIAG_LDS_BYTES, s, a);
 }
 
@@ -699,11 +799,82 @@ int potrf_default_nbo(int Np) {
     return Np >= 8192 ? 4 : 1;   // measured (tools/probes/potrf_bench): two-level pays from N = 8192 (10.4 -> 9.5 ms), not below
 }
 
+// A[row0.., col0 .. col0+ncols) -= L[row0.., kcol0 .. kcol0+ktiles) L[col0.., same]^T on the lower tiles (row >= col)
+static void syrk_update(hipStream_t st, double* A, long ld, int nb, int kcol0, int ktiles, int row0, int col0, int ncols) {
+    const int mt = nb - row0;
+    if (mt <= 0 || ncols <= 0) return;
+    const double* Ap = A + (long)row0 * NB + (long)kcol0 * NB * ld;
+    const double* Bp = A + (long)col0 * NB + (long)kcol0 * NB * ld;
+    double* Cp = A + (long)row0 * NB + (long)col0 * NB * ld;
+    GemmDesc u = mkdesc(Ap, ld, Bp, ld, Cp, ld, mt, ncols, ktiles * NB, -1.0, 1.0);
+    u.tri = 1;
+    u.tri_off = col0 - row0;
+    launch_tri_gemm<false, false>(st, u, 1);
+}
+
+__global__ void raise_flag_kernel(int* flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Hybrid schedule (default from N = 8192): the block columns are factored nbo at a time by the persistent kernel in PANEL
+// mode on the main stream -- a small grid (64 workgroups) that lives on the CUs the side stream's mask leaves free -- while
+// the previous block's contribution to everything beyond the current block runs as ordinary full-rate tile-GEMM launches on
+// the CU-masked side stream.  Per block B = [b0, b1):
+//   main   panel kernel: phase 0 applies block B-1 to block column b0, then steps b0 .. b1-1 (inner updates only)
+//   side   after the panel kernel (event):  columns b1+1 .. b1+nbo-1  ("next rest", then a device flag the next panel kernel
+//          waits for inside its first step),  then columns >= b1+nbo ("far rest", event).  Column b1 is phase 0 of panel B+1.
+//   main   panel B+1 starts when far rest of B-1 has finished (its columns were last written there).
+// flags: one device word per block (zeroed here).
+void launch_potrf_hybrid(hipStream_t s, double* A, int Np, double* Linv, int* info, int* sync, int* flags, PotrfAux* aux, int nbo) {
+    ensure_dyn_lds((const void*)potrf_persistent_kernel, DIAG_LDS_BYTES);
+    const int nb = Np / NB;
+    const long ld = Np;
+    const int nblocks = (nb + nbo - 1) / nbo;
+    (void)hipMemsetAsync(flags, 0, (size_t)(nblocks + 1) * sizeof(int), s);
+    hipEvent_t far_done[2] = {nullptr, nullptr};        // far rest of block B-1 / B-2 (ring of the aux events)
+    int ev_i = 0;
+    for (int B = 0, b0 = 0; b0 < nb; ++B, b0 += nbo) {
+        const int b1 = std::min(b0 + nbo, nb);
+        // the panel's columns were last written by the far rest of block B-2 (and the flags memset by nothing else)
+        if (far_done[B & 1]) (void)hipStreamWaitEvent(s, far_done[B & 1], 0);
+        (void)hipMemsetAsync(sync, 0, (size_t)(PK_FLAGS + 2 * nb) * sizeof(int), s);
+        PersistArgs a;
+        a.A = A; a.ld = Np; a.nb = nb; a.Linv = Linv; a.info = info; a.sync = sync;
+        a.nbo = nbo; a.timeout = 20000000LL; a.trace = nullptr;
+        a.j0 = b0; a.j1 = b1;                 // b1 == nb: last block, runs to the end
+        a.k0 = B > 0 ? b0 - nbo : b0;
+        a.ext_flag = (B > 0 && b1 - b0 > 1) ? flags + B : nullptr;
+        const int work = nb - b0;             // panel tiles of the first step (+ chain)
+        const int G = std::max(2, std::min(64, 1 + work));
+        hipLaunchKernelGGL(potrf_persistent_kernel, dim3(G), dim3(256), DIAG_LDS_BYTES, s, a);
+        if (b1 >= nb) break;
+        hipEvent_t panel_done = aux->ev[ev_i % PotrfAux::NEV];
+        hipEvent_t fd = aux->ev[(ev_i + 1) % PotrfAux::NEV];
+        ev_i += 2;
+        (void)hipEventRecord(panel_done, s);
+        (void)hipStreamWaitEvent(aux->side, panel_done, 0);
+        const int n1 = std::min(b1 + nbo, nb);
+        const int kt = b1 - b0;
+        // next rest: columns b1+1 .. n1-1 (rows >= column), then the flag panel B+1 polls
+        syrk_update(aux->side, A, ld, nb, b0, kt, b1 + 1, b1 + 1, n1 - (b1 + 1));
+        hipLaunchKernelGGL(raise_flag_kernel, dim3(1), dim3(1), 0, aux->side, flags + B + 1);
+        // far rest: columns >= n1
+        syrk_update(aux->side, A, ld, nb, b0, kt, n1, n1, nb - n1);
+        (void)hipEventRecord(fd, aux->side);
+        far_done[B & 1] = fd;                 // panel B+2 waits for it
+    }
+    for (hipEvent_t e : far_done)
+        if (e) (void)hipStreamWaitEvent(s, e, 0);
+}
+
 void launch_potrf(hipStream_t s, double* A, int Np, double* Linv, int* info, int nbo, PotrfAux* aux, int* persist_sync) {
     diag_attr();
     const int nb = Np / NB;
     const long ld = Np;
-    if (persist_sync && nb >= 3 && potrf_default_mode() == 1) {
+    const int mode = potrf_default_mode(Np);
+    if (persist_sync && mode == 2 && aux && aux->side && nb >= 2 * potrf_hybrid_nbo()) {
+        launch_potrf_hybrid(s, A, Np, Linv, info, persist_sync, persist_sync + PK_FLAGS + 2 * nb, aux, potrf_hybrid_nbo());
+        return;
+    }
+    if (persist_sync && nb >= 3 && mode >= 1) {
         launch_potrf_persistent(s, A, Np, Linv, info, persist_sync);
         return;
     }

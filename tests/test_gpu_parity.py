@@ -67,9 +67,9 @@ def test_cholesky_solve_inverse(ctx, oracle, N):
 
 @pytest.mark.parametrize("N", [384, 1000, 2304])
 def test_potrf_schedules_agree(N, monkeypatch):
-    """The Cholesky schedules (kernels_chol.hip): multi-launch one-level (default below N = 8192), two-level with the outer
-    update on a CU-masked side stream (default from N = 8192; forced here by SLS_POTRF_NBO), and the single-launch persistent
-    kernel (SLS_POTRF_MODE=1, with and without its two-level update).  One-level multi-launch and one-level persistent run the
+    """The Cholesky schedules (kernels_chol.hip): the single-launch persistent kernel (default; with and without its two-level
+    update), the multi-launch forms (SLS_POTRF_MODE=0: one-level, two-level, two-level with the outer update on a CU-masked
+    side stream) and the hybrid (SLS_POTRF_MODE=2: persistent panels + side-stream updates).  One-level multi-launch and one-level persistent run the
     same arithmetic per tile: identical bits.  The two-level forms sum the outer update in one k loop: agreement to rounding.
     Every variant must also reject an indefinite matrix (the persistent kernel reports through the same info word)."""
     rng = np.random.default_rng(N)
@@ -80,7 +80,8 @@ def test_potrf_schedules_agree(N, monkeypatch):
                       ("multi2", {"SLS_POTRF_MODE": "0", "SLS_POTRF_NBO": "2", "SLS_POTRF_LOOKAHEAD": "0"}),
                       ("multi2look", {"SLS_POTRF_MODE": "0", "SLS_POTRF_NBO": "2", "SLS_POTRF_LOOKAHEAD": "4"}),
                       ("persist1", {"SLS_POTRF_MODE": "1", "SLS_POTRF_PNBO": "1"}),
-                      ("persist4", {"SLS_POTRF_MODE": "1", "SLS_POTRF_PNBO": "4"})):
+                      ("persist4", {"SLS_POTRF_MODE": "1", "SLS_POTRF_PNBO": "4"}),
+                      ("hybrid2", {"SLS_POTRF_MODE": "2", "SLS_POTRF_HNBO": "2", "SLS_POTRF_LOOKAHEAD": "8"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         c = sls().Context(0)          # a fresh context: the look-ahead side stream is created per context
@@ -96,6 +97,7 @@ def test_potrf_schedules_agree(N, monkeypatch):
     assert np.array_equal(res["multi2"], res["multi2look"])        # the side stream changes the schedule, not the arithmetic
     close(res["persist4"], res["multi"], rtol=1e-12, atol=1e-13)
     close(res["multi2"], res["multi"], rtol=1e-12, atol=1e-13)
+    close(res["hybrid2"], res["multi"], rtol=1e-12, atol=1e-13)   # N = 384 (3 blocks < 2 nbo) falls back to the persistent form
 
 
 def test_potrf_rejects_indefinite(ctx):

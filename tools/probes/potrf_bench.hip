@@ -98,6 +98,12 @@ int main(int argc, char** argv) {
         };
         run(1, nullptr, "one-level (nbo=1)", true);
         run(1, nullptr, "persistent single launch", false, true);
+        if (getenv("POTRF_BENCH_HYBRID")) {
+            PotrfAux aux;
+            potrf_aux_create(&aux, 8);
+            run(1, &aux, "hybrid (mode from env)", false, true);
+            potrf_aux_destroy(&aux);
+        }
         if (getenv("POTRF_BENCH_TRACE")) {
             const int nb = Np / 128;
             long long* tr; hipMalloc(&tr, (size_t)nb * 16 * 8); hipMemset(tr, 0, (size_t)nb * 16 * 8);

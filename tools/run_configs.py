@@ -29,6 +29,10 @@ X, y, theta, b = synth_problem(oracle, D, N); Xs = synth_candidates(oracle, D, M
 gp = m.GP(ctx, X, y, theta, b, 0)
 out["C2_gp_fit_predict_N2048_D16_M4096"] = {"fit_ms_wall_incl_upload": wall(lambda: m.GP(ctx, X, y, theta, b, 0).close()),
                                             "predict_ms_wall_incl_pcie": wall(lambda: gp.predict(Xs))}
+ctx.prof_enable(True); ctx.prof_reset()
+for _ in range(3): m.GP(ctx, X, y, theta, b, 0).close()
+out["C2_gp_fit_predict_N2048_D16_M4096"]["fit_device_ms_by_stage"] = {k: ctx.prof_get(k)[0] / 3 for k in ("gram", "potrf", "trtri", "lauum")}
+ctx.prof_enable(False)
 t0 = time.perf_counter(); ref = oracle.Regressor(X, y, theta, b, kernel=0); t1 = time.perf_counter(); ref.predict_batch(Xs); t2 = time.perf_counter()
 out["C2_gp_fit_predict_N2048_D16_M4096"]["cpu_oracle_fit_s"] = t1 - t0
 out["C2_gp_fit_predict_N2048_D16_M4096"]["cpu_oracle_predict_s"] = t2 - t1
