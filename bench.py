@@ -182,24 +182,45 @@ def main():
     starts_dev = torch.from_numpy(np.ascontiguousarray(starts[:, lo:lo + S_loc].T)).to(dev)
     gp = sls.GP(ctx, X, y, theta, b, kernel_id)
 
-    comm, exchange = None, "none (1 GPU)"
+    comm, comm_ctx, exchange = None, None, "none (1 GPU)"
     if world > 1:
-        if args.backend == "nccl" and not args.same_device:
-            uid = [sls.Comm.unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            err = ""
+        try_rccl = args.backend == "nccl" and (not args.same_device or os.environ.get("SLS_BENCH_TRY_RCCL_SAME_DEVICE") == "1")
+        if try_rccl:
+            # The communicator lives on its OWN context and is created (and tried once) on a watchdog thread: if RCCL's
+            # bootstrap cannot complete on this node the measurement still happens, over the rendezvous group, and says so.
+            import threading
             try:
-                comm = sls.Comm(ctx, uid[0], rank, world)
-            except sls.SlsError as e:                    # keep the measurement alive, say so in the JSON line
-                err = str(e)
-            ok = torch.tensor([1.0 if comm is not None else 0.0], dtype=torch.float64)
+                uid = [sls.Comm.unique_id() if rank == 0 else None]
+            except sls.SlsError as e:
+                uid = [None]
+                print(f"[bench] rank 0: {e}", file=sys.stderr)
+            dist.broadcast_object_list(uid, src=0)
+            box = {}
+
+            def make():
+                try:
+                    cctx = sls.Context(local_rank)
+                    c = sls.Comm(cctx, uid[0], rank, world)
+                    v, i, x = c.allgather_best(float(rank), rank, np.full(D, float(rank)))   # highest rank wins
+                    assert (v, i) == (float(world - 1), world - 1) and x[0] == world - 1, (v, i)
+                    box["comm"], box["ctx"] = c, cctx
+                except Exception as e:                                                         # noqa: BLE001
+                    box["err"] = repr(e)
+            if uid[0] is not None:
+                t = threading.Thread(target=make, daemon=True)
+                t.start()
+                t.join(timeout=float(os.environ.get("SLS_BENCH_RCCL_TIMEOUT", "180")))
+                if t.is_alive():
+                    box["err"] = "ncclCommInitRank / first ncclAllGather did not return within the watchdog timeout"
+            else:
+                box["err"] = "RCCL could not be loaded on rank 0"
+            ok = torch.tensor([1.0 if "comm" in box and "err" not in box else 0.0], dtype=torch.float64)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if ok.item() < 1.0:
-                if comm is not None:
-                    comm.close()
-                comm = None
-                exchange = f"torch.distributed gloo all_gather (RCCL communicator unavailable on some rank: {err or 'see other ranks'})"
+                exchange = ("torch.distributed gloo all_gather (RCCL communicator unavailable on some rank: "
+                            f"{box.get('err', 'see other ranks')})")
             else:
+                comm, comm_ctx = box["comm"], box["ctx"]
                 exchange = "ncclAllGather inside libsls_hip (sls_comm_allgather_best), RCCL over xGMI"
         else:
             exchange = "torch.distributed gloo all_gather (test mode)"
@@ -301,6 +322,7 @@ def main():
         print(json.dumps(out))
     if comm is not None:
         comm.close()
+        comm_ctx.close()
     gp.close()
     ctx.close()
     if world > 1:

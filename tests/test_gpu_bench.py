@@ -52,3 +52,22 @@ def test_bench_line_contract_and_two_rank_merge():
     assert two["result"]["best_index"] == one["result"]["best_index"]
     assert two["result"]["best_value"] == one["result"]["best_value"]
     np.testing.assert_array_equal(two["result"]["best_x"], one["result"]["best_x"])
+
+
+@pytest.mark.gpu
+def test_bench_survives_an_unusable_rccl_communicator():
+    """bench.py --gpus N creates its RCCL communicator (inside libsls_hip) on a watchdog thread and tries it once before
+    the timed region.  Two ranks forced onto GPU 0 is a configuration RCCL refuses (one rank per GPU) or never completes:
+    every rank must then agree on the rendezvous group for the exchange, say so in config.exchange, and still produce the
+    single-rank answer."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", SLS_BENCH_TRY_RCCL_SAME_DEVICE="1",
+               SLS_BENCH_RCCL_TIMEOUT="30")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29631", "bench.py", "--gpus", "2", "--backend", "nccl", "--same-device"] + SMALL
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    two = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    one = run([sys.executable, "bench.py", "--gpus", "1"] + SMALL)
+    ex = two["config"]["exchange"]
+    assert ("RCCL communicator unavailable" in ex) or ("ncclAllGather inside libsls_hip" in ex), ex
+    assert two["result"]["best_index"] == one["result"]["best_index"] and two["result"]["best_value"] == one["result"]["best_value"]
