@@ -331,7 +331,7 @@ struct sls_gp {
     int best_index = 0;
     double mu_best = 0, logdet = 0;
     // evaluation workspace (grown on demand)
-    DBuf Ks, Cs, P, parts, Gs, Gm, XsT, ns, raw, outv, outg, outm, outs;
+    DBuf Ks, Cs, P, parts, Gs, Gm, Gpart, XsT, ns, raw, outv, outg, outm, outs;
     int ws_chunk = 0;
     // L-BFGS state
     DBuf pair_mu, pair_sg, pair_dmu, pair_dsg;
@@ -584,7 +584,13 @@ static void eval_candidates(sls_gp* g, const double* xr, long ldr, int S, const 
         }
         if (want_grad) {
             ProfScope ps(c, "grad_gemm");
-            launch_grad_gemm(c->stream, g->P.p, Cs, ldk, Sp, g->XT.p, g->XaT.p, Np, Np, D <= 64 ? -g->Dcols : g->Dcols, g->Gs.p, g->Gm.p);
+            double* part = nullptr;
+            if (D <= 64 && grad_gemm_wants_split(Sp)) {
+                g->Gpart.ensure((size_t)8 * Sp * 64);
+                part = g->Gpart.p;
+            }
+            launch_grad_gemm(c->stream, g->P.p, Cs, ldk, Sp, g->XT.p, g->XaT.p, Np, Np, D <= 64 ? -g->Dcols : g->Dcols, g->Gs.p, g->Gm.p,
+                             part);
         }
         {
             ProfScope ps(c, "finalize");

@@ -77,8 +77,11 @@ void launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk
 void launch_var_gemm(hipStream_t s, const double* Ks, long ldk, int Sp, const double* Linv, int Np, double* kw_part,
                      double* cw_part);
 // Gs[n + d*ldk] = sum_i P[n,i] XT[i,d] ;  Gm[n + d*ldk] = sum_i Cs[n,i] XaT[i,d]   (d < Dcols)
+// part (D <= 64 only, may be NULL): scratch of 8 * Sp * 64 doubles; used when grad_gemm_wants_split(Sp) to spread the
+// contraction of a small launch over four times as many workgroups (same bits as the unsplit form).
+inline bool grad_gemm_wants_split(int Sp) { return 2 * (Sp / 128) < 384; }   // fewer tiles than half the chip's 768 slots
 void launch_grad_gemm(hipStream_t s, const double* P, const double* Cs, long ldk, int Sp, const double* XT, const double* XaT,
-                      long ld, int Np, int Dcols, double* Gs, double* Gm);
+                      long ld, int Np, int Dcols, double* Gs, double* Gm, double* part = nullptr);
 struct FinalizeArgs {
     int S, D, nbt;            // candidates in this chunk, dims, number of 128-row tiles of i
     long ldk;                 // candidate leading dimension of this chunk

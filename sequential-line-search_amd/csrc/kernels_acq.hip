@@ -288,19 +288,37 @@ __global__ __launch_bounds__(256, 2) void grad_gemm_kernel(const double* __restr
             for (int r = 0; r < 4; ++r) C[(long)(m0 + acc_m(i)) + (long)(n0 + acc_n(j, r)) * ldk] = acc.v[i][j][r];
 }
 
-// D <= 64: 128 x 64 tiles (no wasted MFMA columns), 3 workgroups per CU
+// D <= 64: 128 x 64 tiles (no wasted MFMA columns), 3 workgroups per CU.
+// The contraction over the N training points is ALWAYS summed as four quarter ranges, ((q0 + q1) + q2) + q3, each quarter
+// accumulated from zero: one workgroup runs the four quarters back to back (gridDim.z == 1), or -- when the launch has fewer
+// tiles than the chip has workgroup slots (small active sets, the per-GPU shard of a multi-GPU run) -- four workgroups
+// take one quarter each and grad_reduce4_kernel adds the partials in that same order.  Either way the same bits, so a
+// candidate's gradient does not depend on how many other candidates share its launch.
 __global__ __launch_bounds__(256, 3) void grad_gemm64_kernel(const double* __restrict__ P, const double* __restrict__ Cs, long ldk,
                                                              int Sp, const double* __restrict__ XT, const double* __restrict__ XaT,
-                                                             long ld, int Np, double* __restrict__ Gs, double* __restrict__ Gm) {
+                                                             long ld, int Np, double* __restrict__ Gs, double* __restrict__ Gm,
+                                                             double* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
     const int m0 = blockIdx.x * GEMM_BM;
     const double* A = blockIdx.y == 0 ? P : Cs;
     const double* B = blockIdx.y == 0 ? XT : XaT;
-    double* C = blockIdx.y == 0 ? Gs : Gm;
-    Acc64 acc;
-    acc.zero();
-    gemm_tile_n64(acc, A + m0, ldk, B, ld, 0, Np, lds);
+    const bool split = gridDim.z > 1;
+    double* C = split ? part + ((long)blockIdx.z * 2 + blockIdx.y) * (long)Sp * 64 : (blockIdx.y == 0 ? Gs : Gm);
+    const long ldc = split ? (long)Sp : ldk;
+    const int q = Np / 4;                                   // Np is a multiple of 128: quarters are multiples of 32
+    Acc64 tot;
+    tot.zero();
+    const int c0 = split ? blockIdx.z : 0, c1 = split ? blockIdx.z + 1 : 4;
+    for (int c = c0; c < c1; ++c) {
+        Acc64 acc;
+        acc.zero();
+        gemm_tile_n64(acc, A + m0, ldk, B, ld, c * q, (c + 1) * q, lds);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tot.v[i][j] = (c == c0) ? acc.v[i][j] : tot.v[i][j] + acc.v[i][j];
+    }
     const int lane = threadIdx.x & 63, wm = (threadIdx.x >> 6) * 32;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -308,16 +326,33 @@ __global__ __launch_bounds__(256, 3) void grad_gemm64_kernel(const double* __res
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                C[(long)(m0 + wm + 16 * i + (lane & 15)) + (long)(16 * j + (lane >> 4) + 4 * r) * ldk] = acc.v[i][j][r];
+                C[(long)(m0 + wm + 16 * i + (lane & 15)) + (long)(16 * j + (lane >> 4) + 4 * r) * ldc] = tot.v[i][j][r];
+}
+
+__global__ __launch_bounds__(256) void grad_reduce4_kernel(const double* __restrict__ part, int Sp, long ldk, double* __restrict__ Gs,
+                                                           double* __restrict__ Gm) {
+    const long idx = blockIdx.x * 256L + threadIdx.x;       // n + d * Sp, d < 64
+    if (idx >= (long)Sp * 64) return;
+    const long n = idx % Sp, d = idx / Sp;
+    const long stride = (long)Sp * 64;
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+        const double* p = part + (long)y * stride + idx;
+        const double v = ((p[0] + p[2 * stride]) + p[4 * stride]) + p[6 * stride];
+        (y == 0 ? Gs : Gm)[n + d * ldk] = v;
+    }
 }
 
 void launch_grad_gemm(hipStream_t s, const double* P, const double* Cs, long ldk, int Sp, const double* XT, const double* XaT,
-                      long ld, int Np, int Dcols, double* Gs, double* Gm) {
+                      long ld, int Np, int Dcols, double* Gs, double* Gm, double* part) {
     ensure_dyn_lds((const void*)grad_gemm_kernel, GEMM_LDS_BYTES);
     ensure_dyn_lds((const void*)grad_gemm64_kernel, GEMM_N64_LDS_BYTES);
     if (Dcols < 0) {   // caller signals D <= 64 by passing -Dcols
-        hipLaunchKernelGGL(grad_gemm64_kernel, dim3(Sp / GEMM_BM, 2), dim3(GEMM_THREADS), GEMM_N64_LDS_BYTES, s, P, Cs, ldk, Sp, XT,
-                           XaT, ld, Np, Gs, Gm);
+        const bool split = part != nullptr && grad_gemm_wants_split(Sp);
+        hipLaunchKernelGGL(grad_gemm64_kernel, dim3(Sp / GEMM_BM, 2, split ? 4 : 1), dim3(GEMM_THREADS), GEMM_N64_LDS_BYTES, s, P, Cs,
+                           ldk, Sp, XT, XaT, ld, Np, Gs, Gm, part);
+        if (split)
+            hipLaunchKernelGGL(grad_reduce4_kernel, dim3((unsigned)(((long)Sp * 64 + 255) / 256)), dim3(256), 0, s, part, Sp, ldk, Gs, Gm);
         return;
     }
     const int nt = (Sp / GEMM_BM) * (Dcols / GEMM_BN);
