@@ -14,7 +14,7 @@ import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsls_hip.so")
+LIB_PATH = os.environ.get("SLS_HIP_LIB") or os.path.join(_HERE, "libsls_hip.so")   # SLS_HIP_LIB: A/B runs of another build
 
 KERNEL_SE, KERNEL_MATERN52 = 0, 1
 ACQ_EI, ACQ_UCB = 0, 1

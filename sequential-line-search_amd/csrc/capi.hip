@@ -529,7 +529,7 @@ static void ensure_eval_ws(sls_gp* g, int chunk) {
     g->Ks.ensure(C * Np);
     if (g->kernel == SLS_KERNEL_ARD_MATERN52) g->Cs.ensure(C * Np);
     g->P.ensure(C * Np);
-    g->parts.ensure(4 * nbt * C);
+    g->parts.ensure(6 * nbt * C);   // mu, ca: one per row tile; kw, cw: one per half row tile
     g->Gs.ensure(C * g->Dcols);
     g->Gm.ensure(C * g->Dcols);
     g->XsT.ensure(C * g->Dcols);
@@ -568,17 +568,18 @@ static void eval_candidates(sls_gp* g, const double* xr, long ldr, int S, const 
         double* mu_part = g->parts.p;
         double* ca_part = mu_part + (size_t)nbt * ldk;
         double* kw_part = ca_part + (size_t)nbt * ldk;
-        double* cw_part = kw_part + (size_t)nbt * ldk;
+        double* cw_part = kw_part + (size_t)2 * nbt * ldk;
         {
             ProfScope ps(c, "cross_gram");
             launch_prep_cands(c->stream, xr + s0, ldr, D, sc, g->inv_ell.p, g->XsT.p, ldk, Sp, g->Dcols, g->ns.p);
             launch_cross_gram(c->stream, g->XsT.p, ldk, g->ns.p, Sp, g->XT.p, Np, g->nx.p, Np, N, g->Dp, ks, g->alpha.p, g->Ks.p, Cs,
                               ldk, mu_part, ca_part);
         }
+        int split_first = 0x7fffffff;
         {
             ProfScope ps(c, want_grad ? "acq_gemm" : "var_gemm");
             if (want_grad || !tri_predict())
-                launch_acq_gemm(c->stream, g->Ks.p, Cs, ldk, Sp, g->Kinv.p, Np, g->P.p, kw_part, cw_part, c->d_info + 32);
+                split_first = launch_acq_gemm(c->stream, g->Ks.p, Cs, ldk, Sp, g->Kinv.p, Np, g->P.p, kw_part, cw_part, c->d_info + 32);
             else
                 launch_var_gemm(c->stream, g->Ks.p, ldk, Sp, g->Linv.p, Np, kw_part, cw_part);
         }
@@ -595,7 +596,7 @@ static void eval_candidates(sls_gp* g, const double* xr, long ldr, int S, const 
         {
             ProfScope ps(c, "finalize");
             FinalizeArgs f;
-            f.S = sc; f.D = D; f.nbt = nbt; f.ldk = ldk;
+            f.S = sc; f.D = D; f.nbt = nbt; f.ldk = ldk; f.ntm = Sp / 128; f.split_first = split_first;
             f.mu_part = mu_part; f.ca_part = ca_part; f.kw_part = kw_part; f.cw_part = cw_part;
             f.Gs = g->Gs.p; f.Gm = g->Gm.p; f.XsT = g->XsT.p; f.inv_ell = g->inv_ell.p;
             f.a = g->a; f.mu_best = g->mu_best; f.ucb_h = o.ucb_h; f.acq = o.acq;

@@ -106,15 +106,19 @@ __device__ __forceinline__ void slab_row_to_lds(const double* g, double* l) {
 // The k loop starts at slab `kfirst` (kb <= kfirst < ke, multiple of 16) and wraps around at ke: tiles that share an
 // operand panel are started a slab apart so that their global loads of one slab do not miss the L2 simultaneously.
 // `lds` is the 73728-byte, 16-byte aligned dynamic LDS block.
-template <bool A_KC, bool B_KC>
+// NJ = 4: the whole 128 x 128 tile (wave (wm, wn) owns a 64 x 64 quadrant).  NJ = 2: only the 64 columns [64 nhalf, 64 nhalf
+// + 64) of it -- wave (wm, sub) owns 64 x 32 at column 64 nhalf + 32 sub, accumulators acc.v[i][0..1] -- with the same slabs,
+// the same fragment layout and the same k order, so every element gets the bits the full tile would give it at half the
+// MFMA work per workgroup (used to split the tiles of a partially filled last generation over twice as many workgroups).
+template <bool A_KC, bool B_KC, int NJ = 4>
 __device__ __forceinline__ void gemm_tile(Acc& acc, const double* __restrict__ A, long lda,
                                           const double* __restrict__ B, long ldb, int kb, int ke, double* lds,
-                                          int kfirst = -1) {
+                                          int kfirst = -1, int nhalf = 0) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = (wave & 1) * 64;   // wave's m offset inside the tile
-    const int wn = (wave >> 1) * 64;  // wave's n offset
+    const int wn = NJ == 4 ? (wave >> 1) * 64 : 64 * nhalf + (wave >> 1) * 32;  // wave's n offset
     if (kb >= ke) return;
     if (kfirst < kb || kfirst >= ke) kfirst = kb;
 
@@ -169,15 +173,15 @@ __device__ __forceinline__ void gemm_tile(Acc& acc, const double* __restrict__ A
         const double* lb = lds + cur + GEMM_LDS_TILE;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            double af[4], bf[4];
+            double af[4], bf[NJ];
 #pragma unroll
             for (int i = 0; i < 4; ++i) af[i] = frag_read<A_KC>(la, wm + 16 * i, kk, lane);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bf[j] = frag_read<B_KC>(lb, wn + 16 * j, kk, lane);
+            for (int j = 0; j < NJ; ++j) bf[j] = frag_read<B_KC>(lb, wn + 16 * j, kk, lane);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NJ; ++j)
                     acc.v[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc.v[i][j], 0, 0, 0);
         }
         const int nxt = cur ^ (2 * GEMM_LDS_TILE);

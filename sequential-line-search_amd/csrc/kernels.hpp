@@ -71,8 +71,10 @@ void launch_nll_small(hipStream_t s, int kernel, const NllSmallArgs& args);
 
 // ---- kernels_acq.hip ---------------------------------------------------------
 // P[n + i*ldk] = Cs * (Kinv Ks)  and the partial column sums kw_part (Ks.*W), cw_part (Cs.*W) per 128-row tile of i.
-void launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk, int Sp, const double* Kinv, int Np, double* P,
-                     double* kw_part, double* cw_part, int* sync = nullptr);
+// kw_part / cw_part: [2 tn + half][candidate] (whole tiles use the even slot).  Returns the index (in the kernel's grouped tile
+// order) of the first tile that ran as two half tiles (= the tile count if none): FinalizeArgs::split_first.
+int launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk, int Sp, const double* Kinv, int Np, double* P,
+                    double* kw_part, double* cw_part, int* sync = nullptr);
 // kw_part = per-tile partial sums of (Linv Ks)^2 (triangular contraction), cw_part = 0: the no-gradient form of acq_gemm
 void launch_var_gemm(hipStream_t s, const double* Ks, long ldk, int Sp, const double* Linv, int Np, double* kw_part,
                      double* cw_part);
@@ -84,6 +86,7 @@ void launch_grad_gemm(hipStream_t s, const double* P, const double* Cs, long ldk
                       long ld, int Np, int Dcols, double* Gs, double* Gm, double* part = nullptr);
 struct FinalizeArgs {
     int S, D, nbt;            // candidates in this chunk, dims, number of 128-row tiles of i
+    int ntm, split_first;     // candidate tiles of the chunk; first half-split tile of launch_acq_gemm (INT_MAX: none)
     long ldk;                 // candidate leading dimension of this chunk
     const double *mu_part, *ca_part, *kw_part, *cw_part, *Gs, *Gm, *XsT, *inv_ell;
     double a, mu_best, ucb_h;

@@ -18,8 +18,13 @@ namespace slsk {
 // acq_gemm: tile = 128 candidates (m) x 128 rows of K^-1 (n').  acc = W = (K^-1 K*)^T tile.
 // Epilogue: P = C* .* W stored candidate-major; per-tile partial sums over n' of K*.*W and C*.*W.
 // ---------------------------------------------------------------------------------------------------------
-template <bool MATERN>
-__device__ __forceinline__ void acq_tile(int t, int ntm, int ntn, const double* __restrict__ Ks, const double* __restrict__ Cs,
+// HALF = false: the whole tile.  HALF = true: its 64 K^-1 rows [64 nhalf, 64 nhalf + 64) only (see gemm_tile NJ = 2).
+// Partial sums over the K^-1 rows are formed in ONE fixed order whichever form computes them: per lane a running sum over
+// its 16 elements of a 64-row half in (j, r) order, then the two cross-lane steps; the sum of a tile is half 0 + half 1 --
+// added in the tile kernel (whole tile: slot 2 tn holds the sum, slot 2 tn + 1 zero) or by finalize (half tiles: one slot
+// each), the same addition either way: a candidate's sums do not depend on whether its tile ran whole or as two halves.
+template <bool MATERN, bool HALF>
+__device__ __forceinline__ void acq_tile(int t, int nhalf, int ntm, int ntn, const double* __restrict__ Ks, const double* __restrict__ Cs,
                                          long ldk, const double* __restrict__ Kinv, int Np, double* __restrict__ P,
                                          double* __restrict__ kw_part, double* __restrict__ cw_part, int stagger, double* lds) {
     // grouped order: 8 candidate tiles x all K^-1 row tiles, so the 64 tiles resident on one XCD share panels in L2
@@ -36,18 +41,30 @@ __device__ __forceinline__ void acq_tile(int t, int ntm, int ntn, const double* 
     // summation order of a candidate's row must not depend on which tile position (tm) the candidate occupies, or the
     // active-set compaction of the maximiser would change its bits.  Measured effect on time: none; off by default.
     const int ks = stagger ? (tn & 15) * GEMM_BK : 0;
-    gemm_tile<false, false>(acc, Ks + m0, ldk, Kinv + n0, (long)Np, 0, Np, lds, ks);
+    gemm_tile<false, false, HALF ? 2 : 4>(acc, Ks + m0, ldk, Kinv + n0, (long)Np, 0, Np, lds, ks, nhalf);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NJ = HALF ? 2 : 4;
+    const int nbase = HALF ? 64 * nhalf + (wave >> 1) * 32 : (wave >> 1) * 64;
+    double* red = lds;
+    double* ex = lds + 1024;                          // half tile: [which][wm wave][i][lane] running sums handed lo -> hi
+    // Per lane ONE running sum over the 16 elements of a 64-row half in (j, r) order.  In a half tile those 16 elements sit in
+    // two waves (rows 0..31: wave >> 1 = 0, rows 32..63: wave >> 1 = 1, same lane positions): the second continues the first's
+    // running sums, handed over through LDS, so the order of additions is the whole tile's.
+    if (HALF && (wave >> 1) == 1) __syncthreads();    // wait for the lo waves' sums (they hit the matching barrier below)
     double skw[4], scw[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const long gm_ = m0 + acc_m(i);
         double pk = 0.0, pc = 0.0;
+        if (HALF && (wave >> 1) == 1) {
+            pk = ex[((0 * 2 + (wave & 1)) * 4 + i) * 64 + lane];
+            pc = ex[((1 * 2 + (wave & 1)) * 4 + i) * 64 + lane];
+        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const long off = gm_ + (long)(n0 + acc_n(j, r)) * ldk;
+                const long off = gm_ + (long)(n0 + nbase + 16 * j + (lane >> 4) + 4 * r) * ldk;
                 const double wv = acc.v[i][j][r];
                 const double k = Ks[off];
                 const double c = MATERN ? Cs[off] : k;
@@ -56,9 +73,14 @@ __device__ __forceinline__ void acq_tile(int t, int ntm, int ntn, const double* 
                 pc += p;
                 if (MATERN) pk += k * wv;
             }
+        if (HALF && (wave >> 1) == 0) {
+            ex[((0 * 2 + (wave & 1)) * 4 + i) * 64 + lane] = pk;
+            ex[((1 * 2 + (wave & 1)) * 4 + i) * 64 + lane] = pc;
+        }
         scw[i] = pc;
         skw[i] = MATERN ? pk : pc;
     }
+    if (HALF && (wave >> 1) == 0) __syncthreads();    // publish the lo sums
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         skw[i] += __shfl_xor(skw[i], 16);
@@ -66,46 +88,42 @@ __device__ __forceinline__ void acq_tile(int t, int ntm, int ntn, const double* 
         scw[i] += __shfl_xor(scw[i], 16);
         scw[i] += __shfl_xor(scw[i], 32);
     }
-    double* red = lds;
-    if (lane < 16) {
+    if (lane < 16 && (!HALF || (wave >> 1) == 1)) {   // half tile: the hi waves hold the half's sums
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int ml = (wave & 1) * 64 + 16 * i + lane;
-            red[((wave >> 1) * 2 + 0) * 128 + ml] = skw[i];
-            red[((wave >> 1) * 2 + 1) * 128 + ml] = scw[i];
+            const int slot = HALF ? 0 : (wave >> 1);
+            red[(slot * 2 + 0) * 128 + ml] = skw[i];
+            red[(slot * 2 + 1) * 128 + ml] = scw[i];
         }
     }
     __syncthreads();
     if (threadIdx.x < 128) {
         const int ml = threadIdx.x;
-        kw_part[(long)tn * ldk + m0 + ml] = red[0 * 128 + ml] + red[2 * 128 + ml];
-        cw_part[(long)tn * ldk + m0 + ml] = red[1 * 128 + ml] + red[3 * 128 + ml];
+        if (HALF) {
+            kw_part[(long)(2 * tn + nhalf) * ldk + m0 + ml] = red[0 * 128 + ml];
+            cw_part[(long)(2 * tn + nhalf) * ldk + m0 + ml] = red[1 * 128 + ml];
+        } else {
+            // whole tile: the two halves' sums added here, into the even slot (finalize ignores the odd slot of a whole tile)
+            kw_part[(long)(2 * tn + 0) * ldk + m0 + ml] = red[0 * 128 + ml] + red[2 * 128 + ml];
+            cw_part[(long)(2 * tn + 0) * ldk + m0 + ml] = red[1 * 128 + ml] + red[3 * 128 + ml];
+        }
     }
 }
 
-// The persistent, generation-gated form (default) or one tile per workgroup (sync == nullptr, SLS_PERSIST=0).
-// Persistent: gridDim.x = 8 * slots workgroups, all resident (slots = 2 per CU x 32 CUs per XCD), workgroup b = slot b>>3 of
-// XCD b&7.  Generation i of XCD x is the 64-tile chunk x + 8 i (an 8 x 8 block of tiles sharing 16 operand panels); the 64
-// slots of an XCD start each generation together, gated by a per-XCD counter of finished tiles.  Panel sharing through the
-// 4 MB L2 only works while the co-resident sharers of a panel are within ~16 slabs of each other in k; the gate enforces
-// that (PMC: hit rate 0.80-0.86 in every run) where the ungated form depends on how far the tiles of an XCD drift apart
-// (hit rates 0.37-0.85, 80-350 GB per 65 536-candidate launch observed across builds with an identical k loop; 0.42 / 333 GB
-// with the LDS-direct loads).  One gate per XCD costs ~1 % kernel time: both workgroups of a CU then run their epilogues
-// at the same moment instead of hiding them behind each other's MFMA loop; two phase-shifted gate groups (below) recover
-// it.  The wait is a bounded spin: the
-// gate is a locality hint, not a correctness requirement, and an unexpected residency pattern cannot hang the device.
+// ntiles: the tiles this launch runs as whole tiles (the first ntiles of the grouped order); a partially filled last
+// generation goes to acq_gemm_half_kernel instead (launch_acq_gemm).
 template <bool MATERN>
 __global__ __launch_bounds__(256, 2) void acq_gemm_kernel(const double* __restrict__ Ks, const double* __restrict__ Cs, long ldk,
                                                           int Sp, const double* __restrict__ Kinv, int Np,
                                                           double* __restrict__ P, double* __restrict__ kw_part,
                                                           double* __restrict__ cw_part, int stagger, int* __restrict__ sync,
-                                                          int phase) {
+                                                          int phase, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
     const int ntm = Sp / GEMM_BM, ntn = Np / GEMM_BN;
-    const int ntiles = ntm * ntn;
     if (sync == nullptr) {
-        acq_tile<MATERN>(xcd_remap(blockIdx.x, ntiles), ntm, ntn, Ks, Cs, ldk, Kinv, Np, P, kw_part, cw_part, stagger, lds);
+        acq_tile<MATERN, false>(xcd_remap(blockIdx.x, ntiles), 0, ntm, ntn, Ks, Cs, ldk, Kinv, Np, P, kw_part, cw_part, stagger, lds);
         return;
     }
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
@@ -138,16 +156,32 @@ __global__ __launch_bounds__(256, 2) void acq_gemm_kernel(const double* __restri
             __syncthreads();
         }
         const int t = c * slots + slot;
-        if (t < ntiles) acq_tile<MATERN>(t, ntm, ntn, Ks, Cs, ldk, Kinv, Np, P, kw_part, cw_part, stagger, lds);
+        if (t < ntiles) acq_tile<MATERN, false>(t, 0, ntm, ntn, Ks, Cs, ldk, Kinv, Np, P, kw_part, cw_part, stagger, lds);
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_fetch_add(gate, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-void launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk, int Sp, const double* Kinv, int Np, double* P,
-                     double* kw_part, double* cw_part, int* sync) {
+// The partially filled LAST generation (at most half of the 512 workgroup slots would hold a tile): its tiles
+// [tail_first, tail_first + gridDim.x / 2) run as half tiles on twice as many workgroups, unit u = tile u / 2, half u & 1.
+template <bool MATERN>
+__global__ __launch_bounds__(256, 2) void acq_gemm_half_kernel(const double* __restrict__ Ks, const double* __restrict__ Cs, long ldk,
+                                                               int Sp, const double* __restrict__ Kinv, int Np,
+                                                               double* __restrict__ P, double* __restrict__ kw_part,
+                                                               double* __restrict__ cw_part, int stagger, int tail_first) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* lds = reinterpret_cast<double*>(smem);
+    const int u = xcd_remap(blockIdx.x, gridDim.x);
+    acq_tile<MATERN, true>(tail_first + (u >> 1), u & 1, Sp / GEMM_BM, Np / GEMM_BN, Ks, Cs, ldk, Kinv, Np, P, kw_part, cw_part, stagger,
+                           lds);
+}
+
+int launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk, int Sp, const double* Kinv, int Np, double* P,
+                    double* kw_part, double* cw_part, int* sync) {
     ensure_dyn_lds((const void*)acq_gemm_kernel<false>, GEMM_LDS_BYTES);
     ensure_dyn_lds((const void*)acq_gemm_kernel<true>, GEMM_LDS_BYTES);
+    ensure_dyn_lds((const void*)acq_gemm_half_kernel<false>, GEMM_LDS_BYTES);
+    ensure_dyn_lds((const void*)acq_gemm_half_kernel<true>, GEMM_LDS_BYTES);
     const int nt = (Sp / GEMM_BM) * (Np / GEMM_BN);
     // SLS_STAGGER (0 default: plain k loop, 1: staggered by tn) and SLS_PERSIST (1 default: gated form, 0 one tile per
     // workgroup) are read per call so that tests and A/B runs can switch within one process
@@ -163,19 +197,39 @@ void launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk
     // persistent, generation-gated form when there are at least two generations of tiles (MI355X: 256 CUs x 2 = 512 slots)
     const bool persist = persist_env && sync && nt >= 1024 && Np >= 2048;
     const int stagger = stagger_env != 0 ? 1 : 0;
+    // Tail split (SLS_TAIL_SPLIT=0 disables): the chip holds 512 tiles at a time; if the last such generation is at most half
+    // full its tiles run as half tiles on twice the workgroups in a second launch (same bits, half the time for that
+    // generation: 663 -> 642 ms per step on the 8 192-start shard of an 8-GPU run).
+    const char* et = getenv("SLS_TAIL_SPLIT");
+    const bool tail_ok = et ? atoi(et) != 0 : true;
+    const int rem = nt % 512;
+    const int tail = (tail_ok && rem > 0 && rem <= 256) ? rem : 0;
+    const int nmain = nt - tail;
     int* sy = nullptr;
-    int grid = nt;
-    if (persist) {
+    int grid = nmain;
+    if (persist && nmain >= 1024) {
         (void)hipMemsetAsync(sync, 0, 16 * sizeof(int), s);
         sy = sync;
         grid = 512;
     }
-    if (Cs != Ks)
-        hipLaunchKernelGGL(acq_gemm_kernel<true>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, Ks, Cs, ldk, Sp, Kinv, Np, P,
-                           kw_part, cw_part, stagger, sy, phase);
-    else
-        hipLaunchKernelGGL(acq_gemm_kernel<false>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, Ks, Cs, ldk, Sp, Kinv, Np, P,
-                           kw_part, cw_part, stagger, sy, phase);
+    const bool matern = Cs != Ks;
+    if (nmain > 0) {
+        if (matern)
+            hipLaunchKernelGGL(acq_gemm_kernel<true>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, Ks, Cs, ldk, Sp, Kinv, Np, P,
+                               kw_part, cw_part, stagger, sy, phase, nmain);
+        else
+            hipLaunchKernelGGL(acq_gemm_kernel<false>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, Ks, Cs, ldk, Sp, Kinv, Np, P,
+                               kw_part, cw_part, stagger, sy, phase, nmain);
+    }
+    if (tail > 0) {
+        if (matern)
+            hipLaunchKernelGGL(acq_gemm_half_kernel<true>, dim3(2 * tail), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, Ks, Cs, ldk, Sp, Kinv,
+                               Np, P, kw_part, cw_part, stagger, nmain);
+        else
+            hipLaunchKernelGGL(acq_gemm_half_kernel<false>, dim3(2 * tail), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, Ks, Cs, ldk, Sp, Kinv,
+                               Np, P, kw_part, cw_part, stagger, nmain);
+    }
+    return nmain;   // tiles [nmain, nt) ran as two halves
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -212,8 +266,8 @@ __device__ __forceinline__ void var_tile(int tm, int tn, const double* __restric
     __syncthreads();
     if (threadIdx.x < 128) {
         const int ml = threadIdx.x;
-        kw_part[(long)tn * ldk + m0 + ml] = red[ml] + red[128 + ml];
-        cw_part[(long)tn * ldk + m0 + ml] = 0.0;
+        kw_part[(long)(2 * tn) * ldk + m0 + ml] = red[ml] + red[128 + ml];   // even slot of acq_gemm's layout (whole tile)
+        cw_part[(long)(2 * tn) * ldk + m0 + ml] = 0.0;
     }
     __syncthreads();
 }
@@ -367,12 +421,21 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs p) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= p.S) return;
     double mu = 0.0, ca = 0.0, kw = 0.0, cw = 0.0;
+    const int tm_ = n >> 7, grp_ = tm_ >> 3;
+    const int gm_ = min(8, p.ntm - 8 * grp_);
+    const int tile_base = grp_ * 8 * p.nbt + (tm_ - 8 * grp_);       // tile index = tile_base + t * gm_ (acq_tile's order)
     #pragma unroll 8
     for (int t = 0; t < p.nbt; ++t) {
         mu += p.mu_part[(long)t * p.ldk + n];
         ca += p.ca_part[(long)t * p.ldk + n];
-        kw += p.kw_part[(long)t * p.ldk + n];
-        cw += p.cw_part[(long)t * p.ldk + n];
+        // tile (tm, t) in acq_gemm's grouped order; the tiles from split_first on ran as two halves (one slot each)
+        double kt = p.kw_part[(long)(2 * t) * p.ldk + n], ct = p.cw_part[(long)(2 * t) * p.ldk + n];
+        if (tile_base + t * gm_ >= p.split_first) {
+            kt += p.kw_part[(long)(2 * t + 1) * p.ldk + n];
+            ct += p.cw_part[(long)(2 * t + 1) * p.ldk + n];
+        }
+        kw += kt;
+        cw += ct;
     }
     const double s2 = p.a - kw;
     const double sigma = s2 < 0.0 ? 0.0 : sqrt(s2);   // gaussian-process-regressor.cpp:253-254

@@ -210,6 +210,30 @@ def test_acq_gemm_scheduling_variants_agree(ctx, oracle, kernel, monkeypatch):
     gp.close()
 
 
+@pytest.mark.parametrize("M", [100, 4736, 8960])
+def test_acq_gemm_tail_split_is_bit_identical(ctx, oracle, M, monkeypatch):
+    """When the last 512-tile generation of an acq_gemm launch is at most half full its tiles run as HALF tiles on twice as
+    many workgroups (SLS_TAIL_SPLIT, default on).  Values and gradients must be bit-identical to the unsplit schedule: M = 100
+    (16 tiles, all split), 4736 (592 tiles, one-tile-per-workgroup form, 80 in the tail), 8960 (1120 tiles, persistent gated
+    form, 96 in the tail), N = 2048."""
+    D, N = 16, 2048
+    X, y, theta, b = synth_problem(oracle, D, N)
+    Xs = synth_candidates(oracle, D, M)
+    monkeypatch.setenv("SLS_WAVE_PATH", "0")
+    gp = sls().GP(ctx, X, y, theta, b, 1)
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SLS_TAIL_SPLIT", flag)
+        out[flag] = gp.acq_eval(Xs) + gp.predict_grad(Xs)
+    for a_, b_ in zip(out["1"], out["0"]):
+        assert np.array_equal(a_, b_)
+    ref = oracle.Regressor(X, y, theta, b, kernel=1)
+    v_o, g_o = ref.acq_eval_batch(Xs[:, -64:])
+    np.testing.assert_allclose(out["1"][0][-64:], v_o, rtol=1e-6, atol=1e-9 * np.abs(v_o).max())
+    np.testing.assert_allclose(out["1"][1][:, -64:], g_o, rtol=1e-6, atol=1e-7 * np.abs(g_o).max())
+    gp.close()
+
+
 def test_beyond_headline_size_n16384(ctx, oracle):
     """Twice the headline N (N = 16 384: 2 GB per N x N matrix, 128 block steps of the Cholesky, 7 trtri levels): the
     size-independent posterior identities must still hold; the predictions here take the triangular var_gemm path on its
