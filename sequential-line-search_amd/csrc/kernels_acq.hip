@@ -544,20 +544,27 @@ void launch_clamp_starts(hipStream_t s, const double* starts, int D, int S, doub
     hipLaunchKernelGGL(clamp_starts_kernel, dim3((Sp + 255) / 256), dim3(256), 0, s, starts, D, S, xt, ld, Sp);
 }
 
-__global__ __launch_bounds__(256) void lbfgs_step_kernel(LbfgsState st, const double* __restrict__ val,
+__global__ __launch_bounds__(64) void lbfgs_step_kernel(LbfgsState st, const double* __restrict__ val,
                                                          const double* __restrict__ grad, int first) {
-    const int j = blockIdx.x * 256 + threadIdx.x;   // column of (val, grad)
+    const int j = blockIdx.x * 64 + threadIdx.x;     // column of (val, grad); 64-thread workgroups: small active sets spread over
+                                                      // 4x as many CUs (the kernel is bound by per-CU memory throughput)
     if (j >= st.nlive) return;
     const int n = st.live ? st.live[j] : j;          // the start it belongs to
     const long ld = st.ld, ldv = st.ldv;
     const int D = st.D, m = st.m;
+    // the state arrays are distinct buffers: restrict-qualified views let the compiler issue a pass's loads together instead
+    // of ordering every load behind the previous store (350 us per call at 8 192 starts were ~64 serialised round trips
+    // per pass of the two-loop recursion)
+    double* __restrict__ x_ = st.x; double* __restrict__ g_ = st.g; double* __restrict__ dir_ = st.dir;
+    double* __restrict__ xt_ = st.xt; double* __restrict__ scr_ = st.scr;
+    double* __restrict__ ShA = st.Sh; double* __restrict__ YhA = st.Yh;
     bool need_dir = false;
     if (first) {
         st.f[n] = -val[j];
         #pragma unroll 8
         for (int d = 0; d < D; ++d) {
-            st.x[n + d * ld] = st.xt[n + d * ld];
-            st.g[n + d * ld] = -grad[j + d * ldv];
+            x_[n + d * ld] = xt_[n + d * ld];
+            g_[n + d * ld] = -grad[j + d * ldv];
         }
         st.hlen[n] = 0; st.hpos[n] = 0; st.nbt[n] = 0; st.done[n] = 0; st.t[n] = 1.0;
         need_dir = true;
@@ -567,20 +574,20 @@ __global__ __launch_bounds__(256) void lbfgs_step_kernel(LbfgsState st, const do
         double gs = 0.0, ss = 0.0;
         #pragma unroll 8
         for (int d = 0; d < D; ++d) {
-            const double sd = st.xt[n + d * ld] - st.x[n + d * ld];
-            gs += st.g[n + d * ld] * sd;
+            const double sd = xt_[n + d * ld] - x_[n + d * ld];
+            gs += g_[n + d * ld] * sd;
             ss += sd * sd;
         }
         if (ss == 0.0) { st.done[n] = 1; return; }
         if (ft <= st.f[n] + st.c1 * gs) {
             double sy = 0.0, yy = 0.0;
             const int idx = st.hpos[n];
-            double* Sh = st.Sh + (long)idx * D * ld;
-            double* Yh = st.Yh + (long)idx * D * ld;
+            double* __restrict__ Sh = ShA + (long)idx * D * ld;
+            double* __restrict__ Yh = YhA + (long)idx * D * ld;
             #pragma unroll 8
             for (int d = 0; d < D; ++d) {
-                const double sd = st.xt[n + d * ld] - st.x[n + d * ld];
-                const double yd = -grad[j + d * ldv] - st.g[n + d * ld];
+                const double sd = xt_[n + d * ld] - x_[n + d * ld];
+                const double yd = -grad[j + d * ldv] - g_[n + d * ld];
                 Sh[n + d * ld] = sd;
                 Yh[n + d * ld] = yd;
                 sy += sd * yd;
@@ -593,8 +600,8 @@ __global__ __launch_bounds__(256) void lbfgs_step_kernel(LbfgsState st, const do
             }
             #pragma unroll 8
             for (int d = 0; d < D; ++d) {
-                st.x[n + d * ld] = st.xt[n + d * ld];
-                st.g[n + d * ld] = -grad[j + d * ldv];
+                x_[n + d * ld] = xt_[n + d * ld];
+                g_[n + d * ld] = -grad[j + d * ldv];
             }
             st.f[n] = ft;
             need_dir = true;
@@ -611,11 +618,11 @@ __global__ __launch_bounds__(256) void lbfgs_step_kernel(LbfgsState st, const do
         double pgmax = 0.0, pgn2 = 0.0;
         #pragma unroll 8
         for (int d = 0; d < D; ++d) {
-            double v = st.g[n + d * ld];
-            const double xv = st.x[n + d * ld];
+            double v = g_[n + d * ld];
+            const double xv = x_[n + d * ld];
             if ((xv <= 0.0 && v > 0.0) || (xv >= 1.0 && v < 0.0)) v = 0.0;
-            st.scr[n + d * ld] = v;
-            st.dir[n + d * ld] = v;
+            scr_[n + d * ld] = v;
+            dir_[n + d * ld] = v;
             pgmax = fmax(pgmax, fabs(v));
             pgn2 += v * v;
         }
@@ -630,21 +637,21 @@ __global__ __launch_bounds__(256) void lbfgs_step_kernel(LbfgsState st, const do
                 al[h] = 0.0;
                 if (h < hlen) {
                     const int idx = (hpos - 1 - h + 2 * m) % m;
-                    const double* Sh = st.Sh + (long)idx * D * ld;
-                    const double* Yh = st.Yh + (long)idx * D * ld;
+                    const double* __restrict__ Sh = ShA + (long)idx * D * ld;
+                    const double* __restrict__ Yh = YhA + (long)idx * D * ld;
                     double dot = 0.0;
                     #pragma unroll 8
-                    for (int d = 0; d < D; ++d) dot += Sh[n + d * ld] * st.dir[n + d * ld];
+                    for (int d = 0; d < D; ++d) dot += Sh[n + d * ld] * dir_[n + d * ld];
                     al[h] = st.rho[(long)idx * ld + n] * dot;
                     #pragma unroll 8
-                    for (int d = 0; d < D; ++d) st.dir[n + d * ld] -= al[h] * Yh[n + d * ld];
+                    for (int d = 0; d < D; ++d) dir_[n + d * ld] -= al[h] * Yh[n + d * ld];
                 }
             }
             double gamma;
             if (hlen > 0) {
                 const int idx = (hpos - 1 + m) % m;
-                const double* Sh = st.Sh + (long)idx * D * ld;
-                const double* Yh = st.Yh + (long)idx * D * ld;
+                const double* __restrict__ Sh = ShA + (long)idx * D * ld;
+                const double* __restrict__ Yh = YhA + (long)idx * D * ld;
                 double sy = 0.0, yy = 0.0;
                 #pragma unroll 8
                 for (int d = 0; d < D; ++d) {
@@ -657,27 +664,27 @@ __global__ __launch_bounds__(256) void lbfgs_step_kernel(LbfgsState st, const do
                 gamma = 1.0 / (nn > 1.0 ? nn : 1.0);
             }
             #pragma unroll 8
-            for (int d = 0; d < D; ++d) st.dir[n + d * ld] *= gamma;
+            for (int d = 0; d < D; ++d) dir_[n + d * ld] *= gamma;
 #pragma unroll
             for (int h = 7; h >= 0; --h) {
                 if (h < hlen) {
                     const int idx = (hpos - 1 - h + 2 * m) % m;
-                    const double* Sh = st.Sh + (long)idx * D * ld;
-                    const double* Yh = st.Yh + (long)idx * D * ld;
+                    const double* __restrict__ Sh = ShA + (long)idx * D * ld;
+                    const double* __restrict__ Yh = YhA + (long)idx * D * ld;
                     double dot = 0.0;
                     #pragma unroll 8
-                    for (int d = 0; d < D; ++d) dot += Yh[n + d * ld] * st.dir[n + d * ld];
+                    for (int d = 0; d < D; ++d) dot += Yh[n + d * ld] * dir_[n + d * ld];
                     const double beta = st.rho[(long)idx * ld + n] * dot;
                     #pragma unroll 8
-                    for (int d = 0; d < D; ++d) st.dir[n + d * ld] += Sh[n + d * ld] * (al[h] - beta);
+                    for (int d = 0; d < D; ++d) dir_[n + d * ld] += Sh[n + d * ld] * (al[h] - beta);
                 }
             }
             double gd = 0.0;
             #pragma unroll 8
             for (int d = 0; d < D; ++d) {
-                const double pg = st.scr[n + d * ld];
-                const double dv = (pg == 0.0) ? 0.0 : -st.dir[n + d * ld];
-                st.dir[n + d * ld] = dv;
+                const double pg = scr_[n + d * ld];
+                const double dv = (pg == 0.0) ? 0.0 : -dir_[n + d * ld];
+                dir_[n + d * ld] = dv;
                 gd += pg * dv;
             }
             if (!(gd < 0.0)) {
@@ -687,9 +694,9 @@ __global__ __launch_bounds__(256) void lbfgs_step_kernel(LbfgsState st, const do
                 gd = 0.0;
                 #pragma unroll 8
                 for (int d = 0; d < D; ++d) {
-                    const double pg = st.scr[n + d * ld];
+                    const double pg = scr_[n + d * ld];
                     const double dv = -gamma * pg;
-                    st.dir[n + d * ld] = dv;
+                    dir_[n + d * ld] = dv;
                     gd += pg * dv;
                 }
                 if (!(gd < 0.0)) done = true;
@@ -705,21 +712,21 @@ __global__ __launch_bounds__(256) void lbfgs_step_kernel(LbfgsState st, const do
     bool moved = false;
     #pragma unroll 8
     for (int d = 0; d < D; ++d) {
-        const double xv = st.x[n + d * ld];
+        const double xv = x_[n + d * ld];
         double v = xv;
         if (!done) {
-            v = v + t * st.dir[n + d * ld];
+            v = v + t * dir_[n + d * ld];
             v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
             moved = moved || (v != xv);
         }
-        st.xt[n + d * ld] = v;
+        xt_[n + d * ld] = v;
     }
     if (!done && !moved) st.done[n] = 1;
 }
 
 void launch_lbfgs_step(hipStream_t s, const LbfgsState& st, const double* val, const double* grad, bool first) {
     if (st.nlive <= 0) return;
-    hipLaunchKernelGGL(lbfgs_step_kernel, dim3((st.nlive + 255) / 256), dim3(256), 0, s, st, val, grad, (int)first);
+    hipLaunchKernelGGL(lbfgs_step_kernel, dim3((st.nlive + 63) / 64), dim3(64), 0, s, st, val, grad, (int)first);
 }
 
 // One workgroup: thread t owns the contiguous segment [t*per, (t+1)*per) of the input list, counts its survivors, an
