@@ -196,6 +196,159 @@ __device__ __forceinline__ void gemm_tile(Acc& acc, const double* __restrict__ A
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Ring form of the M-contiguous x M-contiguous tile: slabs of BK k-rows in a ring of STAGES LDS stages, the LDS-direct
+// loads of slab s + STAGES - 1 issued as soon as the barrier of slab s has retired slab s - 1.  Same fragment layout and
+// the same k order as gemm_tile, hence the same bits; what changes is how long a load may take before somebody waits for
+// it: gemm_tile waits for slab s + 1 at the end of slab s (~48 MFMAs = 1.3 us after the issue), the ring with BK = 8 and
+// four stages waits ~2.75 slabs = 88 MFMAs = 2.4 us after it, with the same 73 728 bytes of LDS (two workgroups per CU).
+// The barrier is a bare s_barrier behind an explicit s_waitcnt: __syncthreads() carries a workgroup fence, for which the
+// compiler emits s_waitcnt vmcnt(0) -- that drains the ring (it is why the first 4-stage attempt measured "no change").
+// lgkmcnt(0): this wave's LDS reads of the retiring slab have returned before anybody's load may overwrite it.
+template <int N>
+__device__ __forceinline__ void ring_wait_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <int NJ = 4, int BK = 8, int STAGES = 4>
+__device__ __forceinline__ void gemm_tile_ring(Acc& acc, const double* __restrict__ A, long lda, const double* __restrict__ B,
+                                               long ldb, int kb, int ke, double* lds, int kfirst = -1, int nhalf = 0) {
+    static_assert(BK == 8 || BK == 16, "slab depth");
+    static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
+    constexpr int SLAB = BK * GEMM_LDS_MC_LD;      // doubles per operand slab
+    constexpr int STAGE = 2 * SLAB;                // A slab | B slab
+    constexpr int RPW = BK / 4;                    // k-rows each wave brings per slab and operand
+    constexpr int LPW = 2 * RPW;                   // loads per wave and slab
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wave & 1) * 64;
+    const int wn = NJ == 4 ? (wave >> 1) * 64 : 64 * nhalf + (wave >> 1) * 32;
+    if (kb >= ke) return;
+    if (kfirst < kb || kfirst >= ke) kfirst = kb;
+    const int nst = (ke - kb) / BK;
+    const double* Ap = A + 2 * lane;
+    const double* Bp = B + 2 * lane;
+    int kiss = kfirst;                             // k of the next slab to issue
+    int siss = 0;                                  // its ring position
+    auto issue = [&]() {
+        double* base = lds + siss * STAGE;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int row = RPW * wave + r;
+            slab_row_to_lds(Ap + (long)(kiss + row) * lda, base + row * GEMM_LDS_MC_LD);
+            slab_row_to_lds(Bp + (long)(kiss + row) * ldb, base + SLAB + row * GEMM_LDS_MC_LD);
+        }
+        kiss += BK;
+        if (kiss >= ke) kiss = kb;
+        siss = (siss + 1 == STAGES) ? 0 : siss + 1;
+    };
+    for (int s = 0; s < STAGES - 1 && s < nst; ++s) issue();
+    int scur = 0;
+    for (int s = 0; s < nst; ++s) {
+        // slabs s + 1 .. s + STAGES - 2 may stay in flight
+        const int later = nst - 1 - s;
+        if (later >= STAGES - 2) ring_wait_barrier<(STAGES - 2) * LPW>();
+        else if (STAGES == 4 && later == 1) ring_wait_barrier<LPW>();
+        else ring_wait_barrier<0>();
+        if (s + STAGES - 1 < nst) issue();         // into the stage slab s - 1 occupied
+        const double* la = lds + scur * STAGE;
+        const double* lb = la + SLAB;
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            double af[4], bf[NJ];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = frag_read<false>(la, wm + 16 * i, kk, lane);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bf[j] = frag_read<false>(lb, wn + 16 * j, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc.v[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc.v[i][j], 0, 0, 0);
+        }
+        scur = (scur + 1 == STAGES) ? 0 : scur + 1;
+    }
+    ring_wait_barrier<0>();                        // the callers reuse the LDS block in their epilogues
+}
+
+// Software-pipelined ring (BK = 8, four stages): the two k-groups of a slab alternate with the barrier in between,
+//     read F1 (slab s, k-group 1) | 16 MFMAs on F0 | wait + barrier (slab s + 1 landed, slab s read by everybody)
+//     | issue slab s + 4 into slab s's stage | read F0 (slab s + 1, k-group 0) | 16 MFMAs on F1
+// so every fragment read is issued 16 MFMAs (~1000 cycles) before its first use and the instructions behind a barrier are
+// MFMAs whose operands are already in registers: the wave has no LDS-latency bubble per slab (gemm_tile and the plain ring
+// expose one after every barrier, which only the co-resident workgroup's wave can fill).
+template <int NJ = 4>
+__device__ __forceinline__ void gemm_tile_pipe(Acc& acc, const double* __restrict__ A, long lda, const double* __restrict__ B,
+                                               long ldb, int kb, int ke, double* lds, int kfirst = -1, int nhalf = 0) {
+    constexpr int BK = 8, STAGES = 4;
+    constexpr int SLAB = BK * GEMM_LDS_MC_LD;
+    constexpr int STAGE = 2 * SLAB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wave & 1) * 64;
+    const int wn = NJ == 4 ? (wave >> 1) * 64 : 64 * nhalf + (wave >> 1) * 32;
+    if (kb >= ke) return;
+    if (kfirst < kb || kfirst >= ke) kfirst = kb;
+    const int nst = (ke - kb) / BK;
+    const double* Ap = A + 2 * lane;
+    const double* Bp = B + 2 * lane;
+    int kiss = kfirst, siss = 0;
+    auto issue = [&]() {
+        double* base = lds + siss * STAGE;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int row = 2 * wave + r;
+            slab_row_to_lds(Ap + (long)(kiss + row) * lda, base + row * GEMM_LDS_MC_LD);
+            slab_row_to_lds(Bp + (long)(kiss + row) * ldb, base + SLAB + row * GEMM_LDS_MC_LD);
+        }
+        kiss += BK;
+        if (kiss >= ke) kiss = kb;
+        siss = (siss + 1) & (STAGES - 1);
+    };
+    auto wait_for = [&](int later) {   // `later` slabs behind the awaited one may stay in flight (4 loads per wave each)
+        if (later >= 3) ring_wait_barrier<12>();
+        else if (later == 2) ring_wait_barrier<8>();
+        else if (later == 1) ring_wait_barrier<4>();
+        else ring_wait_barrier<0>();
+    };
+    auto read = [&](double (&af)[4], double (&bf)[NJ], int stage, int kk) {
+        const double* la = lds + stage * STAGE;
+        const double* lb = la + SLAB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = frag_read<false>(la, wm + 16 * i, kk, lane);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bf[j] = frag_read<false>(lb, wn + 16 * j, kk, lane);
+    };
+    auto mfma = [&](const double (&af)[4], const double (&bf)[NJ]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                acc.v[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc.v[i][j], 0, 0, 0);
+    };
+    for (int s = 0; s < STAGES && s < nst; ++s) issue();
+    wait_for(min(STAGES, nst) - 1);
+    double a0[4], b0[NJ], a1[4], b1[NJ];
+    read(a0, b0, 0, 0);
+    int scur = 0;
+    for (int s = 0; s < nst; ++s) {
+        read(a1, b1, scur, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < nst) {
+            wait_for(min(STAGES - 2, nst - 2 - s));
+            if (s + STAGES < nst) issue();         // into slab s's stage
+            read(a0, b0, (scur + 1) & (STAGES - 1), 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        scur = (scur + 1) & (STAGES - 1);
+    }
+    ring_wait_barrier<0>();                        // the callers reuse the LDS block in their epilogues
+}
+
 // 128 x 64 output tile (A M- or K-contiguous, B K-contiguous), for products whose second dimension is small (the gradient
 // contractions have n' = D <= 64 for the headline configuration; a 128-wide tile would waste half of its MFMAs).
 // 4 waves stacked along m: wave w owns rows 32 w .. 32 w + 31 (2 A fragments) x all 64 columns (4 B fragments).
