@@ -3,9 +3,10 @@
 // One workgroup (256 threads = 4 waves, 2x2) computes a 128x128 tile of
 //     C[m][n] (+)= sum_k opA[m][k] * opB[n][k]
 // with v_mfma_f64_16x16x4_f64.  Each wave owns a 64x64 sub-tile = 4x4 MFMA
-// tiles (128 accumulator VGPRs).  Operand tiles are staged global -> regs ->
-// LDS in BK=16 slabs, double buffered, one barrier per slab (64 MFMAs per wave
-// between barriers).
+// tiles (128 accumulator VGPRs).  Operand slabs of BK=16 k-rows are double
+// buffered in LDS, one barrier per slab (64 MFMAs per wave between barriers):
+// LDS-direct loads for M-contiguous operands (gemm_tile_mc), global -> regs ->
+// LDS for K-contiguous ones.
 //
 // Both operands are "M x K" style matrices; each may be stored either
 //   M-contiguous ("MC"):  elem(m,k) = P[m + k*ld]   (column-major M x K)
@@ -101,252 +102,191 @@ __device__ __forceinline__ void slab_row_to_lds(const double* g, double* l) {
                                      0);
 }
 
-// Accumulate acc += opA[m0.., kb..ke) * opB[n0.., kb..ke)^T.
-// A, B point at row m0 / n0, k = 0 of their panels.  kb, ke multiples of 16.
-// The k loop starts at slab `kfirst` (kb <= kfirst < ke, multiple of 16) and wraps around at ke: tiles that share an
-// operand panel are started a slab apart so that their global loads of one slab do not miss the L2 simultaneously.
-// `lds` is the 73728-byte, 16-byte aligned dynamic LDS block.
-// NJ = 4: the whole 128 x 128 tile (wave (wm, wn) owns a 64 x 64 quadrant).  NJ = 2: only the 64 columns [64 nhalf, 64 nhalf
-// + 64) of it -- wave (wm, sub) owns 64 x 32 at column 64 nhalf + 32 sub, accumulators acc.v[i][0..1] -- with the same slabs,
-// the same fragment layout and the same k order, so every element gets the bits the full tile would give it at half the
-// MFMA work per workgroup (used to split the tiles of a partially filled last generation over twice as many workgroups).
-template <bool A_KC, bool B_KC, int NJ = 4>
-__device__ __forceinline__ void gemm_tile(Acc& acc, const double* __restrict__ A, long lda,
-                                          const double* __restrict__ B, long ldb, int kb, int ke, double* lds,
-                                          int kfirst = -1, int nhalf = 0) {
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = (wave & 1) * 64;   // wave's m offset inside the tile
-    const int wn = NJ == 4 ? (wave >> 1) * 64 : 64 * nhalf + (wave >> 1) * 32;  // wave's n offset
-    if (kb >= ke) return;
-    if (kfirst < kb || kfirst >= ke) kfirst = kb;
-
-    // NOTE: LDS buffers are selected by integer offset from the one LDS base pointer.  Selecting between
-    // pointers (double* buf[2]) makes hipcc lose the LDS address space and emit flat_load/flat_store, whose
-    // s_waitcnt vmcnt(0) then drains the global prefetch before every MFMA group (measured: 72 % -> MFMA busy).
-    // layout: [A0 | B0 | A1 | B1], each GEMM_LDS_TILE doubles
-    // Both operands M-contiguous: a k-row of a slab is 128 contiguous doubles = 64 lanes x 16 B, exactly what one
-    // global_load_lds_dwordx4 (LDS-direct load, gfx950) deposits at LDS base + 16 B * lane.  The slab then never passes
-    // through VGPRs: no staging registers (-32 VGPRs), no ds_write, no vmcnt -> ds_write dependency in the MFMA stream
-    // (gemm_probe_lds: 70.0 -> 71.2 TFLOP/s at 16384 x 8192 x 8192, 50 -> 56 TFLOP/s at 2048^3).  Wave w brings rows
-    // 4w .. 4w+3 of both operands; the loads of slab s+1 are issued at the top of slab s and must have landed
-    // (s_waitcnt vmcnt(0)) before the barrier that publishes the buffer.
-    constexpr bool DIRECT = !A_KC && !B_KC;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    auto issue_direct = [&](int k0, int bufoff) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 4 * wave_u + r;
-            slab_row_to_lds(A + 2 * lane + (long)(k0 + row) * lda, lds + bufoff + row * GEMM_LDS_MC_LD);
-            slab_row_to_lds(B + 2 * lane + (long)(k0 + row) * ldb, lds + bufoff + GEMM_LDS_TILE + row * GEMM_LDS_MC_LD);
-        }
-    };
-    Stage sa, sb;
-    if (DIRECT) {
-        issue_direct(kfirst, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-        stage_load<A_KC>(sa, A, lda, kfirst, tid);
-        stage_load<B_KC>(sb, B, ldb, kfirst, tid);
-        stage_store<A_KC>(sa, lds, tid);
-        stage_store<B_KC>(sb, lds + GEMM_LDS_TILE, tid);
-    }
-    __syncthreads();
-
-    int cur = 0;   // offset (doubles) of the buffer pair being consumed
-    int knext = kfirst;
-    const int nslab = (ke - kb) / GEMM_BK;
-    for (int s = 0; s < nslab; ++s) {
-        const bool more = (s + 1) < nslab;
-        knext += GEMM_BK;
-        if (knext >= ke) knext = kb;
-        if (more) {
-            if (DIRECT) {
-                issue_direct(knext, cur ^ (2 * GEMM_LDS_TILE));
-            } else {
-                stage_load<A_KC>(sa, A, lda, knext, tid);
-                stage_load<B_KC>(sb, B, ldb, knext, tid);
-            }
-        }
-        const double* la = lds + cur;
-        const double* lb = lds + cur + GEMM_LDS_TILE;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            double af[4], bf[NJ];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = frag_read<A_KC>(la, wm + 16 * i, kk, lane);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) bf[j] = frag_read<B_KC>(lb, wn + 16 * j, kk, lane);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    acc.v[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc.v[i][j], 0, 0, 0);
-        }
-        const int nxt = cur ^ (2 * GEMM_LDS_TILE);
-        if (DIRECT) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else if (more) {
-            stage_store<A_KC>(sa, lds + nxt, tid);
-            stage_store<B_KC>(sb, lds + nxt + GEMM_LDS_TILE, tid);
-        }
-        __syncthreads();
-        cur = nxt;
-    }
+// ---------------------------------------------------------------------------------------------------------------------
+// gemm_tile_mc: both operands M-contiguous (the acquisition GEMM, the variance GEMM, the Gram products, most of the
+// Cholesky chain).  A k-row of a slab is 128 contiguous doubles = 64 lanes x 16 B, exactly what one LDS-direct load
+// (global_load_lds_dwordx4, gfx950) deposits at M0 + 16 B * lane: the slab never passes through VGPRs.  Double buffered
+// BK = 16 slabs as before; what round 2 changed, from measurements with tools/probes/gemm_probe_ring.hip (16384 x 8192 x
+// 8192: 70.3 -> 73 TFLOP/s, same bits):
+//   * fp64 MFMA and the vector ALU do not co-execute on gfx950 (SQ_VALU_MFMA_COEXEC_CYCLES = 0; 24 dependent
+//     v_lshl_add_u64 per slab cost the MFMA-only loop 3.2 %): every VALU instruction in the k loop is paid in MFMA
+//     cycles.  The loads therefore use the SADDR form -- a uniform row pointer in SGPRs, advanced with scalar adds, plus
+//     one constant 32-bit lane offset -- instead of a 64-bit per-lane address computed with VALU adds per load (the
+//     compiler only emits that form outside loops, hence the inline assembly), the last slab is peeled (no branch around
+//     the loads) and the two LDS buffers alternate at compile time (their offsets fold into the ds_read immediates).
+//   * the fragments of the next k-group are read four MFMAs before they are needed, and the barrier that publishes the
+//     next slab sits in the MIDDLE of the last k-group: eight MFMAs whose operands are already in registers follow it,
+//     behind which the first fragment reads of the new slab complete.
+//   * the barrier is a bare s_barrier behind an explicit s_waitcnt (ring_wait_barrier): __syncthreads() adds a workgroup
+//     fence for which the compiler drains vmcnt AND places no MFMA across.
+// Deeper rings (BK = 8 x 4 stages, loads three slabs ahead) were measured slower (68.4): the loss was never load latency
+// (an L2-resident operand set gives the same rate) but issue cycles; see DESIGN.md 8a.
+__device__ __forceinline__ void slab_row_to_lds_saddr(const double* srow, unsigned lane_off, unsigned lds_byte_addr) {
+    // srow: wave-uniform address of the k-row (SGPR pair); lane_off = 16 * lane; lds_byte_addr: LDS address for lane 0 (M0)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(srow), "s"(lds_byte_addr)
+                 : "memory", "m0");
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Ring form of the M-contiguous x M-contiguous tile: slabs of BK k-rows in a ring of STAGES LDS stages, the LDS-direct
-// loads of slab s + STAGES - 1 issued as soon as the barrier of slab s has retired slab s - 1.  Same fragment layout and
-// the same k order as gemm_tile, hence the same bits; what changes is how long a load may take before somebody waits for
-// it: gemm_tile waits for slab s + 1 at the end of slab s (~48 MFMAs = 1.3 us after the issue), the ring with BK = 8 and
-// four stages waits ~2.75 slabs = 88 MFMAs = 2.4 us after it, with the same 73 728 bytes of LDS (two workgroups per CU).
-// The barrier is a bare s_barrier behind an explicit s_waitcnt: __syncthreads() carries a workgroup fence, for which the
-// compiler emits s_waitcnt vmcnt(0) -- that drains the ring (it is why the first 4-stage attempt measured "no change").
-// lgkmcnt(0): this wave's LDS reads of the retiring slab have returned before anybody's load may overwrite it.
 template <int N>
 __device__ __forceinline__ void ring_wait_barrier() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <int NJ = 4, int BK = 8, int STAGES = 4>
-__device__ __forceinline__ void gemm_tile_ring(Acc& acc, const double* __restrict__ A, long lda, const double* __restrict__ B,
-                                               long ldb, int kb, int ke, double* lds, int kfirst = -1, int nhalf = 0) {
-    static_assert(BK == 8 || BK == 16, "slab depth");
-    static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
-    constexpr int SLAB = BK * GEMM_LDS_MC_LD;      // doubles per operand slab
-    constexpr int STAGE = 2 * SLAB;                // A slab | B slab
-    constexpr int RPW = BK / 4;                    // k-rows each wave brings per slab and operand
-    constexpr int LPW = 2 * RPW;                   // loads per wave and slab
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = (wave & 1) * 64;
-    const int wn = NJ == 4 ? (wave >> 1) * 64 : 64 * nhalf + (wave >> 1) * 32;
-    if (kb >= ke) return;
-    if (kfirst < kb || kfirst >= ke) kfirst = kb;
-    const int nst = (ke - kb) / BK;
-    const double* Ap = A + 2 * lane;
-    const double* Bp = B + 2 * lane;
-    int kiss = kfirst;                             // k of the next slab to issue
-    int siss = 0;                                  // its ring position
-    auto issue = [&]() {
-        double* base = lds + siss * STAGE;
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) {
-            const int row = RPW * wave + r;
-            slab_row_to_lds(Ap + (long)(kiss + row) * lda, base + row * GEMM_LDS_MC_LD);
-            slab_row_to_lds(Bp + (long)(kiss + row) * ldb, base + SLAB + row * GEMM_LDS_MC_LD);
-        }
-        kiss += BK;
-        if (kiss >= ke) kiss = kb;
-        siss = (siss + 1 == STAGES) ? 0 : siss + 1;
+// One BK = 16 slab out of the LDS buffer at cur_off (doubles) while the next slab is loaded into the buffer at nxt_off.  f0
+// holds the fragments of k-group 0 on entry and those of the next slab's k-group 0 on exit; Arow / Brow: this wave's first
+// k-row of the NEXT slab (wave-uniform).
+template <int NJ>
+__device__ __forceinline__ void mc_slab(Acc& acc, double (&f0)[4 + NJ], double (&f1)[4 + NJ], const double* Arow, const double* Brow,
+                                        long lda, long ldb, unsigned lane_off, unsigned lds_base, const double* lds, int cur_off,
+                                        int nxt_off, int wave, int wm, int wn, int lane) {
+    auto issue = [&](int l) {   // load l of the next slab: l < 4 -> A row 4 wave + l, else B row 4 wave + l - 4
+        const int r = l & 3;
+        const double* g = l < 4 ? Arow + (long)r * lda : Brow + (long)r * ldb;
+        const unsigned d = lds_base + 8u * (unsigned)(nxt_off + (l < 4 ? 0 : GEMM_LDS_TILE) + (4 * wave + r) * GEMM_LDS_MC_LD);
+        slab_row_to_lds_saddr(g, lane_off, d);
     };
-    for (int s = 0; s < STAGES - 1 && s < nst; ++s) issue();
-    int scur = 0;
-    for (int s = 0; s < nst; ++s) {
-        // slabs s + 1 .. s + STAGES - 2 may stay in flight
-        const int later = nst - 1 - s;
-        if (later >= STAGES - 2) ring_wait_barrier<(STAGES - 2) * LPW>();
-        else if (STAGES == 4 && later == 1) ring_wait_barrier<LPW>();
-        else ring_wait_barrier<0>();
-        if (s + STAGES - 1 < nst) issue();         // into the stage slab s - 1 occupied
-        const double* la = lds + scur * STAGE;
-        const double* lb = la + SLAB;
+    auto read = [&](double (&f)[4 + NJ], int bufoff, int kk) {
 #pragma unroll
-        for (int kk = 0; kk < BK / 4; ++kk) {
-            double af[4], bf[NJ];
+        for (int i = 0; i < 4; ++i) f[i] = frag_read<false>(lds + bufoff, wm + 16 * i, kk, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = frag_read<false>(la, wm + 16 * i, kk, lane);
+        for (int j = 0; j < NJ; ++j) f[4 + j] = frag_read<false>(lds + bufoff + GEMM_LDS_TILE, wn + 16 * j, kk, lane);
+    };
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) bf[j] = frag_read<false>(lb, wn + 16 * j, kk, lane);
+    for (int kk = 0; kk < 4; ++kk) {
+        double(&f)[4 + NJ] = (kk & 1) ? f1 : f0;
+        double(&g)[4 + NJ] = (kk & 1) ? f0 : f1;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
 #pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    acc.v[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc.v[i][j], 0, 0, 0);
+            for (int j = 0; j < NJ; ++j) {
+                acc.v[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[4 + j], f[i], acc.v[i][j], 0, 0, 0);
+                const int m = (kk * 4 + i) * NJ + j + 1;            // MFMAs of this slab issued so far
+                if ((m & 1) == 0 && m <= 16) {                      // one load per two MFMAs: all eight within the first 16
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue(m / 2 - 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (kk < 3 && i == 2) {                                 // next k-group's fragments, one row of MFMAs ahead
+                __builtin_amdgcn_sched_barrier(0);
+                read(g, cur_off, kk + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (kk == 3 && i == 1) {                                // next slab landed, this one read by everybody
+                __builtin_amdgcn_sched_barrier(0);
+                ring_wait_barrier<0>();
+                read(g, nxt_off, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        scur = (scur + 1 == STAGES) ? 0 : scur + 1;
     }
-    ring_wait_barrier<0>();                        // the callers reuse the LDS block in their epilogues
 }
 
-// Software-pipelined ring (BK = 8, four stages): the two k-groups of a slab alternate with the barrier in between,
-//     read F1 (slab s, k-group 1) | 16 MFMAs on F0 | wait + barrier (slab s + 1 landed, slab s read by everybody)
-//     | issue slab s + 4 into slab s's stage | read F0 (slab s + 1, k-group 0) | 16 MFMAs on F1
-// so every fragment read is issued 16 MFMAs (~1000 cycles) before its first use and the instructions behind a barrier are
-// MFMAs whose operands are already in registers: the wave has no LDS-latency bubble per slab (gemm_tile and the plain ring
-// expose one after every barrier, which only the co-resident workgroup's wave can fill).
+// acc += A[m0.., kb..ke) * B[n0.., kb..ke)^T for M-contiguous A, B (pointing at row m0 / n0, k = 0); kb, ke multiples of 16.
+// NJ = 4: the whole 128 x 128 tile (wave (wm, wn) owns a 64 x 64 quadrant).  NJ = 2: only the 64 columns [64 nhalf, 64 nhalf
+// + 64) of it -- wave (wm, sub) owns 64 x 32 at column 64 nhalf + 32 sub, accumulators acc.v[i][0..1] -- with the same slabs,
+// the same fragment layout and the same k order, so every element gets the bits the full tile would give it at half the
+// MFMA work per workgroup (used to split the tiles of a partially filled last generation over twice as many workgroups).
+// Every slab runs the same code: the last one "prefetches" the first slab again (1/nslab extra traffic, from L2) instead of
+// being a peeled copy of the loop body -- peeled tails made the register allocator spill the accumulators.
+// `lds`: the 73 728-byte, 16-byte aligned dynamic LDS block; free for reuse on return (all waves have passed a barrier).
 template <int NJ = 4>
-__device__ __forceinline__ void gemm_tile_pipe(Acc& acc, const double* __restrict__ A, long lda, const double* __restrict__ B,
-                                               long ldb, int kb, int ke, double* lds, int kfirst = -1, int nhalf = 0) {
-    constexpr int BK = 8, STAGES = 4;
-    constexpr int SLAB = BK * GEMM_LDS_MC_LD;
-    constexpr int STAGE = 2 * SLAB;
+__device__ __forceinline__ void gemm_tile_mc(Acc& acc, const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb,
+                                             int kb, int ke, double* lds, int nhalf = 0) {
+    if (kb >= ke) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = (wave & 1) * 64;
     const int wn = NJ == 4 ? (wave >> 1) * 64 : 64 * nhalf + (wave >> 1) * 32;
-    if (kb >= ke) return;
-    if (kfirst < kb || kfirst >= ke) kfirst = kb;
-    const int nst = (ke - kb) / BK;
-    const double* Ap = A + 2 * lane;
-    const double* Bp = B + 2 * lane;
-    int kiss = kfirst, siss = 0;
-    auto issue = [&]() {
-        double* base = lds + siss * STAGE;
+    const unsigned lane_off = 16u * lane;
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) double*)lds;
+    const double* A0 = A + (long)(kb + 4 * wave) * lda;       // wave-uniform: this wave's rows of the first slab
+    const double* B0 = B + (long)(kb + 4 * wave) * ldb;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int row = 2 * wave + r;
-            slab_row_to_lds(Ap + (long)(kiss + row) * lda, base + row * GEMM_LDS_MC_LD);
-            slab_row_to_lds(Bp + (long)(kiss + row) * ldb, base + SLAB + row * GEMM_LDS_MC_LD);
-        }
-        kiss += BK;
-        if (kiss >= ke) kiss = kb;
-        siss = (siss + 1) & (STAGES - 1);
-    };
-    auto wait_for = [&](int later) {   // `later` slabs behind the awaited one may stay in flight (4 loads per wave each)
-        if (later >= 3) ring_wait_barrier<12>();
-        else if (later == 2) ring_wait_barrier<8>();
-        else if (later == 1) ring_wait_barrier<4>();
-        else ring_wait_barrier<0>();
-    };
-    auto read = [&](double (&af)[4], double (&bf)[NJ], int stage, int kk) {
-        const double* la = lds + stage * STAGE;
-        const double* lb = la + SLAB;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = frag_read<false>(la, wm + 16 * i, kk, lane);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) bf[j] = frag_read<false>(lb, wn + 16 * j, kk, lane);
-    };
-    auto mfma = [&](const double (&af)[4], const double (&bf)[NJ]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-                acc.v[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc.v[i][j], 0, 0, 0);
-    };
-    for (int s = 0; s < STAGES && s < nst; ++s) issue();
-    wait_for(min(STAGES, nst) - 1);
-    double a0[4], b0[NJ], a1[4], b1[NJ];
-    read(a0, b0, 0, 0);
-    int scur = 0;
-    for (int s = 0; s < nst; ++s) {
-        read(a1, b1, scur, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma(a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < nst) {
-            wait_for(min(STAGES - 2, nst - 2 - s));
-            if (s + STAGES < nst) issue();         // into slab s's stage
-            read(a0, b0, (scur + 1) & (STAGES - 1), 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        mfma(a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        scur = (scur + 1) & (STAGES - 1);
+    for (int r = 0; r < 4; ++r) {
+        slab_row_to_lds_saddr(A0 + (long)r * lda, lane_off, lds_base + 8u * (unsigned)((4 * wave + r) * GEMM_LDS_MC_LD));
+        slab_row_to_lds_saddr(B0 + (long)r * ldb, lane_off, lds_base + 8u * (unsigned)(GEMM_LDS_TILE + (4 * wave + r) * GEMM_LDS_MC_LD));
     }
-    ring_wait_barrier<0>();                        // the callers reuse the LDS block in their epilogues
+    ring_wait_barrier<0>();
+    double f0[4 + NJ], f1[4 + NJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f0[i] = frag_read<false>(lds, wm + 16 * i, 0, lane);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) f0[4 + j] = frag_read<false>(lds + GEMM_LDS_TILE, wn + 16 * j, 0, lane);
+    const int nslab = (ke - kb) / GEMM_BK;
+    const double* Arow = A0;
+    const double* Brow = B0;
+    int cur = 0;
+    for (int s = 0; s < nslab; ++s) {
+        const bool last = s + 1 == nslab;
+        Arow = last ? A0 : Arow + (long)GEMM_BK * lda;
+        Brow = last ? B0 : Brow + (long)GEMM_BK * ldb;
+        const int nxt = cur ^ (2 * GEMM_LDS_TILE);
+        mc_slab<NJ>(acc, f0, f1, Arow, Brow, lda, ldb, lane_off, lds_base, lds, cur, nxt, wave, wm, wn, lane);
+        cur = nxt;
+    }
+    ring_wait_barrier<0>();
+}
+
+// Accumulate acc += opA[m0.., kb..ke) * opB[n0.., kb..ke)^T.
+// A, B point at row m0 / n0, k = 0 of their panels.  kb, ke multiples of 16.  `lds` is the 73728-byte, 16-byte aligned
+// dynamic LDS block.  Both operands M-contiguous: gemm_tile_mc above (NJ / nhalf: see there).  Otherwise (a K-contiguous
+// operand cannot use LDS-direct loads: its slab rows are 16 doubles) the slab is staged global -> VGPR -> LDS, double
+// buffered, one barrier per slab.
+template <bool A_KC, bool B_KC, int NJ = 4>
+__device__ __forceinline__ void gemm_tile(Acc& acc, const double* __restrict__ A, long lda,
+                                          const double* __restrict__ B, long ldb, int kb, int ke, double* lds, int nhalf = 0) {
+    if constexpr (!A_KC && !B_KC) {
+        gemm_tile_mc<NJ>(acc, A, lda, B, ldb, kb, ke, lds, nhalf);
+    } else {
+        static_assert(NJ == 4, "half tiles exist for the M-contiguous form only");
+        const int tid = threadIdx.x;
+        const int lane = tid & 63;
+        const int wave = tid >> 6;
+        const int wm = (wave & 1) * 64;   // wave's m offset inside the tile
+        const int wn = (wave >> 1) * 64;  // wave's n offset
+        if (kb >= ke) return;
+        // NOTE: LDS buffers are selected by integer offset from the one LDS base pointer.  Selecting between
+        // pointers (double* buf[2]) makes hipcc lose the LDS address space and emit flat_load/flat_store, whose
+        // s_waitcnt vmcnt(0) then drains the global prefetch before every MFMA group (measured: 72 % -> MFMA busy).
+        // layout: [A0 | B0 | A1 | B1], each GEMM_LDS_TILE doubles
+        Stage sa, sb;
+        stage_load<A_KC>(sa, A, lda, kb, tid);
+        stage_load<B_KC>(sb, B, ldb, kb, tid);
+        stage_store<A_KC>(sa, lds, tid);
+        stage_store<B_KC>(sb, lds + GEMM_LDS_TILE, tid);
+        __syncthreads();
+        int cur = 0;   // offset (doubles) of the buffer pair being consumed
+        for (int k0 = kb; k0 < ke; k0 += GEMM_BK) {
+            const bool more = (k0 + GEMM_BK) < ke;
+            if (more) {
+                stage_load<A_KC>(sa, A, lda, k0 + GEMM_BK, tid);
+                stage_load<B_KC>(sb, B, ldb, k0 + GEMM_BK, tid);
+            }
+            const double* la = lds + cur;
+            const double* lb = lds + cur + GEMM_LDS_TILE;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                double af[4], bf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = frag_read<A_KC>(la, wm + 16 * i, kk, lane);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[j] = frag_read<B_KC>(lb, wn + 16 * j, kk, lane);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc.v[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc.v[i][j], 0, 0, 0);
+            }
+            const int nxt = cur ^ (2 * GEMM_LDS_TILE);
+            if (more) {
+                stage_store<A_KC>(sa, lds + nxt, tid);
+                stage_store<B_KC>(sb, lds + nxt + GEMM_LDS_TILE, tid);
+            }
+            __syncthreads();
+            cur = nxt;
+        }
+    }
 }
 
 // 128 x 64 output tile (A M- or K-contiguous, B K-contiguous), for products whose second dimension is small (the gradient

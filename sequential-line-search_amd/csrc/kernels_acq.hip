@@ -26,7 +26,7 @@ namespace slsk {
 template <bool MATERN, bool HALF>
 __device__ __forceinline__ void acq_tile(int t, int nhalf, int ntm, int ntn, const double* __restrict__ Ks, const double* __restrict__ Cs,
                                          long ldk, const double* __restrict__ Kinv, int Np, double* __restrict__ P,
-                                         double* __restrict__ kw_part, double* __restrict__ cw_part, int stagger, double* lds) {
+                                         double* __restrict__ kw_part, double* __restrict__ cw_part, double* lds) {
     // grouped order: 8 candidate tiles x all K^-1 row tiles, so the 64 tiles resident on one XCD share panels in L2
     const int GM = 8;
     const int gsz = GM * ntn;
@@ -36,12 +36,9 @@ __device__ __forceinline__ void acq_tile(int t, int nhalf, int ntm, int ntn, con
     const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
     Acc acc;
     acc.zero();
-    // Optional staggered k start (SLS_STAGGER=1): tile (tm, tn) begins (tn & 15) slabs into the k loop and wraps, so the
-    // sharers of a K* panel do not all miss on the same slab in the same microsecond.  The offset depends on tn ONLY: the
-    // summation order of a candidate's row must not depend on which tile position (tm) the candidate occupies, or the
-    // active-set compaction of the maximiser would change its bits.  Measured effect on time: none; off by default.
-    const int ks = stagger ? (tn & 15) * GEMM_BK : 0;
-    gemm_tile<false, false, HALF ? 2 : 4>(acc, Ks + m0, ldk, Kinv + n0, (long)Np, 0, Np, lds, ks, nhalf);
+    // The k loop runs 0 .. Np in the same order for every tile: a candidate's summation order does not depend on the tile
+    // position it occupies (the active-set compaction of the maximiser moves candidates between tiles).
+    gemm_tile<false, false, HALF ? 2 : 4>(acc, Ks + m0, ldk, Kinv + n0, (long)Np, 0, Np, lds, nhalf);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int NJ = HALF ? 2 : 4;
     const int nbase = HALF ? 64 * nhalf + (wave >> 1) * 32 : (wave >> 1) * 64;
@@ -117,13 +114,13 @@ template <bool MATERN>
 __global__ __launch_bounds__(256, 2) void acq_gemm_kernel(const double* __restrict__ Ks, const double* __restrict__ Cs, long ldk,
                                                           int Sp, const double* __restrict__ Kinv, int Np,
                                                           double* __restrict__ P, double* __restrict__ kw_part,
-                                                          double* __restrict__ cw_part, int stagger, int* __restrict__ sync,
+                                                          double* __restrict__ cw_part, int* __restrict__ sync,
                                                           int phase, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
     const int ntm = Sp / GEMM_BM, ntn = Np / GEMM_BN;
     if (sync == nullptr) {
-        acq_tile<MATERN, false>(xcd_remap(blockIdx.x, ntiles), 0, ntm, ntn, Ks, Cs, ldk, Kinv, Np, P, kw_part, cw_part, stagger, lds);
+        acq_tile<MATERN, false>(xcd_remap(blockIdx.x, ntiles), 0, ntm, ntn, Ks, Cs, ldk, Kinv, Np, P, kw_part, cw_part, lds);
         return;
     }
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
@@ -156,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void acq_gemm_kernel(const double* __restri
             __syncthreads();
         }
         const int t = c * slots + slot;
-        if (t < ntiles) acq_tile<MATERN, false>(t, 0, ntm, ntn, Ks, Cs, ldk, Kinv, Np, P, kw_part, cw_part, stagger, lds);
+        if (t < ntiles) acq_tile<MATERN, false>(t, 0, ntm, ntn, Ks, Cs, ldk, Kinv, Np, P, kw_part, cw_part, lds);
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_fetch_add(gate, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -168,12 +165,11 @@ template <bool MATERN>
 __global__ __launch_bounds__(256, 2) void acq_gemm_half_kernel(const double* __restrict__ Ks, const double* __restrict__ Cs, long ldk,
                                                                int Sp, const double* __restrict__ Kinv, int Np,
                                                                double* __restrict__ P, double* __restrict__ kw_part,
-                                                               double* __restrict__ cw_part, int stagger, int tail_first) {
+                                                               double* __restrict__ cw_part, int tail_first) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
     const int u = xcd_remap(blockIdx.x, gridDim.x);
-    acq_tile<MATERN, true>(tail_first + (u >> 1), u & 1, Sp / GEMM_BM, Np / GEMM_BN, Ks, Cs, ldk, Kinv, Np, P, kw_part, cw_part, stagger,
-                           lds);
+    acq_tile<MATERN, true>(tail_first + (u >> 1), u & 1, Sp / GEMM_BM, Np / GEMM_BN, Ks, Cs, ldk, Kinv, Np, P, kw_part, cw_part, lds);
 }
 
 int launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk, int Sp, const double* Kinv, int Np, double* P,
@@ -183,11 +179,9 @@ int launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk,
     ensure_dyn_lds((const void*)acq_gemm_half_kernel<false>, GEMM_LDS_BYTES);
     ensure_dyn_lds((const void*)acq_gemm_half_kernel<true>, GEMM_LDS_BYTES);
     const int nt = (Sp / GEMM_BM) * (Np / GEMM_BN);
-    // SLS_STAGGER (0 default: plain k loop, 1: staggered by tn) and SLS_PERSIST (1 default: gated form, 0 one tile per
-    // workgroup) are read per call so that tests and A/B runs can switch within one process
-    const char* es = getenv("SLS_STAGGER");
+    // SLS_PERSIST (1 default: gated form, 0 one tile per workgroup) is read per call so that tests and A/B runs can switch
+    // within one process
     const char* ep = getenv("SLS_PERSIST");
-    const int stagger_env = es ? atoi(es) : 0;
     const int persist_env = ep ? atoi(ep) : 1;
     // SLS_GATE_PHASE: start offset (ticks of the 100 MHz clock) between the two gate groups of an XCD; 0: one gate per XCD.
     // Measured per 65 536-candidate launch: phase 0 124.8 ms / 77 GB (hit rate 0.856); phase 2000..8000 123.2-123.3 ms /
@@ -196,7 +190,6 @@ int launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk,
     const int phase = eph ? atoi(eph) : 2000;
     // persistent, generation-gated form when there are at least two generations of tiles (MI355X: 256 CUs x 2 = 512 slots)
     const bool persist = persist_env && sync && nt >= 1024 && Np >= 2048;
-    const int stagger = stagger_env != 0 ? 1 : 0;
     // Tail split (SLS_TAIL_SPLIT=0 disables): the chip holds 512 tiles at a time; if the last such generation is at most half
     // full its tiles run as half tiles on twice the workgroups in a second launch (same bits, half the time for that
     // generation: 663 -> 642 ms per step on the 8 192-start shard of an 8-GPU run).
@@ -216,18 +209,18 @@ int launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk,
     if (nmain > 0) {
         if (matern)
             hipLaunchKernelGGL(acq_gemm_kernel<true>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, Ks, Cs, ldk, Sp, Kinv, Np, P,
-                               kw_part, cw_part, stagger, sy, phase, nmain);
+                               kw_part, cw_part, sy, phase, nmain);
         else
             hipLaunchKernelGGL(acq_gemm_kernel<false>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, Ks, Cs, ldk, Sp, Kinv, Np, P,
-                               kw_part, cw_part, stagger, sy, phase, nmain);
+                               kw_part, cw_part, sy, phase, nmain);
     }
     if (tail > 0) {
         if (matern)
             hipLaunchKernelGGL(acq_gemm_half_kernel<true>, dim3(2 * tail), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, Ks, Cs, ldk, Sp, Kinv,
-                               Np, P, kw_part, cw_part, stagger, nmain);
+                               Np, P, kw_part, cw_part, nmain);
         else
             hipLaunchKernelGGL(acq_gemm_half_kernel<false>, dim3(2 * tail), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, Ks, Cs, ldk, Sp, Kinv,
-                               Np, P, kw_part, cw_part, stagger, nmain);
+                               Np, P, kw_part, cw_part, nmain);
     }
     return nmain;   // tiles [nmain, nt) ran as two halves
 }

@@ -392,53 +392,12 @@ __device__ __forceinline__ bool pk_setup(const PersistArgs& a, PkBarrier& bs, bo
     return ok != 0;
 }
 
-// gemm_tile for a workgroup that owns the whole CU (160 KB of LDS, no co-resident workgroup to hide its waits): the same
-// 128 x 128 tile, wave quadrants, fragment layout and k order as gemm_tile<false, false> (=> identical bits), but the operand
-// slabs run through a ring of FOUR LDS stages with the LDS-direct loads issued three slabs ahead, so a slab's ~2 us load
-// latency is covered by the ~1.7 us of MFMA work of each of the three slabs in front of it (gemm_tile's two stages leave one
-// workgroup per CU waiting: measured 2.4 us per slab instead of 1.7).
+// The workers' and the chain's full 128 x 128 x K products: gemm_tile_mc (gemm_f64.hpp).  Round 2 first used a four-stage ring
+// of BK = 16 slabs here (147 KB of LDS) -- whose __syncthreads() drained the ring with the compiler's s_waitcnt vmcnt(0), so
+// it never ran deeper than a double buffer; the shared tile is faster and needs half the LDS.
 __device__ __forceinline__ void gemm_tile_deep(Acc& acc, const double* __restrict__ A, long lda, const double* __restrict__ B,
                                                long ldb, int K, double* lds) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
-    constexpr int STAGE = 2 * GEMM_LDS_TILE;             // doubles per stage: A slab | B slab
-    const int nslab = K / GEMM_BK;
-    auto issue = [&](int s) {
-        double* base = lds + (s & 3) * STAGE;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 4 * wave + r;
-            slab_row_to_lds(A + 2 * lane + (long)(GEMM_BK * s + row) * lda, base + row * GEMM_LDS_MC_LD);
-            slab_row_to_lds(B + 2 * lane + (long)(GEMM_BK * s + row) * ldb, base + GEMM_LDS_TILE + row * GEMM_LDS_MC_LD);
-        }
-    };
-    for (int s = 0; s < 3 && s < nslab; ++s) issue(s);
-    for (int s = 0; s < nslab; ++s) {
-        // slabs s+1, s+2 (8 loads each per wave) may still be in flight
-        const int later = min(2, nslab - 1 - s);
-        if (later == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if (later == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                 // slab s complete in LDS; nobody reads slab s-1 any more
-        if (s + 3 < nslab) issue(s + 3);                 // into the stage slab s-1 occupied
-        const double* la = lds + (s & 3) * STAGE;
-        const double* lb = la + GEMM_LDS_TILE;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            double af[4], bf[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = frag_read<false>(la, wm + 16 * i, kk, lane);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bf[j] = frag_read<false>(lb, wn + 16 * j, kk, lane);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc.v[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc.v[i][j], 0, 0, 0);
-        }
-    }
-    __syncthreads();
+    gemm_tile_mc<4>(acc, A, lda, B, ldb, 0, K, lds);
 }
 
 // 128 x 128 tile helpers on top of gemm_tile (operands in global memory / L2)
