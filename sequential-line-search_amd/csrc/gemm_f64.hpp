@@ -135,10 +135,14 @@ __device__ __forceinline__ void ring_wait_barrier() {
 // One BK = 16 slab out of the LDS buffer at cur_off (doubles) while the next slab is loaded into the buffer at nxt_off.  f0
 // holds the fragments of k-group 0 on entry and those of the next slab's k-group 0 on exit; Arow / Brow: this wave's first
 // k-row of the NEXT slab (wave-uniform).
-template <int NJ>
+// CUR = 0 / 1: the buffer is known at compile time (its offsets fold into the ds_read immediates: no VALU address update
+// per slab); CUR = -1: cur_rt / nxt_rt say which.
+template <int NJ, int CUR>
 __device__ __forceinline__ void mc_slab(Acc& acc, double (&f0)[4 + NJ], double (&f1)[4 + NJ], const double* Arow, const double* Brow,
-                                        long lda, long ldb, unsigned lane_off, unsigned lds_base, const double* lds, int cur_off,
-                                        int nxt_off, int wave, int wm, int wn, int lane) {
+                                        long lda, long ldb, unsigned lane_off, unsigned lds_base, const double* lds, int cur_rt,
+                                        int nxt_rt, int wave, int wm, int wn, int lane) {
+    const int cur_off = CUR < 0 ? cur_rt : CUR * 2 * GEMM_LDS_TILE;
+    const int nxt_off = CUR < 0 ? nxt_rt : (1 - CUR) * 2 * GEMM_LDS_TILE;
     auto issue = [&](int l) {   // load l of the next slab: l < 4 -> A row 4 wave + l, else B row 4 wave + l - 4
         const int r = l & 3;
         const double* g = l < 4 ? Arow + (long)r * lda : Brow + (long)r * ldb;
@@ -190,7 +194,9 @@ __device__ __forceinline__ void mc_slab(Acc& acc, double (&f0)[4 + NJ], double (
 // Every slab runs the same code: the last one "prefetches" the first slab again (1/nslab extra traffic, from L2) instead of
 // being a peeled copy of the loop body -- peeled tails made the register allocator spill the accumulators.
 // `lds`: the 73 728-byte, 16-byte aligned dynamic LDS block; free for reuse on return (all waves have passed a barrier).
-template <int NJ = 4>
+// EVEN: the caller guarantees an even number of slabs (ke - kb a multiple of 32): the loop then runs two slabs per iteration
+// with compile-time buffers.
+template <int NJ = 4, bool EVEN = false>
 __device__ __forceinline__ void gemm_tile_mc(Acc& acc, const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb,
                                              int kb, int ke, double* lds, int nhalf = 0) {
     if (kb >= ke) return;
@@ -216,14 +222,26 @@ __device__ __forceinline__ void gemm_tile_mc(Acc& acc, const double* __restrict_
     const int nslab = (ke - kb) / GEMM_BK;
     const double* Arow = A0;
     const double* Brow = B0;
-    int cur = 0;
-    for (int s = 0; s < nslab; ++s) {
-        const bool last = s + 1 == nslab;
-        Arow = last ? A0 : Arow + (long)GEMM_BK * lda;
-        Brow = last ? B0 : Brow + (long)GEMM_BK * ldb;
-        const int nxt = cur ^ (2 * GEMM_LDS_TILE);
-        mc_slab<NJ>(acc, f0, f1, Arow, Brow, lda, ldb, lane_off, lds_base, lds, cur, nxt, wave, wm, wn, lane);
-        cur = nxt;
+    if constexpr (EVEN) {
+        for (int s = 0; s < nslab; s += 2) {
+            Arow += (long)GEMM_BK * lda;
+            Brow += (long)GEMM_BK * ldb;
+            mc_slab<NJ, 0>(acc, f0, f1, Arow, Brow, lda, ldb, lane_off, lds_base, lds, 0, 0, wave, wm, wn, lane);
+            const bool last = s + 2 == nslab;
+            Arow = last ? A0 : Arow + (long)GEMM_BK * lda;
+            Brow = last ? B0 : Brow + (long)GEMM_BK * ldb;
+            mc_slab<NJ, 1>(acc, f0, f1, Arow, Brow, lda, ldb, lane_off, lds_base, lds, 0, 0, wave, wm, wn, lane);
+        }
+    } else {
+        int cur = 0;
+        for (int s = 0; s < nslab; ++s) {
+            const bool last = s + 1 == nslab;
+            Arow = last ? A0 : Arow + (long)GEMM_BK * lda;
+            Brow = last ? B0 : Brow + (long)GEMM_BK * ldb;
+            const int nxt = cur ^ (2 * GEMM_LDS_TILE);
+            mc_slab<NJ, -1>(acc, f0, f1, Arow, Brow, lda, ldb, lane_off, lds_base, lds, cur, nxt, wave, wm, wn, lane);
+            cur = nxt;
+        }
     }
     ring_wait_barrier<0>();
 }
@@ -233,11 +251,11 @@ __device__ __forceinline__ void gemm_tile_mc(Acc& acc, const double* __restrict_
 // dynamic LDS block.  Both operands M-contiguous: gemm_tile_mc above (NJ / nhalf: see there).  Otherwise (a K-contiguous
 // operand cannot use LDS-direct loads: its slab rows are 16 doubles) the slab is staged global -> VGPR -> LDS, double
 // buffered, one barrier per slab.
-template <bool A_KC, bool B_KC, int NJ = 4>
+template <bool A_KC, bool B_KC, int NJ = 4, bool EVEN = false>
 __device__ __forceinline__ void gemm_tile(Acc& acc, const double* __restrict__ A, long lda,
                                           const double* __restrict__ B, long ldb, int kb, int ke, double* lds, int nhalf = 0) {
     if constexpr (!A_KC && !B_KC) {
-        gemm_tile_mc<NJ>(acc, A, lda, B, ldb, kb, ke, lds, nhalf);
+        gemm_tile_mc<NJ, EVEN>(acc, A, lda, B, ldb, kb, ke, lds, nhalf);
     } else {
         static_assert(NJ == 4, "half tiles exist for the M-contiguous form only");
         const int tid = threadIdx.x;

@@ -38,7 +38,7 @@ __device__ __forceinline__ void acq_tile(int t, int nhalf, int ntm, int ntn, con
     acc.zero();
     // The k loop runs 0 .. Np in the same order for every tile: a candidate's summation order does not depend on the tile
     // position it occupies (the active-set compaction of the maximiser moves candidates between tiles).
-    gemm_tile<false, false, HALF ? 2 : 4>(acc, Ks + m0, ldk, Kinv + n0, (long)Np, 0, Np, lds, nhalf);
+    gemm_tile<false, false, HALF ? 2 : 4, true>(acc, Ks + m0, ldk, Kinv + n0, (long)Np, 0, Np, lds, nhalf);   // Np % 128 == 0
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int NJ = HALF ? 2 : 4;
     const int nbase = HALF ? 64 * nhalf + (wave >> 1) * 32 : (wave >> 1) * 64;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void acq_gemm_kernel(const double* __restri
                                                           int Sp, const double* __restrict__ Kinv, int Np,
                                                           double* __restrict__ P, double* __restrict__ kw_part,
                                                           double* __restrict__ cw_part, int* __restrict__ sync,
-                                                          int phase, int ntiles) {
+                                                          int phase, int ntiles, int prio) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
     const int ntm = Sp / GEMM_BM, ntn = Np / GEMM_BN;
@@ -131,6 +131,10 @@ __global__ __launch_bounds__(256, 2) void acq_gemm_kernel(const double* __restri
     // panel stay a few slabs apart, inside the L2 window.
     const int half = slots >> 1;
     const int grp = phase > 0 ? (slot >= half ? 1 : 0) : 0;
+    // The two workgroups of a CU (slots s, s + half) at different wave priorities: two waves that alternate on a SIMD's
+    // MFMA pipe lose ~3 % to the switches (MFMA-only loop: 77.2 TFLOP/s with one wave per SIMD, 75.1 with two); with a
+    // strict order the favoured wave issues back to back and the other one fills its bubbles.
+    if (prio && slot >= half) __builtin_amdgcn_s_setprio(1);
     int* gate = sync + 2 * xcd + grp;
     const int per_gen = phase > 0 ? half : slots;
     if (grp == 1) {
@@ -188,6 +192,8 @@ int launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk,
     // 112 GB (0.795: each group of 8 x 4 tiles shares 12 panels); ungated 124.9 ms / 333 GB (0.42).
     const char* eph = getenv("SLS_GATE_PHASE");
     const int phase = eph ? atoi(eph) : 2000;
+    const char* epr = getenv("SLS_ACQ_PRIO");
+    const int prio = epr ? atoi(epr) : 0;
     // persistent, generation-gated form when there are at least two generations of tiles (MI355X: 256 CUs x 2 = 512 slots)
     const bool persist = persist_env && sync && nt >= 1024 && Np >= 2048;
     // Tail split (SLS_TAIL_SPLIT=0 disables): the chip holds 512 tiles at a time; if the last such generation is at most half
@@ -209,10 +215,10 @@ int launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk,
     if (nmain > 0) {
         if (matern)
             hipLaunchKernelGGL(acq_gemm_kernel<true>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, Ks, Cs, ldk, Sp, Kinv, Np, P,
-                               kw_part, cw_part, sy, phase, nmain);
+                               kw_part, cw_part, sy, phase, nmain, prio);
         else
             hipLaunchKernelGGL(acq_gemm_kernel<false>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, Ks, Cs, ldk, Sp, Kinv, Np, P,
-                               kw_part, cw_part, sy, phase, nmain);
+                               kw_part, cw_part, sy, phase, nmain, prio);
     }
     if (tail > 0) {
         if (matern)
@@ -236,7 +242,7 @@ __device__ __forceinline__ void var_tile(int tm, int tn, const double* __restric
     const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
     Acc acc;
     acc.zero();
-    gemm_tile<false, false>(acc, Ks + m0, ldk, Linv + n0, (long)Np, 0, GEMM_BN * (tn + 1), lds);
+    gemm_tile<false, false, 4, true>(acc, Ks + m0, ldk, Linv + n0, (long)Np, 0, GEMM_BN * (tn + 1), lds);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double sv[4];
 #pragma unroll

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void tri_gemm_kernel(GemmDesc g) {
     const double* Bp = B_KC ? B + (long)n0 * g.ldb : B + n0;
     Acc acc;
     acc.zero();
-    gemm_tile<A_KC, B_KC>(acc, Ap, g.lda, Bp, g.ldb, kb, ke, lds);
+    gemm_tile<A_KC, B_KC, 4, true>(acc, Ap, g.lda, Bp, g.ldb, kb, ke, lds);   // kb, ke multiples of 128
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -397,7 +397,7 @@ __device__ __forceinline__ bool pk_setup(const PersistArgs& a, PkBarrier& bs, bo
 // it never ran deeper than a double buffer; the shared tile is faster and needs half the LDS.
 __device__ __forceinline__ void gemm_tile_deep(Acc& acc, const double* __restrict__ A, long lda, const double* __restrict__ B,
                                                long ldb, int K, double* lds) {
-    gemm_tile_mc<4>(acc, A, lda, B, ldb, 0, K, lds);
+    gemm_tile_mc<4, true>(acc, A, lda, B, ldb, 0, K, lds);   // K: multiples of 128
 }
 
 // 128 x 128 tile helpers on top of gemm_tile (operands in global memory / L2)

@@ -390,7 +390,7 @@ __device__ __forceinline__ void gemm_tile_ablate(Acc& acc, const double* __restr
 
 template <int VAR>
 __global__ __launch_bounds__(256, 2) void probe_kernel(const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb,
-                                                       double* __restrict__ C, long ldc, int M, int N, int K, int hot) {
+                                                       double* __restrict__ C, long ldc, int M, int N, int K, int hot, int* cu_cnt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
     const int ntm = M / 128, ntn = N / 128;
@@ -412,7 +412,23 @@ __global__ __launch_bounds__(256, 2) void probe_kernel(const double* __restrict_
     if (VAR == 3) gemm_tile_ring<4, 8, 3>(acc, A + m0, lda, B + n0, ldb, 0, K, lds);
     if (VAR == 4) gemm_tile_ring<4, 16, 4>(acc, A + m0, lda, B + n0, ldb, 0, K, lds);
     if (VAR == 6) gemm_tile_pipe<4>(acc, A + m0, lda, B + n0, ldb, 0, K, lds);
-    if (VAR == 40) gemm_tile_mc<4>(acc, A + m0, lda, B + n0, ldb, 0, K, lds);
+    if (VAR == 50 || VAR == 53) {   // the two workgroups of a CU at different priorities (which one arrived first: per-CU counter)
+        __shared__ int s_par;
+        if (threadIdx.x == 0) {
+            unsigned x, h;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(h));
+            s_par = atomicAdd(&cu_cnt[(x & 7) * 256 + ((h >> 8) & 0xff)], 1) & 1;
+        }
+        __syncthreads();
+        if (s_par) {
+            if (VAR == 50) __builtin_amdgcn_s_setprio(3);
+            else __builtin_amdgcn_s_setprio(1);
+        }
+    }
+    if (VAR == 40 || VAR == 50 || VAR == 51 || VAR == 53) gemm_tile_mc<4>(acc, A + m0, lda, B + n0, ldb, 0, K, lds);
+    if (VAR == 41) gemm_tile_mc<4, true>(acc, A + m0, lda, B + n0, ldb, 0, K, lds);
+    if (VAR == 52) gemm_tile_ablate<15>(acc, A + m0, lda, B + n0, ldb, K, lds);
     if (VAR == 20) gemm_tile_spread<2>(acc, A + m0, lda, B + n0, ldb, K, lds);
     if (VAR == 21) gemm_tile_spread<4>(acc, A + m0, lda, B + n0, ldb, K, lds);
     if (VAR == 22) gemm_tile_spread<1>(acc, A + m0, lda, B + n0, ldb, K, lds);
@@ -439,17 +455,18 @@ __global__ void checksum_kernel(const double* C, long n, unsigned long long* out
 }
 
 static int g_hot = 0;
+static int* g_cnt = nullptr;
 template <int VAR>
 static void run(int M, int N, int K, int reps, const double* dA, const double* dB, double* dC, int lds_bytes, const char* name) {
     hipFuncSetAttribute((const void*)probe_kernel<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     const int nt = (M / 128) * (N / 128);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipMemset(dC, 0, (size_t)M * N * 8);
-    hipLaunchKernelGGL(probe_kernel<VAR>, dim3(nt), dim3(256), lds_bytes, 0, dA, (long)M, dB, (long)N, dC, (long)M, M, N, K, g_hot);
+    hipLaunchKernelGGL(probe_kernel<VAR>, dim3(nt), dim3(256), lds_bytes, 0, dA, (long)M, dB, (long)N, dC, (long)M, M, N, K, g_hot, g_cnt);
     hipDeviceSynchronize();
     hipEventRecord(e0);
     for (int r = 0; r < reps; ++r)
-        hipLaunchKernelGGL(probe_kernel<VAR>, dim3(nt), dim3(256), lds_bytes, 0, dA, (long)M, dB, (long)N, dC, (long)M, M, N, K, g_hot);
+        hipLaunchKernelGGL(probe_kernel<VAR>, dim3(nt), dim3(256), lds_bytes, 0, dA, (long)M, dB, (long)N, dC, (long)M, M, N, K, g_hot, g_cnt);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
     unsigned long long* dh; hipMalloc(&dh, 8); hipMemset(dh, 0, 8);
@@ -464,6 +481,7 @@ int main(int argc, char** argv) {
     const int M = atoi(argv[1]), N = atoi(argv[2]), K = atoi(argv[3]);
     const int reps = argc > 4 ? atoi(argv[4]) : 2;
     g_hot = getenv("L2HOT") ? 1 : 0;
+    hipMalloc(&g_cnt, 2048 * 4); hipMemset(g_cnt, 0, 2048 * 4);
     double *dA, *dB, *dC;
     hipMalloc(&dA, (size_t)M * K * 8); hipMalloc(&dB, (size_t)N * K * 8); hipMalloc(&dC, (size_t)M * N * 8);
     std::vector<double> h((size_t)1 << 22);
@@ -500,6 +518,16 @@ int main(int argc, char** argv) {
         run<32>(M, N, K, reps, dA, dB, dC, GEMM_LDS_BYTES, "spread2 (saddr, peeled): 1 / 1");
         run<40>(M, N, K, reps, dA, dB, dC, GEMM_LDS_BYTES, "gemm_tile_mc (saddr asm)");
         run<0>(M, N, K, reps, dA, dB, dC, GEMM_LDS_BYTES, "gemm_tile again");
+    }
+    if (getenv("PRIO")) {
+        run<40>(M, N, K, reps, dA, dB, dC, GEMM_LDS_BYTES, "gemm_tile_mc");
+        run<41>(M, N, K, reps, dA, dB, dC, GEMM_LDS_BYTES, "gemm_tile_mc<EVEN> (2 slabs / iteration)");
+        run<50>(M, N, K, reps, dA, dB, dC, GEMM_LDS_BYTES, "gemm_tile_mc, CU partner at prio 3");
+        run<53>(M, N, K, reps, dA, dB, dC, GEMM_LDS_BYTES, "gemm_tile_mc, CU partner at prio 1");
+        run<51>(M, N, K, reps, dA, dB, dC, 160 * 1024, "gemm_tile_mc, 1 WG/CU");
+        run<52>(M, N, K, reps, dA, dB, dC, 160 * 1024, "MFMA only, 1 WG/CU");
+        run<115>(M, N, K, reps, dA, dB, dC, GEMM_LDS_BYTES, "MFMA only, 2 WG/CU");
+        run<40>(M, N, K, reps, dA, dB, dC, GEMM_LDS_BYTES, "gemm_tile_mc again");
     }
     if (getenv("SWEEP")) {
         run<1021>(M, N, K, reps, dA, dB, dC, GEMM_LDS_BYTES, "spread2 read@2 barrier@1 (base)");
