@@ -447,14 +447,13 @@ struct ChainAcc {
     }
 };
 
+// wait until at most N of this wave's loads are outstanding, then the workgroup barrier -- a bare s_barrier: __syncthreads()
+// carries a fence for which the compiler waits for vmcnt(0), i.e. for EVERY slab in flight (each of the 8 steps then paid a
+// full load latency: 17.5 us per product where the MFMAs need 7.7)
 template <int N>
-__device__ __forceinline__ void chain_wait_vm() {
-    if (N >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    else if (N >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (N >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (N >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (N >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+__device__ __forceinline__ void chain_wait_barrier() {
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+    ring_wait_barrier<N>();
 }
 
 template <bool TRI>
@@ -481,9 +480,8 @@ __device__ __forceinline__ void chain_gemm(ChainAcc& acc, const double* __restri
     auto step = [&](auto S) {
         constexpr int s = decltype(S)::value;
         // slab s has landed when at most the loads issued after it are outstanding (8 per slab TRI, 4 otherwise)
-        if (TRI) chain_wait_vm<8 * (s <= 5 ? 2 : 7 - s)>();
-        else chain_wait_vm<4 * (7 - s)>();
-        __syncthreads();                                 // every wave's part of slab s is in LDS; slab s-1 is no longer read
+        if (TRI) chain_wait_barrier<8 * (s <= 5 ? 2 : 7 - s)>();   // every wave's part of slab s is in LDS; slab s-1 is no longer read
+        else chain_wait_barrier<4 * (7 - s)>();
         if (TRI && s + 3 < 8) issue(s + 3);              // into the buffer of slab s - 1
         const double* la = TRI ? lds + (s & 3) * 2 * SLAB : lds + s * SLAB;
         const double* lb = TRI ? la + SLAB : la;
