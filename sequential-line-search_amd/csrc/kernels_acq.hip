@@ -543,80 +543,106 @@ void launch_clamp_starts(hipStream_t s, const double* starts, int D, int S, doub
     hipLaunchKernelGGL(clamp_starts_kernel, dim3((Sp + 255) / 256), dim3(256), 0, s, starts, D, S, xt, ld, Sp);
 }
 
+// FOUR lanes per start (q = 0..3 own the dimensions q, q + 4, ...), 16 starts per 64-thread workgroup.  With one thread per
+// start the 8 192-start shard of an 8-GPU run put one wave on 128 of the chip's 1024 SIMDs, each walking a serial chain of ~20
+// passes over D (16.6 ms per step).  Sums over the dimensions are formed per lane and combined as (q0 + q1) + (q2 + q3) in
+// every lane (xor shuffles: the same bits in all four), so the four lanes of a start take the same branches; the scalar state of
+// a start is read once, carried in registers and written back by lane q = 0.  The group size is fixed: a start's arithmetic must
+// not depend on how many starts are alive (active-set compaction).
 __global__ __launch_bounds__(64) void lbfgs_step_kernel(LbfgsState st, const double* __restrict__ val,
                                                          const double* __restrict__ grad, int first) {
-    const int j = blockIdx.x * 64 + threadIdx.x;     // column of (val, grad); 64-thread workgroups: small active sets spread over
-                                                      // 4x as many CUs (the kernel is bound by per-CU memory throughput)
+    const int q = threadIdx.x >> 4;
+    const int j = blockIdx.x * 16 + (threadIdx.x & 15);     // column of (val, grad)
     if (j >= st.nlive) return;
+    auto gsum = [](double v) {
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        return v;
+    };
+    auto gmax = [](double v) {
+        v = fmax(v, __shfl_xor(v, 16));
+        v = fmax(v, __shfl_xor(v, 32));
+        return v;
+    };
     const int n = st.live ? st.live[j] : j;          // the start it belongs to
     const long ld = st.ld, ldv = st.ldv;
     const int D = st.D, m = st.m;
     // the state arrays are distinct buffers: restrict-qualified views let the compiler issue a pass's loads together instead
-    // of ordering every load behind the previous store (350 us per call at 8 192 starts were ~64 serialised round trips
-    // per pass of the two-loop recursion)
+    // of ordering every load behind the previous store
     double* __restrict__ x_ = st.x; double* __restrict__ g_ = st.g; double* __restrict__ dir_ = st.dir;
     double* __restrict__ xt_ = st.xt; double* __restrict__ scr_ = st.scr;
     double* __restrict__ ShA = st.Sh; double* __restrict__ YhA = st.Yh;
+    // scalar state of the start (identical in its four lanes)
+    double f_v = 0.0, t_v = 1.0;
+    int hlen_v = 0, hpos_v = 0, nbt_v = 0;
+    bool done = false;
+    int idx_new = -1;            // history slot written in this call (its rho is not in memory yet for the other lanes)
+    double rho_new = 0.0;
     bool need_dir = false;
     if (first) {
-        st.f[n] = -val[j];
-        #pragma unroll 8
-        for (int d = 0; d < D; ++d) {
+        f_v = -val[j];
+        #pragma unroll 4
+        for (int d = q; d < D; d += 4) {
             x_[n + d * ld] = xt_[n + d * ld];
             g_[n + d * ld] = -grad[j + d * ldv];
         }
-        st.hlen[n] = 0; st.hpos[n] = 0; st.nbt[n] = 0; st.done[n] = 0; st.t[n] = 1.0;
         need_dir = true;
     } else {
         if (st.done[n]) return;
+        f_v = st.f[n]; t_v = st.t[n]; hlen_v = st.hlen[n]; hpos_v = st.hpos[n]; nbt_v = st.nbt[n];
         const double ft = -val[j];
         double gs = 0.0, ss = 0.0;
-        #pragma unroll 8
-        for (int d = 0; d < D; ++d) {
+        #pragma unroll 4
+        for (int d = q; d < D; d += 4) {
             const double sd = xt_[n + d * ld] - x_[n + d * ld];
             gs += g_[n + d * ld] * sd;
             ss += sd * sd;
         }
-        if (ss == 0.0) { st.done[n] = 1; return; }
-        if (ft <= st.f[n] + st.c1 * gs) {
+        gs = gsum(gs);
+        ss = gsum(ss);
+        if (ss == 0.0) {
+            if (q == 0) st.done[n] = 1;
+            return;
+        }
+        if (ft <= f_v + st.c1 * gs) {
             double sy = 0.0, yy = 0.0;
-            const int idx = st.hpos[n];
+            const int idx = hpos_v;
             double* __restrict__ Sh = ShA + (long)idx * D * ld;
             double* __restrict__ Yh = YhA + (long)idx * D * ld;
-            #pragma unroll 8
-            for (int d = 0; d < D; ++d) {
-                const double sd = xt_[n + d * ld] - x_[n + d * ld];
-                const double yd = -grad[j + d * ldv] - g_[n + d * ld];
+            #pragma unroll 4
+            for (int d = q; d < D; d += 4) {
+                const double xtd = xt_[n + d * ld], gtd = -grad[j + d * ldv];
+                const double sd = xtd - x_[n + d * ld];
+                const double yd = gtd - g_[n + d * ld];
                 Sh[n + d * ld] = sd;
                 Yh[n + d * ld] = yd;
                 sy += sd * yd;
                 yy += yd * yd;
+                x_[n + d * ld] = xtd;
+                g_[n + d * ld] = gtd;
             }
+            sy = gsum(sy);
+            yy = gsum(yy);
             if (sy > 1e-10 * yy && sy > 0.0) {
-                st.rho[(long)idx * ld + n] = 1.0 / sy;
-                st.hpos[n] = (idx + 1) % m;
-                if (st.hlen[n] < m) st.hlen[n] += 1;
+                idx_new = idx;
+                rho_new = 1.0 / sy;
+                if (q == 0) st.rho[(long)idx * ld + n] = rho_new;
+                hpos_v = (idx + 1) % m;
+                if (hlen_v < m) hlen_v += 1;
             }
-            #pragma unroll 8
-            for (int d = 0; d < D; ++d) {
-                x_[n + d * ld] = xt_[n + d * ld];
-                g_[n + d * ld] = -grad[j + d * ldv];
-            }
-            st.f[n] = ft;
+            f_v = ft;
             need_dir = true;
         } else {
-            st.t[n] *= st.shrink;
-            const int nb = st.nbt[n] + 1;
-            st.nbt[n] = nb;
-            if (nb > st.max_backtracks) { st.done[n] = 1; }
+            t_v *= st.shrink;
+            nbt_v += 1;
+            if (nbt_v > st.max_backtracks) done = true;
         }
     }
-    bool done = st.done[n] != 0;
     if (!done && need_dir) {
         // projected gradient -> scr (pg), two-loop recursion in dir
         double pgmax = 0.0, pgn2 = 0.0;
-        #pragma unroll 8
-        for (int d = 0; d < D; ++d) {
+        #pragma unroll 4
+        for (int d = q; d < D; d += 4) {
             double v = g_[n + d * ld];
             const double xv = x_[n + d * ld];
             if ((xv <= 0.0 && v > 0.0) || (xv >= 1.0 && v < 0.0)) v = 0.0;
@@ -625,11 +651,14 @@ __global__ __launch_bounds__(64) void lbfgs_step_kernel(LbfgsState st, const dou
             pgmax = fmax(pgmax, fabs(v));
             pgn2 += v * v;
         }
+        pgmax = gmax(pgmax);
+        pgn2 = gsum(pgn2);
         if (!(pgmax > st.gtol)) {
             done = true;
         } else {
-            int hlen = st.hlen[n];
-            const int hpos = st.hpos[n];
+            const int hlen = hlen_v;
+            const int hpos = hpos_v;
+            auto rho_of = [&](int idx) { return idx == idx_new ? rho_new : st.rho[(long)idx * ld + n]; };
             double al[8];
 #pragma unroll
             for (int h = 0; h < 8; ++h) {
@@ -639,11 +668,11 @@ __global__ __launch_bounds__(64) void lbfgs_step_kernel(LbfgsState st, const dou
                     const double* __restrict__ Sh = ShA + (long)idx * D * ld;
                     const double* __restrict__ Yh = YhA + (long)idx * D * ld;
                     double dot = 0.0;
-                    #pragma unroll 8
-                    for (int d = 0; d < D; ++d) dot += Sh[n + d * ld] * dir_[n + d * ld];
-                    al[h] = st.rho[(long)idx * ld + n] * dot;
-                    #pragma unroll 8
-                    for (int d = 0; d < D; ++d) dir_[n + d * ld] -= al[h] * Yh[n + d * ld];
+                    #pragma unroll 4
+                    for (int d = q; d < D; d += 4) dot += Sh[n + d * ld] * dir_[n + d * ld];
+                    al[h] = rho_of(idx) * gsum(dot);
+                    #pragma unroll 4
+                    for (int d = q; d < D; d += 4) dir_[n + d * ld] -= al[h] * Yh[n + d * ld];
                 }
             }
             double gamma;
@@ -652,18 +681,18 @@ __global__ __launch_bounds__(64) void lbfgs_step_kernel(LbfgsState st, const dou
                 const double* __restrict__ Sh = ShA + (long)idx * D * ld;
                 const double* __restrict__ Yh = YhA + (long)idx * D * ld;
                 double sy = 0.0, yy = 0.0;
-                #pragma unroll 8
-                for (int d = 0; d < D; ++d) {
+                #pragma unroll 4
+                for (int d = q; d < D; d += 4) {
                     sy += Sh[n + d * ld] * Yh[n + d * ld];
                     yy += Yh[n + d * ld] * Yh[n + d * ld];
                 }
-                gamma = sy / yy;
+                gamma = gsum(sy) / gsum(yy);
             } else {
                 const double nn = sqrt(pgn2);
                 gamma = 1.0 / (nn > 1.0 ? nn : 1.0);
             }
-            #pragma unroll 8
-            for (int d = 0; d < D; ++d) dir_[n + d * ld] *= gamma;
+            #pragma unroll 4
+            for (int d = q; d < D; d += 4) dir_[n + d * ld] *= gamma;
 #pragma unroll
             for (int h = 7; h >= 0; --h) {
                 if (h < hlen) {
@@ -671,61 +700,66 @@ __global__ __launch_bounds__(64) void lbfgs_step_kernel(LbfgsState st, const dou
                     const double* __restrict__ Sh = ShA + (long)idx * D * ld;
                     const double* __restrict__ Yh = YhA + (long)idx * D * ld;
                     double dot = 0.0;
-                    #pragma unroll 8
-                    for (int d = 0; d < D; ++d) dot += Yh[n + d * ld] * dir_[n + d * ld];
-                    const double beta = st.rho[(long)idx * ld + n] * dot;
-                    #pragma unroll 8
-                    for (int d = 0; d < D; ++d) dir_[n + d * ld] += Sh[n + d * ld] * (al[h] - beta);
+                    #pragma unroll 4
+                    for (int d = q; d < D; d += 4) dot += Yh[n + d * ld] * dir_[n + d * ld];
+                    const double beta = rho_of(idx) * gsum(dot);
+                    #pragma unroll 4
+                    for (int d = q; d < D; d += 4) dir_[n + d * ld] += Sh[n + d * ld] * (al[h] - beta);
                 }
             }
             double gd = 0.0;
-            #pragma unroll 8
-            for (int d = 0; d < D; ++d) {
+            #pragma unroll 4
+            for (int d = q; d < D; d += 4) {
                 const double pg = scr_[n + d * ld];
                 const double dv = (pg == 0.0) ? 0.0 : -dir_[n + d * ld];
                 dir_[n + d * ld] = dv;
                 gd += pg * dv;
             }
+            gd = gsum(gd);
             if (!(gd < 0.0)) {
-                st.hlen[n] = 0;
+                hlen_v = 0;
                 const double nn = sqrt(pgn2);
                 gamma = 1.0 / (nn > 1.0 ? nn : 1.0);
                 gd = 0.0;
-                #pragma unroll 8
-                for (int d = 0; d < D; ++d) {
+                #pragma unroll 4
+                for (int d = q; d < D; d += 4) {
                     const double pg = scr_[n + d * ld];
                     const double dv = -gamma * pg;
                     dir_[n + d * ld] = dv;
                     gd += pg * dv;
                 }
+                gd = gsum(gd);
                 if (!(gd < 0.0)) done = true;
             }
-            if (!done) { st.t[n] = 1.0; st.nbt[n] = 0; }
+            if (!done) { t_v = 1.0; nbt_v = 0; }
         }
-        if (done) st.done[n] = 1;
     }
     // propose the next trial point.  A trial that coincides with x (the step vanished in the clamp / in rounding) would be
     // evaluated once and then stop the start with x, f unchanged ("ss == 0" above): it is retired here, one evaluation
     // earlier, with the same end state.
-    const double t = st.t[n];
-    bool moved = false;
-    #pragma unroll 8
-    for (int d = 0; d < D; ++d) {
+    double moved = 0.0;
+    #pragma unroll 4
+    for (int d = q; d < D; d += 4) {
         const double xv = x_[n + d * ld];
         double v = xv;
         if (!done) {
-            v = v + t * dir_[n + d * ld];
+            v = v + t_v * dir_[n + d * ld];
             v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
-            moved = moved || (v != xv);
+            if (v != xv) moved = 1.0;
         }
         xt_[n + d * ld] = v;
     }
-    if (!done && !moved) st.done[n] = 1;
+    moved = gmax(moved);
+    if (!done && moved == 0.0) done = true;
+    if (q == 0) {
+        st.f[n] = f_v; st.t[n] = t_v; st.hlen[n] = hlen_v; st.hpos[n] = hpos_v; st.nbt[n] = nbt_v;
+        st.done[n] = done ? 1 : 0;
+    }
 }
 
 void launch_lbfgs_step(hipStream_t s, const LbfgsState& st, const double* val, const double* grad, bool first) {
     if (st.nlive <= 0) return;
-    hipLaunchKernelGGL(lbfgs_step_kernel, dim3((st.nlive + 63) / 64), dim3(64), 0, s, st, val, grad, (int)first);
+    hipLaunchKernelGGL(lbfgs_step_kernel, dim3((st.nlive + 15) / 16), dim3(64), 0, s, st, val, grad, (int)first);
 }
 
 // One workgroup: thread t owns the contiguous segment [t*per, (t+1)*per) of the input list, counts its survivors, an
