@@ -2,12 +2,15 @@
 // and keyword arguments of the reference's binding (python/pySequentialLineSearch.cpp:13-153), so the reference's
 // python-examples recipes run unchanged on the MI355X path.  Vectors / matrices cross the boundary as numpy float64
 // arrays (the reference relies on pybind11/eigen.h; Eigen is not available here, hence the small casters below).
-// Additions: set_random_seed(), and batched predict_mean_stdev / acquisition_values on (D, M) arrays.
+// Additions: set_random_seed(), set/get_global_search_strategy(), set/get_devices(), and batched predict_mean_stdev /
+// acquisition_values on (D, M) arrays.
 #include <pybind11/functional.h>
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include <sequential-line-search/acquisition-function.hpp>
+#include <sequential-line-search/device.hpp>
 #include <sequential-line-search/preference-regressor.hpp>
 #include <sequential-line-search/preferential-bayesian-optimizer.hpp>
 #include <sequential-line-search/sequential-line-search.hpp>
@@ -72,6 +75,14 @@ PYBIND11_MODULE(pySequentialLineSearch, m)
 {
     m.doc() = "sequential-line-search on AMD MI355X (libsls_hip)";
     m.def("set_random_seed", &utils::SetRandomSeed, "seed"_a);
+    // run-time switches of the MI355X build (the reference chooses the maximiser branch at compile time and has one device)
+    py::enum_<GlobalSearchStrategy>(m, "GlobalSearchStrategy")
+        .value("DirectThenLbfgs", GlobalSearchStrategy::DirectThenLbfgs)
+        .value("ParallelMultiStart", GlobalSearchStrategy::ParallelMultiStart);
+    m.def("set_global_search_strategy", &acquisition_func::SetGlobalSearchStrategy, "strategy"_a);
+    m.def("get_global_search_strategy", &acquisition_func::GetGlobalSearchStrategy);
+    m.def("set_devices", &device::SetDevices, "devices"_a);
+    m.def("get_devices", [] { return device::Devices(); });
 
     py::enum_<CurrentBestSelectionStrategy>(m, "CurrentBestSelectionStrategy", py::arithmetic())
         .value("LargestExpectValue", CurrentBestSelectionStrategy::LargestExpectValue)

@@ -523,7 +523,7 @@ void launch_combine(hipStream_t s, int S, int D, long ld, const double* mu, cons
 
 // ---------------------------------------------------------------------------------------------------------
 // Lock-step bounded L-BFGS (the oracle's slso_acq_maximize is the same algorithm, statement by
-// statement).  One thread per start; every per-start vector is candidate-major so all accesses coalesce.
+// statement).  Four lanes per start (see lbfgs_step_kernel); every per-start vector is candidate-major so all accesses coalesce.
 // Minimises phi = -acq on [0,1]^D.
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void clamp_starts_kernel(const double* __restrict__ starts, int D, int S, double* __restrict__ xt,

@@ -99,3 +99,11 @@ def test_python_binding_runs_reference_recipe():
         pbo.submit_feedback_data(int(np.argmax([objective(x) for x in o])))
         pbo.determine_next_query(32, 10)
     assert len(pbo.get_current_options()) == 3
+    # run-time switches of this build: maximiser branch and device list
+    assert sls_py.get_devices() == [0]
+    before = sls_py.get_global_search_strategy()
+    sls_py.set_global_search_strategy(sls_py.GlobalSearchStrategy.ParallelMultiStart)
+    assert sls_py.get_global_search_strategy() == sls_py.GlobalSearchStrategy.ParallelMultiStart
+    pbo.submit_feedback_data(0)
+    pbo.determine_next_query(32, 10)
+    sls_py.set_global_search_strategy(before)
