@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of tile scheduling variants inside the real acq_gemm_kernel: FETCH_SIZE and TCC hit/miss passes.
-# usage: prof_stagger.sh "SLS_PERSIST=0 SLS_STAGGER=1" "SLS_PERSIST=1 SLS_STAGGER=0" ...
+# usage: prof_stagger.sh "SLS_PERSIST=0 SLS_GATE_PHASE=0" "SLS_PERSIST=1 SLS_GATE_PHASE=2000" ...
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_stagger
