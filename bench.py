@@ -209,7 +209,7 @@ def main():
             if uid[0] is not None:
                 t = threading.Thread(target=make, daemon=True)
                 t.start()
-                t.join(timeout=float(os.environ.get("SLS_BENCH_RCCL_TIMEOUT", "180")))
+                t.join(timeout=float(os.environ.get("SLS_BENCH_RCCL_TIMEOUT", "90")))
                 if t.is_alive():
                     box["err"] = "ncclCommInitRank / first ncclAllGather did not return within the watchdog timeout"
             else:
