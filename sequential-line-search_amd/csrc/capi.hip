@@ -326,7 +326,7 @@ struct sls_gp {
     double a = 0, b = 0;
     std::vector<double> theta, Xh, yh;
     bool host_stale = false;   // sls_gp_refit_dev replaced the device X / y: Xh / yh are refreshed before their next use
-    DBuf X, y, inv_ell, XT, XaT, nx, L, Linv, Kinv, alpha, tvec, mu_data, scal, gemv_part;
+    DBuf X, y, inv_ell, XT, XaT, nx, L, Linv, Kinv, U, alpha, tvec, mu_data, scal, gemv_part;   // U = (L^-1)^T, needed by the fit only
     long* d_idx = nullptr;
     int best_index = 0;
     double mu_best = 0, logdet = 0;
@@ -364,11 +364,11 @@ static void gp_fit_device(sls_gp* g) {
     }
     {
         ProfScope ps(c, "trtri");
-        launch_trtri(c->stream, g->L.p, Np, g->Linv.p, g->Kinv.p);
+        launch_trtri(c->stream, g->L.p, Np, g->Linv.p, g->Kinv.p, g->U.p);
     }
     {
         ProfScope ps(c, "lauum");
-        launch_lauum(c->stream, g->Linv.p, Np, g->Kinv.p);
+        launch_lauum(c->stream, g->U.p, Np, g->Kinv.p);
     }
     // alpha = Linv^T (Linv y);  mu at the data points = y - b alpha;  x_best = first argmax  (regressor.cpp:29-43 hoisted)
     launch_gemv_n(c->stream, g->Linv.p, Np, g->y.p, g->tvec.p, g->gemv_part.p);
@@ -411,7 +411,7 @@ static void gp_setup(sls_gp* g) {
     const size_t Np = g->Np;
     g->X.ensure((size_t)D * N); g->y.ensure(Np); g->inv_ell.ensure(g->Dcols);
     g->XT.ensure(Np * g->Dcols); g->XaT.ensure(Np * g->Dcols); g->nx.ensure(Np);
-    g->L.ensure(Np * Np); g->Linv.ensure(Np * Np); g->Kinv.ensure(Np * Np);
+    g->L.ensure(Np * Np); g->Linv.ensure(Np * Np); g->Kinv.ensure(Np * Np); g->U.ensure(Np * Np);
     g->alpha.ensure(Np); g->tvec.ensure(Np); g->mu_data.ensure(Np); g->scal.ensure(8);
     g->gemv_part.ensure((Np / 128) * Np);
     g->ws_chunk = 0;   // the evaluation workspace depends on Np
@@ -1087,15 +1087,16 @@ extern "C" int sls_potri(sls_ctx* c, const double* L, int N, double* Ainv) {
     SLS_REQUIRE(c && L && Ainv && N >= 1, "sls_potri: bad argument");
     SLS_HIP(hipSetDevice(c->device));
     const int Np = round_up(N, 128);
-    DBuf Ld, Li, Ki;
+    DBuf Ld, Li, Ki, Ui;
     upload_padded_spd(c, Ld, L, N, Np);
     launch_zero_upper(c->stream, Ld.p, Np);
     Li.ensure((size_t)Np * Np);
     Ki.ensure((size_t)Np * Np);
+    Ui.ensure((size_t)Np * Np);
     launch_fill(c->stream, Li.p, (long)Np * Np, 0.0);
     launch_diag_inverse(c->stream, Ld.p, Np, Li.p);
-    launch_trtri(c->stream, Ld.p, Np, Li.p, Ki.p);
-    launch_lauum(c->stream, Li.p, Np, Ki.p);
+    launch_trtri(c->stream, Ld.p, Np, Li.p, Ki.p, Ui.p);
+    launch_lauum(c->stream, Ui.p, Np, Ki.p);
     d2h_matrix(c, Ainv, Ki.p, N, Np);
     sync(c);
     SLS_CATCH

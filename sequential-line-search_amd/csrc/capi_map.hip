@@ -87,8 +87,9 @@ static void nll_factor(sls_nll* h, const double* theta, double b) {
         SLS_HIP(hipMemsetAsync(c->d_info, 0, 64, c->stream));
         launch_fill(c->stream, h->Linv.p, (long)Np * Np, 0.0);
         launch_potrf(c->stream, h->L.p, Np, h->Linv.p, c->d_info, 0, c->potrf_lookahead(Np), c->potrf_sync(Np));
-        launch_trtri(c->stream, h->L.p, Np, h->Linv.p, h->Kinv.p);
-        launch_lauum(c->stream, h->Linv.p, Np, h->Kinv.p);
+        h->G.ensure((size_t)Np * Np);   // the gradient's weight matrix, written after the factorisation: holds (L^-1)^T until then
+        launch_trtri(c->stream, h->L.p, Np, h->Linv.p, h->Kinv.p, h->G.p);
+        launch_lauum(c->stream, h->G.p, Np, h->Kinv.p);
         launch_logdet(c->stream, h->L.p, Np, N, h->scal.p + 4);
         SLS_HIP(hipMemcpyAsync(info2, c->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         SLS_HIP(hipMemcpyAsync(&h->logdet, h->scal.p + 4, sizeof(double), hipMemcpyDeviceToHost, c->stream));

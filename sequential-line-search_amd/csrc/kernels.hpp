@@ -171,11 +171,11 @@ void launch_potrf_persistent(hipStream_t s, double* A, int Np, double* Linv, int
 void potrf_aux_create(PotrfAux* aux, int free_per_xcd);
 void potrf_aux_destroy(PotrfAux* aux);
 // Linv <- L^-1 (lower) given L and the diagonal-block inverses already in Linv; tmp is an Np x Np scratch.
-void launch_trtri(hipStream_t s, const double* L, int Np, double* Linv, double* tmp);
+void launch_trtri(hipStream_t s, const double* L, int Np, double* Linv, double* tmp, double* U);   // U <- (L^-1)^T
 // diagonal-block inverses only (for potrs / potri on a caller-supplied factor)
 void launch_diag_inverse(hipStream_t s, const double* L, int Np, double* Linv);
 // Kinv <- Linv^T Linv (full symmetric)
-void launch_lauum(hipStream_t s, const double* Linv, int Np, double* Kinv);
+void launch_lauum(hipStream_t s, const double* U, int Np, double* Kinv);                           // K^-1 = U U^T
 // B (Np x Rp, ld = Np, Rp multiple of 128) <- (L L^T)^-1 B using the block inverses in Linv's diagonal
 void launch_potrs(hipStream_t s, const double* L, const double* Linv, int Np, double* B, int Rp);
 // y = A x; `part` is a caller-owned scratch of (Np/128) * Np doubles (per-chunk partial sums, reduced in fixed order)

@@ -37,34 +37,44 @@ struct GemmDesc {
     int tri;           // 1: only tiles tm >= tn + tri_off
     int tri_off;
     int order;         // tile issue order (longest k range first): 0 blockIdx = tm + tn*mt; 1 lower triangle row by row from
-                       // tm = 0 (grid = mt (mt + 1) / 2, kmode 3); 2 rows from tm = mt - 1 down (kmode 2)
-    int kmode;         // 0: [0,K)  1: [128 tn, K)  2: [0, 128 (tm+1))  3: [128 max(tm,tn), K)
-    int vb_stride, vb_off, vb_limit;   // tile row valid iff batch*vb_stride + vb_off + tm < vb_limit
+                       // tm = 0 (grid = mt (mt + 1) / 2, kmode 3); 2 rows from tm = mt - 1 down (kmode 2); 3 rows from tm = 0 (kmode 4)
+    int kmode;         // 0: [0,K)  1: [128 tn, K)  2: [0, 128 (tm+1))  3: [128 max(tm,tn), K)  4: [128 tm, K)
+    int vb_stride, vb_off, vb_limit;   // tile row (vb_on_n: tile column) valid iff batch*vb_stride + vb_off + tm (tn) < vb_limit
+    int vb_on_n;
 };
 
-template <bool A_KC, bool B_KC>
+// NJ = 4: one workgroup per 128 x 128 tile.  NJ = 2 (both operands M-contiguous only): two workgroups per tile, each the 64
+// columns [64 h, 64 h + 64) -- same slabs, fragments and k order (gemm_tile_mc), so the same bits at twice the workgroup count,
+// for launches whose 128 x 128 tiling leaves most of the chip's workgroup slots empty.
+template <bool A_KC, bool B_KC, int NJ = 4>
 __global__ __launch_bounds__(256, 2) void tri_gemm_kernel(GemmDesc g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
-    int tm = blockIdx.x % g.mt, tn = blockIdx.x / g.mt;
+    const int unit = NJ == 4 ? blockIdx.x : blockIdx.x >> 1;
+    const int nhalf = NJ == 4 ? 0 : blockIdx.x & 1;
+    int tm = unit % g.mt, tn = unit / g.mt;
     if (g.order == 1) {          // row-major enumeration of the lower triangle: all tiles of row tm share one k length
-        int t = blockIdx.x;
+        int t = unit;
         tm = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
         while (tm * (tm + 1) / 2 > t) --tm;
         while ((tm + 1) * (tm + 2) / 2 <= t) ++tm;
         tn = t - tm * (tm + 1) / 2;
     } else if (g.order == 2) {
-        tm = g.mt - 1 - blockIdx.x / g.nt;
-        tn = blockIdx.x % g.nt;
+        tm = g.mt - 1 - unit / g.nt;
+        tn = unit % g.nt;
+    } else if (g.order == 3) {
+        tm = unit / g.nt;
+        tn = unit % g.nt;
     }
     const int batch = blockIdx.y;
     if (g.tri && tn + g.tri_off > tm) return;
-    if (batch * g.vb_stride + g.vb_off + tm >= g.vb_limit) return;
+    if (batch * g.vb_stride + g.vb_off + (g.vb_on_n ? tn : tm) >= g.vb_limit) return;
     const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
     int kb = 0, ke = g.K;
     if (g.kmode == 1) kb = NB * tn;
     else if (g.kmode == 2) ke = min(g.K, NB * (tm + 1));
     else if (g.kmode == 3) kb = NB * max(tm, tn);
+    else if (g.kmode == 4) kb = NB * tm;
     const double* A = g.A + batch * g.strideA;
     const double* B = g.B + batch * g.strideB;
     double* C = g.C + batch * g.strideC;
@@ -72,14 +82,16 @@ __global__ __launch_bounds__(256, 2) void tri_gemm_kernel(GemmDesc g) {
     const double* Bp = B_KC ? B + (long)n0 * g.ldb : B + n0;
     Acc acc;
     acc.zero();
-    gemm_tile<A_KC, B_KC, 4, true>(acc, Ap, g.lda, Bp, g.ldb, kb, ke, lds);   // kb, ke multiples of 128
+    gemm_tile<A_KC, B_KC, NJ, true>(acc, Ap, g.lda, Bp, g.ldb, kb, ke, lds, nhalf);   // kb, ke multiples of 128
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ncol0 = NJ == 4 ? (wave >> 1) * 64 : 64 * nhalf + (wave >> 1) * 32;   // this wave's first column in the tile
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                double* c = C + (long)(m0 + acc_m(i)) + (long)(n0 + acc_n(j, r)) * g.ldc;
+                double* c = C + (long)(m0 + acc_m(i)) + (long)(n0 + ncol0 + 16 * j + (lane >> 4) + 4 * r) * g.ldc;
                 double v = g.alpha * acc.v[i][j][r];
                 if (g.beta != 0.0) v += g.beta * *c;
                 *c = v;
@@ -136,6 +148,13 @@ static void launch_tri_gemm(hipStream_t s, const GemmDesc& g, int batches) {
     const int grid = g.order == 1 ? g.mt * (g.mt + 1) / 2 : g.mt * g.nt;
     hipLaunchKernelGGL((tri_gemm_kernel<A_KC, B_KC>), dim3(grid, batches), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, g);
 }
+// both operands M-contiguous, half tiles (two workgroups per 128 x 128 tile)
+static void launch_tri_gemm_mc_half(hipStream_t s, const GemmDesc& g, int batches) {
+    ensure_dyn_lds((const void*)tri_gemm_kernel<false, false, 2>, GEMM_LDS_BYTES);
+    if (g.mt <= 0 || g.nt <= 0 || batches <= 0) return;
+    const int grid = g.order == 1 ? g.mt * (g.mt + 1) / 2 : g.mt * g.nt;
+    hipLaunchKernelGGL((tri_gemm_kernel<false, false, 2>), dim3(2 * grid, batches), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, g);
+}
 
 static GemmDesc mkdesc(const double* A, long lda, const double* B, long ldb, double* C, long ldc, int mt, int nt, int K,
                        double alpha, double beta) {
@@ -144,7 +163,7 @@ static GemmDesc mkdesc(const double* A, long lda, const double* B, long ldb, dou
     g.B = B; g.ldb = ldb; g.strideB = 0;
     g.C = C; g.ldc = ldc; g.strideC = 0;
     g.mt = mt; g.nt = nt; g.K = K; g.alpha = alpha; g.beta = beta;
-    g.tri = 0; g.tri_off = 0; g.order = 0; g.kmode = 0; g.vb_stride = 0; g.vb_off = 0; g.vb_limit = 1 << 30;
+    g.tri = 0; g.tri_off = 0; g.order = 0; g.kmode = 0; g.vb_stride = 0; g.vb_off = 0; g.vb_limit = 1 << 30; g.vb_on_n = 0;
     return g;
 }
 
@@ -902,33 +921,62 @@ void launch_diag_inverse(hipStream_t s, const double* L, int Np, double* Linv) {
     }
 }
 
-// Linv (diagonal blocks already inverted) <- full lower-triangular inverse.  Level with half-size h blocks:
-// pair p = blocks [2hp, 2hp+h) | [2hp+h, min(2hp+2h, nb));  tmp = L21 X11 ; X21 = -X22 tmp.
-void launch_trtri(hipStream_t s, const double* L, int Np, double* Linv, double* tmp) {
+// dst block = (src block)^T for `batches` blocks of tr x tc 32 x 32 sub-tiles each (through a padded LDS tile: both sides
+// coalesced).  Blocks whose first tile row lies beyond the matrix are skipped (vb_*, as in GemmDesc).
+__global__ __launch_bounds__(256) void transpose_blocks_kernel(const double* __restrict__ src, double* __restrict__ dst, long ld,
+                                                               long stride, int vb_stride, int vb_off, int vb_limit) {
+    __shared__ double tile[32][33];
+    const int batch = blockIdx.z;
+    // rows of the source block beyond the matrix do not exist (last pair of a level): 128-row granularity
+    if (batch * vb_stride + vb_off + (int)(blockIdx.x / 4) >= vb_limit) return;
+    const double* S = src + batch * stride;
+    double* Dp = dst + batch * stride;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int r = ty; r < 32; r += 8) tile[r][tx] = S[(long)(32 * blockIdx.x + tx) + (long)(32 * blockIdx.y + r) * ld];   // tile[col][row]
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) Dp[(long)(32 * blockIdx.y + tx) + (long)(32 * blockIdx.x + r) * ld] = tile[tx][r];
+}
+
+// Linv (diagonal blocks already inverted) <- full lower-triangular inverse X = L^-1, and U <- X^T (upper triangular), level by
+// level (recursive doubling).  Level with half-size h blocks, pair p = blocks F = [2hp, 2hp+h) | S = [2hp+h, min(2hp+2h, nb)):
+//     W (F x S) = U_FF L_SF^T        (= (L_SF X_FF)^T)         k >= 128 tm
+//     X_SF      = -X_SS W^T                                     k <  128 (tm + 1)
+//     U_FS      = X_SF^T                                        (transpose_blocks_kernel)
+// Keeping the transposed inverse next to the inverse makes BOTH products NT forms of column-major operands, i.e. both operands
+// M-contiguous: they run on gemm_tile_mc (LDS-direct loads, 0.95 of the MFMA peak) instead of the staged K-contiguous path
+// (0.6-0.7), and so does lauum (K^-1 = U U^T).  Every element is the same dot product in the same k order as in the NN form
+// (tmp = L_SF X_FF, X_SF = -X_SS tmp), so the results are bit-identical to it.  W lives in `tmp` (the K^-1 buffer, free until
+// lauum).  U's strictly-lower blocks are never read; its diagonal blocks are the transposed diagonal blocks of X.
+void launch_trtri(hipStream_t s, const double* L, int Np, double* Linv, double* tmp, double* U) {
     const int nb = Np / NB;
     const long ld = Np;
+    // diagonal blocks: U_jj = X_jj^T (zeros included)
+    hipLaunchKernelGGL(transpose_blocks_kernel, dim3(4, 4, nb), dim3(256), 0, s, Linv, U, ld, (long)NB * (ld + 1), 0, 0, 1 << 30);
     for (int h = 1; h < nb; h *= 2) {
         const int pairs = (nb + 2 * h - 1) / (2 * h);
         const long pstride = (long)2 * h * NB * (ld + 1);
-        const long off21 = (long)h * NB;   // rows of the second half, columns of the first
-        // tmp21 = L21 * X11 : A = L21 (M-contig), B elem(n,k) = X11[k + n ld] (K-contig), k >= 128 tn
-        GemmDesc g1 = mkdesc(L + off21, ld, Linv, ld, tmp + off21, ld, h, h, h * NB, 1.0, 0.0);
+        const long off21 = (long)h * NB;          // block (S, F): rows of the second half, columns of the first
+        const long off12 = (long)h * NB * ld;     // block (F, S)
+        const bool narrow = (long)h * h * pairs <= 512;   // fewer 128 x 128 tiles than workgroup slots: half tiles
+        // W = U_FF * L_SF^T : A = U_FF (M-contig, k >= 128 tm), B elem(n,k) = L_SF[n + k ld] (M-contig); columns n in S
+        GemmDesc g1 = mkdesc(U, ld, L + off21, ld, tmp + off12, ld, h, h, h * NB, 1.0, 0.0);
         g1.strideA = g1.strideB = g1.strideC = pstride;
-        g1.kmode = 1;
-        g1.vb_stride = 2 * h; g1.vb_off = h; g1.vb_limit = nb;
-        const bool narrow = (long)h * h * pairs <= 512;   // fewer 128 x 128 tiles than workgroup slots
-        if (narrow) launch_tri_gemm64<false>(s, g1, pairs);
-        else launch_tri_gemm<false, true>(s, g1, pairs);
-        // X21 = -X22 * tmp21 : A = X22 (M-contig), B elem(n,k) = tmp21[k + n ld] (K-contig), k < 128 (tm+1)
-        GemmDesc g2 = mkdesc(Linv + (long)h * NB * (ld + 1), ld, tmp + off21, ld, Linv + off21, ld, h, h, h * NB, -1.0, 0.0);
+        g1.kmode = 4;
+        g1.vb_stride = 2 * h; g1.vb_off = h; g1.vb_limit = nb; g1.vb_on_n = 1;
+        g1.order = 3;       // k >= 128 tm: long rows first
+        if (narrow) launch_tri_gemm_mc_half(s, g1, pairs);
+        else launch_tri_gemm<false, false>(s, g1, pairs);
+        // X_SF = -X_SS * W^T : A = X_SS (M-contig, k < 128 (tm+1)), B elem(n,k) = W[n + k ld] (M-contig); rows m in S
+        GemmDesc g2 = mkdesc(Linv + (long)h * NB * (ld + 1), ld, tmp + off12, ld, Linv + off21, ld, h, h, h * NB, -1.0, 0.0);
         g2.strideA = g2.strideB = g2.strideC = pstride;
         g2.kmode = 2;
         g2.vb_stride = 2 * h; g2.vb_off = h; g2.vb_limit = nb;
-        if (narrow) launch_tri_gemm64<false>(s, g2, pairs);
-        else {
-            g2.order = 2;   // k < 128 (tm + 1): long rows first
-            launch_tri_gemm<false, true>(s, g2, pairs);
-        }
+        g2.order = 2;       // k < 128 (tm + 1): long rows first
+        if (narrow) launch_tri_gemm_mc_half(s, g2, pairs);
+        else launch_tri_gemm<false, false>(s, g2, pairs);
+        // U_FS = X_SF^T
+        hipLaunchKernelGGL(transpose_blocks_kernel, dim3(4 * h, 4 * h, pairs), dim3(256), 0, s, Linv + off21, U + off12,
+                           ld, pstride, 2 * h, h, nb);
     }
 }
 
@@ -946,25 +994,24 @@ __global__ __launch_bounds__(256) void symmetrize_kernel(double* __restrict__ A,
     }
 }
 
-void launch_lauum(hipStream_t s, const double* Linv, int Np, double* Kinv) {
+// K^-1 = X^T X = U U^T with U = X^T (launch_trtri): lower tiles, A elem(m,k) = U[m + k ld], B elem(n,k) = U[n + k ld] (both
+// M-contiguous), k >= 128 max(tm,tn) = 128 tm.
+void launch_lauum(hipStream_t s, const double* U, int Np, double* Kinv) {
     const int nb = Np / NB;
     const long ld = Np;
-    // lower tiles of X^T X: A elem(m,k) = X[k + m ld], B elem(n,k) = X[k + n ld], k >= 128 max(tm,tn)
-    GemmDesc g = mkdesc(Linv, ld, Linv, ld, Kinv, ld, nb, nb, Np, 1.0, 0.0);
+    GemmDesc g = mkdesc(U, ld, U, ld, Kinv, ld, nb, nb, Np, 1.0, 0.0);
     g.tri = 1;
     g.kmode = 3;
-    // small matrices leave most workgroup slots empty: 128 x 64 tiles double the count (SLS_LAUUM_N64=0/1 overrides)
+    g.order = 1;            // rows from the top, longest k range first, no idle workgroups
+    // small matrices leave most workgroup slots empty: half tiles double the count (SLS_LAUUM_N64=0/1 overrides)
     static int n64_env = -2;
     if (n64_env == -2) {
         const char* e = getenv("SLS_LAUUM_N64");
         n64_env = e ? atoi(e) : -1;
     }
-    const bool narrow = n64_env >= 0 ? n64_env != 0 : nb <= 8;   // measured: N=1024 0.16 -> 0.09 ms, N=4096 0.84 -> 1.0 ms
-    if (narrow) launch_tri_gemm64<true>(s, g, 1);
-    else {
-        g.order = 1;        // k >= 128 max(tm, tn) = 128 tm: rows from the top, longest k range first, no idle workgroups
-        launch_tri_gemm<true, true>(s, g, 1);
-    }
+    const bool narrow = n64_env >= 0 ? n64_env != 0 : nb <= 8;
+    if (narrow) launch_tri_gemm_mc_half(s, g, 1);
+    else launch_tri_gemm<false, false>(s, g, 1);
     hipLaunchKernelGGL(symmetrize_kernel, dim3(Np / 32, Np / 32), dim3(256), 0, s, Kinv, Np);
 }
 
