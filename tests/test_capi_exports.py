@@ -44,3 +44,16 @@ def test_merge_rank_results_first_maximum():
     m = sls()
     best = m.merge_rank_results([(1.0, 7, [0.1]), (2.0, 40, [0.2]), (2.0, 12, [0.3]), (-1.0, 0, [0.4])])
     assert best[0] == 2.0 and best[1] == 12 and best[2][0] == 0.3
+
+
+def test_m0_is_not_live_across_the_saddr_load_statements():
+    """gemm_f64.hpp writes M0 inside its inline-assembly LDS-direct loads (the compiler only emits the SADDR form outside loops)
+    and lists it as clobbered, which clang does not promise to honour for a reserved register.  tools/check_m0.py compiles the
+    kernel sources to gfx950 ISA and verifies that every compiler-placed reader of M0 sees a compiler-placed write in its own
+    basic block with none of those statements in between."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_m0.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "kernels_acq.hip" in r.stdout and "kernels_chol.hip" in r.stdout
