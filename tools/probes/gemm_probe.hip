@@ -1,4 +1,6 @@
-// tiny probe for PMC / variant runs: gemm_probe M N K mode  (mode 0: plain, 1: k start staggered by (tm&7)+(tn&7) slabs, 2: (tm+tn)&7, 3: 2((tm+tn)&7), 4: 2((tm&7)+(tn&7))).  A 2-slab-deep register prefetch was tried and spills (256 VGPRs, 22 TFLOP/s).
+// tiny probe for PMC / variant runs of the library's 128x128 tile: gemm_probe M N K 0.  (Round 1 also measured staggered k starts
+// here, modes 1-4; the k loop of gemm_tile_mc no longer takes a start offset -- tools/probes/ubench.hip keeps its own copy of
+// that experiment.)  A 2-slab-deep register prefetch was tried and spills (256 VGPRs, 22 TFLOP/s).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -23,8 +25,8 @@ __global__ __launch_bounds__(256, 2) void probe_kernel(const double* __restrict_
     if (MODE == 2) ks = ((tm + tn) & 7) * GEMM_BK;
     if (MODE == 3) ks = ((tm + tn) & 7) * 2 * GEMM_BK;
     if (MODE == 4) ks = ((tm & 7) + (tn & 7)) * 2 * GEMM_BK;
-    if (MODE == 0) gemm_tile<false, false>(acc, A + m0, lda, B + n0, ldb, 0, K, lds);
-    else gemm_tile<false, false>(acc, A + m0, lda, B + n0, ldb, 0, K, lds, ks);
+    (void)ks;
+    gemm_tile<false, false>(acc, A + m0, lda, B + n0, ldb, 0, K, lds);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll

@@ -1,9 +1,9 @@
 #!/bin/bash
 # A/B of tile scheduling variants inside the real acq_gemm_kernel: FETCH_SIZE and TCC hit/miss passes.
-# usage: prof_stagger.sh "SLS_PERSIST=0 SLS_GATE_PHASE=0" "SLS_PERSIST=1 SLS_GATE_PHASE=2000" ...
+# usage: prof_gate_variants.sh "SLS_PERSIST=0 SLS_GATE_PHASE=0" "SLS_PERSIST=1 SLS_GATE_PHASE=2000" ...
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/prof_stagger
+OUT=$R/gpurun_out/prof_gate_variants
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp
 BENCH="python $R/bench.py --steps 1 --warmup 0 --n-local 3 --no-cpu-baseline"
