@@ -1,6 +1,5 @@
 // tiny probe for PMC / variant runs of the library's 128x128 tile: gemm_probe M N K 0.  (Round 1 also measured staggered k starts
-// here, modes 1-4; the k loop of gemm_tile_mc no longer takes a start offset -- tools/probes/ubench.hip keeps its own copy of
-// that experiment.)  A 2-slab-deep register prefetch was tried and spills (256 VGPRs, 22 TFLOP/s).
+// here, modes 1-4; the k loop of gemm_tile_mc no longer takes a start offset.)  A 2-slab-deep register prefetch was tried and spills (256 VGPRs, 22 TFLOP/s).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -81,13 +81,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const double* __restrict__
     const double* Bp = B_KC ? B + (long)n0 * ldb : B + n0;
     Acc acc;
     acc.zero();
-    if (group_m < 0) {
-        // staggered k start: the tiles sharing an operand panel on one XCD request a given slab one slab-time apart
-        const int ks = (((tm & 7) + (tn & 7)) * GEMM_BK * STAGGER) % K;
-        gemm_tile<A_KC, B_KC>(acc, Ap, lda, Bp, ldb, 0, K, lds, ks);
-    } else {
-        gemm_tile<A_KC, B_KC>(acc, Ap, lda, Bp, ldb, 0, K, lds);
-    }
+    // (round 1 measured a staggered k start here for group_m < 0; gemm_tile no longer takes a start offset)
+    gemm_tile<A_KC, B_KC>(acc, Ap, lda, Bp, ldb, 0, K, lds);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
