@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <mutex>
+#include <map>
 #include <set>
 #include <utility>
 
@@ -20,11 +21,15 @@ namespace slsk {
 // so the opt-in is recorded per current device, under a lock (launch wrappers run on one host thread per device).
 inline void ensure_dyn_lds(const void* fn, int bytes) {
     static std::mutex mtx;
-    static std::set<std::pair<int, const void*>> done;
+    static std::map<std::pair<int, const void*>, int> done;   // (device, kernel) -> largest size set so far
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(mtx);
-    if (done.insert({dev, fn}).second) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    int& have = done[{dev, fn}];
+    if (bytes > have) {
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        have = bytes;
+    }
 }
 
 struct KernelSpec {

@@ -141,19 +141,29 @@ static void launch_tri_gemm64(hipStream_t s, const GemmDesc& g, int batches) {
     hipLaunchKernelGGL(tri_gemm64_kernel<A_KC>, dim3(g.mt * g.nt * 2, batches), dim3(GEMM_THREADS), GEMM_N64_LDS_BYTES, s, g);
 }
 
+// LDS request of the tile kernels.  one_per_cu: 96 KB, so that only one workgroup fits a CU -- one wave per SIMD keeps the MFMA
+// pipe to itself (see launch_acq_gemm); measured for trtri at N = 8192: 3.44 -> 3.19 ms, for lauum no difference.
+// SLS_TRI_WG_PER_CU=1 / 2 forces either for every launch (A/B switch).
+static int tri_lds_bytes(bool one_per_cu) {
+    const char* e = getenv("SLS_TRI_WG_PER_CU");
+    if (e) one_per_cu = atoi(e) == 1;
+    return one_per_cu ? 96 * 1024 : GEMM_LDS_BYTES;
+}
 template <bool A_KC, bool B_KC>
-static void launch_tri_gemm(hipStream_t s, const GemmDesc& g, int batches) {
-    ensure_dyn_lds((const void*)tri_gemm_kernel<A_KC, B_KC>, GEMM_LDS_BYTES);
+static void launch_tri_gemm(hipStream_t s, const GemmDesc& g, int batches, bool one_per_cu = false) {
+    const int lds_bytes = tri_lds_bytes(one_per_cu);
+    ensure_dyn_lds((const void*)tri_gemm_kernel<A_KC, B_KC>, lds_bytes);
     if (g.mt <= 0 || g.nt <= 0 || batches <= 0) return;
     const int grid = g.order == 1 ? g.mt * (g.mt + 1) / 2 : g.mt * g.nt;
-    hipLaunchKernelGGL((tri_gemm_kernel<A_KC, B_KC>), dim3(grid, batches), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, g);
+    hipLaunchKernelGGL((tri_gemm_kernel<A_KC, B_KC>), dim3(grid, batches), dim3(GEMM_THREADS), lds_bytes, s, g);
 }
 // both operands M-contiguous, half tiles (two workgroups per 128 x 128 tile)
-static void launch_tri_gemm_mc_half(hipStream_t s, const GemmDesc& g, int batches) {
-    ensure_dyn_lds((const void*)tri_gemm_kernel<false, false, 2>, GEMM_LDS_BYTES);
+static void launch_tri_gemm_mc_half(hipStream_t s, const GemmDesc& g, int batches, bool one_per_cu = false) {
+    const int lds_bytes = tri_lds_bytes(one_per_cu);
+    ensure_dyn_lds((const void*)tri_gemm_kernel<false, false, 2>, lds_bytes);
     if (g.mt <= 0 || g.nt <= 0 || batches <= 0) return;
     const int grid = g.order == 1 ? g.mt * (g.mt + 1) / 2 : g.mt * g.nt;
-    hipLaunchKernelGGL((tri_gemm_kernel<false, false, 2>), dim3(2 * grid, batches), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, g);
+    hipLaunchKernelGGL((tri_gemm_kernel<false, false, 2>), dim3(2 * grid, batches), dim3(GEMM_THREADS), lds_bytes, s, g);
 }
 
 static GemmDesc mkdesc(const double* A, long lda, const double* B, long ldb, double* C, long ldc, int mt, int nt, int K,
@@ -964,16 +974,16 @@ void launch_trtri(hipStream_t s, const double* L, int Np, double* Linv, double* 
         g1.kmode = 4;
         g1.vb_stride = 2 * h; g1.vb_off = h; g1.vb_limit = nb; g1.vb_on_n = 1;
         g1.order = 3;       // k >= 128 tm: long rows first
-        if (narrow) launch_tri_gemm_mc_half(s, g1, pairs);
-        else launch_tri_gemm<false, false>(s, g1, pairs);
+        if (narrow) launch_tri_gemm_mc_half(s, g1, pairs, true);
+        else launch_tri_gemm<false, false>(s, g1, pairs, true);
         // X_SF = -X_SS * W^T : A = X_SS (M-contig, k < 128 (tm+1)), B elem(n,k) = W[n + k ld] (M-contig); rows m in S
         GemmDesc g2 = mkdesc(Linv + (long)h * NB * (ld + 1), ld, tmp + off12, ld, Linv + off21, ld, h, h, h * NB, -1.0, 0.0);
         g2.strideA = g2.strideB = g2.strideC = pstride;
         g2.kmode = 2;
         g2.vb_stride = 2 * h; g2.vb_off = h; g2.vb_limit = nb;
         g2.order = 2;       // k < 128 (tm + 1): long rows first
-        if (narrow) launch_tri_gemm_mc_half(s, g2, pairs);
-        else launch_tri_gemm<false, false>(s, g2, pairs);
+        if (narrow) launch_tri_gemm_mc_half(s, g2, pairs, true);
+        else launch_tri_gemm<false, false>(s, g2, pairs, true);
         // U_FS = X_SF^T
         hipLaunchKernelGGL(transpose_blocks_kernel, dim3(4 * h, 4 * h, pairs), dim3(256), 0, s, Linv + off21, U + off12,
                            ld, pstride, 2 * h, h, nb);

@@ -174,10 +174,10 @@ def test_c5_size_map_gradient(ctx, oracle):
 
 @pytest.mark.parametrize("kernel", [0, 1])
 def test_acq_gemm_scheduling_variants_agree(ctx, oracle, kernel, monkeypatch):
-    """The tile-scheduling variants of acq_gemm_kernel (one tile per workgroup, persistent generation-gated form with one or
-    two gate groups per XCD) only change the ORDER in which tiles run: values and gradients must be bit-identical across
-    them, and agree with the oracle, at a size where the gated form is active (N = 2048 -> 16 row tiles, 8192 candidates ->
-    64 column tiles = 1024 tiles = two generations)."""
+    """The tile-scheduling variants of acq_gemm_kernel (one or two workgroups per CU; one tile per workgroup or the persistent
+    generation-gated form with one or two gate groups per XCD) only change the ORDER in which tiles run: values and gradients
+    must be bit-identical across them, and agree with the oracle, at a size where the gated forms are active (N = 2048 -> 16
+    row tiles, 8192 candidates -> 64 column tiles = 1024 tiles = two to four generations)."""
     D, N, M = 16, 2048, 8192
     X, y, theta, b = synth_problem(oracle, D, N)
     Xs = synth_candidates(oracle, D, M)
@@ -185,8 +185,11 @@ def test_acq_gemm_scheduling_variants_agree(ctx, oracle, kernel, monkeypatch):
     ctx.set_candidate_chunk(16384)
     monkeypatch.setenv("SLS_WAVE_PATH", "0")
     base = None
-    for env in ({"SLS_PERSIST": "0", "SLS_GATE_PHASE": "2000"}, {"SLS_PERSIST": "1", "SLS_GATE_PHASE": "2000"},
-                {"SLS_PERSIST": "1", "SLS_GATE_PHASE": "0"}):
+    for env in ({"SLS_ACQ_WG_PER_CU": "1", "SLS_PERSIST": "0", "SLS_GATE_PHASE": "2000"},     # the default
+                {"SLS_ACQ_WG_PER_CU": "1", "SLS_PERSIST": "1", "SLS_GATE_PHASE": "2000"},
+                {"SLS_ACQ_WG_PER_CU": "2", "SLS_PERSIST": "0", "SLS_GATE_PHASE": "2000"},
+                {"SLS_ACQ_WG_PER_CU": "2", "SLS_PERSIST": "1", "SLS_GATE_PHASE": "2000"},
+                {"SLS_ACQ_WG_PER_CU": "2", "SLS_PERSIST": "1", "SLS_GATE_PHASE": "0"}):
         for k_, v_ in env.items():
             monkeypatch.setenv(k_, v_)
         val, grad = gp.acq_eval(Xs)

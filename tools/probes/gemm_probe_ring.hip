@@ -525,6 +525,7 @@ int main(int argc, char** argv) {
         run<50>(M, N, K, reps, dA, dB, dC, GEMM_LDS_BYTES, "gemm_tile_mc, CU partner at prio 3");
         run<53>(M, N, K, reps, dA, dB, dC, GEMM_LDS_BYTES, "gemm_tile_mc, CU partner at prio 1");
         run<51>(M, N, K, reps, dA, dB, dC, 160 * 1024, "gemm_tile_mc, 1 WG/CU");
+        run<41>(M, N, K, reps, dA, dB, dC, 160 * 1024, "gemm_tile_mc<EVEN>, 1 WG/CU");
         run<52>(M, N, K, reps, dA, dB, dC, 160 * 1024, "MFMA only, 1 WG/CU");
         run<115>(M, N, K, reps, dA, dB, dC, GEMM_LDS_BYTES, "MFMA only, 2 WG/CU");
         run<40>(M, N, K, reps, dA, dB, dC, GEMM_LDS_BYTES, "gemm_tile_mc again");
