@@ -57,14 +57,25 @@ __device__ __forceinline__ void acq_tile(int t, int nhalf, int ntm, int ntn, con
             pk = ex[((0 * 2 + (wave & 1)) * 4 + i) * 64 + lane];
             pc = ex[((1 * 2 + (wave & 1)) * 4 + i) * 64 + lane];
         }
+        // all K* / C* values of this row block first (up to 32 loads in flight), then the arithmetic and the stores: written
+        // load - use - store per element the compiler emits 64 dependent memory round trips per lane
+        double kv[NJ][4], cv[NJ][4];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long off = gm_ + (long)(n0 + nbase + 16 * j + (lane >> 4) + 4 * r) * ldk;
+                kv[j][r] = Ks[off];
+                if (MATERN) cv[j][r] = Cs[off];
+            }
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const long off = gm_ + (long)(n0 + nbase + 16 * j + (lane >> 4) + 4 * r) * ldk;
                 const double wv = acc.v[i][j][r];
-                const double k = Ks[off];
-                const double c = MATERN ? Cs[off] : k;
+                const double k = kv[j][r];
+                const double c = MATERN ? cv[j][r] : k;
                 const double p = c * wv;
                 P[off] = p;
                 pc += p;
@@ -111,7 +122,7 @@ __device__ __forceinline__ void acq_tile(int t, int nhalf, int ntm, int ntn, con
 // ntiles: the tiles this launch runs as whole tiles (the first ntiles of the grouped order); a partially filled last
 // generation goes to acq_gemm_half_kernel instead (launch_acq_gemm).
 template <bool MATERN>
-__global__ __launch_bounds__(256, 2) void acq_gemm_kernel(const double* __restrict__ Ks, const double* __restrict__ Cs, long ldk,
+__global__ __launch_bounds__(256, 1) void acq_gemm_kernel(const double* __restrict__ Ks, const double* __restrict__ Cs, long ldk,
                                                           int Sp, const double* __restrict__ Kinv, int Np,
                                                           double* __restrict__ P, double* __restrict__ kw_part,
                                                           double* __restrict__ cw_part, int* __restrict__ sync,
@@ -166,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void acq_gemm_kernel(const double* __restri
 // The partially filled LAST generation (at most half of the 512 workgroup slots would hold a tile): its tiles
 // [tail_first, tail_first + gridDim.x / 2) run as half tiles on twice as many workgroups, unit u = tile u / 2, half u & 1.
 template <bool MATERN>
-__global__ __launch_bounds__(256, 2) void acq_gemm_half_kernel(const double* __restrict__ Ks, const double* __restrict__ Cs, long ldk,
+__global__ __launch_bounds__(256, 1) void acq_gemm_half_kernel(const double* __restrict__ Ks, const double* __restrict__ Cs, long ldk,
                                                                int Sp, const double* __restrict__ Kinv, int Np,
                                                                double* __restrict__ P, double* __restrict__ kw_part,
                                                                double* __restrict__ cw_part, int tail_first) {
