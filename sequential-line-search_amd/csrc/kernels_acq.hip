@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256, 1) void acq_gemm_kernel(const double* __restri
     }
     int gen = 0;
     for (int c = xcd; c < nchunks; c += 8, ++gen) {
-        if (gen > 0) {
+        if (gen > 0 && phase >= 0) {   // phase < 0: persistent but ungated (SLS_PERSIST=2)
             if (threadIdx.x == 0) {
                 const int target = per_gen * gen;
                 const long long t0 = wall_clock64();
@@ -190,11 +190,12 @@ __global__ __launch_bounds__(256, 1) void acq_gemm_half_kernel(const double* __r
 int launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk, int Sp, const double* Kinv, int Np, double* P,
                     double* kw_part, double* cw_part, int* sync) {
     const int nt = (Sp / GEMM_BM) * (Np / GEMM_BN);
-    // SLS_PERSIST (1: persistent generation-gated form, 0: one tile per workgroup; default: gated iff two workgroups per CU,
-    // see below) is read per call so that tests and A/B runs can switch within one process
+    // SLS_PERSIST (0: one tile per workgroup, 1: persistent workgroups with generation gates, 2: persistent without gates;
+    // default 1 with two workgroups per CU, 2 with one, see below) is read per call so that tests and A/B runs can switch
+    // within one process
     const char* ep = getenv("SLS_PERSIST");
     const char* ew0 = getenv("SLS_ACQ_WG_PER_CU");
-    const int persist_env = ep ? atoi(ep) : ((ew0 && atoi(ew0) == 2) ? 1 : 0);
+    const int persist_env = ep ? atoi(ep) : ((ew0 && atoi(ew0) == 2) ? 1 : 2);
     // SLS_GATE_PHASE: start offset (ticks of the 100 MHz clock) between the two gate groups of an XCD; 0: one gate per XCD.
     // Measured per 65 536-candidate launch: phase 0 124.8 ms / 77 GB (hit rate 0.856); phase 2000..8000 123.2-123.3 ms /
     // 112 GB (0.795: each group of 8 x 4 tiles shares 12 panels); ungated 124.9 ms / 333 GB (0.42).
@@ -206,10 +207,11 @@ int launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk,
     // SLS_ACQ_WG_PER_CU (default 1): one workgroup per CU (a 96 KB LDS request keeps a second one out).  One wave per SIMD has
     // the MFMA pipe to itself -- two waves alternating on it lose ~3 % to the switches (gemm_probe_ring, 16384 x 8192 x 8192:
     // 76.8 TFLOP/s = the MFMA-only loop's rate, against 75.0 with two workgroups per CU).  The tile epilogues are then hidden by
-    // nobody, which is why this form runs UNGATED, one tile per workgroup in the XCD-grouped order: the hardware dispatcher
-    // starts the next tile's workgroup the moment a CU frees up (with generation gates 0.9455 of peak, without 0.9587; two
-    // workgroups per CU, gated: 0.9502; bench step 4349 -> 4311 ms, 8 192-start shard 584.7 -> 574.9 ms), at 156 instead of
-    // 120 GB of fabric traffic per 65 536-candidate launch.  2 = two per CU, generation-gated (the round-1 form).
+    // nobody, which is why this form runs UNGATED (with generation gates 0.9455 of peak, without 0.9587; two workgroups per
+    // CU, gated: 0.9502; bench step 4349 -> 4311 ms, 8 192-start shard 584.7 -> 574.9 ms), at 156-161 instead of 120 GB of
+    // fabric traffic per 65 536-candidate launch.  Persistent workgroups walking their tile lists without gates are another
+    // 0.25 % faster than one workgroup per tile (4293 / 4298 -> 4285 / 4282 ms): no workgroup launch between tiles.
+    // 2 = two per CU, generation-gated (the round-1 form).
     const char* ew = getenv("SLS_ACQ_WG_PER_CU");
     const int wg_per_cu = (ew && atoi(ew) == 2) ? 2 : 1;
     const int cap = 256 * wg_per_cu;                                 // tiles the chip holds at a time
@@ -219,6 +221,7 @@ int launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk,
     ensure_dyn_lds((const void*)acq_gemm_half_kernel<false>, lds_bytes);
     ensure_dyn_lds((const void*)acq_gemm_half_kernel<true>, lds_bytes);
     const bool persist = persist_env && sync && nt >= 2 * cap && Np >= 2048;
+    const int phase_k = persist_env == 2 ? -1 : phase;               // SLS_PERSIST=2: persistent workgroups without the gates
     // Tail split (SLS_TAIL_SPLIT=0 disables): the chip holds 512 tiles at a time; if the last such generation is at most half
     // full its tiles run as half tiles on twice the workgroups in a second launch (same bits, half the time for that
     // generation: 663 -> 642 ms per step on the 8 192-start shard of an 8-GPU run).
@@ -238,10 +241,10 @@ int launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk,
     if (nmain > 0) {
         if (matern)
             hipLaunchKernelGGL(acq_gemm_kernel<true>, dim3(grid), dim3(GEMM_THREADS), lds_bytes, s, Ks, Cs, ldk, Sp, Kinv, Np, P,
-                               kw_part, cw_part, sy, phase, nmain, prio);
+                               kw_part, cw_part, sy, phase_k, nmain, prio);
         else
             hipLaunchKernelGGL(acq_gemm_kernel<false>, dim3(grid), dim3(GEMM_THREADS), lds_bytes, s, Ks, Cs, ldk, Sp, Kinv, Np, P,
-                               kw_part, cw_part, sy, phase, nmain, prio);
+                               kw_part, cw_part, sy, phase_k, nmain, prio);
     }
     if (tail > 0) {
         if (matern)
