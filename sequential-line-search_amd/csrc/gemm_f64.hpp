@@ -325,9 +325,19 @@ struct Acc64 {
     }
 };
 
-template <bool A_KC = false>
+// A_LD (M-contiguous A only): doubles per k-row of the A slab image.  144 is conflict-free for the fragment reads; 136 (two-way
+// conflicts on them) brings two buffers down to 53 248 B, so that THREE workgroups fit a CU's 160 KB: the HBM-bound gradient
+// contraction wants bytes in flight, not LDS read bandwidth.
+template <int A_LD>
+constexpr int gemm_n64_lds_bytes() {
+    return 2 * (16 * A_LD + GEMM_N64_LDS_B) * 8;
+}
+template <bool A_KC = false, int A_LD = GEMM_LDS_MC_LD>
 __device__ __forceinline__ void gemm_tile_n64(Acc64& acc, const double* __restrict__ A, long lda,
                                               const double* __restrict__ B, long ldb, int kb, int ke, double* lds) {
+    static_assert(!A_KC || A_LD == GEMM_LDS_MC_LD, "the K-contiguous image has its own padding");
+    constexpr int A_SLAB = 16 * A_LD;                  // doubles (= GEMM_LDS_TILE for the default)
+    constexpr int BUF = A_SLAB + GEMM_N64_LDS_B;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wm = (tid >> 6) * 32;
@@ -357,7 +367,7 @@ __device__ __forceinline__ void gemm_tile_n64(Acc64& acc, const double* __restri
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 4 * wave_u + r;
-            slab_row_to_lds(A + 2 * lane + (long)(k0 + row) * lda, lds + bufoff + row * GEMM_LDS_MC_LD);
+            slab_row_to_lds(A + 2 * lane + (long)(k0 + row) * lda, lds + bufoff + row * A_LD);
         }
     };
     if (DIRECT_A) issue_a(kb, 0);
@@ -365,23 +375,25 @@ __device__ __forceinline__ void gemm_tile_n64(Acc64& acc, const double* __restri
     load_b(kb);
     if (DIRECT_A) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else stage_store<A_KC>(sa, lds, tid);
-    store_b(lds + GEMM_LDS_TILE);
+    store_b(lds + A_SLAB);
     __syncthreads();
     int cur = 0;
     for (int k0 = kb; k0 < ke; k0 += GEMM_BK) {
         const bool more = (k0 + GEMM_BK) < ke;
         if (more) {
-            if (DIRECT_A) issue_a(k0 + GEMM_BK, cur ^ GEMM_N64_LDS_BUF);
+            if (DIRECT_A) issue_a(k0 + GEMM_BK, cur ^ BUF);
             else stage_load<A_KC>(sa, A, lda, k0 + GEMM_BK, tid);
             load_b(k0 + GEMM_BK);
         }
         const double* la = lds + cur;
-        const double* lb = lds + cur + GEMM_LDS_TILE;
+        const double* lb = lds + cur + A_SLAB;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             double af[2], bf[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = frag_read<A_KC>(la, wm + 16 * i, kk, lane);
+            for (int i = 0; i < 2; ++i)
+                af[i] = A_KC ? frag_read<true>(la, wm + 16 * i, kk, lane)
+                             : la[(4 * kk + (lane >> 4)) * A_LD + wm + 16 * i + (lane & 15)];
 #pragma unroll
             for (int j = 0; j < 4; ++j) bf[j] = frag_read<true>(lb, 16 * j, kk, lane);
 #pragma unroll
@@ -390,10 +402,10 @@ __device__ __forceinline__ void gemm_tile_n64(Acc64& acc, const double* __restri
                 for (int j = 0; j < 4; ++j)
                     acc.v[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[j], af[i], acc.v[i][j], 0, 0, 0);
         }
-        const int nxt = cur ^ GEMM_N64_LDS_BUF;
+        const int nxt = cur ^ BUF;
         if (more) {
             if (!DIRECT_A) stage_store<A_KC>(sa, lds + nxt, tid);
-            store_b(lds + nxt + GEMM_LDS_TILE);
+            store_b(lds + nxt + A_SLAB);
         }
         if (DIRECT_A) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();

@@ -367,6 +367,7 @@ __global__ __launch_bounds__(256, 2) void grad_gemm_kernel(const double* __restr
             for (int r = 0; r < 4; ++r) C[(long)(m0 + acc_m(i)) + (long)(n0 + acc_n(j, r)) * ldk] = acc.v[i][j][r];
 }
 
+constexpr int GRAD64_A_LD = 136;   // A slab rows of 136 doubles: 53 248 B of LDS per workgroup, three workgroups per CU (gemm_tile_n64)
 // D <= 64: 128 x 64 tiles (no wasted MFMA columns), 3 workgroups per CU.
 // The contraction over the N training points is ALWAYS summed as four quarter ranges, ((q0 + q1) + q2) + q3, each quarter
 // accumulated from zero: one workgroup runs the four quarters back to back (gridDim.z == 1), or -- when the launch has fewer
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(256, 3) void grad_gemm64_kernel(const double* __res
     for (int c = c0; c < c1; ++c) {
         Acc64 acc;
         acc.zero();
-        gemm_tile_n64(acc, A + m0, ldk, B, ld, c * q, (c + 1) * q, lds);
+        gemm_tile_n64<false, GRAD64_A_LD>(acc, A + m0, ldk, B, ld, c * q, (c + 1) * q, lds);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -425,10 +426,10 @@ __global__ __launch_bounds__(256) void grad_reduce4_kernel(const double* __restr
 void launch_grad_gemm(hipStream_t s, const double* P, const double* Cs, long ldk, int Sp, const double* XT, const double* XaT,
                       long ld, int Np, int Dcols, double* Gs, double* Gm, double* part) {
     ensure_dyn_lds((const void*)grad_gemm_kernel, GEMM_LDS_BYTES);
-    ensure_dyn_lds((const void*)grad_gemm64_kernel, GEMM_N64_LDS_BYTES);
+    ensure_dyn_lds((const void*)grad_gemm64_kernel, gemm_n64_lds_bytes<GRAD64_A_LD>());
     if (Dcols < 0) {   // caller signals D <= 64 by passing -Dcols
         const bool split = part != nullptr && grad_gemm_wants_split(Sp);
-        hipLaunchKernelGGL(grad_gemm64_kernel, dim3(Sp / GEMM_BM, 2, split ? 4 : 1), dim3(GEMM_THREADS), GEMM_N64_LDS_BYTES, s, P, Cs,
+        hipLaunchKernelGGL(grad_gemm64_kernel, dim3(Sp / GEMM_BM, 2, split ? 4 : 1), dim3(GEMM_THREADS), gemm_n64_lds_bytes<GRAD64_A_LD>(), s, P, Cs,
                            ldk, Sp, XT, XaT, ld, Np, Gs, Gm, part);
         if (split)
             hipLaunchKernelGGL(grad_reduce4_kernel, dim3((unsigned)(((long)Sp * 64 + 255) / 256)), dim3(256), 0, s, part, Sp, ldk, Gs, Gm);
