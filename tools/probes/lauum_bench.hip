@@ -21,6 +21,37 @@ int main(int argc, char** argv) {
     const int nb = Np / NB;
     hipStream_t s; hipStreamCreate(&s);
     double* K; hipMalloc(&K, (size_t)Np * Np * 8);
+    // context experiment: the same lauum launch right behind a persistent potrf (8 ms in which 255 of the 256 workgroups
+    // mostly sleep) -- does the chip come out of that in a slower state?
+    if (getenv("AFTER_POTRF")) {
+        double *A0, *A, *Li, *U; int* info;
+        const size_t bytes = (size_t)Np * Np * 8;
+        hipMalloc(&A0, bytes); hipMalloc(&A, bytes); hipMalloc(&Li, bytes); hipMalloc(&U, bytes); hipMalloc(&info, 8192);
+        hipLaunchKernelGGL(fill_u, dim3((unsigned)(((long)Np * Np + 255) / 256)), dim3(256), 0, s, U, (long)Np, Np);
+        // SPD matrix: U^T U + I would need a product; use a diagonally dominant one instead
+        std::vector<double> h((size_t)Np * Np, 0.0);
+        for (int i = 0; i < Np; ++i) { h[(size_t)i * Np + i] = 4.0; if (i + 1 < Np) { h[(size_t)i * Np + i + 1] = 1.0; h[(size_t)(i + 1) * Np + i] = 1.0; } }
+        hipMemcpy(A0, h.data(), bytes, hipMemcpyHostToDevice);
+        GemmDesc g = mkdesc(U, Np, U, Np, K, Np, nb, nb, Np, 1.0, 0.0);
+        g.tri = 1; g.kmode = 3; g.order = 1;
+        for (int mode = 0; mode < 2; ++mode) {
+            float best = 1e30f;
+            for (int rep = 0; rep < 4; ++rep) {
+                hipMemcpyAsync(A, A0, bytes, hipMemcpyDeviceToDevice, s);
+                hipMemsetAsync(info, 0, 8192, s);
+                hipMemsetAsync(Li, 0, bytes, s);
+                hipStreamSynchronize(s);
+                hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+                if (mode == 1) launch_potrf(s, A, Np, Li, info, 0, nullptr, info + 64);
+                hipEventRecord(e0, s);
+                launch_tri_gemm<false, false>(s, g, 1, false);
+                hipEventRecord(e1, s); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                if (rep > 0 && ms < best) best = ms;
+            }
+            printf("N=%d lauum %-28s %8.3f ms\n", Np, mode ? "right behind a potrf" : "behind an idle stream", best);
+        }
+    }
     for (int pad : pads) {
         const long ld = Np + pad;
         double* U; hipMalloc(&U, (size_t)ld * Np * 8);
