@@ -304,7 +304,9 @@ def main():
                        "starts_per_gpu": S_loc, "n_local_evals": args.n_local, "kernel": args.kernel,
                        "candidate_chunk": chunk, "parallelism": f"starts sharded over {world} GPU(s), one all-gather", "exchange": exchange,
                        "evals_cap_per_step": evals_cap, "evals_issued_per_step": evals_issued,
-                       "evals_semantics": "n_local is a cap per start (NLopt max_evals); finished starts leave the batch"},
+                       "evals_semantics": "n_local is a cap per start (NLopt max_evals); finished starts leave the batch",
+                       "acq_gemm_form": ("2 workgroups per CU, persistent, generation-gated" if os.environ.get("SLS_ACQ_WG_PER_CU") == "2"
+                                         else "1 workgroup per CU, persistent, ungated") + " (SLS_ACQ_WG_PER_CU / SLS_PERSIST)"},
             "roofline": {"bound": "mfma", "kernel": "acq_gemm_kernel", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
                          "traffic_source": traffic_source, "avg_launch_ms": avg_ms, "launches": gemm_launches,
