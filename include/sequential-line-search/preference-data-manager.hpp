@@ -17,7 +17,8 @@ namespace sequential_line_search
         void AddNewPoints(const Eigen::VectorXd& x_preferable, const std::vector<Eigen::VectorXd>& xs_other,
                           const bool merge_close_points = true, const double epsilon = 1e-04);
 
-        const Eigen::VectorXd GetLastSelectedDataPoint() const { return eig::Col(m_X, m_D.back()[0]); }
+        const Eigen::VectorXd GetLastSelectedDataPoint() const { return eig::Col(m_X, GetLastDataSample()[0]); }
+        const Preference&     GetLastDataSample() const { return m_D.back(); }
         int                   GetNumDataPoints() const { return m_X.cols(); }
         const Eigen::MatrixXd&         GetX() const { return m_X; }
         const std::vector<Preference>& GetD() const { return m_D; }

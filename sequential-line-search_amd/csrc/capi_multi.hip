@@ -60,7 +60,8 @@ Rccl* rccl() {
             for (const char* n : names)
                 if ((r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
         if (!r.lib) {
-            r.why = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?");
+            const char* e = dlerror();   // one call: dlerror() clears the state it returns
+            r.why = std::string("cannot load librccl: ") + (e ? e : "?");
             return;
         }
 #define SLS_SYM(field, name)                                                     \
