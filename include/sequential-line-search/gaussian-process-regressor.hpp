@@ -49,6 +49,18 @@ namespace sequential_line_search
 
         sls_gp* GetDeviceHandle() const override;
 
+        /// Extension: what the MAP fit of the first constructor did (all zero for the second constructor).
+        struct MapFitStats
+        {
+            double final_value  = 0.0;   ///< log posterior at the returned (a, b, r)
+            double direct_value = 0.0;   ///< best value of the DIRECT phase
+            double prior_value  = 0.0;   ///< value at the prior medians (the reference's x_ini)
+            int    evals_direct = 0;
+            int    evals_local  = 0;
+            double seconds      = 0.0;
+        };
+        const MapFitStats& GetMapFitStats() const { return m_map_stats; }
+
         /// Extension: add one observation without refitting (O(N^2) update on the device; hyper-parameters unchanged).
         /// m_K_y / m_K_y_inv are refreshed only if this object materialises them.
         void AppendPoint(const Eigen::VectorXd& x, double y);
@@ -62,6 +74,7 @@ namespace sequential_line_search
         Eigen::VectorXd m_kernel_hyperparams;
         double          m_noise_hyperparam;
         bool            m_materialize = true;
+        MapFitStats     m_map_stats;
 
         std::shared_ptr<device::GpHandle> m_handle;
     };

@@ -169,7 +169,7 @@ slsk::PotrfAux* sls_ctx::potrf_lookahead(int Np) {
     const char* e = getenv("SLS_POTRF_LOOKAHEAD");
     const int f = e ? atoi(e) : SLS_POTRF_LOOKAHEAD_DEFAULT;
     const int mode = slsk::potrf_default_mode(Np);
-    if (f <= 0 || mode == 1 || (mode == 0 && slsk::potrf_default_nbo(Np) <= 1)) return nullptr;
+    if (f <= 0 || mode == 1 || mode == 3 || (mode == 0 && slsk::potrf_default_nbo(Np) <= 1)) return nullptr;
     if (!potrf_aux.side) slsk::potrf_aux_create(&potrf_aux, f);
     return &potrf_aux;
 }
@@ -178,6 +178,12 @@ int* sls_ctx::potrf_sync(int Np) {
     // sync words of the single-launch factorisation live behind the info words; nullptr (multi-launch schedule) if they
     // would not fit (N > 60 000)
     return (potrf_persistent_ok && 32 + 2 * (Np / 128) + Np / 128 + 2 <= 960) ? d_info + 64 : nullptr;
+}
+
+int* sls_ctx::potrf_df_sync(int Np) {
+    if (!potrf_persistent_ok || slsk::potrf_default_mode(Np) != 3) return nullptr;
+    potrf_df.ensure((slsk::potrf_dataflow_sync_ints(Np) + 1) / 2);
+    return reinterpret_cast<int*>(potrf_df.p);
 }
 
 namespace slsk {
@@ -360,7 +366,7 @@ static void gp_fit_device(sls_gp* g) {
     launch_fill(c->stream, g->Linv.p, (long)Np * Np, 0.0);
     {
         ProfScope ps(c, "potrf");
-        launch_potrf(c->stream, g->L.p, Np, g->Linv.p, c->d_info, 0, c->potrf_lookahead(Np), c->potrf_sync(Np));
+        launch_potrf(c->stream, g->L.p, Np, g->Linv.p, c->d_info, 0, c->potrf_lookahead(Np), c->potrf_sync(Np), c->potrf_df_sync(Np));
     }
     {
         ProfScope ps(c, "trtri");
@@ -1043,7 +1049,7 @@ extern "C" int sls_potrf(sls_ctx* c, double* A, int N) {
     for (int attempt = 0;; ++attempt) {
         upload_padded_spd(c, Ad, A, N, Np);
         SLS_HIP(hipMemsetAsync(c->d_info, 0, 64, c->stream));
-        launch_potrf(c->stream, Ad.p, Np, Li.p, c->d_info, 0, c->potrf_lookahead(Np), c->potrf_sync(Np));
+        launch_potrf(c->stream, Ad.p, Np, Li.p, c->d_info, 0, c->potrf_lookahead(Np), c->potrf_sync(Np), c->potrf_df_sync(Np));
         launch_zero_upper(c->stream, Ad.p, Np);
         SLS_HIP(hipMemcpyAsync(info2, c->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         d2h_matrix(c, out.data(), Ad.p, N, Np);

@@ -86,7 +86,7 @@ static void nll_factor(sls_nll* h, const double* theta, double b) {
         launch_gram_sym(c->stream, h->XT.p, Np, h->Dp, h->nx.p, Np, N, ks, b, h->L.p, true);
         SLS_HIP(hipMemsetAsync(c->d_info, 0, 64, c->stream));
         launch_fill(c->stream, h->Linv.p, (long)Np * Np, 0.0);
-        launch_potrf(c->stream, h->L.p, Np, h->Linv.p, c->d_info, 0, c->potrf_lookahead(Np), c->potrf_sync(Np));
+        launch_potrf(c->stream, h->L.p, Np, h->Linv.p, c->d_info, 0, c->potrf_lookahead(Np), c->potrf_sync(Np), c->potrf_df_sync(Np));
         h->G.ensure((size_t)Np * Np);   // the gradient's weight matrix, written after the factorisation: holds (L^-1)^T until then
         launch_trtri(c->stream, h->L.p, Np, h->Linv.p, h->Kinv.p, h->G.p);
         launch_lauum(c->stream, h->G.p, Np, h->Kinv.p);

@@ -62,6 +62,10 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
 // workgroup barrier that waits for this wave's LDS traffic only (not for outstanding global stores)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+#ifndef SLS_DIAG16_V
+#define SLS_DIAG16_V 1
+#endif
+#if SLS_DIAG16_V == 0
 template <bool FACTOR>
 __device__ __forceinline__ void diag16(double* As, double* Tk, int c0, int lane, int* info, int global_off) {
     const int row = lane & 15;
@@ -109,6 +113,74 @@ __device__ __forceinline__ void diag16(double* As, double* Tk, int c0, int lane,
         Tk[row + 16 * col] = (col <= row) ? bq[r] * own_inv : 0.0;
     }
 }
+
+#else
+template <bool FACTOR>
+__device__ __forceinline__ void diag16(double* As, double* Tk, int c0, int lane, int* info, int global_off) {
+    const int row = lane & 15, g = lane >> 4;
+    double a[16];
+    double own_inv = 1.0;
+    int bad = 16;                                   // first non-positive pivot of this tile (16: none)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a[j] = As[c0 + row + (c0 + j) * DL];
+#if SLS_DIAG16_V == 1
+    // dd[j]: the running diagonal A_jj - sum_{m<k} L_jm^2, kept in EVERY lane (the same fma lane j applies to its own a[j]:
+    // in lane j the column value lik IS its broadcast), so that the next pivot is one fma behind the broadcast of column k
+    // instead of fma -> broadcast: the serial chain per pivot is rsq, 4 Newton ops, 1 mul, 1 broadcast, 1 fma.
+    double dd[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dd[j] = bcast(a[j], j);
+#endif
+    // inverse: B = I; for k: B[i,:] -= (L[i,k] / L_kk) B[k,:] (i > k); finally B[i,:] /= L_ii.  Row k of B is final before step
+    // k, so its scaling waits until the end (no select on the chain).  The columns of B are independent and are dealt to
+    // the four 16-lane rows of the wave: lane (row, g) keeps columns g, g+4, g+8, g+12, the broadcast of row k stays inside
+    // each 16-lane row, and step k costs k/4 + 1 broadcast + fma pairs instead of k + 1 (columns > k see B[k,j] = 0).
+    // Step k of the inverse only needs column k of L, so it is issued right behind pivot k and fills the pivot chain's
+    // latency bubbles (one wave, in-order issue) instead of following it as a second serial loop.
+    double bq[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bq[r] = (row == 4 * r + g) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+#if SLS_DIAG16_V == 1
+        const double d = dd[k];
+#else
+        const double d = bcast(a[k], k);
+#endif
+        double inv;
+        if (FACTOR) {
+            bad = (!(d > 0.0) && bad == 16) ? k : bad;      // off the chain: reported once, after the loop
+            inv = rsqrt_nr(d);
+            const double lik = a[k] * inv;   // lane k: d * rsqrt(d) = L_kk; rows < k hold unused upper-triangle values
+            a[k] = lik;
+#pragma unroll
+            for (int j = k + 1; j < 16; ++j) {
+                const double bc = bcast(lik, j);
+#if SLS_DIAG16_V == 1
+                dd[j] = fma(-bc, bc, dd[j]);
+#endif
+                a[j] -= lik * bc;
+            }
+        } else {
+            inv = 1.0 / d;
+        }
+        own_inv = (row == k) ? inv : own_inv;
+        const double ck = (row > k) ? a[k] * inv : 0.0;
+#pragma unroll
+        for (int r = 0; r <= k / 4; ++r) bq[r] = fma(-ck, bcast(bq[r], k), bq[r]);
+    }
+    if (FACTOR && bad < 16 && lane == 0 && info) atomicCAS(info, 0, global_off + c0 + bad + 1);
+    if (FACTOR && lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) As[c0 + row + (c0 + j) * DL] = (j <= row) ? a[j] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int col = 4 * r + g;
+        Tk[row + 16 * col] = (col <= row) ? bq[r] * own_inv : 0.0;
+    }
+}
+#endif
 
 // Linv^T tiles in the strictly-upper part of As -> natural strictly-lower positions: the 28 tiles are dealt 7 per wave
 // (tile t -> wave t & 3) with compile-time coordinates (one branch on the wave id instead of 28), reads before writes.

@@ -166,7 +166,11 @@ struct PotrfAux {
 };
 int potrf_default_nbo(int Np);
 void launch_potrf(hipStream_t s, double* A, int Np, double* Linv, int* info, int nbo = 0, PotrfAux* aux = nullptr,
-                  int* persist_sync = nullptr);
+                  int* persist_sync = nullptr, int* dataflow_sync = nullptr);
+// Dataflow form of the single-launch factorisation (SLS_POTRF_MODE=3, default): per-tile ownership and ready flags instead
+// of grid barriers.  sync = potrf_dataflow_sync_ints(Np) ints of device scratch; returns false when not applicable.
+size_t potrf_dataflow_sync_ints(int Np);
+bool launch_potrf_dataflow(hipStream_t s, double* A, int Np, double* Linv, int* info, int* sync, long long* trace = nullptr);
 // The whole factorisation in ONE persistent launch (see kernels_chol.hip); sync = device scratch of >= 8 + 2 (Np/128) ints.
 // info[1] != 0 afterwards: a bounded wait expired (the kernel aborted; results undefined).  launch_potrf takes this path
 // when persist_sync != nullptr, Np >= 384 and SLS_POTRF_MODE is 1 (default; 0 = multi-launch schedule).

@@ -17,7 +17,7 @@
 #include "kernels.hpp"
 
 #ifndef SLS_POTRF_MODE_DEFAULT
-#define SLS_POTRF_MODE_DEFAULT 1
+#define SLS_POTRF_MODE_DEFAULT 3
 #endif
 
 namespace slsk {
@@ -304,6 +304,11 @@ struct PersistArgs {
     int* ext_flag;    // nullptr or a device word another stream raises when columns j0+1 .. have received [k0, j0)
     long long timeout;
     long long* trace;   // optional (probes): 16 wall-clock stamps per step, [0..7] workgroup 0, [8..15] workgroup 1
+    int pr;             // dataflow form: rows of the owner grid
+    int map;            // dataflow form: 0 cyclic PR x PC owner grid, 1 tiles dealt round-robin in column-major order
+    int near;           // dataflow form: columns at the start of an outer block that take the previous block step by step
+    int acq;            // dataflow form: 1 agent-scope acquire before every task, 0 compiler-level ordering only (probes)
+    int idle_sleep;     // dataflow form: s_sleep argument of an idle scheduling round
 };
 constexpr int PK_FLAGS = 32;
 #define PK_STAMP(slot) do { if (a.trace && threadIdx.x == 0) a.trace[16 * j + (slot)] = wall_clock64(); } while (0)
@@ -449,6 +454,42 @@ __device__ __forceinline__ void pk_sub_tile(double* C, long ld, const Acc& acc) 
                 *c = *c - acc.v[i][jj][r];
             }
 }
+// Accumulator tile -> global memory through a column-major LDS image [128][DL] (147 KB: workgroups that own a CU's whole LDS):
+// the accumulator layout gives every lane 8-byte accesses 64 KB apart (16 lanes per 128-byte run), and a 128 x 128 read-modify-
+// write issued that way takes 16 us per tile (measured in the dataflow Cholesky: as long as the K = 128 product itself).
+// From the image every wave moves whole 1 KB columns with 16-byte accesses, all loads of a half tile in flight at once.
+// SUB: C -= acc, otherwise C = acc.  WT: write-through (sc1) stores -- the tile is read by other CUs next (the caller drains
+// and raises a flag), otherwise plain stores.  Values are only moved: same bits as pk_sub_tile / pk_store_tile.
+typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
+template <bool SUB, bool WT>
+__device__ __forceinline__ void tile_commit(double* __restrict__ C, long ld, const Acc& acc, double* img) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) img[acc_m(i) + acc_n(jj, r) * DL] = acc.v[i][jj][r];
+    lds_barrier();
+    auto rsrc = __builtin_amdgcn_make_buffer_rsrc(C, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        d2_t cv[16];
+        if (SUB) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) cv[q] = *reinterpret_cast<const d2_t*>(C + 2 * lane + (long)(w + 4 * (16 * h + q)) * ld);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int c = w + 4 * (16 * h + q);
+            d2_t v = *reinterpret_cast<const d2_t*>(img + 2 * lane + c * DL);
+            if (SUB) v = cv[q] - v;
+            if (WT) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rsrc, (int)((2 * lane + (long)c * ld) * 8), 0, 16);
+            else *reinterpret_cast<d2_t*>(C + 2 * lane + (long)c * ld) = v;
+        }
+    }
+}
+
 // the workgroup's own global stores -> its own later loads: stores complete (barrier), this CU's L1 dropped
 __device__ __forceinline__ void pk_self_fence() {
     __syncthreads();
@@ -702,13 +743,254 @@ __global__ __launch_bounds__(256) void potrf_persistent_kernel(PersistArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Single-launch factorisation, DATAFLOW form (default): no grid barriers.
+//
+// The barrier form above keeps chain and workers in lock step: the chain waits until every worker has left step j-1, the
+// workers wait twice per step for the slowest tile, and at the end of an outer block the chain stands still for the whole
+// K = 128 nbo update (0.9 ms per block at N = 8192).  Here every lower tile (i, k) has ONE owner for its whole life -- worker
+// (i mod PR) + PR (k mod PC), the workers numbered XCD by XCD so that an XCD's workers form a compact PR x ~32/PR patch of the
+// cyclic grid and share their row / column panels in the XCD's L2 -- and the owner applies the tile's updates in the fixed
+// chunks of the two-level schedule (one K = 128 nbo accumulation per finished outer block, single steps inside the tile's own
+// block: the chunking does not depend on timing, so the bits do not either), then turns it into L_ik = A_ik T_kk^T.  What is
+// ready is decided from flags: panel_done[i][j] (L_ij stored), factored[j] (L_jj, T_jj stored), chain_ready[j] (tiles
+// (j+1, j) and (j+1, j+1) carry every update the chain does not apply itself).  A worker scans its tiles in column order
+// (column k is needed at step k), runs the first task whose inputs exist, and only sleeps when none does; a task never
+// waits inside, so there is no circular wait, and a task's inputs were produced on tiles of smaller column index.
+// Ownership also removes the coherence traffic of the barrier form: a tile under update is read and written by one CU only
+// (no release / acquire per step), panels are written once -- write-through (sc1) stores + drained flag -- and read by CUs
+// that never touched those addresses before.  The chain (workgroup 0) is the barrier form's chain with its waits replaced by
+// chain_ready[j]; at a block boundary it applies only step j (K = 128) to the next diagonal tile, the owner having applied
+// the block's earlier steps as one shorter chunk (the barrier form ran the whole K = 128 nbo product on the chain there).
+// Bit-identical to the one-level multi-launch schedule for nbo = 1; agreement to rounding for nbo > 1.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int DF_FACT = 32;          // sync: [DF_FACT + j] factored, [DF_FACT + nb + j] chain_ready, [DF_FACT + 2 nb + i + j nb] panel_done
+constexpr int DF_MAXT = 64;          // owned tiles per worker (launcher checks)
+constexpr int DF_WIN = 16;           // tiles examined per scheduling round (16 lanes each)
+
+// end of the update chunk of tile (., k) that starts at step j0: a finished outer block in one accumulation (K = 128 nbo),
+// single steps inside the tile's own block -- and, for the first `near` columns of a block, also for the block just before
+// it: those tiles are needed right after that block's last step, a K = 128 nbo product (110 us) would sit on the chain's path.
+// A function of (k, j0) only: the summation order never depends on timing.
+__device__ __forceinline__ int df_chunk_end(int k, int j0, int target, int nbo, int near) {
+    const int bj = j0 / nbo, bk = k / nbo;
+    int j1 = (bj < bk && !(bj == bk - 1 && k - bk * nbo < near)) ? (bj + 1) * nbo : j0 + 1;
+    return min(j1, target);
+}
+__device__ __forceinline__ int df_flag(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// every wave drains its write-through stores, then ONE flag operation
+__device__ __forceinline__ void df_publish_store(int* p) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void df_publish_add(int* p) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* lds = reinterpret_cast<double*>(smem);
+    const int G = gridDim.x, b = blockIdx.x, nb = a.nb, nbo = a.nbo;
+    const long ld = a.ld;
+    int* factored = a.sync + DF_FACT;
+    int* chain_ready = a.sync + DF_FACT + nb;
+    int* panel_done = a.sync + DF_FACT + 2 * nb;        // [i + j nb]
+    if (b == 0) {
+        // ---- the chain ----
+        diag_block<true>(a.A, ld, a.Linv, ld, a.info, 0, smem);
+        pk_signal(factored + 0);
+        for (int j = 0; j <= nb - 2; ++j) {
+            double* Ajj = a.A + (long)j * NB * (ld + 1);
+            double* Tjj = a.Linv + (long)j * NB * (ld + 1);
+            double* Asub = Ajj + NB;                           // tile (j+1, j)
+            double* Anext = Ajj + (long)NB * (ld + 1);         // tile (j+1, j+1)
+            PK_STAMP(0);
+            if (!pk_wait_count(chain_ready + j, 2, a)) return; // both tiles carry their owners' updates (steps < j)
+            PK_STAMP(1);
+            pk_self_fence();                                   // T_jj, written by this workgroup a moment ago
+            {
+                ChainAcc ca;
+                ca.zero();
+                chain_gemm<true>(ca, Asub, ld, Tjj, ld, lds);                     // L_{j+1,j} = A_{j+1,j} T_jj^T
+                chain_store<true>(Asub, ld, ca);
+            }
+            pk_signal(panel_done + (j + 1) + (long)j * nb);
+            PK_STAMP(2);
+            pk_inv_l1();
+            {
+                ChainAcc ca;
+                ca.zero();
+                chain_gemm<false>(ca, Asub, ld, Asub, ld, lds);                   // A_{j+1,j+1} -= L_{j+1,j} L_{j+1,j}^T
+                chain_store<false>(Anext, ld, ca);
+            }
+            pk_self_fence();
+            PK_STAMP(3);
+            diag_block<true>(Anext, ld, Tjj + (long)NB * (ld + 1), ld, a.info, (j + 1) * NB, smem);
+            pk_signal(factored + j + 1);
+            PK_STAMP(4);
+        }
+        return;
+    }
+    // ---- the workers ----
+    int* st = reinterpret_cast<int*>(smem + 128 * DL * 8);     // scheduler state behind the tile image of tile_commit
+    int* t_i = st, *t_k = st + DF_MAXT, *t_done = st + 2 * DF_MAXT, *t_fin = st + 3 * DF_MAXT, *ready = st + 4 * DF_MAXT, *hdr = st + 4 * DF_MAXT + DF_WIN;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        // worker index, XCD by XCD
+        unsigned x;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+        const int xcc = (int)(x & 7);
+        const int rank = __hip_atomic_fetch_add(a.sync + 8 + xcc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(a.sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = pk_spin(a.sync + 1, G - 1, a.info + 1, a.timeout) ? 1 : 0;
+        int widx = rank;
+        for (int q = 0; q < xcc; ++q) widx += __hip_atomic_load(a.sync + 8 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int W = G - 1, PR = a.pr, PC = W / PR;
+        int nt = 0;
+        if (ok && a.map == 1) {
+            // tiles in column-major order (without (0, 0)) dealt round-robin: even in total work and at every stage
+            int k = 0;
+            long off = 0;                                    // tiles before column k
+            for (long t = widx; nt < DF_MAXT; t += W) {
+                const long tt = t + 1;                       // skip (0, 0)
+                while (k < nb && tt >= off + (nb - k)) { off += nb - k; ++k; }
+                if (k >= nb) break;
+                t_i[nt] = k + (int)(tt - off); t_k[nt] = k; t_done[nt] = 0; t_fin[nt] = 0;
+                ++nt;
+            }
+        } else if (ok && widx < PR * PC) {
+            const int r = widx % PR, c = widx / PR;
+            for (int k = c; k < nb; k += PC)
+                for (int i = k + ((r - k % PR) + PR) % PR; i < nb; i += PR) {
+                    if (i == 0 || nt >= DF_MAXT) continue;   // tile (0, 0) is the chain's from the start
+                    t_i[nt] = i; t_k[nt] = k; t_done[nt] = 0; t_fin[nt] = 0;
+                    ++nt;
+                }
+        }
+        hdr[0] = ok ? nt : -1;
+    }
+    __syncthreads();
+    const int nt = hdr[0];
+    if (nt <= 0) return;
+    int first = 0;
+    long long t_progress = wall_clock64();
+    const int slot = tid >> 4, l = tid & 15;
+    // optional statistics (probes): ticks of the 100 MHz clock in tasks / in scheduling rounds that found work / idle, task counts
+    long long st_task = 0, st_idle = 0, st_t0 = t_progress, st_n_upd = 0, st_n_panel = 0, st_rounds = 0, st_gemm = 0, st_rmw = 0;
+    for (;;) {
+        while (first < nt && t_fin[first]) ++first;            // uniform: every thread reads the same LDS words
+        if (first >= nt) break;
+        const long long st_round0 = a.trace ? wall_clock64() : 0;
+        ++st_rounds;
+        // ---- which tasks have their inputs? 16 lanes per tile, one flag per lane ----
+        {
+            const int t = first + slot;
+            bool valid = t < nt && !t_fin[t];
+            bool ok = true;
+            if (valid) {
+                const int i = t_i[t], k = t_k[t], d = t_done[t];
+                const int target = i == k ? k - 1 : k;         // steps the owner applies (the chain applies step k-1 to (k, k))
+                if (d < target) {
+                    const int j0 = d;
+                    const int j1 = df_chunk_end(k, j0, target, nbo, a.near);
+                    const int j = j0 + (l & 7);
+                    if (j < j1 && !(l >= 8 && i == k)) ok = df_flag(panel_done + (l < 8 ? i : k) + (long)j * nb) != 0;
+                } else if (i > k + 1) {
+                    if (l == 0) ok = df_flag(factored + k) != 0;
+                }
+            }
+            const unsigned long long m = __ballot(ok);
+            const unsigned grp = (unsigned)(m >> (16 * ((tid >> 4) & 3))) & 0xffffu;
+            if (l == 0) ready[slot] = (valid && grp == 0xffffu) ? 1 : 0;
+        }
+        __syncthreads();
+        int sel = -1;
+#pragma unroll
+        for (int q = DF_WIN - 1; q >= 0; --q)
+            if (ready[q]) sel = q;
+        __syncthreads();
+        if (sel < 0) {
+            if (__hip_atomic_load(a.info + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+            if (wall_clock64() - t_progress > a.timeout) {
+                if (tid == 0) __hip_atomic_store(a.info + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            if (a.idle_sleep <= 16) __builtin_amdgcn_s_sleep(16);
+            else if (a.idle_sleep <= 32) __builtin_amdgcn_s_sleep(32);
+            else __builtin_amdgcn_s_sleep(64);
+            if (a.trace) st_idle += wall_clock64() - st_round0;
+            continue;
+        }
+        if (a.acq) {
+            if (tid < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        __syncthreads();
+        const long long st_task0 = a.trace ? wall_clock64() : 0;
+        const int t = first + sel;
+        const int i = t_i[t], k = t_k[t], d = t_done[t];
+        const int target = i == k ? k - 1 : k;
+        double* Cik = a.A + (long)i * NB + (long)k * NB * ld;
+        if (d < target) {
+            const int j0 = d;
+            const int j1 = df_chunk_end(k, j0, target, nbo, a.near);
+            Acc acc;
+            acc.zero();
+            gemm_tile_deep(acc, a.A + (long)i * NB + (long)j0 * NB * ld, ld, a.A + (long)k * NB + (long)j0 * NB * ld, ld, (j1 - j0) * NB, lds);
+            const long long st_g = a.trace ? wall_clock64() : 0;
+            st_gemm += st_g - st_task0;
+            const bool last = j1 == target;
+            const bool to_chain = last && i <= k + 1;         // (k+1, k) and (k, k) go to the chain after their last update
+            if (to_chain) {
+                tile_commit<true, true>(Cik, ld, acc, lds);
+                df_publish_add(chain_ready + (i == k ? k - 1 : k));
+            } else {
+                tile_commit<true, false>(Cik, ld, acc, lds);
+                if (a.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st_rmw += wall_clock64() - st_g; }
+                __syncthreads();
+            }
+            if (tid == 0) {
+                t_done[t] = j1;
+                if (to_chain) t_fin[t] = 1;
+            }
+            ++st_n_upd;
+        } else if (i > k + 1) {
+            ++st_n_panel;
+            Acc acc;
+            acc.zero();
+            gemm_tile_deep(acc, Cik, ld, a.Linv + (long)k * NB * (ld + 1), ld, NB, lds);
+            tile_commit<false, true>(Cik, ld, acc, lds);
+            df_publish_store(panel_done + i + (long)k * nb);
+            if (tid == 0) t_fin[t] = 1;
+        } else {
+            // no update to apply at all: tiles (1, 0) and (1, 1)
+            if (tid == 0) {
+                __hip_atomic_fetch_add(chain_ready + (i == k ? k - 1 : k), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                t_fin[t] = 1;
+            }
+        }
+        __syncthreads();
+        t_progress = wall_clock64();
+        if (a.trace) st_task += t_progress - st_task0;
+    }
+    if (a.trace && tid == 0) {
+        long long* o = a.trace + 16 * (long)nb + 16 * (long)(b - 1);
+        o[0] = st_task; o[1] = st_idle; o[2] = wall_clock64() - st_t0; o[3] = st_n_upd; o[4] = st_n_panel; o[5] = st_rounds; o[6] = nt; o[7] = st_gemm; o[8] = st_rmw;
+    }
+}
+
 int potrf_persistent_nbo(int Np) {
     const char* e = getenv("SLS_POTRF_PNBO");
     if (e && atoi(e) >= 1) return atoi(e);
     return Np >= 8192 ? 8 : 1;
 }
 
-// 0: multi-launch schedule, 1: single persistent launch (default), 2: hybrid (persistent panels + side-stream updates).
+// 0: multi-launch schedule, 1: single persistent launch with grid barriers, 2: hybrid (persistent panels + side-stream
+// updates), 3: single persistent launch, dataflow form (default).
 // Measured on MI355X (tools/probes/potrf_bench, ms at N = 2048 / 4096 / 8192 / 16384): multi-launch 1.40 / 3.16 / 10.4 (8.8
 // two-level + look-ahead) / 56.4; persistent 1.11 / 2.72 / 8.56 / 39.3; hybrid (nbo 4) 1.67 / 3.62 / 9.18 / 41.7 -- the
 // hybrid's side-stream launches serialise behind each other more than they overlap with the panels, so it stays opt-in.
@@ -742,8 +1024,54 @@ void launch_potrf_persistent(hipStream_t s, double* A, int Np, double* Linv, int
     a.timeout = 20000000LL;   // 0.2 s of the 100 MHz wall clock
     a.trace = trace;
     a.nbo = potrf_persistent_nbo(Np);
-    a.j0 = 0; a.j1 = nb; a.k0 = 0; a.ext_flag = nullptr;
+    a.j0 = 0; a.j1 = nb; a.k0 = 0; a.ext_flag = nullptr; a.pr = 1; a.map = 0; a.near = 0; a.acq = 1; a.idle_sleep = 16;
     hipLaunchKernelGGL(potrf_persistent_kernel, dim3(G), dim3(256), DIAG_LDS_BYTES, s, a);
+}
+
+int potrf_dataflow_nbo(int Np) {
+    const char* e = getenv("SLS_POTRF_DNBO");
+    if (e && atoi(e) >= 1) return std::min(8, atoi(e));
+    // measured (tools/probes/potrf_bench, ms at N = 8192): nbo 1: 7.1, 2: 5.0, 4: 5.5 (5.25 with near = 3), 8: 5.75; at 4096
+    // nbo 1 and 2 tie (2.28): below 8192 the chain is the limit and single steps keep the multi-launch schedule's bits
+    return Np >= 8192 ? 2 : 1;
+}
+// ints of device scratch the dataflow form needs (0: the matrix is too large for its tables)
+size_t potrf_dataflow_sync_ints(int Np) {
+    const size_t nb = Np / NB;
+    return DF_FACT + 2 * nb + nb * nb;
+}
+// false: not applicable (too few blocks / too many tiles per worker) -- the caller uses another schedule
+bool launch_potrf_dataflow(hipStream_t s, double* A, int Np, double* Linv, int* info, int* sync, long long* trace) {
+    ensure_dyn_lds((const void*)potrf_dataflow_kernel, DIAG_LDS_BYTES);
+    const int nb = Np / NB;
+    int dev = 0, n_cu = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (n_cu <= 0) n_cu = 64;
+    const int tiles = nb * (nb + 1) / 2 - 1;
+    const int G = std::max(2, std::min(n_cu, 1 + tiles));
+    const int W = G - 1;
+    const char* e = getenv("SLS_POTRF_DPR");
+    int PR = e ? atoi(e) : (W >= 144 ? 12 : W >= 36 ? 6 : W >= 4 ? 2 : 1);
+    PR = std::max(1, std::min(PR, W));
+    const int PC = W / PR;
+    auto envi = [](const char* n, int dflt) { const char* v = getenv(n); return v ? atoi(v) : dflt; };
+    const int map = envi("SLS_POTRF_DMAP", 1);   // round-robin: 5.0 vs 5.7 ms at N = 8192 (the cyclic grid leaves 1.4x work on some owners)
+    if (map == 1 ? (tiles + W - 1) / W > DF_MAXT : ((nb + PR - 1) / PR) * ((nb + PC - 1) / PC) > DF_MAXT) return false;
+    (void)hipMemsetAsync(sync, 0, potrf_dataflow_sync_ints(Np) * sizeof(int), s);
+    PersistArgs a;
+    a.A = A; a.ld = Np; a.nb = nb; a.Linv = Linv; a.info = info; a.sync = sync;
+    a.timeout = 20000000LL;   // 0.2 s of the 100 MHz wall clock
+    a.trace = trace;
+    a.nbo = potrf_dataflow_nbo(Np);
+    a.j0 = 0; a.j1 = nb; a.k0 = 0; a.ext_flag = nullptr;
+    a.pr = PR;
+    a.map = map;
+    a.near = envi("SLS_POTRF_DNEAR", 0);
+    a.acq = envi("SLS_POTRF_DACQ", 1);
+    a.idle_sleep = envi("SLS_POTRF_DSLEEP", 16);
+    hipLaunchKernelGGL(potrf_dataflow_kernel, dim3(G), dim3(256), DIAG_LDS_BYTES, s, a);
+    return true;
 }
 
 // Two-level right-looking factorisation.  Outer blocks of `nbo` 128-columns: inside an outer block every 128-step is
@@ -828,6 +1156,7 @@ void launch_potrf_hybrid(hipStream_t s, double* A, int Np, double* Linv, int* in
         a.j0 = b0; a.j1 = b1;                 // b1 == nb: last block, runs to the end
         a.k0 = B > 0 ? b0 - nbo : b0;
         a.ext_flag = (B > 0 && b1 - b0 > 1) ? flags + B : nullptr;
+        a.pr = 1; a.map = 0; a.near = 0; a.acq = 1; a.idle_sleep = 16;
         const int work = nb - b0;             // panel tiles of the first step (+ chain)
         const int G = std::max(2, std::min(64, 1 + work));
         hipLaunchKernelGGL(potrf_persistent_kernel, dim3(G), dim3(256), DIAG_LDS_BYTES, s, a);
@@ -851,11 +1180,13 @@ void launch_potrf_hybrid(hipStream_t s, double* A, int Np, double* Linv, int* in
         if (e) (void)hipStreamWaitEvent(s, e, 0);
 }
 
-void launch_potrf(hipStream_t s, double* A, int Np, double* Linv, int* info, int nbo, PotrfAux* aux, int* persist_sync) {
+void launch_potrf(hipStream_t s, double* A, int Np, double* Linv, int* info, int nbo, PotrfAux* aux, int* persist_sync,
+                  int* dataflow_sync) {
     diag_attr();
     const int nb = Np / NB;
     const long ld = Np;
     const int mode = potrf_default_mode(Np);
+    if (dataflow_sync && nb >= 3 && mode == 3 && launch_potrf_dataflow(s, A, Np, Linv, info, dataflow_sync)) return;
     if (persist_sync && mode == 2 && aux && aux->side && nb >= 2 * potrf_hybrid_nbo()) {
         launch_potrf_hybrid(s, A, Np, Linv, info, persist_sync, persist_sync + PK_FLAGS + 2 * nb, aux, potrf_hybrid_nbo());
         return;

@@ -122,7 +122,7 @@ namespace sequential_line_search
     namespace optim
     {
         std::vector<double> MaximizeBounded(const Objective& f, std::vector<double> x, const std::vector<double>& lo,
-                                            const std::vector<double>& hi, int max_evals, double* best_value)
+                                            const std::vector<double>& hi, int max_evals, double* best_value, int* evals_used)
         {
             const size_t n = x.size();
             const int    m = 8;
@@ -240,6 +240,7 @@ namespace sequential_line_search
                 if (!accepted) break;
             }
             if (best_value) *best_value = -fx;
+            if (evals_used) *evals_used = evals;
             return x;
         }
     } // namespace optim

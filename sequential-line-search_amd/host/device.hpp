@@ -61,7 +61,8 @@ namespace sequential_line_search
         /// evaluations.  Stand-in for nloptutil::solve(..., LD_LBFGS / LD_TNEWTON, ..., is_max = true, max_evals):
         /// NLopt is not available, so iterates differ from the reference while the optimum is the same.
         std::vector<double> MaximizeBounded(const Objective& f, std::vector<double> x0, const std::vector<double>& lower,
-                                            const std::vector<double>& upper, int max_evals, double* best_value = nullptr);
+                                            const std::vector<double>& upper, int max_evals, double* best_value = nullptr,
+                                            int* evals_used = nullptr);
 
         /// values[k] = f(xs[k]) for a whole batch of points (one device call per batch).
         using BatchObjective = std::function<void(const std::vector<std::vector<double>>& xs, std::vector<double>& values)>;

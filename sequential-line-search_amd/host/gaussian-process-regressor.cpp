@@ -1,4 +1,5 @@
 // GaussianProcessRegressor over the C ABI (reference: src/gaussian-process-regressor.cpp).
+#include <chrono>
 #include <cmath>
 #include <sequential-line-search/gaussian-process-regressor.hpp>
 
@@ -101,6 +102,7 @@ namespace sequential_line_search
     void GaussianProcessRegressor::PerformMapEstimation()
     {
         const int         D = static_cast<int>(m_X.rows());
+        const auto        t_start = std::chrono::steady_clock::now();
         device::NllHandle nll(m_X, KernelId(m_kernel_type));
         const double      lo = std::log(1e-8), hi = std::log(5e+01);
 
@@ -132,16 +134,19 @@ namespace sequential_line_search
         };
         const std::vector<double> lin_lower(D + 2, 1e-8), lin_upper(D + 2, 5e+01);
         double                    direct_v = 0.0;
-        const std::vector<double> xg       = optim::DirectMaximize(batch, lin_lower, lin_upper, 300, &direct_v);
+        const std::vector<double> xg       = optim::DirectMaximize(batch, lin_lower, lin_upper, 300, &direct_v, &m_map_stats.evals_direct);
         std::vector<double> best(D + 2);
         best[0] = std::log(0.5); best[1] = std::log(1e-4);
         for (int d = 0; d < D; ++d) best[2 + d] = std::log(0.5);
-        if (direct_v > objective(best, nullptr))
+        m_map_stats.direct_value = direct_v;
+        m_map_stats.prior_value  = objective(best, nullptr);
+        if (direct_v > m_map_stats.prior_value)
             for (int i = 0; i < D + 2; ++i) best[i] = std::log(xg[i]);
         // local phase: bounded quasi-Newton in log-parameters from the global phase's point (reference: TNEWTON, 1000
         // evaluations, :295; same bounds)
         const std::vector<double> lower(D + 2, lo), upper(D + 2, hi);
-        const std::vector<double> z = optim::MaximizeBounded(objective, best, lower, upper, 1000);
+        const std::vector<double> z = optim::MaximizeBounded(objective, best, lower, upper, 1000, &m_map_stats.final_value, &m_map_stats.evals_local);
+        m_map_stats.seconds         = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
 
         m_kernel_hyperparams    = VectorXd(D + 1);
         m_kernel_hyperparams(0) = std::exp(z[0]);

@@ -67,8 +67,9 @@ def test_cholesky_solve_inverse(ctx, oracle, N):
 
 @pytest.mark.parametrize("N", [384, 1000, 2304])
 def test_potrf_schedules_agree(N, monkeypatch):
-    """The Cholesky schedules (kernels_chol.hip): the single-launch persistent kernel (default; with and without its two-level
-    update), the multi-launch forms (SLS_POTRF_MODE=0: one-level, two-level, two-level with the outer update on a CU-masked
+    """The Cholesky schedules (kernels_chol.hip): the single-launch dataflow kernel (default: per-tile ownership + ready flags;
+    both owner maps, single steps and chunked updates), the single-launch kernel with grid barriers (with and without its
+    two-level update), the multi-launch forms (SLS_POTRF_MODE=0: one-level, two-level, two-level with the outer update on a CU-masked
     side stream) and the hybrid (SLS_POTRF_MODE=2: persistent panels + side-stream updates).  One-level multi-launch and one-level persistent run the
     same arithmetic per tile: identical bits.  The two-level forms sum the outer update in one k loop: agreement to rounding.
     Every variant must also reject an indefinite matrix (the persistent kernel reports through the same info word)."""
@@ -81,7 +82,11 @@ def test_potrf_schedules_agree(N, monkeypatch):
                       ("multi2look", {"SLS_POTRF_MODE": "0", "SLS_POTRF_NBO": "2", "SLS_POTRF_LOOKAHEAD": "4"}),
                       ("persist1", {"SLS_POTRF_MODE": "1", "SLS_POTRF_PNBO": "1"}),
                       ("persist4", {"SLS_POTRF_MODE": "1", "SLS_POTRF_PNBO": "4"}),
-                      ("hybrid2", {"SLS_POTRF_MODE": "2", "SLS_POTRF_HNBO": "2", "SLS_POTRF_LOOKAHEAD": "8"})):
+                      ("hybrid2", {"SLS_POTRF_MODE": "2", "SLS_POTRF_HNBO": "2", "SLS_POTRF_LOOKAHEAD": "8"}),
+                      ("dataflow1", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "1", "SLS_POTRF_DMAP": "1"}),
+                      ("dataflow1cyc", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "1", "SLS_POTRF_DMAP": "0"}),
+                      ("dataflow2", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "2", "SLS_POTRF_DMAP": "1"}),
+                      ("dataflow4near", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "4", "SLS_POTRF_DNEAR": "2", "SLS_POTRF_DMAP": "0"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         c = sls().Context(0)          # a fresh context: the look-ahead side stream is created per context
@@ -94,6 +99,10 @@ def test_potrf_schedules_agree(N, monkeypatch):
     for name, v in res.items():
         close(v, L, rtol=1e-10, atol=1e-12)
     assert np.array_equal(res["multi"], res["persist1"])
+    assert np.array_equal(res["multi"], res["dataflow1"])         # per-tile ownership changes who computes, not what
+    assert np.array_equal(res["multi"], res["dataflow1cyc"])
+    close(res["dataflow2"], res["multi"], rtol=1e-12, atol=1e-13)
+    close(res["dataflow4near"], res["multi"], rtol=1e-12, atol=1e-13)
     assert np.array_equal(res["multi2"], res["multi2look"])        # the side stream changes the schedule, not the arithmetic
     close(res["persist4"], res["multi"], rtol=1e-12, atol=1e-13)
     close(res["multi2"], res["multi"], rtol=1e-12, atol=1e-13)

@@ -98,6 +98,59 @@ int main(int argc, char** argv) {
         };
         run(1, nullptr, "one-level (nbo=1)", true);
         run(1, nullptr, "persistent single launch", false, true);
+        {   // dataflow form (SLS_POTRF_DNBO / SLS_POTRF_DPR from the environment)
+            int* dsync; hipMalloc(&dsync, potrf_dataflow_sync_ints(Np) * sizeof(int));
+            float best = 1e30f; bool ok = true;
+            for (int rep = 0; rep < 5 && ok; ++rep) {
+                hipMemcpyAsync(A, A0, bytes, hipMemcpyDeviceToDevice, s);
+                hipMemsetAsync(info, 0, 64, s);
+                hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+                hipEventRecord(e0, s);
+                ok = launch_potrf_dataflow(s, A, Np, Linv, info, dsync);
+                hipEventRecord(e1, s); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                if (rep > 0 && ms < best) best = ms;
+            }
+            int inf2[2] = {0, 0}; hipMemcpy(inf2, info, 8, hipMemcpyDeviceToHost);
+            hipLaunchKernelGGL(maxdiff_lower, dim3(1024), dim3(256), 0, s, A, Lref, Np, red);
+            std::vector<double> h(1024); hipStreamSynchronize(s); hipMemcpy(h.data(), red, 1024 * 8, hipMemcpyDeviceToHost);
+            double md = 0.0; for (double v : h) md = fmax(md, v);
+            printf("N=%5d %-34s %8.3f ms  %6.2f TFLOP/s  info=%d abort=%d applicable=%d  max|L - L_ref|=%.2e\n", Np, "dataflow single launch", best,
+                   (double)Np * Np * Np / 3.0 / (best * 1e-3) / 1e12, inf2[0], inf2[1], (int)ok, md);
+            if (getenv("POTRF_BENCH_TRACE") && ok) {
+                const int nb = Np / 128;
+                const size_t trn = (size_t)nb * 16 + 16 * 512;
+                long long* tr; hipMalloc(&tr, trn * 8); hipMemset(tr, 0, trn * 8);
+                hipMemcpyAsync(A, A0, bytes, hipMemcpyDeviceToDevice, s);
+                hipMemsetAsync(info, 0, 64, s);
+                launch_potrf_dataflow(s, A, Np, Linv, info, dsync, tr);
+                hipStreamSynchronize(s);
+                std::vector<long long> ht(trn); hipMemcpy(ht.data(), tr, ht.size() * 8, hipMemcpyDeviceToHost);
+                {   // worker statistics
+                    double task = 0, idle = 0, life = 0, tmax = 0, lmax = 0; long nu = 0, np_ = 0, rounds = 0; int nw = 0; double gsum = 0, rsum = 0;
+                    for (int w = 0; w < 512; ++w) {
+                        const long long* o = ht.data() + 16 * nb + 16 * w;
+                        if (o[6] == 0) continue;
+                        ++nw; task += o[0] / 100.0; idle += o[1] / 100.0; life += o[2] / 100.0; tmax = fmax(tmax, o[0] / 100.0); lmax = fmax(lmax, o[2] / 100.0);
+                        nu += o[3]; np_ += o[4]; rounds += o[5]; gsum += o[7] / 100.0; rsum += o[8] / 100.0;
+                    }
+                    printf("  workers with tiles: %d; per worker (us): in tasks mean %.0f max %.0f, idle rounds mean %.0f, lifetime mean %.0f max %.0f; tasks: %ld updates %ld panels, %ld scheduling rounds; mean task %.1f us; update tasks: k loop %.1f us, C read-modify-write + drain %.1f us (wave 0, mean)\n",
+                           nw, task / nw, tmax, idle / nw, life / nw, lmax, nu, np_, rounds, task / (nu + np_), gsum / nu, rsum / nu);
+                }
+                printf("dataflow chain trace N=%d (us from the chain's step start): step | wait-for-tiles gemm1+signal gemm2 diag+signal | step start since step 0\n", Np);
+                double waited = 0.0;
+                for (int j = 0; j < nb - 1; ++j) {
+                    const long long* g = ht.data() + 16 * j; const double t0 = (double)g[0];
+                    auto us = [&](long long v) { return v ? ((double)v - t0) / 100.0 : -1.0; };
+                    waited += us(g[1]);
+                    if (j < 4 || j % 8 == 0 || j > nb - 3)
+                        printf("  %3d | %7.1f %6.1f %6.1f %6.1f | %8.1f\n", j, us(g[1]), us(g[2]), us(g[3]), us(g[4]), ((double)g[0] - (double)ht[0]) / 100.0);
+                }
+                printf("  chain waited %.1f us in total for its tiles\n", waited);
+                hipFree(tr);
+            }
+            hipFree(dsync);
+        }
         if (getenv("POTRF_BENCH_HYBRID")) {
             PotrfAux aux;
             potrf_aux_create(&aux, 8);
