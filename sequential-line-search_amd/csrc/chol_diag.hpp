@@ -1,6 +1,8 @@
 // LDS-resident Cholesky + triangular inverse of a (<=) 128x128 SPD block: device code shared by chol_diag_kernel
 // (kernels_chol.hip) and the fused small-problem MAP kernel (kernels_small.hip).
 #pragma once
+#include <type_traits>
+
 #include "gemm_f64.hpp"
 
 namespace slsk {
@@ -48,7 +50,7 @@ __device__ __forceinline__ double bcast(double x, int k) {
     return __builtin_bit_cast(double, r);
 }
 
-// 16x16 diagonal tile at (c0, c0): optional in-register Cholesky, then inverse.  Executed by one full wave; lane & 15 = row.
+// rsqrt for the pivots of diag16 below.
 // 1/sqrt(d) to full fp64 accuracy: hardware v_rsq_f64 seed (measured max rel. error 5.2e-8) + one third-order Newton step
 // on the residual (-> 1.4e-16, identical to a second step; diag_timing.hip).  The correctly-rounded sqrt()/division pair
 // of the math library costs ~350 dependent cycles on the pivot chain.
@@ -62,59 +64,12 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
 // workgroup barrier that waits for this wave's LDS traffic only (not for outstanding global stores)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-#ifndef SLS_DIAG16_V
-#define SLS_DIAG16_V 1
-#endif
-#if SLS_DIAG16_V == 0
-template <bool FACTOR>
-__device__ __forceinline__ void diag16(double* As, double* Tk, int c0, int lane, int* info, int global_off) {
-    const int row = lane & 15;
-    double a[16], dinv[16];
-    double own_inv = 1.0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) a[j] = As[c0 + row + (c0 + j) * DL];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const double d = bcast(a[k], k);
-        if (FACTOR) {
-            if (!(d > 0.0) && lane == 0 && info) atomicCAS(info, 0, global_off + c0 + k + 1);
-            const double inv = rsqrt_nr(d);
-            dinv[k] = inv;
-            const double lik = a[k] * inv;   // lane k: d * rsqrt(d) = L_kk; rows < k hold unused upper-triangle values
-            a[k] = lik;
-#pragma unroll
-            for (int j = k + 1; j < 16; ++j) a[j] -= lik * bcast(lik, j);
-        } else {
-            dinv[k] = 1.0 / d;
-        }
-        own_inv = (row == k) ? dinv[k] : own_inv;
-    }
-    // inverse: B = I; for k: B[i,:] -= (L[i,k] / L_kk) B[k,:] (i > k); finally B[i,:] /= L_ii.  Row k of B is final before step
-    // k, so its scaling waits until the end (no select on the chain).  The columns of B are independent and are dealt to
-    // the four 16-lane rows of the wave: lane (row, g) keeps columns g, g+4, g+8, g+12, the broadcast of row k stays inside
-    // each 16-lane row, and step k costs k/4 + 1 broadcast + fma pairs instead of k + 1 (columns > k see B[k,j] = 0).
-    const int g = lane >> 4;
-    double bq[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bq[r] = (row == 4 * r + g) ? 1.0 : 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const double ck = (row > k) ? a[k] * dinv[k] : 0.0;
-#pragma unroll
-        for (int r = 0; r <= k / 4; ++r) bq[r] = fma(-ck, bcast(bq[r], k), bq[r]);
-    }
-    if (FACTOR && lane < 16) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) As[c0 + row + (c0 + j) * DL] = (j <= row) ? a[j] : 0.0;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int col = 4 * r + g;
-        Tk[row + 16 * col] = (col <= row) ? bq[r] * own_inv : 0.0;
-    }
-}
-
-#else
+// 16x16 diagonal tile at (c0, c0): optional in-register Cholesky, then inverse.  Executed by one full wave; lane & 15 = row.
+// Measured (tools/probes/diag_timing, cycles per call on MI355X): 4650 as two consecutive loops with a branch per pivot for
+// the failure report; 4400 in this form (one basic block: step k of the inverse issued right behind pivot k, failure recorded
+// in a register and reported once); 4850 with the running diagonal kept in every lane (pivot one fma behind the broadcast
+// instead of fma -> broadcast); 5300 with v_fmac_f64_dpp fusing broadcast + fma.  The wave is ISSUE-bound (~660 fp64 / DPP
+// instructions at ~7 cycles), not latency-bound: shortening the dependency chain buys nothing, fewer instructions would.
 template <bool FACTOR>
 __device__ __forceinline__ void diag16(double* As, double* Tk, int c0, int lane, int* info, int global_off) {
     const int row = lane & 15, g = lane >> 4;
@@ -123,30 +78,16 @@ __device__ __forceinline__ void diag16(double* As, double* Tk, int c0, int lane,
     int bad = 16;                                   // first non-positive pivot of this tile (16: none)
 #pragma unroll
     for (int j = 0; j < 16; ++j) a[j] = As[c0 + row + (c0 + j) * DL];
-#if SLS_DIAG16_V == 1
-    // dd[j]: the running diagonal A_jj - sum_{m<k} L_jm^2, kept in EVERY lane (the same fma lane j applies to its own a[j]:
-    // in lane j the column value lik IS its broadcast), so that the next pivot is one fma behind the broadcast of column k
-    // instead of fma -> broadcast: the serial chain per pivot is rsq, 4 Newton ops, 1 mul, 1 broadcast, 1 fma.
-    double dd[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) dd[j] = bcast(a[j], j);
-#endif
     // inverse: B = I; for k: B[i,:] -= (L[i,k] / L_kk) B[k,:] (i > k); finally B[i,:] /= L_ii.  Row k of B is final before step
     // k, so its scaling waits until the end (no select on the chain).  The columns of B are independent and are dealt to
     // the four 16-lane rows of the wave: lane (row, g) keeps columns g, g+4, g+8, g+12, the broadcast of row k stays inside
     // each 16-lane row, and step k costs k/4 + 1 broadcast + fma pairs instead of k + 1 (columns > k see B[k,j] = 0).
-    // Step k of the inverse only needs column k of L, so it is issued right behind pivot k and fills the pivot chain's
-    // latency bubbles (one wave, in-order issue) instead of following it as a second serial loop.
     double bq[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) bq[r] = (row == 4 * r + g) ? 1.0 : 0.0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-#if SLS_DIAG16_V == 1
-        const double d = dd[k];
-#else
         const double d = bcast(a[k], k);
-#endif
         double inv;
         if (FACTOR) {
             bad = (!(d > 0.0) && bad == 16) ? k : bad;      // off the chain: reported once, after the loop
@@ -154,13 +95,7 @@ __device__ __forceinline__ void diag16(double* As, double* Tk, int c0, int lane,
             const double lik = a[k] * inv;   // lane k: d * rsqrt(d) = L_kk; rows < k hold unused upper-triangle values
             a[k] = lik;
 #pragma unroll
-            for (int j = k + 1; j < 16; ++j) {
-                const double bc = bcast(lik, j);
-#if SLS_DIAG16_V == 1
-                dd[j] = fma(-bc, bc, dd[j]);
-#endif
-                a[j] -= lik * bc;
-            }
+            for (int j = k + 1; j < 16; ++j) a[j] -= lik * bcast(lik, j);
         } else {
             inv = 1.0 / d;
         }
@@ -180,7 +115,6 @@ __device__ __forceinline__ void diag16(double* As, double* Tk, int c0, int lane,
         Tk[row + 16 * col] = (col <= row) ? bq[r] * own_inv : 0.0;
     }
 }
-#endif
 
 // Linv^T tiles in the strictly-upper part of As -> natural strictly-lower positions: the 28 tiles are dealt 7 per wave
 // (tile t -> wave t & 3) with compile-time coordinates (one branch on the wave id instead of 28), reads before writes.

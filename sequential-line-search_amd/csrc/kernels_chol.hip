@@ -23,6 +23,7 @@
 namespace slsk {
 
 constexpr int NB = 128;
+typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------------------------------
 // generic tile GEMM with triangular k-ranges:  C = alpha * opA opB^T + beta * C
@@ -189,7 +190,9 @@ void launch_gemm_plain(hipStream_t s, const double* A, long lda, bool a_kc, cons
 // Cholesky factor + inverse of ONE 128 x 128 diagonal block by the calling workgroup (256 threads, `smem` = DIAG_LDS_BYTES of
 // LDS): A (lower triangle read) -> L in place (FACTOR) and T = L^-1 into Tout.  Shared by the one-block launch
 // (chol_diag_kernel) and the single-launch persistent factorisation (potrf_persistent_kernel).
-template <bool FACTOR>
+// LOAD = false: the caller has already built the LDS image As (lower tiles of A, upper tiles zero) and passed a barrier.
+// WT: write-through (sc1) stores for L and T -- the caller publishes them with a drained flag instead of a release fence.
+template <bool FACTOR, bool LOAD = true, bool WT = false>
 __device__ __forceinline__ void diag_block(double* __restrict__ A, long lda, double* __restrict__ Tout, long ldt,
                                            int* __restrict__ info, int global_off, char* smem) {
     double* As = reinterpret_cast<double*>(smem);   // [i + j*DL]
@@ -198,7 +201,7 @@ __device__ __forceinline__ void diag_block(double* __restrict__ A, long lda, dou
     const int fl = lane & 15, fk = lane >> 4;       // fragment index / k sub-index
 
     DIAG_STAMP(1);
-    {   // thread -> (row pair, column): 64 threads cover one column with 16-byte loads, 4 columns per pass
+    if (LOAD) {   // thread -> (row pair, column): 64 threads cover one column with 16-byte loads, 4 columns per pass
         const int i2 = 2 * (tid & 63), jc = tid >> 6;
 #pragma unroll 8
         for (int p = 0; p < 32; ++p) {
@@ -207,9 +210,11 @@ __device__ __forceinline__ void diag_block(double* __restrict__ A, long lda, dou
             if ((i2 >> 4) < (j >> 4)) v = d2_t{0.0, 0.0};
             *reinterpret_cast<d2_t*>(As + i2 + j * DL) = v;
         }
+        __syncthreads();
     }
-    __syncthreads();
     DIAG_STAMP(2);
+    auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(A, 0, 0x7fffffff, 0x00020000);
+    auto rsrcT = __builtin_amdgcn_make_buffer_rsrc(Tout, 0, 0x7fffffff, 0x00020000);
 
     chol_diag_steps<FACTOR>(As, Ts, info, global_off, 8);
     __syncthreads();
@@ -226,7 +231,8 @@ __device__ __forceinline__ void diag_block(double* __restrict__ A, long lda, dou
             d2_t v = *reinterpret_cast<const d2_t*>(As + i2 + j * DL);
             if (i2 < j) v[0] = 0.0;
             if (i2 + 1 < j) v[1] = 0.0;
-            *reinterpret_cast<d2_t*>(A + (long)i2 + (long)j * lda) = v;
+            if (WT) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rsrcA, (int)((i2 + (long)j * lda) * 8), 0, 16);
+            else *reinterpret_cast<d2_t*>(A + (long)i2 + (long)j * lda) = v;
         }
     }
     DIAG_STAMP(4);
@@ -252,7 +258,8 @@ __device__ __forceinline__ void diag_block(double* __restrict__ A, long lda, dou
             d2_t v = {0.0, 0.0};
             if (ti > tj) v = *reinterpret_cast<const d2_t*>(As + i2 + j * DL);
             else if (ti == tj) v = *reinterpret_cast<const d2_t*>(Ts + 256 * ti + (i2 & 15) + 16 * (j & 15));
-            *reinterpret_cast<d2_t*>(Tout + (long)i2 + (long)j * ldt) = v;
+            if (WT) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rsrcT, (int)((i2 + (long)j * ldt) * 8), 0, 16);
+            else *reinterpret_cast<d2_t*>(Tout + (long)i2 + (long)j * ldt) = v;
         }
     }
     DIAG_STAMP(6);
@@ -309,6 +316,7 @@ struct PersistArgs {
     int near;           // dataflow form: columns at the start of an outer block that take the previous block step by step
     int acq;            // dataflow form: 1 agent-scope acquire before every task, 0 compiler-level ordering only (probes)
     int idle_sleep;     // dataflow form: s_sleep argument of an idle scheduling round
+    int fuse;           // dataflow form: 1 the chain keeps its tiles in LDS between products (default), 0 through global memory
 };
 constexpr int PK_FLAGS = 32;
 #define PK_STAMP(slot) do { if (a.trace && threadIdx.x == 0) a.trace[16 * j + (slot)] = wall_clock64(); } while (0)
@@ -460,7 +468,6 @@ __device__ __forceinline__ void pk_sub_tile(double* C, long ld, const Acc& acc) 
 // From the image every wave moves whole 1 KB columns with 16-byte accesses, all loads of a half tile in flight at once.
 // SUB: C -= acc, otherwise C = acc.  WT: write-through (sc1) stores -- the tile is read by other CUs next (the caller drains
 // and raises a flag), otherwise plain stores.  Values are only moved: same bits as pk_sub_tile / pk_store_tile.
-typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
 template <bool SUB, bool WT>
 __device__ __forceinline__ void tile_commit(double* __restrict__ C, long ld, const Acc& acc, double* img) {
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -743,6 +750,82 @@ __global__ __launch_bounds__(256) void potrf_persistent_kernel(PersistArgs a) {
     }
 }
 
+// ---- the dataflow chain's products with their results kept in LDS ----------------------------------------
+// ChainAcc (wave w: 16-row blocks w and 7 - w) -> image img[m + n DL]: the layout of diag_block's As, and of eight
+// consecutive operand slabs [16][DL] when the image is read as an operand with k = n.
+template <bool TRI>
+__device__ __forceinline__ void chain_acc_to_image(const ChainAcc& acc, double* img) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int mi = a == 0 ? wave : 7 - wave;
+#pragma unroll
+        for (int nj = 0; nj < 8; ++nj) {
+            if (!TRI && nj > mi) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) img[(16 * nj + (lane >> 4) + 4 * r) * DL + 16 * mi + (lane & 15)] = acc.v[a][nj][r];
+        }
+    }
+}
+// image -> global tile, whole 1 KB columns per wave, write-through (the panel tile L_{j+1,j} the workers wait for)
+__device__ __forceinline__ void chain_image_store_wt(double* __restrict__ C, long ld, const double* img) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    auto rsrc = __builtin_amdgcn_make_buffer_rsrc(C, 0, 0x7fffffff, 0x00020000);
+#pragma unroll 8
+    for (int q = 0; q < 32; ++q) {
+        const int c = w + 4 * q;
+        const d2_t v = *reinterpret_cast<const d2_t*>(img + 2 * lane + c * DL);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rsrc, (int)((2 * lane + (long)c * ld) * 8), 0, 16);
+    }
+}
+// C -= A A^T on the lower 16 x 16 blocks with A (128 x 128, element (m, k) at img[m + k DL]) resident in LDS: the MFMA
+// sequence of chain_gemm<false> (slab by slab, k ascending) without its loads and barriers -- same bits.
+__device__ __forceinline__ void chain_syrk_image(ChainAcc& acc, const double* img) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int mi0 = wave, mi1 = 7 - wave;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const double* la = img + s * GEMM_LDS_TILE;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int krow = (4 * kk + (lane >> 4)) * GEMM_LDS_MC_LD + (lane & 15);
+            const double a0 = la[krow + 16 * mi0], a1 = la[krow + 16 * mi1];
+#pragma unroll
+            for (int nj = 0; nj < 8; ++nj) {
+                if (nj <= mi1) {
+                    const double bf = la[krow + 16 * nj];
+                    if (nj <= mi0) acc.v[0][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf, a0, acc.v[0][nj], 0, 0, 0);
+                    acc.v[1][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf, a1, acc.v[1][nj], 0, 0, 0);
+                }
+            }
+        }
+    }
+}
+// image <- (global tile) - image on the lower 16 x 16 blocks, zero above: diag_block's input, built in place
+__device__ __forceinline__ void chain_image_rsub(const double* __restrict__ C, long ld, double* img) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ti = lane >> 3;                                    // 16-row block of rows 2 lane, 2 lane + 1
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        d2_t cv[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int c = w + 4 * (16 * h + q);
+            cv[q] = d2_t{0.0, 0.0};
+            if (ti >= (c >> 4)) cv[q] = *reinterpret_cast<const d2_t*>(C + 2 * lane + (long)c * ld);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int c = w + 4 * (16 * h + q);
+            d2_t v = d2_t{0.0, 0.0};
+            if (ti >= (c >> 4)) v = cv[q] - *reinterpret_cast<const d2_t*>(img + 2 * lane + c * DL);
+            *reinterpret_cast<d2_t*>(img + 2 * lane + c * DL) = v;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Single-launch factorisation, DATAFLOW form (default): no grid barriers.
 //
@@ -800,8 +883,17 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
     int* panel_done = a.sync + DF_FACT + 2 * nb;        // [i + j nb]
     if (b == 0) {
         // ---- the chain ----
-        diag_block<true>(a.A, ld, a.Linv, ld, a.info, 0, smem);
-        pk_signal(factored + 0);
+        // Everything between two diagonal blocks stays in LDS: the panel tile L_{j+1,j} = A_{j+1,j} T_jj^T goes accumulators ->
+        // LDS image -> global (write-through, coalesced) and is the LDS-resident operand of the next product; A_{j+1,j+1} -
+        // L L^T is formed in place in the image, which is diag_block's input.  (The barrier form stores and re-loads both
+        // tiles through global memory with 8-byte accesses 64 KB apart: 34 us per step for 15 us of MFMA work.)
+        if (a.fuse == 0) {
+            diag_block<true>(a.A, ld, a.Linv, ld, a.info, 0, smem);
+            pk_signal(factored + 0);
+        } else {
+            diag_block<true, true, true>(a.A, ld, a.Linv, ld, a.info, 0, smem);
+            df_publish_store(factored + 0);
+        }
         for (int j = 0; j <= nb - 2; ++j) {
             double* Ajj = a.A + (long)j * NB * (ld + 1);
             double* Tjj = a.Linv + (long)j * NB * (ld + 1);
@@ -810,26 +902,53 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             PK_STAMP(0);
             if (!pk_wait_count(chain_ready + j, 2, a)) return; // both tiles carry their owners' updates (steps < j)
             PK_STAMP(1);
-            pk_self_fence();                                   // T_jj, written by this workgroup a moment ago
+            if (a.fuse == 0) {
+                pk_self_fence();                                   // T_jj, written by this workgroup a moment ago
+                {
+                    ChainAcc ca;
+                    ca.zero();
+                    chain_gemm<true>(ca, Asub, ld, Tjj, ld, lds);                     // L_{j+1,j} = A_{j+1,j} T_jj^T
+                    chain_store<true>(Asub, ld, ca);
+                }
+                pk_signal(panel_done + (j + 1) + (long)j * nb);
+                PK_STAMP(2);
+                pk_inv_l1();
+                {
+                    ChainAcc ca;
+                    ca.zero();
+                    chain_gemm<false>(ca, Asub, ld, Asub, ld, lds);                   // A_{j+1,j+1} -= L_{j+1,j} L_{j+1,j}^T
+                    chain_store<false>(Anext, ld, ca);
+                }
+                pk_self_fence();
+                PK_STAMP(3);
+                diag_block<true>(Anext, ld, Tjj + (long)NB * (ld + 1), ld, a.info, (j + 1) * NB, smem);
+                pk_signal(factored + j + 1);
+                PK_STAMP(4);
+                continue;
+            }
             {
                 ChainAcc ca;
                 ca.zero();
-                chain_gemm<true>(ca, Asub, ld, Tjj, ld, lds);                     // L_{j+1,j} = A_{j+1,j} T_jj^T
-                chain_store<true>(Asub, ld, ca);
+                chain_gemm<true>(ca, Asub, ld, Tjj, ld, lds);                         // L_{j+1,j} = A_{j+1,j} T_jj^T (ends with a barrier)
+                chain_acc_to_image<true>(ca, lds);
             }
-            pk_signal(panel_done + (j + 1) + (long)j * nb);
+            lds_barrier();
+            chain_image_store_wt(Asub, ld, lds);
+            df_publish_store(panel_done + (j + 1) + (long)j * nb);                    // drains every wave's stores
             PK_STAMP(2);
-            pk_inv_l1();
             {
                 ChainAcc ca;
                 ca.zero();
-                chain_gemm<false>(ca, Asub, ld, Asub, ld, lds);                   // A_{j+1,j+1} -= L_{j+1,j} L_{j+1,j}^T
-                chain_store<false>(Anext, ld, ca);
+                chain_syrk_image(ca, lds);                                            // L_{j+1,j} L_{j+1,j}^T, operand in LDS
+                lds_barrier();                                                        // every wave has read the operand
+                chain_acc_to_image<false>(ca, lds);
             }
-            pk_self_fence();
+            lds_barrier();
+            chain_image_rsub(Anext, ld, lds);                                         // image = A_{j+1,j+1} - L L^T, zero above
+            __syncthreads();
             PK_STAMP(3);
-            diag_block<true>(Anext, ld, Tjj + (long)NB * (ld + 1), ld, a.info, (j + 1) * NB, smem);
-            pk_signal(factored + j + 1);
+            diag_block<true, false, true>(Anext, ld, Tjj + (long)NB * (ld + 1), ld, a.info, (j + 1) * NB, smem);
+            df_publish_store(factored + j + 1);
             PK_STAMP(4);
         }
         return;
@@ -1024,7 +1143,7 @@ void launch_potrf_persistent(hipStream_t s, double* A, int Np, double* Linv, int
     a.timeout = 20000000LL;   // 0.2 s of the 100 MHz wall clock
     a.trace = trace;
     a.nbo = potrf_persistent_nbo(Np);
-    a.j0 = 0; a.j1 = nb; a.k0 = 0; a.ext_flag = nullptr; a.pr = 1; a.map = 0; a.near = 0; a.acq = 1; a.idle_sleep = 16;
+    a.j0 = 0; a.j1 = nb; a.k0 = 0; a.ext_flag = nullptr; a.pr = 1; a.map = 0; a.near = 0; a.acq = 1; a.idle_sleep = 16; a.fuse = 0;
     hipLaunchKernelGGL(potrf_persistent_kernel, dim3(G), dim3(256), DIAG_LDS_BYTES, s, a);
 }
 
@@ -1070,6 +1189,7 @@ bool launch_potrf_dataflow(hipStream_t s, double* A, int Np, double* Linv, int* 
     a.near = envi("SLS_POTRF_DNEAR", 0);
     a.acq = envi("SLS_POTRF_DACQ", 1);
     a.idle_sleep = envi("SLS_POTRF_DSLEEP", 16);
+    a.fuse = envi("SLS_POTRF_DFUSE", 1);
     hipLaunchKernelGGL(potrf_dataflow_kernel, dim3(G), dim3(256), DIAG_LDS_BYTES, s, a);
     return true;
 }
@@ -1156,7 +1276,7 @@ void launch_potrf_hybrid(hipStream_t s, double* A, int Np, double* Linv, int* in
         a.j0 = b0; a.j1 = b1;                 // b1 == nb: last block, runs to the end
         a.k0 = B > 0 ? b0 - nbo : b0;
         a.ext_flag = (B > 0 && b1 - b0 > 1) ? flags + B : nullptr;
-        a.pr = 1; a.map = 0; a.near = 0; a.acq = 1; a.idle_sleep = 16;
+        a.pr = 1; a.map = 0; a.near = 0; a.acq = 1; a.idle_sleep = 16; a.fuse = 0;
         const int work = nb - b0;             // panel tiles of the first step (+ chain)
         const int G = std::max(2, std::min(64, 1 + work));
         hipLaunchKernelGGL(potrf_persistent_kernel, dim3(G), dim3(256), DIAG_LDS_BYTES, s, a);

@@ -12,6 +12,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionfinish(session, exitstatus):
+    """Evidence records of the GPU tests (tests/util.py: record): divergent-start counts, per-seed errors, timings."""
+    try:
+        import json
+
+        from util import EVIDENCE
+        if EVIDENCE:
+            out = os.path.join(ROOT, "gpurun_out")
+            os.makedirs(out, exist_ok=True)
+            with open(os.path.join(out, "test_evidence.json"), "w") as f:
+                json.dump(EVIDENCE, f, indent=1)
+    except Exception:
+        pass
+
+
 @pytest.fixture(scope="session")
 def fixtures():
     import json

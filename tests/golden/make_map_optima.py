@@ -12,7 +12,9 @@ iterate-by-iterate comparison is impossible.  What CAN be pinned is the optimum:
 (minimize(method="TNC")) and L-BFGS-B maximise a numpy/scipy implementation of the same objectives -- kernels written from the
 published definitions, LAPACK cho_factor / cho_solve, analytic gradients checked against finite
 differences at generation time -- from the reference's initial point and from a set of seeded random starts; the best
-optimum found and its objective value are stored.  Nothing here reads /root/reference, the oracle or the HIP library.
+optimum found and its objective value are stored, together with every distinct local optimum the starts reached (the GP
+objective is multi-modal: DIRECT(300) in D + 2 dimensions decides the basin, and the library's DIRECT need not land in the basin
+scipy's best start found).  Nothing here reads /root/reference, the oracle or the HIP library.
 
 The functions below are also imported by tests/test_gpu_map_fit.py to evaluate the numpy objective at the point the
 library returns (the library may legitimately end in a better local optimum than scipy: the test then checks stationarity
@@ -137,8 +139,9 @@ def projected_grad_log(x, g, lo, hi, log_mask):
     return out
 
 
-def _maximise(fun_z, z0s, bounds):
-    """Best of TNC and L-BFGS-B over the starts; fun_z returns (value, grad) of the objective to MAXIMISE in z."""
+def _maximise(fun_z, z0s, bounds, found=None):
+    """Best of TNC and L-BFGS-B over the starts; fun_z returns (value, grad) of the objective to MAXIMISE in z.
+    found (optional list): every local optimum reached, as (value, z)."""
     best = None
     for z0 in z0s:
         for method, opts in (("TNC", dict(maxfun=20000, ftol=1e-15, gtol=1e-10, xtol=1e-15)),
@@ -148,6 +151,8 @@ def _maximise(fun_z, z0s, bounds):
                 res = minimize(lambda zz: tuple(-v for v in fun_z(zz)), z, jac=True, method=method, bounds=bounds, options=opts)
                 z = res.x
             v = fun_z(z)[0]
+            if found is not None:
+                found.append((v, z.copy()))
             if best is None or v > best[0]:
                 best = (v, z.copy(), method)
     return best
@@ -184,16 +189,31 @@ def main():
                     v, g = gp_map_objective(kind, X, y, x)
                     return v, g * x
                 starts = [np.log(np.concatenate([[0.5, 1e-4], np.full(D, 0.5)]))]           # the reference's x_ini (prior medians)
+                # the modes of the three log-normal priors, and the same with a small signal variance: the "no dimension
+                # matters" optimum every problem of this family has (all r on the prior's mode, the data explained by noise)
+                mode = lambda med, var: np.log(med) - var
+                starts.append(np.concatenate([[mode(0.5, 0.5), mode(1e-4, 0.5)], np.full(D, mode(0.5, 0.5))]))
+                starts.append(np.concatenate([[np.log(5e-3), mode(1e-4, 0.5)], np.full(D, mode(0.5, 0.5))]))
                 for _ in range(6):
                     starts.append(np.concatenate([rng.uniform(np.log(0.05), np.log(5.0), 1), rng.uniform(np.log(1e-6), np.log(1e-1), 1),
                                                   rng.uniform(np.log(0.1), np.log(10.0), D)]))
-                v, z, method = _maximise(fz, starts, [(LOG_LO, LOG_HI)] * (D + 2))
+                found = []
+                v, z, method = _maximise(fz, starts, [(LOG_LO, LOG_HI)] * (D + 2), found)
                 x = np.exp(z)
+                # distinct local optima (value to 1e-7 relative), best first
+                found.sort(key=lambda t: -t[0])
+                uniq = []
+                for (fv, fzv) in found:
+                    if np.isfinite(fv) and not any(abs(fv - u[0]) <= 1e-7 * max(1.0, abs(fv)) for u in uniq):
+                        uniq.append((fv, fzv))
+                out[f"{name}/local_values"] = np.array([u[0] for u in uniq])
+                out[f"{name}/local_x"] = np.exp(np.array([u[1] for u in uniq]))
                 pg = projected_grad_log(x, gp_map_objective(kind, X, y, x)[1], LOG_LO, LOG_HI, np.ones(D + 2, bool))
                 gp_cases.append(name)
                 out[f"{name}/X"], out[f"{name}/y"], out[f"{name}/kernel"] = X, y, np.array(kind)
                 out[f"{name}/x_opt"], out[f"{name}/value"], out[f"{name}/pg_inf"] = x, np.array(v), np.array(np.max(np.abs(pg)))
-                print(name, "value %.9f" % v, method, "a %.4g b %.4g r[:3]" % (x[0], x[1]), x[2:5], "pg_inf %.2e" % np.max(np.abs(pg)))
+                print(name, "value %.9f" % v, method, "a %.4g b %.4g r[:3]" % (x[0], x[1]), x[2:5], "pg_inf %.2e" % np.max(np.abs(pg)),
+                      "local optima:", np.round(out[f"{name}/local_values"], 4))
     for (D, M, npref) in ((2, 25, 12), (6, 60, 30)):
         X, f = synth(rng, D, M)
         prefs = []

@@ -26,22 +26,37 @@ def relerr(a, b, floor=1e-300):
     return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor))) if a.size else 0.0
 
 
-def assert_starts_agree(rg, ro, min_frac=0.95, margin_tol=1e-6, basin_rtol=1e-3):
+EVIDENCE = []      # records of the running session; tests/conftest.py writes them to gpurun_out/test_evidence.json at the end
+
+
+def record(kind, **payload):
+    EVIDENCE.append(dict(kind=kind, **payload))
+
+
+def assert_starts_agree(rg, ro, min_frac=0.95, margin_tol=1e-6, basin_rtol=1e-3, label="", max_divergent=None, allow_basin=True):
     """Per-start end values of the HIP maximiser (rg) against the oracle run with diag=True (ro).
 
     Both sides run the same bounded L-BFGS statement by statement; they differ only in summation order.  A start can end
     elsewhere only where a DISCRETE decision of the algorithm sat within rounding of its threshold and the two sides took
     different branches: the Armijo test  ft <= f + c1 g.s  (measured on MI355X: 1 of 96 starts, margin 3.5e-9;
     tools/diverging_starts.py), or a clamp / active-bound / curvature test of a start that runs along the box boundary.
-    Asserted: at least `min_frac` of the starts agree to 1e-6; a start that does not agree either has a near-threshold Armijo
-    test on the oracle side (relative margin < margin_tol) or still ends in the same basin (within basin_rtol) -- the
-    chosen maximiser itself is held to 1e-6 by the callers."""
+    Asserted: at least `min_frac` of the starts agree to 1e-6 (and at most `max_divergent` differ, when given); a start that
+    does not agree has a near-threshold Armijo test on the oracle side (relative margin < margin_tol) or -- only where
+    `allow_basin` -- still ends in the same basin (within basin_rtol).  The chosen maximiser itself is held to 1e-6 by the
+    callers.  Every call leaves a record (count, indices, margins of the divergent starts) in the session's evidence file,
+    so that a drift of the divergence rate is visible from run to run."""
     scale = max(np.abs(ro["y_stars"]).max(), 1e-300)
     agree = np.isclose(rg["y_stars"], ro["y_stars"], rtol=1e-6, atol=1e-12 * scale)
+    bad = np.nonzero(~agree)[0]
+    record("starts_agree", label=label, starts=int(agree.size), divergent=int(bad.size), indices=[int(i) for i in bad[:32]],
+           armijo_margins=[float(ro["armijo_margin"][i]) for i in bad[:32]],
+           rel_gap=[float(abs(rg["y_stars"][i] - ro["y_stars"][i]) / scale) for i in bad[:32]])
     assert agree.mean() >= min_frac, f"only {agree.mean():.2%} of the starts end at the oracle's value"
-    for i in np.nonzero(~agree)[0]:
-        near = np.isclose(rg["y_stars"][i], ro["y_stars"][i], rtol=basin_rtol, atol=1e-9 * scale)
+    if max_divergent is not None:
+        assert bad.size <= max_divergent, f"{bad.size} divergent starts (bound {max_divergent}): {bad[:16]}"
+    for i in bad:
+        near = allow_basin and np.isclose(rg["y_stars"][i], ro["y_stars"][i], rtol=basin_rtol, atol=1e-9 * scale)
         assert ro["armijo_margin"][i] < margin_tol or near, (
-            f"start {i} ends at {rg['y_stars'][i]!r} vs oracle {ro['y_stars'][i]!r}: not the same basin, and no Armijo test was "
-            f"closer than {ro['armijo_margin'][i]:.2e} to its threshold")
+            f"start {i} ends at {rg['y_stars'][i]!r} vs oracle {ro['y_stars'][i]!r}: " + ("not the same basin, and " if allow_basin else "")
+            + f"no Armijo test was closer than {ro['armijo_margin'][i]:.2e} to its threshold")
     return agree

@@ -2,6 +2,7 @@
 #define SLS_DIAG_TIMING 1
 #include "../../sequential-line-search_amd/csrc/kernels_chol.hip"
 #include <cmath>
+#include <cstring>
 #include <cstdio>
 #include <vector>
 
@@ -66,6 +67,11 @@ int main() {
         }
         hipMemcpy(L.data(), dA, A.size() * 8, hipMemcpyDeviceToHost);
         hipMemcpy(T.data(), dL, A.size() * 8, hipMemcpyDeviceToHost);
+        {   // order-independent fingerprints of the factor and of the diagonal-block inverses (A/B of diag16 variants: same bits?)
+            unsigned long long hL = 0, hT = 0;
+            for (size_t q = 0; q < L.size(); ++q) { unsigned long long u; memcpy(&u, &L[q], 8); hL += u * (2 * q + 1); memcpy(&u, &T[q], 8); hT += u * (2 * q + 1); }
+            printf("fingerprints N=%d: L %016llx  T %016llx\n", Np, hL, hT);
+        }
         if (Np == 1024) {
             double r1 = 0, r2 = 0;
             for (int i = 0; i < Np; ++i) for (int j = 0; j <= i; ++j) {
