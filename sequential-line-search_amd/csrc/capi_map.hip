@@ -106,6 +106,13 @@ static void nll_factor(sls_nll* h, const double* theta, double b) {
     h->have_factor = true;
 }
 
+// split-K factor of the gradient's Y = G X~ product: a power of two dividing nt, about 512 workgroups in the launch
+static int nll_y_chunks(int nt, int ncols) {
+    int c = 1;
+    while (c * 2 <= nt && nt % (c * 2) == 0 && nt * ncols * c * 2 <= 512) c *= 2;
+    return c;
+}
+
 // N <= 128: the whole evaluation is one single-workgroup launch (kernels_small.hip); SLS_NLL_SMALL=0 forces the tiled path
 static bool nll_small_ok(const sls_nll* h, bool want_theta_grad) {
     if (h->N > NLL_SMALL_MAX_N) return false;
@@ -180,7 +187,7 @@ static void nll_eval_impl(sls_nll* h, const double* y, const double* theta, doub
     const int nt = Np / 128;
     if (want_grad) {
         h->G.ensure((size_t)Np * Np);
-        h->Y.ensure((size_t)Np * h->Dcols);
+        h->Y.ensure((size_t)Np * h->Dcols * nll_y_chunks(nt, h->Dcols / 128));
         h->parts.ensure((size_t)nt * nt);
         launch_nll_weight(c->stream, h->XT.p, Np, h->Dp, h->nx.p, Np, N, KernelSpec{h->kernel, theta[0]}, h->alpha.p, h->Kinv.p,
                           h->G.p, h->parts.p);
@@ -191,7 +198,10 @@ static void nll_eval_impl(sls_nll* h, const double* y, const double* theta, doub
     std::vector<double> gl(D, 0.0);
     if (grad_theta) {
         launch_gemv_n(c->stream, h->G.p, Np, h->ones.p, h->svec.p, h->gemv_part.p);
-        launch_gemm_plain(c->stream, h->G.p, Np, false, h->XT.p, Np, true, h->Y.p, Np, nt, h->Dcols / 128, Np, 1.0, 0.0);
+        // Y = G X~ has only nt x Dcols/128 output tiles: split the contraction so that the launch fills the chip
+        const int yc = nll_y_chunks(nt, h->Dcols / 128);
+        launch_gemm_splitk_nt(c->stream, h->G.p, Np, h->XT.p, Np, h->Y.p, Np, (long)Np * h->Dcols, nt, h->Dcols / 128, Np, yc);
+        launch_sum_chunks(c->stream, h->Y.p, (long)Np * h->Dcols, yc, (long)Np * h->Dcols);
         launch_lengthscale_grad(c->stream, h->XT.p, h->Y.p, h->svec.p, h->inv_ell.p, Np, N, D, h->gl.p);
         SLS_HIP(hipMemcpyAsync(gl.data(), h->gl.p, (size_t)D * 8, hipMemcpyDeviceToHost, c->stream));
     }

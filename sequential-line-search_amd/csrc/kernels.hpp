@@ -167,6 +167,8 @@ struct PotrfAux {
 int potrf_default_nbo(int Np);
 void launch_potrf(hipStream_t s, double* A, int Np, double* Linv, int* info, int nbo = 0, PotrfAux* aux = nullptr,
                   int* persist_sync = nullptr, int* dataflow_sync = nullptr);
+void launch_gemm_splitk_nt(hipStream_t s, const double* A, long lda, const double* B, long ldb, double* Cpart, long ldc,
+                           long part_stride, int mt, int nt, int K, int chunks);
 // Dataflow form of the single-launch factorisation (SLS_POTRF_MODE=3, default): per-tile ownership and ready flags instead
 // of grid barriers.  sync = potrf_dataflow_sync_ints(Np) ints of device scratch; returns false when not applicable.
 size_t potrf_dataflow_sync_ints(int Np);
@@ -220,5 +222,6 @@ void launch_nll_scalars(hipStream_t s, const double* part, int nparts, const dou
 // gl[p] = 2 * inv_ell[p] * sum_j XT[j,p] * (XT[j,p] * s_j - Y[j,p]),  p < D
 void launch_lengthscale_grad(hipStream_t s, const double* XT, const double* Y, const double* svec, const double* inv_ell,
                              long ld, int N, int D, double* gl);
+void launch_sum_chunks(hipStream_t s, double* Y, long n, int chunks, long stride);
 
 }  // namespace slsk

@@ -187,6 +187,19 @@ void launch_gemm_plain(hipStream_t s, const double* A, long lda, bool a_kc, cons
     else launch_tri_gemm<true, false>(s, g, 1);
 }
 
+// C_part[c] = A[:, K_c] * B[:, K_c]^T for `chunks` equal ranges K_c of the contraction (A M-contiguous, B K-contiguous): a tall
+// product with few output tiles (the MAP gradient's Y = G X~: N x D x N, N / 128 tiles) spread over chunks x as many workgroups.
+// The caller adds the partial results in chunk order (fixed order: deterministic).
+void launch_gemm_splitk_nt(hipStream_t s, const double* A, long lda, const double* B, long ldb, double* Cpart, long ldc,
+                           long part_stride, int mt, int nt, int K, int chunks) {
+    const int Kc = K / chunks;                        // multiple of 128 (caller)
+    GemmDesc g = mkdesc(A, lda, B, ldb, Cpart, ldc, mt, nt, Kc, 1.0, 0.0);
+    g.strideA = (long)Kc * lda;
+    g.strideB = Kc;
+    g.strideC = part_stride;
+    launch_tri_gemm<false, true>(s, g, chunks);
+}
+
 // Cholesky factor + inverse of ONE 128 x 128 diagonal block by the calling workgroup (256 threads, `smem` = DIAG_LDS_BYTES of
 // LDS): A (lower triangle read) -> L in place (FACTOR) and T = L^-1 into Tout.  Shared by the one-block launch
 // (chol_diag_kernel) and the single-launch persistent factorisation (potrf_persistent_kernel).
@@ -1470,7 +1483,9 @@ void launch_lauum(hipStream_t s, const double* U, int Np, double* Kinv) {
         const char* e = getenv("SLS_LAUUM_N64");
         n64_env = e ? atoi(e) : -1;
     }
-    const bool narrow = n64_env >= 0 ? n64_env != 0 : nb <= 8;
+    // measured inside the C5 evaluation (N = 4096): 3.41 -> 3.24 ms per evaluation with half tiles (the longest tile's k loop,
+    // 32 slabs of 13.6 us on a shared CU, bounds the launch); at N = 8192 whole tiles win (2.9 ms, 0.80 of peak)
+    const bool narrow = n64_env >= 0 ? n64_env != 0 : nb <= 32;
     if (narrow) launch_tri_gemm_mc_half(s, g, 1);
     else launch_tri_gemm<false, false>(s, g, 1);
     hipLaunchKernelGGL(symmetrize_kernel, dim3(Np / 32, Np / 32), dim3(256), 0, s, Kinv, Np);

@@ -79,24 +79,25 @@ __global__ __launch_bounds__(256, 2) void gram_sym_kernel(const double* __restri
     Acc acc;
     acc.zero();
     gemm_tile<false, false>(acc, XT + m0, ld, XT + n0, ld, 0, Dp, lds);
+    // epilogue column by column (acc_tile_by_columns): 16-byte stores, a whole 1 KB column of K per wave instruction
+    acc_tile_by_columns<true>(acc, lds, [&](int col, int row, d2_t dot) {
+        const int gj = n0 + col;
+        const double nj = nx[gj];
+        const d2_t ni = *reinterpret_cast<const d2_t*>(nx + m0 + row);
+        d2_t out;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int gi = m0 + acc_m(i);
-        const double ni = nx[gi];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gj = n0 + acc_n(j, r);
-                double q = ni + nx[gj] - 2.0 * acc.v[i][j][r];
-                q = (q < 0.0 || gi == gj) ? 0.0 : q;
-                double k, c;
-                kernel_kc(kernel, a, q, k, c);
-                if (gi == gj) k += b;
-                if (gi >= N || gj >= N) k = (gi == gj) ? 1.0 : 0.0;
-                K[(long)gi + (long)gj * Np] = k;
-            }
-    }
+        for (int e = 0; e < 2; ++e) {
+            const int gi = m0 + row + e;
+            double q = ni[e] + nj - 2.0 * dot[e];
+            q = (q < 0.0 || gi == gj) ? 0.0 : q;
+            double k, c;
+            kernel_kc(kernel, a, q, k, c);
+            if (gi == gj) k += b;
+            if (gi >= N || gj >= N) k = (gi == gj) ? 1.0 : 0.0;
+            out[e] = k;
+        }
+        *reinterpret_cast<d2_t*>(K + (long)(m0 + row) + (long)gj * Np) = out;
+    });
 }
 
 void launch_gram_sym(hipStream_t s, const double* XT, long ld, int Dp, const double* nx, int Np, int N, KernelSpec ks, double b,
@@ -126,56 +127,42 @@ __global__ __launch_bounds__(256, 2) void cross_gram_kernel(const double* __rest
     acc.zero();
     gemm_tile<false, false>(acc, XsT + m0, lds_, XT + n0, ld, 0, Dp, lds);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double smu[4], sca[4];
+    // Epilogue column by column (acc_tile_by_columns): a column = one training point over the tile's 128 candidates, 1 KB
+    // contiguous in K* / C*, written with 16-byte stores.  A thread keeps the partial sums of its two candidates over the 32
+    // training points it visits (wave + 4 q in each half, ascending); the four waves' sums are added in wave order below.
+    // The order depends on nothing but the tile's structure: a candidate's bits do not depend on its position in the batch.
+    const d2_t nm = *reinterpret_cast<const d2_t*>(ns + m0 + 2 * lane);
+    d2_t smu = {0.0, 0.0}, sca = {0.0, 0.0};
+    acc_tile_by_columns<true>(acc, lds, [&](int col, int row, d2_t dot) {
+        const int gi = n0 + col;
+        const double ni = nx[gi];
+        const double al = alpha ? alpha[gi] : 0.0;
+        d2_t kv, cv;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int gm = m0 + acc_m(i);
-        const double nm = ns[gm];
-        double pm = 0.0, pc = 0.0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gi = n0 + acc_n(j, r);
-                double q = nm + nx[gi] - 2.0 * acc.v[i][j][r];
-                q = q < 0.0 ? 0.0 : q;
-                double k, c;
-                kernel_kc(MATERN ? SLS_KERNEL_ARD_MATERN52 : SLS_KERNEL_ARD_SQUARED_EXPONENTIAL, a, q, k, c);
-                if (gi >= N) { k = 0.0; c = 0.0; }
-                Ks[(long)gm + (long)gi * ldk] = k;
-                if (MATERN) Cs[(long)gm + (long)gi * ldk] = c;
-                if (alpha) {
-                    const double al = alpha[gi];
-                    pm += al * k;
-                    pc += al * c;
-                }
-            }
-        smu[i] = pm;
-        sca[i] = pc;
-    }
+        for (int e = 0; e < 2; ++e) {
+            double q = nm[e] + ni - 2.0 * dot[e];
+            q = q < 0.0 ? 0.0 : q;
+            double k, c;
+            kernel_kc(MATERN ? SLS_KERNEL_ARD_MATERN52 : SLS_KERNEL_ARD_SQUARED_EXPONENTIAL, a, q, k, c);
+            if (gi >= N) { k = 0.0; c = 0.0; }
+            kv[e] = k;
+            cv[e] = c;
+            smu[e] += al * k;
+            sca[e] += al * c;
+        }
+        *reinterpret_cast<d2_t*>(Ks + (long)(m0 + row) + (long)gi * ldk) = kv;
+        if (MATERN) *reinterpret_cast<d2_t*>(Cs + (long)(m0 + row) + (long)gi * ldk) = cv;
+    });
     if (alpha) {
-        // reduce over the 4 lane groups (lane>>4), then over the two wave columns through LDS
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            smu[i] += __shfl_xor(smu[i], 16);
-            smu[i] += __shfl_xor(smu[i], 32);
-            sca[i] += __shfl_xor(sca[i], 16);
-            sca[i] += __shfl_xor(sca[i], 32);
-        }
-        double* red = lds;  // [2 wn][2 arrays][128]
-        if (lane < 16) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int ml = (wave & 1) * 64 + 16 * i + lane;
-                red[((wave >> 1) * 2 + 0) * 128 + ml] = smu[i];
-                red[((wave >> 1) * 2 + 1) * 128 + ml] = sca[i];
-            }
-        }
+        __syncthreads();
+        double* red = lds;  // [4 waves][2 arrays][128]
+        *reinterpret_cast<d2_t*>(red + (wave * 2 + 0) * 128 + 2 * lane) = smu;
+        *reinterpret_cast<d2_t*>(red + (wave * 2 + 1) * 128 + 2 * lane) = sca;
         __syncthreads();
         if (threadIdx.x < 128) {
             const int ml = threadIdx.x;
-            mu_part[(long)tn * ldk + m0 + ml] = red[0 * 128 + ml] + red[2 * 128 + ml];
-            ca_part[(long)tn * ldk + m0 + ml] = red[1 * 128 + ml] + red[3 * 128 + ml];
+            mu_part[(long)tn * ldk + m0 + ml] = ((red[0 * 128 + ml] + red[2 * 128 + ml]) + red[4 * 128 + ml]) + red[6 * 128 + ml];
+            ca_part[(long)tn * ldk + m0 + ml] = ((red[1 * 128 + ml] + red[3 * 128 + ml]) + red[5 * 128 + ml]) + red[7 * 128 + ml];
         }
     }
 }

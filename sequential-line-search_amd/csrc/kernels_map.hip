@@ -26,34 +26,37 @@ __global__ __launch_bounds__(256) void nll_weight_kernel(const double* __restric
     acc.zero();
     gemm_tile<false, false>(acc, XT + m0, ld, XT + n0, ld, 0, Dp, lds);
     double part = 0.0;
+    // column by column (acc_tile_by_columns): K^-1 is read and G written with 16-byte accesses, 1 KB per wave instruction
+    acc_tile_by_columns<true>(acc, lds, [&](int col, int row, d2_t dot) {
+        const int gj = n0 + col;
+        const double nj = nx[gj], aj = alpha[gj];
+        const d2_t ni = *reinterpret_cast<const d2_t*>(nx + m0 + row);
+        const d2_t ai = *reinterpret_cast<const d2_t*>(alpha + m0 + row);
+        const long off = (long)(m0 + row) + (long)gj * Np;
+        const d2_t kinv = *reinterpret_cast<const d2_t*>(Kinv + off);
+        d2_t g;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int gi = m0 + acc_m(i);
-        const double ni = nx[gi];
-        const double ai = alpha[gi];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gj = n0 + acc_n(j, r);
-                double q = ni + nx[gj] - 2.0 * acc.v[i][j][r];
-                q = (q < 0.0 || gi == gj) ? 0.0 : q;
-                double k, c;
-                if (!MATERN) {
-                    k = a * exp(-0.5 * q);
-                    c = k;
-                } else {
-                    const double s = sqrt(5.0 * q), e = exp(-s);
-                    k = a * (1.0 + s + (5.0 / 3.0) * q) * e;
-                    c = a * (5.0 / 3.0) * (1.0 + s) * e;
-                }
-                const long off = (long)gi + (long)gj * Np;
-                double w = 0.5 * (ai * alpha[gj] - Kinv[off]);
-                if (gi >= N || gj >= N) w = 0.0;
-                G[off] = w * c;
-                part += w * k;
+        for (int e = 0; e < 2; ++e) {
+            const int gi = m0 + row + e;
+            double q = ni[e] + nj - 2.0 * dot[e];
+            q = (q < 0.0 || gi == gj) ? 0.0 : q;
+            double k, c;
+            if (!MATERN) {
+                k = a * exp(-0.5 * q);
+                c = k;
+            } else {
+                const double s = sqrt(5.0 * q), ex = exp(-s);
+                k = a * (1.0 + s + (5.0 / 3.0) * q) * ex;
+                c = a * (5.0 / 3.0) * (1.0 + s) * ex;
             }
-    }
+            double w = 0.5 * (ai[e] * aj - kinv[e]);
+            if (gi >= N || gj >= N) w = 0.0;
+            g[e] = w * c;
+            part += w * k;
+        }
+        *reinterpret_cast<d2_t*>(G + off) = g;
+    });
+    __syncthreads();
     // deterministic block reduction: wave shuffle tree, then 4 waves through LDS
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
@@ -102,6 +105,19 @@ __global__ __launch_bounds__(256) void nll_scalars_kernel(const double* __restri
 void launch_nll_scalars(hipStream_t s, const double* part, int nparts, const double* alpha, const double* y,
                         const double* Kinv, int Np, int N, double* out) {
     hipLaunchKernelGGL(nll_scalars_kernel, dim3(1), dim3(256), 0, s, part, nparts, alpha, y, Kinv, Np, N, out);
+}
+
+// Y[idx] = sum_c Ypart[c][idx] in chunk order (split-K partial products of launch_gemm_splitk_nt), in place in chunk 0
+__global__ __launch_bounds__(256) void sum_chunks_kernel(double* __restrict__ Y, long n, int chunks, long stride) {
+    const long i = 2 * (blockIdx.x * 256L + threadIdx.x);
+    if (i >= n) return;
+    d2_t v = *reinterpret_cast<const d2_t*>(Y + i);
+    for (int c = 1; c < chunks; ++c) v += *reinterpret_cast<const d2_t*>(Y + (long)c * stride + i);
+    *reinterpret_cast<d2_t*>(Y + i) = v;
+}
+void launch_sum_chunks(hipStream_t s, double* Y, long n, int chunks, long stride) {
+    if (chunks <= 1) return;
+    hipLaunchKernelGGL(sum_chunks_kernel, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, s, Y, n, chunks, stride);
 }
 
 __global__ __launch_bounds__(256) void lengthscale_grad_kernel(const double* __restrict__ XT, const double* __restrict__ Y,
