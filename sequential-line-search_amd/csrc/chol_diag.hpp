@@ -70,6 +70,10 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // in a register and reported once); 4850 with the running diagonal kept in every lane (pivot one fma behind the broadcast
 // instead of fma -> broadcast); 5300 with v_fmac_f64_dpp fusing broadcast + fma.  The wave is ISSUE-bound (~660 fp64 / DPP
 // instructions at ~7 cycles), not latency-bound: shortening the dependency chain buys nothing, fewer instructions would.
+// Also measured and not kept (round 3): wave 0 as a pure pivot wave (only its own panel tile + the next diagonal tile's update
+// from registers, waves 1-3 meeting on an LDS counter instead of the second barrier): 57 500 vs 57 900 cycles per block --
+// waves 1-3 (trailing update ~600 cycles per 16 x 16 tile, S tiles) are then the longer path; three tiles in flight per wave
+// did not shorten them (not latency-bound either), and a k-interleaved S phase compiled into a branch per MFMA (80 000).
 template <bool FACTOR>
 __device__ __forceinline__ void diag16(double* As, double* Tk, int c0, int lane, int* info, int global_off) {
     const int row = lane & 15, g = lane >> 4;

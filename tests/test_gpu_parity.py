@@ -239,7 +239,7 @@ def test_multistart_maximizer_matches_oracle(ctx, oracle, kernel, acq, path):
     rg = gp.acq_maximize(starts, n_local, acq, 2.0)
     # every start follows the same trajectory (same algorithm, fp64 rounding apart); the rare exception is a start whose
     # Armijo test sat at rounding level of its threshold
-    assert_starts_agree(rg, ro, label=f"acq_maximize D={D} N={N} S={S} kernel={kernel} acq={acq}")
+    assert_starts_agree(rg, ro, label=f"acq_maximize D={D} N={N} S={S} kernel={kernel} acq={acq}", max_divergent=3)   # measured: 0 or 1 of 96
     # many starts converge to the same maximiser, so the winning INDEX is decided by the last bits; what must
     # agree is the chosen maximiser and its value (north_star: within 1e-6 relative), and the GPU's winner must
     # be one of the oracle's tied winners
@@ -658,13 +658,11 @@ def test_randomised_configurations(ctx, oracle, seed, path):
     mu, sg = gp.predict(Xs); muo, sgo = ref.predict_batch(Xs)
     scale = max(np.abs(muo).max(), 1e-30)
     close(mu, muo, rtol=RTOL, atol=1e-6 * scale)
-    # sigma^2 = a - k.K^-1 k cancels down to ~b: its relative error is (a / sigma^2) * kappa(K_y) * eps, and kappa ~ a N / b.  The
-    # north_star's 1e-6 holds wherever that floor is below it; the other seeds are held to the floor itself (x 100 for the
-    # constant), never looser than 1e-5 (values) / 1e-4 (gradients, which divide by sigma once more).  The evidence file names
-    # the seeds that needed more than 1e-6 and their kappa.
+    # north_star's 1e-6 for every seed: measured on MI355X the largest deviations over the 20 cases are 2.6e-11 (sigma), 1.4e-12
+    # (EI, UCB) and 2.2e-12 (gradients) although kappa(K_y) reaches 7e7 at b = 1e-6 (gpurun_out/test_evidence.json names every
+    # seed with its kappa and errors; earlier rounds ran this test at 1e-5 / 1e-4 without knowing that none of them needs it)
     kappa = theta[0] * N / b
-    floor = 100 * kappa * 2.2e-16 * theta[0] / max(float(np.min(sgo)) ** 2, 1e-300)
-    tol_v, tol_g = min(1e-5, max(1e-6, floor)), min(1e-4, max(1e-6, 10 * floor))
+    tol_v = tol_g = 1e-6
     errs = dict(sigma=relerr(sg, np.maximum(sgo, 1e-7 * np.sqrt(theta[0]))))
     close(sg, sgo, rtol=tol_v, atol=1e-7 * np.sqrt(theta[0]))
     for acq, h in ((0, 1.0), (1, 0.7)):
@@ -677,7 +675,7 @@ def test_randomised_configurations(ctx, oracle, seed, path):
         errs[f"grad{acq}"] = float(np.max(np.abs(g[finite] - go[finite])) / max(np.abs(go[finite]).max(), 1e-30)) if finite.any() else 0.0
     from util import record
     record("randomised", seed=int(seed), path=path, D=D, N=N, M=M, kernel=kernel, b=b, kappa=float(kappa), tol_values=float(tol_v),
-           tol_grads=float(tol_g), needs_more_than_1e6=bool(tol_v > 1e-6), **errs)
+           tol_grads=float(tol_g), **errs)
     gp.close()
 
 
@@ -695,8 +693,8 @@ def test_wave_path_matches_tiled_path_and_oracle(ctx, oracle, kernel, D, N, S, m
         monkeypatch.setenv("SLS_WAVE_PATH", "0")
         rt = gp.acq_maximize(starts, 15, acq, 1.5)
         ro = oracle.Regressor(X, y, theta, b, kernel=kernel).acq_maximize(starts, 15, acq, 1.5, diag=True)
-        assert_starts_agree(rw, ro, min_frac=0.9, label=f"wave D={D} N={N} S={S} kernel={kernel} acq={acq}")
-        assert_starts_agree(rt, ro, min_frac=0.9, label=f"tiled D={D} N={N} S={S} kernel={kernel} acq={acq}")
+        assert_starts_agree(rw, ro, min_frac=0.9, max_divergent=2, label=f"wave D={D} N={N} S={S} kernel={kernel} acq={acq}")
+        assert_starts_agree(rt, ro, min_frac=0.9, max_divergent=2, label=f"tiled D={D} N={N} S={S} kernel={kernel} acq={acq}")
         for other in (rt, ro):
             close(rw["value"], other["value"], rtol=RTOL)
             close(rw["x"], other["x"], rtol=RTOL, atol=1e-7)
