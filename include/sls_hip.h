@@ -205,6 +205,10 @@ int sls_nll_eval(sls_nll* h, const double* y, const double* theta, double b, dou
 /* objective(x, grad) of src/gaussian-process-regressor.cpp:141-193 with x = (a, b, r_1..r_D) and the file's fixed
  * log-normal priors (:18-24).  grad (D + 2) may be NULL. */
 int sls_gp_nll_grad(sls_nll* h, const double* y, const double* x, double* value, double* grad);
+/* values[k] = the same objective at xs[k] = (a, b, r_1..r_D), k < B, no gradients: the B independent evaluations of one DIRECT
+   iteration of PerformMapEstimation (src/gaussian-process-regressor.cpp:294) in ONE launch for N <= 128 (one workgroup per
+   parameter set).  A parameter set whose K_y is not positive definite yields -HUGE_VAL instead of an error. */
+int sls_gp_nll_batch(sls_nll* h, const double* y, const double* xs, int B, double* values);
 /* objective(x, grad) of src/preference-regressor.cpp:129-259.  x = (y_1..y_M [, a, b, r_1..r_D] if use_map_hyperparams);
  * prefs_flat / pref_offsets: CSR image of std::vector<Preference> (n_prefs tuples, first index = preferred point).
  * grad (same length as x) may be NULL.  BTL terms (include/sequential-line-search/utils.hpp:25-52) run on the host. */

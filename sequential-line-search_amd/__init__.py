@@ -50,7 +50,7 @@ EXPORTS = [
     "sls_ctx_set_candidate_chunk", "sls_gram", "sls_gram_cross", "sls_potrf", "sls_potrs", "sls_potri", "sls_gp_create",
     "sls_gp_destroy", "sls_gp_get_matrix", "sls_gp_get_summary", "sls_gp_predict", "sls_gp_predict_grad", "sls_acq_eval",
     "sls_lbfgs_default_opts", "sls_acq_maximize", "sls_acq_maximize_dev", "sls_gp_refit_dev", "sls_prof_enable",
-    "sls_prof_reset", "sls_prof_get", "sls_nll_create", "sls_nll_destroy", "sls_nll_eval", "sls_gp_nll_grad",
+    "sls_prof_reset", "sls_prof_get", "sls_nll_create", "sls_nll_destroy", "sls_nll_eval", "sls_gp_nll_grad", "sls_gp_nll_batch",
     "sls_pref_objective", "sls_acq_eval_pair", "sls_acq_maximize_pair", "sls_gp_append_point", "sls_acq_last_stats",
     "sls_multi_create", "sls_multi_destroy", "sls_multi_size", "sls_multi_exchange", "sls_multi_ctx", "sls_multi_gp_create",
     "sls_multi_gp_destroy", "sls_multi_gp_shard", "sls_multi_acq_maximize", "sls_comm_unique_id", "sls_comm_create",
@@ -297,6 +297,15 @@ class Nll:
         g = np.empty(self.D + 2) if want_grad else None
         _ck(lib().sls_gp_nll_grad(self.h, _p(y), _p(x), C.byref(val), _p(g) if want_grad else None))
         return (val.value, g) if want_grad else val.value
+
+    def gp_objective_batch(self, y, xs):
+        """Values of the GP MAP objective at the rows of xs (B x (D + 2): a, b, r_1..r_D), one device call (sls_gp_nll_batch)."""
+        y = _f(y)
+        xs = np.ascontiguousarray(xs, dtype=np.float64)
+        assert xs.ndim == 2 and xs.shape[1] == self.D + 2
+        out = np.empty(xs.shape[0])
+        _ck(lib().sls_gp_nll_batch(self.h, _p(y), _p(xs), xs.shape[0], _p(out)))
+        return out
 
     def pref_objective(self, prefs, x, use_map=False, a=0.5, r=0.5, b=0.005, prior_var=0.25, btl_scale=0.01,
                        noiseless=False, want_grad=True):

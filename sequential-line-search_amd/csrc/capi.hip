@@ -342,7 +342,7 @@ struct sls_gp {
     // L-BFGS state
     DBuf pair_mu, pair_sg, pair_dmu, pair_dsg;
     DBuf lb_x, lb_g, lb_dir, lb_xt, lb_scr, lb_S, lb_Y, lb_rho, lb_f, lb_t, lb_val, lb_grad, lb_xc;
-    int* lb_int = nullptr;    // hlen | hpos | nbt | done | live list A | live list B | live count (+ padding)
+    int* lb_int = nullptr;    // hlen | hpos | nbt | done | live list A | live list B | live count (+ padding) | block counts
     int lb_Sp = 0, lb_m = 0;
     // statistics of the last sls_acq_maximize* call on this handle (sls_acq_last_stats)
     long stat_issued = 0, stat_cap = 0;
@@ -748,7 +748,7 @@ static void ensure_lbfgs(sls_gp* g, int Sp, int m) {
     g->lb_f.ensure(S); g->lb_t.ensure(S); g->lb_val.ensure(S); g->lb_grad.ensure(S * D); g->lb_xc.ensure(S * D);
     if (g->lb_int) (void)hipFree(g->lb_int);
     g->lb_int = nullptr;
-    SLS_HIP(hipMalloc((void**)&g->lb_int, (S * 6 + 64) * sizeof(int)));
+    SLS_HIP(hipMalloc((void**)&g->lb_int, (S * 6 + 128 + S / 1024 + 8) * sizeof(int)));   // ... | count (64) | block counts
     g->lb_Sp = Sp; g->lb_m = m;
 }
 
@@ -808,11 +808,19 @@ static void maximize_impl(sls_gp* g, sls_gp* gs, int acq_type, double ucb_h, con
             w.XT = g->XT.p; w.inv_ell = g->inv_ell.p; w.Kinv = g->Kinv.p; w.alpha = g->alpha.p; w.starts = starts_dev;
             w.x_out = st.x; w.f_out = st.f; w.ld = Sp;
             w.ev_mu = w.ev_sigma = w.ev_dmu = w.ev_dsigma = w.ev_val = w.ev_grad = nullptr;
+            // evaluations of starts that were still moving (finished starts run idle to keep the barriers uniform): counted
+            // by the kernel into the live-count words of the integer scratch
+            unsigned long long* d_useful = reinterpret_cast<unsigned long long*>(g->lb_int + 6 * (size_t)Sp + 32);
+            SLS_HIP(hipMemsetAsync(d_useful, 0, sizeof(unsigned long long), c->stream));
+            w.useful = d_useful;
             {
                 ProfScope ps(c, "acq_wave");
                 launch_maximize_wave(c->stream, w);
             }
-            g->stat_issued = g->stat_cap;   // the per-start wavefront kernel keeps no count; upper bound
+            unsigned long long useful = 0;
+            SLS_HIP(hipMemcpyAsync(&useful, d_useful, sizeof(useful), hipMemcpyDeviceToHost, c->stream));
+            sync(c);
+            g->stat_issued = (long)useful;
             g->stat_rounds = n_local;
             used_wave = true;
         }
@@ -829,35 +837,39 @@ static void maximize_impl(sls_gp* g, sls_gp* gs, int acq_type, double ucb_h, con
         int* live_a = g->lb_int + 4 * (size_t)Sp;
         int* live_b = live_a + Sp;
         int* d_count = live_b + Sp;
+        int* d_blocks = d_count + 64;     // per-block counts of the compaction
         launch_clamp_starts(c->stream, starts_dev, D, S, st.xt, Sp, Sp);
         const double* trial = st.xt;      // candidate-major trial points of this round, leading dimension Sp
         const int* live = nullptr;        // identity
-        int nlive = S;
+        int nlive = S, moving = S;
         st.ldv = Sp;
         for (int ev = 0; ev < n_local && nlive > 0; ++ev) {
             eval_acq(g, gs, trial, Sp, nlive, acq_type, ucb_h, g->lb_val.p, g->lb_grad.p, Sp);
-            g->stat_issued += nlive;
+            g->stat_issued += compact ? nlive : moving;       // SLS_COMPACT=0 evaluates finished starts too: they do not count
             g->stat_rounds += 1;
             {
                 ProfScope ps(c, "lbfgs");
                 st.live = live; st.nlive = nlive;
                 launch_lbfgs_step(c->stream, st, g->lb_val.p, g->lb_grad.p, ev == 0);
-                if (compact && ev + 1 < n_local) {
+                if (ev + 1 < n_local) {
                     int* live_next = (live == live_a) ? live_b : live_a;
-                    launch_compact_live(c->stream, live, nlive, st.done, live_next, d_count);
-                    launch_gather_trials(c->stream, st.xt, Sp, D, live_next, d_count, nlive, g->lb_xc.p, Sp);
-                    live = live_next;
-                    trial = g->lb_xc.p;
+                    launch_compact_live(c->stream, live, nlive, st.done, live_next, d_count, d_blocks);
+                    if (compact) {
+                        launch_gather_trials(c->stream, st.xt, Sp, D, live_next, d_count, nlive, g->lb_xc.p, Sp);
+                        live = live_next;
+                        trial = g->lb_xc.p;
+                    }
                 }
             }
-            if (compact && ev + 1 < n_local) {
+            if (ev + 1 < n_local) {
                 int cnt = 0;
                 SLS_HIP(hipMemcpyAsync(&cnt, d_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
                 sync(c);
-                nlive = cnt;
+                if (compact) nlive = cnt;
+                else moving = cnt;                            // statistics only: the launch shapes stay at S
             }
         }
-        g->stat_live_end = nlive;
+        g->stat_live_end = compact ? nlive : moving;
     }   // !used_wave
     launch_argmax_neg(c->stream, st.f, S, g->scal.p + 2, g->d_idx + 1);
     double bv = 0;

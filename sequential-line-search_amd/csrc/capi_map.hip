@@ -24,7 +24,7 @@ using namespace slsk;
 struct sls_nll {
     sls_ctx* ctx = nullptr;
     int D = 0, N = 0, Np = 0, Dp = 0, Dcols = 0, kernel = 0;
-    DBuf X, y, inv_ell, XT, nx, L, Linv, Kinv, alpha, tvec, G, Y, svec, ones, parts, scal, gl, gemv_part, small_in, small_out;
+    DBuf X, y, inv_ell, XT, nx, L, Linv, Kinv, alpha, tvec, G, Y, svec, ones, parts, scal, gl, gemv_part, small_in, small_out, small_info;
     std::vector<double> cached_theta;
     double cached_b = -1.0;
     bool have_factor = false;
@@ -134,6 +134,7 @@ static void nll_small_eval(sls_nll* h, const double* y, const double* theta, dou
     h->small_out.ensure(160);
     args.out = h->small_out.p;
     args.in_dev = nullptr;
+    args.batch = 1; args.in_stride = 0; args.out_stride = 0;
     std::vector<double> in;   // staging for the D > 16 upload: must outlive the stream synchronisation below
     if (D <= NLL_SMALL_MAX_GRAD_D) {
         args.a = theta[0]; args.b = b;
@@ -262,6 +263,77 @@ extern "C" int sls_gp_nll_grad(sls_nll* h, const double* y, const double* x, dou
         grad[0] = gth[0] + log_lognormal_d(a, a_mu, a_s2);                                   // calc_grad :120-124
         grad[1] = gb + log_lognormal_d(b, b_mu, b_s2);
         for (int d = 0; d < D; ++d) grad[2 + d] = gth[1 + d] + log_lognormal_d(x[2 + d], r_mu, r_s2);
+    }
+    SLS_CATCH
+}
+
+// values[k] = GP MAP objective at xs[k] = (a, b, r_1..r_D), k < B, without gradients: what DIRECT asks for per iteration
+// (src/gaussian-process-regressor.cpp:294 runs them one by one).  N <= 128: ONE launch, one workgroup per parameter set;
+// larger problems are evaluated in turn.  A parameter set whose K_y is not positive definite gets -HUGE_VAL.
+extern "C" int sls_gp_nll_batch(sls_nll* h, const double* y, const double* xs, int B, double* values) {
+    SLS_TRY
+    std::unique_lock<std::recursive_mutex> lock_;
+    if (h) {
+        lock_ = std::unique_lock<std::recursive_mutex>(h->ctx->mtx);
+        (void)hipSetDevice(h->ctx->device);
+    }
+    SLS_REQUIRE(h && y && xs && values && B >= 0, "sls_gp_nll_batch: bad argument");
+    const int D = h->D, N = h->N;
+    sls_ctx* c = h->ctx;
+    const double a_mu = std::log(0.5), a_s2 = 0.5, b_mu = std::log(1e-4), b_s2 = 0.5, r_mu = std::log(0.5), r_s2 = 0.5;
+    auto prior = [&](const double* x) {
+        double reg = log_lognormal(x[0], a_mu, a_s2) + log_lognormal(x[1], b_mu, b_s2);
+        for (int d = 0; d < D; ++d) reg += log_lognormal(x[2 + d], r_mu, r_s2);
+        return reg;
+    };
+    if (!nll_small_ok(h, false) || B <= 1) {
+        std::vector<double> theta(D + 1);
+        for (int k = 0; k < B; ++k) {
+            const double* x = xs + (size_t)k * (D + 2);
+            theta[0] = x[0];
+            for (int d = 0; d < D; ++d) theta[1 + d] = x[2 + d];
+            double quad = 0, logdet = 0;
+            try {
+                nll_eval_impl(h, y, theta.data(), x[1], &quad, &logdet, nullptr, nullptr, nullptr);
+                values[k] = -0.5 * quad - 0.5 * logdet - 0.5 * N * std::log(2.0 * M_PI) + prior(x);
+            } catch (const HipFail& f) {
+                if (f.code != SLS_ERR_NOT_SPD) throw;
+                values[k] = -HUGE_VAL;
+            }
+        }
+        return SLS_OK;
+    }
+    const size_t in_stride = 2 + D + N, out_stride = 8;
+    std::vector<double> in((size_t)B * in_stride);
+    for (int k = 0; k < B; ++k) {
+        const double* x = xs + (size_t)k * (D + 2);
+        SLS_REQUIRE(x[0] > 0.0 && x[1] >= 0.0, "sls_gp_nll_batch: signal variance must be positive, noise level >= 0");
+        double* o = in.data() + (size_t)k * in_stride;
+        o[0] = x[0]; o[1] = x[1];
+        for (int d = 0; d < D; ++d) {
+            SLS_REQUIRE(x[2 + d] > 0.0, "length scale %d must be positive", d);
+            o[2 + d] = x[2 + d];
+        }
+        std::memcpy(o + 2 + D, y, sizeof(double) * N);
+    }
+    h->small_in.ensure(in.size());
+    h->small_out.ensure(std::max<size_t>(160, (size_t)B * out_stride));
+    h->small_info.ensure(((size_t)B + 1) / 2 + 1);
+    SLS_HIP(hipMemcpyAsync(h->small_in.p, in.data(), in.size() * 8, hipMemcpyHostToDevice, c->stream));
+    NllSmallArgs args;
+    args.X = h->X.p; args.D = D; args.N = N; args.want_grad = 0;
+    args.info = reinterpret_cast<int*>(h->small_info.p);
+    args.out = h->small_out.p; args.in_dev = h->small_in.p;
+    args.batch = B; args.in_stride = (long)in_stride; args.out_stride = (long)out_stride;
+    args.a = args.b = 0.0;
+    launch_nll_small(c->stream, h->kernel, args);
+    std::vector<double> out((size_t)B * out_stride);
+    SLS_HIP(hipMemcpyAsync(out.data(), h->small_out.p, out.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    SLS_HIP(hipStreamSynchronize(c->stream));
+    h->have_factor = false;
+    for (int k = 0; k < B; ++k) {
+        const double* o = out.data() + (size_t)k * out_stride;
+        values[k] = o[4] != 0.0 ? -HUGE_VAL : -0.5 * o[2] - 0.5 * o[3] - 0.5 * N * std::log(2.0 * M_PI) + prior(xs + (size_t)k * (D + 2));
     }
     SLS_CATCH
 }

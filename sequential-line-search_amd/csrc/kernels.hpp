@@ -68,6 +68,10 @@ struct NllSmallArgs {
     int* info;
     double* out;
     const double* in_dev;
+    // batch > 1: workgroup w evaluates the parameter set in_dev + w * in_stride (in_dev must be set) into out + w * out_stride,
+    // with its own pivot-failure word info[w]
+    int batch;
+    long in_stride, out_stride;
     double a, b;
     double ell[NLL_SMALL_MAX_GRAD_D];
     double y[NLL_SMALL_MAX_N];
@@ -129,7 +133,8 @@ void launch_lbfgs_step(hipStream_t s, const LbfgsState& st, const double* val, c
 // Stable compaction of the starts that are still moving: live_out[0..count) = { n in live_in (or 0..n_in) : !done[n] } in
 // increasing order, count -> *count_out (device); then xc[j + d*ldc] = xt[live_out[j] + d*ld] (padding columns up to the
 // next multiple of 128 are filled with 0.5 so that the tile kernels read finite numbers).
-void launch_compact_live(hipStream_t s, const int* live_in, int n_in, const int* done, int* live_out, int* count_out);
+void launch_compact_live(hipStream_t s, const int* live_in, int n_in, const int* done, int* live_out, int* count_out,
+                         int* block_counts /* (n_in + 1023) / 1024 ints of scratch */);
 void launch_gather_trials(hipStream_t s, const double* xt, long ld, int D, const int* live, const int* count_dev, int n_max,
                           double* xc, long ldc);
 void launch_clamp_starts(hipStream_t s, const double* starts /*D x S col-major*/, int D, int S, double* xt, long ld, int Sp);
@@ -145,6 +150,7 @@ struct WaveArgs {
     int max_backtracks;
     const double *XT, *inv_ell, *Kinv, *alpha, *starts;   // XT [i + d*Np] scaled; starts D x S column-major (raw)
     double *x_out, *f_out;                // x_out[n + d*ld], f_out[n] = -acq at the end point
+    unsigned long long* useful;           // optional: += evaluations of starts that were still moving (the others run idle)
     long ld;
     // evaluation-only mode (n_local == 0): `starts` holds the M query points; any of these may be NULL
     double *ev_mu, *ev_sigma, *ev_dmu, *ev_dsigma, *ev_val, *ev_grad;

@@ -791,34 +791,68 @@ void launch_lbfgs_step(hipStream_t s, const LbfgsState& st, const double* val, c
 
 // One workgroup: thread t owns the contiguous segment [t*per, (t+1)*per) of the input list, counts its survivors, an
 // exclusive scan over the 1024 counts gives its output offset (stable, increasing order).
-__global__ __launch_bounds__(1024) void compact_live_kernel(const int* __restrict__ live_in, int n_in, const int* __restrict__ done,
-                                                            int* __restrict__ live_out, int* __restrict__ count_out) {
-    __shared__ int cnt[1024];
-    const int t = threadIdx.x;
-    const int per = (n_in + 1023) / 1024;
-    const int lo = min(t * per, n_in), hi = min(lo + per, n_in);
+// Stable compaction of the starts still moving, in two small multi-block launches (the single-workgroup form walked 64
+// dependent gathers per thread: 158 us per round at 65 536 starts, 1.3 % of an 8-GPU shard's step): blocks of 1024 entries,
+// (1) live entries per block, (2) every block adds up the counts of the blocks before it (at most 64 words) and scatters its
+// entries behind that offset by an in-block exclusive scan.  Output order = input order, as before (same live lists).
+__device__ __forceinline__ int compact_flags(const int* __restrict__ live_in, int n_in, const int* __restrict__ done, int base, int (&n)[4]) {
     int c = 0;
-    for (int i = lo; i < hi; ++i) {
-        const int n = live_in ? live_in[i] : i;
-        c += done[n] ? 0 : 1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = base + e;
+        n[e] = -1;
+        if (i < n_in) {
+            const int idx = live_in ? live_in[i] : i;
+            if (!done[idx]) { n[e] = idx; ++c; }
+        }
     }
-    cnt[t] = c;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {   // inclusive Hillis-Steele scan
-        const int v = t >= o ? cnt[t - o] : 0;
-        __syncthreads();
-        cnt[t] += v;
-        __syncthreads();
-    }
-    int pos = cnt[t] - c;
-    for (int i = lo; i < hi; ++i) {
-        const int n = live_in ? live_in[i] : i;
-        if (!done[n]) live_out[pos++] = n;
-    }
-    if (t == 1023) count_out[0] = cnt[1023];
+    return c;
 }
-void launch_compact_live(hipStream_t s, const int* live_in, int n_in, const int* done, int* live_out, int* count_out) {
-    hipLaunchKernelGGL(compact_live_kernel, dim3(1), dim3(1024), 0, s, live_in, n_in, done, live_out, count_out);
+__global__ __launch_bounds__(256) void compact_count_kernel(const int* __restrict__ live_in, int n_in, const int* __restrict__ done,
+                                                            int* __restrict__ block_counts) {
+    __shared__ int red[4];
+    int n[4];
+    int c = compact_flags(live_in, n_in, done, blockIdx.x * 1024 + 4 * threadIdx.x, n);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void compact_scatter_kernel(const int* __restrict__ live_in, int n_in, const int* __restrict__ done,
+                                                              const int* __restrict__ block_counts, int* __restrict__ live_out,
+                                                              int* __restrict__ count_out) {
+    __shared__ int wsum[4];
+    __shared__ int boff;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (wave == 0) {                                         // offset of this block = entries of the blocks before it
+        int v = 0;
+        for (int q = lane; q < (int)blockIdx.x; q += 64) v += block_counts[q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) boff = v;
+    }
+    int n[4];
+    const int c = compact_flags(live_in, n_in, done, blockIdx.x * 1024 + 4 * t, n);
+    int incl = c;                                            // inclusive scan inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int pos = boff + incl - c;
+    for (int w = 0; w < wave; ++w) pos += wsum[w];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (n[e] >= 0) live_out[pos++] = n[e];
+    if (blockIdx.x == gridDim.x - 1 && t == 255) count_out[0] = pos;
+}
+void launch_compact_live(hipStream_t s, const int* live_in, int n_in, const int* done, int* live_out, int* count_out, int* block_counts) {
+    const int nb = (n_in + 1023) / 1024;
+    hipLaunchKernelGGL(compact_count_kernel, dim3(nb), dim3(256), 0, s, live_in, n_in, done, block_counts);
+    hipLaunchKernelGGL(compact_scatter_kernel, dim3(nb), dim3(256), 0, s, live_in, n_in, done, block_counts, live_out, count_out);
 }
 
 __global__ __launch_bounds__(256) void gather_trials_kernel(const double* __restrict__ xt, long ld, int D, const int* __restrict__ live,

@@ -39,15 +39,16 @@ __global__ __launch_bounds__(256) void nll_small_kernel(const NllSmallArgs args)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fl = lane & 15, fk = lane >> 4;
     const double* __restrict__ X = args.X;
-    double* __restrict__ out = args.out;
-    int* __restrict__ info = args.info;
+    double* __restrict__ out = args.out + (long)blockIdx.x * args.out_stride;
+    int* __restrict__ info = args.info + blockIdx.x;
+    const double* __restrict__ in_dev = args.in_dev ? args.in_dev + (long)blockIdx.x * args.in_stride : nullptr;
     const int D = args.D, N = args.N, want_grad = args.want_grad;
     const int nb16 = (N + 15) >> 4, Nb = 16 * nb16;
     // hyper-parameters and targets travel in the kernel argument block (no upload); D > 16 falls back to a device buffer
-    const double a = args.in_dev ? args.in_dev[0] : args.a, b = args.in_dev ? args.in_dev[1] : args.b;
-    for (int d = tid; d < D; d += 256) small_scratch(As, 256 + d) = 1.0 / (args.in_dev ? args.in_dev[2 + d] : args.ell[d]);
+    const double a = in_dev ? in_dev[0] : args.a, b = in_dev ? in_dev[1] : args.b;
+    for (int d = tid; d < D; d += 256) small_scratch(As, 256 + d) = 1.0 / (in_dev ? in_dev[2 + d] : args.ell[d]);
     for (int i = tid; i < 128; i += 256)
-        small_scratch(As, 128 + i) = i < N ? (args.in_dev ? args.in_dev[2 + D + i] : args.y[i]) : 0.0;
+        small_scratch(As, 128 + i) = i < N ? (in_dev ? in_dev[2 + D + i] : args.y[i]) : 0.0;
     if (tid == 0) *info = 0;
     __syncthreads();
 
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256) void nll_small_kernel(const NllSmallArgs args)
         if (tid < N)
             for (int j = 0; j < N; ++j) s = fma(As[tid + j * DL], small_scratch(As, 128 + j), s);
         small_scratch(As, tid) = s;
-        if (tid < N) out[SMALL_OUT_ALPHA + tid] = s;
+        if (tid < N && args.batch <= 1) out[SMALL_OUT_ALPHA + tid] = s;   // batch mode: 8 output words per parameter set
     }
     __syncthreads();
     double s1 = 0.0, s2 = 0.0;
@@ -200,9 +201,9 @@ void launch_nll_small(hipStream_t s, int kernel, const NllSmallArgs& args) {
     ensure_dyn_lds((const void*)nll_small_kernel<false>, DIAG_LDS_BYTES);
     ensure_dyn_lds((const void*)nll_small_kernel<true>, DIAG_LDS_BYTES);
     if (kernel == SLS_KERNEL_ARD_MATERN52)
-        hipLaunchKernelGGL(nll_small_kernel<true>, dim3(1), dim3(256), DIAG_LDS_BYTES, s, args);
+        hipLaunchKernelGGL(nll_small_kernel<true>, dim3(args.batch > 1 ? args.batch : 1), dim3(256), DIAG_LDS_BYTES, s, args);
     else
-        hipLaunchKernelGGL(nll_small_kernel<false>, dim3(1), dim3(256), DIAG_LDS_BYTES, s, args);
+        hipLaunchKernelGGL(nll_small_kernel<false>, dim3(args.batch > 1 ? args.batch : 1), dim3(256), DIAG_LDS_BYTES, s, args);
 }
 
 }  // namespace slsk

@@ -191,6 +191,7 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
     double dir0 = 0.0, dir1 = 0.0, t = 1.0;
     int hlen = 0, hpos = 0, nbt = 0;
     bool done = false, need_dir = true;
+    int n_useful = 1;                            // evaluations this start needed (the first one included)
 
     for (int ev = 1; ev < p.n_local; ++ev) {
         if (!done && need_dir) {
@@ -262,6 +263,7 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
         const double xt1 = done ? x1 : clamp01(x1 + t * dir1);
         evaluate(xt0, xt1, val, gr0, gr1);          // every wave evaluates every round (uniform barriers, lock-step count)
         if (!done) {
+            ++n_useful;
             const double ft = -val;
             const double sd0 = has0 ? xt0 - x0 : 0.0, sd1 = has1 ? xt1 - x1 : 0.0;
             const double gs = wave_sum(g0 * sd0 + g1 * sd1);
@@ -294,6 +296,7 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
         if (has0) p.x_out[n + (long)d0 * p.ld] = x0;
         if (has1) p.x_out[n + (long)d1 * p.ld] = x1;
         if (lane == 0) p.f_out[n] = f;
+        if (lane == 0 && p.useful) atomicAdd(p.useful, (unsigned long long)n_useful);
     }
 }
 

@@ -123,14 +123,14 @@ namespace sequential_line_search
 
         // global phase: DIRECT, 300 evaluations on the reference's box [1e-8, 50]^(D+2) in the reference's (linear)
         // parameters (:291-294); DIRECT ignores x_ini.  The prior medians (the reference's x_ini) stay in the race.
+        // the points of one DIRECT iteration are independent: ONE device call (one workgroup per point for N <= 128)
         const optim::BatchObjective batch = [&](const std::vector<std::vector<double>>& xs, std::vector<double>& values) {
             values.resize(xs.size());
+            if (xs.empty()) return;
+            std::vector<double> flat(xs.size() * (D + 2));
             for (size_t k = 0; k < xs.size(); ++k)
-            {
-                std::vector<double> z(xs[k].size());
-                for (size_t i = 0; i < z.size(); ++i) z[i] = std::log(xs[k][i]);
-                values[k] = objective(z, nullptr);
-            }
+                for (int i = 0; i < D + 2; ++i) flat[k * (D + 2) + i] = xs[k][i];
+            device::Check(sls_gp_nll_batch(nll.h, m_y.data(), flat.data(), static_cast<int>(xs.size()), values.data()), "sls_gp_nll_batch");
         };
         const std::vector<double> lin_lower(D + 2, 1e-8), lin_upper(D + 2, 5e+01);
         double                    direct_v = 0.0;

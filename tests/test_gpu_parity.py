@@ -282,11 +282,13 @@ def test_active_set_compaction_is_bit_identical(ctx, oracle, kernel, D, N, S, n_
     for va, vu in zip(a[:-1], u[:-1]):
         assert np.array_equal(np.asarray(va), np.asarray(vu))
     sa, su = a[-1], u[-1]
-    assert su["evals_issued"] == su["evals_cap"] == S * n_local
-    assert sa["evals_cap"] == S * n_local and S <= sa["evals_issued"] <= su["evals_issued"]
+    # evals_issued counts evaluations of starts that were still moving -- also where SLS_COMPACT=0 re-evaluates the finished
+    # ones: the same starts retire in the same round under both schedules
+    assert su["evals_cap"] == sa["evals_cap"] == S * n_local
+    assert S <= sa["evals_issued"] == su["evals_issued"] <= S * n_local
     assert sa["rounds"] <= n_local
     if not pair:
-        assert sa["evals_issued"] < su["evals_issued"]      # the corner starts retire early
+        assert sa["evals_issued"] < S * n_local             # the corner starts retire early
         # same end points as the oracle's all-starts-every-round loop
         ro = oracle.Regressor(X, y, theta, b, kernel=kernel).acq_maximize(starts, n_local, diag=True) if N <= 300 else None
         if ro is not None:
@@ -690,8 +692,13 @@ def test_wave_path_matches_tiled_path_and_oracle(ctx, oracle, kernel, D, N, S, m
     for acq in (0, 1):
         monkeypatch.setenv("SLS_WAVE_PATH", "1")
         rw = gp.acq_maximize(starts, 15, acq, 1.5)
+        sw = gp.last_stats()
         monkeypatch.setenv("SLS_WAVE_PATH", "0")
         rt = gp.acq_maximize(starts, 15, acq, 1.5)
+        st = gp.last_stats()
+        # both paths count the evaluations of starts still moving: equal unless a start took another branch
+        assert 0 < sw["evals_issued"] <= sw["evals_cap"] == S * 15
+        assert abs(sw["evals_issued"] - st["evals_issued"]) <= 2 * 15, (sw, st)
         ro = oracle.Regressor(X, y, theta, b, kernel=kernel).acq_maximize(starts, 15, acq, 1.5, diag=True)
         assert_starts_agree(rw, ro, min_frac=0.9, max_divergent=2, label=f"wave D={D} N={N} S={S} kernel={kernel} acq={acq}")
         assert_starts_agree(rt, ro, min_frac=0.9, max_divergent=2, label=f"tiled D={D} N={N} S={S} kernel={kernel} acq={acq}")
@@ -729,3 +736,29 @@ def test_triangular_prediction_path(ctx, oracle, kernel, D, N, M, grow, monkeypa
         out[flag] = (mu, sg, ei)
     close(out["1"][1], out["0"][1], rtol=1e-8, atol=1e-10)
     gp.close()
+
+
+@pytest.mark.parametrize("D,N", [(1, 12), (8, 90), (32, 128), (6, 300)])
+def test_gp_map_objective_batch_matches_single_evaluations(ctx, oracle, D, N):
+    """sls_gp_nll_batch (the B independent points of one DIRECT iteration of the GP MAP fit in ONE launch, one workgroup per
+    point for N <= 128; src/gaussian-process-regressor.cpp:294 evaluates them one by one): bit for bit the values of B single
+    sls_gp_nll_grad calls; a point whose K_y is not positive definite comes back as -inf instead of failing the batch."""
+    X, y, _, _ = synth_problem(oracle, D, N)
+    rng = np.random.default_rng(D * 1000 + N)
+    B = 37
+    xs = np.exp(rng.uniform(np.log(1e-3), np.log(5.0), (B, D + 2)))
+    xs[:, 1] = np.exp(rng.uniform(np.log(1e-6), np.log(1e-1), B))
+    xs[5] = np.concatenate([[1.0, 1e-300], np.full(D, 50.0)])      # K_y = all-ones + ~0: not positive definite in fp64
+    for kernel in (0, 1):
+        h = sls().Nll(ctx, X, kernel)
+        vb = h.gp_objective_batch(y, xs)
+        for k in range(B):
+            try:
+                v = h.gp_objective(y, xs[k], want_grad=False)
+            except sls().SlsError:
+                v = -np.inf
+            assert (vb[k] == v) or (np.isneginf(vb[k]) and np.isneginf(v)), (kernel, k, vb[k], v)
+        assert np.isneginf(vb[5]) or N == 1
+        vo = np.array([oracle.gp_map_objective(kernel, X, y, xs[k])[0] for k in (0, 1, 2)])
+        np.testing.assert_allclose(vb[:3], vo, rtol=1e-8)
+        h.close()
