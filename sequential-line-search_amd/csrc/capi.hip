@@ -175,12 +175,13 @@ slsk::PotrfAux* sls_ctx::potrf_lookahead(int Np) {
 }
 
 int* sls_ctx::potrf_sync(int Np) {
-    // sync words of the single-launch factorisation live behind the info words; nullptr (multi-launch schedule) if they
-    // would not fit (N > 60 000)
+    // sync words of the single-launch factorisation (barrier form) live behind the info words; nullptr (multi-launch schedule)
+    // if they would not fit: 32 + 3 nb + 2 <= 960, i.e. nb <= 308 (N <= 39 424)
     return (potrf_persistent_ok && 32 + 2 * (Np / 128) + Np / 128 + 2 <= 960) ? d_info + 64 : nullptr;
 }
 
 int* sls_ctx::potrf_df_sync(int Np) {
+    if (!potrf_persistent_ok && potrf_rearm > 0 && --potrf_rearm == 0) potrf_persistent_ok = true;   // once per fit
     if (!potrf_persistent_ok || slsk::potrf_default_mode(Np) != 3) return nullptr;
     potrf_df.ensure((slsk::potrf_dataflow_sync_ints(Np) + 1) / 2);
     return reinterpret_cast<int*>(potrf_df.p);
@@ -193,7 +194,12 @@ bool potrf_gave_up(sls_ctx* c, int abort_flag, int attempt) {
         set_error("Cholesky factorisation aborted: a device-side wait expired");
         throw HipFail{SLS_ERR_HIP};
     }
-    c->potrf_persistent_ok = false;   // this context uses the multi-launch schedule from now on
+    // The single-launch forms need every workgroup resident at once; another kernel on the device (a second context, a
+    // profiler) can prevent that.  This context uses the multi-launch schedule for the next fits and then tries again; the
+    // count is visible through sls_prof_get("potrf_fallbacks").
+    c->potrf_persistent_ok = false;
+    c->potrf_rearm = 16;
+    c->potrf_fallbacks += 1;
     return true;
 }
 }  // namespace slsk
@@ -296,6 +302,11 @@ extern "C" int sls_prof_get(sls_ctx* ctx, const char* name, double* total_ms, lo
     std::unique_lock<std::recursive_mutex> lock_(ctx->mtx);
     (void)hipStreamSynchronize(ctx->stream);
     ctx->prof_collect();
+    if (std::string(name) == "potrf_fallbacks") {          // not a timing: how often a single-launch Cholesky gave up
+        if (total_ms) *total_ms = 0.0;
+        if (launches) *launches = ctx->potrf_fallbacks;
+        return SLS_OK;
+    }
     auto it = ctx->prof.find(name);
     if (total_ms) *total_ms = it == ctx->prof.end() ? 0.0 : it->second.ms;
     if (launches) *launches = it == ctx->prof.end() ? 0 : it->second.launches;

@@ -100,6 +100,8 @@ struct sls_ctx {
     slsk::PotrfAux* potrf_lookahead(int Np);   // nullptr unless SLS_POTRF_LOOKAHEAD selects the two-stream schedule
     int* potrf_sync(int Np);             // device sync words for launch_potrf_persistent (nullptr: multi-launch schedule)
     bool potrf_persistent_ok = true;     // cleared when a persistent factorisation gave up (bounded wait expired)
+    int potrf_rearm = 0;                 // fits left on the multi-launch schedule before the single-launch form is tried again
+    long potrf_fallbacks = 0;            // how often a single-launch factorisation gave up (sls_prof_get("potrf_fallbacks"))
     slsk::DBuf potrf_df;                 // flag tables of the dataflow form (grown on demand)
     int* potrf_df_sync(int Np);          // nullptr: dataflow form switched off for this context
 
