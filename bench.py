@@ -284,7 +284,7 @@ def main():
         achieved = flops_total / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         avg_ms = gemm_ms / max(gemm_launches, 1)
         traffic, traffic_source = None, None
-        for name in ("r02_pmc_acq_gemm.json", "r01_pmc_acq_gemm.json"):
+        for name in ("r03_pmc_acq_gemm.json", "r02_pmc_acq_gemm.json", "r01_pmc_acq_gemm.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc) and (N, D) == (8192, 64):
                 try:
