@@ -264,4 +264,85 @@ __device__ __forceinline__ void chol_diag_steps(double* As, double* Ts, int* __r
     }
 }
 
+// Factor ONLY: the Cholesky factor of the 128 x 128 LDS image (lower tiles of As) and the inverses of its eight 16 x 16 diagonal
+// tiles (Ts); the block inverse is NOT built (no S / T phases).  For callers that solve against L_jj with the small inverses
+// instead of multiplying by T_jj (the dataflow Cholesky's panel tiles), the block inverse leaves the serial chain altogether
+// and is formed afterwards, for all diagonal blocks at once.
+// With the inverse gone waves 1-3 only carry panel and update tiles, and wave 0 can be a pure PIVOT wave: per step it takes
+// the one panel tile it needs itself, L_{kb+1,kb}, applies it to the next diagonal tile straight from its accumulators (the
+// accumulator layout is the MFMA operand layout) and runs on into the next pivot chain -- one workgroup barrier per step on
+// its path instead of two.  Waves 1-3 meet each other and wave 0's tile on an LDS counter (s_barrier would need wave 0).
+// (The same restructuring WITH the inverse phases gained nothing: waves 1-3 were then the longer path, see diag16.)
+// Same operations per element as chol_diag_steps<true>: L and the 16 x 16 inverses have the same bits.
+__device__ __forceinline__ void chol_factor_steps(double* As, double* Ts, int* __restrict__ info, int global_off) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fl = lane & 15, fk = lane >> 4;
+    constexpr int nb16 = 8;
+    // arrival counter in the padding rows of the last LDS column (rows 128 .. 143 of a column are never part of the matrix)
+    int* sync_word = reinterpret_cast<int*>(As + 127 * DL + 128);
+    if (tid == 0) *sync_word = 0;                    // visible to everybody behind the first step's barrier
+    for (int kb = 0; kb < nb16; ++kb) {
+        const int c0 = 16 * kb;
+        if (wave == 0) diag16<true>(As, Ts + 256 * kb, c0, lane, info, global_off);
+        __syncthreads();                              // T16(kb), L16(kb) visible; waves 1-3 have finished the update of step kb - 1
+        if (kb == nb16 - 1) break;
+        const double* Tk = Ts + 256 * kb;
+        auto panel_tile = [&](int r) {                // L_r = A_r T16^T, in place
+            d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int k = 4 * kk + fk;
+                const double af = As[(c0 + k) * DL + 16 * r + fl];   // A_r[m = fl][k]
+                const double bf = Tk[fl + 16 * k];                    // T[n = fl][k]
+                acc = mfma16(bf, af, acc);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) As[(c0 + fk + 4 * q) * DL + 16 * r + fl] = acc[q];
+            return acc;
+        };
+        if (wave == 0) {
+            const d4_t p = panel_tile(kb + 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the tile is in LDS
+            if (lane == 0) __hip_atomic_fetch_add(sync_word, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int d = kb + 1;
+            d4_t acc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = As[(16 * d + fk + 4 * q) * DL + 16 * d + fl];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc = mfma16(p[kk], -p[kk], acc);   // bf = L[n = fl][k], af = -L[m = fl][k]: both p[kk]
+#pragma unroll
+            for (int q = 0; q < 4; ++q) As[(16 * d + fk + 4 * q) * DL + 16 * d + fl] = acc[q];
+        } else {
+            for (int r = kb + 1 + wave; r < nb16; r += 3) panel_tile(r);       // rows kb + 2 .. 7
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(sync_word, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            while (__hip_atomic_load(sync_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * (kb + 1)) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            // trailing update A_ij -= L_i L_j^T, 7 >= i >= j > kb, tiles in column-major order after the first (wave 0's)
+            int i = kb + 1, j = kb + 1;
+            auto advance = [&](int n) {
+                for (; n > 0; --n) {
+                    if (++i == nb16) { ++j; i = j; }
+                }
+            };
+            advance(wave);
+            while (j < nb16) {
+                d4_t acc;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = As[(16 * j + fk + 4 * q) * DL + 16 * i + fl];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int k = c0 + 4 * kk + fk;
+                    const double af = -As[k * DL + 16 * i + fl];
+                    const double bf = As[k * DL + 16 * j + fl];
+                    acc = mfma16(bf, af, acc);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) As[(16 * j + fk + 4 * q) * DL + 16 * i + fl] = acc[q];
+                advance(3);
+            }
+        }
+    }
+}
+
 }  // namespace slsk

@@ -330,6 +330,7 @@ struct PersistArgs {
     int acq;            // dataflow form: 1 agent-scope acquire before every task, 0 compiler-level ordering only (probes)
     int idle_sleep;     // dataflow form: s_sleep argument of an idle scheduling round
     int fuse;           // dataflow form: 1 the chain keeps its tiles in LDS between products (default), 0 through global memory
+    int trsm;           // dataflow form: 1 panel tiles by triangular solves, block inverses formed after the factorisation
 };
 constexpr int PK_FLAGS = 32;
 #define PK_STAMP(slot) do { if (a.trace && threadIdx.x == 0) a.trace[16 * j + (slot)] = wall_clock64(); } while (0)
@@ -763,6 +764,112 @@ __global__ __launch_bounds__(256) void potrf_persistent_kernel(PersistArgs a) {
     }
 }
 
+// ---- panel tiles as triangular solves (dataflow form, SLS_POTRF_DTRSM=1) ------------------------------------
+// X = A L^-T for a 128 x 128 tile A and the lower-triangular diagonal block L = L_jj, by 16-column blocks:
+//     X_s = (A_s - sum_{k<s} X_k L_sk^T) T16_s^T ,   T16_s = (L_ss)^-1 (the eight 16 x 16 inverses diag16 produces anyway).
+// Right-looking over the SAME slab stream as chain_gemm<true> (slab s = columns 16 s .. 16 s + 15 of A and of L, both
+// M-contiguous, LDS-direct loads, ring of four slab pairs): when slab s lands, X_s = (A_s - S_s) T16_s^T closes block s and every
+// later block receives S_c += X_s L_cs^T.  288 MFMAs per wave -- the count of the product with the full inverse T_jj restricted
+// to its non-zero blocks -- but the 128 x 128 inverse itself is no longer needed by any panel tile: the chain stops building it
+// (no S / T phases in the diagonal block, no transposes, no 128 KB store per step); launch_diag_inverse forms all T_jj after
+// the factorisation, in parallel.  Wave w owns the 16-row blocks w and 7 - w; V[a][c] holds S_c until step c and X_c afterwards.
+template <class T16>
+__device__ __forceinline__ void chain_trsm(ChainAcc& V, const double* __restrict__ A, long lda, const double* __restrict__ L, long ldl,
+                                           T16&& t16, double* lds) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fl = lane & 15, fk = lane >> 4;
+    const int mi[2] = {wave, 7 - wave};
+    constexpr int SLAB = GEMM_LDS_TILE;
+    auto issue = [&](int s) {                            // wave w brings k-rows 4w .. 4w+3 of slab s
+        double* base = lds + (s & 3) * 2 * SLAB;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * wave + r;
+            slab_row_to_lds(A + 2 * lane + (long)(16 * s + row) * lda, base + row * GEMM_LDS_MC_LD);
+            slab_row_to_lds(L + 2 * lane + (long)(16 * s + row) * ldl, base + SLAB + row * GEMM_LDS_MC_LD);
+        }
+    };
+    V.zero();
+    issue(0); issue(1); issue(2);
+    auto step = [&](auto S) {
+        constexpr int s = decltype(S)::value;
+        chain_wait_barrier<8 * (s <= 5 ? 2 : 7 - s)>();  // every wave's part of slab s is in LDS; slab s-1 is no longer read
+        if (s + 3 < 8) issue(s + 3);                     // into the buffer of slab s - 1
+        const double* la = lds + (s & 3) * 2 * SLAB;     // A[:, 16 s ..]: element (m, kk) at la[kk * LD + m]
+        const double* lb = la + SLAB;                    // L[:, 16 s ..]
+        double tf[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) tf[kk] = t16(s, fl, 4 * kk + fk);   // T16_s[n = fl][k] (LDS in both users)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            d4_t r;                                       // A_s - S_s in the accumulator layout (m = fl, n = fk + 4 q)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r[q] = la[(fk + 4 * q) * GEMM_LDS_MC_LD + 16 * mi[a] + fl] - V.v[a][s][q];
+            d4_t x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) x = __builtin_amdgcn_mfma_f64_16x16x4f64(tf[kk], r[kk], x, 0, 0, 0);   // r as the A fragment: (m = fl, k = fk + 4 kk)
+            V.v[a][s] = x;
+#pragma unroll
+            for (int c = s + 1; c < 8; ++c) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const double bf = lb[(fk + 4 * kk) * GEMM_LDS_MC_LD + 16 * c + fl];   // L[16 c + n][16 s + k]
+                    V.v[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf, x[kk], V.v[a][c], 0, 0, 0);
+                }
+            }
+        }
+    };
+    step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
+    step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+    step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
+    __syncthreads();                                     // LDS free for the next user
+}
+
+// Diagonal block of the TRSM form: factor only (chol_factor_steps), L stored write-through, and the eight 16 x 16 inverses
+// into the diagonal tiles of Tout (= their final place inside T_jj; the rest of T_jj comes from launch_diag_inverse).
+template <bool LOAD>
+__device__ __forceinline__ void diag_block_factor(double* __restrict__ A, long lda, double* __restrict__ Tout, long ldt,
+                                                  int* __restrict__ info, int global_off, char* smem) {
+    double* As = reinterpret_cast<double*>(smem);
+    double* Ts = As + 128 * DL;
+    const int tid = threadIdx.x;
+    if (LOAD) {
+        const int i2 = 2 * (tid & 63), jc = tid >> 6;
+#pragma unroll 8
+        for (int p = 0; p < 32; ++p) {
+            const int j = 4 * p + jc;
+            d2_t v = *reinterpret_cast<const d2_t*>(A + (long)i2 + (long)j * lda);
+            if ((i2 >> 4) < (j >> 4)) v = d2_t{0.0, 0.0};
+            *reinterpret_cast<d2_t*>(As + i2 + j * DL) = v;
+        }
+        __syncthreads();
+    }
+    chol_factor_steps(As, Ts, info, global_off);
+    __syncthreads();
+    auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(A, 0, 0x7fffffff, 0x00020000);
+    auto rsrcT = __builtin_amdgcn_make_buffer_rsrc(Tout, 0, 0x7fffffff, 0x00020000);
+    {
+        const int i2 = 2 * (tid & 63), jc = tid >> 6;
+#pragma unroll 8
+        for (int p = 0; p < 32; ++p) {
+            const int j = 4 * p + jc;
+            d2_t v = *reinterpret_cast<const d2_t*>(As + i2 + j * DL);
+            if (i2 < j) v[0] = 0.0;
+            if (i2 + 1 < j) v[1] = 0.0;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rsrcA, (int)((i2 + (long)j * lda) * 8), 0, 16);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {                        // 8 tiles x 16 columns x 8 row pairs = 1024 16-byte stores
+        const int idx = tid + 256 * p;
+        const int t = idx >> 7, c = (idx >> 3) & 15, r2 = 2 * (idx & 7);
+        const d2_t v = *reinterpret_cast<const d2_t*>(Ts + 256 * t + r2 + 16 * c);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rsrcT, (int)(((16 * t + r2) + (long)(16 * t + c) * ldt) * 8), 0, 16);
+    }
+}
+
 // ---- the dataflow chain's products with their results kept in LDS ----------------------------------------
 // ChainAcc (wave w: 16-row blocks w and 7 - w) -> image img[m + n DL]: the layout of diag_block's As, and of eight
 // consecutive operand slabs [16][DL] when the image is read as an operand with k = n.
@@ -900,7 +1007,10 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
         // LDS image -> global (write-through, coalesced) and is the LDS-resident operand of the next product; A_{j+1,j+1} -
         // L L^T is formed in place in the image, which is diag_block's input.  (The barrier form stores and re-loads both
         // tiles through global memory with 8-byte accesses 64 KB apart: 34 us per step for 15 us of MFMA work.)
-        if (a.fuse == 0) {
+        if (a.trsm) {
+            diag_block_factor<true>(a.A, ld, a.Linv, ld, a.info, 0, smem);
+            df_publish_store(factored + 0);
+        } else if (a.fuse == 0) {
             diag_block<true>(a.A, ld, a.Linv, ld, a.info, 0, smem);
             pk_signal(factored + 0);
         } else {
@@ -941,8 +1051,13 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             }
             {
                 ChainAcc ca;
-                ca.zero();
-                chain_gemm<true>(ca, Asub, ld, Tjj, ld, lds);                         // L_{j+1,j} = A_{j+1,j} T_jj^T (ends with a barrier)
+                if (a.trsm) {
+                    const double* Ts = lds + 128 * DL;                                // the 16 x 16 inverses of block j, still in LDS
+                    chain_trsm(ca, Asub, ld, Ajj, ld, [&](int s, int n, int k) { return Ts[256 * s + n + 16 * k]; }, lds);
+                } else {
+                    ca.zero();
+                    chain_gemm<true>(ca, Asub, ld, Tjj, ld, lds);                     // L_{j+1,j} = A_{j+1,j} T_jj^T (ends with a barrier)
+                }
                 chain_acc_to_image<true>(ca, lds);
             }
             lds_barrier();
@@ -960,15 +1075,20 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             chain_image_rsub(Anext, ld, lds);                                         // image = A_{j+1,j+1} - L L^T, zero above
             __syncthreads();
             PK_STAMP(3);
-            diag_block<true, false, true>(Anext, ld, Tjj + (long)NB * (ld + 1), ld, a.info, (j + 1) * NB, smem);
+            if (a.trsm) {
+                diag_block_factor<false>(Anext, ld, Tjj + (long)NB * (ld + 1), ld, a.info, (j + 1) * NB, smem);
+            } else {
+                diag_block<true, false, true>(Anext, ld, Tjj + (long)NB * (ld + 1), ld, a.info, (j + 1) * NB, smem);
+            }
             df_publish_store(factored + j + 1);
             PK_STAMP(4);
         }
         return;
     }
     // ---- the workers ----
-    int* st = reinterpret_cast<int*>(smem + 128 * DL * 8);     // scheduler state behind the tile image of tile_commit
-    int* t_i = st, *t_k = st + DF_MAXT, *t_done = st + 2 * DF_MAXT, *t_fin = st + 3 * DF_MAXT, *ready = st + 4 * DF_MAXT, *hdr = st + 4 * DF_MAXT + DF_WIN;
+    // scheduler state in the padding rows of the LDS image (rows 128 .. 143 of column k: 32 ints that no tile image, operand slab
+    // or staging buffer ever touches): word `arr` of column k.  The 16 KB behind the image hold the diagonal block's 16 x 16 inverses.
+    auto SW = [&](int arr, int k) -> int& { return reinterpret_cast<int*>(lds + k * DL + 128)[arr]; };
     const int tid = threadIdx.x;
     if (tid == 0) {
         // worker index, XCD by XCD
@@ -990,7 +1110,7 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
                 const long tt = t + 1;                       // skip (0, 0)
                 while (k < nb && tt >= off + (nb - k)) { off += nb - k; ++k; }
                 if (k >= nb) break;
-                t_i[nt] = k + (int)(tt - off); t_k[nt] = k; t_done[nt] = 0; t_fin[nt] = 0;
+                SW(0, nt) = k + (int)(tt - off); SW(1, nt) = k; SW(2, nt) = 0; SW(3, nt) = 0;
                 ++nt;
             }
         } else if (ok && widx < PR * PC) {
@@ -998,14 +1118,14 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             for (int k = c; k < nb; k += PC)
                 for (int i = k + ((r - k % PR) + PR) % PR; i < nb; i += PR) {
                     if (i == 0 || nt >= DF_MAXT) continue;   // tile (0, 0) is the chain's from the start
-                    t_i[nt] = i; t_k[nt] = k; t_done[nt] = 0; t_fin[nt] = 0;
+                    SW(0, nt) = i; SW(1, nt) = k; SW(2, nt) = 0; SW(3, nt) = 0;
                     ++nt;
                 }
         }
-        hdr[0] = ok ? nt : -1;
+        SW(5, 0) = ok ? nt : -1;
     }
     __syncthreads();
-    const int nt = hdr[0];
+    const int nt = SW(5, 0);
     if (nt <= 0) return;
     int first = 0;
     long long t_progress = wall_clock64();
@@ -1013,17 +1133,17 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
     // optional statistics (probes): ticks of the 100 MHz clock in tasks / in scheduling rounds that found work / idle, task counts
     long long st_task = 0, st_idle = 0, st_t0 = t_progress, st_n_upd = 0, st_n_panel = 0, st_rounds = 0, st_gemm = 0, st_rmw = 0;
     for (;;) {
-        while (first < nt && t_fin[first]) ++first;            // uniform: every thread reads the same LDS words
+        while (first < nt && SW(3, first)) ++first;            // uniform: every thread reads the same LDS words
         if (first >= nt) break;
         const long long st_round0 = a.trace ? wall_clock64() : 0;
         ++st_rounds;
         // ---- which tasks have their inputs? 16 lanes per tile, one flag per lane ----
         {
             const int t = first + slot;
-            bool valid = t < nt && !t_fin[t];
+            bool valid = t < nt && !SW(3, t);
             bool ok = true;
             if (valid) {
-                const int i = t_i[t], k = t_k[t], d = t_done[t];
+                const int i = SW(0, t), k = SW(1, t), d = SW(2, t);
                 const int target = i == k ? k - 1 : k;         // steps the owner applies (the chain applies step k-1 to (k, k))
                 if (d < target) {
                     const int j0 = d;
@@ -1036,13 +1156,13 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             }
             const unsigned long long m = __ballot(ok);
             const unsigned grp = (unsigned)(m >> (16 * ((tid >> 4) & 3))) & 0xffffu;
-            if (l == 0) ready[slot] = (valid && grp == 0xffffu) ? 1 : 0;
+            if (l == 0) SW(4, slot) = (valid && grp == 0xffffu) ? 1 : 0;
         }
         __syncthreads();
         int sel = -1;
 #pragma unroll
         for (int q = DF_WIN - 1; q >= 0; --q)
-            if (ready[q]) sel = q;
+            if (SW(4, q)) sel = q;
         __syncthreads();
         if (sel < 0) {
             if (__hip_atomic_load(a.info + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
@@ -1064,7 +1184,7 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
         __syncthreads();
         const long long st_task0 = a.trace ? wall_clock64() : 0;
         const int t = first + sel;
-        const int i = t_i[t], k = t_k[t], d = t_done[t];
+        const int i = SW(0, t), k = SW(1, t), d = SW(2, t);
         const int target = i == k ? k - 1 : k;
         double* Cik = a.A + (long)i * NB + (long)k * NB * ld;
         if (d < target) {
@@ -1086,23 +1206,39 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
                 __syncthreads();
             }
             if (tid == 0) {
-                t_done[t] = j1;
-                if (to_chain) t_fin[t] = 1;
+                SW(2, t) = j1;
+                if (to_chain) SW(3, t) = 1;
             }
             ++st_n_upd;
         } else if (i > k + 1) {
             ++st_n_panel;
-            Acc acc;
-            acc.zero();
-            gemm_tile_deep(acc, Cik, ld, a.Linv + (long)k * NB * (ld + 1), ld, NB, lds);
-            tile_commit<false, true>(Cik, ld, acc, lds);
+            if (a.trsm) {
+                const double* Lkk = a.A + (long)k * NB * (ld + 1);
+                const double* Tkk = a.Linv + (long)k * NB * (ld + 1);              // its diagonal 16 x 16 tiles hold the small inverses
+                double* Ts = lds + 128 * DL;                                       // the eight small inverses -> LDS (16 KB)
+                for (int q = tid; q < 1024; q += 256) {
+                    const int t16i = q >> 7, c = (q >> 3) & 15, r2 = 2 * (q & 7);
+                    *reinterpret_cast<d2_t*>(Ts + 256 * t16i + r2 + 16 * c) = *reinterpret_cast<const d2_t*>(Tkk + (16 * t16i + r2) + (long)(16 * t16i + c) * ld);
+                }
+                __syncthreads();
+                ChainAcc ca;
+                chain_trsm(ca, Cik, ld, Lkk, ld, [&](int s, int n, int kq) { return Ts[256 * s + n + 16 * kq]; }, lds);
+                chain_acc_to_image<true>(ca, lds);
+                lds_barrier();
+                chain_image_store_wt(Cik, ld, lds);
+            } else {
+                Acc acc;
+                acc.zero();
+                gemm_tile_deep(acc, Cik, ld, a.Linv + (long)k * NB * (ld + 1), ld, NB, lds);
+                tile_commit<false, true>(Cik, ld, acc, lds);
+            }
             df_publish_store(panel_done + i + (long)k * nb);
-            if (tid == 0) t_fin[t] = 1;
+            if (tid == 0) SW(3, t) = 1;
         } else {
             // no update to apply at all: tiles (1, 0) and (1, 1)
             if (tid == 0) {
                 __hip_atomic_fetch_add(chain_ready + (i == k ? k - 1 : k), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                t_fin[t] = 1;
+                SW(3, t) = 1;
             }
         }
         __syncthreads();
@@ -1156,7 +1292,7 @@ void launch_potrf_persistent(hipStream_t s, double* A, int Np, double* Linv, int
     a.timeout = 20000000LL;   // 0.2 s of the 100 MHz wall clock
     a.trace = trace;
     a.nbo = potrf_persistent_nbo(Np);
-    a.j0 = 0; a.j1 = nb; a.k0 = 0; a.ext_flag = nullptr; a.pr = 1; a.map = 0; a.near = 0; a.acq = 1; a.idle_sleep = 16; a.fuse = 0;
+    a.j0 = 0; a.j1 = nb; a.k0 = 0; a.ext_flag = nullptr; a.pr = 1; a.map = 0; a.near = 0; a.acq = 1; a.idle_sleep = 16; a.fuse = 0; a.trsm = 0;
     hipLaunchKernelGGL(potrf_persistent_kernel, dim3(G), dim3(256), DIAG_LDS_BYTES, s, a);
 }
 
@@ -1203,7 +1339,9 @@ bool launch_potrf_dataflow(hipStream_t s, double* A, int Np, double* Linv, int* 
     a.acq = envi("SLS_POTRF_DACQ", 1);
     a.idle_sleep = envi("SLS_POTRF_DSLEEP", 16);
     a.fuse = envi("SLS_POTRF_DFUSE", 1);
+    a.trsm = envi("SLS_POTRF_DTRSM", 1) && a.fuse;
     hipLaunchKernelGGL(potrf_dataflow_kernel, dim3(G), dim3(256), DIAG_LDS_BYTES, s, a);
+    if (a.trsm) launch_diag_inverse(s, A, Np, Linv);     // T_jj for every diagonal block, off the factorisation's serial chain
     return true;
 }
 
@@ -1289,7 +1427,7 @@ void launch_potrf_hybrid(hipStream_t s, double* A, int Np, double* Linv, int* in
         a.j0 = b0; a.j1 = b1;                 // b1 == nb: last block, runs to the end
         a.k0 = B > 0 ? b0 - nbo : b0;
         a.ext_flag = (B > 0 && b1 - b0 > 1) ? flags + B : nullptr;
-        a.pr = 1; a.map = 0; a.near = 0; a.acq = 1; a.idle_sleep = 16; a.fuse = 0;
+        a.pr = 1; a.map = 0; a.near = 0; a.acq = 1; a.idle_sleep = 16; a.fuse = 0; a.trsm = 0;
         const int work = nb - b0;             // panel tiles of the first step (+ chain)
         const int G = std::max(2, std::min(64, 1 + work));
         hipLaunchKernelGGL(potrf_persistent_kernel, dim3(G), dim3(256), DIAG_LDS_BYTES, s, a);
@@ -1384,15 +1522,14 @@ void launch_potrf(hipStream_t s, double* A, int Np, double* Linv, int* info, int
     }
 }
 
+__global__ __launch_bounds__(256) void diag_inverse_batched_kernel(const double* __restrict__ L, long ld, double* __restrict__ Linv) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const long off = (long)blockIdx.x * NB * (ld + 1);
+    diag_block<false>(const_cast<double*>(L) + off, ld, Linv + off, ld, nullptr, 0, smem);   // FACTOR = false never writes A
+}
 void launch_diag_inverse(hipStream_t s, const double* L, int Np, double* Linv) {
-    diag_attr();
-    const int nb = Np / NB;
-    const long ld = Np;
-    for (int j = 0; j < nb; ++j) {
-        // FACTOR = false never writes A
-        hipLaunchKernelGGL(chol_diag_kernel<false>, dim3(1), dim3(256), DIAG_LDS_BYTES, s,
-                           const_cast<double*>(L) + (long)j * NB * (ld + 1), ld, Linv + (long)j * NB * (ld + 1), ld, nullptr, 0);
-    }
+    ensure_dyn_lds((const void*)diag_inverse_batched_kernel, DIAG_LDS_BYTES);
+    hipLaunchKernelGGL(diag_inverse_batched_kernel, dim3(Np / NB), dim3(256), DIAG_LDS_BYTES, s, L, (long)Np, Linv);
 }
 
 // dst block = (src block)^T for `batches` blocks of tr x tc 32 x 32 sub-tiles each (through a padded LDS tile: both sides

@@ -2,6 +2,8 @@
 
 Tolerance: BASELINE.json's north_star asks for 1e-6 relative in fp64; the assertions below use 1e-6 or tighter
 (absolute floors only where the quantity itself underflows / cancels to ~0)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -83,10 +85,14 @@ def test_potrf_schedules_agree(N, monkeypatch):
                       ("persist1", {"SLS_POTRF_MODE": "1", "SLS_POTRF_PNBO": "1"}),
                       ("persist4", {"SLS_POTRF_MODE": "1", "SLS_POTRF_PNBO": "4"}),
                       ("hybrid2", {"SLS_POTRF_MODE": "2", "SLS_POTRF_HNBO": "2", "SLS_POTRF_LOOKAHEAD": "8"}),
-                      ("dataflow1", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "1", "SLS_POTRF_DMAP": "1"}),
-                      ("dataflow1cyc", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "1", "SLS_POTRF_DMAP": "0"}),
+                      ("dataflow1", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "1", "SLS_POTRF_DMAP": "1", "SLS_POTRF_DTRSM": "0"}),
+                      ("dataflow1cyc", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "1", "SLS_POTRF_DMAP": "0", "SLS_POTRF_DTRSM": "0"}),
+                      ("dataflow1unfused", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "1", "SLS_POTRF_DFUSE": "0"}),
+                      ("dataflow1trsm", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "1", "SLS_POTRF_DTRSM": "1"}),
                       ("dataflow2", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "2", "SLS_POTRF_DMAP": "1"}),
                       ("dataflow4near", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "4", "SLS_POTRF_DNEAR": "2", "SLS_POTRF_DMAP": "0"})):
+        for k in [k for k in os.environ if k.startswith("SLS_POTRF_")]:
+            monkeypatch.delenv(k)      # every variant starts from the defaults
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         c = sls().Context(0)          # a fresh context: the look-ahead side stream is created per context
@@ -101,6 +107,9 @@ def test_potrf_schedules_agree(N, monkeypatch):
     assert np.array_equal(res["multi"], res["persist1"])
     assert np.array_equal(res["multi"], res["dataflow1"])         # per-tile ownership changes who computes, not what
     assert np.array_equal(res["multi"], res["dataflow1cyc"])
+    assert np.array_equal(res["multi"], res["dataflow1unfused"])
+    # default form: panel tiles by triangular solves against L_jj (16 x 16 inverses) instead of products with T_jj: rounding
+    close(res["dataflow1trsm"], res["multi"], rtol=1e-12, atol=1e-13)
     close(res["dataflow2"], res["multi"], rtol=1e-12, atol=1e-13)
     close(res["dataflow4near"], res["multi"], rtol=1e-12, atol=1e-13)
     assert np.array_equal(res["multi2"], res["multi2look"])        # the side stream changes the schedule, not the arithmetic
