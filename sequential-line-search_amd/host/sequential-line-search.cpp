@@ -2,6 +2,9 @@
 #include <sequential-line-search/acquisition-function.hpp>
 #include <sequential-line-search/preference-data-manager.hpp>
 #include <sequential-line-search/preference-regressor.hpp>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <sequential-line-search/sequential-line-search.hpp>
 #include <sequential-line-search/slider.hpp>
 #include <sequential-line-search/utils.hpp>
@@ -79,16 +82,23 @@ namespace sequential_line_search
 
         m_data->AddNewPoints(x_chosen, {x_prev_max, x_prev_ei}, true);
 
+        const bool timing = std::getenv("SLS_HOST_TIMING") != nullptr;   // stderr: ms in the MAP fit / in the acquisition maximiser
+        const auto t0     = std::chrono::steady_clock::now();
         m_regressor = std::make_shared<PreferenceRegressor>(m_data->GetX(), m_data->GetD(), m_use_map_hyperparams, m_kernel_signal_var,
                                                             m_kernel_length_scale, m_noise_level, m_kernel_hyperparams_prior_var,
                                                             m_btl_scale, num_map_estimation_iters, m_kernel_type);
 
+        const auto     t1     = std::chrono::steady_clock::now();
         const VectorXd x_plus = (m_current_best_selection_strategy == CurrentBestSelectionStrategy::LargestExpectValue)
                                     ? m_regressor->FindArgMax()
                                     : x_chosen;
         const VectorXd x_acquisition =
             acquisition_func::FindNextPoint(*m_regressor, num_global_search_iters, num_local_search_iters, m_acquisition_func_type,
                                             m_gaussian_process_upper_confidence_bound_hyperparam);
+        if (timing)
+            std::fprintf(stderr, "SubmitFeedbackData: N %d  MAP fit %.2f ms  next point %.2f ms\n", (int)m_data->GetX().cols(),
+                         std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
 
         m_slider = std::make_shared<Slider>(x_plus, x_acquisition, m_use_slider_enlargement);
     }
