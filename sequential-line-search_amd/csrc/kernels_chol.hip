@@ -1299,9 +1299,10 @@ void launch_potrf_persistent(hipStream_t s, double* A, int Np, double* Linv, int
 int potrf_dataflow_nbo(int Np) {
     const char* e = getenv("SLS_POTRF_DNBO");
     if (e && atoi(e) >= 1) return std::min(8, atoi(e));
-    // measured (tools/probes/potrf_bench, ms at N = 8192): nbo 1: 7.1, 2: 5.0, 4: 5.5 (5.25 with near = 3), 8: 5.75; at 4096
-    // nbo 1 and 2 tie (2.28): below 8192 the chain is the limit and single steps keep the multi-launch schedule's bits
-    return Np >= 8192 ? 2 : 1;
+    // measured (tools/probes/df_scan2.sh, TRSM chain; ms): N = 8192: nbo 2: 4.31, 3: 4.83, 4: 5.15 (4.36 with near = 4), 8 + near 4:
+    // 4.71; N = 16384 (the workers are the limit: fewer read-modify-write passes win): 2: 26.1, 4: 24.0, 8 + near 3: 23.6 (62
+    // TFLOP/s = 0.79 of peak); N = 4096: 1: 1.69, 2: 1.83
+    return Np >= 16384 ? 8 : Np >= 8192 ? 2 : 1;
 }
 // ints of device scratch the dataflow form needs (0: the matrix is too large for its tables)
 size_t potrf_dataflow_sync_ints(int Np) {
@@ -1335,7 +1336,7 @@ bool launch_potrf_dataflow(hipStream_t s, double* A, int Np, double* Linv, int* 
     a.j0 = 0; a.j1 = nb; a.k0 = 0; a.ext_flag = nullptr;
     a.pr = PR;
     a.map = map;
-    a.near = envi("SLS_POTRF_DNEAR", 0);
+    a.near = envi("SLS_POTRF_DNEAR", Np >= 16384 ? 3 : 0);
     a.acq = envi("SLS_POTRF_DACQ", 1);
     a.idle_sleep = envi("SLS_POTRF_DSLEEP", 16);
     a.fuse = envi("SLS_POTRF_DFUSE", 1);
