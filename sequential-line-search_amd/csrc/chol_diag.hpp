@@ -274,7 +274,15 @@ __device__ __forceinline__ void chol_diag_steps(double* As, double* Ts, int* __r
 // its path instead of two.  Waves 1-3 meet each other and wave 0's tile on an LDS counter (s_barrier would need wave 0).
 // (The same restructuring WITH the inverse phases gained nothing: waves 1-3 were then the longer path, see diag16.)
 // Same operations per element as chol_diag_steps<true>: L and the 16 x 16 inverses have the same bits.
-__device__ __forceinline__ void chol_factor_steps(double* As, double* Ts, int* __restrict__ info, int global_off) {
+// publish(s): optional hook run by waves 1-3 (uniformly, 192 threads) as soon as column block s of L and T16_s are final --
+// right behind the panel tiles of step s (the two-workgroup chain of the dataflow Cholesky streams them to the workgroup that
+// solves the next panel tile while this one is still factoring); the last block (s = 7) is published behind the last barrier.
+struct NoPublish {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+template <class Publish = NoPublish>
+__device__ __forceinline__ void chol_factor_steps(double* As, double* Ts, int* __restrict__ info, int global_off,
+                                                  Publish&& publish = NoPublish{}) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fl = lane & 15, fk = lane >> 4;
     constexpr int nb16 = 8;
@@ -285,7 +293,10 @@ __device__ __forceinline__ void chol_factor_steps(double* As, double* Ts, int* _
         const int c0 = 16 * kb;
         if (wave == 0) diag16<true>(As, Ts + 256 * kb, c0, lane, info, global_off);
         __syncthreads();                              // T16(kb), L16(kb) visible; waves 1-3 have finished the update of step kb - 1
-        if (kb == nb16 - 1) break;
+        if (kb == nb16 - 1) {
+            if (wave != 0) publish(kb);
+            break;
+        }
         const double* Tk = Ts + 256 * kb;
         auto panel_tile = [&](int r) {                // L_r = A_r T16^T, in place
             d4_t acc = {0.0, 0.0, 0.0, 0.0};
@@ -318,6 +329,7 @@ __device__ __forceinline__ void chol_factor_steps(double* As, double* Ts, int* _
             if (lane == 0) __hip_atomic_fetch_add(sync_word, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             while (__hip_atomic_load(sync_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * (kb + 1)) __builtin_amdgcn_s_sleep(1);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            publish(kb);                                  // column block kb of L is final
             // trailing update A_ij -= L_i L_j^T, 7 >= i >= j > kb, tiles in column-major order after the first (wave 0's)
             int i = kb + 1, j = kb + 1;
             auto advance = [&](int n) {

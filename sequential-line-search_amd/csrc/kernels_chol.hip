@@ -331,6 +331,7 @@ struct PersistArgs {
     int idle_sleep;     // dataflow form: s_sleep argument of an idle scheduling round
     int fuse;           // dataflow form: 1 the chain keeps its tiles in LDS between products (default), 0 through global memory
     int trsm;           // dataflow form: 1 panel tiles by triangular solves, block inverses formed after the factorisation
+    int chain2;         // dataflow form: 1 two chain workgroups (factor / follow with the solve), needs trsm
 };
 constexpr int PK_FLAGS = 32;
 #define PK_STAMP(slot) do { if (a.trace && threadIdx.x == 0) a.trace[16 * j + (slot)] = wall_clock64(); } while (0)
@@ -870,6 +871,128 @@ __device__ __forceinline__ void diag_block_factor(double* __restrict__ A, long l
     }
 }
 
+// ---- two-workgroup chain (SLS_POTRF_DCHAIN2=1) ---------------------------------------------------------------
+// With one chain workgroup a step is  solve (14 us) -> L L^T + next diagonal tile (14 us) -> diagonal block (22 us), strictly in
+// sequence on one CU.  The solve X = A L_jj^-T consumes L_jj column block by column block (chain_trsm), and column block s of
+// L_jj is final as soon as step s of the diagonal block's factorisation has formed its panel tiles: a SECOND workgroup can run
+// the solve WHILE the first one is still factoring, one 16-column step behind.  The two chain workgroups alternate roles:
+//     D_j  factors diagonal block j in its LDS and streams every finished column block (16 KB of L + the 2 KB inverse of its
+//          diagonal tile, write-through) behind a flag slab_ready[8 j + s];
+//     H_j  (the other workgroup) follows those flags with the streamed solve for tile (j+1, j), stores L_{j+1,j}, forms
+//          A_{j+1,j+1} - L L^T in its LDS -- and is thereby D_{j+1}, while the first workgroup becomes H_{j+1}.
+// Per step the chain now costs  diagonal block + (last solve step + L L^T + tile commit)  instead of the sum of all three.
+// diag_block_stream: factor the image (optionally loaded from global memory first), publishing as it goes.
+__device__ __forceinline__ void diag_block_stream(double* __restrict__ A, long lda, double* __restrict__ Tout, long ldt,
+                                                  int* __restrict__ info, int global_off, char* smem, bool load,
+                                                  int* __restrict__ slab_flags, int* __restrict__ factored_flag) {
+    double* As = reinterpret_cast<double*>(smem);
+    double* Ts = As + 128 * DL;
+    const int tid = threadIdx.x;
+    int* pub_word = reinterpret_cast<int*>(As + 125 * DL + 128);     // arrivals of waves 1-3 per published block (padding row)
+    if (load) {
+        const int i2 = 2 * (tid & 63), jc = tid >> 6;
+#pragma unroll 8
+        for (int p = 0; p < 32; ++p) {
+            const int j = 4 * p + jc;
+            d2_t v = *reinterpret_cast<const d2_t*>(A + (long)i2 + (long)j * lda);
+            if ((i2 >> 4) < (j >> 4)) v = d2_t{0.0, 0.0};
+            *reinterpret_cast<d2_t*>(As + i2 + j * DL) = v;
+        }
+    }
+    if (tid == 0) *pub_word = 0;
+    __syncthreads();
+    auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(A, 0, 0x7fffffff, 0x00020000);
+    auto rsrcT = __builtin_amdgcn_make_buffer_rsrc(Tout, 0, 0x7fffffff, 0x00020000);
+    chol_factor_steps(As, Ts, info, global_off, [&](int s) {
+        // waves 1-3: columns 16 s .. 16 s + 15 of L (all 128 rows: zeros above the diagonal are part of the operand slab) and
+        // the inverse of the diagonal tile, write-through; every wave drains its own stores, the last one to arrive raises the flag
+        const int t = tid - 64;
+        for (int idx = t; idx < 1024; idx += 192) {
+            const int col = 16 * s + (idx >> 6), r2 = 2 * (idx & 63);
+            const d2_t v = *reinterpret_cast<const d2_t*>(As + r2 + col * DL);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rsrcA, (int)((r2 + (long)col * lda) * 8), 0, 16);
+        }
+        if (t < 128) {
+            const int c = t >> 3, r2 = 2 * (t & 7);
+            const d2_t v = *reinterpret_cast<const d2_t*>(Ts + 256 * s + r2 + 16 * c);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rsrcT, (int)(((16 * s + r2) + (long)(16 * s + c) * ldt) * 8), 0, 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if ((tid & 63) == 0) {
+            const int old = __hip_atomic_fetch_add(pub_word, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (old == 3 * (s + 1) - 1) {
+                __hip_atomic_store(slab_flags + s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (s == 7) __hip_atomic_store(factored_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    });
+    __syncthreads();
+}
+
+// workgroup-level wait for a flag whose payload this CU has never read before (no L1 line to drop): compiler-level ordering only
+__device__ __forceinline__ bool pk_wait_flag_first_touch(int* p, const PersistArgs& a) {
+    int ok = 1;
+    if ((threadIdx.x & 63) == 0) ok = pk_spin(p, 1, a.info + 1, a.timeout) ? 1 : 0;
+    ok = __builtin_amdgcn_readfirstlane(ok);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __syncthreads();
+    return ok != 0;
+}
+
+// chain_trsm following the diagonal block's column blocks as they are published (slab_flags[s]); T: the global T_jj block whose
+// diagonal 16 x 16 tiles hold the small inverses.  The A slabs (no dependence on the factorisation) run three ahead in the ring.
+__device__ __forceinline__ bool chain_trsm_stream(ChainAcc& V, const double* __restrict__ A, long lda, const double* __restrict__ L, long ldl,
+                                                  const double* __restrict__ T, long ldt, int* __restrict__ slab_flags, double* lds,
+                                                  const PersistArgs& a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fl = lane & 15, fk = lane >> 4;
+    const int mi[2] = {wave, 7 - wave};
+    constexpr int SLAB = GEMM_LDS_TILE;
+    auto issue = [&](const double* P, long ldp, int s, int half) {   // wave w brings k-rows 4w .. 4w+3 of slab s
+        double* base = lds + (s & 3) * 2 * SLAB + half * SLAB;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * wave + r;
+            slab_row_to_lds(P + 2 * lane + (long)(16 * s + row) * ldp, base + row * GEMM_LDS_MC_LD);
+        }
+    };
+    V.zero();
+    issue(A, lda, 0, 0); issue(A, lda, 1, 0); issue(A, lda, 2, 0);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        if (!pk_wait_flag_first_touch(slab_flags + s, a)) return false;   // its barrier: every wave has finished step s - 1
+        issue(L, ldl, s, 1);
+        double tf[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) tf[kk] = T[(16 * s + fl) + (long)(16 * s + 4 * kk + fk) * ldt];   // T16_s[n = fl][k]
+        ring_wait_barrier<0>();                          // slab s of L (and of A, issued earlier) is in LDS for every wave
+        if (s + 3 < 8) issue(A, lda, s + 3, 0);          // into the buffer of slab s - 1
+        const double* la = lds + (s & 3) * 2 * SLAB;
+        const double* lb = la + SLAB;
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2) {
+            d4_t r;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r[q] = la[(fk + 4 * q) * GEMM_LDS_MC_LD + 16 * mi[q2] + fl] - V.v[q2][s][q];
+            d4_t x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) x = __builtin_amdgcn_mfma_f64_16x16x4f64(tf[kk], r[kk], x, 0, 0, 0);
+            V.v[q2][s] = x;
+#pragma unroll
+            for (int c = s + 1; c < 8; ++c) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const double bf = lb[(fk + 4 * kk) * GEMM_LDS_MC_LD + 16 * c + fl];
+                    V.v[q2][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf, x[kk], V.v[q2][c], 0, 0, 0);
+                }
+            }
+        }
+    }
+    __syncthreads();                                     // LDS free for the next user
+    return true;
+}
+
 // ---- the dataflow chain's products with their results kept in LDS ----------------------------------------
 // ChainAcc (wave w: 16-row blocks w and 7 - w) -> image img[m + n DL]: the layout of diag_block's As, and of eight
 // consecutive operand slabs [16][DL] when the image is read as an operand with k = n.
@@ -1001,6 +1124,53 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
     int* factored = a.sync + DF_FACT;
     int* chain_ready = a.sync + DF_FACT + nb;
     int* panel_done = a.sync + DF_FACT + 2 * nb;        // [i + j nb]
+    const int nchain = a.chain2 ? 2 : 1;
+    if (a.chain2 && b < 2) {
+        // ---- the chain, two workgroups alternating between factoring (D_j) and following with the solve (H_j) ----
+        int* slab_ready = panel_done + (long)nb * nb;   // [8 j + s]
+        auto Hstep = [&](int k) -> bool {
+            double* Akk = a.A + (long)k * NB * (ld + 1);
+            double* Tkk = a.Linv + (long)k * NB * (ld + 1);
+            double* Asub = Akk + NB;                           // tile (k+1, k)
+            double* Anext = Akk + (long)NB * (ld + 1);         // tile (k+1, k+1)
+            const int j = k;                                   // (PK_STAMP indexes the trace by j)
+            PK_STAMP(0);
+            if (!pk_wait_count(chain_ready + k, 2, a)) return false;   // both tiles carry their owners' updates (steps < k)
+            PK_STAMP(1);
+            {
+                ChainAcc ca;
+                if (!chain_trsm_stream(ca, Asub, ld, Akk, ld, Tkk, ld, slab_ready + 8 * k, lds, a)) return false;
+                chain_acc_to_image<true>(ca, lds);
+            }
+            lds_barrier();
+            chain_image_store_wt(Asub, ld, lds);
+            df_publish_store(panel_done + (k + 1) + (long)k * nb);
+            PK_STAMP(2);
+            {
+                ChainAcc ca;
+                ca.zero();
+                chain_syrk_image(ca, lds);
+                lds_barrier();
+                chain_acc_to_image<false>(ca, lds);
+            }
+            lds_barrier();
+            chain_image_rsub(Anext, ld, lds);
+            PK_STAMP(3);
+            return true;
+        };
+        auto Dstep = [&](int j, bool load) {
+            diag_block_stream(a.A + (long)j * NB * (ld + 1), ld, a.Linv + (long)j * NB * (ld + 1), ld, a.info, j * NB, smem, load,
+                              slab_ready + 8 * j, factored + j);
+        };
+        if (b == 0) Dstep(0, true);
+        for (int k = (b == 0 ? 1 : 0); k <= nb - 2; k += 2) {
+            if (!Hstep(k)) return;
+            Dstep(k + 1, false);
+            const int j = k;
+            PK_STAMP(4);
+        }
+        return;
+    }
     if (b == 0) {
         // ---- the chain ----
         // Everything between two diagonal blocks stays in LDS: the panel tile L_{j+1,j} = A_{j+1,j} T_jj^T goes accumulators ->
@@ -1097,10 +1267,10 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
         const int xcc = (int)(x & 7);
         const int rank = __hip_atomic_fetch_add(a.sync + 8 + xcc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(a.sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int ok = pk_spin(a.sync + 1, G - 1, a.info + 1, a.timeout) ? 1 : 0;
+        int ok = pk_spin(a.sync + 1, G - nchain, a.info + 1, a.timeout) ? 1 : 0;
         int widx = rank;
         for (int q = 0; q < xcc; ++q) widx += __hip_atomic_load(a.sync + 8 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int W = G - 1, PR = a.pr, PC = W / PR;
+        const int W = G - nchain, PR = a.pr, PC = W / PR;
         int nt = 0;
         if (ok && a.map == 1) {
             // tiles in column-major order (without (0, 0)) dealt round-robin: even in total work and at every stage
@@ -1292,7 +1462,7 @@ void launch_potrf_persistent(hipStream_t s, double* A, int Np, double* Linv, int
     a.timeout = 20000000LL;   // 0.2 s of the 100 MHz wall clock
     a.trace = trace;
     a.nbo = potrf_persistent_nbo(Np);
-    a.j0 = 0; a.j1 = nb; a.k0 = 0; a.ext_flag = nullptr; a.pr = 1; a.map = 0; a.near = 0; a.acq = 1; a.idle_sleep = 16; a.fuse = 0; a.trsm = 0;
+    a.j0 = 0; a.j1 = nb; a.k0 = 0; a.ext_flag = nullptr; a.pr = 1; a.map = 0; a.near = 0; a.acq = 1; a.idle_sleep = 16; a.fuse = 0; a.trsm = 0; a.chain2 = 0;
     hipLaunchKernelGGL(potrf_persistent_kernel, dim3(G), dim3(256), DIAG_LDS_BYTES, s, a);
 }
 
@@ -1307,7 +1477,7 @@ int potrf_dataflow_nbo(int Np) {
 // ints of device scratch the dataflow form needs (0: the matrix is too large for its tables)
 size_t potrf_dataflow_sync_ints(int Np) {
     const size_t nb = Np / NB;
-    return DF_FACT + 2 * nb + nb * nb;
+    return DF_FACT + 2 * nb + nb * nb + 8 * nb;      // factored, chain_ready, panel_done[nb][nb], slab_ready[nb][8]
 }
 // false: not applicable (too few blocks / too many tiles per worker) -- the caller uses another schedule
 bool launch_potrf_dataflow(hipStream_t s, double* A, int Np, double* Linv, int* info, int* sync, long long* trace) {
@@ -1318,13 +1488,19 @@ bool launch_potrf_dataflow(hipStream_t s, double* A, int Np, double* Linv, int* 
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     if (n_cu <= 0) n_cu = 64;
     const int tiles = nb * (nb + 1) / 2 - 1;
-    const int G = std::max(2, std::min(n_cu, 1 + tiles));
-    const int W = G - 1;
+    auto envi = [](const char* n, int dflt) { const char* v = getenv(n); return v ? atoi(v) : dflt; };
+    const int fuse = envi("SLS_POTRF_DFUSE", 1), trsm = envi("SLS_POTRF_DTRSM", 1) && fuse;
+    // two chain workgroups: opt-in.  Measured (profiles/r03_potrf_dataflow_chain2.log): 0.78 vs 0.82 ms at N = 2048, 4.33 vs 4.24 at
+    // 8192 -- the follower gets its tiles 39-45 us after the diagonal block before (two worker tasks in sequence: the panel tile
+    // L_{j+2,j}, then the update of (j+2, j+1) with it), so the step is bound by that path (~48 us) instead of the chain's own 51
+    const int chain2 = envi("SLS_POTRF_DCHAIN2", 0) && trsm && n_cu >= 4;
+    const int nchain = chain2 ? 2 : 1;
+    const int G = std::max(nchain + 1, std::min(n_cu, nchain + tiles));
+    const int W = G - nchain;
     const char* e = getenv("SLS_POTRF_DPR");
     int PR = e ? atoi(e) : (W >= 144 ? 12 : W >= 36 ? 6 : W >= 4 ? 2 : 1);
     PR = std::max(1, std::min(PR, W));
     const int PC = W / PR;
-    auto envi = [](const char* n, int dflt) { const char* v = getenv(n); return v ? atoi(v) : dflt; };
     const int map = envi("SLS_POTRF_DMAP", 1);   // round-robin: 5.0 vs 5.7 ms at N = 8192 (the cyclic grid leaves 1.4x work on some owners)
     if (map == 1 ? (tiles + W - 1) / W > DF_MAXT : ((nb + PR - 1) / PR) * ((nb + PC - 1) / PC) > DF_MAXT) return false;
     (void)hipMemsetAsync(sync, 0, potrf_dataflow_sync_ints(Np) * sizeof(int), s);
@@ -1339,8 +1515,9 @@ bool launch_potrf_dataflow(hipStream_t s, double* A, int Np, double* Linv, int* 
     a.near = envi("SLS_POTRF_DNEAR", Np >= 16384 ? 3 : 0);
     a.acq = envi("SLS_POTRF_DACQ", 1);
     a.idle_sleep = envi("SLS_POTRF_DSLEEP", 16);
-    a.fuse = envi("SLS_POTRF_DFUSE", 1);
-    a.trsm = envi("SLS_POTRF_DTRSM", 1) && a.fuse;
+    a.fuse = fuse;
+    a.trsm = trsm;
+    a.chain2 = chain2;
     hipLaunchKernelGGL(potrf_dataflow_kernel, dim3(G), dim3(256), DIAG_LDS_BYTES, s, a);
     if (a.trsm) launch_diag_inverse(s, A, Np, Linv);     // T_jj for every diagonal block, off the factorisation's serial chain
     return true;
@@ -1428,7 +1605,7 @@ void launch_potrf_hybrid(hipStream_t s, double* A, int Np, double* Linv, int* in
         a.j0 = b0; a.j1 = b1;                 // b1 == nb: last block, runs to the end
         a.k0 = B > 0 ? b0 - nbo : b0;
         a.ext_flag = (B > 0 && b1 - b0 > 1) ? flags + B : nullptr;
-        a.pr = 1; a.map = 0; a.near = 0; a.acq = 1; a.idle_sleep = 16; a.fuse = 0; a.trsm = 0;
+        a.pr = 1; a.map = 0; a.near = 0; a.acq = 1; a.idle_sleep = 16; a.fuse = 0; a.trsm = 0; a.chain2 = 0;
         const int work = nb - b0;             // panel tiles of the first step (+ chain)
         const int G = std::max(2, std::min(64, 1 + work));
         hipLaunchKernelGGL(potrf_persistent_kernel, dim3(G), dim3(256), DIAG_LDS_BYTES, s, a);

@@ -89,6 +89,7 @@ def test_potrf_schedules_agree(N, monkeypatch):
                       ("dataflow1cyc", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "1", "SLS_POTRF_DMAP": "0", "SLS_POTRF_DTRSM": "0"}),
                       ("dataflow1unfused", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "1", "SLS_POTRF_DFUSE": "0"}),
                       ("dataflow1trsm", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "1", "SLS_POTRF_DTRSM": "1"}),
+                      ("dataflow1chain2", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "1", "SLS_POTRF_DCHAIN2": "1"}),
                       ("dataflow2", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "2", "SLS_POTRF_DMAP": "1"}),
                       ("dataflow4near", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "4", "SLS_POTRF_DNEAR": "2", "SLS_POTRF_DMAP": "0"})):
         for k in [k for k in os.environ if k.startswith("SLS_POTRF_")]:
@@ -110,6 +111,8 @@ def test_potrf_schedules_agree(N, monkeypatch):
     assert np.array_equal(res["multi"], res["dataflow1unfused"])
     # default form: panel tiles by triangular solves against L_jj (16 x 16 inverses) instead of products with T_jj: rounding
     close(res["dataflow1trsm"], res["multi"], rtol=1e-12, atol=1e-13)
+    # two chain workgroups (one factors, the other follows with the streamed solve): who computes changes, not what
+    assert np.array_equal(res["dataflow1chain2"], res["dataflow1trsm"])
     close(res["dataflow2"], res["multi"], rtol=1e-12, atol=1e-13)
     close(res["dataflow4near"], res["multi"], rtol=1e-12, atol=1e-13)
     assert np.array_equal(res["multi2"], res["multi2look"])        # the side stream changes the schedule, not the arithmetic
