@@ -14,7 +14,7 @@ namespace sequential_line_search
         /// per device for the search and the per-device winners are merged with a single ncclAllGather.  A device may be
         /// listed more than once (logical shards on one GPU; the merge then happens on the host).
         void                    SetDevices(const std::vector<int>& devices);
-        const std::vector<int>& Devices();
+        std::vector<int> Devices();   // by value: a copy taken under the lock (SetDevices may run on another thread)
     } // namespace device
 } // namespace sequential_line_search
 

@@ -69,7 +69,7 @@ namespace sequential_line_search
             g_devices_set = true;
         }
 
-        const std::vector<int>& Devices()
+        std::vector<int> Devices()
         {
             std::lock_guard<std::mutex> lock(g_multi_mtx);
             LoadDevicesFromEnv();

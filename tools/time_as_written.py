@@ -6,7 +6,7 @@ oracle's as-written entry points at N in {128, 256, 512, 1024}, D = 64. A power 
 largest sizes and evaluated at N = 8192. The multi-start loop of the reference is embarrassingly parallel over `nproc`
 threads, so the whole-machine rate is cores / t. The result is an EXTRAPOLATION and is labelled so.
 
-Writes profiles/r01_cpu_as_written.json. Test/measurement infrastructure only (uses oracle/).
+Writes profiles/r03_cpu_as_written.json (round 3: run on the GPU box, whose core count it records). Test/measurement infrastructure only (uses oracle/).
 """
 import json, os, sys, time
 import numpy as np
@@ -54,5 +54,5 @@ out = {
     "C4_step_seconds_all_cores": 65536 * 50 * t8192 / cores,
 }
 print(json.dumps(out))
-os.makedirs(os.path.join(R, "profiles"), exist_ok=True)
-json.dump(out, open(os.path.join(R, "profiles", "r01_cpu_as_written.json"), "w"), indent=1)
+os.makedirs(os.path.join(R, "gpurun_out"), exist_ok=True)
+json.dump(out, open(os.path.join(R, "gpurun_out", "cpu_as_written.json"), "w"), indent=1)
