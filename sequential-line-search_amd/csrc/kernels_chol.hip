@@ -10,6 +10,7 @@
 // Triangular inverse: recursive doubling over block pairs, X21 = -X22 (L21 X11), every level two batched GEMMs.
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 #include "chol_diag.hpp"
@@ -1421,6 +1422,35 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
     }
 }
 
+// The single-launch factorisations need ALL their workgroups resident at once (one per CU, the CU's whole LDS).  Two of them
+// in flight on one device -- two contexts on the same GPU (sls_multi with a repeated device, one context per host thread) --
+// would each get part of the chip, spin for the rest until the bounded waits expire and fall back to the multi-launch
+// schedule.  They are therefore serialised per device: a launch first waits (on the host) for the previous one's completion
+// event.  Processes sharing a GPU are not covered; there the fallback + re-arm path takes over.
+namespace {
+struct PersistSerial {
+    std::mutex m;
+    hipEvent_t done = nullptr;
+};
+PersistSerial g_persist_serial[64];
+struct PersistSerialScope {
+    PersistSerial* p;
+    hipStream_t s;
+    PersistSerialScope(hipStream_t s_) : s(s_) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        p = &g_persist_serial[dev & 63];
+        p->m.lock();
+        if (p->done) (void)hipEventSynchronize(p->done);
+        else (void)hipEventCreateWithFlags(&p->done, hipEventDisableTiming);
+    }
+    ~PersistSerialScope() {
+        (void)hipEventRecord(p->done, s);
+        p->m.unlock();
+    }
+};
+}  // namespace
+
 int potrf_persistent_nbo(int Np) {
     const char* e = getenv("SLS_POTRF_PNBO");
     if (e && atoi(e) >= 1) return atoi(e);
@@ -1463,6 +1493,7 @@ void launch_potrf_persistent(hipStream_t s, double* A, int Np, double* Linv, int
     a.trace = trace;
     a.nbo = potrf_persistent_nbo(Np);
     a.j0 = 0; a.j1 = nb; a.k0 = 0; a.ext_flag = nullptr; a.pr = 1; a.map = 0; a.near = 0; a.acq = 1; a.idle_sleep = 16; a.fuse = 0; a.trsm = 0; a.chain2 = 0;
+    PersistSerialScope serial(s);
     hipLaunchKernelGGL(potrf_persistent_kernel, dim3(G), dim3(256), DIAG_LDS_BYTES, s, a);
 }
 
@@ -1518,7 +1549,10 @@ bool launch_potrf_dataflow(hipStream_t s, double* A, int Np, double* Linv, int* 
     a.fuse = fuse;
     a.trsm = trsm;
     a.chain2 = chain2;
-    hipLaunchKernelGGL(potrf_dataflow_kernel, dim3(G), dim3(256), DIAG_LDS_BYTES, s, a);
+    {
+        PersistSerialScope serial(s);
+        hipLaunchKernelGGL(potrf_dataflow_kernel, dim3(G), dim3(256), DIAG_LDS_BYTES, s, a);
+    }
     if (a.trsm) launch_diag_inverse(s, A, Np, Linv);     // T_jj for every diagonal block, off the factorisation's serial chain
     return true;
 }

@@ -66,3 +66,38 @@ def test_rccl_communicator_single_rank_allgather():
         v, i, xo = comm.allgather_best(1.25 + k, 4242 + k, x)
         assert v == 1.25 + k and i == 4242 + k and np.array_equal(xo, x)
     comm.close(); ctx.close()
+
+
+def test_concurrent_contexts_on_one_device_do_not_fall_back(oracle):
+    """Two host threads, one context each, on the SAME GPU, fitting at the same time (what sls_multi does with a repeated
+    device, and what sls_hip.h recommends for multi-threaded callers).  The single-launch Cholesky needs every workgroup resident
+    at once, so two of them in flight would starve each other into their bounded-wait fallback; launches are serialised per
+    device instead: same bits as a lone fit, and no fallback recorded on either context."""
+    import threading
+    m = sls()
+    D, N = 6, 1500
+    X, y, theta, b = synth_problem(oracle, D, N)
+    Xs = synth_candidates(oracle, D, 64)
+    c0 = m.Context(0)
+    g = m.GP(c0, X, y, theta, b, 1)
+    ref = g.predict(Xs)
+    g.close()
+    out, ctxs = {}, [m.Context(0), m.Context(0)]
+
+    def work(i):
+        res = []
+        for _ in range(6):
+            gp = m.GP(ctxs[i], X, y, theta, b, 1)
+            res.append(gp.predict(Xs))
+            gp.close()
+        out[i] = res
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    for i in range(2):
+        for mu, sg in out[i]:
+            assert np.array_equal(mu, ref[0]) and np.array_equal(sg, ref[1])
+        assert ctxs[i].prof_get("potrf_fallbacks")[1] == 0
+        ctxs[i].close()
+    c0.close()
