@@ -1092,7 +1092,7 @@ __device__ __forceinline__ void chain_image_rsub(const double* __restrict__ C, l
 // Bit-identical to the one-level multi-launch schedule for nbo = 1; agreement to rounding for nbo > 1.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int DF_FACT = 32;          // sync: [DF_FACT + j] factored, [DF_FACT + nb + j] chain_ready, [DF_FACT + 2 nb + i + j nb] panel_done
-constexpr int DF_MAXT = 64;          // owned tiles per worker (launcher checks)
+constexpr int DF_MAXT = 120;         // owned tiles per worker (launcher checks; state lives in the LDS padding of columns 0 .. DF_MAXT - 1): N <= ~31 000
 constexpr int DF_WIN = 16;           // tiles examined per scheduling round (16 lanes each)
 
 // end of the update chunk of tile (., k) that starts at step j0: a finished outer block in one accumulation (K = 128 nbo),
