@@ -8,22 +8,25 @@ import heapq
 import sys
 
 
+def chunks_of(i, k, nbo, near):
+    """Update chunks (j0, j1) of tile (i, k): df_chunk_end of the kernel."""
+    target = k - 1 if i == k else k
+    out, d = [], 0
+    while d < target:
+        if d // nbo < k // nbo and not (near and d // nbo == k // nbo - 1 and k % nbo < near):
+            j1 = (d // nbo + 1) * nbo
+        else:
+            j1 = d + 1
+        j1 = min(j1, target)
+        out.append((d, j1))
+        d = j1
+    return out
+
+
 def simulate(nb, PR=12, nbo=8, W=255, chain_step=(13.0, 21.0, 36.0), t_gemm=13.6, t_rmw=3.5, t_sched=3.5, near=0, verbose=False):
-    PC = W // PR
+    PC = max(1, W // PR)
     owner = lambda i, k: (i % PR) + PR * (k % PC)
-    # chunk boundaries of tile (i, k): list of (j0, j1)
-    def chunks(i, k):
-        target = k - 1 if i == k else k
-        out, d = [], 0
-        while d < target:
-            if d // nbo < k // nbo and not (near and d // nbo == k // nbo - 1 and k % nbo < near):
-                j1 = (d // nbo + 1) * nbo
-            else:
-                j1 = d + 1
-            j1 = min(j1, target)
-            out.append((d, j1))
-            d = j1
-        return out
+    chunks = lambda i, k: chunks_of(i, k, nbo, near)
     tiles = {}
     for k in range(nb):
         for i in range(k, nb):
@@ -121,7 +124,11 @@ def simulate(nb, PR=12, nbo=8, W=255, chain_step=(13.0, 21.0, 36.0), t_gemm=13.6
     chain_try(INF)
     total = chain_free
     act = [b for b, m in zip(busy, mine) if m]
-    return dict(total_us=total, chain_wait_us=chain_wait, busy_max=max(act), busy_mean=sum(act) / len(act), workers=len(act))
+    unfinished = sum(1 for t in tiles.values() if not t["fin"])
+    if chain_j <= nb - 2:
+        total = float("inf")                      # the chain never got its tiles: a circular wait in the schedule
+    return dict(total_us=total, chain_wait_us=chain_wait, busy_max=max(act), busy_mean=sum(act) / len(act), workers=len(act),
+                steps_done=chain_j, tiles_unfinished=unfinished)
 
 
 if __name__ == "__main__":
