@@ -354,8 +354,13 @@ __device__ __forceinline__ bool pk_spin(int* p, int target, int* abort_flag, lon
     }
     return true;
 }
-// this CU's vector L1 only (the L2 is handled once per XCD by the barrier leader)
-__device__ __forceinline__ void pk_inv_l1() { asm volatile("buffer_inv sc0" ::: "memory"); }
+// this CU's vector L1 only (the L2 is handled once per XCD by the barrier leader).  `buffer_inv sc1`: the agent-scope form.  Round 2
+// used `buffer_inv sc0` here, which is a WORKGROUP-scope invalidate and drops nothing another CU's stores could have made stale
+// (MI355X_MICROARCH.md, "inter-workgroup visibility"): the barrier form then relied on its tiles' streaming reads evicting the
+// 32 KB L1 by themselves -- true in every test, but not a guarantee, and the likely reason why the fused chain step of round 2
+// (which re-read small, recently touched regions) gave build-dependent factors.  The dataflow form needs no such invalidate for
+// its update tiles at all (one owner per tile) and takes a real agent-scope acquire before every task.
+__device__ __forceinline__ void pk_inv_l1() { asm volatile("buffer_inv sc1" ::: "memory"); }
 
 // Workgroup-level wait on a flag raised by pk_signal.  The diagonal-block code owns every byte of the 160 KB of LDS, so
 // there is no shared word for a broadcast: lane 0 of EVERY wave spins and hands its verdict to its own wave; the barrier
