@@ -176,6 +176,13 @@ sls_gp* sls_multi_gp_shard(sls_multi_gp* g, int shard);
  * index of the winner; evals_issued (may be NULL) sums the shards' sls_acq_last_stats. */
 int sls_multi_acq_maximize(sls_multi_gp* g, int acq_type, double ucb_h, const double* starts, int S, int n_local,
                            const sls_lbfgs_opts* opts, double* x_out, double* val_out, long* idx_out, long* evals_issued);
+/* GP MAP objective over the devices of `m`: the B independent points of one DIRECT iteration of PerformMapEstimation
+   (src/gaussian-process-regressor.cpp:294) dealt round-robin, point k on shard k mod n, values gathered through host memory (no
+   collective; the N^3 factorisation of ONE evaluation does not shard).  Bit-identical to sls_gp_nll_batch on one device. */
+typedef struct sls_multi_nll sls_multi_nll;
+int sls_multi_nll_create(sls_multi* m, const double* X, int D, int N, int kernel, sls_multi_nll** out);
+int sls_multi_nll_destroy(sls_multi_nll* g);
+int sls_multi_gp_nll_batch(sls_multi_nll* g, const double* y, const double* xs, int B, double* values);
 
 /* (2) one process per GPU (torch.distributed.run / mpirun).  Rank 0 calls sls_comm_unique_id and distributes the 128 bytes
  * (any side channel); every rank then calls sls_comm_create on its context.  sls_comm_allgather_best is the single exchange

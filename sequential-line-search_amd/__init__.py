@@ -50,7 +50,8 @@ EXPORTS = [
     "sls_ctx_set_candidate_chunk", "sls_gram", "sls_gram_cross", "sls_potrf", "sls_potrs", "sls_potri", "sls_gp_create",
     "sls_gp_destroy", "sls_gp_get_matrix", "sls_gp_get_summary", "sls_gp_predict", "sls_gp_predict_grad", "sls_acq_eval",
     "sls_lbfgs_default_opts", "sls_acq_maximize", "sls_acq_maximize_dev", "sls_gp_refit_dev", "sls_prof_enable",
-    "sls_prof_reset", "sls_prof_get", "sls_nll_create", "sls_nll_destroy", "sls_nll_eval", "sls_gp_nll_grad", "sls_gp_nll_batch",
+    "sls_prof_reset", "sls_prof_get", "sls_nll_create", "sls_nll_destroy", "sls_nll_eval", "sls_gp_nll_grad", "sls_gp_nll_batch", "sls_multi_nll_create", "sls_multi_nll_destroy",
+    "sls_multi_gp_nll_batch",
     "sls_pref_objective", "sls_acq_eval_pair", "sls_acq_maximize_pair", "sls_gp_append_point", "sls_acq_last_stats",
     "sls_multi_create", "sls_multi_destroy", "sls_multi_size", "sls_multi_exchange", "sls_multi_ctx", "sls_multi_gp_create",
     "sls_multi_gp_destroy", "sls_multi_gp_shard", "sls_multi_acq_maximize", "sls_comm_unique_id", "sls_comm_create",
@@ -379,6 +380,28 @@ class MultiGP:
                                          C.byref(opts) if opts is not None else None, _p(x), C.byref(val), C.byref(idx),
                                          C.byref(issued)))
         return dict(index=idx.value, x=x, value=val.value, evals_issued=issued.value)
+
+
+class MultiNll:
+    """GP MAP objective over the devices of a Multi: the points of a batch dealt round-robin (sls_multi_gp_nll_batch)."""
+
+    def __init__(self, multi, X, kernel=KERNEL_MATERN52):
+        X = _f(X)
+        self.D, self.N = X.shape
+        self.h = C.c_void_p()
+        _ck(lib().sls_multi_nll_create(multi.h, _p(X), self.D, self.N, int(kernel), C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().sls_multi_nll_destroy(self.h)
+            self.h = None
+
+    def gp_objective_batch(self, y, xs):
+        y = _f(y)
+        xs = np.ascontiguousarray(xs, dtype=np.float64)
+        out = np.empty(xs.shape[0])
+        _ck(lib().sls_multi_gp_nll_batch(self.h, _p(y), _p(xs), xs.shape[0], _p(out)))
+        return out
 
 
 class Comm:

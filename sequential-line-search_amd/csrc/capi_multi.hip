@@ -382,3 +382,56 @@ extern "C" int sls_multi_acq_maximize(sls_multi_gp* g, int acq_type, double ucb_
     } catch (const HipFail& f) { return f.code; }
     return SLS_OK;
 }
+
+// ---- MAP objective over several devices: the B independent points of one DIRECT iteration dealt round-robin ----------------
+// The N^3 factorisation of one evaluation does not shard; the evaluations of a batch do: point k runs on shard
+// k mod n, each shard one sls_gp_nll_batch over its points, the values come back through host memory (no collective: B doubles).
+// Every point is evaluated by the same kernels as on one device: the values are bit-identical to sls_gp_nll_batch.
+struct sls_multi_nll {
+    sls_multi* m = nullptr;
+    int D = 0;
+    std::vector<sls_nll*> hs;
+};
+
+extern "C" int sls_multi_nll_create(sls_multi* m, const double* X, int D, int N, int kernel, sls_multi_nll** out) {
+    if (!m || !out) { set_error("sls_multi_nll_create: NULL argument"); return SLS_ERR_INVALID; }
+    std::unique_ptr<sls_multi_nll> g(new sls_multi_nll());
+    g->m = m; g->D = D;
+    const int n = (int)m->devices.size();
+    g->hs.assign(n, nullptr);
+    const int rc = for_each_shard(n, [&](int r) { return sls_nll_create(m->ctxs[r], X, D, N, kernel, &g->hs[r]); });
+    if (rc != SLS_OK) {
+        for (sls_nll* h : g->hs) sls_nll_destroy(h);
+        return rc;
+    }
+    *out = g.release();
+    return SLS_OK;
+}
+
+extern "C" int sls_multi_nll_destroy(sls_multi_nll* g) {
+    if (!g) return SLS_OK;
+    for (size_t r = 0; r < g->hs.size(); ++r) {
+        (void)hipSetDevice(g->m->devices[r]);
+        sls_nll_destroy(g->hs[r]);
+    }
+    delete g;
+    return SLS_OK;
+}
+
+extern "C" int sls_multi_gp_nll_batch(sls_multi_nll* g, const double* y, const double* xs, int B, double* values) {
+    try {
+        SLS_REQUIRE(g && y && xs && values && B >= 0, "sls_multi_gp_nll_batch: bad argument");
+        const int n = (int)g->hs.size(), W = g->D + 2;
+        return for_each_shard(n, [&](int r) {
+            std::vector<double> mine, vals;
+            for (int k = r; k < B; k += n) mine.insert(mine.end(), xs + (size_t)k * W, xs + (size_t)(k + 1) * W);
+            const int nb = (int)(mine.size() / W);
+            if (nb == 0) return (int)SLS_OK;
+            vals.resize(nb);
+            const int rc = sls_gp_nll_batch(g->hs[r], y, mine.data(), nb, vals.data());
+            if (rc != SLS_OK) return rc;
+            for (int q = 0; q < nb; ++q) values[r + (size_t)q * n] = vals[q];
+            return (int)SLS_OK;
+        });
+    } catch (const HipFail& f) { return f.code; }
+}

@@ -117,6 +117,13 @@ namespace sequential_line_search
                   "sls_nll_create");
         }
         NllHandle::~NllHandle() { sls_nll_destroy(h); }
+
+        MultiNllHandle::MultiNllHandle(const Eigen::MatrixXd& X, int kernel)
+        {
+            Check(sls_multi_nll_create(Multi(), X.data(), static_cast<int>(X.rows()), static_cast<int>(X.cols()), kernel, &h),
+                  "sls_multi_nll_create");
+        }
+        MultiNllHandle::~MultiNllHandle() { sls_multi_nll_destroy(h); }
     } // namespace device
 
     namespace optim

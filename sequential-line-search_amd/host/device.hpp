@@ -42,6 +42,17 @@ namespace sequential_line_search
             GpHandle& operator=(const GpHandle&) = delete;
         };
 
+        /// MAP objective handles on every configured device (Devices().size() >= 2): batches of independent evaluations are
+        /// dealt round-robin over them (sls_multi_gp_nll_batch).
+        struct MultiNllHandle
+        {
+            sls_multi_nll* h = nullptr;
+            MultiNllHandle(const Eigen::MatrixXd& X, int kernel);
+            ~MultiNllHandle();
+            MultiNllHandle(const MultiNllHandle&)            = delete;
+            MultiNllHandle& operator=(const MultiNllHandle&) = delete;
+        };
+
         struct NllHandle
         {
             sls_nll* h = nullptr;

@@ -1,5 +1,6 @@
 // GaussianProcessRegressor over the C ABI (reference: src/gaussian-process-regressor.cpp).
 #include <chrono>
+#include <memory>
 #include <cmath>
 #include <sequential-line-search/gaussian-process-regressor.hpp>
 
@@ -123,14 +124,22 @@ namespace sequential_line_search
 
         // global phase: DIRECT, 300 evaluations on the reference's box [1e-8, 50]^(D+2) in the reference's (linear)
         // parameters (:291-294); DIRECT ignores x_ini.  The prior medians (the reference's x_ini) stay in the race.
-        // the points of one DIRECT iteration are independent: ONE device call (one workgroup per point for N <= 128)
+        // the points of one DIRECT iteration are independent: ONE device call (one workgroup per point for N <= 128); with several
+        // devices configured (device::SetDevices / SLS_DEVICES) and a problem large enough for the tiled pipeline, the points of
+        // a batch are dealt over the devices -- the part of a MAP fit that shards (the N^3 factorisation of one evaluation does not)
+        std::unique_ptr<device::MultiNllHandle> multi;
+        if (device::Multi() && m_X.cols() > 128) multi.reset(new device::MultiNllHandle(m_X, KernelId(m_kernel_type)));
         const optim::BatchObjective batch = [&](const std::vector<std::vector<double>>& xs, std::vector<double>& values) {
             values.resize(xs.size());
             if (xs.empty()) return;
             std::vector<double> flat(xs.size() * (D + 2));
             for (size_t k = 0; k < xs.size(); ++k)
                 for (int i = 0; i < D + 2; ++i) flat[k * (D + 2) + i] = xs[k][i];
-            device::Check(sls_gp_nll_batch(nll.h, m_y.data(), flat.data(), static_cast<int>(xs.size()), values.data()), "sls_gp_nll_batch");
+            if (multi)
+                device::Check(sls_multi_gp_nll_batch(multi->h, m_y.data(), flat.data(), static_cast<int>(xs.size()), values.data()),
+                              "sls_multi_gp_nll_batch");
+            else
+                device::Check(sls_gp_nll_batch(nll.h, m_y.data(), flat.data(), static_cast<int>(xs.size()), values.data()), "sls_gp_nll_batch");
         };
         const std::vector<double> lin_lower(D + 2, 1e-8), lin_upper(D + 2, 5e+01);
         double                    direct_v = 0.0;

@@ -101,3 +101,26 @@ def test_concurrent_contexts_on_one_device_do_not_fall_back(oracle):
         assert ctxs[i].prof_get("potrf_fallbacks")[1] == 0
         ctxs[i].close()
     c0.close()
+
+
+@pytest.mark.parametrize("N", [90, 300])
+def test_map_objective_batch_over_logical_shards_is_bit_identical(oracle, N):
+    """sls_multi_gp_nll_batch: the points of a DIRECT iteration dealt round-robin over the devices (three logical shards on GPU 0
+    here) give bit for bit the values of sls_gp_nll_batch on one device -- the part of a MAP fit (BASELINE config 5) that shards."""
+    m = sls()
+    D = 8
+    X, y, _, _ = synth_problem(oracle, D, N)
+    rng = np.random.default_rng(N)
+    xs = np.exp(rng.uniform(np.log(1e-2), np.log(3.0), (11, D + 2)))
+    xs[:, 1] = np.exp(rng.uniform(np.log(1e-5), np.log(1e-2), 11))
+    c = m.Context(0)
+    h = m.Nll(c, X, 1)
+    one = h.gp_objective_batch(y, xs)
+    h.close()
+    mg = m.Multi([0, 0, 0])
+    mh = m.MultiNll(mg, X, 1)
+    three = mh.gp_objective_batch(y, xs)
+    mh.close()
+    mg.close()
+    c.close()
+    assert np.array_equal(one, three)
