@@ -82,7 +82,7 @@ void* pool_alloc(size_t bytes) {
     return p;
 }
 
-void pool_free(void* p, size_t bytes) {
+void pool_free(void* p, size_t bytes, bool in_flight) {
     if (!p) return;
     if (bytes == 0) bytes = 8;
     int dev = 0;
@@ -98,7 +98,10 @@ void pool_free(void* p, size_t bytes) {
             // released after the same entry point (a handle's ~30 buffers cost one ~5 us call, normally on an idle device
             // because handles and temporaries are released after their stream has been synchronised).
             const long epoch = g_work_epoch.load();
-            if (P.synced_epoch != epoch) {
+            // (in_flight: the block is released by the entry point that queued work on it -- a buffer regrown between two
+            // launches -- so the epoch's earlier synchronisation does not cover it: synchronise again before it can be reused
+            // by another context's stream)
+            if (P.synced_epoch != epoch || in_flight) {
                 int cur = 0;
                 (void)hipGetDevice(&cur);
                 if (cur != dev) (void)hipSetDevice(dev);

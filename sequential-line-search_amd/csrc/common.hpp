@@ -49,7 +49,7 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // driver.  At most SLS_POOL_MB (default 16384) MB stay cached per device; beyond that blocks go back to the driver.
 void note_entry();                           // every C-ABI entry point: device work may be queued from here on
 void* pool_alloc(size_t bytes);              // throws HipFail on failure
-void pool_free(void* p, size_t bytes);
+void pool_free(void* p, size_t bytes, bool in_flight = false);   // in_flight: work queued in THIS entry may still use the block
 void pool_trim(int device);                  // return every cached block of `device` to the driver
 
 // Owning device buffer of doubles (or raw bytes).
@@ -60,14 +60,14 @@ struct DBuf {
     DBuf(const DBuf&) = delete;
     DBuf& operator=(const DBuf&) = delete;
     ~DBuf() { release(); }
-    void release() {
-        if (p) pool_free(p, n * sizeof(double));
+    void release(bool in_flight = false) {
+        if (p) pool_free(p, n * sizeof(double), in_flight);
         p = nullptr;
         n = 0;
     }
     void ensure(size_t doubles) {
         if (doubles <= n && p) return;
-        release();
+        release(true);   // a regrow in the middle of an entry point: kernels queued a moment ago may still read the old block
         p = static_cast<double*>(pool_alloc(doubles * sizeof(double)));
         n = doubles;
     }
