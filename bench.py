@@ -123,9 +123,12 @@ def stage_rooflines(prof, N, D, Np, cand, matern):
     out = {}
     t = per_launch_ms("cross_gram")          # writes K* (and C*): 8 N S_c bytes each; HBM-write bound
     out["cross_gram"] = {"bound": "hbm", "achieved_GBps": (2 if matern else 1) * 8.0 * N * cand / (t * 1e-3) / 1e9, "peak_GBps": 8000.0}
-    t = per_launch_ms("grad_gemm")           # reads P and C*: 16 N S_c bytes; 4 N D S_c flops
-    out["grad_gemm"] = {"bound": "hbm", "achieved_GBps": 16.0 * N * cand / (t * 1e-3) / 1e9, "peak_GBps": 8000.0,
-                        "achieved_TFLOPs": 4.0 * N * D * cand / (t * 1e-3) / 1e12}
+    t = per_launch_ms("grad_gemm")           # reads P and C*: 16 N S_c bytes; 4 N D S_c flops, i.e. D / 4 flop per byte: the
+    # binding roofline is the one with the LONGER minimum time (fp64 MFMA from D >= 40: ridge 78.6 TFLOP/s / 8 TB/s = 9.8 flop/B)
+    gg_bytes, gg_flops = 16.0 * N * cand, 4.0 * N * D * cand
+    out["grad_gemm"] = {"bound": "mfma" if gg_flops / (PEAK_FP64_MFMA_TFLOPS * 1e12) >= gg_bytes / 8e12 else "hbm",
+                        "achieved_GBps": gg_bytes / (t * 1e-3) / 1e9, "peak_GBps": 8000.0,
+                        "achieved_TFLOPs": gg_flops / (t * 1e-3) / 1e12, "peak_TFLOPs": PEAK_FP64_MFMA_TFLOPS}
     t = per_launch_ms("gram")                # writes the lower triangle of K_y: 4 N^2 bytes
     out["gram"] = {"bound": "hbm", "achieved_GBps": 4.0 * N * N / (t * 1e-3) / 1e9, "peak_GBps": 8000.0}
     # potrf N^3/3, triangular inverse N^3/3 (the recursive doubling executes ~N^3/3 MFMA flops: its GEMMs run over
