@@ -181,7 +181,7 @@ size_t potrf_dataflow_sync_ints(int Np);
 bool launch_potrf_dataflow(hipStream_t s, double* A, int Np, double* Linv, int* info, int* sync, long long* trace = nullptr);
 // The whole factorisation in ONE persistent launch (see kernels_chol.hip); sync = device scratch of >= 8 + 2 (Np/128) ints.
 // info[1] != 0 afterwards: a bounded wait expired (the kernel aborted; results undefined).  launch_potrf takes this path
-// when persist_sync != nullptr, Np >= 384 and SLS_POTRF_MODE is 1 (default; 0 = multi-launch schedule).
+// when persist_sync != nullptr, Np >= 384 and SLS_POTRF_MODE is 1 (or 3 where the dataflow form does not apply; 0 = multi-launch).
 int potrf_default_mode(int Np);
 void launch_potrf_persistent(hipStream_t s, double* A, int Np, double* Linv, int* info, int* sync, long long* trace = nullptr);
 // side stream restricted by a CU mask that leaves `free_per_xcd` CUs of each of the 8 XCDs to other streams (0: plain stream)
