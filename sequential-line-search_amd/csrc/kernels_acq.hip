@@ -784,9 +784,292 @@ __global__ __launch_bounds__(64) void lbfgs_step_kernel(LbfgsState st, const dou
     }
 }
 
+// The same step with the start's vectors in REGISTERS (D <= 4 DPL; lane q holds the dimensions q + 4 e, e < DPL).  The kernel
+// above walks ~20 + 4 m passes over D through global memory, each pass loading what the previous one stored (dir is read and
+// rewritten 2 m + 3 times): all of a launch's waves are resident at once, so its duration is ONE wave's chain of store -> load
+// round trips (505 us per round at 45 000 live starts, 6x what its bytes need).  Here x, g, the direction and the newest (s, y)
+// pair stay in registers from the first load to the last store; the history is only read, so the loads of a pair do not wait
+// for anything and those of the next pair are issued while the current one is used (the loads are unconditional -- every slot
+// of the ring is valid memory -- and the arithmetic of a slot beyond hlen is skipped).  Expressions, summation order and
+// branches are those of lbfgs_step_kernel: the bits are the same (tests run both, SLS_LBFGS_REG=0 selects the memory form).
+template <int DPL>
+__global__ __launch_bounds__(64) void lbfgs_step_reg_kernel(LbfgsState st, const double* __restrict__ val,
+                                                             const double* __restrict__ grad, int first) {
+    const int q = threadIdx.x >> 4;
+    const int j = blockIdx.x * 16 + (threadIdx.x & 15);     // column of (val, grad)
+    if (j >= st.nlive) return;
+    auto gsum = [](double v) {
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        return v;
+    };
+    auto gmax = [](double v) {
+        v = fmax(v, __shfl_xor(v, 16));
+        v = fmax(v, __shfl_xor(v, 32));
+        return v;
+    };
+    const int n = st.live ? st.live[j] : j;
+    const long ld = st.ld, ldv = st.ldv;
+    const int D = st.D, m = st.m;
+    double* __restrict__ x_ = st.x; double* __restrict__ g_ = st.g; double* __restrict__ dir_ = st.dir;
+    double* __restrict__ xt_ = st.xt;
+    double* __restrict__ ShA = st.Sh; double* __restrict__ YhA = st.Yh;
+    double xr[DPL], gr[DPL], dr[DPL], sn[DPL], yn[DPL];
+    double f_v = 0.0, t_v = 1.0;
+    int hlen_v = 0, hpos_v = 0, nbt_v = 0;
+    bool done = false;
+    bool have_new = false;       // (sn, yn, rho_new) is the newest history pair, written to slot hpos - 1 in this call
+    double rho_new = 0.0;
+    bool need_dir = false;
+    if (first) {
+        f_v = -val[j];
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) {
+            const int d = q + 4 * e;
+            if (d < D) {
+                xr[e] = xt_[n + d * ld];
+                gr[e] = -grad[j + d * ldv];
+                x_[n + d * ld] = xr[e];
+                g_[n + d * ld] = gr[e];
+            }
+        }
+        need_dir = true;
+    } else {
+        if (st.done[n]) return;
+        f_v = st.f[n]; t_v = st.t[n]; hlen_v = st.hlen[n]; hpos_v = st.hpos[n]; nbt_v = st.nbt[n];
+        const double ft = -val[j];
+        double xtr[DPL];
+        double gs = 0.0, ss = 0.0;
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) {
+            const int d = q + 4 * e;
+            if (d < D) { xtr[e] = xt_[n + d * ld]; xr[e] = x_[n + d * ld]; gr[e] = g_[n + d * ld]; }
+        }
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) {
+            const int d = q + 4 * e;
+            if (d < D) {
+                const double sd = xtr[e] - xr[e];
+                gs += gr[e] * sd;
+                ss += sd * sd;
+            }
+        }
+        gs = gsum(gs);
+        ss = gsum(ss);
+        if (ss == 0.0) {
+            if (q == 0) st.done[n] = 1;
+            return;
+        }
+        if (ft <= f_v + st.c1 * gs) {
+            double sy = 0.0, yy = 0.0;
+            const int idx = hpos_v;
+            double* __restrict__ Sh = ShA + (long)idx * D * ld;
+            double* __restrict__ Yh = YhA + (long)idx * D * ld;
+#pragma unroll
+            for (int e = 0; e < DPL; ++e) {
+                const int d = q + 4 * e;
+                if (d < D) {
+                    const double xtd = xtr[e], gtd = -grad[j + d * ldv];
+                    const double sd = xtd - xr[e];
+                    const double yd = gtd - gr[e];
+                    Sh[n + d * ld] = sd;
+                    Yh[n + d * ld] = yd;
+                    sn[e] = sd;
+                    yn[e] = yd;
+                    sy += sd * yd;
+                    yy += yd * yd;
+                    xr[e] = xtd;
+                    gr[e] = gtd;
+                    x_[n + d * ld] = xtd;
+                    g_[n + d * ld] = gtd;
+                }
+            }
+            sy = gsum(sy);
+            yy = gsum(yy);
+            if (sy > 1e-10 * yy && sy > 0.0) {
+                have_new = true;
+                rho_new = 1.0 / sy;
+                if (q == 0) st.rho[(long)idx * ld + n] = rho_new;
+                hpos_v = (idx + 1) % m;
+                if (hlen_v < m) hlen_v += 1;
+            }
+            f_v = ft;
+            need_dir = true;
+        } else {
+            t_v *= st.shrink;
+            nbt_v += 1;
+            if (nbt_v > st.max_backtracks) done = true;
+        }
+    }
+    // projected gradient of dimension e (recomputed where the memory form re-reads its scratch copy: the same value)
+    auto pg_of = [&](int e) {
+        double v = gr[e];
+        const double xv = xr[e];
+        if ((xv <= 0.0 && v > 0.0) || (xv >= 1.0 && v < 0.0)) v = 0.0;
+        return v;
+    };
+    bool have_dir = false;       // dr holds the new direction (to be stored); otherwise the stored one is used below
+    if (!done && need_dir) {
+        double pgmax = 0.0, pgn2 = 0.0;
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) {
+            const int d = q + 4 * e;
+            if (d < D) {
+                const double v = pg_of(e);
+                dr[e] = v;
+                pgmax = fmax(pgmax, fabs(v));
+                pgn2 += v * v;
+            }
+        }
+        pgmax = gmax(pgmax);
+        pgn2 = gsum(pgn2);
+        if (!(pgmax > st.gtol)) {
+            done = true;
+        } else {
+            const int hlen = hlen_v;
+            const int hpos = hpos_v;
+            double al[8];
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                al[h] = 0.0;
+                if (h < m) {                                       // uniform; the ring has m valid slots
+                    const int idx = (hpos - 1 - h + 2 * m) % m;
+                    const double* __restrict__ Sh = ShA + (long)idx * D * ld;
+                    const double* __restrict__ Yh = YhA + (long)idx * D * ld;
+                    const bool newest = h == 0 && have_new;
+                    double sh[DPL], yh[DPL];
+#pragma unroll
+                    for (int e = 0; e < DPL; ++e) {
+                        const int d = q + 4 * e;
+                        if (d < D) { sh[e] = Sh[n + d * ld]; yh[e] = Yh[n + d * ld]; }
+                    }
+                    const double rho = st.rho[(long)idx * ld + n];
+                    if (h < hlen) {
+                        double dot = 0.0;
+#pragma unroll
+                        for (int e = 0; e < DPL; ++e)
+                            if (q + 4 * e < D) dot += (newest ? sn[e] : sh[e]) * dr[e];
+                        al[h] = (newest ? rho_new : rho) * gsum(dot);
+#pragma unroll
+                        for (int e = 0; e < DPL; ++e)
+                            if (q + 4 * e < D) dr[e] -= al[h] * (newest ? yn[e] : yh[e]);
+                    }
+                }
+            }
+            double gamma;
+            if (hlen > 0) {
+                const int idx = (hpos - 1 + m) % m;
+                const double* __restrict__ Sh = ShA + (long)idx * D * ld;
+                const double* __restrict__ Yh = YhA + (long)idx * D * ld;
+                double sy = 0.0, yy = 0.0;
+#pragma unroll
+                for (int e = 0; e < DPL; ++e) {
+                    const int d = q + 4 * e;
+                    if (d < D) {
+                        const double sv = have_new ? sn[e] : Sh[n + d * ld];
+                        const double yv = have_new ? yn[e] : Yh[n + d * ld];
+                        sy += sv * yv;
+                        yy += yv * yv;
+                    }
+                }
+                gamma = gsum(sy) / gsum(yy);
+            } else {
+                const double nn = sqrt(pgn2);
+                gamma = 1.0 / (nn > 1.0 ? nn : 1.0);
+            }
+#pragma unroll
+            for (int e = 0; e < DPL; ++e)
+                if (q + 4 * e < D) dr[e] *= gamma;
+#pragma unroll
+            for (int h = 7; h >= 0; --h) {
+                if (h < m) {
+                    const int idx = (hpos - 1 - h + 2 * m) % m;
+                    const double* __restrict__ Sh = ShA + (long)idx * D * ld;
+                    const double* __restrict__ Yh = YhA + (long)idx * D * ld;
+                    const bool newest = h == 0 && have_new;
+                    double sh[DPL], yh[DPL];
+#pragma unroll
+                    for (int e = 0; e < DPL; ++e) {
+                        const int d = q + 4 * e;
+                        if (d < D) { sh[e] = Sh[n + d * ld]; yh[e] = Yh[n + d * ld]; }
+                    }
+                    const double rho = st.rho[(long)idx * ld + n];
+                    if (h < hlen) {
+                        double dot = 0.0;
+#pragma unroll
+                        for (int e = 0; e < DPL; ++e)
+                            if (q + 4 * e < D) dot += (newest ? yn[e] : yh[e]) * dr[e];
+                        const double beta = (newest ? rho_new : rho) * gsum(dot);
+#pragma unroll
+                        for (int e = 0; e < DPL; ++e)
+                            if (q + 4 * e < D) dr[e] += (newest ? sn[e] : sh[e]) * (al[h] - beta);
+                    }
+                }
+            }
+            double gd = 0.0;
+#pragma unroll
+            for (int e = 0; e < DPL; ++e) {
+                if (q + 4 * e < D) {
+                    const double pg = pg_of(e);
+                    const double dv = (pg == 0.0) ? 0.0 : -dr[e];
+                    dr[e] = dv;
+                    gd += pg * dv;
+                }
+            }
+            gd = gsum(gd);
+            if (!(gd < 0.0)) {
+                hlen_v = 0;
+                const double nn = sqrt(pgn2);
+                gamma = 1.0 / (nn > 1.0 ? nn : 1.0);
+                gd = 0.0;
+#pragma unroll
+                for (int e = 0; e < DPL; ++e) {
+                    if (q + 4 * e < D) {
+                        const double pg = pg_of(e);
+                        const double dv = -gamma * pg;
+                        dr[e] = dv;
+                        gd += pg * dv;
+                    }
+                }
+                gd = gsum(gd);
+                if (!(gd < 0.0)) done = true;
+            }
+            if (!done) { t_v = 1.0; nbt_v = 0; }
+            have_dir = true;
+        }
+    }
+    double moved = 0.0;
+#pragma unroll
+    for (int e = 0; e < DPL; ++e) {
+        const int d = q + 4 * e;
+        if (d < D) {
+            if (have_dir) dir_[n + d * ld] = dr[e];
+            const double xv = xr[e];
+            double v = xv;
+            if (!done) {
+                v = v + t_v * (have_dir ? dr[e] : dir_[n + d * ld]);
+                v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+                if (v != xv) moved = 1.0;
+            }
+            xt_[n + d * ld] = v;
+        }
+    }
+    moved = gmax(moved);
+    if (!done && moved == 0.0) done = true;
+    if (q == 0) {
+        st.f[n] = f_v; st.t[n] = t_v; st.hlen[n] = hlen_v; st.hpos[n] = hpos_v; st.nbt[n] = nbt_v;
+        st.done[n] = done ? 1 : 0;
+    }
+}
+
 void launch_lbfgs_step(hipStream_t s, const LbfgsState& st, const double* val, const double* grad, bool first) {
     if (st.nlive <= 0) return;
-    hipLaunchKernelGGL(lbfgs_step_kernel, dim3((st.nlive + 15) / 16), dim3(64), 0, s, st, val, grad, (int)first);
+    const char* renv = getenv("SLS_LBFGS_REG");
+    const bool use_reg = renv ? atoi(renv) != 0 : true;
+    const dim3 grid((st.nlive + 15) / 16), block(64);
+    if (use_reg && st.D <= 16) hipLaunchKernelGGL(lbfgs_step_reg_kernel<4>, grid, block, 0, s, st, val, grad, (int)first);
+    else if (use_reg && st.D <= 64) hipLaunchKernelGGL(lbfgs_step_reg_kernel<16>, grid, block, 0, s, st, val, grad, (int)first);
+    else hipLaunchKernelGGL(lbfgs_step_kernel, grid, block, 0, s, st, val, grad, (int)first);
 }
 
 // One workgroup: thread t owns the contiguous segment [t*per, (t+1)*per) of the input list, counts its survivors, an

@@ -264,6 +264,27 @@ def test_multistart_maximizer_matches_oracle(ctx, oracle, kernel, acq, path):
     gp.close()
 
 
+@pytest.mark.parametrize("D,N,S,n_local,history", [(6, 300, 700, 40, 6), (16, 640, 3000, 30, 3), (37, 384, 2000, 30, 8), (64, 512, 1500, 25, 6),
+                                                    (70, 256, 600, 12, 6)])
+def test_lbfgs_step_register_form_is_bit_identical(ctx, oracle, D, N, S, n_local, history, monkeypatch):
+    """lbfgs_step_reg_kernel (a start's vectors in registers, D <= 64) against lbfgs_step_kernel (every pass through global
+    memory, SLS_LBFGS_REG=0; also what D > 64 runs): same expressions in the same order, so every start must end with the same
+    bits -- accepted and rejected steps, curvature pairs that are dropped, resets, backtracking, corner starts."""
+    monkeypatch.setenv("SLS_WAVE_PATH", "0")
+    X, y, theta, b = synth_problem(oracle, D, N)
+    starts = synth_candidates(oracle, D, S)
+    starts[:, ::5] = np.round(starts[:, ::5])
+    gp = sls().GP(ctx, X, y, theta, b, 1)
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SLS_LBFGS_REG", flag)
+        r = gp.acq_maximize(starts, n_local, opts=sls().LbfgsOpts(history, 1e-4, 0.5, 0.0, 20))
+        out[flag] = (r["y_stars"], r["x_stars"], r["value"], r["index"], r["x"], gp.last_stats()["evals_issued"])
+    for va, vu in zip(out["1"], out["0"]):
+        assert np.array_equal(np.asarray(va), np.asarray(vu))
+    gp.close()
+
+
 @pytest.mark.parametrize("kernel", [0, 1])
 @pytest.mark.parametrize("D,N,S,n_local,pair", [(6, 300, 700, 30, False), (16, 2048, 9000, 14, False), (4, 200, 300, 20, True)])
 def test_active_set_compaction_is_bit_identical(ctx, oracle, kernel, D, N, S, n_local, pair, monkeypatch):
