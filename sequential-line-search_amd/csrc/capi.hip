@@ -758,7 +758,8 @@ static void ensure_lbfgs(sls_gp* g, int Sp, int m) {
     if (Sp <= g->lb_Sp && m <= g->lb_m) return;
     const size_t D = g->D, S = Sp;
     g->lb_x.ensure(S * D); g->lb_g.ensure(S * D); g->lb_dir.ensure(S * D); g->lb_xt.ensure(S * D); g->lb_scr.ensure(S * D);
-    g->lb_S.ensure(S * D * m); g->lb_Y.ensure(S * D * m); g->lb_rho.ensure(S * m);
+    const size_t Dh = D <= 16 ? 16 : (D <= 64 ? 64 : D);   // lbfgs_step_reg_kernel keeps rows of 4 DPL doubles per (start, pair)
+    g->lb_S.ensure(S * Dh * m); g->lb_Y.ensure(S * Dh * m); g->lb_rho.ensure(S * m);
     g->lb_f.ensure(S); g->lb_t.ensure(S); g->lb_val.ensure(S); g->lb_grad.ensure(S * D); g->lb_xc.ensure(S * D);
     if (g->lb_int) (void)hipFree(g->lb_int);
     g->lb_int = nullptr;

@@ -8,6 +8,7 @@
 //   G_mu, G_sigma     [n + d*Sp]
 // Padding to the 128-wide GEMM tile keeps every kernel free of edge code.
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include <mutex>
@@ -90,7 +91,13 @@ void launch_var_gemm(hipStream_t s, const double* Ks, long ldk, int Sp, const do
 // Gs[n + d*ldk] = sum_i P[n,i] XT[i,d] ;  Gm[n + d*ldk] = sum_i Cs[n,i] XaT[i,d]   (d < Dcols)
 // part (D <= 64 only, may be NULL): scratch of 8 * Sp * 64 doubles; used when grad_gemm_wants_split(Sp) to spread the
 // contraction of a small launch over four times as many workgroups (same bits as the unsplit form).
-inline bool grad_gemm_wants_split(int Sp) { return 2 * (Sp / 128) < 384; }   // fewer tiles than half the chip's 768 slots
+// Always, since round 3: four times as many workgroups of a quarter of the work each fill the 768 slots evenly at every active-set
+// size (C4: 85.9 -> 79.2 ms per step including grad_reduce4_kernel).  SLS_GRAD_SPLIT_TILES=t: split only launches of fewer than
+// t tiles (0: never) -- the tests run both forms against each other.
+inline bool grad_gemm_wants_split(int Sp) {
+    const char* e = getenv("SLS_GRAD_SPLIT_TILES");
+    return e == nullptr || 2 * (Sp / 128) < atoi(e);
+}
 void launch_grad_gemm(hipStream_t s, const double* P, const double* Cs, long ldk, int Sp, const double* XT, const double* XaT,
                       long ld, int Np, int Dcols, double* Gs, double* Gm, double* part = nullptr);
 struct FinalizeArgs {

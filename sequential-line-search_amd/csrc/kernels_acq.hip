@@ -815,6 +815,19 @@ __global__ __launch_bounds__(64) void lbfgs_step_reg_kernel(LbfgsState st, const
     double* __restrict__ xt_ = st.xt;
     double* __restrict__ ShA = st.Sh; double* __restrict__ YhA = st.Yh;
     double xr[DPL], gr[DPL], dr[DPL], sn[DPL], yn[DPL];
+#pragma unroll
+    for (int e = 0; e < DPL; ++e) xr[e] = gr[e] = dr[e] = sn[e] = yn[e] = 0.0;
+    // history pair `idx` of start n: one row of 4 DPL doubles, lane q's DPL values (dimensions q, q + 4, ...) contiguous -- read
+    // and written with 16-byte accesses, and only the rows of LIVE starts are touched (lbfgs_step_kernel's [h][d][n] arrays are
+    // fetched line by line whatever is alive: 800 MB per round at 65 536 starts, the whole cost of that kernel)
+    auto hrow = [&](double* base, int idx) { return base + (((long)n * m + idx) * 4 + q) * DPL; };
+    auto hload = [&](const double* row, double (&v)[DPL]) {
+#pragma unroll
+        for (int e = 0; e < DPL; e += 2) {
+            const d2_t t = *reinterpret_cast<const d2_t*>(row + e);
+            v[e] = t[0]; v[e + 1] = t[1];
+        }
+    };
     double f_v = 0.0, t_v = 1.0;
     int hlen_v = 0, hpos_v = 0, nbt_v = 0;
     bool done = false;
@@ -863,8 +876,6 @@ __global__ __launch_bounds__(64) void lbfgs_step_reg_kernel(LbfgsState st, const
         if (ft <= f_v + st.c1 * gs) {
             double sy = 0.0, yy = 0.0;
             const int idx = hpos_v;
-            double* __restrict__ Sh = ShA + (long)idx * D * ld;
-            double* __restrict__ Yh = YhA + (long)idx * D * ld;
 #pragma unroll
             for (int e = 0; e < DPL; ++e) {
                 const int d = q + 4 * e;
@@ -872,8 +883,6 @@ __global__ __launch_bounds__(64) void lbfgs_step_reg_kernel(LbfgsState st, const
                     const double xtd = xtr[e], gtd = -grad[j + d * ldv];
                     const double sd = xtd - xr[e];
                     const double yd = gtd - gr[e];
-                    Sh[n + d * ld] = sd;
-                    Yh[n + d * ld] = yd;
                     sn[e] = sd;
                     yn[e] = yd;
                     sy += sd * yd;
@@ -882,6 +891,15 @@ __global__ __launch_bounds__(64) void lbfgs_step_reg_kernel(LbfgsState st, const
                     gr[e] = gtd;
                     x_[n + d * ld] = xtd;
                     g_[n + d * ld] = gtd;
+                }
+            }
+            {
+                double* __restrict__ Sh = hrow(ShA, idx);
+                double* __restrict__ Yh = hrow(YhA, idx);
+#pragma unroll
+                for (int e = 0; e < DPL; e += 2) {
+                    *reinterpret_cast<d2_t*>(Sh + e) = d2_t{sn[e], sn[e + 1]};
+                    *reinterpret_cast<d2_t*>(Yh + e) = d2_t{yn[e], yn[e + 1]};
                 }
             }
             sy = gsum(sy);
@@ -934,15 +952,10 @@ __global__ __launch_bounds__(64) void lbfgs_step_reg_kernel(LbfgsState st, const
                 al[h] = 0.0;
                 if (h < m) {                                       // uniform; the ring has m valid slots
                     const int idx = (hpos - 1 - h + 2 * m) % m;
-                    const double* __restrict__ Sh = ShA + (long)idx * D * ld;
-                    const double* __restrict__ Yh = YhA + (long)idx * D * ld;
                     const bool newest = h == 0 && have_new;
                     double sh[DPL], yh[DPL];
-#pragma unroll
-                    for (int e = 0; e < DPL; ++e) {
-                        const int d = q + 4 * e;
-                        if (d < D) { sh[e] = Sh[n + d * ld]; yh[e] = Yh[n + d * ld]; }
-                    }
+                    hload(hrow(ShA, idx), sh);
+                    hload(hrow(YhA, idx), yh);
                     const double rho = st.rho[(long)idx * ld + n];
                     if (h < hlen) {
                         double dot = 0.0;
@@ -959,15 +972,15 @@ __global__ __launch_bounds__(64) void lbfgs_step_reg_kernel(LbfgsState st, const
             double gamma;
             if (hlen > 0) {
                 const int idx = (hpos - 1 + m) % m;
-                const double* __restrict__ Sh = ShA + (long)idx * D * ld;
-                const double* __restrict__ Yh = YhA + (long)idx * D * ld;
+                double sh[DPL], yh[DPL];
+                hload(hrow(ShA, idx), sh);
+                hload(hrow(YhA, idx), yh);
                 double sy = 0.0, yy = 0.0;
 #pragma unroll
                 for (int e = 0; e < DPL; ++e) {
-                    const int d = q + 4 * e;
-                    if (d < D) {
-                        const double sv = have_new ? sn[e] : Sh[n + d * ld];
-                        const double yv = have_new ? yn[e] : Yh[n + d * ld];
+                    if (q + 4 * e < D) {
+                        const double sv = have_new ? sn[e] : sh[e];
+                        const double yv = have_new ? yn[e] : yh[e];
                         sy += sv * yv;
                         yy += yv * yv;
                     }
@@ -984,15 +997,10 @@ __global__ __launch_bounds__(64) void lbfgs_step_reg_kernel(LbfgsState st, const
             for (int h = 7; h >= 0; --h) {
                 if (h < m) {
                     const int idx = (hpos - 1 - h + 2 * m) % m;
-                    const double* __restrict__ Sh = ShA + (long)idx * D * ld;
-                    const double* __restrict__ Yh = YhA + (long)idx * D * ld;
                     const bool newest = h == 0 && have_new;
                     double sh[DPL], yh[DPL];
-#pragma unroll
-                    for (int e = 0; e < DPL; ++e) {
-                        const int d = q + 4 * e;
-                        if (d < D) { sh[e] = Sh[n + d * ld]; yh[e] = Yh[n + d * ld]; }
-                    }
+                    hload(hrow(ShA, idx), sh);
+                    hload(hrow(YhA, idx), yh);
                     const double rho = st.rho[(long)idx * ld + n];
                     if (h < hlen) {
                         double dot = 0.0;

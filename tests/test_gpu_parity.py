@@ -264,6 +264,25 @@ def test_multistart_maximizer_matches_oracle(ctx, oracle, kernel, acq, path):
     gp.close()
 
 
+@pytest.mark.parametrize("kernel", [0, 1])
+@pytest.mark.parametrize("D,N,M", [(8, 640, 1000), (64, 1024, 5000), (33, 384, 130)])
+def test_gradient_contraction_split_is_bit_identical(ctx, oracle, kernel, D, N, M, monkeypatch):
+    """grad_gemm64_kernel sums the contraction over the training points as four quarter ranges, ((q0 + q1) + q2) + q3: by one
+    workgroup per tile (SLS_GRAD_SPLIT_TILES=0) or by four workgroups + grad_reduce4_kernel (default).  Same bits."""
+    X, y, theta, b = synth_problem(oracle, D, N)
+    Xs = synth_candidates(oracle, D, M)
+    gp = sls().GP(ctx, X, y, theta, b, kernel)
+    out = []
+    for flag in (None, "0"):
+        if flag is None:
+            monkeypatch.delenv("SLS_GRAD_SPLIT_TILES", raising=False)
+        else:
+            monkeypatch.setenv("SLS_GRAD_SPLIT_TILES", flag)
+        out.append(gp.acq_eval(Xs, 0, 1.0, want_grad=True))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    gp.close()
+
+
 @pytest.mark.parametrize("D,N,S,n_local,history", [(6, 300, 700, 40, 6), (16, 640, 3000, 30, 3), (37, 384, 2000, 30, 8), (64, 512, 1500, 25, 6),
                                                     (70, 256, 600, 12, 6)])
 def test_lbfgs_step_register_form_is_bit_identical(ctx, oracle, D, N, S, n_local, history, monkeypatch):
