@@ -176,6 +176,10 @@ sls_gp* sls_multi_gp_shard(sls_multi_gp* g, int shard);
  * index of the winner; evals_issued (may be NULL) sums the shards' sls_acq_last_stats. */
 int sls_multi_acq_maximize(sls_multi_gp* g, int acq_type, double ucb_h, const double* starts, int S, int n_local,
                            const sls_lbfgs_opts* opts, double* x_out, double* val_out, long* idx_out, long* evals_issued);
+/* sls_gp_predict over all devices: the M points (D x M, host) are split into contiguous column slices, shard r predicts its
+ * slice on its device and writes mu / sigma at the slice's offset (gaussian-process-regressor.cpp:234-255 for M points; no
+ * collective -- the outputs are disjoint).  A point's arithmetic does not depend on its slice: bit-identical to sls_gp_predict. */
+int sls_multi_gp_predict(sls_multi_gp* g, const double* Xs, int M, double* mu, double* sigma);
 /* GP MAP objective over the devices of `m`: the B independent points of one DIRECT iteration of PerformMapEstimation
    (src/gaussian-process-regressor.cpp:294) dealt round-robin, point k on shard k mod n, values gathered through host memory (no
    collective; the N^3 factorisation of ONE evaluation does not shard).  Bit-identical to sls_gp_nll_batch on one device. */

@@ -54,7 +54,7 @@ EXPORTS = [
     "sls_multi_gp_nll_batch",
     "sls_pref_objective", "sls_acq_eval_pair", "sls_acq_maximize_pair", "sls_gp_append_point", "sls_acq_last_stats",
     "sls_multi_create", "sls_multi_destroy", "sls_multi_size", "sls_multi_exchange", "sls_multi_ctx", "sls_multi_gp_create",
-    "sls_multi_gp_destroy", "sls_multi_gp_shard", "sls_multi_acq_maximize", "sls_comm_unique_id", "sls_comm_create",
+    "sls_multi_gp_destroy", "sls_multi_gp_shard", "sls_multi_acq_maximize", "sls_multi_gp_predict", "sls_comm_unique_id", "sls_comm_create",
     "sls_comm_destroy", "sls_comm_allgather_best", "sls_device_trim_cache",
 ]
 
@@ -380,6 +380,14 @@ class MultiGP:
                                          C.byref(opts) if opts is not None else None, _p(x), C.byref(val), C.byref(idx),
                                          C.byref(issued)))
         return dict(index=idx.value, x=x, value=val.value, evals_issued=issued.value)
+
+    def predict(self, Xs):
+        """PredictMu / PredictSigma at the M columns of Xs, the columns sharded over the devices (sls_multi_gp_predict)."""
+        Xs = _f(Xs)
+        M = Xs.shape[1]
+        mu, sigma = np.empty(M), np.empty(M)
+        _ck(lib().sls_multi_gp_predict(self.h, _p(Xs), M, _p(mu), _p(sigma)))
+        return mu, sigma
 
 
 class MultiNll:

@@ -383,6 +383,19 @@ extern "C" int sls_multi_acq_maximize(sls_multi_gp* g, int acq_type, double ucb_
     return SLS_OK;
 }
 
+extern "C" int sls_multi_gp_predict(sls_multi_gp* g, const double* Xs, int M, double* mu, double* sigma) {
+    try {
+        SLS_REQUIRE(g && Xs && M >= 0, "sls_multi_gp_predict: bad argument");
+        const int n = (int)g->m->devices.size(), D = g->D;
+        return for_each_shard(n, [&](int r) {
+            int lo, hi;
+            shard_range(M, r, n, &lo, &hi);
+            if (hi <= lo) return (int)SLS_OK;
+            return sls_gp_predict(g->gps[r], Xs + (size_t)lo * D, hi - lo, mu ? mu + lo : nullptr, sigma ? sigma + lo : nullptr);
+        });
+    } catch (const HipFail& f) { return f.code; }
+}
+
 // ---- MAP objective over several devices: the B independent points of one DIRECT iteration dealt round-robin ----------------
 // The N^3 factorisation of one evaluation does not shard; the evaluations of a batch do: point k runs on shard
 // k mod n, each shard one sls_gp_nll_batch over its points, the values come back through host memory (no collective: B doubles).

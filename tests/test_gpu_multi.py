@@ -35,6 +35,24 @@ def test_sharded_maximisation_reproduces_single_device_winner(oracle, devices):
     mgp.close(); multi.close(); gp.close(); ctx.close()
 
 
+@pytest.mark.parametrize("M", [1, 2, 4096])
+def test_sharded_predict_is_bit_identical(oracle, M):
+    """BASELINE config C2's predict over several devices (candidate columns shard with no collective): three
+    logical shards on the one GPU, against the single-device call -- also with fewer points than shards."""
+    m = sls()
+    D, N = 16, 2048 if M > 2 else 300
+    X, y, theta, b = synth_problem(oracle, D, N)
+    Xs = synth_candidates(oracle, D, M)
+    ctx = m.Context(0)
+    gp = m.GP(ctx, X, y, theta, b, 0)
+    mu1, s1 = gp.predict(Xs)
+    multi = m.Multi([0, 0, 0])
+    mgp = m.MultiGP(multi, X, y, theta, b, 0)
+    mu3, s3 = mgp.predict(Xs)
+    assert np.array_equal(mu1, mu3) and np.array_equal(s1, s3)
+    mgp.close(); multi.close(); gp.close(); ctx.close()
+
+
 def test_more_shards_than_starts_and_ties():
     """Two starts over three shards (one shard idle), identical starts (a tie: the lowest global index wins)."""
     m = sls()
