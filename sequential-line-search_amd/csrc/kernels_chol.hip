@@ -1234,20 +1234,25 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
                     ca.zero();
                     chain_gemm<true>(ca, Asub, ld, Tjj, ld, lds);                     // L_{j+1,j} = A_{j+1,j} T_jj^T (ends with a barrier)
                 }
+                PK_STAMP(5);                                                          // (5 .. 9: fine stamps, POTRF_BENCH_FINE=1 in the probe)
                 chain_acc_to_image<true>(ca, lds);
             }
             lds_barrier();
+            PK_STAMP(6);
             chain_image_store_wt(Asub, ld, lds);
+            PK_STAMP(7);
             df_publish_store(panel_done + (j + 1) + (long)j * nb);                    // drains every wave's stores
             PK_STAMP(2);
             {
                 ChainAcc ca;
                 ca.zero();
                 chain_syrk_image(ca, lds);                                            // L_{j+1,j} L_{j+1,j}^T, operand in LDS
+                PK_STAMP(8);
                 lds_barrier();                                                        // every wave has read the operand
                 chain_acc_to_image<false>(ca, lds);
             }
             lds_barrier();
+            PK_STAMP(9);
             chain_image_rsub(Anext, ld, lds);                                         // image = A_{j+1,j+1} - L L^T, zero above
             __syncthreads();
             PK_STAMP(3);

@@ -145,6 +145,9 @@ int main(int argc, char** argv) {
                     waited += us(g[1]);
                     if (j < 4 || j % 8 == 0 || j > nb - 3)
                         printf("  %3d | %7.1f %6.1f %6.1f %6.1f | %8.1f\n", j, us(g[1]), us(g[2]), us(g[3]), us(g[4]), ((double)g[0] - (double)ht[0]) / 100.0);
+                    if (getenv("POTRF_BENCH_FINE") && j >= 1 && j < 4)
+                        printf("        fine: solve loop done %.1f  image %.1f  stores issued %.1f  published %.1f | LL^T MFMAs done %.1f  image %.1f  tile subtracted %.1f\n",
+                               us(g[5]), us(g[6]), us(g[7]), us(g[2]), us(g[8]), us(g[9]), us(g[3]));
                 }
                 printf("  chain waited %.1f us in total for its tiles\n", waited);
                 hipFree(tr);
