@@ -1028,29 +1028,57 @@ __device__ __forceinline__ void chain_image_store_wt(double* __restrict__ C, lon
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rsrc, (int)((2 * lane + (long)c * ld) * 8), 0, 16);
     }
 }
-// C -= A A^T on the lower 16 x 16 blocks with A (128 x 128, element (m, k) at img[m + k DL]) resident in LDS: the MFMA
-// sequence of chain_gemm<false> (slab by slab, k ascending) without its loads and barriers -- same bits.
-__device__ __forceinline__ void chain_syrk_image(ChainAcc& acc, const double* img) {
+// A A^T on the lower 16 x 16 blocks with A (128 x 128, element (m, k) at img[m + k DL]) resident in LDS: the MFMA sequence of
+// chain_gemm<false> per block (slab by slab, k ascending) without its loads and barriers -- same bits -- but with FEWER FRAGMENT
+// READS: the 36 lower blocks are dealt to the waves as 3 x 3 groups (wave 0: rows 5-7 x
+// columns 0-2, wave 1: rows 5-7 x columns 3-5, wave 2: rows 2-4 x columns 0-2, wave 3: the three 2 x 2 triangles on the
+// diagonal), so a wave reads 5-6 fragments per k step for its nine MFMAs instead of 10-11 (rows w and 7 - w against every column
+// block) -- the A and B fragments of a row block are the same LDS words.  Measured with the fine stamps (POTRF_BENCH_FINE=1):
+// the chain's products are bounded by their LDS reads (11.0 us for 7.7 us of MFMA work; 12.4 us with 18 reads per nine MFMAs).
+// Every block still sums its k in ascending order: same bits.  Result -> image in place (one barrier inside: every wave has
+// read the operand before anybody overwrites it).
+template <int W>
+__device__ __forceinline__ void chain_syrk_inplace_wave(double* img) {
+    constexpr int NB9[4][9][2] = {
+        {{5, 0}, {5, 1}, {5, 2}, {6, 0}, {6, 1}, {6, 2}, {7, 0}, {7, 1}, {7, 2}},
+        {{5, 3}, {5, 4}, {5, 5}, {6, 3}, {6, 4}, {6, 5}, {7, 3}, {7, 4}, {7, 5}},
+        {{2, 0}, {2, 1}, {2, 2}, {3, 0}, {3, 1}, {3, 2}, {4, 0}, {4, 1}, {4, 2}},
+        {{0, 0}, {1, 0}, {1, 1}, {3, 3}, {4, 3}, {4, 4}, {6, 6}, {7, 6}, {7, 7}}};
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int mi0 = wave, mi1 = 7 - wave;
+    const int l0 = (lane >> 4) * GEMM_LDS_MC_LD + (lane & 15);
+    d4_t acc[9];
+#pragma unroll
+    for (int p = 0; p < 9; ++p) acc[p] = d4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        const double* la = img + s * GEMM_LDS_TILE;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            const int krow = (4 * kk + (lane >> 4)) * GEMM_LDS_MC_LD + (lane & 15);
-            const double a0 = la[krow + 16 * mi0], a1 = la[krow + 16 * mi1];
+            const double* la = img + s * GEMM_LDS_TILE + 4 * kk * GEMM_LDS_MC_LD + l0;
+            double f[8];
 #pragma unroll
-            for (int nj = 0; nj < 8; ++nj) {
-                if (nj <= mi1) {
-                    const double bf = la[krow + 16 * nj];
-                    if (nj <= mi0) acc.v[0][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf, a0, acc.v[0][nj], 0, 0, 0);
-                    acc.v[1][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf, a1, acc.v[1][nj], 0, 0, 0);
-                }
+            for (int b = 0; b < 8; ++b) {
+                bool used = false;
+#pragma unroll
+                for (int p = 0; p < 9; ++p) used = used || NB9[W][p][0] == b || NB9[W][p][1] == b;
+                if (used) f[b] = la[16 * b];
             }
+#pragma unroll
+            for (int p = 0; p < 9; ++p) acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[NB9[W][p][1]], f[NB9[W][p][0]], acc[p], 0, 0, 0);
         }
     }
+    lds_barrier();
+#pragma unroll
+    for (int p = 0; p < 9; ++p)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            img[(16 * NB9[W][p][1] + (lane >> 4) + 4 * r) * DL + 16 * NB9[W][p][0] + (lane & 15)] = acc[p][r];
+}
+__device__ __forceinline__ void chain_syrk_inplace(double* img) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave == 0) chain_syrk_inplace_wave<0>(img);
+    else if (wave == 1) chain_syrk_inplace_wave<1>(img);
+    else if (wave == 2) chain_syrk_inplace_wave<2>(img);
+    else chain_syrk_inplace_wave<3>(img);
 }
 // image <- (global tile) - image on the lower 16 x 16 blocks, zero above: diag_block's input, built in place
 __device__ __forceinline__ void chain_image_rsub(const double* __restrict__ C, long ld, double* img) {
@@ -1152,13 +1180,7 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             chain_image_store_wt(Asub, ld, lds);
             df_publish_store(panel_done + (k + 1) + (long)k * nb);
             PK_STAMP(2);
-            {
-                ChainAcc ca;
-                ca.zero();
-                chain_syrk_image(ca, lds);
-                lds_barrier();
-                chain_acc_to_image<false>(ca, lds);
-            }
+            chain_syrk_inplace(lds);
             lds_barrier();
             chain_image_rsub(Anext, ld, lds);
             PK_STAMP(3);
@@ -1243,14 +1265,8 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             PK_STAMP(7);
             df_publish_store(panel_done + (j + 1) + (long)j * nb);                    // drains every wave's stores
             PK_STAMP(2);
-            {
-                ChainAcc ca;
-                ca.zero();
-                chain_syrk_image(ca, lds);                                            // L_{j+1,j} L_{j+1,j}^T, operand in LDS
-                PK_STAMP(8);
-                lds_barrier();                                                        // every wave has read the operand
-                chain_acc_to_image<false>(ca, lds);
-            }
+            chain_syrk_inplace(lds);                                                  // image <- L_{j+1,j} L_{j+1,j}^T, operand = the image
+            PK_STAMP(8);
             lds_barrier();
             PK_STAMP(9);
             chain_image_rsub(Anext, ld, lds);                                         // image = A_{j+1,j+1} - L L^T, zero above
