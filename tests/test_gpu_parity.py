@@ -697,9 +697,25 @@ def test_pair_objective_of_find_next_points(ctx, oracle, acq):
     g1.close(); g2.close()
 
 
-@pytest.mark.parametrize("seed", range(10))
+def _within(x, ref, rtol, atol):
+    x, ref = np.asarray(x, dtype=float), np.asarray(ref, dtype=float)
+    return bool(np.all(np.abs(x - ref) <= rtol * np.abs(ref) + atol))
+
+
+@pytest.mark.parametrize("seed", range(10 + int(os.environ.get("SLS_TEST_EXTRA_SEEDS", "0"))))   # extra seeds: one-off stress sweeps
 def test_randomised_configurations(ctx, oracle, seed, path):
-    """Random problem shapes / hyper-parameters (ragged sizes, anisotropic length scales, noise from 1e-6 to 1e-1)."""
+    """Random problem shapes / hyper-parameters (ragged sizes, anisotropic length scales, noise from 1e-6 to 1e-1).
+
+    north_star's 1e-6 holds FLAT for the 20 committed cases (seeds 0-9 on both paths: measured max 2.6e-11 on sigma, 1.4e-12 on
+    EI / UCB, 2.2e-12 on gradients, kappa up to 7e7).  It cannot hold for every input: sigma^2 = a - k^T K_y^-1 k is a
+    cancellation, and with the reference's formula (explicit inverse, src/gaussian-process-regressor.cpp:245-255) its fp64
+    error is of the order cond(K_y) eps a, i.e. cond eps a / (2 sigma) on sigma.  A sweep of 490 more seeds
+    (SLS_TEST_EXTRA_SEEDS=490, profiles/r03_random_sweep.json) has such cases, e.g. seed 46: sigma down to 1e-3 at cond 2.6e6,
+    seed 67: sigma down to 9e-4 at cond 6.5e7 -- where the oracle (the reference's formula) AND the HIP path (explicit L^-1 /
+    K_y^-1 as well) are each off by 1e-8 / 1e-6 against an extended-precision solve, LAPACK's solve-based evaluation by 1e-12
+    (tools/seed_conditioning.py, profiles/r03_seed_conditioning.log); in 500 seeds, 12 are of this kind, all with D <= 5 and
+    sigma_min <= 3e-3.  Every case must therefore agree within 1e-6 PLUS that first-order bound (which is zero to working
+    precision unless the problem is ill-conditioned AND sigma is tiny); the record says which cases needed the second term."""
     rng = np.random.default_rng(1000 + seed)
     D = int(rng.integers(1, 40)); N = int(rng.integers(2, 400)); M = int(rng.integers(1, 300)); kernel = int(rng.integers(0, 2))
     X = rng.uniform(0, 1, (D, N))
@@ -711,25 +727,40 @@ def test_randomised_configurations(ctx, oracle, seed, path):
     ref = oracle.Regressor(X, y, theta, b, kernel=kernel)
     mu, sg = gp.predict(Xs); muo, sgo = ref.predict_batch(Xs)
     scale = max(np.abs(muo).max(), 1e-30)
-    close(mu, muo, rtol=RTOL, atol=1e-6 * scale)
-    # north_star's 1e-6 for every seed: measured on MI355X the largest deviations over the 20 cases are 2.6e-11 (sigma), 1.4e-12
-    # (EI, UCB) and 2.2e-12 (gradients) although kappa(K_y) reaches 7e7 at b = 1e-6 (gpurun_out/test_evidence.json names every
-    # seed with its kappa and errors; earlier rounds ran this test at 1e-5 / 1e-4 without knowing that none of them needs it)
-    kappa = theta[0] * N / b
-    tol_v = tol_g = 1e-6
+    eps = np.finfo(float).eps
+    kappa = (theta[0] * N + b) / b                         # >= cond(K_y): eigenvalues in [b, a N + b]
+    d_s2 = kappa * eps * theta[0]                          # first-order fp64 error of k^T K_y^-1 k through an explicit inverse
+    d_sigma = d_s2 / (2.0 * np.maximum(sgo, 1e-150))       # ... of sigma, per point
+    d_mu = kappa * eps * np.abs(y).max()
+    strict = True                                          # every comparison within the flat 1e-6?
+    strict &= _within(mu, muo, RTOL, 1e-6 * scale)
+    assert _within(mu, muo, RTOL, 1e-6 * scale + d_mu)
+    a_sig = 1e-7 * np.sqrt(theta[0])
+    strict &= _within(sg, sgo, 1e-6, a_sig)
+    assert _within(sg, sgo, 1e-6, a_sig + d_sigma), (np.max(np.abs(sg - sgo)), kappa)
     errs = dict(sigma=relerr(sg, np.maximum(sgo, 1e-7 * np.sqrt(theta[0]))))
-    close(sg, sgo, rtol=tol_v, atol=1e-7 * np.sqrt(theta[0]))
     for acq, h in ((0, 1.0), (1, 0.7)):
         v, g = gp.acq_eval(Xs, acq, h); vo, go = ref.acq_eval_batch(Xs, acq, h)
-        close(v, vo, rtol=tol_v, atol=1e-7 * max(np.abs(vo).max(), 1e-30))
+        a_v = 1e-7 * max(np.abs(vo).max(), 1e-30)
+        d_v = (0.4 * d_sigma + d_mu) if acq == 0 else (d_mu + h * d_sigma)      # |dEI/dsigma| = phi <= 0.4, |dEI/dmu| = Phi <= 1
+        strict &= _within(v, vo, 1e-6, a_v)
+        assert _within(v, vo, 1e-6, a_v + d_v), (acq, np.max(np.abs(v - vo)), kappa)
         finite = np.isfinite(go)
         assert np.array_equal(np.isfinite(g), finite)
-        close(g[finite], go[finite], rtol=tol_g, atol=1e-6 * max(np.abs(go[finite]).max(), 1e-30))
+        gmax = max(np.abs(go[finite]).max(), 1e-30) if finite.any() else 1.0
+        # gradients carry 1 / sigma and, through phi(z) and Phi(z), z = (mu - mu+) / sigma: the relative bound of sigma per column
+        # times (1 + z^2) <~ 50, on the column's largest component
+        colmax = np.max(np.abs(np.where(finite, go, 0.0)), axis=0, keepdims=True)
+        d_g = 50.0 * (d_sigma / np.maximum(sgo, 1e-150))[None, :] * colmax + np.zeros_like(go)
+        strict &= _within(g[finite], go[finite], 1e-6, 1e-6 * gmax)
+        assert _within(g[finite], go[finite], 1e-6, 1e-6 * gmax + d_g[finite]), (acq, kappa)
         errs[f"acq{acq}"] = float(np.max(np.abs(v - vo)) / max(np.abs(vo).max(), 1e-30))
-        errs[f"grad{acq}"] = float(np.max(np.abs(g[finite] - go[finite])) / max(np.abs(go[finite]).max(), 1e-30)) if finite.any() else 0.0
+        errs[f"grad{acq}"] = float(np.max(np.abs(g[finite] - go[finite])) / gmax) if finite.any() else 0.0
+    if seed < 10:
+        assert strict, "a committed case no longer holds at the flat 1e-6"
     from util import record
-    record("randomised", seed=int(seed), path=path, D=D, N=N, M=M, kernel=kernel, b=b, kappa=float(kappa), tol_values=float(tol_v),
-           tol_grads=float(tol_g), **errs)
+    record("randomised", seed=int(seed), path=path, D=D, N=N, M=M, kernel=kernel, b=b, kappa=float(kappa), flat_1e6=bool(strict),
+           sigma_min=float(np.min(sgo)), bound_sigma_rel=float(np.max(d_sigma / np.maximum(sgo, 1e-150))), **errs)
     gp.close()
 
 
