@@ -138,3 +138,59 @@ def test_random_append_equals_refit(ctx, oracle, seed):
     v1 = gp.acq_eval(Xs, 0, 1.0, want_grad=False); v2 = full.acq_eval(Xs, 0, 1.0, want_grad=False)
     assert np.all(np.abs(v1 - v2) <= 1e-6 * max(np.abs(v2).max(), 1e-30) + 0.4 * d_sigma)
     gp.close(); full.close()
+
+
+@pytest.mark.parametrize("seed", range(4 + EXTRA))
+def test_random_preference_objective(ctx, oracle, seed, monkeypatch):
+    """PreferenceRegressor's MAP objective (src/preference-regressor.cpp:53-291) at random data: M points in random preference
+    tuples of 2-5 indices, goodness values of random scale, with / without the hyper-parameters in the argument, both kernels,
+    fused small kernel or tiled pipeline -- value 1e-9, gradient 1e-6 of its largest component (+ conditioning term)."""
+    rng = np.random.default_rng(9000 + seed)
+    D = int(rng.integers(1, 16)); M = int(rng.integers(3, 160)); kernel = int(rng.integers(0, 2)); use_map = bool(rng.integers(0, 2))
+    X = rng.uniform(0, 1, (D, M))
+    prefs = []
+    for _ in range(int(rng.integers(1, max(2, M // 2)))):
+        n = int(rng.integers(2, min(6, M + 1)))
+        prefs.append([int(i) for i in rng.choice(M, size=n, replace=False)])
+    yv = rng.normal(0, 10 ** rng.uniform(-2.5, -1.0), M)
+    a = rng.uniform(0.2, 1.0); b = float(10 ** rng.uniform(-4, -1.5))
+    x = np.concatenate([yv, [a, b], rng.uniform(0.3, 0.9, D)]) if use_map else yv
+    kw = {} if use_map else dict(a=a, b=b, r=float(rng.uniform(0.3, 0.9)))
+    vo, go = oracle.pref_objective(kernel, X, prefs, x, use_map=use_map, **kw)
+    if rng.integers(0, 2):
+        monkeypatch.setenv("SLS_NLL_SMALL", "0")
+    h = sls().Nll(ctx, X, kernel)
+    v, g = h.pref_objective(prefs, x, use_map=use_map, **kw)
+    kappa = (a * M + b) / b
+    eps = np.finfo(float).eps
+    assert abs(v - vo) <= 1e-9 * abs(vo) + 1e3 * kappa * eps * (1.0 + float(yv @ yv) / a), (v, vo)
+    gmax = np.abs(go).max()
+    assert np.max(np.abs(g - go)) <= 1e-6 * gmax + 1e3 * kappa * eps * gmax, (np.max(np.abs(g - go)) / gmax, kappa)
+    record("stress_pref", seed=int(seed), D=D, M=M, kernel=kernel, use_map=use_map, value_rel=float(abs(v - vo) / abs(vo)),
+           grad_rel=float(np.max(np.abs(g - go)) / gmax))
+    h.close()
+
+
+@pytest.mark.parametrize("seed", range(3 + EXTRA // 4))
+def test_random_sharded_maximisation_is_bit_identical(oracle, seed):
+    """sls_multi_acq_maximize over 2-5 logical shards of the one GPU against the single-device call at random shapes: winner index,
+    value and point bit for bit, and the same evaluation count (every start retires at the same evaluation)."""
+    rng = np.random.default_rng(9500 + seed)
+    m = sls()
+    D = int(rng.integers(1, 12)); N = int(rng.integers(3, 400)); S = int(rng.integers(1, 700)); kernel = int(rng.integers(0, 2))
+    n_local = int(rng.integers(2, 16)); shards = int(rng.integers(2, 6))
+    X = rng.uniform(0, 1, (D, N))
+    y = np.sin(X.sum(axis=0) * 2.5) + 0.05 * rng.normal(size=N)
+    theta = np.concatenate([[rng.uniform(0.2, 1.5)], rng.uniform(0.3, 1.2, D) * np.sqrt(max(D, 4) / 4.0)])
+    b = float(10 ** rng.uniform(-4, -1))
+    starts = rng.uniform(0, 1, (D, S))
+    c = m.Context(0)
+    gp = m.GP(c, X, y, theta, b, kernel)
+    one = gp.acq_maximize(starts, n_local)
+    issued = gp.last_stats()["evals_issued"]
+    multi = m.Multi([0] * shards)
+    mgp = m.MultiGP(multi, X, y, theta, b, kernel)
+    r = mgp.acq_maximize(starts, n_local)
+    assert r["index"] == one["index"] and r["value"] == one["value"] and np.array_equal(r["x"], one["x"]), (seed, shards, S)
+    assert r["evals_issued"] == issued
+    mgp.close(); multi.close(); gp.close(); c.close()
