@@ -194,3 +194,23 @@ def test_random_sharded_maximisation_is_bit_identical(oracle, seed):
     assert r["index"] == one["index"] and r["value"] == one["value"] and np.array_equal(r["x"], one["x"]), (seed, shards, S)
     assert r["evals_issued"] == issued
     mgp.close(); multi.close(); gp.close(); c.close()
+
+
+@pytest.mark.parametrize("N", [2049, 3001, 4999])
+def test_large_ragged_orders(ctx, N):
+    """Orders that are not multiples of the 128 tile, in the range of the single-launch dataflow Cholesky with many tiles per
+    owner (identity padding inside the last tile row): factor, solve and inverse against numpy's residual bounds."""
+    rng = np.random.default_rng(N)
+    Q = rng.normal(size=(N, 64))
+    A = Q @ Q.T / 64 + np.diag(10.0 ** rng.uniform(-3, 0, N))
+    L = ctx.potrf(A)
+    eps = np.finfo(float).eps
+    nA = np.abs(A).max()
+    assert np.all(np.triu(L, 1) == 0)
+    assert np.max(np.abs(L @ L.T - A)) <= 50 * N * eps * nA
+    B = rng.normal(size=(N, 3))
+    Xs = ctx.potrs(L, B)
+    assert np.max(np.abs(A @ Xs - B)) <= 1e3 * N * eps * (nA * np.abs(Xs).max() + np.abs(B).max())
+    Ai = ctx.potri(L)
+    assert np.array_equal(Ai, Ai.T)
+    assert np.max(np.abs(A @ Ai - np.eye(N))) <= 1e3 * N * eps * np.linalg.cond(A)
