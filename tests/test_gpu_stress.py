@@ -214,3 +214,40 @@ def test_large_ragged_orders(ctx, N):
     Ai = ctx.potri(L)
     assert np.array_equal(Ai, Ai.T)
     assert np.max(np.abs(A @ Ai - np.eye(N))) <= 1e3 * N * eps * np.linalg.cond(A)
+
+
+@pytest.mark.parametrize("seed", range(3 + EXTRA // 4))
+def test_random_gp_map_fit_ends_at_a_bounded_stationary_point(ctx, seed):
+    """GaussianProcessRegressor(X, y, kernel) -- PerformMapEstimation (src/gaussian-process-regressor.cpp:274-299) through the
+    restated C++ class -- on random data: the fit must return finite hyper-parameters inside the reference's box, not below the
+    DIRECT point or the prior medians, with a projected gradient (in the log-parameters the local phase runs in, from an
+    independent device evaluation) of at most 1e-4 |objective| unless the 1000-evaluation cap of the local phase was reached."""
+    import ctypes as C
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sls().lib()
+    host = C.CDLL(os.path.join(root, "sequential-line-search_amd", "libsequential-line-search.so"))
+    dp = C.POINTER(C.c_double)
+    host.slsh_gp_map_fit.argtypes = [dp, C.c_int, C.c_int, dp, C.c_int, dp, dp]
+    host.slsh_last_error.restype = C.c_char_p
+    rng = np.random.default_rng(9700 + seed)
+    D = int(rng.integers(1, 9)); N = int(rng.integers(3, 160)); kernel = int(rng.integers(0, 2))
+    X = np.asfortranarray(rng.uniform(0, 1, (D, N)))
+    y = np.ascontiguousarray(np.sin(X.sum(axis=0) * rng.uniform(1, 5)) * rng.uniform(0.2, 2.0) + 10 ** rng.uniform(-3, -1) * rng.normal(size=N))
+    x = np.zeros(D + 2); st = np.zeros(8)
+    rc = host.slsh_gp_map_fit(X.ctypes.data_as(dp), D, N, y.ctypes.data_as(dp), kernel, x.ctypes.data_as(dp), st.ctypes.data_as(dp))
+    assert rc == 0, host.slsh_last_error()
+    final, direct, prior, evals_local = st[0], st[1], st[2], int(st[4])
+    lo, hi = np.log(1e-8), np.log(50.0)
+    assert np.all(np.isfinite(x)) and np.all(x > 0) and np.all(np.log(x) >= lo - 1e-9) and np.all(np.log(x) <= hi + 1e-9)
+    assert final >= direct - 1e-9 * max(1.0, abs(final)) and final >= prior - 1e-9 * max(1.0, abs(final))
+    h = sls().Nll(ctx, X, kernel)
+    v, g = h.gp_objective(y, x)
+    h.close()
+    assert abs(v - final) <= 1e-9 * max(1.0, abs(v))
+    gz = g * x
+    z = np.log(x)
+    gz[(z <= lo + 1e-12) & (gz < 0)] = 0.0
+    gz[(z >= hi - 1e-12) & (gz > 0)] = 0.0
+    record("stress_map_fit", seed=int(seed), D=D, N=N, kernel=kernel, objective=float(final), pg_over_obj=float(np.max(np.abs(gz)) / max(1.0, abs(v))),
+           evals_local=evals_local)
+    assert evals_local >= 1000 or np.max(np.abs(gz)) <= 1e-4 * max(1.0, abs(v)), (np.max(np.abs(gz)), v, evals_local)
