@@ -1453,6 +1453,10 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
 // would each get part of the chip, spin for the rest until the bounded waits expire and fall back to the multi-launch
 // schedule.  They are therefore serialised per device: a launch first waits (on the host) for the previous one's completion
 // event.  Processes sharing a GPU are not covered; there the fallback + re-arm path takes over.
+static int envi(const char* n, int dflt) {
+    const char* v = getenv(n);
+    return v ? atoi(v) : dflt;
+}
 namespace {
 struct PersistSerial {
     std::mutex m;
@@ -1515,7 +1519,7 @@ void launch_potrf_persistent(hipStream_t s, double* A, int Np, double* Linv, int
     (void)hipMemsetAsync(sync, 0, (size_t)(PK_FLAGS + 2 * nb) * sizeof(int), s);
     PersistArgs a;
     a.A = A; a.ld = Np; a.nb = nb; a.Linv = Linv; a.info = info; a.sync = sync;
-    a.timeout = 20000000LL;   // 0.2 s of the 100 MHz wall clock
+    a.timeout = envi("SLS_POTRF_TIMEOUT_TICKS", 20000000);   // 0.2 s of the 100 MHz wall clock (test hook: 1 makes every wait expire)
     a.trace = trace;
     a.nbo = potrf_persistent_nbo(Np);
     a.j0 = 0; a.j1 = nb; a.k0 = 0; a.ext_flag = nullptr; a.pr = 1; a.map = 0; a.near = 0; a.acq = 1; a.idle_sleep = 16; a.fuse = 0; a.trsm = 0; a.chain2 = 0;
@@ -1545,7 +1549,6 @@ bool launch_potrf_dataflow(hipStream_t s, double* A, int Np, double* Linv, int* 
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     if (n_cu <= 0) n_cu = 64;
     const int tiles = nb * (nb + 1) / 2 - 1;
-    auto envi = [](const char* n, int dflt) { const char* v = getenv(n); return v ? atoi(v) : dflt; };
     const int fuse = envi("SLS_POTRF_DFUSE", 1), trsm = envi("SLS_POTRF_DTRSM", 1) && fuse;
     // two chain workgroups: opt-in.  Measured (profiles/r03_potrf_dataflow_chain2.log): 0.78 vs 0.82 ms at N = 2048, 4.33 vs 4.24 at
     // 8192 -- the follower gets its tiles 39-45 us after the diagonal block before (two worker tasks in sequence: the panel tile
@@ -1563,7 +1566,7 @@ bool launch_potrf_dataflow(hipStream_t s, double* A, int Np, double* Linv, int* 
     (void)hipMemsetAsync(sync, 0, potrf_dataflow_sync_ints(Np) * sizeof(int), s);
     PersistArgs a;
     a.A = A; a.ld = Np; a.nb = nb; a.Linv = Linv; a.info = info; a.sync = sync;
-    a.timeout = 20000000LL;   // 0.2 s of the 100 MHz wall clock
+    a.timeout = envi("SLS_POTRF_TIMEOUT_TICKS", 20000000);   // 0.2 s of the 100 MHz wall clock (test hook: 1 makes every wait expire)
     a.trace = trace;
     a.nbo = potrf_dataflow_nbo(Np);
     a.j0 = 0; a.j1 = nb; a.k0 = 0; a.ext_flag = nullptr;

@@ -121,6 +121,45 @@ def test_concurrent_contexts_on_one_device_do_not_fall_back(oracle):
     c0.close()
 
 
+def test_single_launch_cholesky_gives_up_falls_back_and_rearms(oracle, monkeypatch):
+    """The failure path of the single-launch Cholesky, forced: SLS_POTRF_TIMEOUT_TICKS=1 makes every device-side wait of the
+    dataflow kernel expire (what happens when its workgroups cannot all be resident: a second process on the GPU, a profiler).
+    The fit must still come out right -- recomputed on the multi-launch schedule --, the context counts ONE fallback, stays on
+    the multi-launch schedule for the next 16 factorisations without further aborts, then goes back to the single-launch form."""
+    m = sls()
+    D, N = 6, 1000
+    X, y, theta, b = synth_problem(oracle, D, N)
+    Xs = synth_candidates(oracle, D, 64)
+    c0 = m.Context(0)
+    g = m.GP(c0, X, y, theta, b, 1)
+    mu0, s0 = g.predict(Xs)
+    g.close()
+    c = m.Context(0)
+    monkeypatch.setenv("SLS_POTRF_TIMEOUT_TICKS", "1")
+    g = m.GP(c, X, y, theta, b, 1)
+    mu1, s1 = g.predict(Xs)
+    g.close()
+    assert c.prof_get("potrf_fallbacks")[1] == 1
+    np.testing.assert_allclose(mu1, mu0, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(s1, s0, rtol=1e-9, atol=1e-12)
+    for _ in range(14):                                   # multi-launch fits (16 factorisations, the recomputation included): no further fallback
+        g = m.GP(c, X, y, theta, b, 1)
+        g.close()
+    assert c.prof_get("potrf_fallbacks")[1] == 1
+    monkeypatch.delenv("SLS_POTRF_TIMEOUT_TICKS")
+    for _ in range(3):                                    # re-armed: the single-launch form again, now with its normal waits
+        g = m.GP(c, X, y, theta, b, 1)
+        mu2, s2 = g.predict(Xs)
+        g.close()
+    assert c.prof_get("potrf_fallbacks")[1] == 1
+    assert np.array_equal(mu2, mu0) and np.array_equal(s2, s0)
+    monkeypatch.setenv("SLS_POTRF_TIMEOUT_TICKS", "1")      # and it gives up again when the condition returns
+    g = m.GP(c, X, y, theta, b, 1)
+    g.close()
+    assert c.prof_get("potrf_fallbacks")[1] == 2
+    c.close(); c0.close()
+
+
 @pytest.mark.parametrize("N", [90, 300])
 def test_map_objective_batch_over_logical_shards_is_bit_identical(oracle, N):
     """sls_multi_gp_nll_batch: the points of a DIRECT iteration dealt round-robin over the devices (three logical shards on GPU 0
