@@ -160,6 +160,30 @@ def test_single_launch_cholesky_gives_up_falls_back_and_rearms(oracle, monkeypat
     c.close(); c0.close()
 
 
+def test_map_evaluation_survives_a_cholesky_that_gives_up(oracle, monkeypatch):
+    """The same forced expiry inside sls_gp_nll_grad: the evaluation enqueues factorisation and gradient in one go and reads the
+    factorisation's status back with the results (capi_map.hip); when the status says "gave up" the WHOLE evaluation is run
+    once more on the multi-launch schedule -- value and gradient must be those of an undisturbed context."""
+    m = sls()
+    D, N = 5, 700
+    X, y, _, _ = synth_problem(oracle, D, N)
+    x = np.concatenate([[0.6, 0.01], np.linspace(0.4, 0.9, D)])
+    c0 = m.Context(0)
+    h0 = m.Nll(c0, X, 1)
+    v0, g0 = h0.gp_objective(y, x)
+    h0.close()
+    c = m.Context(0)
+    h = m.Nll(c, X, 1)
+    monkeypatch.setenv("SLS_POTRF_TIMEOUT_TICKS", "1")
+    v1, g1 = h.gp_objective(y, x)
+    assert c.prof_get("potrf_fallbacks")[1] == 1
+    np.testing.assert_allclose(v1, v0, rtol=1e-10)
+    np.testing.assert_allclose(g1, g0, rtol=1e-7, atol=1e-9 * np.abs(g0).max())
+    v2, g2 = h.gp_objective(y, x * 1.01)                    # the next evaluation: multi-launch from the start, no new fallback
+    assert c.prof_get("potrf_fallbacks")[1] == 1 and np.isfinite(v2) and np.all(np.isfinite(g2))
+    h.close(); c.close(); c0.close()
+
+
 @pytest.mark.parametrize("N", [90, 300])
 def test_map_objective_batch_over_logical_shards_is_bit_identical(oracle, N):
     """sls_multi_gp_nll_batch: the points of a DIRECT iteration dealt round-robin over the devices (three logical shards on GPU 0
