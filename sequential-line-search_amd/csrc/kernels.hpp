@@ -153,6 +153,7 @@ void launch_argmax(hipStream_t s, const double* y, int n, double* out_val, long*
 struct WaveArgs {
     int S, D, N, Np, m, n_local, acq, matern;
     int lds_per_wave, Dr;                 // filled by the launcher
+    int stage_kinv, stage_xt;             // filled by the launcher: K^-1 / XT copied into LDS behind the four waves' areas
     double a, mu_best, ucb_h, c1, shrink, gtol;
     int max_backtracks;
     const double *XT, *inv_ell, *Kinv, *alpha, *starts;   // XT [i + d*Np] scaled; starts D x S column-major (raw)

@@ -13,6 +13,8 @@
 // and the L-BFGS state (x, g, direction, history) lives in registers / LDS with lanes over d.
 // Per evaluation that is 2 N^2 + 6 N D flops on the VALU of one SIMD: faster than the tiled path while
 // N <= 512 and the starts fit the chip a few times over.
+#include <cstdlib>
+
 #include "kernels.hpp"
 #include "../../include/sls_hip.h"
 
@@ -46,12 +48,37 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
     double* rho = Yh + m * p.Dr;                        // [m]
     const int d0 = lane, d1 = lane + 64;
     const bool has0 = d0 < D, has1 = d1 < D;
+    // Few starts (the single start of the DIRECT -> L-BFGS branch, the 10..100 of a small multi-start): K^-1 and the design
+    // matrix are copied into LDS once per workgroup and every evaluation reads them from there.  An evaluation is three short
+    // loops whose every trip needs a global word (L2 at best: ~1 us from a chip that is otherwise idle); with one wavefront per
+    // start nothing hides that, and 320 evaluations in sequence took 7 ms (22 us each) at N = 60, D = 32.  Values only move:
+    // same bits.
+    const double* KinvP = p.Kinv;
+    const double* XTP = p.XT;
+    {
+        double* shared = smem + 4L * p.lds_per_wave;
+        if (p.stage_kinv) {
+            for (int idx = threadIdx.x; idx < Np * Np; idx += 256) shared[idx] = p.Kinv[idx];
+            KinvP = shared;
+            shared += (long)Np * Np;
+        }
+        if (p.stage_xt) {
+            for (int idx = threadIdx.x; idx < Np * D; idx += 256) shared[idx] = p.XT[idx];
+            XTP = shared;
+        }
+        if (p.stage_kinv || p.stage_xt) __syncthreads();
+    }
 
+    // per-lane constants of every evaluation, read once: 1 / l_d of this lane's dimensions, alpha_i of its rows
+    const double il0 = has0 ? p.inv_ell[d0] : 0.0, il1 = has1 ? p.inv_ell[d1] : 0.0;
+    double alr[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) alr[r] = (64 * r < Np && lane + 64 * r < N) ? p.alpha[lane + 64 * r] : 0.0;
     // ---- objective: value and gradient of the acquisition function at xq (lanes over d) ----
     double last_mu = 0.0, last_sigma = 0.0, last_dm[2] = {0.0, 0.0}, last_ds[2] = {0.0, 0.0};   // predictive parts of the last call
     auto evaluate = [&](const double xq0, const double xq1, double& val, double& gr0, double& gr1) {
-        if (has0) xs[d0] = (xq0 - 0.5) * p.inv_ell[d0];
-        if (has1) xs[d1] = (xq1 - 0.5) * p.inv_ell[d1];
+        if (has0) xs[d0] = (xq0 - 0.5) * il0;
+        if (has1) xs[d1] = (xq1 - 0.5) * il1;
         __syncthreads();
         double kr[8], cr[8];
         double mu = 0.0, ca = 0.0;
@@ -64,7 +91,7 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
                 if (i < N) {
                     double q = 0.0;
                     for (int d = 0; d < D; ++d) {
-                        const double df = xs[d] - p.XT[i + (long)d * Np];
+                        const double df = xs[d] - XTP[i + (long)d * Np];
                         q += df * df;
                     }
                     if (p.matern) {
@@ -75,7 +102,7 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
                         kr[r] = p.a * exp(-0.5 * q);
                         cr[r] = kr[r];
                     }
-                    const double al = p.alpha[i];
+                    const double al = alr[r];
                     mu += al * kr[r];
                     ca += al * cr[r];
                     cab[i] = cr[r] * al;
@@ -90,7 +117,7 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
         for (int r = 0; r < 8; ++r) w[r] = 0.0;
         for (int j = 0; j < N; ++j) {
             const double kj = kb[j];
-            const double* col = p.Kinv + (long)j * Np;
+            const double* col = KinvP + (long)j * Np;
 #pragma unroll
             for (int r = 0; r < 8; ++r)
                 if (64 * r < Np) w[r] += col[lane + 64 * r] * kj;
@@ -123,13 +150,13 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
             const int d = lane + 64 * e;
             if (d < D) {
                 double gm = 0.0, gs = 0.0;
-                const double* xrow = p.XT + (long)d * Np;
+                const double* xrow = XTP + (long)d * Np;
                 for (int i = 0; i < N; ++i) {
                     const double xi = xrow[i];
                     gm += xi * cab[i];
                     gs += xi * cwb[i];
                 }
-                const double il = p.inv_ell[d];
+                const double il = e == 0 ? il0 : il1;
                 dm[e] = -il * (xs[d] * ca - gm);
                 ds[e] = inv_sigma * il * (xs[d] * cw - gs);
             }
@@ -309,7 +336,15 @@ size_t wave_lds_bytes(int D, int Np, int m, int* lds_per_wave, int* Dr) {
 }
 
 void launch_maximize_wave(hipStream_t s, WaveArgs a) {
-    const size_t bytes = wave_lds_bytes(a.D, a.Np, a.m, &a.lds_per_wave, &a.Dr);
+    size_t bytes = wave_lds_bytes(a.D, a.Np, a.m, &a.lds_per_wave, &a.Dr);
+    // staging only for launches that leave the chip idle anyway (<= 64 workgroups): with many starts the occupancy is worth more
+    const char* senv = getenv("SLS_WAVE_STAGE");
+    const bool allow = (senv ? atoi(senv) != 0 : true) && a.S <= 256 && a.n_local > 1;
+    const size_t cap = 160 * 1024, kb = (size_t)a.Np * a.Np * 8, xb = (size_t)a.Np * a.D * 8;
+    a.stage_kinv = allow && bytes + kb <= cap;
+    if (a.stage_kinv) bytes += kb;
+    a.stage_xt = allow && a.stage_kinv && bytes + xb <= cap;
+    if (a.stage_xt) bytes += xb;
     ensure_dyn_lds((const void*)maximize_wave_kernel, 160 * 1024);   // opt in to the CU's whole LDS once per device
     hipLaunchKernelGGL(maximize_wave_kernel, dim3((a.S + 3) / 4), dim3(256), bytes, s, a);
 }

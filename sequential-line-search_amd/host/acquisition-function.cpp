@@ -1,4 +1,7 @@
 // acquisition_func over the C ABI (reference: src/acquisition-function.cpp).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -178,16 +181,36 @@ namespace sequential_line_search
     {
         const unsigned num_dim = regressor.GetNumDims();
         sls_gp*        h       = RequireHandle(regressor);
+        // SLS_HOST_TIMING: where the time of one call goes (stderr) -- DIRECT's own bookkeeping on the host, its batched device
+        // evaluations, the local phase
+        const bool timing = std::getenv("SLS_HOST_TIMING") != nullptr;
+        using clk         = std::chrono::steady_clock;
+        double ms_dev = 0.0;
+        int    batches = 0;
         const optim::BatchObjective objective = [&](const std::vector<std::vector<double>>& xs, std::vector<double>& values) {
+            const auto t0 = clk::now();
             MatrixXd Xs(num_dim, static_cast<long>(xs.size()));
             for (size_t m = 0; m < xs.size(); ++m)
                 for (unsigned d = 0; d < num_dim; ++d) Xs(d, static_cast<long>(m)) = xs[m][d];
             values.resize(xs.size());
             device::Check(sls_acq_eval(h, AcqId(func_type), hyperparam, Xs.data(), static_cast<int>(xs.size()), values.data(), nullptr),
                           "sls_acq_eval");
+            ms_dev += std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+            ++batches;
         };
         const std::vector<double> lower(num_dim, 0.0), upper(num_dim, 1.0);
+        const auto                t_direct0 = clk::now();
         const std::vector<double> xg = optim::DirectMaximize(objective, lower, upper, static_cast<int>(num_global_search_iters));
+        const double ms_direct = std::chrono::duration<double, std::milli>(clk::now() - t_direct0).count();
+        const auto   t_local0  = clk::now();
+        struct Report {
+            bool on; double direct, dev; int batches; clk::time_point t0;
+            ~Report() {
+                if (on)
+                    std::fprintf(stderr, "  FindNextPointDirect: DIRECT %.2f ms (%d batched evaluations: %.2f ms on the device side, %.2f ms host bookkeeping), local phase %.2f ms\n",
+                                 direct, batches, dev, direct - dev, std::chrono::duration<double, std::milli>(clk::now() - t0).count());
+            }
+        } report{timing, ms_direct, ms_dev, batches, t_local0};
         MatrixXd start(num_dim, 1);
         for (unsigned d = 0; d < num_dim; ++d) start(d, 0) = xg[d];
         if (num_local_search_iters == 0)

@@ -764,6 +764,25 @@ def test_randomised_configurations(ctx, oracle, seed, path):
     gp.close()
 
 
+@pytest.mark.parametrize("D,N,S,n_local", [(1, 20, 1, 40), (32, 61, 1, 320), (32, 128, 7, 30), (8, 100, 256, 12), (70, 130, 3, 25), (6, 300, 40, 10)])
+def test_wave_path_lds_staging_is_bit_identical(ctx, oracle, D, N, S, n_local, monkeypatch):
+    """Launches of at most 256 starts copy K^-1 (and, if it still fits, the design matrix) into LDS once per workgroup
+    (kernels_wave.hip): values only move, so every start must end with the bits of the unstaged kernel (SLS_WAVE_STAGE=0) --
+    with both arrays staged, with K^-1 alone (N = 128: the design matrix no longer fits) and with neither (N = 300)."""
+    monkeypatch.setenv("SLS_WAVE_PATH", "1")
+    X, y, theta, b = synth_problem(oracle, D, N)
+    starts = synth_candidates(oracle, D, S)
+    gp = sls().GP(ctx, X, y, theta, b, 1)
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SLS_WAVE_STAGE", flag)
+        r = gp.acq_maximize(starts, n_local)
+        out[flag] = (r["y_stars"], r["x_stars"], r["value"], r["index"], r["x"], gp.last_stats()["evals_issued"])
+    for va, vu in zip(out["1"], out["0"]):
+        assert np.array_equal(np.asarray(va), np.asarray(vu))
+    gp.close()
+
+
 @pytest.mark.parametrize("kernel", [0, 1])
 @pytest.mark.parametrize("D,N,S", [(1, 20, 100), (32, 90, 10), (70, 300, 33), (128, 500, 9)])
 def test_wave_path_matches_tiled_path_and_oracle(ctx, oracle, kernel, D, N, S, monkeypatch):
