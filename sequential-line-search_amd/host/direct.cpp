@@ -32,10 +32,22 @@ namespace sequential_line_search
                 double                     g;       // value to MINIMISE (= -f)
             };
 
+            // 3^(-2 l), tabulated once: the selection step asks for every rectangle's size in every iteration (1600 rectangles x 32
+            // dimensions x 11 iterations in sequential_line_search_nd: std::pow was most of the 1.9 ms DIRECT spent on the host)
+            const double* Pow3m2()
+            {
+                static const std::vector<double> t = [] {
+                    std::vector<double> v(256);
+                    for (int l = 0; l < 256; ++l) v[l] = std::pow(3.0, -2.0 * l);
+                    return v;
+                }();
+                return t.data();
+            }
             double HalfDiagonal(const Rect& r)
             {
-                double s = 0.0;
-                for (unsigned char l : r.level) s += std::pow(3.0, -2.0 * l);
+                const double* t = Pow3m2();
+                double        s = 0.0;
+                for (unsigned char l : r.level) s += t[l];
                 return 0.5 * std::sqrt(s);
             }
 
