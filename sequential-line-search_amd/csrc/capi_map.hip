@@ -139,8 +139,8 @@ static void nll_small_eval(sls_nll* h, const double* y, const double* theta, dou
     args.out = h->small_out.p;
     args.in_dev = nullptr;
     args.batch = 1; args.in_stride = 0; args.out_stride = 0;
-    std::vector<double> in;   // staging for the D > 16 upload: must outlive the stream synchronisation below
-    if (D <= NLL_SMALL_MAX_GRAD_D) {
+    std::vector<double> in;   // staging for the D > 32 upload: must outlive the stream synchronisation below
+    if (D <= NLL_SMALL_MAX_ARG_D) {
         args.a = theta[0]; args.b = b;
         for (int d = 0; d < D; ++d) args.ell[d] = theta[1 + d];
         std::memcpy(args.y, y, sizeof(double) * N);

@@ -63,6 +63,7 @@ void launch_cross_gram(hipStream_t s, const double* XsT, long lds_, const double
 // D <= NLL_SMALL_MAX_GRAD_D), [32..32+N) alpha.  X: raw D x N column-major design matrix (device).
 constexpr int NLL_SMALL_MAX_N = 128;
 constexpr int NLL_SMALL_MAX_GRAD_D = 16;
+constexpr int NLL_SMALL_MAX_ARG_D = 32;    // up to here the length scales travel in the kernel argument block (no upload)
 struct NllSmallArgs {
     const double* X;
     int D, N, want_grad;
@@ -74,7 +75,7 @@ struct NllSmallArgs {
     int batch;
     long in_stride, out_stride;
     double a, b;
-    double ell[NLL_SMALL_MAX_GRAD_D];
+    double ell[NLL_SMALL_MAX_ARG_D];
     double y[NLL_SMALL_MAX_N];
 };
 void launch_nll_small(hipStream_t s, int kernel, const NllSmallArgs& args);

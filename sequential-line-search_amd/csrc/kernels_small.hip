@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void nll_small_kernel(const NllSmallArgs args)
     const double* __restrict__ in_dev = args.in_dev ? args.in_dev + (long)blockIdx.x * args.in_stride : nullptr;
     const int D = args.D, N = args.N, want_grad = args.want_grad;
     const int nb16 = (N + 15) >> 4, Nb = 16 * nb16;
-    // hyper-parameters and targets travel in the kernel argument block (no upload); D > 16 falls back to a device buffer
+    // hyper-parameters and targets travel in the kernel argument block (no upload); D > 32 (NLL_SMALL_MAX_ARG_D) falls back to a device buffer
     const double a = in_dev ? in_dev[0] : args.a, b = in_dev ? in_dev[1] : args.b;
     for (int d = tid; d < D; d += 256) small_scratch(As, 256 + d) = 1.0 / (in_dev ? in_dev[2 + d] : args.ell[d]);
     for (int i = tid; i < 128; i += 256)
