@@ -29,6 +29,13 @@ struct sls_nll {
     double cached_b = -1.0;
     bool have_factor = false;
     double logdet = 0.0;
+    // results of the one-workgroup evaluation (kernels_small.hip): page-locked host memory the kernel writes DIRECTLY (mapped),
+    // read after the stream synchronisation -- no device-to-host copy call per evaluation
+    double* small_host = nullptr;      // host address
+    double* small_host_dev = nullptr;  // the same memory as the device sees it
+    ~sls_nll() {
+        if (small_host) (void)hipHostFree(small_host);
+    }
 };
 
 extern "C" int sls_nll_create(sls_ctx* ctx, const double* X, int D, int N, int kernel, sls_nll** out) {
@@ -135,8 +142,13 @@ static void nll_small_eval(sls_nll* h, const double* y, const double* theta, dou
     NllSmallArgs args;
     args.X = h->X.p; args.D = D; args.N = N; args.want_grad = want_grad ? 1 : 0;
     args.info = c->d_info;
+    static const bool zero_copy = [] { const char* e = getenv("SLS_SMALL_ZEROCOPY"); return e ? atoi(e) != 0 : true; }();
+    if (zero_copy && !h->small_host) {
+        SLS_HIP(hipHostMalloc((void**)&h->small_host, 160 * sizeof(double), hipHostMallocMapped));
+        SLS_HIP(hipHostGetDevicePointer((void**)&h->small_host_dev, h->small_host, 0));
+    }
     h->small_out.ensure(160);
-    args.out = h->small_out.p;
+    args.out = zero_copy ? h->small_host_dev : h->small_out.p;
     args.in_dev = nullptr;
     args.batch = 1; args.in_stride = 0; args.out_stride = 0;
     std::vector<double> in;   // staging for the D > 32 upload: must outlive the stream synchronisation below
@@ -154,10 +166,16 @@ static void nll_small_eval(sls_nll* h, const double* y, const double* theta, dou
         args.in_dev = h->small_in.p;
     }
     launch_nll_small(c->stream, h->kernel, args);
-    double out[160];   // (a page-locked buffer and length scales in the kernel arguments for D <= 128 were measured: C3 4 % slower)
+    double out_stack[160];
+    const double* out = out_stack;
     const int nout = alpha ? 32 + N : 32;
-    SLS_HIP(hipMemcpyAsync(out, h->small_out.p, nout * 8, hipMemcpyDeviceToHost, c->stream));
-    SLS_HIP(hipStreamSynchronize(c->stream));
+    if (zero_copy) {
+        SLS_HIP(hipStreamSynchronize(c->stream));
+        out = h->small_host;
+    } else {
+        SLS_HIP(hipMemcpyAsync(out_stack, h->small_out.p, nout * 8, hipMemcpyDeviceToHost, c->stream));
+        SLS_HIP(hipStreamSynchronize(c->stream));
+    }
     if (out[4] != 0.0) {
         set_error("sls_nll_eval: K_y is not positive definite (pivot %d)", (int)out[4] - 1);
         throw HipFail{SLS_ERR_NOT_SPD};
