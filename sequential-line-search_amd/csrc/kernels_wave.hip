@@ -221,6 +221,9 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
     int n_useful = 1;                            // evaluations this start needed (the first one included)
 
     for (int ev = 1; ev < p.n_local; ++ev) {
+        // all four starts of the workgroup finished (or the shadows of the last one): nothing left that could change
+        // (the barriers inside evaluate() need every wave, so the decision is taken for the workgroup as a whole)
+        if (__syncthreads_and(done ? 1 : 0)) break;
         if (!done && need_dir) {
             // projected gradient, two-loop recursion (same statements as the oracle's lb_direction)
             double pg0 = g0, pg1 = g1;
