@@ -10,7 +10,10 @@ move stops consuming evaluations.  value = candidate evaluations ACTUALLY PERFOR
 ranks; `config.evals_issued_per_step`, at most 65 536 x 50 = `config.evals_cap_per_step`); ms_per_step is the step time.
 Strong scaling: the 65 536 starts are fixed and split over the ranks; every rank repeats the (cheap) fit.
 
-Launch: python bench.py [--gpus N --steps K --warmup W];  for N > 1 under torch.distributed.run (one rank per GPU).
+Launch: python bench.py [--gpus N --steps K --warmup W].  For N > 1 the ranks are one process per GPU: either the caller
+starts them (torch.distributed.run --nproc-per-node N ... bench.py --gpus N, the driver's form), or -- invoked plainly --
+bench.py starts that same torch.distributed.run itself on 127.0.0.1 and a free port and relays rank 0's JSON line
+(`config.launcher` says which).
 """
 import argparse
 import importlib
@@ -147,6 +150,31 @@ def stage_rooflines(prof, N, D, Np, cand, matern):
     return out
 
 
+def canonical_argv(args):
+    """The parsed arguments under their long names (torch.distributed.run's own parser prefix-matches a script argument
+    such as `--n` against its options even behind the script path)."""
+    out = ["--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--num-train", str(args.n),
+           "--dims", str(args.d), "--starts", str(args.starts), "--n-local", str(args.n_local), "--kernel", args.kernel,
+           "--chunk", str(args.chunk), "--backend", args.backend]
+    return out + (["--no-cpu-baseline"] if args.no_cpu_baseline else []) + (["--same-device"] if args.same_device else [])
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks the way the driver would (one process per GPU under
+    torch.distributed.run, rendezvous on 127.0.0.1 and a free port), pass every argument through, relay the output."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SLS_BENCH_LAUNCHER="self")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + canonical_argv(args)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
     import torch
@@ -156,8 +184,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+            raise SystemExit(self_spawn(args))
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
     if args.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -306,6 +335,8 @@ def main():
             "config": {"workload": "C4: multi-start EI maximisation", "N": N, "D": D, "starts_total": S,
                        "starts_per_gpu": S_loc, "n_local_evals": args.n_local, "kernel": args.kernel,
                        "candidate_chunk": chunk, "parallelism": f"starts sharded over {world} GPU(s), one all-gather", "exchange": exchange,
+                       "launcher": ("single process" if world == 1 else "torch.distributed.run started by bench.py itself"
+                                    if os.environ.get("SLS_BENCH_LAUNCHER") == "self" else "torch.distributed.run (caller)"),
                        "evals_cap_per_step": evals_cap, "evals_issued_per_step": evals_issued,
                        "evals_semantics": "n_local is a cap per start (NLopt max_evals); finished starts leave the batch",
                        "acq_gemm_form": ("2 workgroups per CU, persistent, generation-gated" if os.environ.get("SLS_ACQ_WG_PER_CU") == "2"

@@ -55,6 +55,32 @@ def test_bench_line_contract_and_two_rank_merge():
 
 
 @pytest.mark.gpu
+def test_bench_gpus_n_without_a_launcher_spawns_its_own_ranks():
+    """`python bench.py --gpus 2 ...` invoked PLAINLY (no torch.distributed.run around it, short option names and all) must
+    not die: it starts the two ranks itself and prints the one JSON line, with the single-rank winner bit for bit
+    (multi-start loop of src/acquisition-function.cpp:121-153 sharded over ranks)."""
+    short = ["--n", "640", "--d", "8", "--starts", "3000", "--n-local", "8", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    one = run([sys.executable, "bench.py", "--gpus", "1"] + short)
+    two = run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--same-device"] + short)
+    assert two["n_gpus"] == 2 and two["config"]["starts_per_gpu"] == 1500
+    assert "started by bench.py itself" in two["config"]["launcher"] and one["config"]["launcher"] == "single process"
+    assert two["result"]["best_index"] == one["result"]["best_index"]
+    assert two["result"]["best_value"] == one["result"]["best_value"]
+    np.testing.assert_array_equal(two["result"]["best_x"], one["result"]["best_x"])
+
+
+def test_bench_self_spawn_arguments_round_trip(monkeypatch):
+    """The argument list bench.py hands to the ranks it spawns parses back to the same namespace (CPU)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--n", "300", "--d", "5", "--starts", "77", "--kernel", "se",
+                                      "--same-device", "--no-cpu-baseline", "--steps", "3"])
+    a = bench.parse()
+    monkeypatch.setattr(sys, "argv", ["bench.py"] + bench.canonical_argv(a))
+    assert vars(bench.parse()) == vars(a)
+
+
+@pytest.mark.gpu
 def test_bench_survives_an_unusable_rccl_communicator():
     """bench.py --gpus N creates its RCCL communicator (inside libsls_hip) on a watchdog thread and tries it once before
     the timed region.  Two ranks forced onto GPU 0 is a configuration RCCL refuses (one rank per GPU) or never completes:
