@@ -44,6 +44,7 @@ extern "C" {
 #define SLS_ERR_HIP (-2)
 #define SLS_ERR_NOT_SPD (-3)
 #define SLS_ERR_NO_DEVICE (-4)
+#define SLS_ERR_UNSUPPORTED (-5) /* the problem is outside what this entry point runs on the device; use the general path */
 
 typedef struct sls_ctx sls_ctx;
 typedef struct sls_gp sls_gp;
@@ -222,7 +223,9 @@ int sls_gp_nll_grad(sls_nll* h, const double* y, const double* x, double* value,
 int sls_gp_nll_batch(sls_nll* h, const double* y, const double* xs, int B, double* values);
 /* objective(x, grad) of src/preference-regressor.cpp:129-259.  x = (y_1..y_M [, a, b, r_1..r_D] if use_map_hyperparams);
  * prefs_flat / pref_offsets: CSR image of std::vector<Preference> (n_prefs tuples, first index = preferred point).
- * grad (same length as x) may be NULL.  BTL terms (include/sequential-line-search/utils.hpp:25-52) run on the host. */
+ * grad (same length as x) may be NULL.  For M <= 128 the whole objective -- BTL terms (include/sequential-line-search/utils.hpp:
+ * 25-52, no max-subtraction: same overflow behaviour) included -- is one single-workgroup launch; larger problems run the
+ * tiled pipeline with the O(#preferences) BTL terms on the host. */
 typedef struct sls_pref_cfg {
     int use_map_hyperparams;
     double default_a, default_r, default_b, prior_var, btl_scale;
@@ -230,6 +233,20 @@ typedef struct sls_pref_cfg {
 } sls_pref_cfg;
 int sls_pref_objective(sls_nll* h, const unsigned* prefs_flat, const int* pref_offsets, int n_prefs, const double* x,
                        const sls_pref_cfg* cfg, double* value, double* grad);
+/* PreferenceRegressor::PerformMapEstimation (src/preference-regressor.cpp:332-403) as ONE device launch for M <= 128 data points
+ * (with use_map_hyperparams: D <= 16): the objective above -- Bradley-Terry-Luce terms included -- is maximised on the device by
+ * the bounded L-BFGS that stands in for nloptutil::solve(..., LD_TNEWTON, ..., num_iters) (:377).  Variables z = (y_1..y_M
+ * [, log a, log b, log r_1..log r_D]); z0 / lower / upper / z_out have that length; max_evals = NLopt's max_evals.
+ * evals_per_launch: 0 = the whole fit in one launch; k > 0 = launches of k evaluations each, continued from device-resident
+ * state (same machine code, same bits: the test hook behind "one launch == one launch per evaluation").
+ * Returns SLS_ERR_UNSUPPORTED (nothing computed) outside those limits: drive sls_pref_objective from the host instead. */
+int sls_pref_map_fit(sls_nll* h, const unsigned* prefs_flat, const int* pref_offsets, int n_prefs, const sls_pref_cfg* cfg,
+                     const double* z0, const double* lower, const double* upper, int max_evals, int evals_per_launch,
+                     double* z_out, double* value, int* evals_used);
+/* Local phase of GaussianProcessRegressor::PerformMapEstimation (src/gaussian-process-regressor.cpp:295: TNEWTON from the DIRECT
+ * point) in one launch for N <= 128, D <= 16: maximises sls_gp_nll_grad's objective over z = (log a, log b, log r_1..log r_D). */
+int sls_gp_map_fit(sls_nll* h, const double* y, const double* z0, const double* lower, const double* upper, int max_evals,
+                   int evals_per_launch, double* z_out, double* value, int* evals_used);
 
 /* ---- instrumentation ------------------------------------------------------ */
 /* Per-kernel accumulated device time (ms, HIP events on the context's stream) and launch counts since the last reset.

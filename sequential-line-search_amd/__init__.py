@@ -52,11 +52,18 @@ EXPORTS = [
     "sls_lbfgs_default_opts", "sls_acq_maximize", "sls_acq_maximize_dev", "sls_gp_refit_dev", "sls_prof_enable",
     "sls_prof_reset", "sls_prof_get", "sls_nll_create", "sls_nll_destroy", "sls_nll_eval", "sls_gp_nll_grad", "sls_gp_nll_batch", "sls_multi_nll_create", "sls_multi_nll_destroy",
     "sls_multi_gp_nll_batch",
-    "sls_pref_objective", "sls_acq_eval_pair", "sls_acq_maximize_pair", "sls_gp_append_point", "sls_acq_last_stats",
+    "sls_pref_objective", "sls_pref_map_fit", "sls_gp_map_fit", "sls_acq_eval_pair", "sls_acq_maximize_pair", "sls_gp_append_point", "sls_acq_last_stats",
     "sls_multi_create", "sls_multi_destroy", "sls_multi_size", "sls_multi_exchange", "sls_multi_ctx", "sls_multi_gp_create",
     "sls_multi_gp_destroy", "sls_multi_gp_shard", "sls_multi_acq_maximize", "sls_multi_gp_predict", "sls_comm_unique_id", "sls_comm_create",
     "sls_comm_destroy", "sls_comm_allgather_best", "sls_device_trim_cache",
 ]
+
+
+ERR_UNSUPPORTED = -5
+
+
+class Unsupported(SlsError):
+    """SLS_ERR_UNSUPPORTED: the problem is outside what the entry point runs on the device (use the general path)."""
 
 
 def _ck(rc):
@@ -320,6 +327,38 @@ class Nll:
         _ck(lib().sls_pref_objective(self.h, flat.ctypes.data_as(C.POINTER(C.c_uint)), offs.ctypes.data_as(C.POINTER(C.c_int)),
                                      len(prefs), _p(x), C.byref(cfg), C.byref(val), _p(g) if want_grad else None))
         return (val.value, g) if want_grad else val.value
+
+
+    def pref_map_fit(self, prefs, z0, lower, upper, max_evals, evals_per_launch=0, use_map=False, a=0.5, r=0.5, b=0.005,
+                     prior_var=0.25, btl_scale=0.01, noiseless=False):
+        """PreferenceRegressor::PerformMapEstimation on the device (sls_pref_map_fit): z = (y [, log a, log b, log r..]).
+        Returns dict(z, value, evals); raises Unsupported outside the device-resident limits."""
+        z0, lower, upper = _f(z0), _f(lower), _f(upper)
+        flat = np.array([i for p in prefs for i in p], dtype=np.uint32)
+        offs = np.zeros(len(prefs) + 1, dtype=np.int32)
+        offs[1:] = np.cumsum([len(p) for p in prefs])
+        cfg = PrefCfg(int(use_map), a, r, b, prior_var, btl_scale, int(noiseless))
+        z = np.empty(len(z0))
+        val, ev = C.c_double(), C.c_int()
+        rc = lib().sls_pref_map_fit(self.h, flat.ctypes.data_as(C.POINTER(C.c_uint)), offs.ctypes.data_as(C.POINTER(C.c_int)),
+                                    len(prefs), C.byref(cfg), _p(z0), _p(lower), _p(upper), int(max_evals), int(evals_per_launch),
+                                    _p(z), C.byref(val), C.byref(ev))
+        if rc == ERR_UNSUPPORTED:
+            raise Unsupported(lib().sls_last_error().decode())
+        _ck(rc)
+        return dict(z=z, value=val.value, evals=ev.value)
+
+    def gp_map_fit(self, y, z0, lower, upper, max_evals, evals_per_launch=0):
+        """Local phase of GaussianProcessRegressor::PerformMapEstimation on the device (sls_gp_map_fit): z = log (a, b, r..)."""
+        y, z0, lower, upper = _f(y), _f(z0), _f(lower), _f(upper)
+        z = np.empty(len(z0))
+        val, ev = C.c_double(), C.c_int()
+        rc = lib().sls_gp_map_fit(self.h, _p(y), _p(z0), _p(lower), _p(upper), int(max_evals), int(evals_per_launch), _p(z),
+                                  C.byref(val), C.byref(ev))
+        if rc == ERR_UNSUPPORTED:
+            raise Unsupported(lib().sls_last_error().decode())
+        _ck(rc)
+        return dict(z=z, value=val.value, evals=ev.value)
 
 
 class Multi:

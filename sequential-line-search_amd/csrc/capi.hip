@@ -828,13 +828,25 @@ static void maximize_impl(sls_gp* g, sls_gp* gs, int acq_type, double ucb_h, con
             unsigned long long* d_useful = reinterpret_cast<unsigned long long*>(g->lb_int + 6 * (size_t)Sp + 32);
             SLS_HIP(hipMemsetAsync(d_useful, 0, sizeof(unsigned long long), c->stream));
             w.useful = d_useful;
+            long long* d_trace = nullptr;
+            if (getenv("SLS_WAVE_TRACE")) {
+                d_trace = reinterpret_cast<long long*>(g->lb_int + 6 * (size_t)Sp + 64);
+                SLS_HIP(hipMemsetAsync(d_trace, 0, 8 * sizeof(long long), c->stream));
+                w.trace = d_trace;
+            }
             {
                 ProfScope ps(c, "acq_wave");
                 launch_maximize_wave(c->stream, w);
             }
             unsigned long long useful = 0;
             SLS_HIP(hipMemcpyAsync(&useful, d_useful, sizeof(useful), hipMemcpyDeviceToHost, c->stream));
+            long long tr[8] = {};
+            if (d_trace) SLS_HIP(hipMemcpyAsync(tr, d_trace, sizeof(tr), hipMemcpyDeviceToHost, c->stream));
             sync(c);
+            if (d_trace)
+                fprintf(stderr, "wave trace (us): S %d N %d D %d evals %lld | kvec %.1f  Kinv.k %.1f  sums %.1f  grad+acq %.1f  direction %.1f  "
+                        "bookkeeping %.1f  total %.1f\n", S, g->N, D, tr[6], tr[0] * 0.01, tr[1] * 0.01, tr[2] * 0.01, tr[3] * 0.01, tr[4] * 0.01,
+                        tr[5] * 0.01, tr[7] * 0.01);
             g->stat_issued = (long)useful;
             g->stat_rounds = n_local;
             used_wave = true;

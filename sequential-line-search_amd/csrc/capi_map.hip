@@ -33,8 +33,18 @@ struct sls_nll {
     // read after the stream synchronisation -- no device-to-host copy call per evaluation
     double* small_host = nullptr;      // host address
     double* small_host_dev = nullptr;  // the same memory as the device sees it
+    // device-resident MAP fit (map_opt_kernel): index image of the preference tuples (uploaded when it changes), the vectors of
+    // a call, the optimiser state, the result block in mapped host memory, a page-locked staging block
+    DBuf mo_idx, mo_vec, mo_state, mo_btl;
+    std::vector<int> mo_idx_host;      // what mo_idx holds
+    double* mo_out = nullptr;          // mapped: host address
+    double* mo_out_dev = nullptr;
+    char* mo_stage = nullptr;          // page-locked
+    size_t mo_stage_bytes = 0;
     ~sls_nll() {
         if (small_host) (void)hipHostFree(small_host);
+        if (mo_out) (void)hipHostFree(mo_out);
+        if (mo_stage) (void)hipHostFree(mo_stage);
     }
 };
 
@@ -368,6 +378,175 @@ extern "C" int sls_gp_nll_batch(sls_nll* h, const double* y, const double* xs, i
     SLS_CATCH
 }
 
+// ---- device-resident MAP fit / objective (map_opt_kernel, kernels_small.hip) --------------------------------------------
+struct MapOptProblem {
+    int ny = 0, nh = 0, log_hyper = 0, noiseless = 0;
+    const double* y_fixed = nullptr;   // host, N (ny == 0)
+    double a0 = 0, b0 = 0, r0 = 0, mu_a = 0, mu_b = 0, mu_r = 0, s2_a = 1, s2_b = 1, s2_r = 1, btl_scale = 1;
+    const unsigned* prefs_flat = nullptr;
+    const int* pref_offsets = nullptr;
+    int n_prefs = 0;
+};
+
+// N <= 128 (one LDS image), D <= 128 (1/l in the LDS scratch), hyper-parameter gradients for D <= 16 (small_grad);
+// SLS_MAP_DEVICE=0 forces the host-driven optimiser / the host's BTL terms (A/B and tests)
+static bool map_opt_supported(const sls_nll* h, int nh) {
+    if (h->N > NLL_SMALL_MAX_N || h->D > 128) return false;
+    if (nh > 0 && h->D > NLL_SMALL_MAX_GRAD_D) return false;
+    const char* e = getenv("SLS_MAP_DEVICE");
+    return !e || atoi(e) != 0;
+}
+
+// Runs the kernel: the whole fit in one launch (evals_per_launch <= 0 or >= max_evals), in launches of evals_per_launch
+// evaluations continuing from the stored state, or one evaluation (eval_only: value + gradient at z0).
+static void map_opt_run(sls_nll* h, const MapOptProblem& pb, const double* z0, const double* lower, const double* upper, int max_evals,
+                        int evals_per_launch, bool eval_only, double* z_out, double* value, double* grad_out, int* evals_used,
+                        bool* not_spd) {
+    sls_ctx* c = h->ctx;
+    const int D = h->D, N = h->N, n = pb.ny + pb.nh, P = pb.n_prefs;
+    SLS_REQUIRE(n >= 1 && n <= MAP_OPT_MAX_VARS, "map fit: %d variables (limit %d)", n, MAP_OPT_MAX_VARS);
+    SLS_REQUIRE(pb.ny == 0 || pb.ny == N, "map fit: ny must be 0 or N");
+    SLS_REQUIRE(pb.nh == 0 || pb.nh == D + 2, "map fit: nh must be 0 or D + 2");
+    const int F = P > 0 ? pb.pref_offsets[P] : 0;
+    // index image: [pref_off (P+1)] [pref_flat (F)] [csc_off (N+1)] [csc_ent (F)]
+    std::vector<int> idx((size_t)P + 1 + F + N + 1 + F, 0);
+    int* poff = idx.data();
+    int* pflat = poff + P + 1;
+    int* coff = pflat + F;
+    int* cent = coff + N + 1;
+    for (int p = 0; p <= P; ++p) poff[p] = P > 0 ? pb.pref_offsets[p] : 0;
+    for (int p = 0; p < P; ++p) SLS_REQUIRE(poff[p + 1] > poff[p], "preference tuple %d is empty", p);
+    for (int q = 0; q < F; ++q) {
+        SLS_REQUIRE(pb.prefs_flat[q] < (unsigned)N, "preference index %u out of range", pb.prefs_flat[q]);
+        pflat[q] = (int)pb.prefs_flat[q];
+        ++coff[pflat[q] + 1];
+    }
+    for (int j = 0; j < N; ++j) coff[j + 1] += coff[j];
+    {
+        std::vector<int> fill(coff, coff + N);
+        for (int q = 0; q < F; ++q) cent[fill[pflat[q]]++] = q;   // increasing flat position = tuple order (:202-216)
+    }
+    const size_t vec_doubles = (size_t)3 * n + N;
+    const size_t need = idx.size() * sizeof(int) + 8 + vec_doubles * 8;
+    if (need > h->mo_stage_bytes) {
+        if (h->mo_stage) (void)hipHostFree(h->mo_stage);
+        h->mo_stage = nullptr;
+        SLS_HIP(hipHostMalloc((void**)&h->mo_stage, need * 2, hipHostMallocDefault));
+        h->mo_stage_bytes = need * 2;
+    }
+    if (!h->mo_out) {
+        SLS_HIP(hipHostMalloc((void**)&h->mo_out, MAP_OPT_OUT_DOUBLES * sizeof(double), hipHostMallocMapped));
+        SLS_HIP(hipHostGetDevicePointer((void**)&h->mo_out_dev, h->mo_out, 0));
+    }
+    h->mo_idx.ensure((idx.size() + 1) / 2 + 1);
+    h->mo_vec.ensure(vec_doubles);
+    h->mo_state.ensure(MAP_OPT_STATE_DOUBLES);
+    h->mo_btl.ensure(std::max(F, 1));
+    // the previous call's copies have completed (every call ends with a stream synchronisation): the staging block is free
+    double* vst = reinterpret_cast<double*>(h->mo_stage);
+    std::memcpy(vst, z0, sizeof(double) * n);
+    std::memcpy(vst + n, lower, sizeof(double) * n);
+    std::memcpy(vst + 2 * n, upper, sizeof(double) * n);
+    if (pb.ny == 0) std::memcpy(vst + 3 * n, pb.y_fixed, sizeof(double) * N);
+    else std::memset(vst + 3 * n, 0, sizeof(double) * N);
+    SLS_HIP(hipMemcpyAsync(h->mo_vec.p, vst, vec_doubles * 8, hipMemcpyHostToDevice, c->stream));
+    if (idx != h->mo_idx_host) {
+        int* ist = reinterpret_cast<int*>(h->mo_stage + vec_doubles * 8);
+        std::memcpy(ist, idx.data(), idx.size() * sizeof(int));
+        SLS_HIP(hipMemcpyAsync(h->mo_idx.p, ist, idx.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        h->mo_idx_host = idx;
+    }
+    MapOptArgs a;
+    a.X = h->X.p; a.D = D; a.N = N; a.ny = pb.ny; a.nh = pb.nh; a.log_hyper = pb.log_hyper; a.noiseless = pb.noiseless;
+    a.y_fixed = h->mo_vec.p + 3 * n;
+    a.a0 = pb.a0; a.b0 = pb.b0; a.r0 = pb.r0;
+    a.mu_a = pb.mu_a; a.mu_b = pb.mu_b; a.mu_r = pb.mu_r; a.s2_a = pb.s2_a; a.s2_b = pb.s2_b; a.s2_r = pb.s2_r;
+    a.btl_scale = pb.btl_scale;
+    a.n_prefs = P; a.flat_len = F;
+    const int* di = reinterpret_cast<const int*>(h->mo_idx.p);
+    a.pref_off = di; a.pref_flat = di + P + 1; a.csc_off = di + P + 1 + F; a.csc_ent = di + P + 1 + F + N + 1;
+    a.btl_scratch = h->mo_btl.p;
+    a.z0 = h->mo_vec.p; a.lower = h->mo_vec.p + n; a.upper = h->mo_vec.p + 2 * n;
+    a.max_evals = eval_only ? 1 : max_evals;
+    a.eval_only = eval_only ? 1 : 0;
+    a.state = h->mo_state.p;
+    a.out = h->mo_out_dev;
+    a.info = c->d_info;
+    const bool stepwise = !eval_only && evals_per_launch > 0 && evals_per_launch < max_evals;
+    a.budget = stepwise ? evals_per_launch : a.max_evals;
+    a.fresh = 1;
+    const double* out = h->mo_out;
+    for (;;) {
+        launch_map_opt(c->stream, h->kernel, a);
+        SLS_HIP(hipStreamSynchronize(c->stream));
+        if (!stepwise || out[2] != 0.0 || (int)out[1] >= max_evals) break;
+        a.fresh = 0;
+    }
+    h->have_factor = false;   // the tiled path's cached factor (L, Linv, Kinv buffers) was not refreshed
+    if (value) *value = out[0];
+    if (evals_used) *evals_used = (int)out[1];
+    if (not_spd) *not_spd = out[3] != 0.0;
+    if (z_out) std::memcpy(z_out, out + MAP_OPT_OUT_X, sizeof(double) * n);
+    if (grad_out) std::memcpy(grad_out, out + MAP_OPT_OUT_G, sizeof(double) * n);
+}
+
+static MapOptProblem pref_problem(const sls_nll* h, const unsigned* prefs_flat, const int* pref_offsets, int n_prefs,
+                                  const sls_pref_cfg* cfg, bool log_hyper) {
+    MapOptProblem pb;
+    pb.ny = h->N;
+    pb.nh = cfg->use_map_hyperparams ? h->D + 2 : 0;
+    pb.log_hyper = log_hyper ? 1 : 0;
+    pb.noiseless = cfg->noiseless ? 1 : 0;
+    pb.a0 = cfg->default_a; pb.b0 = cfg->default_b; pb.r0 = cfg->default_r;
+    pb.mu_a = std::log(cfg->default_a); pb.mu_b = std::log(cfg->default_b); pb.mu_r = std::log(cfg->default_r);
+    pb.s2_a = pb.s2_b = pb.s2_r = cfg->prior_var;
+    pb.btl_scale = cfg->btl_scale;
+    pb.prefs_flat = prefs_flat; pb.pref_offsets = pref_offsets; pb.n_prefs = n_prefs;
+    return pb;
+}
+
+extern "C" int sls_pref_map_fit(sls_nll* h, const unsigned* prefs_flat, const int* pref_offsets, int n_prefs, const sls_pref_cfg* cfg,
+                                const double* z0, const double* lower, const double* upper, int max_evals, int evals_per_launch,
+                                double* z_out, double* value, int* evals_used) {
+    SLS_TRY
+    std::unique_lock<std::recursive_mutex> lock_;
+    if (h) {
+        lock_ = std::unique_lock<std::recursive_mutex>(h->ctx->mtx);
+        (void)hipSetDevice(h->ctx->device);
+    }
+    SLS_REQUIRE(h && cfg && z0 && lower && upper && z_out && max_evals >= 1 && (n_prefs == 0 || (prefs_flat && pref_offsets)),
+                "sls_pref_map_fit: bad argument");
+    if (!map_opt_supported(h, cfg->use_map_hyperparams ? h->D + 2 : 0)) {
+        set_error("sls_pref_map_fit: N = %d, D = %d outside the device-resident optimiser (N <= 128; D <= 16 with hyper-parameters)", h->N, h->D);
+        return SLS_ERR_UNSUPPORTED;
+    }
+    const MapOptProblem pb = pref_problem(h, prefs_flat, pref_offsets, n_prefs, cfg, true);
+    map_opt_run(h, pb, z0, lower, upper, max_evals, evals_per_launch, false, z_out, value, nullptr, evals_used, nullptr);
+    SLS_CATCH
+}
+
+extern "C" int sls_gp_map_fit(sls_nll* h, const double* y, const double* z0, const double* lower, const double* upper, int max_evals,
+                              int evals_per_launch, double* z_out, double* value, int* evals_used) {
+    SLS_TRY
+    std::unique_lock<std::recursive_mutex> lock_;
+    if (h) {
+        lock_ = std::unique_lock<std::recursive_mutex>(h->ctx->mtx);
+        (void)hipSetDevice(h->ctx->device);
+    }
+    SLS_REQUIRE(h && y && z0 && lower && upper && z_out && max_evals >= 1, "sls_gp_map_fit: bad argument");
+    if (!map_opt_supported(h, h->D + 2)) {
+        set_error("sls_gp_map_fit: N = %d, D = %d outside the device-resident optimiser (N <= 128, D <= 16)", h->N, h->D);
+        return SLS_ERR_UNSUPPORTED;
+    }
+    MapOptProblem pb;
+    pb.ny = 0; pb.nh = h->D + 2; pb.log_hyper = 1; pb.y_fixed = y;
+    // priors: src/gaussian-process-regressor.cpp:18-24
+    pb.mu_a = std::log(0.5); pb.mu_b = std::log(1e-4); pb.mu_r = std::log(0.5);
+    pb.s2_a = pb.s2_b = pb.s2_r = 0.5;
+    map_opt_run(h, pb, z0, lower, upper, max_evals, evals_per_launch, false, z_out, value, nullptr, evals_used, nullptr);
+    SLS_CATCH
+}
+
 // utils::CalcBtl / CalcBtlDerivative (include/sequential-line-search/utils.hpp:25-52), no max-subtraction like the reference
 static double btl(const double* f, int n, double s) {
     double sum = 0.0;
@@ -394,6 +573,24 @@ extern "C" int sls_pref_objective(sls_nll* h, const unsigned* prefs_flat, const 
     SLS_REQUIRE(h && x && cfg && (n_prefs == 0 || (prefs_flat && pref_offsets)), "sls_pref_objective: NULL argument");
     const int D = h->D, M = h->N;
     const bool use_map = cfg->use_map_hyperparams != 0;
+    if (map_opt_supported(h, use_map ? D + 2 : 0)) {
+        // one single-workgroup launch: BTL terms, GP term, priors and the whole gradient on the device (eval_only mode)
+        if (use_map) {
+            SLS_REQUIRE(x[M] > 0.0, "signal variance must be positive");
+            SLS_REQUIRE(cfg->noiseless || x[M + 1] >= 0.0, "noise level must be >= 0");
+            for (int d = 0; d < D; ++d) SLS_REQUIRE(x[M + 2 + d] > 0.0, "length scale %d must be positive", d);
+        }
+        const MapOptProblem pb = pref_problem(h, prefs_flat, pref_offsets, n_prefs, cfg, false);
+        const int n = M + (use_map ? D + 2 : 0);
+        std::vector<double> lo(n, -HUGE_VAL), hi(n, HUGE_VAL);
+        bool bad = false;
+        map_opt_run(h, pb, x, lo.data(), hi.data(), 1, 0, true, nullptr, value, grad, nullptr, &bad);
+        if (bad) {
+            set_error("sls_pref_objective: K_y is not positive definite");
+            return SLS_ERR_NOT_SPD;
+        }
+        return SLS_OK;
+    }
     const double a = use_map ? x[M + 0] : cfg->default_a;
     const double b = cfg->noiseless ? 0.0 : (use_map ? x[M + 1] : cfg->default_b);
     std::vector<double> theta(D + 1), gth(D + 1), alpha(M);

@@ -80,6 +80,39 @@ struct NllSmallArgs {
 };
 void launch_nll_small(hipStream_t s, int kernel, const NllSmallArgs& args);
 
+// Whole MAP FIT for N <= 128 in one single-workgroup launch (map_opt_kernel): the bounded L-BFGS of host/device.cpp
+// (optim::MaximizeBounded) with the objective evaluated in place -- the preference objective of
+// src/preference-regressor.cpp:129-259 (Bradley-Terry-Luce terms from a CSR / CSC image of m_D, GP term, log-normal priors)
+// or the GP marginal-likelihood objective of src/gaussian-process-regressor.cpp:141-193.
+// Variables z (n = ny + nh <= 192):  z[0..ny) = goodness values y (ny = N or 0: y fixed = y_fixed);  z[ny..ny+nh) = (a, b,
+// l_1..l_D) (nh = D + 2 or 0: fixed a0, b0, r0), logarithms if log_hyper.
+constexpr int MAP_OPT_MAX_VARS = 192;
+constexpr int MAP_OPT_HIST = 8;
+constexpr int MAP_OPT_STATE_DOUBLES = (4 + 2 * MAP_OPT_HIST) * MAP_OPT_MAX_VARS + 32;
+constexpr int MAP_OPT_OUT_X = 8, MAP_OPT_OUT_G = 8 + MAP_OPT_MAX_VARS, MAP_OPT_OUT_DOUBLES = 8 + 2 * MAP_OPT_MAX_VARS;
+struct MapOptArgs {
+    const double* X;          // D x N column-major design matrix (device)
+    int D, N, ny, nh, log_hyper, noiseless;
+    const double* y_fixed;    // device, N (ny == 0)
+    double a0, b0, r0;        // fixed hyper-parameters (nh == 0)
+    double mu_a, mu_b, mu_r, s2_a, s2_b, s2_r;   // log-normal priors of a, b, l_d (nh > 0)
+    double btl_scale;
+    int n_prefs, flat_len;
+    const int *pref_off, *pref_flat;   // CSR of the preference tuples: members of tuple p = pref_flat[pref_off[p] .. pref_off[p+1])
+    const int *csc_off, *csc_ent;      // transposed: flat positions that name data point j, in increasing order
+    double* btl_scratch;               // flat_len doubles (device); used when flat_len > 640 (else the LDS scratch)
+    const double *z0, *lower, *upper;  // device, n each
+    int max_evals;            // cap on objective evaluations of the whole fit
+    int budget;               // evaluations performed by THIS launch (>= max_evals: the whole fit in one launch)
+    int eval_only;            // 1: evaluate at z0, write value and gradient, stop
+    int fresh;                // 1: start from z0; 0: continue from `state`
+    double* state;            // MAP_OPT_STATE_DOUBLES (device): optimiser state, stored at the end of every launch
+    double* out;              // MAP_OPT_OUT_DOUBLES: [0] objective at x, [1] evaluations used, [2] finished, [3] last pivot info,
+                              // [8 .. 8+n) x, [8+192 .. 8+192+n) gradient (eval_only)
+    int* info;
+};
+void launch_map_opt(hipStream_t s, int kernel, const MapOptArgs& args);
+
 // ---- kernels_acq.hip ---------------------------------------------------------
 // P[n + i*ldk] = Cs * (Kinv Ks)  and the partial column sums kw_part (Ks.*W), cw_part (Cs.*W) per 128-row tile of i.
 // kw_part / cw_part: [2 tn + half][candidate] (whole tiles use the even slot).  Returns the index (in the kernel's grouped tile
@@ -163,6 +196,10 @@ struct WaveArgs {
     long ld;
     // evaluation-only mode (n_local == 0): `starts` holds the M query points; any of these may be NULL
     double *ev_mu, *ev_sigma, *ev_dmu, *ev_dsigma, *ev_val, *ev_grad;
+    // optional (SLS_WAVE_TRACE=1, probes): ticks of the 100 MHz clock wave 0 of workgroup 0 spent in [0] the kernel-vector loop,
+    // [1] w = K^-1 k, [2] the four reductions, [3] the gradient loop + acquisition, [4] L-BFGS direction, [5] step bookkeeping,
+    // [6] evaluations, [7] whole kernel
+    long long* trace = nullptr;
 };
 constexpr int WAVE_PATH_MAX_NP = 512;     // 8 rows per lane
 constexpr int WAVE_PATH_MAX_D = 128;      // 2 dimensions per lane

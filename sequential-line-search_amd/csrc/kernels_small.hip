@@ -12,6 +12,7 @@
 // (rows 128..143 of the [128 x 144] matrix) serve as scratch for alpha, y, 1/l and the reduction slots.
 #include "chol_diag.hpp"
 #include "kernels.hpp"
+#include "wave_reduce.hpp"
 #include "../../include/sls_hip.h"
 
 namespace slsk {
@@ -19,58 +20,51 @@ namespace slsk {
 constexpr int SMALL_OUT_GL = 8;        // out[8 .. 8+D): length-scale gradient (D <= NLL_SMALL_MAX_GRAD_D)
 constexpr int SMALL_OUT_ALPHA = 32;    // out[32 .. 32+N): alpha
 
+// scratch map (2048 doubles in the padding rows of the LDS matrix):
+//   [0,128) alpha   [128,256) y   [256,384) 1/l   [384,1024) BTL contributions (map_opt)   [1024,1028) reduction slots
+//   [1028,1032) a, b (map_opt)    [1040,1056) l (map_opt)   [1296,1552) gradient wrt the optimiser's variables (map_opt)
+constexpr int SC_ALPHA = 0, SC_Y = 128, SC_INVL = 256, SC_BTL = 384, SC_BTL_MAX = 640, SC_RED = 1024, SC_AB = 1028,
+              SC_ELL = 1040, SC_GZ = 1296;
+
 __device__ __forceinline__ double& small_scratch(double* As, int k) { return As[(k >> 4) * DL + 128 + (k & 15)]; }
 
 __device__ __forceinline__ double small_block_sum(double v, double* As) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    v = wave_sum(v);
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) small_scratch(As, 1024 + (threadIdx.x >> 6)) = v;
+    if ((threadIdx.x & 63) == 0) small_scratch(As, SC_RED + (threadIdx.x >> 6)) = v;
     __syncthreads();
-    return (small_scratch(As, 1024) + small_scratch(As, 1025)) + (small_scratch(As, 1026) + small_scratch(As, 1027));
+    return (small_scratch(As, SC_RED) + small_scratch(As, SC_RED + 1)) + (small_scratch(As, SC_RED + 2) + small_scratch(As, SC_RED + 3));
 }
 
-// scratch map: [0,128) alpha, [128,256) y, [256,384) 1/l, [1024,1028) reduction slots
 template <bool MATERN>
-__global__ __launch_bounds__(256) void nll_small_kernel(const NllSmallArgs args) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* As = reinterpret_cast<double*>(smem);
-    double* Ts = As + 128 * DL;
+__device__ __forceinline__ void small_kern(double a, double q, double& k, double& c) {
+    if (!MATERN) {
+        k = a * exp(-0.5 * q);
+        c = k;
+    } else {
+        const double s = sqrt(5.0 * q), e = exp(-s);
+        k = a * (1.0 + s + (5.0 / 3.0) * q) * e;
+        c = a * (5.0 / 3.0) * (1.0 + s) * e;
+    }
+}
+
+__device__ __forceinline__ double small_pair_q(const double* __restrict__ X, int D, int i, int j, double* As) {
+    double q = 0.0;
+    for (int d = 0; d < D; ++d) {
+        const double t = (X[d + (long)i * D] - X[d + (long)j * D]) * small_scratch(As, SC_INVL + d);
+        q = fma(t, t, q);
+    }
+    return q;
+}
+
+// K_y = K_f(a, l) + b I into the LDS image (1/l in the scratch), Cholesky + inverse on the leading ceil(N/16) blocks,
+// K_y^-1 as a full symmetric image over the dead factor.  Returns sum_i log L_ii (= logdet / 2) in every thread.
+template <bool MATERN>
+__device__ __forceinline__ double small_factor_inverse(double* As, double* Ts, const double* __restrict__ X, int D, int N,
+                                                       double a, double b, int* __restrict__ info) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fl = lane & 15, fk = lane >> 4;
-    const double* __restrict__ X = args.X;
-    double* __restrict__ out = args.out + (long)blockIdx.x * args.out_stride;
-    int* __restrict__ info = args.info + blockIdx.x;
-    const double* __restrict__ in_dev = args.in_dev ? args.in_dev + (long)blockIdx.x * args.in_stride : nullptr;
-    const int D = args.D, N = args.N, want_grad = args.want_grad;
     const int nb16 = (N + 15) >> 4, Nb = 16 * nb16;
-    // hyper-parameters and targets travel in the kernel argument block (no upload); D > 32 (NLL_SMALL_MAX_ARG_D) falls back to a device buffer
-    const double a = in_dev ? in_dev[0] : args.a, b = in_dev ? in_dev[1] : args.b;
-    for (int d = tid; d < D; d += 256) small_scratch(As, 256 + d) = 1.0 / (in_dev ? in_dev[2 + d] : args.ell[d]);
-    for (int i = tid; i < 128; i += 256)
-        small_scratch(As, 128 + i) = i < N ? (in_dev ? in_dev[2 + D + i] : args.y[i]) : 0.0;
-    if (tid == 0) *info = 0;
-    __syncthreads();
-
-    auto pair_q = [&](int i, int j) {
-        double q = 0.0;
-        for (int d = 0; d < D; ++d) {
-            const double t = (X[d + (long)i * D] - X[d + (long)j * D]) * small_scratch(As, 256 + d);
-            q = fma(t, t, q);
-        }
-        return q;
-    };
-    auto kern = [&](double q, double& k, double& c) {
-        if (!MATERN) {
-            k = a * exp(-0.5 * q);
-            c = k;
-        } else {
-            const double s = sqrt(5.0 * q), e = exp(-s);
-            k = a * (1.0 + s + (5.0 / 3.0) * q) * e;
-            c = a * (5.0 / 3.0) * (1.0 + s) * e;
-        }
-    };
-
     // ---- K_y (lower triangle + full diagonal tiles), identity padding up to the next multiple of 16 ----
     for (int idx = tid; idx < Nb * Nb; idx += 256) {
         const int i = idx % Nb, j = idx / Nb;
@@ -80,7 +74,7 @@ __global__ __launch_bounds__(256) void nll_small_kernel(const NllSmallArgs args)
         else if (i == j) v = a + b;
         else {
             double k, c;
-            kern(pair_q(i, j), k, c);
+            small_kern<MATERN>(a, small_pair_q(X, D, i, j, As), k, c);
             v = k;
         }
         As[i + j * DL] = v;
@@ -129,26 +123,47 @@ __global__ __launch_bounds__(256) void nll_small_kernel(const NllSmallArgs args)
             }
     }
     __syncthreads();
+    return ld;
+}
 
-    // ---- alpha = K^-1 y ----
+// alpha = K^-1 y (y in the scratch) into the scratch; gb = 1/2 (alpha.alpha - tr K^-1), quad = y.alpha in every thread
+__device__ __forceinline__ void small_alpha(double* As, int N, double& gb, double& quad) {
+    const int tid = threadIdx.x;
     if (tid < 128) {
+        // eight LDS operand pairs in flight, then their fused multiply-adds in column order: the same sum as the plain loop (a
+        // loop of dependent load -> fma trips ran at ~150 ns per column on the otherwise idle CU).  Columns N .. 8 ceil(N / 8) - 1
+        // exist in the image (identity padding, inside the 16-aligned block) and meet y = 0 there.
         double s = 0.0;
-        if (tid < N)
-            for (int j = 0; j < N; ++j) s = fma(As[tid + j * DL], small_scratch(As, 128 + j), s);
-        small_scratch(As, tid) = s;
-        if (tid < N && args.batch <= 1) out[SMALL_OUT_ALPHA + tid] = s;   // batch mode: 8 output words per parameter set
+        if (tid < N) {
+            for (int j0 = 0; j0 < N; j0 += 8) {
+                double av[8], yv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    av[u] = As[tid + (j0 + u) * DL];
+                    yv[u] = small_scratch(As, SC_Y + j0 + u);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s = fma(av[u], yv[u], s);
+            }
+        }
+        small_scratch(As, SC_ALPHA + tid) = s;
     }
     __syncthreads();
     double s1 = 0.0, s2 = 0.0;
     if (tid < N) {
-        const double al = small_scratch(As, tid);
+        const double al = small_scratch(As, SC_ALPHA + tid);
         s1 = al * al - As[tid + tid * DL];
-        s2 = small_scratch(As, 128 + tid) * al;
+        s2 = small_scratch(As, SC_Y + tid) * al;
     }
-    const double gb = 0.5 * small_block_sum(s1, As);
-    const double quad = small_block_sum(s2, As);
+    gb = 0.5 * small_block_sum(s1, As);
+    quad = small_block_sum(s2, As);
+}
 
-    // ---- gradient contractions over the pairs i >= j ----
+// gradient contractions over the pairs i >= j:  sa = sum W.*K_f,  gl[d] = (1/l_d) sum W_ij c_ij (x~_id - x~_jd)^2 (d < D <= 16)
+template <bool MATERN>
+__device__ __forceinline__ void small_grad(double* As, const double* __restrict__ X, int D, int N, double a, bool want_grad,
+                                           double& sa_t, double (&gl_t)[NLL_SMALL_MAX_GRAD_D]) {
+    const int tid = threadIdx.x;
     double sa = 0.0;
     double gl[NLL_SMALL_MAX_GRAD_D];
 #pragma unroll
@@ -157,44 +172,455 @@ __global__ __launch_bounds__(256) void nll_small_kernel(const NllSmallArgs args)
         for (int idx = tid; idx < N * N; idx += 256) {
             const int i = idx % N, j = idx / N;
             if (i < j) continue;
-            const double w = (i == j ? 0.5 : 1.0) * (small_scratch(As, i) * small_scratch(As, j) - As[i + j * DL]);
+            const double w = (i == j ? 0.5 : 1.0) * (small_scratch(As, SC_ALPHA + i) * small_scratch(As, SC_ALPHA + j) - As[i + j * DL]);
             double q = 0.0, dd[NLL_SMALL_MAX_GRAD_D];
 #pragma unroll
             for (int d = 0; d < NLL_SMALL_MAX_GRAD_D; ++d) {
                 dd[d] = 0.0;
                 if (d < D) {
-                    const double t = (X[d + (long)i * D] - X[d + (long)j * D]) * small_scratch(As, 256 + d);
+                    const double t = (X[d + (long)i * D] - X[d + (long)j * D]) * small_scratch(As, SC_INVL + d);
                     dd[d] = t * t;
                     q += dd[d];
                 }
             }
-            if (D > NLL_SMALL_MAX_GRAD_D) q = pair_q(i, j);   // length-scale gradient not requested for such D (host check)
+            if (D > NLL_SMALL_MAX_GRAD_D) q = small_pair_q(X, D, i, j, As);   // length-scale gradient not requested for such D (host check)
             if (i == j) q = 0.0;
             double k, c;
-            kern(q, k, c);
+            small_kern<MATERN>(a, q, k, c);
             sa = fma(w, k, sa);
             const double g = w * c;
 #pragma unroll
             for (int d = 0; d < NLL_SMALL_MAX_GRAD_D; ++d) gl[d] = fma(g, dd[d], gl[d]);
         }
     }
-    const double sa_t = small_block_sum(sa, As);
-    if (want_grad) {
+    sa_t = small_block_sum(sa, As);
 #pragma unroll
-        for (int d = 0; d < NLL_SMALL_MAX_GRAD_D; ++d) {
-            if (d < D) {   // D is uniform: every thread takes part in the block sums
-                const double t = small_block_sum(gl[d], As);
-                if (tid == 0) out[SMALL_OUT_GL + d] = t * small_scratch(As, 256 + d);
-            }
-        }
+    for (int d = 0; d < NLL_SMALL_MAX_GRAD_D; ++d) {
+        gl_t[d] = 0.0;
+        if (want_grad && d < D) gl_t[d] = small_block_sum(gl[d], As) * small_scratch(As, SC_INVL + d);   // D uniform: all threads take part
     }
+}
+
+template <bool MATERN>
+__global__ __launch_bounds__(256) void nll_small_kernel(const NllSmallArgs args) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* As = reinterpret_cast<double*>(smem);
+    double* Ts = As + 128 * DL;
+    const int tid = threadIdx.x;
+    const double* __restrict__ X = args.X;
+    double* __restrict__ out = args.out + (long)blockIdx.x * args.out_stride;
+    int* __restrict__ info = args.info + blockIdx.x;
+    const double* __restrict__ in_dev = args.in_dev ? args.in_dev + (long)blockIdx.x * args.in_stride : nullptr;
+    const int D = args.D, N = args.N, want_grad = args.want_grad;
+    // hyper-parameters and targets travel in the kernel argument block (no upload); D > 32 (NLL_SMALL_MAX_ARG_D) falls back to a device buffer
+    const double a = in_dev ? in_dev[0] : args.a, b = in_dev ? in_dev[1] : args.b;
+    for (int d = tid; d < D; d += 256) small_scratch(As, SC_INVL + d) = 1.0 / (in_dev ? in_dev[2 + d] : args.ell[d]);
+    for (int i = tid; i < 128; i += 256)
+        small_scratch(As, SC_Y + i) = i < N ? (in_dev ? in_dev[2 + D + i] : args.y[i]) : 0.0;
+    if (tid == 0) *info = 0;
+    __syncthreads();
+
+    const double ld = small_factor_inverse<MATERN>(As, Ts, X, D, N, a, b, info);
+    double gb, quad;
+    small_alpha(As, N, gb, quad);
+    if (tid < N && args.batch <= 1) out[SMALL_OUT_ALPHA + tid] = small_scratch(As, SC_ALPHA + tid);   // batch mode: 8 output words per parameter set
+    double sa_t, gl_t[NLL_SMALL_MAX_GRAD_D];
+    small_grad<MATERN>(As, X, D, N, a, want_grad != 0, sa_t, gl_t);
     if (tid == 0) {
+        if (want_grad) {
+#pragma unroll
+            for (int d = 0; d < NLL_SMALL_MAX_GRAD_D; ++d)
+                if (d < D) out[SMALL_OUT_GL + d] = gl_t[d];
+        }
         out[0] = sa_t;
         out[1] = gb;
         out[2] = quad;
         out[3] = 2.0 * ld;
         out[4] = (double)__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// map_opt_kernel: the whole MAP fit (or one objective evaluation) in ONE single-workgroup launch.
+//
+// Objective (maximised), with y = z[0..ny) or the fixed targets and (a, b, l) = the hyper variables or the fixed defaults:
+//   f = sum_p log BTL_p(y)                                   src/preference-regressor.cpp:151-154, utils.hpp:25-29 (no max-subtraction)
+//     - 1/2 y^T K^-1 y - 1/2 log|K| - N/2 log 2 pi           :165-170  /  src/gaussian-process-regressor.cpp:174-180
+//     + log-normal priors of a, b, l_d (nh > 0)              :175-192  /  :181-192
+//   df/dy = sum_p dBTL_p / BTL_p - K^-1 y                    :199-221, utils.hpp:31-52
+//   df/d(a, b, l)                                            :53-115   /  :66-127   (small_grad, D <= 16)
+// Optimiser: optim::MaximizeBounded of host/device.cpp statement by statement (projected gradient, two-loop recursion over
+// the last 8 pairs, Armijo backtracking by halving, at most 31 trials per direction) as a flat state machine with one
+// objective evaluation per turn.  The optimiser state (x, g, direction, history) is REPLICATED in the registers of each of
+// the four waves -- lane l owns variables l, l + 64, l + 128 -- so its ~25 reductions per iteration are wave
+// shuffles without a workgroup barrier; all waves execute the same instructions on the same values and therefore take the
+// same branches.  The evaluation itself is the one-workgroup pipeline of nll_small_kernel; for fixed hyper-parameters
+// (the reference's use_map_hyperparams = false, src/preference-regressor.cpp:161-162) K^-1 is built once and stays in LDS.
+// `budget` < max_evals: the launch stops after `budget` evaluations and leaves the state in `state`; the next launch (fresh = 0)
+// continues from it with the same machine code -- the one-launch-per-evaluation form the tests compare the single launch with.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int KV = MAP_OPT_MAX_VARS / 64;
+constexpr int MH = MAP_OPT_HIST;
+
+__device__ __forceinline__ double wave_dot(const double (&u)[KV], const double (&v)[KV]) {
+    double p = 0.0;
+#pragma unroll
+    for (int k = 0; k < KV; ++k) p += u[k] * v[k];
+    return wave_sum(p);
+}
+// mathtoolbox::GetLogOfLogNormalDist / ...Derivative
+__device__ __forceinline__ double dev_log_lognormal(double x, double mu, double s2) {
+    const double lx = log(x);
+    return -lx - 0.5 * log(2.0 * M_PI * s2) - (lx - mu) * (lx - mu) / (2.0 * s2);
+}
+__device__ __forceinline__ double dev_log_lognormal_d(double x, double mu, double s2) { return (mu - s2 - log(x)) / (s2 * x); }
+
+template <bool MATERN>
+__global__ __launch_bounds__(256) void map_opt_kernel(const MapOptArgs args) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* As = reinterpret_cast<double*>(smem);
+    double* Ts = As + 128 * DL;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const double* __restrict__ X = args.X;
+    const int D = args.D, N = args.N, ny = args.ny, nh = args.nh, n = ny + nh;
+    const int P = args.n_prefs, F = args.flat_len;
+    const bool btl_lds = F <= SC_BTL_MAX;
+    int* __restrict__ info = args.info;
+    double* __restrict__ state = args.state;
+    double* __restrict__ out = args.out;
+    auto contrib = [&](int q) -> double& { return btl_lds ? small_scratch(As, SC_BTL + q) : args.btl_scratch[q]; };
+
+    // ---- optimiser state: one replica per wave ----
+    double x[KV], g[KV], xt[KV], d[KV], lo[KV], hi[KV], S[MH][KV], Y[MH][KV], rho[MH];
+    double fx = 0.0, t = 1.0, sy_last = 0.0, yy_last = 1.0;
+    int cnt = 0, bt = 0, evals = 0, phase = 0, done = 0;
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+        const int e = lane + 64 * k;
+        lo[k] = e < n ? args.lower[e] : 0.0;
+        hi[k] = e < n ? args.upper[e] : 0.0;
+        x[k] = g[k] = d[k] = 0.0;
+        xt[k] = e < n ? fmin(hi[k], fmax(lo[k], args.z0[e])) : 0.0;
+#pragma unroll
+        for (int h = 0; h < MH; ++h) S[h][k] = Y[h][k] = 0.0;
+    }
+#pragma unroll
+    for (int h = 0; h < MH; ++h) rho[h] = 0.0;
+    if (!args.fresh) {
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            const int e = lane + 64 * k;
+            x[k] = state[0 * MAP_OPT_MAX_VARS + e];
+            g[k] = state[1 * MAP_OPT_MAX_VARS + e];
+            xt[k] = state[2 * MAP_OPT_MAX_VARS + e];
+            d[k] = state[3 * MAP_OPT_MAX_VARS + e];
+#pragma unroll
+            for (int h = 0; h < MH; ++h) {
+                S[h][k] = state[(4 + h) * MAP_OPT_MAX_VARS + e];
+                Y[h][k] = state[(4 + MH + h) * MAP_OPT_MAX_VARS + e];
+            }
+        }
+        const double* sc = state + (4 + 2 * MH) * MAP_OPT_MAX_VARS;
+        fx = sc[0]; t = sc[1]; sy_last = sc[2]; yy_last = sc[3];
+#pragma unroll
+        for (int h = 0; h < MH; ++h) rho[h] = sc[4 + h];
+        cnt = (int)sc[12]; bt = (int)sc[13]; evals = (int)sc[14]; phase = (int)sc[15]; done = (int)sc[16];
+    }
+
+    // ---- fixed inputs ----
+    for (int i = tid; i < 128; i += 256) small_scratch(As, SC_Y + i) = (ny == 0 && i < N) ? args.y_fixed[i] : 0.0;
+    if (nh == 0)
+        for (int dd = tid; dd < D; dd += 256) small_scratch(As, SC_INVL + dd) = 1.0 / args.r0;
+    if (tid == 0) *info = 0;
+    // the first preference tuple of this thread and the first tuple memberships of data point `tid`: indices in registers
+    constexpr int RC = 4;
+    int po = 0, pm = 0, pidx[RC], co = 0, cm = 0, cidx[RC];
+#pragma unroll
+    for (int i = 0; i < RC; ++i) pidx[i] = cidx[i] = 0;
+    if (tid < P) {
+        po = args.pref_off[tid];
+        pm = args.pref_off[tid + 1] - po;
+#pragma unroll
+        for (int i = 0; i < RC; ++i)
+            if (i < pm) pidx[i] = args.pref_flat[po + i];
+    }
+    if (tid < ny && P > 0) {
+        co = args.csc_off[tid];
+        cm = args.csc_off[tid + 1] - co;
+#pragma unroll
+        for (int i = 0; i < RC; ++i)
+            if (i < cm) cidx[i] = args.csc_ent[co + i];
+    }
+    __syncthreads();
+
+    bool have_factor = false, bad = false;
+    double ld = 0.0, a = args.a0, b = args.noiseless ? 0.0 : args.b0;
+    double f_last = 0.0;
+    int budget = args.budget;
+    while (budget > 0 && !done) {
+        --budget;
+        // ---- publish the trial point: y into the scratch, hyper-parameters in linear space ----
+        if (wave == 0) {
+#pragma unroll
+            for (int k = 0; k < KV; ++k) {
+                const int e = lane + 64 * k;
+                if (e < ny) small_scratch(As, SC_Y + e) = xt[k];
+                else if (e < n) {
+                    const int hq = e - ny;
+                    const double v = args.log_hyper ? exp(xt[k]) : xt[k];
+                    if (hq == 0) small_scratch(As, SC_AB) = v;
+                    else if (hq == 1) small_scratch(As, SC_AB + 1) = args.noiseless ? 0.0 : v;
+                    else {
+                        small_scratch(As, SC_ELL + hq - 2) = v;
+                        small_scratch(As, SC_INVL + hq - 2) = 1.0 / v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (nh) {
+            a = small_scratch(As, SC_AB);
+            b = small_scratch(As, SC_AB + 1);
+        }
+        if (nh || !have_factor) {
+            ld = small_factor_inverse<MATERN>(As, Ts, X, D, N, a, b, info);
+            have_factor = true;
+            bad = __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        }
+        double gb, quad;
+        small_alpha(As, N, gb, quad);
+        if (bad && nh && tid == 0) *info = 0;   // every thread has read it (barriers of small_alpha); the next factorisation starts clean
+        double sa_t = 0.0, gl_t[NLL_SMALL_MAX_GRAD_D];
+        if (nh) small_grad<MATERN>(As, X, D, N, a, true, sa_t, gl_t);
+
+        // ---- Bradley-Terry-Luce terms: tuple p on thread p (, p + 256, ...) ----
+        double lsum = 0.0;
+        const double bs = args.btl_scale;
+        for (int p = tid; p < P; p += 256) {
+            const int o = p == tid ? po : args.pref_off[p], m = p == tid ? pm : args.pref_off[p + 1] - o;
+            auto member = [&](int i) { return (p == tid && i < RC) ? pidx[i < RC ? i : 0] : args.pref_flat[o + i]; };
+            const double f0 = small_scratch(As, SC_Y + member(0));
+            double sum = 0.0;
+            for (int i = 0; i < m; ++i) sum += exp(small_scratch(As, SC_Y + member(i)) / bs);
+            const double v = exp(f0 / bs) / sum;                       // CalcBtl
+            lsum += log(v);                                            // calc_log_likelihood
+            const double tmp = -v * v / bs;                            // CalcBtlDerivative
+            double sum2 = 0.0;
+            for (int i = 1; i < m; ++i) {
+                const double r = exp((small_scratch(As, SC_Y + member(i)) - f0) / bs);   // used twice by the reference: once here
+                sum2 += r;
+                contrib(o + i) = r;
+            }
+            contrib(o) = (tmp * (-sum2)) / v;
+            for (int i = 1; i < m; ++i) contrib(o + i) = (tmp * contrib(o + i)) / v;
+        }
+        const double btl_sum = small_block_sum(lsum, As);   // its barriers also publish the contributions (LDS or global, one CU)
+        double gy = 0.0;
+        if (tid < ny) {
+            for (int i = 0; i < cm; ++i) gy += contrib(i < RC ? cidx[i < RC ? i : 0] : args.csc_ent[co + i]);   // :202-216, in tuple order
+            gy -= small_scratch(As, SC_ALPHA + tid);                                                            // :219
+        }
+
+        // ---- value ----
+        double f = btl_sum + (-0.5 * quad - 0.5 * (2.0 * ld) - 0.5 * N * log(2.0 * M_PI));
+        if (nh) {
+            double reg = dev_log_lognormal(a, args.mu_a, args.s2_a);
+            if (!args.noiseless) reg += dev_log_lognormal(b, args.mu_b, args.s2_b);
+            for (int dd = 0; dd < D; ++dd) reg += dev_log_lognormal(small_scratch(As, SC_ELL + dd), args.mu_r, args.s2_r);
+            f += reg;
+        }
+        f_last = f;
+        // ---- gradient wrt the optimiser's variables (minimisation: phi = -f) ----
+        if (tid < n) {
+            double gz;
+            if (tid < ny) gz = gy;
+            else {
+                const int hq = tid - ny;
+                double gx, xv;
+                if (hq == 0) {
+                    xv = a;
+                    gx = sa_t / a + dev_log_lognormal_d(a, args.mu_a, args.s2_a);
+                } else if (hq == 1) {
+                    xv = b;
+                    gx = args.noiseless ? 0.0 : gb + dev_log_lognormal_d(b, args.mu_b, args.s2_b);
+                } else {
+                    xv = small_scratch(As, SC_ELL + hq - 2);
+                    double gl = 0.0;
+#pragma unroll
+                    for (int dd = 0; dd < NLL_SMALL_MAX_GRAD_D; ++dd) gl = (hq - 2 == dd) ? gl_t[dd] : gl;
+                    gx = gl + dev_log_lognormal_d(xv, args.mu_r, args.s2_r);
+                }
+                gz = args.log_hyper ? gx * xv : gx;
+            }
+            small_scratch(As, SC_GZ + tid) = -gz;
+            if (args.eval_only) out[MAP_OPT_OUT_G + tid] = gz;
+        }
+        __syncthreads();
+        ++evals;
+        if (args.eval_only) {
+            done = 1;
+#pragma unroll
+            for (int k = 0; k < KV; ++k) x[k] = xt[k];
+            fx = -f;
+            break;
+        }
+        double gt[KV];
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            const int e = lane + 64 * k;
+            gt[k] = e < n ? small_scratch(As, SC_GZ + e) : 0.0;
+        }
+        const double ft = bad ? HUGE_VAL : -f;
+
+        // ---- advance the optimiser by one evaluation (per wave, no barriers) ----
+        bool need_dir = false;
+        if (phase == 0) {
+#pragma unroll
+            for (int k = 0; k < KV; ++k) { x[k] = xt[k]; g[k] = gt[k]; }
+            fx = ft;
+            phase = 1;
+            need_dir = true;
+        } else {
+            double sv[KV], yv[KV];
+#pragma unroll
+            for (int k = 0; k < KV; ++k) { sv[k] = xt[k] - x[k]; yv[k] = gt[k] - g[k]; }
+            const double gs = wave_dot(g, sv);
+            if (isfinite(ft) && ft <= fx + 1e-4 * gs) {
+                const double sy = wave_dot(sv, yv), yy = wave_dot(yv, yv);
+                if (sy > 1e-10 * yy && sy > 0.0) {
+                    if (cnt == MH) {
+#pragma unroll
+                        for (int h = 0; h + 1 < MH; ++h) {
+                            rho[h] = rho[h + 1];
+#pragma unroll
+                            for (int k = 0; k < KV; ++k) { S[h][k] = S[h + 1][k]; Y[h][k] = Y[h + 1][k]; }
+                        }
+                        cnt = MH - 1;
+                    }
+#pragma unroll
+                    for (int h = 0; h < MH; ++h)
+                        if (h == cnt) {
+                            rho[h] = 1.0 / sy;
+#pragma unroll
+                            for (int k = 0; k < KV; ++k) { S[h][k] = sv[k]; Y[h][k] = yv[k]; }
+                        }
+                    ++cnt;
+                    sy_last = sy;
+                    yy_last = yy;
+                }
+#pragma unroll
+                for (int k = 0; k < KV; ++k) { x[k] = xt[k]; g[k] = gt[k]; }
+                fx = ft;
+                need_dir = true;
+            } else {
+                t *= 0.5;
+                if (++bt > 30) done = 1;
+            }
+        }
+        if (!done && need_dir) {
+            if (evals >= args.max_evals) done = 1;
+            else {
+                double pg[KV], pm_ = 0.0, pn = 0.0;
+#pragma unroll
+                for (int k = 0; k < KV; ++k) {
+                    double v = g[k];
+                    if ((x[k] <= lo[k] && v > 0.0) || (x[k] >= hi[k] && v < 0.0)) v = 0.0;
+                    pg[k] = v;
+                    pm_ = fmax(pm_, fabs(v));
+                    pn += v * v;
+                }
+                const double pgmax = wave_max(pm_), pgn2 = wave_sum(pn);
+                if (!(pgmax > 0.0)) done = 1;
+                else {
+                    double al[MH];
+#pragma unroll
+                    for (int k = 0; k < KV; ++k) d[k] = pg[k];
+#pragma unroll
+                    for (int h = MH - 1; h >= 0; --h) {
+                        al[h] = 0.0;
+                        if (h < cnt) {
+                            al[h] = rho[h] * wave_dot(S[h], d);
+#pragma unroll
+                            for (int k = 0; k < KV; ++k) d[k] -= al[h] * Y[h][k];
+                        }
+                    }
+                    double gamma = cnt > 0 ? sy_last / yy_last : 1.0 / fmax(1.0, sqrt(pgn2));
+#pragma unroll
+                    for (int k = 0; k < KV; ++k) d[k] *= gamma;
+#pragma unroll
+                    for (int h = 0; h < MH; ++h)
+                        if (h < cnt) {
+                            const double beta = rho[h] * wave_dot(Y[h], d);
+#pragma unroll
+                            for (int k = 0; k < KV; ++k) d[k] += S[h][k] * (al[h] - beta);
+                        }
+#pragma unroll
+                    for (int k = 0; k < KV; ++k) d[k] = (pg[k] == 0.0) ? 0.0 : -d[k];
+                    double gd = wave_dot(pg, d);
+                    if (!(gd < 0.0)) {
+                        cnt = 0;
+                        gamma = 1.0 / fmax(1.0, sqrt(pgn2));
+#pragma unroll
+                        for (int k = 0; k < KV; ++k) d[k] = -gamma * pg[k];
+                        gd = wave_dot(pg, d);
+                        if (!(gd < 0.0)) done = 1;
+                    }
+                    t = 1.0;
+                    bt = 0;
+                }
+            }
+        }
+        if (!done) {
+            if (evals >= args.max_evals) done = 1;
+            else {
+                double dv[KV];
+#pragma unroll
+                for (int k = 0; k < KV; ++k) {
+                    xt[k] = fmin(hi[k], fmax(lo[k], x[k] + t * d[k]));
+                    dv[k] = xt[k] - x[k];
+                }
+                if (wave_dot(dv, dv) == 0.0) done = 1;
+            }
+        }
+    }
+
+    // ---- results and the state for a continuation ----
+    if (wave == 0) {
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            const int e = lane + 64 * k;
+            state[0 * MAP_OPT_MAX_VARS + e] = x[k];
+            state[1 * MAP_OPT_MAX_VARS + e] = g[k];
+            state[2 * MAP_OPT_MAX_VARS + e] = xt[k];
+            state[3 * MAP_OPT_MAX_VARS + e] = d[k];
+#pragma unroll
+            for (int h = 0; h < MH; ++h) {
+                state[(4 + h) * MAP_OPT_MAX_VARS + e] = S[h][k];
+                state[(4 + MH + h) * MAP_OPT_MAX_VARS + e] = Y[h][k];
+            }
+            if (e < n) out[MAP_OPT_OUT_X + e] = x[k];
+        }
+        if (lane == 0) {
+            double* sc = state + (4 + 2 * MH) * MAP_OPT_MAX_VARS;
+            sc[0] = fx; sc[1] = t; sc[2] = sy_last; sc[3] = yy_last;
+#pragma unroll
+            for (int h = 0; h < MH; ++h) sc[4 + h] = rho[h];
+            sc[12] = cnt; sc[13] = bt; sc[14] = evals; sc[15] = phase; sc[16] = done;
+            out[0] = args.eval_only ? f_last : -fx;
+            out[1] = evals;
+            out[2] = done;
+            out[3] = bad ? 1.0 : 0.0;
+        }
+    }
+}
+
+void launch_map_opt(hipStream_t s, int kernel, const MapOptArgs& args) {
+    ensure_dyn_lds((const void*)map_opt_kernel<false>, DIAG_LDS_BYTES);
+    ensure_dyn_lds((const void*)map_opt_kernel<true>, DIAG_LDS_BYTES);
+    if (kernel == SLS_KERNEL_ARD_MATERN52)
+        hipLaunchKernelGGL(map_opt_kernel<true>, dim3(1), dim3(256), DIAG_LDS_BYTES, s, args);
+    else
+        hipLaunchKernelGGL(map_opt_kernel<false>, dim3(1), dim3(256), DIAG_LDS_BYTES, s, args);
 }
 
 void launch_nll_small(hipStream_t s, int kernel, const NllSmallArgs& args) {

@@ -16,25 +16,20 @@
 #include <cstdlib>
 
 #include "kernels.hpp"
+#include "wave_reduce.hpp"
 #include "../../include/sls_hip.h"
 
 namespace slsk {
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-    return v;
-}
 
 __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* smem = reinterpret_cast<double*>(smem_raw);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool tracing = p.trace != nullptr;
+    const long long tr_begin = tracing ? wall_clock64() : 0;
+#define WAVE_T0 const long long t_0 = tracing ? wall_clock64() : 0; long long t_prev = t_0
+#define WAVE_T(slot) do { if (tracing) { const long long t_now = wall_clock64(); tr[slot] += t_now - t_prev; t_prev = t_now; } } while (0)
     const int nraw = blockIdx.x * 4 + wave;
     const bool live = nraw < p.S;
     const int n = live ? nraw : p.S - 1;          // surplus waves shadow the last start (uniform barrier counts)
@@ -77,6 +72,8 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
     // ---- objective: value and gradient of the acquisition function at xq (lanes over d) ----
     double last_mu = 0.0, last_sigma = 0.0, last_dm[2] = {0.0, 0.0}, last_ds[2] = {0.0, 0.0};   // predictive parts of the last call
     auto evaluate = [&](const double xq0, const double xq1, double& val, double& gr0, double& gr1) {
+        WAVE_T0;
+        tr[6] += 1;
         if (has0) xs[d0] = (xq0 - 0.5) * il0;
         if (has1) xs[d1] = (xq1 - 0.5) * il1;
         __syncthreads();
@@ -89,8 +86,25 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
             if (64 * r < Np) {
                 const int i = lane + 64 * r;
                 if (i < N) {
+                    // The three loops of an evaluation were chains of dependent  LDS read -> fma  trips: 110-360 cycles per trip on a
+                    // CU that runs nothing else (SLS_WAVE_TRACE=1, N = 61, D = 32: 1.5 + 8.9 + 2.6 of 17.5 us per evaluation).  The
+                    // reads of eight trips are issued together, their arithmetic follows in the original order: same bits.
                     double q = 0.0;
-                    for (int d = 0; d < D; ++d) {
+                    int d = 0;
+                    for (; d + 8 <= D; d += 8) {
+                        double xv[8], tv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            xv[u] = xs[d + u];
+                            tv[u] = XTP[i + (long)(d + u) * Np];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const double df = xv[u] - tv[u];
+                            q += df * df;
+                        }
+                    }
+                    for (; d < D; ++d) {
                         const double df = xs[d] - XTP[i + (long)d * Np];
                         q += df * df;
                     }
@@ -111,16 +125,28 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
             }
         }
         __syncthreads();
+        WAVE_T(0);
         // w = K^-1 k for this lane's rows
         double w[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) w[r] = 0.0;
-        for (int j = 0; j < N; ++j) {
-            const double kj = kb[j];
-            const double* col = KinvP + (long)j * Np;
+        // columns N .. 8 ceil(N / 8) - 1 exist (identity padding of K^-1, Np is a multiple of 128) and meet k_j = 0 there
+        for (int j0 = 0; j0 < N; j0 += 8) {
+            double kj[8], cv[8][8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r)
-                if (64 * r < Np) w[r] += col[lane + 64 * r] * kj;
+            for (int u = 0; u < 8; ++u) {
+                kj[u] = kb[j0 + u];
+                const double* col = KinvP + (long)(j0 + u) * Np;
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    if (64 * r < Np) cv[u][r] = col[lane + 64 * r];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    if (64 * r < Np) w[r] += cv[u][r] * kj[u];
+            }
         }
         double kw = 0.0, cw = 0.0;
 #pragma unroll
@@ -136,10 +162,12 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
             }
         }
         __syncthreads();
+        WAVE_T(1);
         mu = wave_sum(mu);
         ca = wave_sum(ca);
         kw = wave_sum(kw);
         cw = wave_sum(cw);
+        WAVE_T(2);
         const double s2 = p.a - kw;
         const double sigma = s2 < 0.0 ? 0.0 : sqrt(s2);
         const double inv_sigma = 1.0 / sigma;
@@ -151,7 +179,22 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
             if (d < D) {
                 double gm = 0.0, gs = 0.0;
                 const double* xrow = XTP + (long)d * Np;
-                for (int i = 0; i < N; ++i) {
+                int i = 0;
+                for (; i + 8 <= N; i += 8) {
+                    double xv[8], av[8], wv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        xv[u] = xrow[i + u];
+                        av[u] = cab[i + u];
+                        wv[u] = cwb[i + u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        gm += xv[u] * av[u];
+                        gs += xv[u] * wv[u];
+                    }
+                }
+                for (; i < N; ++i) {
                     const double xi = xrow[i];
                     gm += xi * cab[i];
                     gs += xi * cwb[i];
@@ -182,6 +225,7 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
         }
         if (!has0) gr0 = 0.0;
         if (!has1) gr1 = 0.0;
+        WAVE_T(3);
     };
 
     auto clamp01 = [](double v) { return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); };
@@ -224,6 +268,7 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
         // all four starts of the workgroup finished (or the shadows of the last one): nothing left that could change
         // (the barriers inside evaluate() need every wave, so the decision is taken for the workgroup as a whole)
         if (__syncthreads_and(done ? 1 : 0)) break;
+        WAVE_T0;
         if (!done && need_dir) {
             // projected gradient, two-loop recursion (same statements as the oracle's lb_direction)
             double pg0 = g0, pg1 = g1;
@@ -291,7 +336,9 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
         }
         const double xt0 = done ? x0 : clamp01(x0 + t * dir0);
         const double xt1 = done ? x1 : clamp01(x1 + t * dir1);
+        WAVE_T(4);
         evaluate(xt0, xt1, val, gr0, gr1);          // every wave evaluates every round (uniform barriers, lock-step count)
+        if (tracing) t_prev = wall_clock64();
         if (!done) {
             ++n_useful;
             const double ft = -val;
@@ -321,6 +368,11 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
                 if (nbt > p.max_backtracks) done = true;
             }
         }
+        WAVE_T(5);
+    }
+    if (tracing && blockIdx.x == 0 && threadIdx.x == 0) {
+        tr[7] = wall_clock64() - tr_begin;
+        for (int q = 0; q < 8; ++q) p.trace[q] = tr[q];
     }
     if (live) {
         if (has0) p.x_out[n + (long)d0 * p.ld] = x0;

@@ -1,0 +1,51 @@
+// Wave-wide sum / maximum with every lane receiving the result (shared by the one-wavefront-per-start maximiser and the
+// one-workgroup MAP kernels): four DPP steps inside each 16-lane row (quad swaps, half-row and row mirrors: both partners of a
+// step combine the same two values, so all lanes of a row hold the same bits), then two butterfly steps across the rows.  A
+// 64-bit __shfl_xor is two ds_bpermute_b32 (LDS crossbar latency) per step: two steps instead of six -- the optimisers run
+// 15-25 dependent reductions per iteration on ONE wave (measured, C3 local phase: 4.0 us of a 17.5 us evaluation round).
+// A variant that fetched the four row totals with v_readlane (results in SGPRs) faulted on the device in one instantiation
+// (round 4) and was dropped; -DSLS_SHFL_REDUCE builds the plain six-step butterfly.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace slsk {
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+    const long v = __builtin_bit_cast(long, x);
+    const unsigned lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, 0xf, 0xf, true);
+    const unsigned hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, (long)(((unsigned long)hi << 32) | lo));
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#ifdef SLS_SHFL_REDUCE
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+#else
+    v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);   // row_half_mirror
+    v += dpp_f64<0x140>(v);   // row_mirror
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+#endif
+}
+__device__ __forceinline__ double wave_max(double v) {
+#ifdef SLS_SHFL_REDUCE
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+#else
+    v = fmax(v, dpp_f64<0xB1>(v));
+    v = fmax(v, dpp_f64<0x4E>(v));
+    v = fmax(v, dpp_f64<0x141>(v));
+    v = fmax(v, dpp_f64<0x140>(v));
+    v = fmax(v, __shfl_xor(v, 16));
+    v = fmax(v, __shfl_xor(v, 32));
+    return v;
+#endif
+}
+
+}  // namespace slsk

@@ -88,7 +88,8 @@ namespace sequential_line_search
     }
 
     // reference: src/preference-regressor.cpp:332-403.  The objective and its gradient (:129-259) run through
-    // sls_pref_objective; NLopt's LD_TNEWTON is replaced by the bounded L-BFGS of device.hpp with the same evaluation budget.
+    // sls_pref_map_fit / sls_pref_objective; NLopt's LD_TNEWTON is replaced by a bounded L-BFGS with the same evaluation budget
+    // (on the device for the reference's own problem sizes, optim::MaximizeBounded of device.hpp otherwise: same statements).
     // Hyper-parameters are optimised in log-space (their box [1e-8, 10] spans nine decades).
     void PreferenceRegressor::PerformMapEstimation(const unsigned num_iters)
     {
@@ -146,7 +147,15 @@ namespace sequential_line_search
             return v;
         };
 
-        const std::vector<double> z = optim::MaximizeBounded(objective, z0, lower, upper, static_cast<int>(num_iters), &m_map_objective);
+        // M <= 128 (and D <= 16 with hyper-parameters): the whole fit is ONE launch -- objective, BTL terms and the optimiser run
+        // on the device (sls_pref_map_fit); otherwise the same optimiser runs here with one sls_pref_objective call per evaluation
+        std::vector<double> z(opt_dim);
+        const int rc_fit = sls_pref_map_fit(nll.h, flat.data(), offs.data(), static_cast<int>(m_D.size()), &cfg, z0.data(), lower.data(),
+                                            upper.data(), static_cast<int>(num_iters), 0, z.data(), &m_map_objective, nullptr);
+        if (rc_fit == SLS_ERR_UNSUPPORTED)
+            z = optim::MaximizeBounded(objective, z0, lower, upper, static_cast<int>(num_iters), &m_map_objective);
+        else
+            device::Check(rc_fit, "sls_pref_map_fit");
 
         m_y = VectorXd(M);
         for (int i = 0; i < M; ++i) m_y(i) = z[i];

@@ -1,0 +1,269 @@
+"""The device-resident MAP fits (map_opt_kernel; sls_pref_map_fit / sls_gp_map_fit) and the device-side Bradley-Terry-Luce terms.
+
+Reference: PreferenceRegressor::PerformMapEstimation + objective (src/preference-regressor.cpp:129-259,332-403), BTL
+(include/sequential-line-search/utils.hpp:25-52, no max-subtraction), GaussianProcessRegressor::PerformMapEstimation's local
+phase (src/gaussian-process-regressor.cpp:141-193,295).
+
+Checked here:
+  * objective + gradient with the BTL terms on the device vs the oracle (slso_pref_objective) at 1e-9: tuple sizes 2-5, goodness
+    values up to the exp() overflow edge |f| / s -> 709, both kernels, with and without hyper-parameters, and vs the host-BTL path;
+  * one launch == one launch per evaluation (continued from device-resident state), BIT for bit;
+  * the device optimiser vs the same optimiser driven from the host with one objective call per evaluation (same optimum);
+  * scipy's optima (tests/golden/map_optima.npz) through the C ABI directly.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from util import sls, synth_problem
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = sls().Context(0)
+    yield c
+    c.close()
+
+
+def random_prefs(rng, M, n_prefs, sizes=(2, 3, 4, 5)):
+    prefs = []
+    for _ in range(n_prefs):
+        m = int(rng.choice(sizes))
+        prefs.append([int(i) for i in rng.choice(M, size=min(m, M), replace=False)])
+    return prefs
+
+
+def host_path(fn):
+    """Run fn with SLS_MAP_DEVICE=0: BTL terms on the host, optimiser on the host (the pre-round-4 path)."""
+    old = os.environ.get("SLS_MAP_DEVICE")
+    os.environ["SLS_MAP_DEVICE"] = "0"
+    try:
+        return fn()
+    finally:
+        if old is None:
+            del os.environ["SLS_MAP_DEVICE"]
+        else:
+            os.environ["SLS_MAP_DEVICE"] = old
+
+
+@pytest.mark.parametrize("kernel", [0, 1])
+@pytest.mark.parametrize("use_map", [False, True])
+@pytest.mark.parametrize("M,D,n_prefs", [(5, 1, 3), (40, 8, 30), (91, 16, 60), (128, 3, 300), (128, 32, 100)])
+def test_device_btl_objective_and_gradient_vs_oracle(ctx, oracle, kernel, use_map, M, D, n_prefs):
+    if use_map and D > 16:
+        pytest.skip("hyper-parameter gradients on the device cover D <= 16; larger D runs the tiled path (tested in test_gpu_parity)")
+    rng = np.random.default_rng(100 * M + D + 7 * kernel)
+    X = rng.uniform(0, 1, (D, M))
+    prefs = random_prefs(rng, M, n_prefs)
+    h = sls().Nll(ctx, X, kernel)
+    for trial, (yscale, btl_scale) in enumerate([(1.0, 0.01), (0.05, 0.01), (3.0, 1.0), (7.0, 0.01)]):
+        y = rng.normal(size=M) * yscale
+        if trial == 3:
+            # |f| / s up to 709, right below the exp() overflow edge of CalcBtl (709.78), differences within a tuple below it too
+            # (CalcBtlDerivative forms exp((f_i - f_0) / s)): the sum of a tuple's exponentials stays finite (8.2e307 + a few 1e299)
+            y = np.clip(np.abs(y), 0.0, 6.9)
+            y[prefs[0][0]] = 7.09
+        hyp = np.concatenate([[rng.uniform(0.2, 1.0), rng.uniform(1e-3, 1e-2)], rng.uniform(0.2, 1.0, D)])
+        x = np.concatenate([y, hyp]) if use_map else y
+        vo, go = oracle.pref_objective(kernel, X, prefs, x, use_map=use_map, btl_scale=btl_scale)
+        v, g = h.pref_objective(prefs, x, use_map=use_map, btl_scale=btl_scale)
+        assert np.isfinite(vo) and np.isfinite(go).all()
+        scale = max(1.0, abs(vo))
+        assert abs(v - vo) <= 1e-9 * scale, (trial, v, vo)
+        np.testing.assert_allclose(g, go, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(go).max()))
+        vh, gh = host_path(lambda: h.pref_objective(prefs, x, use_map=use_map, btl_scale=btl_scale))
+        assert abs(v - vh) <= 1e-11 * scale
+        np.testing.assert_allclose(g, gh, rtol=1e-10, atol=1e-10 * max(1.0, np.abs(gh).max()))
+        v_only = h.pref_objective(prefs, x, use_map=use_map, btl_scale=btl_scale, want_grad=False)
+        assert v_only == v
+    h.close()
+
+
+def test_device_btl_overflows_like_the_reference(ctx, oracle):
+    """utils.hpp:25-29 has no max-subtraction: f / s > 709.78 makes exp() infinite and the likelihood inf / inf = NaN.  The device
+    terms must do the same (not silently stabilise), like the oracle's restatement."""
+    rng = np.random.default_rng(5)
+    M, D = 12, 2
+    X = rng.uniform(0, 1, (D, M))
+    prefs = [[0, 1, 2], [3, 4], [5, 6, 7, 8]]
+    y = rng.normal(size=M)
+    y[0] = 7.2                                   # 720 > 709.78
+    h = sls().Nll(ctx, X, 1)
+    v, g = h.pref_objective(prefs, y, btl_scale=0.01)
+    vo, go = oracle.pref_objective(1, X, prefs, y, btl_scale=0.01)
+    assert np.isnan(vo) and np.isnan(v)
+    assert np.isnan(g[[0, 1, 2]]).all() and np.isfinite(g[3:]).all()
+    assert np.array_equal(np.isnan(g), np.isnan(go))
+    h.close()
+
+
+def pref_setup(rng, M, D, use_map):
+    X = rng.uniform(0, 1, (D, M))
+    prefs = [[3 * i, 3 * i + 1, 3 * i + 2] for i in range(M // 3)] + random_prefs(rng, M, 5)
+    n = M + (D + 2 if use_map else 0)
+    z0 = np.zeros(n)
+    lo, hi = np.full(n, -10.0), np.full(n, 10.0)
+    if use_map:
+        lo[M:], hi[M:] = np.log(1e-8), np.log(10.0)
+        z0[M], z0[M + 1], z0[M + 2:] = np.log(0.5), np.log(0.005), np.log(0.5)
+    return X, prefs, z0, lo, hi
+
+
+@pytest.mark.parametrize("kernel", [0, 1])
+@pytest.mark.parametrize("use_map,M,D", [(False, 30, 4), (False, 91, 32), (True, 30, 4), (True, 61, 16)])
+def test_pref_fit_one_launch_equals_one_launch_per_evaluation(ctx, kernel, use_map, M, D):
+    rng = np.random.default_rng(31 * M + D)
+    X, prefs, z0, lo, hi = pref_setup(rng, M, D, use_map)
+    h = sls().Nll(ctx, X, kernel)
+    one = h.pref_map_fit(prefs, z0, lo, hi, 100, 0, use_map=use_map)
+    per = h.pref_map_fit(prefs, z0, lo, hi, 100, 1, use_map=use_map)
+    few = h.pref_map_fit(prefs, z0, lo, hi, 100, 7, use_map=use_map)
+    assert one["evals"] == per["evals"] == few["evals"] and 1 < one["evals"] <= 100
+    assert one["value"] == per["value"] == few["value"]
+    assert np.array_equal(one["z"], per["z"]) and np.array_equal(one["z"], few["z"])
+    # the reported value is the objective at the returned point
+    x = one["z"].copy()
+    if use_map:
+        x[M:] = np.exp(x[M:])
+    v = h.pref_objective(prefs, x, use_map=use_map, want_grad=False)
+    assert abs(v - one["value"]) <= 1e-12 * max(1.0, abs(v))
+    assert one["value"] > h.pref_objective(prefs, np.concatenate([z0[:M], np.exp(z0[M:])]), use_map=use_map, want_grad=False)
+    h.close()
+
+
+@pytest.mark.parametrize("kernel", [0, 1])
+@pytest.mark.parametrize("N,D", [(20, 1), (90, 8), (128, 16)])
+def test_gp_fit_one_launch_equals_one_launch_per_evaluation(ctx, oracle, kernel, N, D):
+    X, y, _, _ = synth_problem(oracle, D, N, seed=77 + N)
+    z0 = np.log(np.concatenate([[0.5, 1e-4], np.full(D, 0.5)]))
+    lo, hi = np.full(D + 2, np.log(1e-8)), np.full(D + 2, np.log(50.0))
+    h = sls().Nll(ctx, X, kernel)
+    one = h.gp_map_fit(y, z0, lo, hi, 1000, 0)
+    per = h.gp_map_fit(y, z0, lo, hi, 1000, 1)
+    assert one["evals"] == per["evals"] and one["value"] == per["value"] and np.array_equal(one["z"], per["z"])
+    v, g = h.gp_objective(y, np.exp(one["z"]))
+    vo, go = oracle.gp_map_objective(kernel, X, y, np.exp(one["z"]))
+    assert abs(v - one["value"]) <= 1e-12 * max(1.0, abs(v)) and abs(vo - one["value"]) <= 1e-9 * max(1.0, abs(vo))
+    assert one["value"] >= h.gp_objective(y, np.exp(z0), want_grad=False)
+    # bounded stationary point in the log-parameters (or the evaluation cap was reached)
+    gz = go * np.exp(one["z"])
+    gz[(one["z"] <= lo + 1e-12) & (gz < 0)] = 0.0
+    gz[(one["z"] >= hi - 1e-12) & (gz > 0)] = 0.0
+    assert one["evals"] == 1000 or np.max(np.abs(gz)) <= 1e-4 * max(1.0, abs(vo)), (one["evals"], np.max(np.abs(gz)))
+    h.close()
+
+
+def host_driven_maximise(f, z0, lo, hi, max_evals):
+    """optim::MaximizeBounded (host/device.cpp) restated in numpy: the optimiser the device kernel implements, driven with one
+    objective call per evaluation."""
+    x = np.clip(z0, lo, hi)
+    v, g = f(x)
+    fx, g, evals = -v, -g, 1
+    S, Y, rho = [], [], []
+    while evals < max_evals:
+        pg = g.copy()
+        pg[((x <= lo) & (g > 0)) | ((x >= hi) & (g < 0))] = 0.0
+        if not np.abs(pg).max() > 0:
+            break
+        d = pg.copy()
+        al = [0.0] * len(S)
+        for k in range(len(S) - 1, -1, -1):
+            al[k] = rho[k] * S[k].dot(d)
+            d -= al[k] * Y[k]
+        gamma = S[-1].dot(Y[-1]) / Y[-1].dot(Y[-1]) if S else 1.0 / max(1.0, np.sqrt(pg.dot(pg)))
+        d *= gamma
+        for k in range(len(S)):
+            d += S[k] * (al[k] - rho[k] * Y[k].dot(d))
+        d = np.where(pg == 0.0, 0.0, -d)
+        if not pg.dot(d) < 0:
+            S, Y, rho = [], [], []
+            d = -pg / max(1.0, np.sqrt(pg.dot(pg)))
+            if not pg.dot(d) < 0:
+                break
+        t, accepted, bt = 1.0, False, 0
+        while bt <= 30 and evals < max_evals:
+            xt = np.clip(x + t * d, lo, hi)
+            if (xt - x).dot(xt - x) == 0.0:
+                break
+            vt, gt = f(xt)
+            ft, gt, evals = -vt, -gt, evals + 1
+            if np.isfinite(ft) and ft <= fx + 1e-4 * g.dot(xt - x):
+                s, yv = xt - x, gt - g
+                if s.dot(yv) > 1e-10 * yv.dot(yv) and s.dot(yv) > 0:
+                    S, Y, rho = (S + [s])[-8:], (Y + [yv])[-8:], (rho + [1.0 / s.dot(yv)])[-8:]
+                x, g, fx, accepted = xt, gt, ft, True
+                break
+            t *= 0.5
+            bt += 1
+        if not accepted:
+            break
+    return x, -fx, evals
+
+
+@pytest.mark.parametrize("use_map,M,D", [(False, 40, 6), (True, 40, 6)])
+def test_device_optimiser_reaches_the_host_driven_optimum(ctx, use_map, M, D):
+    rng = np.random.default_rng(9 + M)
+    X, prefs, z0, lo, hi = pref_setup(rng, M, D, use_map)
+    h = sls().Nll(ctx, X, 1)
+
+    def f(z):
+        x = z.copy()
+        if use_map:
+            x[M:] = np.exp(x[M:])
+        v, g = h.pref_objective(prefs, x, use_map=use_map)
+        if use_map:
+            g = g.copy()
+            g[M:] *= x[M:]
+        return v, g
+    dev = h.pref_map_fit(prefs, z0, lo, hi, 5000, 0, use_map=use_map)
+    xh, vh, eh = host_driven_maximise(f, z0, lo, hi, 5000)
+    assert dev["evals"] < 5000 and eh < 5000                       # both converged
+    assert abs(dev["value"] - vh) <= 1e-8 * max(1.0, abs(vh)), (dev["value"], vh)
+    np.testing.assert_allclose(dev["z"], xh, atol=2e-4 * max(1.0, np.abs(xh).max()))
+    # the first iterations follow the same trajectory to rounding (the optimiser IS the same statement sequence)
+    dev5 = h.pref_map_fit(prefs, z0, lo, hi, 5, 0, use_map=use_map)
+    x5, v5, _ = host_driven_maximise(f, z0, lo, hi, 5)
+    assert abs(dev5["value"] - v5) <= 1e-9 * max(1.0, abs(v5))
+    np.testing.assert_allclose(dev5["z"], x5, rtol=1e-8, atol=1e-9)
+    h.close()
+
+
+def test_pref_fit_matches_scipy_optima_through_the_c_abi(ctx):
+    """tests/golden/map_optima.npz (scipy TNC / L-BFGS-B on a numpy objective) against sls_pref_map_fit directly."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "map_optima.npz"))
+    for name in [str(n) for n in z["pref_cases"]]:
+        c = {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith(name + "/")}
+        X, kind, use_map = c["X"], int(c["kernel"]), bool(int(c["use_map"]))
+        D, M = X.shape
+        offs = c["offsets"]
+        prefs = [[int(i) for i in c["prefs_flat"][offs[p]:offs[p + 1]]] for p in range(len(offs) - 1)]
+        n = M + (D + 2 if use_map else 0)
+        z0, lo, hi = np.zeros(n), np.full(n, -10.0), np.full(n, 10.0)
+        if use_map:
+            lo[M:], hi[M:] = np.log(1e-8), np.log(10.0)
+            z0[M], z0[M + 1], z0[M + 2:] = np.log(0.5), np.log(0.005), np.log(0.5)
+        h = sls().Nll(ctx, X, kind)
+        r = h.pref_map_fit(prefs, z0, lo, hi, 20000, 0, use_map=use_map)
+        h.close()
+        scale = max(1.0, abs(float(c["value"])))
+        assert r["value"] >= float(c["value"]) - 1e-6 * scale, (name, r["value"], float(c["value"]))
+        if abs(r["value"] - float(c["value"])) <= 1e-6 * scale:
+            np.testing.assert_allclose(r["z"][:M], c["x_opt"][:M], atol=1e-3 * max(1.0, float(np.max(np.abs(c["x_opt"][:M])))))
+
+
+def test_unsupported_sizes_are_reported_not_computed(ctx):
+    rng = np.random.default_rng(1)
+    X = rng.uniform(0, 1, (3, 130))
+    h = sls().Nll(ctx, X, 1)
+    with pytest.raises(sls().Unsupported):
+        h.pref_map_fit([[0, 1]], np.zeros(130), np.full(130, -10.0), np.full(130, 10.0), 10)
+    h.close()
+    X = rng.uniform(0, 1, (20, 30))
+    h = sls().Nll(ctx, X, 1)
+    with pytest.raises(sls().Unsupported):
+        h.gp_map_fit(np.zeros(30), np.zeros(22), np.full(22, -18.0), np.full(22, 3.9), 10)
+    h.close()

@@ -62,5 +62,68 @@ flops_c5 = N ** 3 + 3.0 * D * N * N
 out["C5_map_objective_gradient_N4096_D128"] = {"ms_per_evaluation": ms_c5,
                                                "map_eval_roofline": {"bound": "mfma", "flops": flops_c5, "achieved_TFLOPs": flops_c5 / (ms_c5 * 1e-3) / 1e12,
                                                                      "peak_TFLOPs": 78.6, "frac": flops_c5 / (ms_c5 * 1e-3) / 1e12 / 78.6}}
+# ---- CPU legs (the oracle, timed on this host): what the reference's CPU path costs in the SAME operating regime -------------
+# Never credit: context for the small configurations, where a CPU factorisation takes microseconds and the GPU path is launch- /
+# start-up-bound.  The oracle is called through ctypes (~3-5 us per call, included); thread count stated per leg.
+def timeit(f, reps):
+    f()
+    t0 = time.perf_counter()
+    for _ in range(reps): f()
+    return (time.perf_counter() - t0) / reps
+
+cores = os.cpu_count()
+rng = np.random.default_rng(7)
+# C1: per iteration (N = 1 .. 20, D = 1): GP MAP fit = 300 DIRECT value evaluations + the local phase (value + gradient; the
+# device fit's own count is not exported by the demo: 100 assumed), then FindNextPoint = fit + 50 D EI values + 10 D EI value+gradient
+c1 = 0.0
+for n in range(1, 21):
+    Xn = rng.uniform(0, 1, (1, n)); yn = np.sin(6 * Xn[0]) + 1.0
+    xh = np.array([0.5, 1e-3, 0.3])
+    t_v = timeit(lambda: oracle.gp_map_objective(1, Xn, yn, xh, want_grad=False), 20)
+    t_g = timeit(lambda: oracle.gp_map_objective(1, Xn, yn, xh, want_grad=True), 20)
+    t_fit = timeit(lambda: oracle.Regressor(Xn, yn, np.array([0.5, 0.3]), 1e-3, kernel=1), 5)
+    rg = oracle.Regressor(Xn, yn, np.array([0.5, 0.3]), 1e-3, kernel=1)
+    q = rng.uniform(0, 1, (1, 1))
+    t_ev = timeit(lambda: rg.acq_eval_batch(q, want_grad=False), 20); t_eg = timeit(lambda: rg.acq_eval_batch(q, want_grad=True), 20)
+    c1 += 300 * t_v + 100 * t_g + t_fit + 50 * t_ev + 10 * t_eg
+out["C1_bayesian_optimization_1d_20_iterations"]["cpu_oracle_wall_s"] = c1
+out["C1_bayesian_optimization_1d_20_iterations"]["cpu_oracle_note"] = ("sum over 20 iterations of 300 + 100 MAP-objective evaluations, the fit, 50 EI values "
+    "and 10 EI value+gradient evaluations at that iteration's N, oracle (hoisted), 1 thread, ctypes call overhead included")
+# C3: per submit at N = 3, 5, .., 61 (D = 32): 100 preference-objective evaluations (value + gradient; the oracle refactors K per
+# call, the reference caches it for use_map_hyperparams = false: an upper bound), the fit, 50 D = 1600 EI values (DIRECT) and
+# 10 D = 320 EI value + gradient evaluations (L-BFGS)
+D3 = 32
+c3 = []
+for n in range(3, 62, 2):
+    Xn = rng.uniform(0, 1, (D3, n)); yn = rng.normal(size=n)
+    prefs = [[3 * i + 1, 3 * i, 3 * i + 2] for i in range(max(1, (n - 1) // 3)) if 3 * i + 2 < n] or [[0, 1, 2][:n]]
+    t_p = timeit(lambda: oracle.pref_objective(1, Xn, prefs, yn, r=0.5, a=0.5, b=0.001, btl_scale=0.01), 5)
+    th = np.concatenate([[0.5], np.full(D3, 0.5)])
+    t_fit = timeit(lambda: oracle.Regressor(Xn, yn, th, 0.001, kernel=1), 3)
+    rg = oracle.Regressor(Xn, yn, th, 0.001, kernel=1)
+    Q = rng.uniform(0, 1, (D3, 160)); q1 = Q[:, :1]
+    t_ev = timeit(lambda: rg.acq_eval_batch(Q, want_grad=False), 3) / 160
+    t_eg = timeit(lambda: rg.acq_eval_batch(q1, want_grad=True), 10)
+    c3.append(1e3 * (100 * t_p + t_fit + 1600 * t_ev + 320 * t_eg))
+out["C3_sequential_line_search_nd_D32_30_iterations"]["cpu_oracle_ms_per_submit_mean"] = float(np.mean(c3))
+out["C3_sequential_line_search_nd_D32_30_iterations"]["cpu_oracle_ms_per_submit_last"] = c3[-1]
+out["C3_sequential_line_search_nd_D32_30_iterations"]["cpu_oracle_note"] = ("per submit: 100 preference-objective evaluations + fit + 1600 EI values + 320 EI "
+    f"value+gradient evaluations at N = 3 .. 61, oracle (hoisted predictor), OMP threads {os.environ.get('OMP_NUM_THREADS')} of {cores} cores")
+# C5: ONE hoisted MAP objective + gradient evaluation at N = 4096, D = 128
+t0 = time.perf_counter(); oracle.gp_map_objective(1, X, y, x, want_grad=True); t_c5 = time.perf_counter() - t0
+out["C5_map_objective_gradient_N4096_D128"]["cpu_oracle_s_per_evaluation"] = t_c5
+out["C5_map_objective_gradient_N4096_D128"]["cpu_oracle_note"] = f"oracle slso_gp_map_objective (hoisted), OMP threads {os.environ.get('OMP_NUM_THREADS')} of {cores} cores"
+# crossover: smallest N (D = 32, Matern) at which ONE fit + 4096-point predict is faster on the device than in the oracle
+cross = None
+for n in (32, 64, 128, 256, 512, 1024):
+    Xn = rng.uniform(0, 1, (32, n)); yn = rng.normal(size=n); th = np.concatenate([[0.5], np.full(32, 1.0)]); Q = rng.uniform(0, 1, (32, 4096))
+    def gpu():
+        g = m.GP(ctx, Xn, yn, th, 0.005, 1); g.predict(Q); g.close()
+    def cpu():
+        oracle.Regressor(Xn, yn, th, 0.005, kernel=1).predict_batch(Q)
+    tg, tc = timeit(gpu, 3), timeit(cpu, 2)
+    out.setdefault("crossover_fit_plus_4096_predict_D32", []).append({"N": n, "gpu_ms": tg * 1e3, "cpu_oracle_ms": tc * 1e3})
+    if cross is None and tg < tc: cross = n
+out["crossover_N_gpu_faster_than_cpu_oracle"] = cross
 json.dump(out, open(os.path.join(R, "gpurun_out", "configs.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
