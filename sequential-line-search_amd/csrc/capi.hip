@@ -172,19 +172,16 @@ slsk::PotrfAux* sls_ctx::potrf_lookahead(int Np) {
     const char* e = getenv("SLS_POTRF_LOOKAHEAD");
     const int f = e ? atoi(e) : SLS_POTRF_LOOKAHEAD_DEFAULT;
     const int mode = slsk::potrf_default_mode(Np);
-    if (f <= 0 || mode == 1 || mode == 3 || (mode == 0 && slsk::potrf_default_nbo(Np) <= 1)) return nullptr;
+    if (f <= 0 || mode == 3 || (mode == 0 && slsk::potrf_default_nbo(Np) <= 1)) return nullptr;
     if (!potrf_aux.side) slsk::potrf_aux_create(&potrf_aux, f);
     return &potrf_aux;
 }
 
-int* sls_ctx::potrf_sync(int Np) {
-    // sync words of the single-launch factorisation (barrier form) live behind the info words; nullptr (multi-launch schedule)
-    // if they would not fit: 32 + 3 nb + 2 <= 960, i.e. nb <= 308 (N <= 39 424)
-    return (potrf_persistent_ok && 32 + 2 * (Np / 128) + Np / 128 + 2 <= 960) ? d_info + 64 : nullptr;
+void sls_ctx::potrf_tick_rearm() {
+    if (!potrf_persistent_ok && potrf_rearm > 0 && --potrf_rearm == 0) potrf_persistent_ok = true;
 }
 
 int* sls_ctx::potrf_df_sync(int Np) {
-    if (!potrf_persistent_ok && potrf_rearm > 0 && --potrf_rearm == 0) potrf_persistent_ok = true;   // once per fit
     if (!potrf_persistent_ok || slsk::potrf_default_mode(Np) != 3) return nullptr;
     potrf_df.ensure((slsk::potrf_dataflow_sync_ints(Np) + 1) / 2);
     return reinterpret_cast<int*>(potrf_df.p);
@@ -197,11 +194,13 @@ bool potrf_gave_up(sls_ctx* c, int abort_flag, int attempt) {
         set_error("Cholesky factorisation aborted: a device-side wait expired");
         throw HipFail{SLS_ERR_HIP};
     }
-    // The single-launch forms need every workgroup resident at once; another kernel on the device (a second context, a
-    // profiler) can prevent that.  This context uses the multi-launch schedule for the next fits and then tries again; the
-    // count is visible through sls_prof_get("potrf_fallbacks").
+    // The single-launch form needs every workgroup resident at once; another kernel on the device (another process, a
+    // profiler, RCCL) can prevent that.  This context uses the multi-launch schedule for the next fits and then tries again,
+    // backing off (16, 64, 256, ... 4096 fits) while the device stays shared; the count is visible through
+    // sls_prof_get("potrf_fallbacks") and in bench.py's line.  The two schedules agree to rounding, not bit for bit.
     c->potrf_persistent_ok = false;
-    c->potrf_rearm = 16;
+    c->potrf_rearm = c->potrf_rearm_next;
+    c->potrf_rearm_next = std::min(4096, c->potrf_rearm_next * 4);
     c->potrf_fallbacks += 1;
     return true;
 }
@@ -241,10 +240,40 @@ extern "C" int sls_ctx_create(int device, sls_ctx** out) {
     SLS_CATCH
 }
 
+void* sls_ctx::host_take(size_t bytes, bool mapped, size_t* got) {
+    int best = -1;
+    for (int i = 0; i < (int)host_free.size(); ++i)
+        if (host_free[i].mapped == mapped && host_free[i].bytes >= bytes && (best < 0 || host_free[i].bytes < host_free[best].bytes)) best = i;
+    if (best >= 0) {
+        HostBlock b = host_free[best];
+        host_free.erase(host_free.begin() + best);
+        *got = b.bytes;
+        return b.p;
+    }
+    void* p = nullptr;
+    const size_t sz = std::max<size_t>(bytes, 4096);
+    if (hipHostMalloc(&p, sz, mapped ? hipHostMallocMapped : hipHostMallocDefault) != hipSuccess) {
+        slsk::set_error("hipHostMalloc(%zu) failed", sz);
+        throw slsk::HipFail{SLS_ERR_HIP};
+    }
+    *got = sz;
+    return p;
+}
+void sls_ctx::host_give(void* p, size_t bytes, bool mapped) {
+    if (!p) return;
+    if (host_free.size() >= 16) {
+        (void)hipHostFree(p);
+        return;
+    }
+    host_free.push_back(HostBlock{p, bytes, mapped});
+}
+
 extern "C" int sls_ctx_destroy(sls_ctx* ctx) {
     if (!ctx) return SLS_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    for (auto& b : ctx->host_free) (void)hipHostFree(b.p);
+    ctx->host_free.clear();
     ctx->prof_collect();
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     slsk::potrf_aux_destroy(&ctx->potrf_aux);
@@ -380,7 +409,8 @@ static void gp_fit_device(sls_gp* g) {
     launch_fill(c->stream, g->Linv.p, (long)Np * Np, 0.0);
     {
         ProfScope ps(c, "potrf");
-        launch_potrf(c->stream, g->L.p, Np, g->Linv.p, c->d_info, 0, c->potrf_lookahead(Np), c->potrf_sync(Np), c->potrf_df_sync(Np));
+        c->potrf_tick_rearm();
+        launch_potrf(c->stream, g->L.p, Np, g->Linv.p, c->d_info, 0, c->potrf_lookahead(Np), c->potrf_df_sync(Np));
     }
     {
         ProfScope ps(c, "trtri");
@@ -1088,7 +1118,8 @@ extern "C" int sls_potrf(sls_ctx* c, double* A, int N) {
     for (int attempt = 0;; ++attempt) {
         upload_padded_spd(c, Ad, A, N, Np);
         SLS_HIP(hipMemsetAsync(c->d_info, 0, 64, c->stream));
-        launch_potrf(c->stream, Ad.p, Np, Li.p, c->d_info, 0, c->potrf_lookahead(Np), c->potrf_sync(Np), c->potrf_df_sync(Np));
+        c->potrf_tick_rearm();
+        launch_potrf(c->stream, Ad.p, Np, Li.p, c->d_info, 0, c->potrf_lookahead(Np), c->potrf_df_sync(Np));
         launch_zero_upper(c->stream, Ad.p, Np);
         SLS_HIP(hipMemcpyAsync(info2, c->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         d2h_matrix(c, out.data(), Ad.p, N, Np);

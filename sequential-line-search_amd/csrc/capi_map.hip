@@ -33,18 +33,23 @@ struct sls_nll {
     // read after the stream synchronisation -- no device-to-host copy call per evaluation
     double* small_host = nullptr;      // host address
     double* small_host_dev = nullptr;  // the same memory as the device sees it
+    size_t small_host_bytes = 0, mo_out_bytes = 0;
     // device-resident MAP fit (map_opt_kernel): index image of the preference tuples (uploaded when it changes), the vectors of
     // a call, the optimiser state, the result block in mapped host memory, a page-locked staging block
     DBuf mo_idx, mo_vec, mo_state, mo_btl;
+    // value-only objective for several parameter sets at once (sls_gp_nll_batch, N > 128): P bordered matrices, their scaled
+    // design matrices, flag tables and results
+    DBuf bt_L, bt_T, bt_XT, bt_nx, bt_il, bt_sync, bt_out;
+    int bt_P = 0;
     std::vector<int> mo_idx_host;      // what mo_idx holds
     double* mo_out = nullptr;          // mapped: host address
     double* mo_out_dev = nullptr;
     char* mo_stage = nullptr;          // page-locked
     size_t mo_stage_bytes = 0;
-    ~sls_nll() {
-        if (small_host) (void)hipHostFree(small_host);
-        if (mo_out) (void)hipHostFree(mo_out);
-        if (mo_stage) (void)hipHostFree(mo_stage);
+    ~sls_nll() {   // page-locked blocks go back to the context (sls_nll_destroy holds its lock)
+        ctx->host_give(small_host, small_host_bytes, true);
+        ctx->host_give(mo_out, mo_out_bytes, true);
+        ctx->host_give(mo_stage, mo_stage_bytes, false);
     }
 };
 
@@ -75,6 +80,7 @@ extern "C" int sls_nll_create(sls_ctx* ctx, const double* X, int D, int N, int k
 extern "C" int sls_nll_destroy(sls_nll* h) {
     if (!h) return SLS_OK;
     slsk::note_entry();
+    std::unique_lock<std::recursive_mutex> lock_(h->ctx->mtx);
     (void)hipSetDevice(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
     delete h;
@@ -105,7 +111,8 @@ static bool nll_factor_enqueue(sls_nll* h, const double* theta, double b) {
     launch_gram_sym(c->stream, h->XT.p, Np, h->Dp, h->nx.p, Np, N, ks, b, h->L.p, true);
     SLS_HIP(hipMemsetAsync(c->d_info, 0, 64, c->stream));
     launch_fill(c->stream, h->Linv.p, (long)Np * Np, 0.0);
-    launch_potrf(c->stream, h->L.p, Np, h->Linv.p, c->d_info, 0, c->potrf_lookahead(Np), c->potrf_sync(Np), c->potrf_df_sync(Np));
+    c->potrf_tick_rearm();
+    launch_potrf(c->stream, h->L.p, Np, h->Linv.p, c->d_info, 0, c->potrf_lookahead(Np), c->potrf_df_sync(Np));
     h->G.ensure((size_t)Np * Np);   // the gradient's weight matrix, written after the factorisation: holds (L^-1)^T until then
     launch_trtri(c->stream, h->L.p, Np, h->Linv.p, h->Kinv.p, h->G.p);
     launch_lauum(c->stream, h->G.p, Np, h->Kinv.p);
@@ -152,9 +159,10 @@ static void nll_small_eval(sls_nll* h, const double* y, const double* theta, dou
     NllSmallArgs args;
     args.X = h->X.p; args.D = D; args.N = N; args.want_grad = want_grad ? 1 : 0;
     args.info = c->d_info;
-    static const bool zero_copy = [] { const char* e = getenv("SLS_SMALL_ZEROCOPY"); return e ? atoi(e) != 0 : true; }();
+    const char* zc_env = getenv("SLS_SMALL_ZEROCOPY");   // read per call, like the other A/B switches
+    const bool zero_copy = zc_env ? atoi(zc_env) != 0 : true;
     if (zero_copy && !h->small_host) {
-        SLS_HIP(hipHostMalloc((void**)&h->small_host, 160 * sizeof(double), hipHostMallocMapped));
+        h->small_host = static_cast<double*>(c->host_take(160 * sizeof(double), true, &h->small_host_bytes));
         SLS_HIP(hipHostGetDevicePointer((void**)&h->small_host_dev, h->small_host, 0));
     }
     h->small_out.ensure(160);
@@ -326,9 +334,9 @@ extern "C" int sls_gp_nll_batch(sls_nll* h, const double* y, const double* xs, i
         for (int d = 0; d < D; ++d) reg += log_lognormal(x[2 + d], r_mu, r_s2);
         return reg;
     };
-    if (!nll_small_ok(h, false) || B <= 1) {
+    auto sequential = [&](int k0, int k1) {
         std::vector<double> theta(D + 1);
-        for (int k = 0; k < B; ++k) {
+        for (int k = k0; k < k1; ++k) {
             const double* x = xs + (size_t)k * (D + 2);
             theta[0] = x[0];
             for (int d = 0; d < D; ++d) theta[1 + d] = x[2 + d];
@@ -341,19 +349,88 @@ extern "C" int sls_gp_nll_batch(sls_nll* h, const double* y, const double* xs, i
                 values[k] = -HUGE_VAL;
             }
         }
+    };
+    // every parameter set is validated up front, the same way on every path: a <= 0, b < 0 or a length scale <= 0 is an error
+    for (int k = 0; k < B; ++k) {
+        const double* x = xs + (size_t)k * (D + 2);
+        SLS_REQUIRE(x[0] > 0.0 && x[1] >= 0.0, "sls_gp_nll_batch: signal variance must be positive, noise level >= 0 (point %d)", k);
+        for (int d = 0; d < D; ++d) SLS_REQUIRE(x[2 + d] > 0.0, "length scale %d must be positive (point %d)", d, k);
+    }
+    if (!nll_small_ok(h, false)) {
+        // N > 128: bordered factorisations (quad and log-det from the factor alone: no inverse), several parameter sets per
+        // persistent launch, each on its own share of the chip -- one factorisation of this size is bound by its serial chain and
+        // leaves most CUs idle.  SLS_NLL_BATCH=0: one full evaluation after the other (the round-3 path).
+        const char* be = getenv("SLS_NLL_BATCH");
+        const int Np2 = round_up(N + 1, 128);
+        const int Pmax = (be && atoi(be) == 0) ? 0 : potrf_dataflow_max_problems(Np2);
+        int* dfs = Pmax >= 1 ? c->potrf_df_sync(Np2) : nullptr;   // nullptr: the single-launch form is switched off
+        if (!dfs || Np2 / 128 < 3) {
+            sequential(0, B);
+            return SLS_OK;
+        }
+        const size_t mat = (size_t)Np2 * Np2, sync_ints = (potrf_dataflow_sync_ints(Np2) + 63) / 64 * 64;
+        const int Dp = h->Dp, Dcols = h->Dcols;
+        if (h->bt_P < Pmax) {
+            h->bt_L.ensure(mat * Pmax); h->bt_T.ensure(mat * Pmax);
+            h->bt_XT.ensure((size_t)Np2 * Dcols * Pmax); h->bt_nx.ensure((size_t)Np2 * Pmax); h->bt_il.ensure((size_t)Dcols * Pmax);
+            h->bt_sync.ensure((sync_ints * Pmax + 1) / 2); h->bt_out.ensure(2 * Pmax);
+            h->bt_P = Pmax;
+        }
+        SLS_HIP(hipMemcpyAsync(h->y.p, y, (size_t)N * 8, hipMemcpyHostToDevice, c->stream));
+        std::vector<double> il((size_t)Dcols * Pmax), out(2 * Pmax);
+        for (int k0 = 0; k0 < B;) {
+            const int P = std::min(Pmax, B - k0);
+            std::fill(il.begin(), il.end(), 0.0);
+            for (int q = 0; q < P; ++q)
+                for (int d = 0; d < D; ++d) il[(size_t)q * Dcols + d] = 1.0 / xs[(size_t)(k0 + q) * (D + 2) + 2 + d];
+            SLS_HIP(hipMemcpyAsync(h->bt_il.p, il.data(), (size_t)Dcols * P * 8, hipMemcpyHostToDevice, c->stream));
+            SLS_HIP(hipStreamSynchronize(c->stream));   // `il` is rewritten for the next group
+            for (int q = 0; q < P; ++q) {
+                const double* x = xs + (size_t)(k0 + q) * (D + 2);
+                double* XTq = h->bt_XT.p + (size_t)q * Np2 * Dcols;
+                double* nxq = h->bt_nx.p + (size_t)q * Np2;
+                launch_prep_points(c->stream, h->X.p, D, N, h->bt_il.p + (size_t)q * Dcols, XTq, Np2, Np2, Dcols, nxq);
+                launch_gram_sym(c->stream, XTq, Np2, Dp, nxq, Np2, N, KernelSpec{h->kernel, x[0]}, x[1], h->bt_L.p + q * mat, true);
+            }
+            launch_border_row(c->stream, h->bt_L.p, (long)mat, P, Np2, N, h->y.p, 1e200);
+            SLS_HIP(hipMemsetAsync(c->d_info, 0, 64, c->stream));
+            c->potrf_tick_rearm();
+            int info[16] = {0};
+            bool ok = launch_potrf_dataflow_batch(c->stream, h->bt_L.p, Np2, h->bt_T.p, c->d_info, reinterpret_cast<int*>(h->bt_sync.p), P,
+                                                  (long)mat, (long)sync_ints, false);
+            if (ok) {
+                launch_border_reduce(c->stream, h->bt_L.p, (long)mat, P, Np2, N, h->bt_out.p);
+                SLS_HIP(hipMemcpyAsync(info, c->d_info, 16 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                SLS_HIP(hipMemcpyAsync(out.data(), h->bt_out.p, 2 * P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+                SLS_HIP(hipStreamSynchronize(c->stream));
+                int aborted = 0;
+                for (int q = 0; q < P; ++q) aborted |= info[2 * q + 1];
+                if (aborted) ok = !potrf_gave_up(c, aborted, 0);   // the context switches to the multi-launch schedule (or throws)
+            }
+            if (!ok) {
+                sequential(k0, B);   // this group and the rest on the general path
+                return SLS_OK;
+            }
+            for (int q = 0; q < P; ++q) {
+                const double* x = xs + (size_t)(k0 + q) * (D + 2);
+                values[k0 + q] = info[2 * q] != 0 ? -HUGE_VAL : -0.5 * out[2 * q] - 0.5 * out[2 * q + 1] - 0.5 * N * std::log(2.0 * M_PI) + prior(x);
+            }
+            k0 += P;
+        }
+        h->have_factor = false;
+        return SLS_OK;
+    }
+    if (B <= 1) {
+        sequential(0, B);
         return SLS_OK;
     }
     const size_t in_stride = 2 + D + N, out_stride = 8;
     std::vector<double> in((size_t)B * in_stride);
     for (int k = 0; k < B; ++k) {
         const double* x = xs + (size_t)k * (D + 2);
-        SLS_REQUIRE(x[0] > 0.0 && x[1] >= 0.0, "sls_gp_nll_batch: signal variance must be positive, noise level >= 0");
         double* o = in.data() + (size_t)k * in_stride;
         o[0] = x[0]; o[1] = x[1];
-        for (int d = 0; d < D; ++d) {
-            SLS_REQUIRE(x[2 + d] > 0.0, "length scale %d must be positive", d);
-            o[2 + d] = x[2 + d];
-        }
+        for (int d = 0; d < D; ++d) o[2 + d] = x[2 + d];
         std::memcpy(o + 2 + D, y, sizeof(double) * N);
     }
     h->small_in.ensure(in.size());
@@ -429,18 +506,18 @@ static void map_opt_run(sls_nll* h, const MapOptProblem& pb, const double* z0, c
     const size_t vec_doubles = (size_t)3 * n + N;
     const size_t need = idx.size() * sizeof(int) + 8 + vec_doubles * 8;
     if (need > h->mo_stage_bytes) {
-        if (h->mo_stage) (void)hipHostFree(h->mo_stage);
+        c->host_give(h->mo_stage, h->mo_stage_bytes, false);
         h->mo_stage = nullptr;
-        SLS_HIP(hipHostMalloc((void**)&h->mo_stage, need * 2, hipHostMallocDefault));
-        h->mo_stage_bytes = need * 2;
+        h->mo_stage_bytes = 0;
+        h->mo_stage = static_cast<char*>(c->host_take(need * 2, false, &h->mo_stage_bytes));
     }
     if (!h->mo_out) {
-        SLS_HIP(hipHostMalloc((void**)&h->mo_out, MAP_OPT_OUT_DOUBLES * sizeof(double), hipHostMallocMapped));
+        h->mo_out = static_cast<double*>(c->host_take(MAP_OPT_OUT_DOUBLES * sizeof(double), true, &h->mo_out_bytes));
         SLS_HIP(hipHostGetDevicePointer((void**)&h->mo_out_dev, h->mo_out, 0));
     }
     h->mo_idx.ensure((idx.size() + 1) / 2 + 1);
     h->mo_vec.ensure(vec_doubles);
-    h->mo_state.ensure(MAP_OPT_STATE_DOUBLES);
+    h->mo_state.ensure(MAP_OPT_STATE_DOUBLES + 8);   // + the optional section trace
     h->mo_btl.ensure(std::max(F, 1));
     // the previous call's copies have completed (every call ends with a stream synchronisation): the staging block is free
     double* vst = reinterpret_cast<double*>(h->mo_stage);
@@ -472,6 +549,11 @@ static void map_opt_run(sls_nll* h, const MapOptProblem& pb, const double* z0, c
     a.state = h->mo_state.p;
     a.out = h->mo_out_dev;
     a.info = c->d_info;
+    a.trace = nullptr;
+    if (getenv("SLS_MAP_TRACE") && !eval_only) {
+        a.trace = reinterpret_cast<long long*>(h->mo_state.p + MAP_OPT_STATE_DOUBLES);
+        SLS_HIP(hipMemsetAsync(a.trace, 0, 8 * sizeof(long long), c->stream));
+    }
     const bool stepwise = !eval_only && evals_per_launch > 0 && evals_per_launch < max_evals;
     a.budget = stepwise ? evals_per_launch : a.max_evals;
     a.fresh = 1;
@@ -481,6 +563,13 @@ static void map_opt_run(sls_nll* h, const MapOptProblem& pb, const double* z0, c
         SLS_HIP(hipStreamSynchronize(c->stream));
         if (!stepwise || out[2] != 0.0 || (int)out[1] >= max_evals) break;
         a.fresh = 0;
+    }
+    if (a.trace) {
+        long long tr[8];
+        SLS_HIP(hipMemcpy(tr, a.trace, sizeof(tr), hipMemcpyDeviceToHost));
+        fprintf(stderr, "map_opt trace (us): N %d n %d prefs %d evals %lld | publish+factor %.1f  alpha %.1f  hyper-grad %.1f  btl %.1f  "
+                "value+gradient %.1f  optimiser %.1f  total %.1f\n", N, n, P, tr[6], tr[0] * 0.01, tr[1] * 0.01, tr[2] * 0.01, tr[3] * 0.01,
+                tr[4] * 0.01, tr[5] * 0.01, tr[7] * 0.01);
     }
     h->have_factor = false;   // the tiled path's cached factor (L, Linv, Kinv buffers) was not refreshed
     if (value) *value = out[0];

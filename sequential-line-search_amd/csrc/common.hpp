@@ -98,12 +98,25 @@ struct sls_ctx {
     // look-ahead schedule of the Cholesky factorisation: CU-masked side stream + events, created on first use
     slsk::PotrfAux potrf_aux;
     slsk::PotrfAux* potrf_lookahead(int Np);   // nullptr unless SLS_POTRF_LOOKAHEAD selects the two-stream schedule
-    int* potrf_sync(int Np);             // device sync words for launch_potrf_persistent (nullptr: multi-launch schedule)
-    bool potrf_persistent_ok = true;     // cleared when a persistent factorisation gave up (bounded wait expired)
+    bool potrf_persistent_ok = true;     // cleared when a single-launch factorisation gave up (bounded wait expired)
     int potrf_rearm = 0;                 // fits left on the multi-launch schedule before the single-launch form is tried again
+    int potrf_rearm_next = 16;           // ... and how many it will be after the next give-up (16, 64, 256, ... 4096)
+    void potrf_tick_rearm();             // once per fit, BEFORE the factorisation is enqueued
     long potrf_fallbacks = 0;            // how often a single-launch factorisation gave up (sls_prof_get("potrf_fallbacks"))
     slsk::DBuf potrf_df;                 // flag tables of the dataflow form (grown on demand)
-    int* potrf_df_sync(int Np);          // nullptr: dataflow form switched off for this context
+    int* potrf_df_sync(int Np);          // nullptr: single-launch form switched off for this context (no side effects)
+
+    // page-locked host blocks (result blocks the small-problem kernels write directly, staging for uploads) handed out to the
+    // handles of this context and taken back when a handle dies: hipHostMalloc + hipHostFree cost ~260 us per block (round 4, C3:
+    // two blocks per SubmitFeedbackData were 0.5 ms of its 4 ms)
+    struct HostBlock {
+        void* p;
+        size_t bytes;
+        bool mapped;
+    };
+    std::vector<HostBlock> host_free;
+    void* host_take(size_t bytes, bool mapped, size_t* got);
+    void host_give(void* p, size_t bytes, bool mapped);
 
     hipEvent_t get_event();
     void prof_begin(const char* name, hipEvent_t& e0);

@@ -110,6 +110,9 @@ struct MapOptArgs {
     double* out;              // MAP_OPT_OUT_DOUBLES: [0] objective at x, [1] evaluations used, [2] finished, [3] last pivot info,
                               // [8 .. 8+n) x, [8+192 .. 8+192+n) gradient (eval_only)
     int* info;
+    // optional (SLS_MAP_TRACE=1, probes): ticks of the 100 MHz clock thread 0 spent in [0] publishing the trial point + factorisation,
+    // [1] alpha, [2] hyper-parameter gradient, [3] BTL terms, [4] value + gradient slots, [5] optimiser, [6] evaluations, [7] kernel
+    long long* trace;
 };
 void launch_map_opt(hipStream_t s, int kernel, const MapOptArgs& args);
 
@@ -218,18 +221,23 @@ struct PotrfAux {
 };
 int potrf_default_nbo(int Np);
 void launch_potrf(hipStream_t s, double* A, int Np, double* Linv, int* info, int nbo = 0, PotrfAux* aux = nullptr,
-                  int* persist_sync = nullptr, int* dataflow_sync = nullptr);
+                  int* dataflow_sync = nullptr);
 void launch_gemm_splitk_nt(hipStream_t s, const double* A, long lda, const double* B, long ldb, double* Cpart, long ldc,
                            long part_stride, int mt, int nt, int K, int chunks);
-// Dataflow form of the single-launch factorisation (SLS_POTRF_MODE=3, default): per-tile ownership and ready flags instead
-// of grid barriers.  sync = potrf_dataflow_sync_ints(Np) ints of device scratch; returns false when not applicable.
+// Single-launch factorisation (SLS_POTRF_MODE=3, default): per-tile ownership and ready flags, no grid barriers.  sync =
+// potrf_dataflow_sync_ints(Np) ints of device scratch; returns false when not applicable.  info[1] != 0 afterwards: a bounded
+// wait expired (the kernel aborted; results undefined).  launch_potrf takes this path when dataflow_sync != nullptr, Np >= 384
+// and SLS_POTRF_MODE is not 0 (0 = multi-launch schedule).
 size_t potrf_dataflow_sync_ints(int Np);
 bool launch_potrf_dataflow(hipStream_t s, double* A, int Np, double* Linv, int* info, int* sync, long long* trace = nullptr);
-// The whole factorisation in ONE persistent launch (see kernels_chol.hip); sync = device scratch of >= 8 + 2 (Np/128) ints.
-// info[1] != 0 afterwards: a bounded wait expired (the kernel aborted; results undefined).  launch_potrf takes this path
-// when persist_sync != nullptr, Np >= 384 and SLS_POTRF_MODE is 1 (or 3 where the dataflow form does not apply; 0 = multi-launch).
+// nprob independent Np x Np factorisations in ONE launch, each on its own share of the chip's workgroups: problem q lives at
+// A + q strideA / Linv + q strideA (doubles), uses sync + q stride_sync (ints) and reports into info[2 q], info[2 q + 1].
+// block_inverses = false: the 128 x 128 inverses T_jj are not formed (callers that only need L).  Same bits per problem as a
+// launch of its own (a tile's arithmetic does not depend on how many workgroups take part).
+int potrf_dataflow_max_problems(int Np);
+bool launch_potrf_dataflow_batch(hipStream_t s, double* A, int Np, double* Linv, int* info, int* sync, int nprob, long strideA,
+                                 long stride_sync, bool block_inverses, long long* trace = nullptr);
 int potrf_default_mode(int Np);
-void launch_potrf_persistent(hipStream_t s, double* A, int Np, double* Linv, int* info, int* sync, long long* trace = nullptr);
 // side stream restricted by a CU mask that leaves `free_per_xcd` CUs of each of the 8 XCDs to other streams (0: plain stream)
 void potrf_aux_create(PotrfAux* aux, int free_per_xcd);
 void potrf_aux_destroy(PotrfAux* aux);
@@ -249,6 +257,10 @@ void launch_fill(hipStream_t s, double* p, long n, double v);
 // mu_data[i] = y[i] - b*alpha[i] (i<N); out: first argmax + value; logdet = 2 sum log L_ii (i<N)
 void launch_mu_data(hipStream_t s, const double* y, const double* alpha, double b, int N, double* mu_data);
 void launch_logdet(hipStream_t s, const double* L, int Np, int N, double* out);
+// bordered factorisation (value-only MAP objective): row N of each of the nprob matrices A + q strideA <- (y^T, c); after the
+// factorisation out[2 q] = y^T K^-1 y (= |row N of L|^2) and out[2 q + 1] = log|K|
+void launch_border_row(hipStream_t s, double* A, long strideA, int nprob, int Np, int N, const double* y, double c);
+void launch_border_reduce(hipStream_t s, const double* L, long strideA, int nprob, int Np, int N, double* out);
 
 // ---- rank-1 growth of the fitted state by one data point (kernels_chol.hip) ----
 // scal_out[0] = k.u, scal_out[1] = l.l, scal_out[2] = u.y  (fixed-order block reductions)

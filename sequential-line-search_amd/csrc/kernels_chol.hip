@@ -10,6 +10,8 @@
 // Triangular inverse: recursive doubling over block pairs, X21 = -X22 (L21 X11), every level two batched GEMMs.
 #include <algorithm>
 #include <cstdlib>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <type_traits>
 
@@ -292,22 +294,11 @@ static void diag_attr() {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Single-launch factorisation: ONE persistent kernel runs all N/128 block steps.
-//
-// The multi-launch schedule below pays a dependent-launch gap for every kernel of every block step -- measured on MI355X:
-// 87 us per step at N = 2048 where the three kernels of a step hold ~40 us of work (tools/probes/potrf_bench) -- and the
-// diagonal block of step j+1 cannot start before the whole trailing update of step j has drained.  Here gridDim.x = number
-// of CUs workgroups (one per CU: every workgroup owns a whole CU's LDS so that any of them could factor a diagonal block)
-// stay resident for the whole factorisation and synchronise through device-scope counters:
-//   workgroup 0        factors the diagonal blocks.  It starts block j+1 as soon as the ONE trailing tile (j+1, j+1) has
-//                      been updated by step j (flag), i.e. concurrently with the rest of that update: the serial chain per
-//                      step is  panel tile -> first update tile -> diagonal block  instead of  3 launches + full update;
-//   workgroups 1..G-1  panel tiles L_ij = A_ij T_jj^T (after the flag "block j factored"), grid barrier, trailing tiles
-//                      A_ik -= L_ij L_kj^T dealt round-robin (tile (j+1, j+1) first), grid barrier.
-// Barriers and flags are release / acquire operations at agent scope (the 8 XCDs have private L2s); every wait is a bounded
-// spin (0.2 s) that raises an abort flag, so an unexpected residency pattern cannot hang the device -- the launcher's
-// caller sees SLS_ERR_HIP instead.  Arithmetic per tile is identical to the multi-launch schedule (same k order): the two
-// produce the same bits.
+// Single-launch factorisation (dataflow form, below): arguments and the flag / wait primitives.
+// Rounds 2-3 also carried a form with grid barriers (potrf_persistent_kernel) and a hybrid of persistent panel kernels with
+// side-stream updates; both were superseded by the dataflow form (DESIGN.md 8a keeps their measurements) and were removed in
+// round 4 together with the probe switches of the dataflow form that measured "no gain" (cyclic owner grid, products with T_jj
+// instead of triangular solves, chain tiles through global memory, acquire / sleep variants).
 // ---------------------------------------------------------------------------------------------------------
 struct PersistArgs {
     double* A;
@@ -315,26 +306,18 @@ struct PersistArgs {
     int nb;
     double* Linv;
     int* info;        // [0] first non-positive pivot + 1, [1] abort
-    // [0] global barrier counter (counts XCD leaders), [1] set-up counter, [8 + x] workgroups resident on XCD x,
-    // [16 + x] arrivals on XCD x, [24 + x] "go" epoch of XCD x, [PK_FLAGS + j] tile (j, j) ready for factoring,
-    // [PK_FLAGS + nb + j] block j factored
-    int* sync;
-    int nbo;          // 128-columns per outer block of the two-level update (1: every step updates the whole trailing matrix)
-    int j0, j1;       // block steps [j0, j1) (j1 = nb: to the end, trailing updates included; j1 < nb: PANEL mode)
-    int k0;           // k0 < j0: first apply the block columns [k0, j0) to block column j0 (hybrid schedule, phase 0)
-    int* ext_flag;    // nullptr or a device word another stream raises when columns j0+1 .. have received [k0, j0)
+    int* sync;        // [1] set-up counter, [8 + x] workers resident on XCD x, [DF_FACT ..] the flag tables (see DF_FACT)
+    int nbo;          // 128-columns per update chunk (1: every step is applied on its own)
     long long timeout;
-    long long* trace;   // optional (probes): 16 wall-clock stamps per step, [0..7] workgroup 0, [8..15] workgroup 1
-    int pr;             // dataflow form: rows of the owner grid
-    int map;            // dataflow form: 0 cyclic PR x PC owner grid, 1 tiles dealt round-robin in column-major order
-    int near;           // dataflow form: columns at the start of an outer block that take the previous block step by step
-    int acq;            // dataflow form: 1 agent-scope acquire before every task, 0 compiler-level ordering only (probes)
-    int idle_sleep;     // dataflow form: s_sleep argument of an idle scheduling round
-    int fuse;           // dataflow form: 1 the chain keeps its tiles in LDS between products (default), 0 through global memory
-    int trsm;           // dataflow form: 1 panel tiles by triangular solves, block inverses formed after the factorisation
-    int chain2;         // dataflow form: 1 two chain workgroups (factor / follow with the solve), needs trsm
+    long long* trace;   // optional (probes): 16 wall-clock stamps per step of the chain, then 16 words per worker
+    int near;           // columns at the start of an outer block that take the previous block step by step
+    // several independent factorisations in ONE launch (the points of a DIRECT iteration of the MAP fit): problem q uses the
+    // workgroups [q gridDim.x / nprob, (q + 1) gridDim.x / nprob) and A + q strideA, Linv + q strideA, sync + q stride_sync,
+    // info + 2 q
+    int nprob;
+    long strideA;
+    long stride_sync;
 };
-constexpr int PK_FLAGS = 32;
 #define PK_STAMP(slot) do { if (a.trace && threadIdx.x == 0) a.trace[16 * j + (slot)] = wall_clock64(); } while (0)
 
 // one lane: spin (RELAXED polls -- an acquire load at agent scope would invalidate the XCD's L2 on every poll) until
@@ -362,19 +345,6 @@ __device__ __forceinline__ bool pk_spin(int* p, int target, int* abort_flag, lon
 // its update tiles at all (one owner per tile) and takes a real agent-scope acquire before every task.
 __device__ __forceinline__ void pk_inv_l1() { asm volatile("buffer_inv sc1" ::: "memory"); }
 
-// Workgroup-level wait on a flag raised by pk_signal.  The diagonal-block code owns every byte of the 160 KB of LDS, so
-// there is no shared word for a broadcast: lane 0 of EVERY wave spins and hands its verdict to its own wave; the barrier
-// then orders the workgroup.  (A wave that gives up leaves the kernel; the others run into bounded waits of their own.)
-__device__ __forceinline__ bool pk_wait_flag(int* p, const PersistArgs& a) {
-    int ok = 1;
-    if ((threadIdx.x & 63) == 0) {
-        ok = pk_spin(p, 1, a.info + 1, a.timeout) ? 1 : 0;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    ok = __builtin_amdgcn_readfirstlane(ok);
-    __syncthreads();
-    return ok != 0;
-}
 // wait until the counter *p reaches `target` (the chain watching the workers' barrier counter)
 __device__ __forceinline__ bool pk_wait_count(int* p, int target, const PersistArgs& a) {
     int ok = 1;
@@ -386,75 +356,6 @@ __device__ __forceinline__ bool pk_wait_count(int* p, int target, const PersistA
     __syncthreads();
     return ok != 0;
 }
-// publish this workgroup's stores (agent-scope release: the XCD's L2 is written back), then raise the flag
-__device__ __forceinline__ void pk_signal(int* p) {
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(p, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Grid barrier, hierarchical.  The 8 XCDs have private L2s, so an agent-scope release / acquire is an L2 write-back /
-// invalidate of the WHOLE XCD L2: with one release + acquire per WORKGROUP a barrier cost ~100 us (32 workgroups per XCD
-// each walking the same L2).  Here the workgroups of an XCD first meet on an XCD-local counter (their stores are already in
-// the shared L2 after the workgroup-scope barrier); the last one to arrive -- the XCD's leader for this barrier -- performs
-// the single release, joins the global barrier of leaders, performs the single acquire, and lets its XCD go.  The others only
-// drop their CU's L1.
-struct PkBarrier {
-    int xcc, xcd_size, n_xcd, epoch;
-};
-__device__ __forceinline__ bool pk_barrier(const PersistArgs& a, PkBarrier& bs, int* also_flag = nullptr, int* also_flag2 = nullptr) {
-    __syncthreads();
-    bs.epoch += 1;
-    int ok = 1;
-    if ((threadIdx.x & 63) == 0) {
-        int* arrive = a.sync + 16 + bs.xcc;
-        int* go = a.sync + 24 + bs.xcc;
-        if (threadIdx.x == 0) {
-            const int old = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old + 1 == bs.xcd_size * bs.epoch) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                __hip_atomic_fetch_add(a.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = pk_spin(a.sync, bs.n_xcd * bs.epoch, a.info + 1, a.timeout) ? 1 : 0;
-                // a flag of the chain workgroup the next phase depends on: waited for HERE, by the 8 leaders, so that the one
-                // acquire below covers it and no worker needs an acquire (= an L2 invalidate) of its own
-                if (ok && also_flag) ok = pk_spin(also_flag, 1, a.info + 1, a.timeout) ? 1 : 0;
-                if (ok && also_flag2) ok = pk_spin(also_flag2, 1, a.info + 1, a.timeout) ? 1 : 0;
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                __hip_atomic_store(go, bs.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        ok = (ok && pk_spin(go, bs.epoch, a.info + 1, a.timeout)) ? 1 : 0;
-        pk_inv_l1();
-    }
-    ok = __builtin_amdgcn_readfirstlane(ok);
-    __syncthreads();
-    return ok != 0;
-}
-// who shares my XCD?  (flat, once per launch: atomics only)
-__device__ __forceinline__ bool pk_setup(const PersistArgs& a, PkBarrier& bs, bool is_worker) {
-    unsigned x;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
-    bs.xcc = (int)(x & 7);
-    bs.epoch = 0;
-    int ok = 1, size = 0, nx = 0;
-    if ((threadIdx.x & 63) == 0) {
-        if (threadIdx.x == 0 && is_worker) {      // the chain workgroup takes no part in the workers' barriers
-            __hip_atomic_fetch_add(a.sync + 8 + bs.xcc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(a.sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        ok = pk_spin(a.sync + 1, (int)gridDim.x - 1, a.info + 1, a.timeout) ? 1 : 0;
-        for (int q = 0; q < 8; ++q) {
-            const int c = __hip_atomic_load(a.sync + 8 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            nx += c > 0 ? 1 : 0;
-            if (q == bs.xcc) size = c;
-        }
-    }
-    bs.xcd_size = __builtin_amdgcn_readfirstlane(size);
-    bs.n_xcd = __builtin_amdgcn_readfirstlane(nx);
-    ok = __builtin_amdgcn_readfirstlane(ok);
-    __syncthreads();
-    return ok != 0;
-}
-
 // The workers' and the chain's full 128 x 128 x K products: gemm_tile_mc (gemm_f64.hpp).  Round 2 first used a four-stage ring
 // of BK = 16 slabs here (147 KB of LDS) -- whose __syncthreads() drained the ring with the compiler's s_waitcnt vmcnt(0), so
 // it never ran deeper than a double buffer; the shared tile is faster and needs half the LDS.
@@ -463,32 +364,12 @@ __device__ __forceinline__ void gemm_tile_deep(Acc& acc, const double* __restric
     gemm_tile_mc<4, true>(acc, A, lda, B, ldb, 0, K, lds);   // K: multiples of 128
 }
 
-// 128 x 128 tile helpers on top of gemm_tile (operands in global memory / L2)
-__device__ __forceinline__ void pk_store_tile(double* C, long ld, const Acc& acc) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) C[(long)acc_m(i) + (long)acc_n(jj, r) * ld] = acc.v[i][jj][r];
-}
-__device__ __forceinline__ void pk_sub_tile(double* C, long ld, const Acc& acc) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double* c = C + (long)acc_m(i) + (long)acc_n(jj, r) * ld;
-                *c = *c - acc.v[i][jj][r];
-            }
-}
 // Accumulator tile -> global memory through a column-major LDS image [128][DL] (147 KB: workgroups that own a CU's whole LDS):
 // the accumulator layout gives every lane 8-byte accesses 64 KB apart (16 lanes per 128-byte run), and a 128 x 128 read-modify-
 // write issued that way takes 16 us per tile (measured in the dataflow Cholesky: as long as the K = 128 product itself).
 // From the image every wave moves whole 1 KB columns with 16-byte accesses, all loads of a half tile in flight at once.
 // SUB: C -= acc, otherwise C = acc.  WT: write-through (sc1) stores -- the tile is read by other CUs next (the caller drains
-// and raises a flag), otherwise plain stores.  Values are only moved: same bits as pk_sub_tile / pk_store_tile.
+// and raises a flag), otherwise plain stores.  Values are only moved.
 template <bool SUB, bool WT>
 __device__ __forceinline__ void tile_commit(double* __restrict__ C, long ld, const Acc& acc, double* img) {
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -518,22 +399,9 @@ __device__ __forceinline__ void tile_commit(double* __restrict__ C, long ld, con
     }
 }
 
-// the workgroup's own global stores -> its own later loads: stores complete (barrier), this CU's L1 dropped
-__device__ __forceinline__ void pk_self_fence() {
-    __syncthreads();
-    pk_inv_l1();
-    __syncthreads();
-}
-
 // ---------------------------------------------------------------------------------------------------------
-// The chain workgroup's two 128 x 128 x 128 products, restricted to the 16 x 16 blocks that matter:
-//   TRI  (panel tile):   C[m][n]  = sum_{k-block <= n-block} A[m][k] B[n][k]    B = T_jj is lower triangular
-//   !TRI (next diagonal): C[m][n] -= sum_k A[m][k] A[n][k]  for n-block <= m-block (the factorisation reads the lower half)
-// A full product is 512 MFMAs per wave = 13.6 us on ONE CU (128 FLOP/clk); both forms need 288.  Wave w owns the 16-row
-// blocks {w, 7 - w} and all column blocks, which balances either triangle exactly.  Skipped terms are exact zeros /
-// unused outputs and the k order is that of gemm_tile, so the results are bit-identical to the full products.
-// Operand slabs (16 k x 128, both M-contiguous) go global -> LDS with LDS-direct loads, all of them in flight early: the
-// workgroup owns 160 KB of LDS and the whole product is only 8 slabs (TRI: ring of 4 x (A, B); !TRI: all 8 A slabs).
+// The chain workgroup's 128 x 128 tiles: wave w owns the 16-row blocks {w, 7 - w} and all eight 16-column blocks (ChainAcc),
+// which balances a triangle exactly.  Operand slabs (16 k x 128, M-contiguous) go global -> LDS with LDS-direct loads.
 // ---------------------------------------------------------------------------------------------------------
 struct ChainAcc {
     d4_t v[2][8];
@@ -554,228 +422,11 @@ __device__ __forceinline__ void chain_wait_barrier() {
     ring_wait_barrier<N>();
 }
 
-template <bool TRI>
-__device__ __forceinline__ void chain_gemm(ChainAcc& acc, const double* __restrict__ A, long lda, const double* __restrict__ B,
-                                           long ldb, double* lds) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int mi0 = wave, mi1 = 7 - wave;
-    constexpr int SLAB = GEMM_LDS_TILE;                 // doubles per operand slab image [16][144]
-    auto issue = [&](int s) {                            // wave w brings k-rows 4w .. 4w+3 of slab s
-        double* base = TRI ? lds + (s & 3) * 2 * SLAB : lds + s * SLAB;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 4 * wave + r;
-            slab_row_to_lds(A + 2 * lane + (long)(16 * s + row) * lda, base + row * GEMM_LDS_MC_LD);
-            if (TRI) slab_row_to_lds(B + 2 * lane + (long)(16 * s + row) * ldb, base + SLAB + row * GEMM_LDS_MC_LD);
-        }
-    };
-    if (TRI) { issue(0); issue(1); issue(2); }
-    else {
-#pragma unroll
-        for (int s = 0; s < 8; ++s) issue(s);
-    }
-    auto step = [&](auto S) {
-        constexpr int s = decltype(S)::value;
-        // slab s has landed when at most the loads issued after it are outstanding (8 per slab TRI, 4 otherwise)
-        if (TRI) chain_wait_barrier<8 * (s <= 5 ? 2 : 7 - s)>();   // every wave's part of slab s is in LDS; slab s-1 is no longer read
-        else chain_wait_barrier<4 * (7 - s)>();
-        if (TRI && s + 3 < 8) issue(s + 3);              // into the buffer of slab s - 1
-        const double* la = TRI ? lds + (s & 3) * 2 * SLAB : lds + s * SLAB;
-        const double* lb = TRI ? la + SLAB : la;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int krow = (4 * kk + (lane >> 4)) * GEMM_LDS_MC_LD + (lane & 15);
-            const double a0 = la[krow + 16 * mi0], a1 = la[krow + 16 * mi1];
-#pragma unroll
-            for (int nj = 0; nj < 8; ++nj) {
-                if (TRI) {
-                    if (nj >= s) {
-                        const double bf = lb[krow + 16 * nj];
-                        acc.v[0][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf, a0, acc.v[0][nj], 0, 0, 0);
-                        acc.v[1][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf, a1, acc.v[1][nj], 0, 0, 0);
-                    }
-                } else {
-                    if (nj <= mi1) {                     // mi1 >= mi0: the longer row
-                        const double bf = lb[krow + 16 * nj];
-                        if (nj <= mi0) acc.v[0][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf, a0, acc.v[0][nj], 0, 0, 0);
-                        acc.v[1][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf, a1, acc.v[1][nj], 0, 0, 0);
-                    }
-                }
-            }
-        }
-    };
-    step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
-    step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
-    step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
-    step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
-    __syncthreads();                                     // LDS free for the next user
-}
-
-// element (a, nj, r) of a ChainAcc: row 16 mi + (lane & 15), column 16 nj + (lane >> 4) + 4 r
-template <bool TRI>
-__device__ __forceinline__ void chain_store(double* __restrict__ C, long ld, const ChainAcc& acc) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const int mi = a == 0 ? wave : 7 - wave;
-#pragma unroll
-        for (int nj = 0; nj < 8; ++nj) {
-            if (!TRI && nj > mi) continue;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double* c = C + (long)(16 * mi + (lane & 15)) + (long)(16 * nj + (lane >> 4) + 4 * r) * ld;
-                if (TRI) *c = acc.v[a][nj][r];
-                else *c = *c - acc.v[a][nj][r];
-            }
-        }
-    }
-}
-
-// Steps [a.j0, a.j1) of the factorisation.  Whole matrix: j0 = 0, j1 = nb, two-level trailing updates inside the kernel.
-// PANEL mode (a.j1 < nb): the block columns [j0, j1) only -- diagonal blocks, all panel tiles below them, and the updates of
-// the panel's own columns; the update of everything beyond column j1 is left to the caller (launch_potrf_hybrid runs it as
-// a full-rate GEMM launch on a second stream while the next panel is being factored here).
-__global__ __launch_bounds__(256) void potrf_persistent_kernel(PersistArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* lds = reinterpret_cast<double*>(smem);
-    const int G = gridDim.x, b = blockIdx.x, nb = a.nb, W = G - 1, w = b - 1, nbo = a.nbo;
-    const int j0 = a.j0, j1 = a.j1;
-    const bool panel = j1 < nb;
-    const int jlast = panel ? j1 - 1 : nb - 2;           // last step that has rows below it to work on
-    const long ld = a.ld;
-    int* factored = a.sync + PK_FLAGS;            // [j]: L_jj, T_jj stored
-    int* sub = a.sync + PK_FLAGS + nb;            // [j]: L_{j+1,j} stored
-    PkBarrier bs;
-    if (!pk_setup(a, bs, b != 0)) return;
-    const bool phase0 = a.k0 < j0;
-    const double* Lprev = a.A + (long)j0 * NB + (long)a.k0 * NB * ld;   // L[j0.., k0 .. j0): the previous block's columns
-    const int Kprev = (j0 - a.k0) * NB;
-    if (b == 0) {
-        // ---- the chain: diagonal block j, then ITS OWN sub-diagonal tile and next diagonal tile, no grid barrier ----
-        if (phase0) {   // tile (j0, j0) -= L[j0, k0..j0) L[j0, k0..j0)^T
-            Acc acc;
-            acc.zero();
-            gemm_tile_deep(acc, Lprev, ld, Lprev, ld, Kprev, lds);
-            pk_sub_tile(a.A + (long)j0 * NB * (ld + 1), ld, acc);
-            pk_self_fence();
-        }
-        diag_block<true>(a.A + (long)j0 * NB * (ld + 1), ld, a.Linv + (long)j0 * NB * (ld + 1), ld, a.info, j0 * NB, smem);
-        pk_signal(factored + j0);
-        // in panel mode the diagonal block j1 belongs to the next launch: the chain stops one step earlier
-        const int jchain = panel ? j1 - 2 : nb - 2;
-        for (int j = j0; j <= jchain; ++j) {
-            double* Ajj = a.A + (long)j * NB * (ld + 1);
-            double* Tjj = a.Linv + (long)j * NB * (ld + 1);
-            double* Asub = Ajj + NB;                           // tile (j+1, j)
-            double* Anext = Ajj + (long)NB * (ld + 1);         // tile (j+1, j+1)
-            PK_STAMP(0);
-            // tiles (j+1, j) and (j+1, j+1) carry the updates of steps < j once the workers have left step j-1
-            // (for j = j0: at B0, i.e. past phase 0)
-            if (!pk_wait_count(a.sync, bs.n_xcd * (2 * (j - j0) + 1), a)) return;
-            PK_STAMP(1);
-            pk_self_fence();                                   // T_jj, written by this workgroup a moment ago
-            {
-                ChainAcc ca;
-                ca.zero();
-                chain_gemm<true>(ca, Asub, ld, Tjj, ld, lds);                     // L_{j+1,j} = A_{j+1,j} T_jj^T
-                chain_store<true>(Asub, ld, ca);
-            }
-            pk_signal(sub + j);
-            PK_STAMP(2);
-            // tile (j0+1, j0+1) also receives [k0, j0) from the other stream: that update must be in before this one
-            if (j == j0 && a.ext_flag && !pk_wait_flag(a.ext_flag, a)) return;
-            pk_inv_l1();
-            // A_{j+1,j+1} -= L_{j+1,k} L_{j+1,k}^T: k = j inside an outer block, all the block's columns at its last step
-            const int J0 = panel ? j0 : (j / nbo) * nbo;
-            const int J1 = panel ? j1 : min(J0 + nbo, nb);
-            const int kc0 = (j + 1 == J1) ? J0 : j;
-            const double* Lr = a.A + (long)(j + 1) * NB + (long)kc0 * NB * ld;
-            if (kc0 == j) {
-                ChainAcc ca;
-                ca.zero();
-                chain_gemm<false>(ca, Lr, ld, Lr, ld, lds);
-                chain_store<false>(Anext, ld, ca);
-            } else {
-                Acc acc;
-                acc.zero();
-                gemm_tile_deep(acc, Lr, ld, Lr, ld, (j + 1 - kc0) * NB, lds);
-                pk_sub_tile(Anext, ld, acc);
-            }
-            pk_self_fence();
-            PK_STAMP(3);
-            diag_block<true>(Anext, ld, Tjj + (long)NB * (ld + 1), ld, a.info, (j + 1) * NB, smem);
-            pk_signal(factored + j + 1);
-            PK_STAMP(4);
-        }
-        return;
-    }
-    // ---- the workers: everything else.  Barrier epochs: B0 = 1, step j: B1 = 2 (j - j0) + 2, B2 = 2 (j - j0) + 3.  The
-    //      chain's flags are folded into the barriers that precede their first use (B0 / B2: block factored; B1:
-    //      sub-diagonal tile stored) ----
-    if (phase0) {   // block column j0 below the diagonal: A_{i,j0} -= L[i, k0..j0) L[j0, k0..j0)^T
-        double* Acol = a.A + (long)(j0 + 1) * NB + (long)j0 * NB * ld;
-        for (int t = w; t < nb - 1 - j0; t += W) {
-            Acc acc;
-            acc.zero();
-            gemm_tile_deep(acc, Lprev + (long)(t + 1) * NB, ld, Lprev, ld, Kprev, lds);
-            pk_sub_tile(Acol + (long)t * NB, ld, acc);
-        }
-    }
-    if (!pk_barrier(a, bs, factored + j0)) return;
-    for (int j = j0; j <= jlast; ++j) {
-        const int rem = nb - 1 - j;                            // block rows / columns below and right of block j
-        double* Ajj = a.A + (long)j * NB * (ld + 1);
-        double* Tjj = a.Linv + (long)j * NB * (ld + 1);
-        double* Apan = Ajj + NB;                               // block column j below the diagonal block
-        const bool chain_has_next = panel ? (j + 1 < j1) : true;   // the chain owns tiles (j+1, j) and (j+1, j+1)
-        if (b == 1) PK_STAMP(8);
-        // panel tiles L_ij = A_ij T_jj^T, in place (row j + 1 is the chain's while it continues with block j + 1)
-        for (int t = (chain_has_next ? 1 : 0) + w; t < rem; t += W) {
-            double* Aij = Apan + (long)t * NB;
-            Acc acc;
-            acc.zero();
-            gemm_tile_deep(acc, Aij, ld, Tjj, ld, NB, lds);
-            pk_store_tile(Aij, ld, acc);
-        }
-        if (b == 1) PK_STAMP(10);
-        if (!pk_barrier(a, bs, chain_has_next ? sub + j : nullptr, j == j0 ? a.ext_flag : nullptr)) return;
-        if (b == 1) PK_STAMP(11);
-        // Trailing update, lower tiles in column-major order; tile t = 0 = (j+1, j+1) belongs to the chain.  Two-level: inside
-        // an outer block [J0, J1) step j only updates the block's own columns (K = 128); the block's LAST step updates
-        // everything beyond with all its columns at once (K = 128 (J1 - J0)): nbo x fewer read-modify-write sweeps over the
-        // trailing matrix.  nbo = 1: every step is a last step.  Panel mode: one block, and no update beyond it.
-        const int J0 = panel ? j0 : (j / nbo) * nbo, J1 = panel ? j1 : min(J0 + nbo, nb);
-        const bool outer = (j + 1 == J1);
-        if (!(panel && outer)) {
-            const int kc0 = outer ? J0 : j;
-            const int K = (j + 1 - kc0) * NB;
-            const int ncols = outer ? rem : J1 - (j + 1);
-            const int ntile = ncols * rem - ncols * (ncols - 1) / 2;
-            const double* Lrow = a.A + (long)(j + 1) * NB + (long)kc0 * NB * ld;   // L[j+1.., kc0 .. j]
-            double* Atr = Ajj + (long)NB * (ld + 1);
-            for (int t = 1 + w; t < ntile; t += W) {
-                int tk = 0, off = 0;
-                while (t >= off + rem - tk) { off += rem - tk; ++tk; }
-                const int ti = tk + (t - off);
-                Acc acc;
-                acc.zero();
-                gemm_tile_deep(acc, Lrow + (long)ti * NB, ld, Lrow + (long)tk * NB, ld, K, lds);
-                pk_sub_tile(Atr + (long)ti * NB + (long)tk * NB * ld, ld, acc);
-            }
-        }
-        if (b == 1) PK_STAMP(13);
-        if (!pk_barrier(a, bs, chain_has_next ? factored + j + 1 : nullptr)) return;
-        if (b == 1) PK_STAMP(14);
-    }
-}
-
-// ---- panel tiles as triangular solves (dataflow form, SLS_POTRF_DTRSM=1) ------------------------------------
+// ---- panel tiles as triangular solves ----------------------------------------------------------------------
 // X = A L^-T for a 128 x 128 tile A and the lower-triangular diagonal block L = L_jj, by 16-column blocks:
 //     X_s = (A_s - sum_{k<s} X_k L_sk^T) T16_s^T ,   T16_s = (L_ss)^-1 (the eight 16 x 16 inverses diag16 produces anyway).
-// Right-looking over the SAME slab stream as chain_gemm<true> (slab s = columns 16 s .. 16 s + 15 of A and of L, both
-// M-contiguous, LDS-direct loads, ring of four slab pairs): when slab s lands, X_s = (A_s - S_s) T16_s^T closes block s and every
+// Right-looking over a slab stream (slab s = columns 16 s .. 16 s + 15 of A and of L, both M-contiguous, LDS-direct loads, ring
+// of four slab pairs): when slab s lands, X_s = (A_s - S_s) T16_s^T closes block s and every
 // later block receives S_c += X_s L_cs^T.  288 MFMAs per wave -- the count of the product with the full inverse T_jj restricted
 // to its non-zero blocks -- but the 128 x 128 inverse itself is no longer needed by any panel tile: the chain stops building it
 // (no S / T phases in the diagonal block, no transposes, no 128 KB store per step); launch_diag_inverse forms all T_jj after
@@ -875,128 +526,6 @@ __device__ __forceinline__ void diag_block_factor(double* __restrict__ A, long l
         const d2_t v = *reinterpret_cast<const d2_t*>(Ts + 256 * t + r2 + 16 * c);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rsrcT, (int)(((16 * t + r2) + (long)(16 * t + c) * ldt) * 8), 0, 16);
     }
-}
-
-// ---- two-workgroup chain (SLS_POTRF_DCHAIN2=1) ---------------------------------------------------------------
-// With one chain workgroup a step is  solve (14 us) -> L L^T + next diagonal tile (14 us) -> diagonal block (22 us), strictly in
-// sequence on one CU.  The solve X = A L_jj^-T consumes L_jj column block by column block (chain_trsm), and column block s of
-// L_jj is final as soon as step s of the diagonal block's factorisation has formed its panel tiles: a SECOND workgroup can run
-// the solve WHILE the first one is still factoring, one 16-column step behind.  The two chain workgroups alternate roles:
-//     D_j  factors diagonal block j in its LDS and streams every finished column block (16 KB of L + the 2 KB inverse of its
-//          diagonal tile, write-through) behind a flag slab_ready[8 j + s];
-//     H_j  (the other workgroup) follows those flags with the streamed solve for tile (j+1, j), stores L_{j+1,j}, forms
-//          A_{j+1,j+1} - L L^T in its LDS -- and is thereby D_{j+1}, while the first workgroup becomes H_{j+1}.
-// Per step the chain now costs  diagonal block + (last solve step + L L^T + tile commit)  instead of the sum of all three.
-// diag_block_stream: factor the image (optionally loaded from global memory first), publishing as it goes.
-__device__ __forceinline__ void diag_block_stream(double* __restrict__ A, long lda, double* __restrict__ Tout, long ldt,
-                                                  int* __restrict__ info, int global_off, char* smem, bool load,
-                                                  int* __restrict__ slab_flags, int* __restrict__ factored_flag) {
-    double* As = reinterpret_cast<double*>(smem);
-    double* Ts = As + 128 * DL;
-    const int tid = threadIdx.x;
-    int* pub_word = reinterpret_cast<int*>(As + 125 * DL + 128);     // arrivals of waves 1-3 per published block (padding row)
-    if (load) {
-        const int i2 = 2 * (tid & 63), jc = tid >> 6;
-#pragma unroll 8
-        for (int p = 0; p < 32; ++p) {
-            const int j = 4 * p + jc;
-            d2_t v = *reinterpret_cast<const d2_t*>(A + (long)i2 + (long)j * lda);
-            if ((i2 >> 4) < (j >> 4)) v = d2_t{0.0, 0.0};
-            *reinterpret_cast<d2_t*>(As + i2 + j * DL) = v;
-        }
-    }
-    if (tid == 0) *pub_word = 0;
-    __syncthreads();
-    auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(A, 0, 0x7fffffff, 0x00020000);
-    auto rsrcT = __builtin_amdgcn_make_buffer_rsrc(Tout, 0, 0x7fffffff, 0x00020000);
-    chol_factor_steps(As, Ts, info, global_off, [&](int s) {
-        // waves 1-3: columns 16 s .. 16 s + 15 of L (all 128 rows: zeros above the diagonal are part of the operand slab) and
-        // the inverse of the diagonal tile, write-through; every wave drains its own stores, the last one to arrive raises the flag
-        const int t = tid - 64;
-        for (int idx = t; idx < 1024; idx += 192) {
-            const int col = 16 * s + (idx >> 6), r2 = 2 * (idx & 63);
-            const d2_t v = *reinterpret_cast<const d2_t*>(As + r2 + col * DL);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rsrcA, (int)((r2 + (long)col * lda) * 8), 0, 16);
-        }
-        if (t < 128) {
-            const int c = t >> 3, r2 = 2 * (t & 7);
-            const d2_t v = *reinterpret_cast<const d2_t*>(Ts + 256 * s + r2 + 16 * c);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rsrcT, (int)(((16 * s + r2) + (long)(16 * s + c) * ldt) * 8), 0, 16);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if ((tid & 63) == 0) {
-            const int old = __hip_atomic_fetch_add(pub_word, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (old == 3 * (s + 1) - 1) {
-                __hip_atomic_store(slab_flags + s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (s == 7) __hip_atomic_store(factored_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    });
-    __syncthreads();
-}
-
-// workgroup-level wait for a flag whose payload this CU has never read before (no L1 line to drop): compiler-level ordering only
-__device__ __forceinline__ bool pk_wait_flag_first_touch(int* p, const PersistArgs& a) {
-    int ok = 1;
-    if ((threadIdx.x & 63) == 0) ok = pk_spin(p, 1, a.info + 1, a.timeout) ? 1 : 0;
-    ok = __builtin_amdgcn_readfirstlane(ok);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    __syncthreads();
-    return ok != 0;
-}
-
-// chain_trsm following the diagonal block's column blocks as they are published (slab_flags[s]); T: the global T_jj block whose
-// diagonal 16 x 16 tiles hold the small inverses.  The A slabs (no dependence on the factorisation) run three ahead in the ring.
-__device__ __forceinline__ bool chain_trsm_stream(ChainAcc& V, const double* __restrict__ A, long lda, const double* __restrict__ L, long ldl,
-                                                  const double* __restrict__ T, long ldt, int* __restrict__ slab_flags, double* lds,
-                                                  const PersistArgs& a) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int fl = lane & 15, fk = lane >> 4;
-    const int mi[2] = {wave, 7 - wave};
-    constexpr int SLAB = GEMM_LDS_TILE;
-    auto issue = [&](const double* P, long ldp, int s, int half) {   // wave w brings k-rows 4w .. 4w+3 of slab s
-        double* base = lds + (s & 3) * 2 * SLAB + half * SLAB;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 4 * wave + r;
-            slab_row_to_lds(P + 2 * lane + (long)(16 * s + row) * ldp, base + row * GEMM_LDS_MC_LD);
-        }
-    };
-    V.zero();
-    issue(A, lda, 0, 0); issue(A, lda, 1, 0); issue(A, lda, 2, 0);
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        if (!pk_wait_flag_first_touch(slab_flags + s, a)) return false;   // its barrier: every wave has finished step s - 1
-        issue(L, ldl, s, 1);
-        double tf[4];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) tf[kk] = T[(16 * s + fl) + (long)(16 * s + 4 * kk + fk) * ldt];   // T16_s[n = fl][k]
-        ring_wait_barrier<0>();                          // slab s of L (and of A, issued earlier) is in LDS for every wave
-        if (s + 3 < 8) issue(A, lda, s + 3, 0);          // into the buffer of slab s - 1
-        const double* la = lds + (s & 3) * 2 * SLAB;
-        const double* lb = la + SLAB;
-#pragma unroll
-        for (int q2 = 0; q2 < 2; ++q2) {
-            d4_t r;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) r[q] = la[(fk + 4 * q) * GEMM_LDS_MC_LD + 16 * mi[q2] + fl] - V.v[q2][s][q];
-            d4_t x = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) x = __builtin_amdgcn_mfma_f64_16x16x4f64(tf[kk], r[kk], x, 0, 0, 0);
-            V.v[q2][s] = x;
-#pragma unroll
-            for (int c = s + 1; c < 8; ++c) {
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const double bf = lb[(fk + 4 * kk) * GEMM_LDS_MC_LD + 16 * c + fl];
-                    V.v[q2][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf, x[kk], V.v[q2][c], 0, 0, 0);
-                }
-            }
-        }
-    }
-    __syncthreads();                                     // LDS free for the next user
-    return true;
 }
 
 // ---- the dataflow chain's products with their results kept in LDS ----------------------------------------
@@ -1153,68 +682,26 @@ __device__ __forceinline__ void df_publish_add(int* p) {
 __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
-    const int G = gridDim.x, b = blockIdx.x, nb = a.nb, nbo = a.nbo;
+    // several independent problems share the launch: this workgroup's problem, its rank inside it, the problem's buffers
+    const int G = gridDim.x / a.nprob, q = blockIdx.x / G, b = blockIdx.x - q * G, nb = a.nb, nbo = a.nbo;
+    a.A += q * a.strideA;
+    a.Linv += q * a.strideA;
+    a.sync += q * a.stride_sync;
+    a.info += 2 * q;
+    if (a.trace) a.trace += q * (16L * nb + 16L * G);
     const long ld = a.ld;
     int* factored = a.sync + DF_FACT;
     int* chain_ready = a.sync + DF_FACT + nb;
     int* panel_done = a.sync + DF_FACT + 2 * nb;        // [i + j nb]
-    const int nchain = a.chain2 ? 2 : 1;
-    if (a.chain2 && b < 2) {
-        // ---- the chain, two workgroups alternating between factoring (D_j) and following with the solve (H_j) ----
-        int* slab_ready = panel_done + (long)nb * nb;   // [8 j + s]
-        auto Hstep = [&](int k) -> bool {
-            double* Akk = a.A + (long)k * NB * (ld + 1);
-            double* Tkk = a.Linv + (long)k * NB * (ld + 1);
-            double* Asub = Akk + NB;                           // tile (k+1, k)
-            double* Anext = Akk + (long)NB * (ld + 1);         // tile (k+1, k+1)
-            const int j = k;                                   // (PK_STAMP indexes the trace by j)
-            PK_STAMP(0);
-            if (!pk_wait_count(chain_ready + k, 2, a)) return false;   // both tiles carry their owners' updates (steps < k)
-            PK_STAMP(1);
-            {
-                ChainAcc ca;
-                if (!chain_trsm_stream(ca, Asub, ld, Akk, ld, Tkk, ld, slab_ready + 8 * k, lds, a)) return false;
-                chain_acc_to_image<true>(ca, lds);
-            }
-            lds_barrier();
-            chain_image_store_wt(Asub, ld, lds);
-            df_publish_store(panel_done + (k + 1) + (long)k * nb);
-            PK_STAMP(2);
-            chain_syrk_inplace(lds);
-            lds_barrier();
-            chain_image_rsub(Anext, ld, lds);
-            PK_STAMP(3);
-            return true;
-        };
-        auto Dstep = [&](int j, bool load) {
-            diag_block_stream(a.A + (long)j * NB * (ld + 1), ld, a.Linv + (long)j * NB * (ld + 1), ld, a.info, j * NB, smem, load,
-                              slab_ready + 8 * j, factored + j);
-        };
-        if (b == 0) Dstep(0, true);
-        for (int k = (b == 0 ? 1 : 0); k <= nb - 2; k += 2) {
-            if (!Hstep(k)) return;
-            Dstep(k + 1, false);
-            const int j = k;
-            PK_STAMP(4);
-        }
-        return;
-    }
+    constexpr int nchain = 1;
     if (b == 0) {
         // ---- the chain ----
         // Everything between two diagonal blocks stays in LDS: the panel tile L_{j+1,j} = A_{j+1,j} T_jj^T goes accumulators ->
         // LDS image -> global (write-through, coalesced) and is the LDS-resident operand of the next product; A_{j+1,j+1} -
         // L L^T is formed in place in the image, which is diag_block's input.  (The barrier form stores and re-loads both
         // tiles through global memory with 8-byte accesses 64 KB apart: 34 us per step for 15 us of MFMA work.)
-        if (a.trsm) {
-            diag_block_factor<true>(a.A, ld, a.Linv, ld, a.info, 0, smem);
-            df_publish_store(factored + 0);
-        } else if (a.fuse == 0) {
-            diag_block<true>(a.A, ld, a.Linv, ld, a.info, 0, smem);
-            pk_signal(factored + 0);
-        } else {
-            diag_block<true, true, true>(a.A, ld, a.Linv, ld, a.info, 0, smem);
-            df_publish_store(factored + 0);
-        }
+        diag_block_factor<true>(a.A, ld, a.Linv, ld, a.info, 0, smem);
+        df_publish_store(factored + 0);
         for (int j = 0; j <= nb - 2; ++j) {
             double* Ajj = a.A + (long)j * NB * (ld + 1);
             double* Tjj = a.Linv + (long)j * NB * (ld + 1);
@@ -1223,39 +710,10 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             PK_STAMP(0);
             if (!pk_wait_count(chain_ready + j, 2, a)) return; // both tiles carry their owners' updates (steps < j)
             PK_STAMP(1);
-            if (a.fuse == 0) {
-                pk_self_fence();                                   // T_jj, written by this workgroup a moment ago
-                {
-                    ChainAcc ca;
-                    ca.zero();
-                    chain_gemm<true>(ca, Asub, ld, Tjj, ld, lds);                     // L_{j+1,j} = A_{j+1,j} T_jj^T
-                    chain_store<true>(Asub, ld, ca);
-                }
-                pk_signal(panel_done + (j + 1) + (long)j * nb);
-                PK_STAMP(2);
-                pk_inv_l1();
-                {
-                    ChainAcc ca;
-                    ca.zero();
-                    chain_gemm<false>(ca, Asub, ld, Asub, ld, lds);                   // A_{j+1,j+1} -= L_{j+1,j} L_{j+1,j}^T
-                    chain_store<false>(Anext, ld, ca);
-                }
-                pk_self_fence();
-                PK_STAMP(3);
-                diag_block<true>(Anext, ld, Tjj + (long)NB * (ld + 1), ld, a.info, (j + 1) * NB, smem);
-                pk_signal(factored + j + 1);
-                PK_STAMP(4);
-                continue;
-            }
             {
                 ChainAcc ca;
-                if (a.trsm) {
-                    const double* Ts = lds + 128 * DL;                                // the 16 x 16 inverses of block j, still in LDS
-                    chain_trsm(ca, Asub, ld, Ajj, ld, [&](int s, int n, int k) { return Ts[256 * s + n + 16 * k]; }, lds);
-                } else {
-                    ca.zero();
-                    chain_gemm<true>(ca, Asub, ld, Tjj, ld, lds);                     // L_{j+1,j} = A_{j+1,j} T_jj^T (ends with a barrier)
-                }
+                const double* Ts = lds + 128 * DL;                                    // the 16 x 16 inverses of block j, still in LDS
+                chain_trsm(ca, Asub, ld, Ajj, ld, [&](int s, int n, int k) { return Ts[256 * s + n + 16 * k]; }, lds);
                 PK_STAMP(5);                                                          // (5 .. 9: fine stamps, POTRF_BENCH_FINE=1 in the probe)
                 chain_acc_to_image<true>(ca, lds);
             }
@@ -1272,11 +730,7 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             chain_image_rsub(Anext, ld, lds);                                         // image = A_{j+1,j+1} - L L^T, zero above
             __syncthreads();
             PK_STAMP(3);
-            if (a.trsm) {
-                diag_block_factor<false>(Anext, ld, Tjj + (long)NB * (ld + 1), ld, a.info, (j + 1) * NB, smem);
-            } else {
-                diag_block<true, false, true>(Anext, ld, Tjj + (long)NB * (ld + 1), ld, a.info, (j + 1) * NB, smem);
-            }
+            diag_block_factor<false>(Anext, ld, Tjj + (long)NB * (ld + 1), ld, a.info, (j + 1) * NB, smem);
             df_publish_store(factored + j + 1);
             PK_STAMP(4);
         }
@@ -1292,15 +746,19 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
         unsigned x;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
         const int xcc = (int)(x & 7);
+        // the tile -> owner map must be a bijection: every worker's count increment is ordered before its arrival (release) and
+        // the counts are read behind the rendezvous (acquire)
         const int rank = __hip_atomic_fetch_add(a.sync + 8 + xcc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(a.sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(a.sync + 1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         int ok = pk_spin(a.sync + 1, G - nchain, a.info + 1, a.timeout) ? 1 : 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         int widx = rank;
         for (int q = 0; q < xcc; ++q) widx += __hip_atomic_load(a.sync + 8 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int W = G - nchain, PR = a.pr, PC = W / PR;
+        const int W = G - nchain;
         int nt = 0;
-        if (ok && a.map == 1) {
-            // tiles in column-major order (without (0, 0)) dealt round-robin: even in total work and at every stage
+        if (ok) {
+            // tiles in column-major order (without (0, 0)) dealt round-robin: even in total work and at every stage (a cyclic
+            // PR x PC owner grid left 1.4x the mean work on some owners: 5.7 vs 5.0 ms at N = 8192, round 3)
             int k = 0;
             long off = 0;                                    // tiles before column k
             for (long t = widx; nt < DF_MAXT; t += W) {
@@ -1310,14 +768,6 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
                 SW(0, nt) = k + (int)(tt - off); SW(1, nt) = k; SW(2, nt) = 0; SW(3, nt) = 0;
                 ++nt;
             }
-        } else if (ok && widx < PR * PC) {
-            const int r = widx % PR, c = widx / PR;
-            for (int k = c; k < nb; k += PC)
-                for (int i = k + ((r - k % PR) + PR) % PR; i < nb; i += PR) {
-                    if (i == 0 || nt >= DF_MAXT) continue;   // tile (0, 0) is the chain's from the start
-                    SW(0, nt) = i; SW(1, nt) = k; SW(2, nt) = 0; SW(3, nt) = 0;
-                    ++nt;
-                }
         }
         SW(5, 0) = ok ? nt : -1;
     }
@@ -1367,17 +817,11 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
                 if (tid == 0) __hip_atomic_store(a.info + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return;
             }
-            if (a.idle_sleep <= 16) __builtin_amdgcn_s_sleep(16);
-            else if (a.idle_sleep <= 32) __builtin_amdgcn_s_sleep(32);
-            else __builtin_amdgcn_s_sleep(64);
+            __builtin_amdgcn_s_sleep(16);
             if (a.trace) st_idle += wall_clock64() - st_round0;
             continue;
         }
-        if (a.acq) {
-            if (tid < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        } else {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        }
+        if (tid < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // correct by the memory model, not only by first-touch reasoning
         __syncthreads();
         const long long st_task0 = a.trace ? wall_clock64() : 0;
         const int t = first + sel;
@@ -1409,12 +853,12 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             ++st_n_upd;
         } else if (i > k + 1) {
             ++st_n_panel;
-            if (a.trsm) {
+            {
                 const double* Lkk = a.A + (long)k * NB * (ld + 1);
                 const double* Tkk = a.Linv + (long)k * NB * (ld + 1);              // its diagonal 16 x 16 tiles hold the small inverses
                 double* Ts = lds + 128 * DL;                                       // the eight small inverses -> LDS (16 KB)
-                for (int q = tid; q < 1024; q += 256) {
-                    const int t16i = q >> 7, c = (q >> 3) & 15, r2 = 2 * (q & 7);
+                for (int q2 = tid; q2 < 1024; q2 += 256) {
+                    const int t16i = q2 >> 7, c = (q2 >> 3) & 15, r2 = 2 * (q2 & 7);
                     *reinterpret_cast<d2_t*>(Ts + 256 * t16i + r2 + 16 * c) = *reinterpret_cast<const d2_t*>(Tkk + (16 * t16i + r2) + (long)(16 * t16i + c) * ld);
                 }
                 __syncthreads();
@@ -1423,11 +867,6 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
                 chain_acc_to_image<true>(ca, lds);
                 lds_barrier();
                 chain_image_store_wt(Cik, ld, lds);
-            } else {
-                Acc acc;
-                acc.zero();
-                gemm_tile_deep(acc, Cik, ld, a.Linv + (long)k * NB * (ld + 1), ld, NB, lds);
-                tile_commit<false, true>(Cik, ld, acc, lds);
             }
             df_publish_store(panel_done + i + (long)k * nb);
             if (tid == 0) SW(3, t) = 1;
@@ -1448,11 +887,12 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
     }
 }
 
-// The single-launch factorisations need ALL their workgroups resident at once (one per CU, the CU's whole LDS).  Two of them
-// in flight on one device -- two contexts on the same GPU (sls_multi with a repeated device, one context per host thread) --
-// would each get part of the chip, spin for the rest until the bounded waits expire and fall back to the multi-launch
-// schedule.  They are therefore serialised per device: a launch first waits (on the host) for the previous one's completion
-// event.  Processes sharing a GPU are not covered; there the fallback + re-arm path takes over.
+// The single-launch factorisation needs ALL its workgroups resident at once (one per CU, the CU's whole LDS).  Two of them in
+// flight on one device -- two contexts on the same GPU (sls_multi with a repeated device, one context per host thread) -- would
+// each get part of the chip, spin for the rest until the bounded waits expire and fall back to the multi-launch schedule.  They
+// are therefore ordered per device ON THE DEVICE: a launch on another stream than the previous one first makes its stream wait
+// for that launch's completion event (no host synchronisation; the mutex only covers wait + launch + record).  Processes
+// sharing a GPU are not covered; there the fallback + re-arm path takes over.
 static int envi(const char* n, int dflt) {
     const char* v = getenv(n);
     return v ? atoi(v) : dflt;
@@ -1461,70 +901,54 @@ namespace {
 struct PersistSerial {
     std::mutex m;
     hipEvent_t done = nullptr;
+    hipStream_t last = nullptr;
+    bool recorded = false;
+    int n_cu = 0, resident_per_cu = -1;
 };
-PersistSerial g_persist_serial[64];
+PersistSerial& persist_serial_of_current_device() {
+    static std::mutex mtx;
+    static std::map<int, std::unique_ptr<PersistSerial>> table;   // one entry per device ordinal, never aliased
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mtx);
+    auto& e = table[dev];
+    if (!e) {
+        e.reset(new PersistSerial());
+        int v = 0;
+        (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+        e->n_cu = v > 0 ? v : 64;
+    }
+    return *e;
+}
 struct PersistSerialScope {
-    PersistSerial* p;
+    PersistSerial& p;
     hipStream_t s;
-    PersistSerialScope(hipStream_t s_) : s(s_) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        p = &g_persist_serial[dev & 63];
-        p->m.lock();
-        if (p->done) (void)hipEventSynchronize(p->done);
-        else (void)hipEventCreateWithFlags(&p->done, hipEventDisableTiming);
+    PersistSerialScope(PersistSerial& p_, hipStream_t s_) : p(p_), s(s_) {
+        p.m.lock();
+        if (p.recorded && p.last != s) (void)hipStreamWaitEvent(s, p.done, 0);   // same stream: already in order
     }
     ~PersistSerialScope() {
-        (void)hipEventRecord(p->done, s);
-        p->m.unlock();
+        if (!p.done && hipEventCreateWithFlags(&p.done, hipEventDisableTiming) != hipSuccess) p.done = nullptr;
+        if (p.done && hipEventRecord(p.done, s) == hipSuccess) {
+            p.recorded = true;
+            p.last = s;
+        } else {
+            // no event: the next launch cannot be ordered behind this one on the device -- wait for it here instead
+            (void)hipStreamSynchronize(s);
+            p.recorded = false;
+        }
+        p.m.unlock();
     }
 };
 }  // namespace
 
-int potrf_persistent_nbo(int Np) {
-    const char* e = getenv("SLS_POTRF_PNBO");
-    if (e && atoi(e) >= 1) return atoi(e);
-    return Np >= 8192 ? 8 : 1;
-}
-
-// 0: multi-launch schedule, 1: single persistent launch with grid barriers, 2: hybrid (persistent panels + side-stream
-// updates), 3: single persistent launch, dataflow form (default).
-// Measured on MI355X (tools/probes/potrf_bench, ms at N = 2048 / 4096 / 8192 / 16384): multi-launch 1.40 / 3.16 / 10.4 (8.8
-// two-level + look-ahead) / 56.4; persistent 1.11 / 2.72 / 8.56 / 39.3; hybrid (nbo 4) 1.67 / 3.62 / 9.18 / 41.7 -- the
-// hybrid's side-stream launches serialise behind each other more than they overlap with the panels, so it stays opt-in.
+// 0: multi-launch schedule, 3: single persistent launch, dataflow form (default; the numbering is historical: 1 was the form
+// with grid barriers, 2 a hybrid of persistent panel kernels and side-stream updates -- both removed in round 4).
 // Read per call: tests and A/B runs switch within one process.
 int potrf_default_mode(int Np) {
     (void)Np;
     const char* e = getenv("SLS_POTRF_MODE");
-    return e ? atoi(e) : SLS_POTRF_MODE_DEFAULT;
-}
-int potrf_hybrid_nbo() {
-    const char* e = getenv("SLS_POTRF_HNBO");
-    return (e && atoi(e) >= 1) ? atoi(e) : 4;
-}
-
-// sync: >= 32 + 2 (Np / 128) ints of device scratch
-void launch_potrf_persistent(hipStream_t s, double* A, int Np, double* Linv, int* info, int* sync, long long* trace) {
-    ensure_dyn_lds((const void*)potrf_persistent_kernel, DIAG_LDS_BYTES);
-    const int nb = Np / NB;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0, v = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
-        n_cu = v > 0 ? v : 64;
-    }
-    const int work = std::max(nb - 1, (nb - 1) * nb / 2);
-    const int G = std::max(2, std::min(n_cu, 1 + work));
-    (void)hipMemsetAsync(sync, 0, (size_t)(PK_FLAGS + 2 * nb) * sizeof(int), s);
-    PersistArgs a;
-    a.A = A; a.ld = Np; a.nb = nb; a.Linv = Linv; a.info = info; a.sync = sync;
-    a.timeout = envi("SLS_POTRF_TIMEOUT_TICKS", 20000000);   // 0.2 s of the 100 MHz wall clock (test hook: 1 makes every wait expire)
-    a.trace = trace;
-    a.nbo = potrf_persistent_nbo(Np);
-    a.j0 = 0; a.j1 = nb; a.k0 = 0; a.ext_flag = nullptr; a.pr = 1; a.map = 0; a.near = 0; a.acq = 1; a.idle_sleep = 16; a.fuse = 0; a.trsm = 0; a.chain2 = 0;
-    PersistSerialScope serial(s);
-    hipLaunchKernelGGL(potrf_persistent_kernel, dim3(G), dim3(256), DIAG_LDS_BYTES, s, a);
+    return (e && atoi(e) == 0) ? 0 : SLS_POTRF_MODE_DEFAULT;
 }
 
 int potrf_dataflow_nbo(int Np) {
@@ -1535,55 +959,66 @@ int potrf_dataflow_nbo(int Np) {
     // TFLOP/s = 0.79 of peak); N = 4096: 1: 1.69, 2: 1.83
     return Np >= 16384 ? 8 : Np >= 8192 ? 2 : 1;
 }
-// ints of device scratch the dataflow form needs (0: the matrix is too large for its tables)
+// ints of device scratch the dataflow form needs per problem
 size_t potrf_dataflow_sync_ints(int Np) {
     const size_t nb = Np / NB;
-    return DF_FACT + 2 * nb + nb * nb + 8 * nb;      // factored, chain_ready, panel_done[nb][nb], slab_ready[nb][8]
+    return DF_FACT + 2 * nb + nb * nb;               // factored, chain_ready, panel_done[nb][nb]
 }
-// false: not applicable (too few blocks / too many tiles per worker) -- the caller uses another schedule
-bool launch_potrf_dataflow(hipStream_t s, double* A, int Np, double* Linv, int* info, int* sync, long long* trace) {
+// How many independent Np x Np factorisations share one launch well: a problem keeps the chip busy with about nb^2 / 14.5 workers
+// (its ~nb^3 / 6 tile tasks of ~20 us against a chain of nb steps of ~48 us); the rest of the CUs can factor other problems.
+// Measured (tools/probes/potrf_bench, POTRF_BENCH_BATCH=1; ms per problem): N = 1024: 0.394 alone, 0.051 with 8 per launch;
+// N = 2048: 0.781 / 0.110 (8); N = 4096: 1.60 alone, 0.63 (3), 0.59 (4), 0.54 (8) -- a little oversubscription still pays, hence
+// the divisor 24.
+int potrf_dataflow_max_problems(int Np) {
+    PersistSerial& ps = persist_serial_of_current_device();
+    const int nb = Np / NB;
+    const int per_problem = 1 + std::max(1, (int)(nb * (double)nb / 24.0));
+    return std::max(1, std::min(8, ps.n_cu / per_problem));
+}
+// nprob problems (A + q strideA, Linv + q strideA, sync + q stride_sync ints, info + 2 q) in one launch.
+// false: not applicable (too few blocks / too many tiles per worker / the kernel cannot be resident once per CU) -- the caller
+// uses another schedule
+bool launch_potrf_dataflow_batch(hipStream_t s, double* A, int Np, double* Linv, int* info, int* sync, int nprob, long strideA,
+                                 long stride_sync, bool block_inverses, long long* trace) {
     ensure_dyn_lds((const void*)potrf_dataflow_kernel, DIAG_LDS_BYTES);
     const int nb = Np / NB;
-    int dev = 0, n_cu = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    if (n_cu <= 0) n_cu = 64;
+    PersistSerial& ps = persist_serial_of_current_device();
+    if (ps.resident_per_cu < 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, potrf_dataflow_kernel, 256, DIAG_LDS_BYTES) != hipSuccess) n = 0;
+        ps.resident_per_cu = n;
+    }
+    if (ps.resident_per_cu < 1 || nprob < 1 || nprob > 8) return false;
+    const int n_cu = ps.n_cu;
     const int tiles = nb * (nb + 1) / 2 - 1;
-    const int fuse = envi("SLS_POTRF_DFUSE", 1), trsm = envi("SLS_POTRF_DTRSM", 1) && fuse;
-    // two chain workgroups: opt-in.  Measured (profiles/r03_potrf_dataflow_chain2.log): 0.78 vs 0.82 ms at N = 2048, 4.33 vs 4.24 at
-    // 8192 -- the follower gets its tiles 39-45 us after the diagonal block before (two worker tasks in sequence: the panel tile
-    // L_{j+2,j}, then the update of (j+2, j+1) with it), so the step is bound by that path (~48 us) instead of the chain's own 51
-    const int chain2 = envi("SLS_POTRF_DCHAIN2", 0) && trsm && n_cu >= 4;
-    const int nchain = chain2 ? 2 : 1;
-    const int G = std::max(nchain + 1, std::min(n_cu, nchain + tiles));
-    const int W = G - nchain;
-    const char* e = getenv("SLS_POTRF_DPR");
-    int PR = e ? atoi(e) : (W >= 144 ? 12 : W >= 36 ? 6 : W >= 4 ? 2 : 1);
-    PR = std::max(1, std::min(PR, W));
-    const int PC = W / PR;
-    const int map = envi("SLS_POTRF_DMAP", 1);   // round-robin: 5.0 vs 5.7 ms at N = 8192 (the cyclic grid leaves 1.4x work on some owners)
-    if (map == 1 ? (tiles + W - 1) / W > DF_MAXT : ((nb + PR - 1) / PR) * ((nb + PC - 1) / PC) > DF_MAXT) return false;
-    (void)hipMemsetAsync(sync, 0, potrf_dataflow_sync_ints(Np) * sizeof(int), s);
+    // (a second chain workgroup that followed the factorisation with a streamed solve was measured again in round 4 -- 0.384 / 0.767 /
+    // 1.661 / 4.37 ms against 0.395 / 0.781 / 1.599 / 4.09 ms at N = 1024 / 2048 / 4096 / 8192, profiles/r04_potrf_chain2.log -- and
+    // removed: the step is bound by the owners' panel + update path, not by the chain alone)
+    constexpr int nchain = 1;
+    const int Gp = std::max(nchain + 1, std::min(n_cu / nprob, nchain + tiles));   // workgroups per problem
+    const int W = Gp - nchain;
+    if (Gp * nprob > n_cu * ps.resident_per_cu || (tiles + W - 1) / W > DF_MAXT) return false;
+    const size_t sync_ints = potrf_dataflow_sync_ints(Np);
+    if (nprob > 1 && (size_t)stride_sync < sync_ints) return false;
+    for (int q = 0; q < nprob; ++q) (void)hipMemsetAsync(sync + q * stride_sync, 0, sync_ints * sizeof(int), s);
     PersistArgs a;
     a.A = A; a.ld = Np; a.nb = nb; a.Linv = Linv; a.info = info; a.sync = sync;
     a.timeout = envi("SLS_POTRF_TIMEOUT_TICKS", 20000000);   // 0.2 s of the 100 MHz wall clock (test hook: 1 makes every wait expire)
     a.trace = trace;
     a.nbo = potrf_dataflow_nbo(Np);
-    a.j0 = 0; a.j1 = nb; a.k0 = 0; a.ext_flag = nullptr;
-    a.pr = PR;
-    a.map = map;
     a.near = envi("SLS_POTRF_DNEAR", Np >= 16384 ? 3 : 0);
-    a.acq = envi("SLS_POTRF_DACQ", 1);
-    a.idle_sleep = envi("SLS_POTRF_DSLEEP", 16);
-    a.fuse = fuse;
-    a.trsm = trsm;
-    a.chain2 = chain2;
+    a.nprob = nprob; a.strideA = strideA; a.stride_sync = stride_sync;
     {
-        PersistSerialScope serial(s);
-        hipLaunchKernelGGL(potrf_dataflow_kernel, dim3(G), dim3(256), DIAG_LDS_BYTES, s, a);
+        PersistSerialScope serial(ps, s);
+        hipLaunchKernelGGL(potrf_dataflow_kernel, dim3(Gp * nprob), dim3(256), DIAG_LDS_BYTES, s, a);
     }
-    if (a.trsm) launch_diag_inverse(s, A, Np, Linv);     // T_jj for every diagonal block, off the factorisation's serial chain
+    // T_jj for every diagonal block, off the factorisation's serial chain (callers that only need the factor skip it)
+    if (block_inverses)
+        for (int q = 0; q < nprob; ++q) launch_diag_inverse(s, A + q * strideA, Np, Linv + q * strideA);
     return true;
+}
+bool launch_potrf_dataflow(hipStream_t s, double* A, int Np, double* Linv, int* info, int* sync, long long* trace) {
+    return launch_potrf_dataflow_batch(s, A, Np, Linv, info, sync, 1, 0, 0, true, trace);
 }
 
 // Two-level right-looking factorisation.  Outer blocks of `nbo` 128-columns: inside an outer block every 128-step is
@@ -1625,88 +1060,12 @@ int potrf_default_nbo(int Np) {
     return Np >= 8192 ? 4 : 1;   // measured (tools/probes/potrf_bench): two-level pays from N = 8192 (10.4 -> 9.5 ms), not below
 }
 
-// A[row0.., col0 .. col0+ncols) -= L[row0.., kcol0 .. kcol0+ktiles) L[col0.., same]^T on the lower tiles (row >= col)
-static void syrk_update(hipStream_t st, double* A, long ld, int nb, int kcol0, int ktiles, int row0, int col0, int ncols) {
-    const int mt = nb - row0;
-    if (mt <= 0 || ncols <= 0) return;
-    const double* Ap = A + (long)row0 * NB + (long)kcol0 * NB * ld;
-    const double* Bp = A + (long)col0 * NB + (long)kcol0 * NB * ld;
-    double* Cp = A + (long)row0 * NB + (long)col0 * NB * ld;
-    GemmDesc u = mkdesc(Ap, ld, Bp, ld, Cp, ld, mt, ncols, ktiles * NB, -1.0, 1.0);
-    u.tri = 1;
-    u.tri_off = col0 - row0;
-    launch_tri_gemm<false, false>(st, u, 1);
-}
-
-__global__ void raise_flag_kernel(int* flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
-
-// Hybrid schedule (default from N = 8192): the block columns are factored nbo at a time by the persistent kernel in PANEL
-// mode on the main stream -- a small grid (64 workgroups) that lives on the CUs the side stream's mask leaves free -- while
-// the previous block's contribution to everything beyond the current block runs as ordinary full-rate tile-GEMM launches on
-// the CU-masked side stream.  Per block B = [b0, b1):
-//   main   panel kernel: phase 0 applies block B-1 to block column b0, then steps b0 .. b1-1 (inner updates only)
-//   side   after the panel kernel (event):  columns b1+1 .. b1+nbo-1  ("next rest", then a device flag the next panel kernel
-//          waits for inside its first step),  then columns >= b1+nbo ("far rest", event).  Column b1 is phase 0 of panel B+1.
-//   main   panel B+1 starts when far rest of B-1 has finished (its columns were last written there).
-// flags: one device word per block (zeroed here).
-void launch_potrf_hybrid(hipStream_t s, double* A, int Np, double* Linv, int* info, int* sync, int* flags, PotrfAux* aux, int nbo) {
-    ensure_dyn_lds((const void*)potrf_persistent_kernel, DIAG_LDS_BYTES);
-    const int nb = Np / NB;
-    const long ld = Np;
-    const int nblocks = (nb + nbo - 1) / nbo;
-    (void)hipMemsetAsync(flags, 0, (size_t)(nblocks + 1) * sizeof(int), s);
-    hipEvent_t far_done[2] = {nullptr, nullptr};        // far rest of block B-1 / B-2 (ring of the aux events)
-    int ev_i = 0;
-    for (int B = 0, b0 = 0; b0 < nb; ++B, b0 += nbo) {
-        const int b1 = std::min(b0 + nbo, nb);
-        // the panel's columns were last written by the far rest of block B-2 (and the flags memset by nothing else)
-        if (far_done[B & 1]) (void)hipStreamWaitEvent(s, far_done[B & 1], 0);
-        (void)hipMemsetAsync(sync, 0, (size_t)(PK_FLAGS + 2 * nb) * sizeof(int), s);
-        PersistArgs a;
-        a.A = A; a.ld = Np; a.nb = nb; a.Linv = Linv; a.info = info; a.sync = sync;
-        a.nbo = nbo; a.timeout = 20000000LL; a.trace = nullptr;
-        a.j0 = b0; a.j1 = b1;                 // b1 == nb: last block, runs to the end
-        a.k0 = B > 0 ? b0 - nbo : b0;
-        a.ext_flag = (B > 0 && b1 - b0 > 1) ? flags + B : nullptr;
-        a.pr = 1; a.map = 0; a.near = 0; a.acq = 1; a.idle_sleep = 16; a.fuse = 0; a.trsm = 0; a.chain2 = 0;
-        const int work = nb - b0;             // panel tiles of the first step (+ chain)
-        const int G = std::max(2, std::min(64, 1 + work));
-        hipLaunchKernelGGL(potrf_persistent_kernel, dim3(G), dim3(256), DIAG_LDS_BYTES, s, a);
-        if (b1 >= nb) break;
-        hipEvent_t panel_done = aux->ev[ev_i % PotrfAux::NEV];
-        hipEvent_t fd = aux->ev[(ev_i + 1) % PotrfAux::NEV];
-        ev_i += 2;
-        (void)hipEventRecord(panel_done, s);
-        (void)hipStreamWaitEvent(aux->side, panel_done, 0);
-        const int n1 = std::min(b1 + nbo, nb);
-        const int kt = b1 - b0;
-        // next rest: columns b1+1 .. n1-1 (rows >= column), then the flag panel B+1 polls
-        syrk_update(aux->side, A, ld, nb, b0, kt, b1 + 1, b1 + 1, n1 - (b1 + 1));
-        hipLaunchKernelGGL(raise_flag_kernel, dim3(1), dim3(1), 0, aux->side, flags + B + 1);
-        // far rest: columns >= n1
-        syrk_update(aux->side, A, ld, nb, b0, kt, n1, n1, nb - n1);
-        (void)hipEventRecord(fd, aux->side);
-        far_done[B & 1] = fd;                 // panel B+2 waits for it
-    }
-    for (hipEvent_t e : far_done)
-        if (e) (void)hipStreamWaitEvent(s, e, 0);
-}
-
-void launch_potrf(hipStream_t s, double* A, int Np, double* Linv, int* info, int nbo, PotrfAux* aux, int* persist_sync,
-                  int* dataflow_sync) {
+void launch_potrf(hipStream_t s, double* A, int Np, double* Linv, int* info, int nbo, PotrfAux* aux, int* dataflow_sync) {
     diag_attr();
     const int nb = Np / NB;
     const long ld = Np;
     const int mode = potrf_default_mode(Np);
     if (dataflow_sync && nb >= 3 && mode == 3 && launch_potrf_dataflow(s, A, Np, Linv, info, dataflow_sync)) return;
-    if (persist_sync && mode == 2 && aux && aux->side && nb >= 2 * potrf_hybrid_nbo()) {
-        launch_potrf_hybrid(s, A, Np, Linv, info, persist_sync, persist_sync + PK_FLAGS + 2 * nb, aux, potrf_hybrid_nbo());
-        return;
-    }
-    if (persist_sync && nb >= 3 && mode >= 1) {
-        launch_potrf_persistent(s, A, Np, Linv, info, persist_sync);
-        return;
-    }
     if (nbo < 1) nbo = potrf_default_nbo(Np);
     const bool look = aux && aux->side && nbo > 1 && nb > 2 * nbo;
     auto syrk = [&](hipStream_t st, int kcol0, int ktiles, int row0, int col0, int ncols) {
@@ -2045,6 +1404,49 @@ __global__ __launch_bounds__(256) void logdet_kernel(const double* __restrict__ 
 }
 void launch_logdet(hipStream_t s, const double* L, int Np, int N, double* out) {
     hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(256), 0, s, L, Np, N, out);
+}
+
+// ---- bordered factorisation: quad = y^T K^-1 y and log|K| from the factor alone --------------------------------------------
+// Row N of the (identity-padded) matrix is replaced by (y^T, c): the factorisation then leaves t = L^-1 y in row N of L
+// (L_Nk = (y_k - sum_{m<k} L_Nm L_km) / L_kk is the forward substitution), so y^T K^-1 y = |t|^2 comes out of the ONE persistent
+// launch -- no inverse, no separate solve.  c only has to keep the last pivot c - |t|^2 positive; nothing else depends on it.
+// Workgroup q of the launch handles problem q (A + q strideA).
+__global__ __launch_bounds__(256) void border_row_kernel(double* __restrict__ A, long strideA, int Np, int N, const double* __restrict__ y,
+                                                         double c) {
+    double* Aq = A + blockIdx.x * strideA;
+    for (int k = threadIdx.x; k <= N; k += 256) Aq[N + (long)k * Np] = k < N ? y[k] : c;
+}
+void launch_border_row(hipStream_t s, double* A, long strideA, int nprob, int Np, int N, const double* y, double c) {
+    hipLaunchKernelGGL(border_row_kernel, dim3(nprob), dim3(256), 0, s, A, strideA, Np, N, y, c);
+}
+// out[2 q] = y^T K^-1 y = sum_k L_Nk^2, out[2 q + 1] = log|K| = 2 sum_{i<N} log L_ii  (fixed summation order)
+__global__ __launch_bounds__(256) void border_reduce_kernel(const double* __restrict__ L, long strideA, int Np, int N,
+                                                            double* __restrict__ out) {
+    __shared__ double red[2][256];
+    const double* Lq = L + blockIdx.x * strideA;
+    double q = 0.0, ld = 0.0;
+    for (int k = threadIdx.x; k < N; k += 256) {
+        const double t = Lq[N + (long)k * Np];
+        q = fma(t, t, q);
+        ld += log(Lq[(long)k * (Np + 1)]);
+    }
+    red[0][threadIdx.x] = q;
+    red[1][threadIdx.x] = ld;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + o];
+            red[1][threadIdx.x] += red[1][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = red[0][0];
+        out[2 * blockIdx.x + 1] = 2.0 * red[1][0];
+    }
+}
+void launch_border_reduce(hipStream_t s, const double* L, long strideA, int nprob, int Np, int N, double* out) {
+    hipLaunchKernelGGL(border_reduce_kernel, dim3(nprob), dim3(256), 0, s, L, strideA, Np, N, out);
 }
 
 }  // namespace slsk

@@ -288,7 +288,11 @@ __global__ __launch_bounds__(256) void map_opt_kernel(const MapOptArgs args) {
     int* __restrict__ info = args.info;
     double* __restrict__ state = args.state;
     double* __restrict__ out = args.out;
-    auto contrib = [&](int q) -> double& { return btl_lds ? small_scratch(As, SC_BTL + q) : args.btl_scratch[q]; };
+    long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool tracing = args.trace != nullptr;
+    const long long tr_begin = tracing ? wall_clock64() : 0;
+    long long t_prev = tr_begin;
+#define MAP_T(slot) do { if (tracing) { const long long t_now = wall_clock64(); tr[slot] += t_now - t_prev; t_prev = t_now; } } while (0)
 
     // ---- optimiser state: one replica per wave ----
     double x[KV], g[KV], xt[KV], d[KV], lo[KV], hi[KV], S[MH][KV], Y[MH][KV], rho[MH];
@@ -334,22 +338,22 @@ __global__ __launch_bounds__(256) void map_opt_kernel(const MapOptArgs args) {
     if (tid == 0) *info = 0;
     // the first preference tuple of this thread and the first tuple memberships of data point `tid`: indices in registers
     constexpr int RC = 4;
-    int po = 0, pm = 0, pidx[RC], co = 0, cm = 0, cidx[RC];
-#pragma unroll
-    for (int i = 0; i < RC; ++i) pidx[i] = cidx[i] = 0;
+    int po = 0, pm = 0, pidx0 = 0, pidx1 = 0, pidx2 = 0, pidx3 = 0, co = 0, cm = 0, cidx0 = 0, cidx1 = 0, cidx2 = 0, cidx3 = 0;
     if (tid < P) {
         po = args.pref_off[tid];
         pm = args.pref_off[tid + 1] - po;
-#pragma unroll
-        for (int i = 0; i < RC; ++i)
-            if (i < pm) pidx[i] = args.pref_flat[po + i];
+        pidx0 = args.pref_flat[po];
+        if (pm > 1) pidx1 = args.pref_flat[po + 1];
+        if (pm > 2) pidx2 = args.pref_flat[po + 2];
+        if (pm > 3) pidx3 = args.pref_flat[po + 3];
     }
     if (tid < ny && P > 0) {
         co = args.csc_off[tid];
         cm = args.csc_off[tid + 1] - co;
-#pragma unroll
-        for (int i = 0; i < RC; ++i)
-            if (i < cm) cidx[i] = args.csc_ent[co + i];
+        if (cm > 0) cidx0 = args.csc_ent[co];
+        if (cm > 1) cidx1 = args.csc_ent[co + 1];
+        if (cm > 2) cidx2 = args.csc_ent[co + 2];
+        if (cm > 3) cidx3 = args.csc_ent[co + 3];
     }
     __syncthreads();
 
@@ -387,39 +391,76 @@ __global__ __launch_bounds__(256) void map_opt_kernel(const MapOptArgs args) {
             have_factor = true;
             bad = __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
         }
+        MAP_T(0);
         double gb, quad;
         small_alpha(As, N, gb, quad);
+        MAP_T(1);
         if (bad && nh && tid == 0) *info = 0;   // every thread has read it (barriers of small_alpha); the next factorisation starts clean
         double sa_t = 0.0, gl_t[NLL_SMALL_MAX_GRAD_D];
         if (nh) small_grad<MATERN>(As, X, D, N, a, true, sa_t, gl_t);
 
+        MAP_T(2);
         // ---- Bradley-Terry-Luce terms: tuple p on thread p (, p + 256, ...) ----
-        double lsum = 0.0;
-        const double bs = args.btl_scale;
-        for (int p = tid; p < P; p += 256) {
-            const int o = p == tid ? po : args.pref_off[p], m = p == tid ? pm : args.pref_off[p + 1] - o;
-            auto member = [&](int i) { return (p == tid && i < RC) ? pidx[i < RC ? i : 0] : args.pref_flat[o + i]; };
-            const double f0 = small_scratch(As, SC_Y + member(0));
-            double sum = 0.0;
-            for (int i = 0; i < m; ++i) sum += exp(small_scratch(As, SC_Y + member(i)) / bs);
-            const double v = exp(f0 / bs) / sum;                       // CalcBtl
-            lsum += log(v);                                            // calc_log_likelihood
-            const double tmp = -v * v / bs;                            // CalcBtlDerivative
-            double sum2 = 0.0;
-            for (int i = 1; i < m; ++i) {
-                const double r = exp((small_scratch(As, SC_Y + member(i)) - f0) / bs);   // used twice by the reference: once here
-                sum2 += r;
-                contrib(o + i) = r;
+        // contrib: the per-member terms d BTL_p / BTL_p, in the LDS scratch (flat_len <= 640) or in global memory -- two
+        // instantiations of the same code, not a run-time pointer choice (a pointer that may be LDS or global is a generic
+        // pointer: flat loads / stores)
+        double btl_sum = 0.0, gy = 0.0;
+        auto btl_terms = [&](auto&& contrib) {
+            double lsum = 0.0;
+            const double bs = args.btl_scale;
+            // one tuple: o = its offset in the flat list, m = its size, (m0 .. m3) = its first RC members
+            auto tuple_terms = [&](int o, int m, int m0, int m1, int m2, int m3) {
+                // the first RC members from registers (a select chain: a dynamically indexed private array lives in scratch memory,
+                // one flat load per member on the dependent path member -> y -> exp), the rest from global memory
+                auto member = [&](int i) {
+                    if (i >= RC) return args.pref_flat[o + i];
+                    int r = m0;
+                    r = (i == 1) ? m1 : r;
+                    r = (i == 2) ? m2 : r;
+                    r = (i == 3) ? m3 : r;
+                    return r;
+                };
+                const double f0 = small_scratch(As, SC_Y + m0);
+                double sum = 0.0;
+                for (int i = 0; i < m; ++i) sum += exp(small_scratch(As, SC_Y + member(i)) / bs);
+                const double v = exp(f0 / bs) / sum;                       // CalcBtl
+                lsum += log(v);                                            // calc_log_likelihood
+                const double tmp = -v * v / bs;                            // CalcBtlDerivative
+                double sum2 = 0.0;
+                for (int i = 1; i < m; ++i) {
+                    const double r = exp((small_scratch(As, SC_Y + member(i)) - f0) / bs);   // used twice by the reference: once here
+                    sum2 += r;
+                    contrib(o + i) = r;
+                }
+                contrib(o) = (tmp * (-sum2)) / v;
+                for (int i = 1; i < m; ++i) contrib(o + i) = (tmp * contrib(o + i)) / v;
+            };
+            static_assert(RC == 4, "tuple_terms takes four register members");
+            if (tid < P) tuple_terms(po, pm, pidx0, pidx1, pidx2, pidx3);
+            for (int p = tid + 256; p < P; p += 256) {       // more than 256 tuples: indices from global memory
+                const int o = args.pref_off[p], m = args.pref_off[p + 1] - o;
+                tuple_terms(o, m, args.pref_flat[o], m > 1 ? args.pref_flat[o + 1] : 0, m > 2 ? args.pref_flat[o + 2] : 0,
+                            m > 3 ? args.pref_flat[o + 3] : 0);
             }
-            contrib(o) = (tmp * (-sum2)) / v;
-            for (int i = 1; i < m; ++i) contrib(o + i) = (tmp * contrib(o + i)) / v;
-        }
-        const double btl_sum = small_block_sum(lsum, As);   // its barriers also publish the contributions (LDS or global, one CU)
-        double gy = 0.0;
-        if (tid < ny) {
-            for (int i = 0; i < cm; ++i) gy += contrib(i < RC ? cidx[i < RC ? i : 0] : args.csc_ent[co + i]);   // :202-216, in tuple order
-            gy -= small_scratch(As, SC_ALPHA + tid);                                                            // :219
-        }
+            btl_sum = small_block_sum(lsum, As);   // its barriers also publish the contributions (LDS or global, one CU)
+            if (tid < ny) {
+                for (int i = 0; i < cm; ++i) {                                                                      // :202-216, in tuple order
+                    int e;
+                    if (i >= RC) e = args.csc_ent[co + i];
+                    else {
+                        e = cidx0;
+                        e = (i == 1) ? cidx1 : e;
+                        e = (i == 2) ? cidx2 : e;
+                        e = (i == 3) ? cidx3 : e;
+                    }
+                    gy += contrib(e);
+                }
+                gy -= small_scratch(As, SC_ALPHA + tid);                                                            // :219
+            }
+        };
+        if (btl_lds) btl_terms([&](int q) -> double& { return small_scratch(As, SC_BTL + q); });
+        else btl_terms([&](int q) -> double& { return args.btl_scratch[q]; });
+        MAP_T(3);
 
         // ---- value ----
         double f = btl_sum + (-0.5 * quad - 0.5 * (2.0 * ld) - 0.5 * N * log(2.0 * M_PI));
@@ -456,7 +497,9 @@ __global__ __launch_bounds__(256) void map_opt_kernel(const MapOptArgs args) {
             if (args.eval_only) out[MAP_OPT_OUT_G + tid] = gz;
         }
         __syncthreads();
+        MAP_T(4);
         ++evals;
+        tr[6] += 1;
         if (args.eval_only) {
             done = 1;
 #pragma unroll
@@ -582,6 +625,11 @@ __global__ __launch_bounds__(256) void map_opt_kernel(const MapOptArgs args) {
                 if (wave_dot(dv, dv) == 0.0) done = 1;
             }
         }
+        MAP_T(5);
+    }
+    if (tracing && tid == 0) {
+        tr[7] = wall_clock64() - tr_begin;
+        for (int q = 0; q < 8; ++q) args.trace[q] += tr[q];
     }
 
     // ---- results and the state for a continuation ----

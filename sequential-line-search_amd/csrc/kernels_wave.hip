@@ -21,6 +21,12 @@
 
 namespace slsk {
 
+// STAGE: 0 K^-1 and the design matrix are read from global memory, 1 K^-1 from its LDS copy, 2 both from LDS.  A template
+// parameter, not a run-time pointer choice: a pointer that may be global OR LDS is a generic pointer, and every read through it
+// a flat_load -- measured in round 4 (SLS_WAVE_TRACE=1, N = 61): 7.7 us per evaluation in the K^-1 k loop alone.
+// R = Np / 64 rows of the training set per lane, also a template parameter: with a run-time bound the `row r exists` tests of the
+// unrolled per-row code became ~130 scalar branches per eight columns of the K^-1 k loop -- the other 7 of its 7.7 us.
+template <int STAGE, int R>
 __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* smem = reinterpret_cast<double*>(smem_raw);
@@ -48,27 +54,29 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
     // loops whose every trip needs a global word (L2 at best: ~1 us from a chip that is otherwise idle); with one wavefront per
     // start nothing hides that, and 320 evaluations in sequence took 7 ms (22 us each) at N = 60, D = 32.  Values only move:
     // same bits.
-    const double* KinvP = p.Kinv;
-    const double* XTP = p.XT;
-    {
-        double* shared = smem + 4L * p.lds_per_wave;
-        if (p.stage_kinv) {
-            for (int idx = threadIdx.x; idx < Np * Np; idx += 256) shared[idx] = p.Kinv[idx];
-            KinvP = shared;
-            shared += (long)Np * Np;
-        }
-        if (p.stage_xt) {
-            for (int idx = threadIdx.x; idx < Np * D; idx += 256) shared[idx] = p.XT[idx];
-            XTP = shared;
-        }
-        if (p.stage_kinv || p.stage_xt) __syncthreads();
-    }
+    double* const sharedK = smem + 4L * p.lds_per_wave;
+    double* const sharedX = sharedK + (STAGE >= 1 ? (long)Np * Np : 0L);
+    if (STAGE >= 1)
+        for (int idx = threadIdx.x; idx < Np * Np; idx += 256) sharedK[idx] = p.Kinv[idx];
+    if (STAGE >= 2)
+        for (int idx = threadIdx.x; idx < Np * D; idx += 256) sharedX[idx] = p.XT[idx];
+    if (STAGE >= 1) __syncthreads();
+    const double* __restrict__ KinvG = p.Kinv;
+    const double* __restrict__ XTG = p.XT;
+    auto kinv_at = [&](long idx) -> double {
+        if constexpr (STAGE >= 1) return sharedK[idx];
+        else return KinvG[idx];
+    };
+    auto xt_at = [&](long idx) -> double {
+        if constexpr (STAGE >= 2) return sharedX[idx];
+        else return XTG[idx];
+    };
 
     // per-lane constants of every evaluation, read once: 1 / l_d of this lane's dimensions, alpha_i of its rows
     const double il0 = has0 ? p.inv_ell[d0] : 0.0, il1 = has1 ? p.inv_ell[d1] : 0.0;
-    double alr[8];
+    double alr[R];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) alr[r] = (64 * r < Np && lane + 64 * r < N) ? p.alpha[lane + 64 * r] : 0.0;
+    for (int r = 0; r < R; ++r) alr[r] = (lane + 64 * r < N) ? p.alpha[lane + 64 * r] : 0.0;
     // ---- objective: value and gradient of the acquisition function at xq (lanes over d) ----
     double last_mu = 0.0, last_sigma = 0.0, last_dm[2] = {0.0, 0.0}, last_ds[2] = {0.0, 0.0};   // predictive parts of the last call
     auto evaluate = [&](const double xq0, const double xq1, double& val, double& gr0, double& gr1) {
@@ -77,13 +85,13 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
         if (has0) xs[d0] = (xq0 - 0.5) * il0;
         if (has1) xs[d1] = (xq1 - 0.5) * il1;
         __syncthreads();
-        double kr[8], cr[8];
+        double kr[R], cr[R];
         double mu = 0.0, ca = 0.0;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
+        for (int r = 0; r < R; ++r) {
             kr[r] = 0.0;
             cr[r] = 0.0;
-            if (64 * r < Np) {
+            {
                 const int i = lane + 64 * r;
                 if (i < N) {
                     // The three loops of an evaluation were chains of dependent  LDS read -> fma  trips: 110-360 cycles per trip on a
@@ -96,7 +104,7 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
                             xv[u] = xs[d + u];
-                            tv[u] = XTP[i + (long)(d + u) * Np];
+                            tv[u] = xt_at(i + (long)(d + u) * Np);
                         }
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
@@ -105,7 +113,7 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
                         }
                     }
                     for (; d < D; ++d) {
-                        const double df = xs[d] - XTP[i + (long)d * Np];
+                        const double df = xs[d] - xt_at(i + (long)d * Np);
                         q += df * df;
                     }
                     if (p.matern) {
@@ -127,31 +135,30 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
         __syncthreads();
         WAVE_T(0);
         // w = K^-1 k for this lane's rows
-        double w[8];
+        double w[R];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) w[r] = 0.0;
-        // columns N .. 8 ceil(N / 8) - 1 exist (identity padding of K^-1, Np is a multiple of 128) and meet k_j = 0 there
-        for (int j0 = 0; j0 < N; j0 += 8) {
-            double kj[8], cv[8][8];
+        for (int r = 0; r < R; ++r) w[r] = 0.0;
+        // G columns in flight, G R = 16 (12 for R = 6) loads per lane.  Columns N .. G ceil(N / G) - 1 exist (identity padding of
+        // K^-1, Np is a multiple of 128) and meet k_j = 0 there
+        constexpr int G = R <= 2 ? 8 : (R <= 4 ? 4 : 2);
+        for (int j0 = 0; j0 < N; j0 += G) {
+            double kj[G], cv[G][R];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < G; ++u) {
                 kj[u] = kb[j0 + u];
-                const double* col = KinvP + (long)(j0 + u) * Np;
 #pragma unroll
-                for (int r = 0; r < 8; ++r)
-                    if (64 * r < Np) cv[u][r] = col[lane + 64 * r];
+                for (int r = 0; r < R; ++r) cv[u][r] = kinv_at((long)(j0 + u) * Np + lane + 64 * r);
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < G; ++u) {
 #pragma unroll
-                for (int r = 0; r < 8; ++r)
-                    if (64 * r < Np) w[r] += cv[u][r] * kj[u];
+                for (int r = 0; r < R; ++r) w[r] += cv[u][r] * kj[u];
             }
         }
         double kw = 0.0, cw = 0.0;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            if (64 * r < Np) {
+        for (int r = 0; r < R; ++r) {
+            {
                 const int i = lane + 64 * r;
                 if (i < N) {
                     kw += kr[r] * w[r];
@@ -178,13 +185,13 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
             const int d = lane + 64 * e;
             if (d < D) {
                 double gm = 0.0, gs = 0.0;
-                const double* xrow = XTP + (long)d * Np;
+                const long xrow = (long)d * Np;
                 int i = 0;
                 for (; i + 8 <= N; i += 8) {
                     double xv[8], av[8], wv[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        xv[u] = xrow[i + u];
+                        xv[u] = xt_at(xrow + i + u);
                         av[u] = cab[i + u];
                         wv[u] = cwb[i + u];
                     }
@@ -195,7 +202,7 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
                     }
                 }
                 for (; i < N; ++i) {
-                    const double xi = xrow[i];
+                    const double xi = xt_at(xrow + i);
                     gm += xi * cab[i];
                     gs += xi * cwb[i];
                 }
@@ -400,8 +407,24 @@ void launch_maximize_wave(hipStream_t s, WaveArgs a) {
     if (a.stage_kinv) bytes += kb;
     a.stage_xt = allow && a.stage_kinv && bytes + xb <= cap;
     if (a.stage_xt) bytes += xb;
-    ensure_dyn_lds((const void*)maximize_wave_kernel, 160 * 1024);   // opt in to the CU's whole LDS once per device
-    hipLaunchKernelGGL(maximize_wave_kernel, dim3((a.S + 3) / 4), dim3(256), bytes, s, a);
+    // opt in to the CU's whole LDS once per device.  K^-1 only fits the LDS next to the waves' own areas for Np = 128 (R = 2).
+    const dim3 grid((a.S + 3) / 4), block(256);
+    const int R = a.Np / 64;
+#define SLS_WAVE_LAUNCH(ST, RR)                                                              \
+    do {                                                                                     \
+        ensure_dyn_lds((const void*)maximize_wave_kernel<ST, RR>, 160 * 1024);               \
+        hipLaunchKernelGGL((maximize_wave_kernel<ST, RR>), grid, block, bytes, s, a);        \
+    } while (0)
+    if (R == 2 && a.stage_xt) SLS_WAVE_LAUNCH(2, 2);
+    else if (R == 2 && a.stage_kinv) SLS_WAVE_LAUNCH(1, 2);
+    else {
+        a.stage_kinv = a.stage_xt = 0;
+        if (R == 2) SLS_WAVE_LAUNCH(0, 2);
+        else if (R == 4) SLS_WAVE_LAUNCH(0, 4);
+        else if (R == 6) SLS_WAVE_LAUNCH(0, 6);
+        else SLS_WAVE_LAUNCH(0, 8);
+    }
+#undef SLS_WAVE_LAUNCH
 }
 
 }  // namespace slsk

@@ -267,3 +267,35 @@ def test_unsupported_sizes_are_reported_not_computed(ctx):
     with pytest.raises(sls().Unsupported):
         h.gp_map_fit(np.zeros(30), np.zeros(22), np.full(22, -18.0), np.full(22, 3.9), 10)
     h.close()
+
+
+@pytest.mark.parametrize("kernel", [0, 1])
+@pytest.mark.parametrize("N,D", [(300, 5), (1000, 8), (1024, 3), (1537, 16)])
+def test_value_only_batch_runs_concurrent_bordered_factorisations(ctx, oracle, kernel, N, D):
+    """sls_gp_nll_batch for N > 128: the B independent points of a DIRECT iteration (src/gaussian-process-regressor.cpp:294) are
+    factored several at a time in ONE persistent launch, each on its own share of the chip, with y as a border row of K_y so that
+    y^T K^-1 y and log|K_y| come from the factor alone.  Values: bit-identical to the same call with one point at a time (how many
+    workgroups share a factorisation never changes a tile's arithmetic), equal to the full evaluation (explicit inverse) and to the
+    oracle to rounding; N = 1024 has no padding row (an extra 128-block carries the border)."""
+    X, y, _, _ = synth_problem(oracle, D, N, seed=500 + N)
+    rng = np.random.default_rng(N + kernel)
+    B = 7
+    xs = np.column_stack([rng.uniform(0.2, 1.5, B), 10.0 ** rng.uniform(-4, -1, B), rng.uniform(0.3, 1.5, (B, D))])
+    h = sls().Nll(ctx, X, kernel)
+    vals = h.gp_objective_batch(y, xs)
+    single = np.array([h.gp_objective_batch(y, xs[k:k + 1])[0] for k in range(B)])
+    assert np.array_equal(vals, single)
+    old = os.environ.get("SLS_NLL_BATCH")
+    os.environ["SLS_NLL_BATCH"] = "0"
+    try:
+        full = h.gp_objective_batch(y, xs)                   # one full evaluation (K^-1, alpha) after the other
+    finally:
+        if old is None:
+            del os.environ["SLS_NLL_BATCH"]
+        else:
+            os.environ["SLS_NLL_BATCH"] = old
+    orc = np.array([oracle.gp_map_objective(kernel, X, y, xs[k], want_grad=False) for k in range(B)])
+    scale = np.maximum(1.0, np.abs(orc))
+    assert np.max(np.abs(vals - full) / scale) <= 1e-10, np.max(np.abs(vals - full) / scale)
+    assert np.max(np.abs(vals - orc) / scale) <= 1e-9, np.max(np.abs(vals - orc) / scale)
+    h.close()

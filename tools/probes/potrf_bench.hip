@@ -70,14 +70,14 @@ int main(int argc, char** argv) {
         hipMalloc(&A0, bytes); hipMalloc(&A, bytes); hipMalloc(&Lref, bytes); hipMalloc(&Linv, bytes); hipMalloc(&red, 1024 * 8);
         hipLaunchKernelGGL(fill_spd, dim3((unsigned)(((long)Np * Np + 255) / 256)), dim3(256), 0, s, A0, Np);
         hipMemsetAsync(Linv, 0, bytes, s);
-        auto run = [&](int nbo, PotrfAux* aux, const char* label, bool is_ref, bool persist = false) {
+        auto run = [&](int nbo, PotrfAux* aux, const char* label, bool is_ref) {
             float best = 1e30f;
             for (int rep = 0; rep < 4; ++rep) {
                 hipMemcpyAsync(A, A0, bytes, hipMemcpyDeviceToDevice, s);
                 hipMemsetAsync(info, 0, 64, s);
                 hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
                 hipEventRecord(e0, s);
-                launch_potrf(s, A, Np, Linv, info, nbo, aux, persist ? info + 64 : nullptr);
+                launch_potrf(s, A, Np, Linv, info, nbo, aux, nullptr);
                 hipEventRecord(e1, s); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 if (rep > 0 && ms < best) best = ms;
@@ -97,7 +97,6 @@ int main(int argc, char** argv) {
             printf("N=%5d %-34s %8.3f ms  %6.2f TFLOP/s  info=%d  max|L - L_ref|=%.2e\n", Np, label, best, tf, inf, md);
         };
         run(1, nullptr, "one-level (nbo=1)", true);
-        run(1, nullptr, "persistent single launch", false, true);
         {   // dataflow form (SLS_POTRF_DNBO / SLS_POTRF_DPR from the environment)
             int* dsync; hipMalloc(&dsync, potrf_dataflow_sync_ints(Np) * sizeof(int));
             float best = 1e30f; bool ok = true;
@@ -154,29 +153,37 @@ int main(int argc, char** argv) {
             }
             hipFree(dsync);
         }
-        if (getenv("POTRF_BENCH_HYBRID")) {
-            PotrfAux aux;
-            potrf_aux_create(&aux, 8);
-            run(1, &aux, "hybrid (mode from env)", false, true);
-            potrf_aux_destroy(&aux);
-        }
-        if (getenv("POTRF_BENCH_TRACE")) {
-            const int nb = Np / 128;
-            long long* tr; hipMalloc(&tr, (size_t)nb * 16 * 8); hipMemset(tr, 0, (size_t)nb * 16 * 8);
-            hipMemcpyAsync(A, A0, bytes, hipMemcpyDeviceToDevice, s);
-            hipMemsetAsync(info, 0, 64, s);
-            launch_potrf_persistent(s, A, Np, Linv, info, info + 64, tr);
-            hipStreamSynchronize(s);
-            std::vector<long long> h((size_t)nb * 16); hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost);
-            printf("trace N=%d (us, relative to the chain's step start): step | chain: workersDone gemm1+signal gemm2 diag+signal | worker 1: start - panelDone B1out - updDone B2out\n", Np);
-            for (int j = 0; j < nb - 1; ++j) {
-                const long long* g = h.data() + 16 * j; const double t0 = (double)g[0];
-                auto us = [&](long long v) { return v ? ((double)v - t0) / 100.0 : -1.0; };
-                if (j < 6 || j % 8 == 0 || j > nb - 4)
-                    printf("  %3d | %6.1f %6.1f %6.1f %6.1f %6.1f | %6.1f %6.1f %6.1f %6.1f %6.1f %6.1f %6.1f\n", j, us(g[1]), us(g[2]), us(g[3]), us(g[4]), -1.0,
-                           us(g[8]), us(g[9]), us(g[10]), us(g[11]), us(g[12]), us(g[13]), us(g[14]));
+        if (getenv("POTRF_BENCH_BATCH")) {
+            // P independent factorisations of the same matrix in ONE launch, each on 1/P of the chip's workgroups, against P launches
+            // in sequence: time per problem, and every problem's factor against the single-problem factor (must be identical bits)
+            for (int P : {2, 3, 4, 6, 8}) {
+                if ((size_t)P * bytes * 2 > (size_t)160 << 30) break;
+                double *Ab, *Lb; int* sb;
+                const size_t sync_ints = (potrf_dataflow_sync_ints(Np) + 63) / 64 * 64;
+                hipMalloc(&Ab, bytes * P); hipMalloc(&Lb, bytes * P); hipMalloc(&sb, sync_ints * sizeof(int) * P);
+                float best = 1e30f; bool ok = true;
+                for (int rep = 0; rep < 4 && ok; ++rep) {
+                    for (int q = 0; q < P; ++q) hipMemcpyAsync(Ab + (size_t)q * Np * Np, A0, bytes, hipMemcpyDeviceToDevice, s);
+                    hipMemsetAsync(info, 0, 64, s);
+                    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+                    hipEventRecord(e0, s);
+                    ok = launch_potrf_dataflow_batch(s, Ab, Np, Lb, info, sb, P, (long)Np * Np, (long)sync_ints, false);
+                    hipEventRecord(e1, s); hipEventSynchronize(e1);
+                    float ms; hipEventElapsedTime(&ms, e0, e1);
+                    if (rep > 0 && ms < best) best = ms;
+                }
+                int inf[16] = {0}; hipMemcpy(inf, info, 64, hipMemcpyDeviceToHost);
+                int bad = 0; for (int q = 0; q < 2 * P; ++q) bad |= inf[q];
+                double md = 0.0;
+                for (int q = 0; q < P && ok; ++q) {
+                    hipLaunchKernelGGL(maxdiff_lower, dim3(1024), dim3(256), 0, s, Ab + (size_t)q * Np * Np, A, Np, red);
+                    std::vector<double> h(1024); hipStreamSynchronize(s); hipMemcpy(h.data(), red, 1024 * 8, hipMemcpyDeviceToHost);
+                    for (double v : h) md = fmax(md, v);
+                }
+                printf("N=%5d batch of %d in one launch: %8.3f ms = %7.3f ms per problem (applicable=%d, info|abort=%d, max|L_q - L_single|=%.2e; "
+                       "suggested P = %d)\n", Np, P, best, best / P, (int)ok, bad, md, potrf_dataflow_max_problems(Np));
+                hipFree(Ab); hipFree(Lb); hipFree(sb);
             }
-            hipFree(tr);
         }
         if (quick) { hipFree(A0); hipFree(A); hipFree(Lref); hipFree(Linv); hipFree(red); continue; }
         for (int nbo : {2, 4, 8}) {

@@ -57,9 +57,18 @@ def ev():
     xx = x.copy(); xx[2] *= (1 + 1e-3 * k[0])
     h.gp_objective(y, xx)
 ms_c5 = wall(ev)
+# the B independent value-only evaluations of a DIRECT iteration (sls_gp_nll_batch): concurrent bordered factorisations vs one
+# full evaluation after the other (SLS_NLL_BATCH=0)
+xsb = np.tile(x, (8, 1)); xsb[:, 2] *= 1 + 1e-3 * np.arange(8)
+ms_b8 = wall(lambda: h.gp_objective_batch(y, xsb))
+os.environ["SLS_NLL_BATCH"] = "0"
+ms_s8 = wall(lambda: h.gp_objective_batch(y, xsb), reps=1)
+del os.environ["SLS_NLL_BATCH"]
 # N^3/3 (potrf) + 2N^3/3 (K^-1 from L) + 2 D N^2 (X G) + N^2 D (Gram) flops per evaluation, against the fp64 MFMA peak
 flops_c5 = N ** 3 + 3.0 * D * N * N
 out["C5_map_objective_gradient_N4096_D128"] = {"ms_per_evaluation": ms_c5,
+                                               "value_only_batch_of_8_ms": ms_b8, "value_only_batch_of_8_sequential_ms": ms_s8,
+                                               "value_only_batch_speedup": ms_s8 / ms_b8,
                                                "map_eval_roofline": {"bound": "mfma", "flops": flops_c5, "achieved_TFLOPs": flops_c5 / (ms_c5 * 1e-3) / 1e12,
                                                                      "peak_TFLOPs": 78.6, "frac": flops_c5 / (ms_c5 * 1e-3) / 1e12 / 78.6}}
 # ---- CPU legs (the oracle, timed on this host): what the reference's CPU path costs in the SAME operating regime -------------
@@ -73,6 +82,11 @@ def timeit(f, reps):
 
 cores = os.cpu_count()
 rng = np.random.default_rng(7)
+import ctypes
+_gomp = ctypes.CDLL("libgomp.so.1")
+def omp_threads(n):          # the small configurations on ONE thread (64 threads make a 60 x 60 factorisation slower), C5 on 64
+    _gomp.omp_set_num_threads(int(n))
+omp_threads(1)
 # C1: per iteration (N = 1 .. 20, D = 1): GP MAP fit = 300 DIRECT value evaluations + the local phase (value + gradient; the
 # device fit's own count is not exported by the demo: 100 assumed), then FindNextPoint = fit + 50 D EI values + 10 D EI value+gradient
 c1 = 0.0
@@ -89,6 +103,7 @@ for n in range(1, 21):
 out["C1_bayesian_optimization_1d_20_iterations"]["cpu_oracle_wall_s"] = c1
 out["C1_bayesian_optimization_1d_20_iterations"]["cpu_oracle_note"] = ("sum over 20 iterations of 300 + 100 MAP-objective evaluations, the fit, 50 EI values "
     "and 10 EI value+gradient evaluations at that iteration's N, oracle (hoisted), 1 thread, ctypes call overhead included")
+out["C1_bayesian_optimization_1d_20_iterations"]["process_start_floor_note"] = "a HIP process that launches one trivial kernel takes 0.19-0.26 s on the same box (tools/probes/hip_startup.hip): C1's GPU wall time is process start"
 # C3: per submit at N = 3, 5, .., 61 (D = 32): 100 preference-objective evaluations (value + gradient; the oracle refactors K per
 # call, the reference caches it for use_map_hyperparams = false: an upper bound), the fit, 50 D = 1600 EI values (DIRECT) and
 # 10 D = 320 EI value + gradient evaluations (L-BFGS)
@@ -97,7 +112,7 @@ c3 = []
 for n in range(3, 62, 2):
     Xn = rng.uniform(0, 1, (D3, n)); yn = rng.normal(size=n)
     prefs = [[3 * i + 1, 3 * i, 3 * i + 2] for i in range(max(1, (n - 1) // 3)) if 3 * i + 2 < n] or [[0, 1, 2][:n]]
-    t_p = timeit(lambda: oracle.pref_objective(1, Xn, prefs, yn, r=0.5, a=0.5, b=0.001, btl_scale=0.01), 5)
+    t_p = timeit(lambda: oracle.pref_objective(1, Xn, prefs, yn, r=0.5, a=0.5, b=0.001, btl_scale=0.01), 3)
     th = np.concatenate([[0.5], np.full(D3, 0.5)])
     t_fit = timeit(lambda: oracle.Regressor(Xn, yn, th, 0.001, kernel=1), 3)
     rg = oracle.Regressor(Xn, yn, th, 0.001, kernel=1)
@@ -108,14 +123,16 @@ for n in range(3, 62, 2):
 out["C3_sequential_line_search_nd_D32_30_iterations"]["cpu_oracle_ms_per_submit_mean"] = float(np.mean(c3))
 out["C3_sequential_line_search_nd_D32_30_iterations"]["cpu_oracle_ms_per_submit_last"] = c3[-1]
 out["C3_sequential_line_search_nd_D32_30_iterations"]["cpu_oracle_note"] = ("per submit: 100 preference-objective evaluations + fit + 1600 EI values + 320 EI "
-    f"value+gradient evaluations at N = 3 .. 61, oracle (hoisted predictor), OMP threads {os.environ.get('OMP_NUM_THREADS')} of {cores} cores")
+    f"value+gradient evaluations at N = 3 .. 61, oracle (hoisted predictor), 1 thread of {cores} cores")
 # C5: ONE hoisted MAP objective + gradient evaluation at N = 4096, D = 128
+omp_threads(int(os.environ.get("OMP_NUM_THREADS", "64")))
 t0 = time.perf_counter(); oracle.gp_map_objective(1, X, y, x, want_grad=True); t_c5 = time.perf_counter() - t0
 out["C5_map_objective_gradient_N4096_D128"]["cpu_oracle_s_per_evaluation"] = t_c5
 out["C5_map_objective_gradient_N4096_D128"]["cpu_oracle_note"] = f"oracle slso_gp_map_objective (hoisted), OMP threads {os.environ.get('OMP_NUM_THREADS')} of {cores} cores"
 # crossover: smallest N (D = 32, Matern) at which ONE fit + 4096-point predict is faster on the device than in the oracle
 cross = None
-for n in (32, 64, 128, 256, 512, 1024):
+for n in (32, 64, 128, 256, 512):
+    omp_threads(1 if n <= 128 else int(os.environ.get("OMP_NUM_THREADS", "64")))
     Xn = rng.uniform(0, 1, (32, n)); yn = rng.normal(size=n); th = np.concatenate([[0.5], np.full(32, 1.0)]); Q = rng.uniform(0, 1, (32, 4096))
     def gpu():
         g = m.GP(ctx, Xn, yn, th, 0.005, 1); g.predict(Q); g.close()
