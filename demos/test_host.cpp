@@ -13,6 +13,8 @@
 #include <sequential-line-search/slider.hpp>
 #include <sequential-line-search/utils.hpp>
 
+#include "device.hpp"   // host/device.hpp: the replica cache and the shared multi-device handle (internal API)
+
 using namespace sequential_line_search;
 using Eigen::MatrixXd;
 using Eigen::VectorXd;
@@ -111,10 +113,28 @@ int main()
             // multi-GPU path behind the same call: three logical shards on device 0 (replicated fit, starts split 22/21/21,
             // per-shard winners merged by first maximum) must return the single-device winner bit for bit
             device::SetDevices({0, 0, 0});
-            double         vmulti = 0.0;
+            const long     builds0 = device::ReplicaBuilds();
+            double         vmulti  = 0.0;
             const VectorXd xm = acquisition_func::FindNextPointFromStarts(gp, starts, 30, AcquisitionFuncType::ExpectedImprovement, 1.0, &vmulti);
-            device::SetDevices({0});
             EXPECT(vmulti == vmax && (xm - xs).norm() == 0.0);
+            EXPECT(device::ReplicaBuilds() == builds0 + 1);
+            // the replicas belong to the regressor's handle: a second (and third) call on the same regressor fits nothing
+            double         vagain = 0.0;
+            const VectorXd xa = acquisition_func::FindNextPointFromStarts(gp, starts, 30, AcquisitionFuncType::ExpectedImprovement, 1.0, &vagain);
+            acquisition_func::FindNextPointFromStarts(gp, starts, 10, AcquisitionFuncType::GaussianProcessUpperConfidenceBound, 1.5);
+            EXPECT(device::ReplicaBuilds() == builds0 + 1);
+            EXPECT(vagain == vmax && (xa - xs).norm() == 0.0);
+            // a reconfiguration while a handle built on the old configuration is still alive must not pull it from under that handle
+            {
+                std::shared_ptr<device::MultiRef> old_multi = device::Multi();
+                device::SetDevices({0, 0});
+                double         v2 = 0.0;
+                const VectorXd x2 = acquisition_func::FindNextPointFromStarts(gp, starts, 30, AcquisitionFuncType::ExpectedImprovement, 1.0, &v2);
+                EXPECT(v2 == vmax && (x2 - xs).norm() == 0.0);
+                EXPECT(device::ReplicaBuilds() == builds0 + 2);             // new configuration: new replicas
+                EXPECT(old_multi && old_multi->m != nullptr && sls_multi_size(old_multi->m) == 3);   // still alive and usable
+            }
+            device::SetDevices({0});
         }
         // empty regressor: acquisition value 0 (src/acquisition-function.cpp:176-179)
         GaussianProcessRegressor empty(MatrixXd(0, 0), VectorXd(0));

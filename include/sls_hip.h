@@ -100,6 +100,16 @@ int sls_gp_append_point(sls_gp* gp, const double* x, double y);
 #define SLS_GP_ALPHA 3      /* N      K_y^-1 y */
 #define SLS_GP_MU_DATA 4    /* N      PredictMu at every data point (regressor.cpp:34-37) */
 int sls_gp_get_matrix(sls_gp* gp, int what, double* out);
+/* How the predictive deviation is formed.  The two reference classes differ (and so do the two modes, by rounding only):
+ *   SLS_SIGMA_EXPLICIT_INVERSE (default)  sigma^2 = a - k^T K_y^-1 k with the explicit inverse, GaussianProcessRegressor::PredictSigma
+ *                                         (src/gaussian-process-regressor.cpp:241-255, m_K_y_inv);
+ *   SLS_SIGMA_CHOLESKY_SOLVE              sigma^2 = a - k . LLT.solve(k) = a - |L^-1 k|^2, PreferenceRegressor::PredictSigma
+ *                                         (src/preference-regressor.cpp:299-313); the sigma gradient uses L^-T (L^-1 k) (:323-330).
+ * For ill-conditioned K_y (cond >= 1e6, sigma <= 3e-3) the first form is only accurate to cond(K_y) eps a / (2 sigma), the second to
+ * ~1e-12; a handle that stands for a PreferenceRegressor should therefore use the second, as the reference does. */
+#define SLS_SIGMA_EXPLICIT_INVERSE 0
+#define SLS_SIGMA_CHOLESKY_SOLVE 1
+int sls_gp_set_sigma_mode(sls_gp* gp, int mode);
 /* best_index / x_best: PredictMaximumPointFromData (src/regressor.cpp:29-43); mu_best = PredictMu(x_best);
  * logdet = CalcLogDetOfSymmetricPositiveDefiniteMatrix(K_y).  Any out pointer may be NULL. */
 int sls_gp_get_summary(sls_gp* gp, int* best_index, double* mu_best, double* logdet);
@@ -136,7 +146,8 @@ int sls_acq_maximize(sls_gp* gp, int acq_type, double ucb_h, const double* start
  *   evals_cap     S * n_local
  *   rounds        lock-step rounds executed (<= n_local)
  *   live_at_end   starts still moving when the cap was reached
- * Any out pointer may be NULL.  (The single-launch wavefront path for small problems reports evals_issued = evals_cap.) */
+ * Any out pointer may be NULL.  (The single-launch wavefront path for small problems counts, inside the kernel, the evaluations
+ * of starts that were still moving, and reports rounds = n_local.) */
 int sls_acq_last_stats(sls_gp* gp, long* evals_issued, long* evals_cap, int* rounds, int* live_at_end);
 /* Same, with the starts already resident in HBM (D x S column-major device buffer) -- the timed path of bench.py. */
 int sls_acq_maximize_dev(sls_gp* gp, int acq_type, double ucb_h, const double* starts_dev, int S, int n_local,
@@ -171,6 +182,10 @@ sls_ctx* sls_multi_ctx(sls_multi* m, int shard);
 /* sls_gp_create on every device (concurrently). */
 int sls_multi_gp_create(sls_multi* m, const double* X, int D, int N, const double* y, const double* theta, double b, int kernel,
                         sls_multi_gp** out);
+/* Replicas of an EXISTING fitted handle (what FindNextPoint* needs when several devices are configured): the shard on the
+ * primary's own device is the primary itself -- no second fit there --, the other devices fit from its data.  `primary` must outlive
+ * the result and must not be refitted or grown (sls_gp_append_point) while the replicas are in use. */
+int sls_multi_gp_create_from(sls_multi* m, sls_gp* primary, sls_multi_gp** out);
 int sls_multi_gp_destroy(sls_multi_gp* g);
 sls_gp* sls_multi_gp_shard(sls_multi_gp* g, int shard);
 /* sls_acq_maximize over all devices: starts (D x S, host) are split into contiguous slices; idx_out is the global start

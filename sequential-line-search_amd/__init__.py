@@ -52,14 +52,15 @@ EXPORTS = [
     "sls_lbfgs_default_opts", "sls_acq_maximize", "sls_acq_maximize_dev", "sls_gp_refit_dev", "sls_prof_enable",
     "sls_prof_reset", "sls_prof_get", "sls_nll_create", "sls_nll_destroy", "sls_nll_eval", "sls_gp_nll_grad", "sls_gp_nll_batch", "sls_multi_nll_create", "sls_multi_nll_destroy",
     "sls_multi_gp_nll_batch",
-    "sls_pref_objective", "sls_pref_map_fit", "sls_gp_map_fit", "sls_acq_eval_pair", "sls_acq_maximize_pair", "sls_gp_append_point", "sls_acq_last_stats",
-    "sls_multi_create", "sls_multi_destroy", "sls_multi_size", "sls_multi_exchange", "sls_multi_ctx", "sls_multi_gp_create",
+    "sls_pref_objective", "sls_pref_map_fit", "sls_gp_map_fit", "sls_gp_set_sigma_mode", "sls_acq_eval_pair", "sls_acq_maximize_pair", "sls_gp_append_point", "sls_acq_last_stats",
+    "sls_multi_create", "sls_multi_destroy", "sls_multi_size", "sls_multi_exchange", "sls_multi_ctx", "sls_multi_gp_create", "sls_multi_gp_create_from",
     "sls_multi_gp_destroy", "sls_multi_gp_shard", "sls_multi_acq_maximize", "sls_multi_gp_predict", "sls_comm_unique_id", "sls_comm_create",
     "sls_comm_destroy", "sls_comm_allgather_best", "sls_device_trim_cache",
 ]
 
 
 ERR_UNSUPPORTED = -5
+SIGMA_EXPLICIT_INVERSE, SIGMA_CHOLESKY_SOLVE = 0, 1
 
 
 class Unsupported(SlsError):
@@ -178,6 +179,10 @@ class GP:
             self.close()
         except Exception:
             pass
+
+    def set_sigma_mode(self, mode):
+        """SIGMA_EXPLICIT_INVERSE (GaussianProcessRegressor, default) or SIGMA_CHOLESKY_SOLVE (PreferenceRegressor)."""
+        _ck(lib().sls_gp_set_sigma_mode(self.h, int(mode)))
 
     def append_point(self, x, y):
         x = _f(x)

@@ -387,6 +387,9 @@ struct sls_gp {
     DBuf lb_x, lb_g, lb_dir, lb_xt, lb_scr, lb_S, lb_Y, lb_rho, lb_f, lb_t, lb_val, lb_grad, lb_xc;
     int* lb_int = nullptr;    // hlen | hpos | nbt | done | live list A | live list B | live count (+ padding) | block counts
     int lb_Sp = 0, lb_m = 0;
+    // 0: sigma^2 = a - k^T K^-1 k with the explicit inverse (GaussianProcessRegressor); 1: a - |L^-1 k|^2, the Cholesky solve of
+    // PreferenceRegressor (sls_gp_set_sigma_mode)
+    int sigma_mode = 0;
     // statistics of the last sls_acq_maximize* call on this handle (sls_acq_last_stats)
     long stat_issued = 0, stat_cap = 0;
     int stat_rounds = 0, stat_live_end = 0;
@@ -427,6 +430,7 @@ static void gp_fit_device(sls_gp* g) {
     launch_mu_data(c->stream, g->y.p, g->alpha.p, g->b, N, g->mu_data.p);
     launch_argmax(c->stream, g->mu_data.p, N, g->scal.p, g->d_idx);
     launch_logdet(c->stream, g->L.p, Np, N, g->scal.p + 1);
+    if (g->sigma_mode == 1) launch_transpose_full(c->stream, g->Linv.p, g->U.p, Np);   // every block of U = (L^-1)^T
 }
 
 static void gp_fetch_summary(sls_gp* g, int attempt = 0) {
@@ -534,6 +538,37 @@ extern "C" int sls_gp_get_summary(sls_gp* g, int* best_index, double* mu_best, d
     return SLS_OK;
 }
 
+namespace slsk {
+int gp_export_inputs(sls_gp* g, int* D, int* N, int* kernel, int* sigma_mode, int* device, double* b, std::vector<double>* X,
+                     std::vector<double>* y, std::vector<double>* theta) {
+    SLS_TRY
+    std::unique_lock<std::recursive_mutex> lock_(g->ctx->mtx);
+    (void)hipSetDevice(g->ctx->device);
+    *D = g->D; *N = g->N; *kernel = g->kernel; *sigma_mode = g->sigma_mode; *device = g->ctx->device; *b = g->b;
+    *theta = g->theta;
+    X->resize((size_t)g->D * g->N);
+    y->resize(g->N);
+    d2h(g->ctx, X->data(), g->X.p, X->size());
+    d2h(g->ctx, y->data(), g->y.p, y->size());
+    sync(g->ctx);
+    SLS_CATCH
+}
+}  // namespace slsk
+
+extern "C" int sls_gp_set_sigma_mode(sls_gp* g, int mode) {
+    SLS_TRY
+    std::unique_lock<std::recursive_mutex> lock_;
+    if (g) {
+        lock_ = std::unique_lock<std::recursive_mutex>(g->ctx->mtx);
+        (void)hipSetDevice(g->ctx->device);
+    }
+    SLS_REQUIRE(g && (mode == SLS_SIGMA_EXPLICIT_INVERSE || mode == SLS_SIGMA_CHOLESKY_SOLVE), "sls_gp_set_sigma_mode: bad argument");
+    if (mode == SLS_SIGMA_CHOLESKY_SOLVE && g->sigma_mode != mode)
+        launch_transpose_full(g->ctx->stream, g->Linv.p, g->U.p, g->Np);   // every block of U = (L^-1)^T (trtri writes the upper ones only)
+    g->sigma_mode = mode;
+    SLS_CATCH
+}
+
 extern "C" int sls_gp_get_matrix(sls_gp* g, int what, double* out) {
     SLS_TRY
     std::unique_lock<std::recursive_mutex> lock_;
@@ -579,7 +614,7 @@ static void ensure_eval_ws(sls_gp* g, int chunk) {
     g->Ks.ensure(C * Np);
     if (g->kernel == SLS_KERNEL_ARD_MATERN52) g->Cs.ensure(C * Np);
     g->P.ensure(C * Np);
-    g->parts.ensure(6 * nbt * C);   // mu, ca: one per row tile; kw, cw: one per half row tile
+    g->parts.ensure(10 * nbt * C);  // mu, ca: one per row tile; kw, cw: one per half row tile; + kw, cw of the solve-based sigma
     g->Gs.ensure(C * g->Dcols);
     g->Gm.ensure(C * g->Dcols);
     g->XsT.ensure(C * g->Dcols);
@@ -633,6 +668,14 @@ static void eval_candidates(sls_gp* g, const double* xr, long ldr, int S, const 
             else
                 launch_var_gemm(c->stream, g->Ks.p, ldk, Sp, g->Linv.p, Np, kw_part, cw_part);
         }
+        // handles of a PreferenceRegressor: sigma from the triangular form |L^-1 k|^2 also when gradients are requested (the
+        // K^-1 product above then only feeds the gradient of sigma)
+        double* kw_solve = nullptr;
+        if (g->sigma_mode == 1 && (want_grad || !tri_predict())) {
+            kw_solve = cw_part + (size_t)2 * nbt * ldk;
+            ProfScope ps(c, "var_gemm");
+            launch_var_gemm(c->stream, g->Ks.p, ldk, Sp, g->Linv.p, Np, kw_solve, kw_solve + (size_t)2 * nbt * ldk);
+        }
         if (want_grad) {
             ProfScope ps(c, "grad_gemm");
             double* part = nullptr;
@@ -648,6 +691,7 @@ static void eval_candidates(sls_gp* g, const double* xr, long ldr, int S, const 
             FinalizeArgs f;
             f.S = sc; f.D = D; f.nbt = nbt; f.ldk = ldk; f.ntm = Sp / 128; f.split_first = split_first;
             f.mu_part = mu_part; f.ca_part = ca_part; f.kw_part = kw_part; f.cw_part = cw_part;
+            f.kw_solve_part = kw_solve;
             f.Gs = g->Gs.p; f.Gm = g->Gm.p; f.XsT = g->XsT.p; f.inv_ell = g->inv_ell.p;
             f.a = g->a; f.mu_best = g->mu_best; f.ucb_h = o.ucb_h; f.acq = o.acq;
             f.ldo = o.ldo;
@@ -674,6 +718,7 @@ static bool eval_small(sls_gp* g, const double* Xs_dev, int M, const EvalOut& o)
     w.matern = g->kernel == SLS_KERNEL_ARD_MATERN52;
     w.a = g->a; w.mu_best = g->mu_best; w.ucb_h = o.ucb_h; w.c1 = 0; w.shrink = 0; w.gtol = 0; w.max_backtracks = 0;
     w.XT = g->XT.p; w.inv_ell = g->inv_ell.p; w.Kinv = g->Kinv.p; w.alpha = g->alpha.p; w.starts = Xs_dev;
+    w.solve_sigma = g->sigma_mode == 1; w.Linv = g->Linv.p; w.U = g->U.p;
     w.x_out = nullptr; w.f_out = nullptr; w.ld = o.ldo;
     w.ev_mu = o.mu; w.ev_sigma = o.sigma; w.ev_dmu = o.dmu; w.ev_dsigma = o.dsigma; w.ev_val = o.val; w.ev_grad = o.grad;
     ProfScope ps(c, "acq_wave");
@@ -851,6 +896,7 @@ static void maximize_impl(sls_gp* g, sls_gp* gs, int acq_type, double ucb_h, con
             w.a = g->a; w.mu_best = g->mu_best; w.ucb_h = ucb_h; w.c1 = o.c1; w.shrink = o.shrink; w.gtol = o.gtol;
             w.max_backtracks = o.max_backtracks;
             w.XT = g->XT.p; w.inv_ell = g->inv_ell.p; w.Kinv = g->Kinv.p; w.alpha = g->alpha.p; w.starts = starts_dev;
+            w.solve_sigma = g->sigma_mode == 1; w.Linv = g->Linv.p; w.U = g->U.p;
             w.x_out = st.x; w.f_out = st.f; w.ld = Sp;
             w.ev_mu = w.ev_sigma = w.ev_dmu = w.ev_dsigma = w.ev_val = w.ev_grad = nullptr;
             // evaluations of starts that were still moving (finished starts run idle to keep the barriers uniform): counted
@@ -1235,6 +1281,7 @@ extern "C" int sls_gp_append_point(sls_gp* g, const double* x, double y_new) {
     launch_mu_data(c->stream, g->y.p, g->alpha.p, g->b, N + 1, g->mu_data.p);
     launch_argmax(c->stream, g->mu_data.p, N + 1, g->scal.p, g->d_idx);
     launch_logdet(c->stream, g->L.p, Np, N + 1, g->scal.p + 1);
+    if (g->sigma_mode == 1) launch_transpose_full(c->stream, g->Linv.p, g->U.p, Np);   // the rank-1 growth does not maintain U
     SLS_HIP(hipMemsetAsync(c->d_info, 0, 64, c->stream));
     gp_fetch_summary(g);
     SLS_REQUIRE(std::isfinite(g->logdet), "sls_gp_append_point: the extended K_y is not positive definite");

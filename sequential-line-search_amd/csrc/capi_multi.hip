@@ -210,6 +210,7 @@ struct sls_multi_gp {
     sls_multi* m = nullptr;
     int D = 0;
     std::vector<sls_gp*> gps;
+    std::vector<char> borrowed;   // gps[r] is the caller's own handle (sls_multi_gp_create_from): not destroyed with the replicas
 };
 
 namespace {
@@ -303,9 +304,47 @@ extern "C" int sls_multi_gp_create(sls_multi* m, const double* X, int D, int N, 
     return SLS_OK;
 }
 
+// Replicas of an EXISTING fitted handle: the shard on the primary's own device (the first one, if the device is listed several
+// times) IS the primary -- its fit is not repeated --, the other shards are fitted from the primary's data (X, y, theta, b, kernel,
+// sigma mode), read back from its device once.  The primary must outlive the replicas and must not be refitted / grown while
+// they are in use (a grown primary needs new replicas).
+extern "C" int sls_multi_gp_create_from(sls_multi* m, sls_gp* primary, sls_multi_gp** out) {
+    if (!m || !primary || !out) { set_error("sls_multi_gp_create_from: NULL argument"); return SLS_ERR_INVALID; }
+    int D = 0, N = 0, kernel = 0, sigma_mode = 0, pdev = 0;
+    double b = 0.0;
+    std::vector<double> X, y, theta;
+    int rc = slsk::gp_export_inputs(primary, &D, &N, &kernel, &sigma_mode, &pdev, &b, &X, &y, &theta);
+    if (rc != SLS_OK) return rc;
+    std::unique_ptr<sls_multi_gp> g(new sls_multi_gp());
+    g->m = m; g->D = D;
+    const int n = (int)m->devices.size();
+    g->gps.assign(n, nullptr);
+    g->borrowed.assign(n, 0);
+    for (int r = 0; r < n; ++r)
+        if (m->devices[r] == pdev) {
+            g->gps[r] = primary;
+            g->borrowed[r] = 1;
+            break;
+        }
+    rc = for_each_shard(n, [&](int r) {
+        if (g->borrowed[r]) return (int)SLS_OK;
+        const int rr = sls_gp_create(m->ctxs[r], X.data(), D, N, y.data(), theta.data(), b, kernel, &g->gps[r]);
+        if (rr != SLS_OK) return rr;
+        return sls_gp_set_sigma_mode(g->gps[r], sigma_mode);
+    });
+    if (rc != SLS_OK) {
+        for (int r = 0; r < n; ++r)
+            if (!g->borrowed[r]) sls_gp_destroy(g->gps[r]);
+        return rc;
+    }
+    *out = g.release();
+    return SLS_OK;
+}
+
 extern "C" int sls_multi_gp_destroy(sls_multi_gp* g) {
     if (!g) return SLS_OK;
     for (size_t r = 0; r < g->gps.size(); ++r) {
+        if (!g->borrowed.empty() && g->borrowed[r]) continue;
         (void)hipSetDevice(g->m->devices[r]);
         sls_gp_destroy(g->gps[r]);
     }

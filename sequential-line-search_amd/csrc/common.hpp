@@ -19,6 +19,9 @@ void set_error(const char* fmt, ...);
 // that its workgroups were not all resident).  The context falls back to the multi-launch schedule for good and the
 // caller repeats the factorisation once; a second failure throws HipFail{SLS_ERR_HIP}.
 bool potrf_gave_up(sls_ctx* c, int abort_flag, int attempt);
+// what a fitted handle was created from (capi_multi.hip: replicas of an existing handle)
+int gp_export_inputs(sls_gp* g, int* D, int* N, int* kernel, int* sigma_mode, int* device, double* b, std::vector<double>* X,
+                     std::vector<double>* y, std::vector<double>* theta);
 
 struct HipFail {
     int code;

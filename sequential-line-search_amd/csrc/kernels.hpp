@@ -142,6 +142,7 @@ struct FinalizeArgs {
     int ntm, split_first;     // candidate tiles of the chunk; first half-split tile of launch_acq_gemm (INT_MAX: none)
     long ldk;                 // candidate leading dimension of this chunk
     const double *mu_part, *ca_part, *kw_part, *cw_part, *Gs, *Gm, *XsT, *inv_ell;
+    const double* kw_solve_part = nullptr;   // solve-based sigma (see WaveArgs::solve_sigma): partial sums of (L^-1 k)^2 from var_gemm
     double a, mu_best, ucb_h;
     int acq;                  // SLS_ACQ_* (used when val/grad requested)
     // outputs (any may be NULL); all candidate-major with leading dimension ldo, offset already applied
@@ -194,6 +195,12 @@ struct WaveArgs {
     double a, mu_best, ucb_h, c1, shrink, gtol;
     int max_backtracks;
     const double *XT, *inv_ell, *Kinv, *alpha, *starts;   // XT [i + d*Np] scaled; starts D x S column-major (raw)
+    // solve_sigma (handles of a PreferenceRegressor, sls_gp_set_sigma_mode): sigma^2 = a - |L^-1 k|^2 and w = L^-T (L^-1 k) as the
+    // reference's k . LLT.solve(k) (src/preference-regressor.cpp:299-313,323-330) instead of the explicit K^-1 of
+    // GaussianProcessRegressor (src/gaussian-process-regressor.cpp:241-255).  Linv = L^-1 (zero above the diagonal), U = Linv^T.
+    int solve_sigma = 0;
+    int stage_ld = 0;                     // filled by the launcher: leading dimension of the staged L^-1 (odd: both passes conflict-free)
+    const double *Linv = nullptr, *U = nullptr;
     double *x_out, *f_out;                // x_out[n + d*ld], f_out[n] = -acq at the end point
     unsigned long long* useful;           // optional: += evaluations of starts that were still moving (the others run idle)
     long ld;
@@ -243,6 +250,7 @@ void potrf_aux_create(PotrfAux* aux, int free_per_xcd);
 void potrf_aux_destroy(PotrfAux* aux);
 // Linv <- L^-1 (lower) given L and the diagonal-block inverses already in Linv; tmp is an Np x Np scratch.
 void launch_trtri(hipStream_t s, const double* L, int Np, double* Linv, double* tmp, double* U);   // U <- (L^-1)^T
+void launch_transpose_full(hipStream_t s, const double* src, double* dst, int Np);   // dst = src^T (Np x Np)
 // diagonal-block inverses only (for potrs / potri on a caller-supplied factor)
 void launch_diag_inverse(hipStream_t s, const double* L, int Np, double* Linv);
 // Kinv <- Linv^T Linv (full symmetric)

@@ -463,6 +463,10 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs p) {
         kw += kt;
         cw += ct;
     }
+    if (p.kw_solve_part) {                            // k . LLT.solve(k) = |L^-1 k|^2 (preference-regressor.cpp:299-313): var_gemm's sums
+        kw = 0.0;
+        for (int t = 0; t < p.nbt; ++t) kw += p.kw_solve_part[(long)(2 * t) * p.ldk + n];
+    }
     const double s2 = p.a - kw;
     const double sigma = s2 < 0.0 ? 0.0 : sqrt(s2);   // gaussian-process-regressor.cpp:253-254
     if (p.mu) p.mu[n] = mu;

@@ -1148,6 +1148,12 @@ __global__ __launch_bounds__(256) void transpose_blocks_kernel(const double* __r
     for (int r = ty; r < 32; r += 8) Dp[(long)(32 * blockIdx.y + tx) + (long)(32 * blockIdx.x + r) * ld] = tile[tx][r];
 }
 
+// dst = src^T for a whole Np x Np matrix (handles with the solve-based sigma read EVERY block of U = (L^-1)^T; trtri leaves the
+// strictly-lower blocks of U unwritten, and the rank-1 growth of sls_gp_append_point does not maintain U at all)
+void launch_transpose_full(hipStream_t s, const double* src, double* dst, int Np) {
+    hipLaunchKernelGGL(transpose_blocks_kernel, dim3(Np / 32, Np / 32, 1), dim3(256), 0, s, src, dst, (long)Np, 0L, 0, 0, 1 << 30);
+}
+
 // Linv (diagonal blocks already inverted) <- full lower-triangular inverse X = L^-1, and U <- X^T (upper triangular), level by
 // level (recursive doubling).  Level with half-size h blocks, pair p = blocks F = [2hp, 2hp+h) | S = [2hp+h, min(2hp+2h, nb)):
 //     W (F x S) = U_FF L_SF^T        (= (L_SF X_FF)^T)         k >= 128 tm

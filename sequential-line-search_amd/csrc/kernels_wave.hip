@@ -26,7 +26,9 @@ namespace slsk {
 // a flat_load -- measured in round 4 (SLS_WAVE_TRACE=1, N = 61): 7.7 us per evaluation in the K^-1 k loop alone.
 // R = Np / 64 rows of the training set per lane, also a template parameter: with a run-time bound the `row r exists` tests of the
 // unrolled per-row code became ~130 scalar branches per eight columns of the K^-1 k loop -- the other 7 of its 7.7 us.
-template <int STAGE, int R>
+// SOLVE: sigma from the Cholesky solve (two triangular passes with L^-1) instead of the explicit K^-1 -- WaveArgs::solve_sigma.
+// With STAGE >= 1 the staged matrix is then L^-1 (leading dimension p.stage_ld, odd, 8 ceil(N / 8) columns).
+template <int STAGE, int R, bool SOLVE>
 __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* smem = reinterpret_cast<double*>(smem_raw);
@@ -55,17 +57,33 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
     // start nothing hides that, and 320 evaluations in sequence took 7 ms (22 us each) at N = 60, D = 32.  Values only move:
     // same bits.
     double* const sharedK = smem + 4L * p.lds_per_wave;
-    double* const sharedX = sharedK + (STAGE >= 1 ? (long)Np * Np : 0L);
-    if (STAGE >= 1)
-        for (int idx = threadIdx.x; idx < Np * Np; idx += 256) sharedK[idx] = p.Kinv[idx];
+    const int ldS = SOLVE ? p.stage_ld : Np, colsS = SOLVE ? ((N + 7) & ~7) : Np;
+    double* const sharedX = sharedK + (STAGE >= 1 ? (long)ldS * colsS : 0L);
+    if (STAGE >= 1) {
+        if (SOLVE) {
+            for (int idx = threadIdx.x; idx < ldS * colsS; idx += 256) {
+                const int i = idx % ldS, j = idx / ldS;
+                sharedK[idx] = i < Np ? p.Linv[i + (long)j * Np] : 0.0;
+            }
+        } else {
+            for (int idx = threadIdx.x; idx < Np * Np; idx += 256) sharedK[idx] = p.Kinv[idx];
+        }
+    }
     if (STAGE >= 2)
         for (int idx = threadIdx.x; idx < Np * D; idx += 256) sharedX[idx] = p.XT[idx];
     if (STAGE >= 1) __syncthreads();
-    const double* __restrict__ KinvG = p.Kinv;
+    const double* __restrict__ KinvG = SOLVE ? p.Linv : p.Kinv;
+    const double* __restrict__ UG = p.U;
     const double* __restrict__ XTG = p.XT;
-    auto kinv_at = [&](long idx) -> double {
-        if constexpr (STAGE >= 1) return sharedK[idx];
-        else return KinvG[idx];
+    // element (i, j) of the first-pass matrix (K^-1, or L^-1 when SOLVE)
+    auto kinv_at = [&](int i, int j) -> double {
+        if constexpr (STAGE >= 1) return sharedK[i + (long)j * ldS];
+        else return KinvG[i + (long)j * Np];
+    };
+    // element (i, j) of L^-T (second pass, SOLVE only): the transposed read of the staged L^-1, or U = (L^-1)^T from global memory
+    auto linvT_at = [&](int i, int j) -> double {
+        if constexpr (STAGE >= 1) return sharedK[j + (long)(i < colsS ? i : colsS - 1) * ldS];
+        else return UG[i + (long)j * Np];
     };
     auto xt_at = [&](long idx) -> double {
         if constexpr (STAGE >= 2) return sharedX[idx];
@@ -147,7 +165,7 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
             for (int u = 0; u < G; ++u) {
                 kj[u] = kb[j0 + u];
 #pragma unroll
-                for (int r = 0; r < R; ++r) cv[u][r] = kinv_at((long)(j0 + u) * Np + lane + 64 * r);
+                for (int r = 0; r < R; ++r) cv[u][r] = kinv_at(lane + 64 * r, j0 + u);
             }
 #pragma unroll
             for (int u = 0; u < G; ++u) {
@@ -156,12 +174,39 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
             }
         }
         double kw = 0.0, cw = 0.0;
+        if constexpr (SOLVE) {
+            // w holds v = L^-1 k: sigma^2 = a - |v|^2 (k . LLT.solve(k)); then w = L^-T v, with v broadcast from LDS
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int i = lane + 64 * r;
+                const double v = i < N ? w[r] : 0.0;
+                kw += v * v;
+                cwb[i] = v;
+                w[r] = 0.0;
+            }
+            __syncthreads();
+            for (int j0 = 0; j0 < N; j0 += G) {       // rows N .. G ceil(N / G) - 1 of L^-1 are identity padding and meet v_j = 0
+                double vj[G], cv[G][R];
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    vj[u] = cwb[j0 + u];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) cv[u][r] = linvT_at(lane + 64 * r, j0 + u);
+                }
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) w[r] += cv[u][r] * vj[u];
+                }
+            }
+            __syncthreads();                          // every lane has read v before c_i w_i overwrites it
+        }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             {
                 const int i = lane + 64 * r;
                 if (i < N) {
-                    kw += kr[r] * w[r];
+                    if constexpr (!SOLVE) kw += kr[r] * w[r];
                     const double t = cr[r] * w[r];
                     cw += t;
                     cwb[i] = t;
@@ -402,7 +447,11 @@ void launch_maximize_wave(hipStream_t s, WaveArgs a) {
     // staging only for launches that leave the chip idle anyway (<= 64 workgroups): with many starts the occupancy is worth more
     const char* senv = getenv("SLS_WAVE_STAGE");
     const bool allow = (senv ? atoi(senv) != 0 : true) && a.S <= 256 && a.n_local > 1;
-    const size_t cap = 160 * 1024, kb = (size_t)a.Np * a.Np * 8, xb = (size_t)a.Np * a.D * 8;
+    // staged first-pass matrix: K^-1 (Np x Np), or for the solve-based sigma L^-1 with an odd leading dimension >= Np + 1 and
+    // 8 ceil(N / 8) columns (both the row-wise first pass and the column-wise second pass are then free of bank conflicts)
+    a.stage_ld = a.solve_sigma ? a.Np + 1 : a.Np;
+    const size_t cap = 160 * 1024, xb = (size_t)a.Np * a.D * 8;
+    const size_t kb = a.solve_sigma ? (size_t)a.stage_ld * ((a.N + 7) & ~7) * 8 : (size_t)a.Np * a.Np * 8;
     a.stage_kinv = allow && bytes + kb <= cap;
     if (a.stage_kinv) bytes += kb;
     a.stage_xt = allow && a.stage_kinv && bytes + xb <= cap;
@@ -410,19 +459,29 @@ void launch_maximize_wave(hipStream_t s, WaveArgs a) {
     // opt in to the CU's whole LDS once per device.  K^-1 only fits the LDS next to the waves' own areas for Np = 128 (R = 2).
     const dim3 grid((a.S + 3) / 4), block(256);
     const int R = a.Np / 64;
-#define SLS_WAVE_LAUNCH(ST, RR)                                                              \
-    do {                                                                                     \
-        ensure_dyn_lds((const void*)maximize_wave_kernel<ST, RR>, 160 * 1024);               \
-        hipLaunchKernelGGL((maximize_wave_kernel<ST, RR>), grid, block, bytes, s, a);        \
+#define SLS_WAVE_LAUNCH(ST, RR, SV)                                                              \
+    do {                                                                                         \
+        ensure_dyn_lds((const void*)maximize_wave_kernel<ST, RR, SV>, 160 * 1024);               \
+        hipLaunchKernelGGL((maximize_wave_kernel<ST, RR, SV>), grid, block, bytes, s, a);        \
     } while (0)
-    if (R == 2 && a.stage_xt) SLS_WAVE_LAUNCH(2, 2);
-    else if (R == 2 && a.stage_kinv) SLS_WAVE_LAUNCH(1, 2);
+    if (a.solve_sigma) {
+        if (R == 2 && a.stage_xt) SLS_WAVE_LAUNCH(2, 2, true);
+        else {
+            if (a.stage_kinv) bytes -= kb;            // (K^-1 alone is not staged in this mode)
+            a.stage_kinv = a.stage_xt = 0;
+            if (R == 2) SLS_WAVE_LAUNCH(0, 2, true);
+            else if (R == 4) SLS_WAVE_LAUNCH(0, 4, true);
+            else if (R == 6) SLS_WAVE_LAUNCH(0, 6, true);
+            else SLS_WAVE_LAUNCH(0, 8, true);
+        }
+    } else if (R == 2 && a.stage_xt) SLS_WAVE_LAUNCH(2, 2, false);
+    else if (R == 2 && a.stage_kinv) SLS_WAVE_LAUNCH(1, 2, false);
     else {
         a.stage_kinv = a.stage_xt = 0;
-        if (R == 2) SLS_WAVE_LAUNCH(0, 2);
-        else if (R == 4) SLS_WAVE_LAUNCH(0, 4);
-        else if (R == 6) SLS_WAVE_LAUNCH(0, 6);
-        else SLS_WAVE_LAUNCH(0, 8);
+        if (R == 2) SLS_WAVE_LAUNCH(0, 2, false);
+        else if (R == 4) SLS_WAVE_LAUNCH(0, 4, false);
+        else if (R == 6) SLS_WAVE_LAUNCH(0, 6, false);
+        else SLS_WAVE_LAUNCH(0, 8, false);
     }
 #undef SLS_WAVE_LAUNCH
 }

@@ -148,17 +148,14 @@ namespace sequential_line_search
         VectorXd x(starts.rows());
         double   v   = 0.0;
         long     idx = 0;
-        if (device::Multi() != nullptr)
+        // several GPUs configured (device::SetDevices / $SLS_DEVICES): the iterations of the reference's parallel multi-start
+        // loop (:125-141) share only the const regressor, so the start set is split over the devices, each holding a replica of
+        // the fitted state, and the per-device winners meet in ONE ncclAllGather.  The replicas belong to the regressor's device
+        // handle: they are built on the first call (the shard on the primary's device IS the primary: no second fit there) and
+        // reused by every later one.
+        if (std::shared_ptr<device::MultiGpHandle> replicas = device::ReplicasFor(RequireHandle(regressor), regressor.GetLargeX().cols()))
         {
-            // several GPUs configured (device::SetDevices / $SLS_DEVICES): the iterations of the reference's parallel
-            // multi-start loop (:125-141) share only the const regressor, so the start set is split over the devices, each
-            // holding a replica of the fitted state, and the per-device winners meet in ONE ncclAllGather.
-            RequireHandle(regressor);
-            const int kernel = regressor.GetKernelType() == KernelType::ArdSquaredExponentialKernel ? SLS_KERNEL_ARD_SQUARED_EXPONENTIAL
-                                                                                                    : SLS_KERNEL_ARD_MATERN52;
-            device::MultiGpHandle replicas(regressor.GetLargeX(), regressor.GetSmallY(), regressor.GetKernelHyperparams(),
-                                           regressor.GetNoiseHyperparam(), kernel);
-            device::Check(sls_multi_acq_maximize(replicas.h, AcqId(func_type), hyperparam, starts.data(),
+            device::Check(sls_multi_acq_maximize(replicas->h, AcqId(func_type), hyperparam, starts.data(),
                                                  static_cast<int>(starts.cols()), static_cast<int>(num_local_search_iters), nullptr,
                                                  x.data(), &v, &idx, nullptr),
                           "sls_multi_acq_maximize");

@@ -2,6 +2,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <map>
 #include <mutex>
 
 namespace sequential_line_search
@@ -31,8 +32,17 @@ namespace sequential_line_search
             std::mutex        g_multi_mtx;
             std::vector<int>  g_devices;
             bool              g_devices_set = false;
-            sls_multi*        g_multi       = nullptr;
-            std::vector<int>  g_multi_devices;
+            std::shared_ptr<MultiRef> g_multi;
+            std::vector<int>          g_multi_devices;
+            struct ReplicaEntry
+            {
+                std::shared_ptr<MultiGpHandle> replicas;
+                std::shared_ptr<MultiRef>      multi;
+                long                           n_points = 0;
+            };
+            std::mutex                       g_replica_mtx;
+            std::map<sls_gp*, ReplicaEntry>  g_replicas;
+            long                             g_replica_builds = 0;
 
             void LoadDevicesFromEnv()
             {
@@ -76,32 +86,56 @@ namespace sequential_line_search
             return g_devices;
         }
 
-        sls_multi* Multi()
+        MultiRef::~MultiRef() { sls_multi_destroy(m); }
+
+        std::shared_ptr<MultiRef> Multi()
         {
             std::lock_guard<std::mutex> lock(g_multi_mtx);
             LoadDevicesFromEnv();
             if (g_devices.size() < 2) return nullptr;
-            if (g_multi && g_multi_devices != g_devices)
-            {
-                sls_multi_destroy(g_multi);
-                g_multi = nullptr;
-            }
+            if (g_multi && g_multi_devices != g_devices) g_multi.reset();   // the old one lives on while handles still use it
             if (!g_multi)
             {
-                Check(sls_multi_create(g_devices.data(), static_cast<int>(g_devices.size()), &g_multi), "sls_multi_create");
+                sls_multi* m = nullptr;
+                Check(sls_multi_create(g_devices.data(), static_cast<int>(g_devices.size()), &m), "sls_multi_create");
+                g_multi         = std::make_shared<MultiRef>(m);
                 g_multi_devices = g_devices;
             }
             return g_multi;
         }
 
-        MultiGpHandle::MultiGpHandle(const Eigen::MatrixXd& X, const Eigen::VectorXd& y, const Eigen::VectorXd& theta, double b,
-                                     int kernel)
+        MultiGpHandle::MultiGpHandle(std::shared_ptr<MultiRef> multi_, sls_gp* primary) : multi(std::move(multi_))
         {
-            Check(sls_multi_gp_create(Multi(), X.data(), static_cast<int>(X.rows()), static_cast<int>(X.cols()), y.data(), theta.data(),
-                                      b, kernel, &h),
-                  "sls_multi_gp_create");
+            Check(sls_multi_gp_create_from(multi->m, primary, &h), "sls_multi_gp_create_from");
         }
         MultiGpHandle::~MultiGpHandle() { sls_multi_gp_destroy(h); }
+
+        std::shared_ptr<MultiGpHandle> ReplicasFor(sls_gp* primary, long n_points)
+        {
+            std::shared_ptr<MultiRef> multi = Multi();
+            if (!multi || !primary) return nullptr;
+            std::lock_guard<std::mutex> lock(g_replica_mtx);
+            ReplicaEntry& e = g_replicas[primary];
+            if (!e.replicas || e.multi != multi || e.n_points != n_points)
+            {
+                e.replicas.reset();
+                e.replicas = std::make_shared<MultiGpHandle>(multi, primary);
+                e.multi    = multi;
+                e.n_points = n_points;
+                ++g_replica_builds;
+            }
+            return e.replicas;
+        }
+        void ForgetReplicas(sls_gp* primary)
+        {
+            std::lock_guard<std::mutex> lock(g_replica_mtx);
+            g_replicas.erase(primary);
+        }
+        long ReplicaBuilds()
+        {
+            std::lock_guard<std::mutex> lock(g_replica_mtx);
+            return g_replica_builds;
+        }
 
         GpHandle::GpHandle(const Eigen::MatrixXd& X, const Eigen::VectorXd& y, const Eigen::VectorXd& theta, double b, int kernel)
         {
@@ -109,7 +143,11 @@ namespace sequential_line_search
                                 kernel, &h),
                   "sls_gp_create");
         }
-        GpHandle::~GpHandle() { sls_gp_destroy(h); }
+        GpHandle::~GpHandle()
+        {
+            ForgetReplicas(h);   // the replicas borrow this handle as one of their shards: they go first
+            sls_gp_destroy(h);
+        }
 
         NllHandle::NllHandle(const Eigen::MatrixXd& X, int kernel)
         {
@@ -118,9 +156,9 @@ namespace sequential_line_search
         }
         NllHandle::~NllHandle() { sls_nll_destroy(h); }
 
-        MultiNllHandle::MultiNllHandle(const Eigen::MatrixXd& X, int kernel)
+        MultiNllHandle::MultiNllHandle(const Eigen::MatrixXd& X, int kernel) : multi(Multi())
         {
-            Check(sls_multi_nll_create(Multi(), X.data(), static_cast<int>(X.rows()), static_cast<int>(X.cols()), kernel, &h),
+            Check(sls_multi_nll_create(multi->m, X.data(), static_cast<int>(X.rows()), static_cast<int>(X.cols()), kernel, &h),
                   "sls_multi_nll_create");
         }
         MultiNllHandle::~MultiNllHandle() { sls_multi_nll_destroy(h); }

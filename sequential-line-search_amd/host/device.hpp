@@ -5,6 +5,7 @@
 #include <sequential-line-search/device.hpp>
 #include <sequential-line-search/eigen-lite.hpp>
 #include <functional>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -21,17 +22,36 @@ namespace sequential_line_search
         sls_ctx* Context();
 
         // SetDevices / Devices: public, include/sequential-line-search/device.hpp
-        /// The process-wide multi-device handle for Devices() (nullptr when only one device is configured).
-        sls_multi* Multi();
+        /// The process-wide multi-device handle for Devices(), shared: a reconfiguration (SetDevices) lets go of it, but it lives
+        /// on until the last handle built on it has gone (another thread may be in the middle of a call).
+        struct MultiRef
+        {
+            sls_multi* m = nullptr;
+            explicit MultiRef(sls_multi* m_) : m(m_) {}
+            ~MultiRef();
+            MultiRef(const MultiRef&)            = delete;
+            MultiRef& operator=(const MultiRef&) = delete;
+        };
+        /// nullptr when only one device is configured.
+        std::shared_ptr<MultiRef> Multi();
 
         struct MultiGpHandle
         {
-            sls_multi_gp* h = nullptr;
-            MultiGpHandle(const Eigen::MatrixXd& X, const Eigen::VectorXd& y, const Eigen::VectorXd& theta, double b, int kernel);
+            std::shared_ptr<MultiRef> multi;   // keeps the communicators alive
+            sls_multi_gp*             h = nullptr;
+            /// replicas of a fitted handle: the shard on the primary's device is the primary itself (sls_multi_gp_create_from)
+            MultiGpHandle(std::shared_ptr<MultiRef> multi, sls_gp* primary);
             ~MultiGpHandle();
             MultiGpHandle(const MultiGpHandle&)            = delete;
             MultiGpHandle& operator=(const MultiGpHandle&) = delete;
         };
+        /// The replicas of `primary` on the configured devices, created on first use and kept until the primary handle dies
+        /// (GpHandle's destructor), the device configuration changes or the primary has grown (n_points differs): a second
+        /// FindNextPoint on the same regressor fits nothing.  nullptr when only one device is configured.
+        std::shared_ptr<MultiGpHandle> ReplicasFor(sls_gp* primary, long n_points);
+        void                           ForgetReplicas(sls_gp* primary);
+        /// how many times replicas were built (tests: "zero sls_gp_create on the second call")
+        long ReplicaBuilds();
 
         struct GpHandle
         {
@@ -46,7 +66,8 @@ namespace sequential_line_search
         /// dealt round-robin over them (sls_multi_gp_nll_batch).
         struct MultiNllHandle
         {
-            sls_multi_nll* h = nullptr;
+            std::shared_ptr<MultiRef> multi;
+            sls_multi_nll*            h = nullptr;
             MultiNllHandle(const Eigen::MatrixXd& X, int kernel);
             ~MultiNllHandle();
             MultiNllHandle(const MultiNllHandle&)            = delete;

@@ -47,6 +47,9 @@ namespace sequential_line_search
 
         // final K, its Cholesky factor and the predictive state live on the device; the public members are copies
         m_handle = std::make_shared<device::GpHandle>(m_X, m_y, m_kernel_hyperparams, m_noise_hyperparam, KernelId(m_kernel_type));
+        // PredictSigma / PredictSigmaDerivative of this class solve with the Cholesky factor (:299-313, :323-330); the explicit
+        // inverse is GaussianProcessRegressor's formula
+        device::Check(sls_gp_set_sigma_mode(m_handle->h, SLS_SIGMA_CHOLESKY_SOLVE), "sls_gp_set_sigma_mode");
         const long M = m_X.cols();
         m_K          = MatrixXd(M, M);
         MatrixXd L(M, M);

@@ -44,7 +44,8 @@ def test_bench_line_contract_and_two_rank_merge():
     assert abs(one["value"] - c["evals_issued_per_step"] / (one["ms_per_step"] * 1e-3)) < 1e-6 * one["value"]
     for name, st in one["stage_rooflines"].items():          # a fraction above 1 is an accounting error, not evidence
         assert 0 < st["frac"] < 1, (name, st)
-    assert "fit_pipeline" in one["stage_rooflines"] and "traffic_source" in r
+    assert "fit_pipeline" in one["stage_rooflines"] and r["traffic"] is None and "traffic_reference" in r
+    assert one["potrf_fallbacks"] == 0
 
     two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                "127.0.0.1", "--master-port", "29617", "bench.py", "--gpus", "2", "--backend", "gloo", "--same-device"] + SMALL)

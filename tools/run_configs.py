@@ -9,6 +9,9 @@ from oracle import oracle_py as oracle
 m = sls(); ctx = m.Context(0)
 BIN = os.path.join(R, "sequential-line-search_amd", "bin")
 out = {}
+T_START = time.perf_counter()
+def stamp(what):
+    print(f"[run_configs] {what}: {time.perf_counter() - T_START:.1f} s since start", file=sys.stderr, flush=True)
 
 def wall(f, reps=3):
     f(); ctx.synchronize()
@@ -23,6 +26,7 @@ p = subprocess.run([os.path.join(BIN, "bayesian_optimization_1d"), "1", "20", "1
 mm = re.search(r"maximizer ([-\d.e]+) maximum ([-\d.e]+)", p.stdout)
 out["C1_bayesian_optimization_1d_20_iterations"] = {"wall_s": time.perf_counter() - t0, "maximizer": float(mm.group(1)), "maximum": float(mm.group(2)),
                                                     "true_optimum": [0.852733, 2.273928]}
+stamp("C1 done")
 # C2: N=2048, D=16, ARD-SE: Gram + Cholesky (+ inverse, alpha) + 4096-point predict
 D, N, M = 16, 2048, 4096
 X, y, theta, b = synth_problem(oracle, D, N); Xs = synth_candidates(oracle, D, M)
@@ -37,6 +41,7 @@ t0 = time.perf_counter(); ref = oracle.Regressor(X, y, theta, b, kernel=0); t1 =
 out["C2_gp_fit_predict_N2048_D16_M4096"]["cpu_oracle_fit_s"] = t1 - t0
 out["C2_gp_fit_predict_N2048_D16_M4096"]["cpu_oracle_predict_s"] = t2 - t1
 gp.close()
+stamp("C2 done")
 # C3: sequential_line_search_nd D=32, 30 iterations (PreferenceRegressor MAP + EI acquisition per step)
 p = subprocess.run([os.path.join(BIN, "sequential_line_search_nd"), "32", "30", "1"], capture_output=True, text=True)
 ms = [float(v) for v in re.findall(r" ms ([-\d.e]+)", p.stdout)]
@@ -46,6 +51,7 @@ out["C3_sequential_line_search_nd_D32_30_iterations"] = {"ms_per_submit_mean": f
                                                          "ms_per_submit_mean_without_first": float(np.mean(ms[1:])), "ms_per_submit_median": float(np.median(ms)),
                                                          "ms_per_submit_last": ms[-1],
                                                          "residual_first": res[0], "residual_last": res[-1]}
+stamp("C3 done")
 # C5: Matern-5/2 MAP objective + gradient, N=4096, D=128
 D, N = 128, 4096
 X, y, theta, b = synth_problem(oracle, D, N)
@@ -71,6 +77,7 @@ out["C5_map_objective_gradient_N4096_D128"] = {"ms_per_evaluation": ms_c5,
                                                "value_only_batch_speedup": ms_s8 / ms_b8,
                                                "map_eval_roofline": {"bound": "mfma", "flops": flops_c5, "achieved_TFLOPs": flops_c5 / (ms_c5 * 1e-3) / 1e12,
                                                                      "peak_TFLOPs": 78.6, "frac": flops_c5 / (ms_c5 * 1e-3) / 1e12 / 78.6}}
+stamp("C5 device done")
 # ---- CPU legs (the oracle, timed on this host): what the reference's CPU path costs in the SAME operating regime -------------
 # Never credit: context for the small configurations, where a CPU factorisation takes microseconds and the GPU path is launch- /
 # start-up-bound.  The oracle is called through ctypes (~3-5 us per call, included); thread count stated per leg.
@@ -104,6 +111,7 @@ out["C1_bayesian_optimization_1d_20_iterations"]["cpu_oracle_wall_s"] = c1
 out["C1_bayesian_optimization_1d_20_iterations"]["cpu_oracle_note"] = ("sum over 20 iterations of 300 + 100 MAP-objective evaluations, the fit, 50 EI values "
     "and 10 EI value+gradient evaluations at that iteration's N, oracle (hoisted), 1 thread, ctypes call overhead included")
 out["C1_bayesian_optimization_1d_20_iterations"]["process_start_floor_note"] = "a HIP process that launches one trivial kernel takes 0.19-0.26 s on the same box (tools/probes/hip_startup.hip): C1's GPU wall time is process start"
+stamp("CPU leg C1 done")
 # C3: per submit at N = 3, 5, .., 61 (D = 32): 100 preference-objective evaluations (value + gradient; the oracle refactors K per
 # call, the reference caches it for use_map_hyperparams = false: an upper bound), the fit, 50 D = 1600 EI values (DIRECT) and
 # 10 D = 320 EI value + gradient evaluations (L-BFGS)
@@ -124,11 +132,13 @@ out["C3_sequential_line_search_nd_D32_30_iterations"]["cpu_oracle_ms_per_submit_
 out["C3_sequential_line_search_nd_D32_30_iterations"]["cpu_oracle_ms_per_submit_last"] = c3[-1]
 out["C3_sequential_line_search_nd_D32_30_iterations"]["cpu_oracle_note"] = ("per submit: 100 preference-objective evaluations + fit + 1600 EI values + 320 EI "
     f"value+gradient evaluations at N = 3 .. 61, oracle (hoisted predictor), 1 thread of {cores} cores")
+stamp("CPU leg C3 done")
 # C5: ONE hoisted MAP objective + gradient evaluation at N = 4096, D = 128
 omp_threads(int(os.environ.get("OMP_NUM_THREADS", "64")))
 t0 = time.perf_counter(); oracle.gp_map_objective(1, X, y, x, want_grad=True); t_c5 = time.perf_counter() - t0
 out["C5_map_objective_gradient_N4096_D128"]["cpu_oracle_s_per_evaluation"] = t_c5
 out["C5_map_objective_gradient_N4096_D128"]["cpu_oracle_note"] = f"oracle slso_gp_map_objective (hoisted), OMP threads {os.environ.get('OMP_NUM_THREADS')} of {cores} cores"
+stamp("CPU leg C5 done")
 # crossover: smallest N (D = 32, Matern) at which ONE fit + 4096-point predict is faster on the device than in the oracle
 cross = None
 for n in (32, 64, 128, 256, 512):
