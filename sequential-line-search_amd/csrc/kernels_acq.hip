@@ -201,8 +201,7 @@ int launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk,
     // 112 GB (0.795: each group of 8 x 4 tiles shares 12 panels); ungated 124.9 ms / 333 GB (0.42).
     const char* eph = getenv("SLS_GATE_PHASE");
     const int phase = eph ? atoi(eph) : 2000;
-    const char* epr = getenv("SLS_ACQ_PRIO");
-    const int prio = epr ? atoi(epr) : 0;
+    const int prio = 0;   // (wave priority for one of a CU's two workgroups was a switch in rounds 2-3: no measurable effect, removed)
     // persistent, generation-gated form when there are at least two generations of tiles (MI355X: 256 CUs x 2 = 512 slots)
     // SLS_ACQ_WG_PER_CU (default 1): one workgroup per CU (a 96 KB LDS request keeps a second one out).  One wave per SIMD has
     // the MFMA pipe to itself -- two waves alternating on it lose ~3 % to the switches (gemm_probe_ring, 16384 x 8192 x 8192:

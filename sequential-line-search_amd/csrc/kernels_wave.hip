@@ -27,7 +27,10 @@ namespace slsk {
 // R = Np / 64 rows of the training set per lane, also a template parameter: with a run-time bound the `row r exists` tests of the
 // unrolled per-row code became ~130 scalar branches per eight columns of the K^-1 k loop -- the other 7 of its 7.7 us.
 // SOLVE: sigma from the Cholesky solve (two triangular passes with L^-1) instead of the explicit K^-1 -- WaveArgs::solve_sigma.
-// With STAGE >= 1 the staged matrix is then L^-1 (leading dimension p.stage_ld, odd, 8 ceil(N / 8) columns).
+// With STAGE >= 1 the staged matrix is then the SYMMETRIC image S = L^-1 (lower triangle) + L^-T (upper triangle): the first pass
+// v = L^-1 k reads S(i, j) for j <= i, the second w = L^-T v reads S(i, j) for j >= i -- both with lanes over i, i.e. the
+// conflict-free access of the K^-1 loop, and one matrix in LDS instead of two.
+// R = 1 serves N <= 64 (Np = 128, but no lane's second row exists): half the loads of every pass.
 template <int STAGE, int R, bool SOLVE>
 __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -57,37 +60,46 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
     // start nothing hides that, and 320 evaluations in sequence took 7 ms (22 us each) at N = 60, D = 32.  Values only move:
     // same bits.
     double* const sharedK = smem + 4L * p.lds_per_wave;
-    const int ldS = SOLVE ? p.stage_ld : Np, colsS = SOLVE ? ((N + 7) & ~7) : Np;
+    const int ldS = Np, colsS = p.stage_cols;
     double* const sharedX = sharedK + (STAGE >= 1 ? (long)ldS * colsS : 0L);
     if (STAGE >= 1) {
         if (SOLVE) {
             for (int idx = threadIdx.x; idx < ldS * colsS; idx += 256) {
                 const int i = idx % ldS, j = idx / ldS;
-                sharedK[idx] = i < Np ? p.Linv[i + (long)j * Np] : 0.0;
+                sharedK[idx] = i >= j ? p.Linv[i + (long)j * Np] : p.U[i + (long)j * Np];   // U = (L^-1)^T, every block kept
             }
         } else {
-            for (int idx = threadIdx.x; idx < Np * Np; idx += 256) sharedK[idx] = p.Kinv[idx];
+            for (int idx = threadIdx.x; idx < ldS * colsS; idx += 256) sharedK[idx] = p.Kinv[idx];
         }
     }
     if (STAGE >= 2)
-        for (int idx = threadIdx.x; idx < Np * D; idx += 256) sharedX[idx] = p.XT[idx];
+        // leading dimension Np + 1 (odd): the kernel-vector loop reads XT with lanes over the ROWS i (stride 1), the gradient loop
+        // with lanes over the DIMENSIONS d -- with the global layout's stride of Np = 128 doubles every lane of that second loop
+        // hit the same LDS bank (a 32-way conflict per read: ~2 of the 2.7 us its N-long loop took at D = 32)
+        for (int idx = threadIdx.x; idx < Np * D; idx += 256) sharedX[(idx % Np) + (long)(idx / Np) * (Np + 1)] = p.XT[idx];
     if (STAGE >= 1) __syncthreads();
     const double* __restrict__ KinvG = SOLVE ? p.Linv : p.Kinv;
     const double* __restrict__ UG = p.U;
     const double* __restrict__ XTG = p.XT;
     // element (i, j) of the first-pass matrix (K^-1, or L^-1 when SOLVE)
     auto kinv_at = [&](int i, int j) -> double {
-        if constexpr (STAGE >= 1) return sharedK[i + (long)j * ldS];
+        if constexpr (STAGE >= 1 && SOLVE) {
+            const double x = sharedK[i + (long)j * ldS];   // unconditional LDS read, then a select (a predicated read costs an exec-mask round trip each)
+            return j <= i ? x : 0.0;
+        }
+        else if constexpr (STAGE >= 1) return sharedK[i + (long)j * ldS];
         else return KinvG[i + (long)j * Np];
     };
     // element (i, j) of L^-T (second pass, SOLVE only): the transposed read of the staged L^-1, or U = (L^-1)^T from global memory
     auto linvT_at = [&](int i, int j) -> double {
-        if constexpr (STAGE >= 1) return sharedK[j + (long)(i < colsS ? i : colsS - 1) * ldS];
-        else return UG[i + (long)j * Np];
+        if constexpr (STAGE >= 1) {
+            const double x = sharedK[i + (long)j * ldS];
+            return j >= i ? x : 0.0;
+        } else return UG[i + (long)j * Np];
     };
-    auto xt_at = [&](long idx) -> double {
-        if constexpr (STAGE >= 2) return sharedX[idx];
-        else return XTG[idx];
+    auto xt_at = [&](int i, int d) -> double {
+        if constexpr (STAGE >= 2) return sharedX[i + (long)d * (Np + 1)];
+        else return XTG[i + (long)d * Np];
     };
 
     // per-lane constants of every evaluation, read once: 1 / l_d of this lane's dimensions, alpha_i of its rows
@@ -122,7 +134,7 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
                             xv[u] = xs[d + u];
-                            tv[u] = xt_at(i + (long)(d + u) * Np);
+                            tv[u] = xt_at(i, d + u);
                         }
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
@@ -131,7 +143,7 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
                         }
                     }
                     for (; d < D; ++d) {
-                        const double df = xs[d] - xt_at(i + (long)d * Np);
+                        const double df = xs[d] - xt_at(i, d);
                         q += df * df;
                     }
                     if (p.matern) {
@@ -157,8 +169,8 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
 #pragma unroll
         for (int r = 0; r < R; ++r) w[r] = 0.0;
         // G columns in flight, G R = 16 (12 for R = 6) loads per lane.  Columns N .. G ceil(N / G) - 1 exist (identity padding of
-        // K^-1, Np is a multiple of 128) and meet k_j = 0 there
-        constexpr int G = R <= 2 ? 8 : (R <= 4 ? 4 : 2);
+        // K^-1, Np is a multiple of 128; the staged copy holds 16 ceil(N / 16) columns) and meet k_j = 0 there
+        constexpr int G = R <= 1 ? 16 : (R <= 2 ? 8 : (R <= 4 ? 4 : 2));
         for (int j0 = 0; j0 < N; j0 += G) {
             double kj[G], cv[G][R];
 #pragma unroll
@@ -230,13 +242,12 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
             const int d = lane + 64 * e;
             if (d < D) {
                 double gm = 0.0, gs = 0.0;
-                const long xrow = (long)d * Np;
                 int i = 0;
                 for (; i + 8 <= N; i += 8) {
                     double xv[8], av[8], wv[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        xv[u] = xt_at(xrow + i + u);
+                        xv[u] = xt_at(i + u, d);
                         av[u] = cab[i + u];
                         wv[u] = cwb[i + u];
                     }
@@ -247,7 +258,7 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
                     }
                 }
                 for (; i < N; ++i) {
-                    const double xi = xt_at(xrow + i);
+                    const double xi = xt_at(i, d);
                     gm += xi * cab[i];
                     gs += xi * cwb[i];
                 }
@@ -447,42 +458,44 @@ void launch_maximize_wave(hipStream_t s, WaveArgs a) {
     // staging only for launches that leave the chip idle anyway (<= 64 workgroups): with many starts the occupancy is worth more
     const char* senv = getenv("SLS_WAVE_STAGE");
     const bool allow = (senv ? atoi(senv) != 0 : true) && a.S <= 256 && a.n_local > 1;
-    // staged first-pass matrix: K^-1 (Np x Np), or for the solve-based sigma L^-1 with an odd leading dimension >= Np + 1 and
-    // 8 ceil(N / 8) columns (both the row-wise first pass and the column-wise second pass are then free of bank conflicts)
-    a.stage_ld = a.solve_sigma ? a.Np + 1 : a.Np;
-    const size_t cap = 160 * 1024, xb = (size_t)a.Np * a.D * 8;
-    const size_t kb = a.solve_sigma ? (size_t)a.stage_ld * ((a.N + 7) & ~7) * 8 : (size_t)a.Np * a.Np * 8;
+    // staged first-pass matrix: 16 ceil(N / 16) columns of K^-1, or of the symmetric image of L^-1 / L^-T (solve-based sigma)
+    a.stage_ld = a.Np;
+    a.stage_cols = std::min(a.Np, (a.N + 15) & ~15);
+    const size_t cap = 160 * 1024, xb = (size_t)(a.Np + 1) * a.D * 8;
+    const size_t kb = (size_t)a.Np * a.stage_cols * 8;
     a.stage_kinv = allow && bytes + kb <= cap;
     if (a.stage_kinv) bytes += kb;
     a.stage_xt = allow && a.stage_kinv && bytes + xb <= cap;
     if (a.stage_xt) bytes += xb;
-    // opt in to the CU's whole LDS once per device.  K^-1 only fits the LDS next to the waves' own areas for Np = 128 (R = 2).
+    // opt in to the CU's whole LDS once per device.  The staged forms exist for Np = 128 only (R <= 2).
     const dim3 grid((a.S + 3) / 4), block(256);
-    const int R = a.Np / 64;
+    const int R = a.N <= 64 ? 1 : a.Np / 64;
 #define SLS_WAVE_LAUNCH(ST, RR, SV)                                                              \
     do {                                                                                         \
         ensure_dyn_lds((const void*)maximize_wave_kernel<ST, RR, SV>, 160 * 1024);               \
         hipLaunchKernelGGL((maximize_wave_kernel<ST, RR, SV>), grid, block, bytes, s, a);        \
     } while (0)
-    if (a.solve_sigma) {
-        if (R == 2 && a.stage_xt) SLS_WAVE_LAUNCH(2, 2, true);
-        else {
-            if (a.stage_kinv) bytes -= kb;            // (K^-1 alone is not staged in this mode)
-            a.stage_kinv = a.stage_xt = 0;
-            if (R == 2) SLS_WAVE_LAUNCH(0, 2, true);
-            else if (R == 4) SLS_WAVE_LAUNCH(0, 4, true);
-            else if (R == 6) SLS_WAVE_LAUNCH(0, 6, true);
-            else SLS_WAVE_LAUNCH(0, 8, true);
-        }
-    } else if (R == 2 && a.stage_xt) SLS_WAVE_LAUNCH(2, 2, false);
-    else if (R == 2 && a.stage_kinv) SLS_WAVE_LAUNCH(1, 2, false);
-    else {
+#define SLS_WAVE_BY_MODE(ST, RR)                                  \
+    do {                                                          \
+        if (a.solve_sigma) SLS_WAVE_LAUNCH(ST, RR, true);         \
+        else SLS_WAVE_LAUNCH(ST, RR, false);                      \
+    } while (0)
+    if (R <= 2 && a.stage_xt) {
+        if (R == 1) SLS_WAVE_BY_MODE(2, 1);
+        else SLS_WAVE_BY_MODE(2, 2);
+    } else if (R <= 2 && a.stage_kinv && !a.solve_sigma) {
+        if (R == 1) SLS_WAVE_LAUNCH(1, 1, false);
+        else SLS_WAVE_LAUNCH(1, 2, false);
+    } else {
+        if (a.stage_kinv) bytes -= kb;                // (the first-pass matrix alone is not staged in the solve mode)
         a.stage_kinv = a.stage_xt = 0;
-        if (R == 2) SLS_WAVE_LAUNCH(0, 2, false);
-        else if (R == 4) SLS_WAVE_LAUNCH(0, 4, false);
-        else if (R == 6) SLS_WAVE_LAUNCH(0, 6, false);
-        else SLS_WAVE_LAUNCH(0, 8, false);
+        if (R == 1) SLS_WAVE_BY_MODE(0, 1);
+        else if (R == 2) SLS_WAVE_BY_MODE(0, 2);
+        else if (R == 4) SLS_WAVE_BY_MODE(0, 4);
+        else if (R == 6) SLS_WAVE_BY_MODE(0, 6);
+        else SLS_WAVE_BY_MODE(0, 8);
     }
+#undef SLS_WAVE_BY_MODE
 #undef SLS_WAVE_LAUNCH
 }
 

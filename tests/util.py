@@ -17,6 +17,21 @@ def synth_problem(oracle, D, N, seed=1234, lengthscale=None):
     return X, y, theta, 0.005
 
 
+def synth_clustered_ard_problem(oracle, D, N, seed=1234):
+    """Data whose MAP hyper-parameters are determined by the data AND reachable by the reference's procedure (DIRECT(300), then a
+    local search from the better of DIRECT's point and the prior medians): the design points sit in a small cube around 0.4 (edge
+    0.1, as late in an optimisation run), so that at the prior's length scale 0.5 the Gram matrix has strong off-diagonal structure
+    (uniform points in [0, 1]^128 are ~4.6 apart: K_y is numerically diagonal there, the likelihood gradient vanishes and every fit
+    ends in the all-noise optimum on the prior's mode, whatever the target).  Every fourth coordinate matters.  A CPU run of the
+    same construction (N = 300, D = 16, L-BFGS-B on the oracle's objective from the prior medians) ends at length scales 0.08
+    (relevant) / 1.5 (irrelevant), a = 0.02, b = 1.5e-5."""
+    X = 0.4 + 0.1 * (oracle.fill_uniform(D * N, seed).reshape((D, N), order="F") - 0.5)
+    rel = np.arange(D) % 4 == 0
+    beta = 1.0 / (rel.sum() * 0.1 ** 2 / 12.0)
+    y = np.exp(-beta * np.sum((X[rel] - 0.4) ** 2, axis=0)) + 0.01 * oracle.fill_normal(N, seed + 1)
+    return X, y, rel
+
+
 def synth_problem_with_signal(oracle, D, N, seed=1234, ard=False):
     """SURVEY 8(d)'s recipe with a target that keeps its signal at the headline dimensions: at D = 64 the recipe's
     exp(-|x - 0.4|^2) is ~2.5e-3 under 1e-2 noise (6e-6 at D = 128) -- the posterior is flat, the maximiser a box corner and a

@@ -1,0 +1,17 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r04
+timeout 900 python -m pytest tests/test_gpu_map_fit.py::test_c5_full_map_fit_with_signal tests/test_gpu_budgets.py tests/test_gpu_host_cpp.py "tests/test_gpu_parity.py" -q -k "signal or budget or host or preference_handles or wave or small" 2>&1 | tail -8
+B=sequential-line-search_amd/bin
+for i in 1 2 3; do SLS_HOST_TIMING=1 $B/sequential_line_search_nd 32 30 1 > gpurun_out/r04/c3_run$i.log 2>&1; done
+python - <<'PY'
+import re,statistics
+for f in ("c3_run1","c3_run2","c3_run3"):
+    t=open(f"gpurun_out/r04/{f}.log").read()
+    ms=[float(v) for v in re.findall(r" ms ([-\d.e]+)",t)]
+    fit=[float(v) for v in re.findall(r"MAP fit ([\d.]+) ms",t)]; nx=[float(v) for v in re.findall(r"next point ([\d.]+) ms",t)]
+    loc=[float(v) for v in re.findall(r"local phase ([\d.]+) ms",t)]
+    print(f,"mean w/o first",statistics.mean(ms[1:]),"median",statistics.median(ms),"max",max(ms[1:]),"map fit mean",statistics.mean(fit[1:]),"next point mean",statistics.mean(nx[1:]),"local phase mean",statistics.mean(loc[1:]))
+PY
+SLS_MAP_TRACE=1 SLS_WAVE_TRACE=1 SLS_HOST_TIMING=1 $B/sequential_line_search_nd 32 30 1 > gpurun_out/r04/c3_trace.log 2>&1; grep "wave trace" gpurun_out/r04/c3_trace.log | tail -5
+grep "wave trace" gpurun_out/r04/c3_trace.log | awk '{n+=1; ev+=$10} END {print "local-phase calls", n, "evaluations", ev}'

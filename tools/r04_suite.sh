@@ -15,3 +15,5 @@ for f in ("c3_run1","c3_run2"):
     print(f,"mean w/o first",statistics.mean(ms[1:]),"median",statistics.median(ms),"max",max(ms[1:]),"map fit mean",statistics.mean(fit[1:]),"next point mean",statistics.mean(nx[1:]))
 PY
 python tools/time_wave_path.py 2>&1 | tee gpurun_out/r04/time_wave_path.log
+SLS_MAP_TRACE=1 SLS_WAVE_TRACE=1 SLS_HOST_TIMING=1 $B/sequential_line_search_nd 32 30 1 > gpurun_out/r04/c3_trace.log 2>&1; grep "wave trace\|map_opt trace" gpurun_out/r04/c3_trace.log | tail -4
+python tools/time_map_fit.py 2>&1 | grep "one launch" | tee gpurun_out/r04/time_map_fit.log
