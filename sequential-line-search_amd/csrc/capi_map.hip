@@ -515,7 +515,11 @@ static void map_opt_run(sls_nll* h, const MapOptProblem& pb, const double* z0, c
         h->mo_out = static_cast<double*>(c->host_take(MAP_OPT_OUT_DOUBLES * sizeof(double), true, &h->mo_out_bytes));
         SLS_HIP(hipHostGetDevicePointer((void**)&h->mo_out_dev, h->mo_out, 0));
     }
-    h->mo_idx.ensure((idx.size() + 1) / 2 + 1);
+    {
+        const double* before = h->mo_idx.p;
+        h->mo_idx.ensure((idx.size() + 1) / 2 + 1);
+        if (h->mo_idx.p != before) h->mo_idx_host.clear();   // a new block: what the old one held is gone
+    }
     h->mo_vec.ensure(vec_doubles);
     h->mo_state.ensure(MAP_OPT_STATE_DOUBLES + 8);   // + the optional section trace
     h->mo_btl.ensure(std::max(F, 1));

@@ -127,7 +127,12 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
                     // The three loops of an evaluation were chains of dependent  LDS read -> fma  trips: 110-360 cycles per trip on a
                     // CU that runs nothing else (SLS_WAVE_TRACE=1, N = 61, D = 32: 1.5 + 8.9 + 2.6 of 17.5 us per evaluation).  The
                     // reads of eight trips are issued together, their arithmetic follows in the original order: same bits.
-                    double q = 0.0;
+                    // Every long sum of an evaluation runs as FOUR chains (terms 0, 4, 8, .. / 1, 5, .. / ..., each in increasing order) added
+                    // as (c0 + c1) + (c2 + c3) -- a fixed order: a start's bits depend on nothing but its own data.  (Tried in round 4
+                    // against the single dependent fma chain per sum: no measurable difference, 3.1 us for the two triangular passes
+                    // either way -- a lone workgroup on an otherwise idle chip is bound by instruction issue at the clock it is given,
+                    // not by fp64 latency.  Kept: shorter rounding chains.)
+                    double q4[4] = {0.0, 0.0, 0.0, 0.0};
                     int d = 0;
                     for (; d + 8 <= D; d += 8) {
                         double xv[8], tv[8];
@@ -139,13 +144,16 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
                             const double df = xv[u] - tv[u];
-                            q += df * df;
+                            q4[u & 3] += df * df;
                         }
                     }
-                    for (; d < D; ++d) {
-                        const double df = xs[d] - xt_at(i, d);
-                        q += df * df;
-                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)        // d is a multiple of 8 here: term d + u belongs to chain u & 3
+                        if (d + u < D) {
+                            const double df = xs[d + u] - xt_at(i, d + u);
+                            q4[u & 3] += df * df;
+                        }
+                    const double q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
                     if (p.matern) {
                         const double s = sqrt(5.0 * q), e = exp(-s);
                         kr[r] = p.a * (1.0 + s + (5.0 / 3.0) * q) * e;
@@ -165,12 +173,12 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
         __syncthreads();
         WAVE_T(0);
         // w = K^-1 k for this lane's rows
-        double w[R];
+        double w[R], w4[4][R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) w[r] = 0.0;
+        for (int r = 0; r < R; ++r) w4[0][r] = w4[1][r] = w4[2][r] = w4[3][r] = 0.0;
         // G columns in flight, G R = 16 (12 for R = 6) loads per lane.  Columns N .. G ceil(N / G) - 1 exist (identity padding of
         // K^-1, Np is a multiple of 128; the staged copy holds 16 ceil(N / 16) columns) and meet k_j = 0 there
-        constexpr int G = R <= 1 ? 16 : (R <= 2 ? 8 : (R <= 4 ? 4 : 2));
+        constexpr int G = R <= 1 ? 16 : (R <= 2 ? 8 : 4);      // a multiple of 4: column j0 + u belongs to chain u & 3
         for (int j0 = 0; j0 < N; j0 += G) {
             double kj[G], cv[G][R];
 #pragma unroll
@@ -182,9 +190,11 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
 #pragma unroll
             for (int u = 0; u < G; ++u) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) w[r] += cv[u][r] * kj[u];
+                for (int r = 0; r < R; ++r) w4[u & 3][r] += cv[u][r] * kj[u];
             }
         }
+#pragma unroll
+        for (int r = 0; r < R; ++r) w[r] = (w4[0][r] + w4[1][r]) + (w4[2][r] + w4[3][r]);
         double kw = 0.0, cw = 0.0;
         if constexpr (SOLVE) {
             // w holds v = L^-1 k: sigma^2 = a - |v|^2 (k . LLT.solve(k)); then w = L^-T v, with v broadcast from LDS
@@ -194,7 +204,7 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
                 const double v = i < N ? w[r] : 0.0;
                 kw += v * v;
                 cwb[i] = v;
-                w[r] = 0.0;
+                w4[0][r] = w4[1][r] = w4[2][r] = w4[3][r] = 0.0;
             }
             __syncthreads();
             for (int j0 = 0; j0 < N; j0 += G) {       // rows N .. G ceil(N / G) - 1 of L^-1 are identity padding and meet v_j = 0
@@ -208,9 +218,11 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
 #pragma unroll
                 for (int u = 0; u < G; ++u) {
 #pragma unroll
-                    for (int r = 0; r < R; ++r) w[r] += cv[u][r] * vj[u];
+                    for (int r = 0; r < R; ++r) w4[u & 3][r] += cv[u][r] * vj[u];
                 }
             }
+#pragma unroll
+            for (int r = 0; r < R; ++r) w[r] = (w4[0][r] + w4[1][r]) + (w4[2][r] + w4[3][r]);
             __syncthreads();                          // every lane has read v before c_i w_i overwrites it
         }
 #pragma unroll
@@ -241,7 +253,7 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
         for (int e = 0; e < 2; ++e) {
             const int d = lane + 64 * e;
             if (d < D) {
-                double gm = 0.0, gs = 0.0;
+                double gm4[4] = {0.0, 0.0, 0.0, 0.0}, gs4[4] = {0.0, 0.0, 0.0, 0.0};
                 int i = 0;
                 for (; i + 8 <= N; i += 8) {
                     double xv[8], av[8], wv[8];
@@ -253,15 +265,18 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        gm += xv[u] * av[u];
-                        gs += xv[u] * wv[u];
+                        gm4[u & 3] += xv[u] * av[u];
+                        gs4[u & 3] += xv[u] * wv[u];
                     }
                 }
-                for (; i < N; ++i) {
-                    const double xi = xt_at(i, d);
-                    gm += xi * cab[i];
-                    gs += xi * cwb[i];
-                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)            // i is a multiple of 8 here
+                    if (i + u < N) {
+                        const double xi = xt_at(i + u, d);
+                        gm4[u & 3] += xi * cab[i + u];
+                        gs4[u & 3] += xi * cwb[i + u];
+                    }
+                const double gm = (gm4[0] + gm4[1]) + (gm4[2] + gm4[3]), gs = (gs4[0] + gs4[1]) + (gs4[2] + gs4[3]);
                 const double il = e == 0 ? il0 : il1;
                 dm[e] = -il * (xs[d] * ca - gm);
                 ds[e] = inv_sigma * il * (xs[d] * cw - gs);

@@ -15,3 +15,4 @@ for f in ("c3_run1","c3_run2","c3_run3"):
 PY
 SLS_MAP_TRACE=1 SLS_WAVE_TRACE=1 SLS_HOST_TIMING=1 $B/sequential_line_search_nd 32 30 1 > gpurun_out/r04/c3_trace.log 2>&1; grep "wave trace" gpurun_out/r04/c3_trace.log | tail -5
 grep "wave trace" gpurun_out/r04/c3_trace.log | awk '{n+=1; ev+=$10} END {print "local-phase calls", n, "evaluations", ev}'
+python tools/time_wave_path.py 2>&1 | tee gpurun_out/r04/time_wave_path.log
