@@ -380,7 +380,7 @@ struct sls_gp {
     int best_index = 0;
     double mu_best = 0, logdet = 0;
     // evaluation workspace (grown on demand)
-    DBuf Ks, Cs, P, parts, Gs, Gm, Gpart, XsT, ns, raw, outv, outg, outm, outs;
+    DBuf Ks, Cs, P, Vs, parts, Gs, Gm, Gpart, XsT, ns, raw, outv, outg, outm, outs;
     int ws_chunk = 0;
     // L-BFGS state
     DBuf pair_mu, pair_sg, pair_dmu, pair_dsg;
@@ -399,9 +399,27 @@ struct sls_gp {
     }
 };
 
+// N <= 128: the whole fit is one single-workgroup launch (kernels_small.hip); SLS_FIT_SMALL=0 forces the tiled pipeline (A/B, tests)
+static bool gp_fit_small_ok(const sls_gp* g) {
+    if (g->N > NLL_SMALL_MAX_N || g->Np != 128 || g->D > 128) return false;
+    const char* e = getenv("SLS_FIT_SMALL");
+    return !e || atoi(e) != 0;
+}
+
 static void gp_fit_device(sls_gp* g) {
     sls_ctx* c = g->ctx;
     const int N = g->N, Np = g->Np, D = g->D;
+    if (gp_fit_small_ok(g)) {
+        GpFitSmallArgs f;
+        f.X = g->X.p; f.y = g->y.p; f.inv_ell = g->inv_ell.p;
+        f.D = D; f.N = N; f.Dcols = g->Dcols; f.a = g->a; f.b = g->b;
+        f.XT = g->XT.p; f.nx = g->nx.p; f.XaT = g->XaT.p; f.L = g->L.p; f.Linv = g->Linv.p; f.U = g->U.p; f.Kinv = g->Kinv.p;
+        f.alpha = g->alpha.p; f.mu_data = g->mu_data.p; f.scal = g->scal.p; f.d_idx = g->d_idx; f.info = c->d_info;
+        SLS_HIP(hipMemsetAsync(c->d_info, 0, 64, c->stream));
+        ProfScope ps(c, "fit_small");
+        launch_gp_fit_small(c->stream, g->kernel, f);
+        return;
+    }
     KernelSpec ks{g->kernel, g->a};
     {
         ProfScope ps(c, "gram");
@@ -661,17 +679,24 @@ static void eval_candidates(sls_gp* g, const double* xr, long ldr, int S, const 
                               ldk, mu_part, ca_part);
         }
         int split_first = 0x7fffffff;
+        const bool solve_grad = g->sigma_mode == 1 && (want_grad || !tri_predict());
         {
             ProfScope ps(c, want_grad ? "acq_gemm" : "var_gemm");
-            if (want_grad || !tri_predict())
+            if (solve_grad) {
+                // handles of a PreferenceRegressor: w = K^-1 k as L^-T (L^-1 k) (LLT.solve, src/preference-regressor.cpp:299-330) --
+                // V = K* L^-T as a plain product, then the acq_gemm tile kernel with (L^-1)^T in the place of K^-1 and V in the
+                // place of K*: P = C* o W and the c.w partial sums come out as usual (its k.w sums are not used: sigma below)
+                g->Vs.ensure((size_t)chunk_max * Np);
+                launch_gemm_plain(c->stream, g->Ks.p, ldk, false, g->Linv.p, Np, false, g->Vs.p, ldk, Sp / 128, Np / 128, Np, 1.0, 0.0);
+                split_first = launch_acq_gemm(c->stream, g->Vs.p, Cs, ldk, Sp, g->U.p, Np, g->P.p, kw_part, cw_part, c->d_info + 32);
+            } else if (want_grad || !tri_predict())
                 split_first = launch_acq_gemm(c->stream, g->Ks.p, Cs, ldk, Sp, g->Kinv.p, Np, g->P.p, kw_part, cw_part, c->d_info + 32);
             else
                 launch_var_gemm(c->stream, g->Ks.p, ldk, Sp, g->Linv.p, Np, kw_part, cw_part);
         }
-        // handles of a PreferenceRegressor: sigma from the triangular form |L^-1 k|^2 also when gradients are requested (the
-        // K^-1 product above then only feeds the gradient of sigma)
+        // ... and sigma from the triangular form |L^-1 k|^2
         double* kw_solve = nullptr;
-        if (g->sigma_mode == 1 && (want_grad || !tri_predict())) {
+        if (solve_grad) {
             kw_solve = cw_part + (size_t)2 * nbt * ldk;
             ProfScope ps(c, "var_gemm");
             launch_var_gemm(c->stream, g->Ks.p, ldk, Sp, g->Linv.p, Np, kw_solve, kw_solve + (size_t)2 * nbt * ldk);
@@ -907,7 +932,7 @@ static void maximize_impl(sls_gp* g, sls_gp* gs, int acq_type, double ucb_h, con
             long long* d_trace = nullptr;
             if (getenv("SLS_WAVE_TRACE")) {
                 d_trace = reinterpret_cast<long long*>(g->lb_int + 6 * (size_t)Sp + 64);
-                SLS_HIP(hipMemsetAsync(d_trace, 0, 8 * sizeof(long long), c->stream));
+                SLS_HIP(hipMemsetAsync(d_trace, 0, 9 * sizeof(long long), c->stream));
                 w.trace = d_trace;
             }
             {
@@ -916,13 +941,13 @@ static void maximize_impl(sls_gp* g, sls_gp* gs, int acq_type, double ucb_h, con
             }
             unsigned long long useful = 0;
             SLS_HIP(hipMemcpyAsync(&useful, d_useful, sizeof(useful), hipMemcpyDeviceToHost, c->stream));
-            long long tr[8] = {};
+            long long tr[9] = {};
             if (d_trace) SLS_HIP(hipMemcpyAsync(tr, d_trace, sizeof(tr), hipMemcpyDeviceToHost, c->stream));
             sync(c);
             if (d_trace)
                 fprintf(stderr, "wave trace (us): S %d N %d D %d evals %lld | kvec %.1f  Kinv.k %.1f  sums %.1f  grad+acq %.1f  direction %.1f  "
-                        "bookkeeping %.1f  total %.1f\n", S, g->N, D, tr[6], tr[0] * 0.01, tr[1] * 0.01, tr[2] * 0.01, tr[3] * 0.01, tr[4] * 0.01,
-                        tr[5] * 0.01, tr[7] * 0.01);
+                        "bookkeeping %.1f  total %.1f  (shader clock %.0f MHz)\n", S, g->N, D, tr[6], tr[0] * 0.01, tr[1] * 0.01, tr[2] * 0.01, tr[3] * 0.01, tr[4] * 0.01,
+                        tr[5] * 0.01, tr[7] * 0.01, tr[7] > 0 ? (double)tr[8] / (tr[7] * 0.01) : 0.0);
             g->stat_issued = (long)useful;
             g->stat_rounds = n_local;
             used_wave = true;

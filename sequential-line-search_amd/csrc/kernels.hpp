@@ -80,6 +80,18 @@ struct NllSmallArgs {
 };
 void launch_nll_small(hipStream_t s, int kernel, const NllSmallArgs& args);
 
+// Whole fit of a GP handle for N <= 128 (Np = 128) in one single-workgroup launch (gp_fit_small_kernel): every output of
+// gp_fit_device (capi.hip).  All pointers device; matrices 128 x 128 column-major, XT / XaT [i + d * 128] with Dcols columns.
+struct GpFitSmallArgs {
+    const double *X, *y, *inv_ell;   // X: raw D x N column-major
+    int D, N, Dcols;
+    double a, b;
+    double *XT, *nx, *XaT, *L, *Linv, *U, *Kinv, *alpha, *mu_data, *scal;   // scal[0] = max_i mu(x_i), scal[1] = log|K_y|
+    long* d_idx;                     // first arg max of mu over the data points
+    int* info;                       // 1 + index of the first non-positive pivot, or 0
+};
+void launch_gp_fit_small(hipStream_t s, int kernel, const GpFitSmallArgs& args);
+
 // Whole MAP FIT for N <= 128 in one single-workgroup launch (map_opt_kernel): the bounded L-BFGS of host/device.cpp
 // (optim::MaximizeBounded) with the objective evaluated in place -- the preference objective of
 // src/preference-regressor.cpp:129-259 (Bradley-Terry-Luce terms from a CSR / CSC image of m_D, GP term, log-normal priors)

@@ -57,13 +57,12 @@ __device__ __forceinline__ double small_pair_q(const double* __restrict__ X, int
     return q;
 }
 
-// K_y = K_f(a, l) + b I into the LDS image (1/l in the scratch), Cholesky + inverse on the leading ceil(N/16) blocks,
-// K_y^-1 as a full symmetric image over the dead factor.  Returns sum_i log L_ii (= logdet / 2) in every thread.
+// K_y = K_f(a, l) + b I into the LDS image (1/l in the scratch) and its Cholesky factorisation on the leading ceil(N/16) blocks: L in the
+// lower triangle of As, L^-T in its strictly-upper tiles, the inverses of the diagonal tiles in Ts.  Returns sum_i log L_ii.
 template <bool MATERN>
-__device__ __forceinline__ double small_factor_inverse(double* As, double* Ts, const double* __restrict__ X, int D, int N,
-                                                       double a, double b, int* __restrict__ info) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fl = lane & 15, fk = lane >> 4;
+__device__ __forceinline__ double small_build_factor(double* As, double* Ts, const double* __restrict__ X, int D, int N,
+                                                     double a, double b, int* __restrict__ info) {
+    const int tid = threadIdx.x;
     const int nb16 = (N + 15) >> 4, Nb = 16 * nb16;
     // ---- K_y (lower triangle + full diagonal tiles), identity padding up to the next multiple of 16 ----
     for (int idx = tid; idx < Nb * Nb; idx += 256) {
@@ -87,7 +86,15 @@ __device__ __forceinline__ double small_factor_inverse(double* As, double* Ts, c
 
     // ---- log det ----
     const double ld = small_block_sum(tid < N ? log(As[tid + tid * DL]) : 0.0, As);
+    return ld;
+}
 
+// K^-1 = L^-T L^-1 as a full symmetric image over the dead factor (after small_build_factor: L in the lower triangle of As, L^-T in its
+// strictly-upper tiles, the inverses of the diagonal tiles in Ts)
+__device__ __forceinline__ void small_inverse_in_place(double* As, double* Ts, int N) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fl = lane & 15, fk = lane >> 4;
+    const int nb16 = (N + 15) >> 4;
     // ---- K^-1 = L^-T L^-1, lower tiles (i >= j) into the lower triangle (L is no longer needed) ----
     {
         int t = 0;
@@ -123,6 +130,16 @@ __device__ __forceinline__ double small_factor_inverse(double* As, double* Ts, c
             }
     }
     __syncthreads();
+}
+
+
+// K_y = K_f(a, l) + b I into the LDS image (1/l in the scratch), Cholesky + inverse on the leading ceil(N/16) blocks,
+// K_y^-1 as a full symmetric image over the dead factor.  Returns sum_i log L_ii (= logdet / 2) in every thread.
+template <bool MATERN>
+__device__ __forceinline__ double small_factor_inverse(double* As, double* Ts, const double* __restrict__ X, int D, int N,
+                                                       double a, double b, int* __restrict__ info) {
+    const double ld = small_build_factor<MATERN>(As, Ts, X, D, N, a, b, info);
+    small_inverse_in_place(As, Ts, N);
     return ld;
 }
 
@@ -669,6 +686,111 @@ void launch_map_opt(hipStream_t s, int kernel, const MapOptArgs& args) {
         hipLaunchKernelGGL(map_opt_kernel<true>, dim3(1), dim3(256), DIAG_LDS_BYTES, s, args);
     else
         hipLaunchKernelGGL(map_opt_kernel<false>, dim3(1), dim3(256), DIAG_LDS_BYTES, s, args);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// gp_fit_small_kernel: the whole fit of a GP handle for N <= 128 in ONE single-workgroup launch (GaussianProcessRegressor /
+// PreferenceRegressor constructors, src/gaussian-process-regressor.cpp:198-232, src/preference-regressor.cpp:289-290, with the
+// hoisted quantities of DESIGN.md 2): scaled design matrix + norms, K_y, L, L^-1, (L^-1)^T, K_y^-1, alpha, alpha o X~, the
+// posterior mean at the data points with its first maximum, log|K_y|.  The tiled pipeline needs ~15 launches for the same at these
+// sizes (175 us of device time + their launch overheads per fit; round 4, C3: one fit per SubmitFeedbackData).
+// ---------------------------------------------------------------------------------------------------------
+template <bool MATERN>
+__global__ __launch_bounds__(256) void gp_fit_small_kernel(const GpFitSmallArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* As = reinterpret_cast<double*>(smem);
+    double* Ts = As + 128 * DL;
+    const int tid = threadIdx.x;
+    const int D = p.D, N = p.N, Dcols = p.Dcols;
+    constexpr int Np = 128;
+    const int nb16 = (N + 15) >> 4, Nb = 16 * nb16;
+    // ---- scaled, centred design matrix and its squared norms (prep_kernel's arithmetic) ----
+    if (tid < Np) {
+        double sq = 0.0;
+        if (tid < N) {
+            for (int d = 0; d < D; ++d) {
+                const double v = (p.X[d + (long)tid * D] - 0.5) * p.inv_ell[d];
+                p.XT[tid + (long)d * Np] = v;
+                sq += v * v;
+            }
+            for (int d = D; d < Dcols; ++d) p.XT[tid + (long)d * Np] = 0.0;
+        } else {
+            for (int d = 0; d < Dcols; ++d) p.XT[tid + (long)d * Np] = 0.0;
+        }
+        p.nx[tid] = sq;
+    }
+    for (int d = tid; d < D; d += 256) small_scratch(As, SC_INVL + d) = p.inv_ell[d];
+    for (int i = tid; i < 128; i += 256) small_scratch(As, SC_Y + i) = i < N ? p.y[i] : 0.0;
+    if (tid == 0) *p.info = 0;
+    __syncthreads();
+
+    const double ld = small_build_factor<MATERN>(As, Ts, p.X, D, N, p.a, p.b, p.info);
+    // ---- L, L^-1 and (L^-1)^T to global memory (identity padding outside the leading Nb x Nb block, zeros above / below) ----
+    for (int idx = tid; idx < Np * Np; idx += 256) {
+        const int i = idx & (Np - 1), j = idx >> 7;
+        double l = 0.0, t = 0.0;
+        if (i >= Nb || j >= Nb) {
+            l = t = (i == j) ? 1.0 : 0.0;
+        } else if (i >= j) {
+            l = As[i + j * DL];
+            // L^-1: same 16 x 16 tile -> the tile's inverse in Ts; other tiles -> the transposed slot in the upper triangle of As
+            t = (i >> 4) == (j >> 4) ? Ts[256 * (i >> 4) + (i & 15) + 16 * (j & 15)] : As[j + i * DL];
+        }
+        p.L[idx] = l;
+        p.Linv[idx] = t;
+        p.U[j + (long)i * Np] = t;
+    }
+    __syncthreads();
+    small_inverse_in_place(As, Ts, N);
+    for (int idx = tid; idx < Np * Np; idx += 256) {
+        const int i = idx & (Np - 1), j = idx >> 7;
+        p.Kinv[idx] = (i < Nb && j < Nb) ? As[i + j * DL] : (i == j ? 1.0 : 0.0);
+    }
+    double gb, quad;
+    small_alpha(As, N, gb, quad);
+    // ---- alpha, alpha o X~, the posterior mean at the data points (mu(x_i) = y_i - b alpha_i) and its first maximum ----
+    double mv = -INFINITY;
+    int mi = 0x7fffffff;
+    if (tid < Np) {
+        const double al = tid < N ? small_scratch(As, SC_ALPHA + tid) : 0.0;
+        p.alpha[tid] = al;
+        for (int d = 0; d < Dcols; ++d) p.XaT[tid + (long)d * Np] = al * p.XT[tid + (long)d * Np];
+        if (tid < N) {
+            const double m = small_scratch(As, SC_Y + tid) - p.b * al;
+            p.mu_data[tid] = m;
+            mv = m;
+            mi = tid;
+        }
+    }
+    // first maximum (Eigen maxCoeff): highest value, ties -> lowest index; all -inf / NaN -> index 0 (argmax_kernel's rule)
+    __syncthreads();
+    double* rv = &small_scratch(As, SC_BTL);
+    if (tid < 128) {
+        small_scratch(As, SC_BTL + tid) = mv;
+        small_scratch(As, SC_BTL + 128 + tid) = (double)mi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int i = 0; i < N; ++i) {
+            const double v = small_scratch(As, SC_BTL + i);
+            if (v > bv) { bv = v; bi = i; }
+        }
+        p.scal[0] = bi == 0x7fffffff ? small_scratch(As, SC_BTL) : bv;
+        p.d_idx[0] = bi == 0x7fffffff ? 0 : bi;
+        p.scal[1] = 2.0 * ld;
+        (void)rv;
+    }
+}
+
+void launch_gp_fit_small(hipStream_t s, int kernel, const GpFitSmallArgs& args) {
+    ensure_dyn_lds((const void*)gp_fit_small_kernel<false>, DIAG_LDS_BYTES);
+    ensure_dyn_lds((const void*)gp_fit_small_kernel<true>, DIAG_LDS_BYTES);
+    if (kernel == SLS_KERNEL_ARD_MATERN52)
+        hipLaunchKernelGGL(gp_fit_small_kernel<true>, dim3(1), dim3(256), DIAG_LDS_BYTES, s, args);
+    else
+        hipLaunchKernelGGL(gp_fit_small_kernel<false>, dim3(1), dim3(256), DIAG_LDS_BYTES, s, args);
 }
 
 void launch_nll_small(hipStream_t s, int kernel, const NllSmallArgs& args) {

@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
     long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool tracing = p.trace != nullptr;
     const long long tr_begin = tracing ? wall_clock64() : 0;
+    const long long tr_cyc0 = tracing ? clock64() : 0;
 #define WAVE_T0 const long long t_0 = tracing ? wall_clock64() : 0; long long t_prev = t_0
 #define WAVE_T(slot) do { if (tracing) { const long long t_now = wall_clock64(); tr[slot] += t_now - t_prev; t_prev = t_now; } } while (0)
     const int nraw = blockIdx.x * 4 + wave;
@@ -451,6 +452,7 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
     if (tracing && blockIdx.x == 0 && threadIdx.x == 0) {
         tr[7] = wall_clock64() - tr_begin;
         for (int q = 0; q < 8; ++q) p.trace[q] = tr[q];
+        p.trace[8] = clock64() - tr_cyc0;        // shader-clock cycles of the same interval: the clock this lone workgroup ran at
     }
     if (live) {
         if (has0) p.x_out[n + (long)d0 * p.ld] = x0;

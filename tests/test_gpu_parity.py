@@ -855,20 +855,11 @@ def test_preference_handles_meet_the_flat_tolerance_on_ill_conditioned_cases(ctx
     _, dsg = gp.predict_grad(Xs)
     ok = np.isfinite(dsg_o)
     assert np.array_equal(np.isfinite(dsg), ok)
-    # d sigma = -(1 / sigma) J K^-1 k.  The wavefront path forms K^-1 k = L^-T (L^-1 k) by two triangular passes (measured on these
-    # cases: <= 3.4e-6 of a column's largest component); the tiled path keeps the explicit inverse for the GRADIENT (one dense GEMM
-    # for all candidates; only sigma itself moved to the triangular form) and carries the conditioning term of
-    # test_randomised_configurations there.
+    # d sigma = -(1 / sigma) J K^-1 k with K^-1 k = L^-T (L^-1 k) on both paths (two triangular passes in the wavefront kernel; a
+    # plain product V = K* L^-T followed by the acq_gemm tiles with (L^-1)^T in the place of K^-1 in the tiled pipeline): measured on
+    # these cases <= 3.4e-6 of a column's largest component
     colmax = np.max(np.abs(np.where(ok, dsg_o, 0.0)), axis=0, keepdims=True) + np.zeros_like(dsg_o)
-    gmax = max(float(np.abs(dsg_o[ok]).max()), 1e-300) if ok.any() else 1.0
-    if path == "wave":
-        assert np.all(np.abs(dsg - dsg_o)[ok] <= 2e-5 * colmax[ok] + 1e-12), np.max(np.abs(dsg - dsg_o)[ok] / np.maximum(colmax[ok], 1e-300))
-    else:
-        eps = np.finfo(float).eps
-        kappa = (theta[0] * N + b) / b
-        d_rel = kappa * eps * theta[0] / (2.0 * np.maximum(sg_o, 1e-150) ** 2)          # relative first-order bound of sigma, per point
-        bound = 1e-6 * gmax + 50.0 * d_rel[None, :] * colmax
-        assert np.all(np.abs(dsg - dsg_o)[ok] <= bound[ok]), np.max(np.abs(dsg - dsg_o)[ok] / gmax)
+    assert np.all(np.abs(dsg - dsg_o)[ok] <= 2e-5 * colmax[ok] + 1e-12), np.max(np.abs(dsg - dsg_o)[ok] / np.maximum(colmax[ok], 1e-300))
     # the gradient route of the acquisition functions uses the same sigma: UCB value = mu + h sigma
     v, g = gp.acq_eval(Xs, 1, 0.7)
     mu_o = np.array([ref.predict_mu(Xs[:, j]) for j in range(Xs.shape[1])])
