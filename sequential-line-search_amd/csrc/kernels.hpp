@@ -212,6 +212,7 @@ struct WaveArgs {
     // GaussianProcessRegressor (src/gaussian-process-regressor.cpp:241-255).  Linv = L^-1 (zero above the diagonal), U = Linv^T.
     int solve_sigma = 0;
     int stage_ld = 0, stage_cols = 0;     // filled by the launcher: leading dimension / columns of the staged first-pass matrix
+    int xch = 0;                          // filled by the launcher: doubles of the cooperative form's exchange area (0: one wave per start)
     const double *Linv = nullptr, *U = nullptr;
     double *x_out, *f_out;                // x_out[n + d*ld], f_out[n] = -acq at the end point
     unsigned long long* useful;           // optional: += evaluations of starts that were still moving (the others run idle)

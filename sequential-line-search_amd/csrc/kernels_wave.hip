@@ -31,7 +31,8 @@ namespace slsk {
 // v = L^-1 k reads S(i, j) for j <= i, the second w = L^-T v reads S(i, j) for j >= i -- both with lanes over i, i.e. the
 // conflict-free access of the K^-1 loop, and one matrix in LDS instead of two.
 // R = 1 serves N <= 64 (Np = 128, but no lane's second row exists): half the loads of every pass.
-template <int STAGE, int R, bool SOLVE>
+// COOP: the launch has ONE start and the four waves of its workgroup share every long sum (see evaluate()).
+template <int STAGE, int R, bool SOLVE, bool COOP = false>
 __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* smem = reinterpret_cast<double*>(smem_raw);
@@ -42,8 +43,8 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
     const long long tr_cyc0 = tracing ? clock64() : 0;
 #define WAVE_T0 const long long t_0 = tracing ? wall_clock64() : 0; long long t_prev = t_0
 #define WAVE_T(slot) do { if (tracing) { const long long t_now = wall_clock64(); tr[slot] += t_now - t_prev; t_prev = t_now; } } while (0)
-    const int nraw = blockIdx.x * 4 + wave;
-    const bool live = nraw < p.S;
+    const int nraw = COOP ? 0 : blockIdx.x * 4 + wave;     // COOP: all four waves carry start 0 (identical state, shared sums)
+    const bool live = COOP ? wave == 0 : nraw < p.S;
     const int n = live ? nraw : p.S - 1;          // surplus waves shadow the last start (uniform barrier counts)
     const int D = p.D, N = p.N, Np = p.Np, m = p.m;
     double* xs = smem + (long)wave * p.lds_per_wave;   // scaled trial point [D]
@@ -60,7 +61,8 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
     // loops whose every trip needs a global word (L2 at best: ~1 us from a chip that is otherwise idle); with one wavefront per
     // start nothing hides that, and 320 evaluations in sequence took 7 ms (22 us each) at N = 60, D = 32.  Values only move:
     // same bits.
-    double* const sharedK = smem + 4L * p.lds_per_wave;
+    double* const xch = smem + 4L * p.lds_per_wave;         // COOP: exchange area for the four waves' partial sums (p.xch doubles)
+    double* const sharedK = xch + p.xch;
     const int ldS = Np, colsS = p.stage_cols;
     double* const sharedX = sharedK + (STAGE >= 1 ? (long)ldS * colsS : 0L);
     if (STAGE >= 1) {
@@ -116,23 +118,101 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
         if (has0) xs[d0] = (xq0 - 0.5) * il0;
         if (has1) xs[d1] = (xq1 - 0.5) * il1;
         __syncthreads();
-        double kr[R], cr[R];
-        double mu = 0.0, ca = 0.0;
+        // Every long sum of an evaluation runs as FOUR chains -- terms 0, 4, 8, .. / 1, 5, 9, .. / ..., each in increasing order --
+        // added as (c0 + c1) + (c2 + c3): a fixed order, so a start's bits depend on nothing but its own data.  One wavefront per
+        // start computes all four chains itself; when the launch has ONE start (COOP: the local phase of the DIRECT -> L-BFGS
+        // branch), the workgroup's four waves -- which would otherwise shadow each other -- take one chain each and exchange the
+        // partial sums through LDS: the same additions in the same order, a quarter of each loop per wave.
+        // The reads of up to 16 loop trips are issued together, their arithmetic follows in order.
+        auto combine4 = [](double c0, double c1, double c2, double c3) { return (c0 + c1) + (c2 + c3); };
+        // out[k] = combine4 of the four waves' part[k] (COOP only): two workgroup barriers
+        auto exchange = [&](auto& part, auto& out, auto K_) {
+            constexpr int K = decltype(K_)::value;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            kr[r] = 0.0;
-            cr[r] = 0.0;
-            {
+            for (int k = 0; k < K; ++k) xch[(wave * K + k) * 64 + lane] = part[k];
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                out[k] = combine4(xch[(0 * K + k) * 64 + lane], xch[(1 * K + k) * 64 + lane], xch[(2 * K + k) * 64 + lane], xch[(3 * K + k) * 64 + lane]);
+            __syncthreads();
+        };
+        // chain c of  sum_d (xs_d - X~_id)^2  for row i
+        auto kvec_chain = [&](int i, int c) {
+            double acc = 0.0;
+            for (int m0 = 0; c + 4 * m0 < D; m0 += 8) {
+                double xv[8], tv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int d = c + 4 * (m0 + u), dc = d < D ? d : D - 1;
+                    xv[u] = xs[dc];
+                    tv[u] = d < D ? xt_at(i, dc) : xv[u];       // beyond D: difference 0
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double df = xv[u] - tv[u];
+                    acc += df * df;
+                }
+            }
+            return acc;
+        };
+        // chain c of  sum_j M(i_r, j) v_j  for this lane's R rows (M: first- or second-pass matrix, v broadcast from LDS)
+        auto mat_chain = [&](auto&& M, const double* v, int c, double (&acc)[R]) {
+            constexpr int T = R <= 1 ? 16 : (R <= 2 ? 8 : 4);
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = 0.0;
+            for (int m0 = 0; c + 4 * m0 < N; m0 += T) {
+                double vj[T], cv[T][R];
+#pragma unroll
+                for (int u = 0; u < T; ++u) {
+                    const int j = c + 4 * (m0 + u), jc = j < N ? j : N - 1;
+                    const double vv = v[jc];
+                    vj[u] = j < N ? vv : 0.0;                    // beyond N: term 0
+#pragma unroll
+                    for (int r = 0; r < R; ++r) cv[u][r] = M(lane + 64 * r, jc);
+                }
+#pragma unroll
+                for (int u = 0; u < T; ++u) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) acc[r] += cv[u][r] * vj[u];
+                }
+            }
+        };
+        // chain c of  sum_i X~_id (c_i alpha_i)  and  sum_i X~_id (c_i w_i)  for dimension d
+        auto grad_chain = [&](int d, int c, double& gm, double& gs) {
+            gm = 0.0;
+            gs = 0.0;
+            for (int m0 = 0; c + 4 * m0 < N; m0 += 8) {
+                double xv[8], av[8], wv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = c + 4 * (m0 + u), ic = i < N ? i : N - 1;
+                    const double x = xt_at(ic, d);
+                    xv[u] = i < N ? x : 0.0;
+                    av[u] = cab[ic];
+                    wv[u] = cwb[ic];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    gm += xv[u] * av[u];
+                    gs += xv[u] * wv[u];
+                }
+            }
+        };
+
+        double kr[R], cr[R], qrow[R];
+        double mu = 0.0, ca = 0.0;
+        if constexpr (COOP) {
+            double part[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) part[r] = (lane + 64 * r < N) ? kvec_chain(lane + 64 * r, wave) : 0.0;
+            exchange(part, qrow, std::integral_constant<int, R>{});
+        } else {
+            // one wave, all four chains: term d belongs to chain d & 3; eight reads in flight
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
                 const int i = lane + 64 * r;
+                qrow[r] = 0.0;
                 if (i < N) {
-                    // The three loops of an evaluation were chains of dependent  LDS read -> fma  trips: 110-360 cycles per trip on a
-                    // CU that runs nothing else (SLS_WAVE_TRACE=1, N = 61, D = 32: 1.5 + 8.9 + 2.6 of 17.5 us per evaluation).  The
-                    // reads of eight trips are issued together, their arithmetic follows in the original order: same bits.
-                    // Every long sum of an evaluation runs as FOUR chains (terms 0, 4, 8, .. / 1, 5, .. / ..., each in increasing order) added
-                    // as (c0 + c1) + (c2 + c3) -- a fixed order: a start's bits depend on nothing but its own data.  (Tried in round 4
-                    // against the single dependent fma chain per sum: no measurable difference, 3.1 us for the two triangular passes
-                    // either way -- a lone workgroup on an otherwise idle chip is bound by instruction issue at the clock it is given,
-                    // not by fp64 latency.  Kept: shorter rounding chains.)
                     double q4[4] = {0.0, 0.0, 0.0, 0.0};
                     int d = 0;
                     for (; d + 8 <= D; d += 8) {
@@ -149,53 +229,72 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
                         }
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)        // d is a multiple of 8 here: term d + u belongs to chain u & 3
+                    for (int u = 0; u < 8; ++u)        // d is a multiple of 8 here
                         if (d + u < D) {
                             const double df = xs[d + u] - xt_at(i, d + u);
                             q4[u & 3] += df * df;
                         }
-                    const double q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
-                    if (p.matern) {
-                        const double s = sqrt(5.0 * q), e = exp(-s);
-                        kr[r] = p.a * (1.0 + s + (5.0 / 3.0) * q) * e;
-                        cr[r] = p.a * (5.0 / 3.0) * (1.0 + s) * e;
-                    } else {
-                        kr[r] = p.a * exp(-0.5 * q);
-                        cr[r] = kr[r];
-                    }
-                    const double al = alr[r];
-                    mu += al * kr[r];
-                    ca += al * cr[r];
-                    cab[i] = cr[r] * al;
+                    qrow[r] = combine4(q4[0], q4[1], q4[2], q4[3]);
                 }
-                kb[i] = kr[r];
             }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            kr[r] = 0.0;
+            cr[r] = 0.0;
+            const int i = lane + 64 * r;
+            if (i < N) {
+                const double q = qrow[r];
+                if (p.matern) {
+                    const double s = sqrt(5.0 * q), e = exp(-s);
+                    kr[r] = p.a * (1.0 + s + (5.0 / 3.0) * q) * e;
+                    cr[r] = p.a * (5.0 / 3.0) * (1.0 + s) * e;
+                } else {
+                    kr[r] = p.a * exp(-0.5 * q);
+                    cr[r] = kr[r];
+                }
+                const double al = alr[r];
+                mu += al * kr[r];
+                ca += al * cr[r];
+                cab[i] = cr[r] * al;
+            }
+            kb[i] = kr[r];
         }
         __syncthreads();
         WAVE_T(0);
-        // w = K^-1 k for this lane's rows
-        double w[R], w4[4][R];
+        // w = K^-1 k for this lane's rows (SOLVE: v = L^-1 k first)
+        double w[R];
+        auto full_pass = [&](auto&& M, const double* v) {
+            if constexpr (COOP) {
+                double part[R];
+                mat_chain(M, v, wave, part);
+                exchange(part, w, std::integral_constant<int, R>{});
+            } else {
+                // one wave, all four chains: column j belongs to chain j & 3.  G columns in flight (G a multiple of 4); columns
+                // N .. G ceil(N / G) - 1 exist (identity padding; the staged copy holds 16 ceil(N / 16) columns) and meet v_j = 0
+                constexpr int G = R <= 1 ? 16 : (R <= 2 ? 8 : 4);
+                double w4[4][R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) w4[0][r] = w4[1][r] = w4[2][r] = w4[3][r] = 0.0;
-        // G columns in flight, G R = 16 (12 for R = 6) loads per lane.  Columns N .. G ceil(N / G) - 1 exist (identity padding of
-        // K^-1, Np is a multiple of 128; the staged copy holds 16 ceil(N / 16) columns) and meet k_j = 0 there
-        constexpr int G = R <= 1 ? 16 : (R <= 2 ? 8 : 4);      // a multiple of 4: column j0 + u belongs to chain u & 3
-        for (int j0 = 0; j0 < N; j0 += G) {
-            double kj[G], cv[G][R];
+                for (int r = 0; r < R; ++r) w4[0][r] = w4[1][r] = w4[2][r] = w4[3][r] = 0.0;
+                for (int j0 = 0; j0 < N; j0 += G) {
+                    double vj[G], cv[G][R];
 #pragma unroll
-            for (int u = 0; u < G; ++u) {
-                kj[u] = kb[j0 + u];
+                    for (int u = 0; u < G; ++u) {
+                        vj[u] = v[j0 + u];
 #pragma unroll
-                for (int r = 0; r < R; ++r) cv[u][r] = kinv_at(lane + 64 * r, j0 + u);
+                        for (int r = 0; r < R; ++r) cv[u][r] = M(lane + 64 * r, j0 + u);
+                    }
+#pragma unroll
+                    for (int u = 0; u < G; ++u) {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) w4[u & 3][r] += cv[u][r] * vj[u];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) w[r] = combine4(w4[0][r], w4[1][r], w4[2][r], w4[3][r]);
             }
-#pragma unroll
-            for (int u = 0; u < G; ++u) {
-#pragma unroll
-                for (int r = 0; r < R; ++r) w4[u & 3][r] += cv[u][r] * kj[u];
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) w[r] = (w4[0][r] + w4[1][r]) + (w4[2][r] + w4[3][r]);
+        };
+        full_pass(kinv_at, kb);
         double kw = 0.0, cw = 0.0;
         if constexpr (SOLVE) {
             // w holds v = L^-1 k: sigma^2 = a - |v|^2 (k . LLT.solve(k)); then w = L^-T v, with v broadcast from LDS
@@ -205,37 +304,19 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
                 const double v = i < N ? w[r] : 0.0;
                 kw += v * v;
                 cwb[i] = v;
-                w4[0][r] = w4[1][r] = w4[2][r] = w4[3][r] = 0.0;
             }
             __syncthreads();
-            for (int j0 = 0; j0 < N; j0 += G) {       // rows N .. G ceil(N / G) - 1 of L^-1 are identity padding and meet v_j = 0
-                double vj[G], cv[G][R];
-#pragma unroll
-                for (int u = 0; u < G; ++u) {
-                    vj[u] = cwb[j0 + u];
-#pragma unroll
-                    for (int r = 0; r < R; ++r) cv[u][r] = linvT_at(lane + 64 * r, j0 + u);
-                }
-#pragma unroll
-                for (int u = 0; u < G; ++u) {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) w4[u & 3][r] += cv[u][r] * vj[u];
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) w[r] = (w4[0][r] + w4[1][r]) + (w4[2][r] + w4[3][r]);
+            full_pass(linvT_at, cwb);
             __syncthreads();                          // every lane has read v before c_i w_i overwrites it
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            {
-                const int i = lane + 64 * r;
-                if (i < N) {
-                    if constexpr (!SOLVE) kw += kr[r] * w[r];
-                    const double t = cr[r] * w[r];
-                    cw += t;
-                    cwb[i] = t;
-                }
+            const int i = lane + 64 * r;
+            if (i < N) {
+                if constexpr (!SOLVE) kw += kr[r] * w[r];
+                const double t = cr[r] * w[r];
+                cw += t;
+                cwb[i] = t;
             }
         }
         __syncthreads();
@@ -250,37 +331,52 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
         const double inv_sigma = 1.0 / sigma;
         // gradient: lanes over d
         double dm[2] = {0.0, 0.0}, ds[2] = {0.0, 0.0};
+        double gsum[4] = {0.0, 0.0, 0.0, 0.0};        // gm, gs of dimensions lane and lane + 64
+        if constexpr (COOP) {
+            double part[4] = {0.0, 0.0, 0.0, 0.0};
+            if (has0) grad_chain(d0, wave, part[0], part[1]);
+            if (has1) grad_chain(d1, wave, part[2], part[3]);
+            exchange(part, gsum, std::integral_constant<int, 4>{});
+        } else {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int d = lane + 64 * e;
+                if (d < D) {
+                    double gm4[4] = {0.0, 0.0, 0.0, 0.0}, gs4[4] = {0.0, 0.0, 0.0, 0.0};
+                    int i = 0;
+                    for (; i + 8 <= N; i += 8) {
+                        double xv[8], av[8], wv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            xv[u] = xt_at(i + u, d);
+                            av[u] = cab[i + u];
+                            wv[u] = cwb[i + u];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            gm4[u & 3] += xv[u] * av[u];
+                            gs4[u & 3] += xv[u] * wv[u];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)            // i is a multiple of 8 here
+                        if (i + u < N) {
+                            const double xi = xt_at(i + u, d);
+                            gm4[u & 3] += xi * cab[i + u];
+                            gs4[u & 3] += xi * cwb[i + u];
+                        }
+                    gsum[2 * e] = combine4(gm4[0], gm4[1], gm4[2], gm4[3]);
+                    gsum[2 * e + 1] = combine4(gs4[0], gs4[1], gs4[2], gs4[3]);
+                }
+            }
+        }
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int d = lane + 64 * e;
             if (d < D) {
-                double gm4[4] = {0.0, 0.0, 0.0, 0.0}, gs4[4] = {0.0, 0.0, 0.0, 0.0};
-                int i = 0;
-                for (; i + 8 <= N; i += 8) {
-                    double xv[8], av[8], wv[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        xv[u] = xt_at(i + u, d);
-                        av[u] = cab[i + u];
-                        wv[u] = cwb[i + u];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        gm4[u & 3] += xv[u] * av[u];
-                        gs4[u & 3] += xv[u] * wv[u];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u)            // i is a multiple of 8 here
-                    if (i + u < N) {
-                        const double xi = xt_at(i + u, d);
-                        gm4[u & 3] += xi * cab[i + u];
-                        gs4[u & 3] += xi * cwb[i + u];
-                    }
-                const double gm = (gm4[0] + gm4[1]) + (gm4[2] + gm4[3]), gs = (gs4[0] + gs4[1]) + (gs4[2] + gs4[3]);
                 const double il = e == 0 ? il0 : il1;
-                dm[e] = -il * (xs[d] * ca - gm);
-                ds[e] = inv_sigma * il * (xs[d] * cw - gs);
+                dm[e] = -il * (xs[d] * ca - gsum[2 * e]);
+                ds[e] = inv_sigma * il * (xs[d] * cw - gsum[2 * e + 1]);
             }
         }
         last_mu = mu; last_sigma = sigma;
@@ -475,6 +571,13 @@ void launch_maximize_wave(hipStream_t s, WaveArgs a) {
     // staging only for launches that leave the chip idle anyway (<= 64 workgroups): with many starts the occupancy is worth more
     const char* senv = getenv("SLS_WAVE_STAGE");
     const bool allow = (senv ? atoi(senv) != 0 : true) && a.S <= 256 && a.n_local > 1;
+    // ONE start (the local phase of the DIRECT -> L-BFGS branch) on a problem of at most 128 points: the four waves of the
+    // workgroup share every long sum (COOP) instead of shadowing each other
+    const int R = a.N <= 64 ? 1 : a.Np / 64;
+    const char* cenv = getenv("SLS_WAVE_COOP");
+    const bool coop = a.S == 1 && a.n_local > 1 && R <= 2 && (cenv ? atoi(cenv) != 0 : true);
+    a.xch = coop ? 4 * 64 * 4 : 0;
+    bytes += (size_t)a.xch * 8;
     // staged first-pass matrix: 16 ceil(N / 16) columns of K^-1, or of the symmetric image of L^-1 / L^-T (solve-based sigma)
     a.stage_ld = a.Np;
     a.stage_cols = std::min(a.Np, (a.N + 15) & ~15);
@@ -485,33 +588,40 @@ void launch_maximize_wave(hipStream_t s, WaveArgs a) {
     a.stage_xt = allow && a.stage_kinv && bytes + xb <= cap;
     if (a.stage_xt) bytes += xb;
     // opt in to the CU's whole LDS once per device.  The staged forms exist for Np = 128 only (R <= 2).
-    const dim3 grid((a.S + 3) / 4), block(256);
-    const int R = a.N <= 64 ? 1 : a.Np / 64;
-#define SLS_WAVE_LAUNCH(ST, RR, SV)                                                              \
-    do {                                                                                         \
-        ensure_dyn_lds((const void*)maximize_wave_kernel<ST, RR, SV>, 160 * 1024);               \
-        hipLaunchKernelGGL((maximize_wave_kernel<ST, RR, SV>), grid, block, bytes, s, a);        \
+    const dim3 grid(coop ? 1 : (a.S + 3) / 4), block(256);
+#define SLS_WAVE_LAUNCH(ST, RR, SV, CO)                                                              \
+    do {                                                                                             \
+        ensure_dyn_lds((const void*)maximize_wave_kernel<ST, RR, SV, CO>, 160 * 1024);               \
+        hipLaunchKernelGGL((maximize_wave_kernel<ST, RR, SV, CO>), grid, block, bytes, s, a);        \
     } while (0)
-#define SLS_WAVE_BY_MODE(ST, RR)                                  \
-    do {                                                          \
-        if (a.solve_sigma) SLS_WAVE_LAUNCH(ST, RR, true);         \
-        else SLS_WAVE_LAUNCH(ST, RR, false);                      \
+#define SLS_WAVE_BY_MODE(ST, RR)                                                  \
+    do {                                                                          \
+        if (a.solve_sigma && coop) SLS_WAVE_LAUNCH(ST, RR, true, true);           \
+        else if (a.solve_sigma) SLS_WAVE_LAUNCH(ST, RR, true, false);             \
+        else if (coop) SLS_WAVE_LAUNCH(ST, RR, false, true);                      \
+        else SLS_WAVE_LAUNCH(ST, RR, false, false);                               \
+    } while (0)
+#define SLS_WAVE_BY_MODE_NOCOOP(ST, RR)                                           \
+    do {                                                                          \
+        if (a.solve_sigma) SLS_WAVE_LAUNCH(ST, RR, true, false);                  \
+        else SLS_WAVE_LAUNCH(ST, RR, false, false);                               \
     } while (0)
     if (R <= 2 && a.stage_xt) {
         if (R == 1) SLS_WAVE_BY_MODE(2, 1);
         else SLS_WAVE_BY_MODE(2, 2);
-    } else if (R <= 2 && a.stage_kinv && !a.solve_sigma) {
-        if (R == 1) SLS_WAVE_LAUNCH(1, 1, false);
-        else SLS_WAVE_LAUNCH(1, 2, false);
+    } else if (R <= 2 && a.stage_kinv && !a.solve_sigma && !coop) {
+        if (R == 1) SLS_WAVE_LAUNCH(1, 1, false, false);
+        else SLS_WAVE_LAUNCH(1, 2, false, false);
     } else {
-        if (a.stage_kinv) bytes -= kb;                // (the first-pass matrix alone is not staged in the solve mode)
+        if (a.stage_kinv) bytes -= kb;                // (the first-pass matrix alone is not staged in the solve / cooperative forms)
         a.stage_kinv = a.stage_xt = 0;
         if (R == 1) SLS_WAVE_BY_MODE(0, 1);
         else if (R == 2) SLS_WAVE_BY_MODE(0, 2);
-        else if (R == 4) SLS_WAVE_BY_MODE(0, 4);
-        else if (R == 6) SLS_WAVE_BY_MODE(0, 6);
-        else SLS_WAVE_BY_MODE(0, 8);
+        else if (R == 4) SLS_WAVE_BY_MODE_NOCOOP(0, 4);
+        else if (R == 6) SLS_WAVE_BY_MODE_NOCOOP(0, 6);
+        else SLS_WAVE_BY_MODE_NOCOOP(0, 8);
     }
+#undef SLS_WAVE_BY_MODE_NOCOOP
 #undef SLS_WAVE_BY_MODE
 #undef SLS_WAVE_LAUNCH
 }

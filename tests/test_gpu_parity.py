@@ -772,6 +772,36 @@ def test_wave_path_lds_staging_is_bit_identical(ctx, oracle, D, N, S, n_local, m
     gp.close()
 
 
+@pytest.mark.parametrize("sigma_mode", [0, 1])
+@pytest.mark.parametrize("D,N,n_local", [(1, 20, 40), (32, 61, 320), (32, 64, 60), (8, 65, 80), (16, 128, 50), (70, 100, 25)])
+def test_single_start_cooperative_form_is_bit_identical(ctx, oracle, D, N, n_local, sigma_mode, monkeypatch):
+    """A launch with ONE start (the local phase of the reference's DIRECT -> L-BFGS branch, src/acquisition-function.cpp:155-165) lets the
+    four waves of its workgroup share every long sum of an evaluation (kernels_wave.hip, COOP) instead of shadowing each other.  Every
+    sum is four fixed chains added as (c0 + c1) + (c2 + c3) whether one wave computes all four or four waves one each: the start
+    must end with exactly the bits it gets as one of many starts of a larger launch, with the cooperative form switched off
+    (SLS_WAVE_COOP=0), staged or not, in both sigma modes."""
+    monkeypatch.setenv("SLS_WAVE_PATH", "1")
+    X, y, theta, b = synth_problem(oracle, D, N)
+    starts = synth_candidates(oracle, D, 9)
+    gp = sls().GP(ctx, X, y, theta, b, 1)
+    gp.set_sigma_mode(sigma_mode)
+    many = gp.acq_maximize(starts, n_local)                      # one wave per start
+    for k in (0, 4):
+        one = gp.acq_maximize(starts[:, k:k + 1], n_local)       # cooperative
+        issued = gp.last_stats()["evals_issued"]
+        assert one["y_stars"][0] == many["y_stars"][k] and np.array_equal(one["x_stars"][:, 0], many["x_stars"][:, k])
+        monkeypatch.setenv("SLS_WAVE_COOP", "0")
+        solo = gp.acq_maximize(starts[:, k:k + 1], n_local)      # one wave, three shadows
+        assert solo["y_stars"][0] == one["y_stars"][0] and np.array_equal(solo["x_stars"], one["x_stars"])
+        assert gp.last_stats()["evals_issued"] == issued
+        monkeypatch.setenv("SLS_WAVE_STAGE", "0")
+        monkeypatch.delenv("SLS_WAVE_COOP")
+        unstaged = gp.acq_maximize(starts[:, k:k + 1], n_local)  # cooperative, K^-1 / X~ from global memory
+        assert unstaged["y_stars"][0] == one["y_stars"][0] and np.array_equal(unstaged["x_stars"], one["x_stars"])
+        monkeypatch.delenv("SLS_WAVE_STAGE")
+    gp.close()
+
+
 @pytest.mark.parametrize("kernel", [0, 1])
 @pytest.mark.parametrize("D,N,S", [(1, 20, 100), (32, 90, 10), (70, 300, 33), (128, 500, 9)])
 def test_wave_path_matches_tiled_path_and_oracle(ctx, oracle, kernel, D, N, S, monkeypatch):
