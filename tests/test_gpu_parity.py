@@ -772,6 +772,27 @@ def test_wave_path_lds_staging_is_bit_identical(ctx, oracle, D, N, S, n_local, m
     gp.close()
 
 
+@pytest.mark.parametrize("D,N,M", [(1, 9, 3), (32, 61, 160), (8, 300, 1000), (16, 500, 4096)])
+def test_value_only_small_evaluations_through_mapped_memory_are_bit_identical(ctx, oracle, D, N, M, monkeypatch):
+    """sls_acq_eval without gradients on a small problem (what every DIRECT iteration of FindNextPoint issues, src/acquisition-
+    function.cpp:155-165) reads its query points from and writes its values to page-locked memory the device maps -- one launch and
+    one synchronisation instead of upload + launch + download.  Values only move: the bits of the copying path (SLS_EVAL_ZEROCOPY=0)."""
+    monkeypatch.setenv("SLS_WAVE_PATH", "1")
+    X, y, theta, b = synth_problem(oracle, D, N)
+    Xs = synth_candidates(oracle, D, M)
+    gp = sls().GP(ctx, X, y, theta, b, 1)
+    for acq, h in ((0, 1.0), (1, 0.7)):
+        v1 = gp.acq_eval(Xs, acq, h, want_grad=False)
+        v1b = gp.acq_eval(Xs[:, :max(1, M // 3)], acq, h, want_grad=False)         # a smaller batch re-uses the block
+        monkeypatch.setenv("SLS_EVAL_ZEROCOPY", "0")
+        v0 = gp.acq_eval(Xs, acq, h, want_grad=False)
+        monkeypatch.delenv("SLS_EVAL_ZEROCOPY")
+        assert np.array_equal(v1, v0) and np.array_equal(v1b, v0[:max(1, M // 3)])
+        vo = oracle.Regressor(X, y, theta, b, kernel=1).acq_eval_batch(Xs[:, :64], acq, h, want_grad=False)
+        np.testing.assert_allclose(v1[:64], vo[:v1[:64].size], rtol=1e-6, atol=1e-9 * max(np.abs(vo).max(), 1e-30))
+    gp.close()
+
+
 @pytest.mark.parametrize("sigma_mode", [0, 1])
 @pytest.mark.parametrize("D,N,n_local", [(1, 20, 40), (32, 61, 320), (32, 64, 60), (8, 65, 80), (16, 128, 50), (70, 100, 25)])
 def test_single_start_cooperative_form_is_bit_identical(ctx, oracle, D, N, n_local, sigma_mode, monkeypatch):
