@@ -268,8 +268,32 @@ void sls_ctx::host_give(void* p, size_t bytes, bool mapped) {
     host_free.push_back(HostBlock{p, bytes, mapped});
 }
 
+static void ctx_destroy_now(sls_ctx* ctx);
+namespace slsk {
+void ctx_retain(sls_ctx* c) { ++c->live_handles; }
+void ctx_release(sls_ctx* c) {
+    bool last;
+    {
+        std::unique_lock<std::recursive_mutex> lock(c->mtx);
+        last = --c->live_handles == 0 && c->destroy_requested;
+    }
+    if (last) ctx_destroy_now(c);
+}
+}  // namespace slsk
+
 extern "C" int sls_ctx_destroy(sls_ctx* ctx) {
     if (!ctx) return SLS_OK;
+    {
+        std::unique_lock<std::recursive_mutex> lock(ctx->mtx);
+        if (ctx->live_handles > 0) {       // handles outlive the context: the last one frees it (slsk::ctx_release)
+            ctx->destroy_requested = true;
+            return SLS_OK;
+        }
+    }
+    ctx_destroy_now(ctx);
+    return SLS_OK;
+}
+static void ctx_destroy_now(sls_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& b : ctx->host_free) (void)hipHostFree(b.p);
@@ -280,7 +304,6 @@ extern "C" int sls_ctx_destroy(sls_ctx* ctx) {
     if (ctx->d_info) (void)hipFree(ctx->d_info);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
-    return SLS_OK;
 }
 
 extern "C" int sls_device_trim_cache(int device) {
@@ -433,18 +456,26 @@ static void gp_fit_device(sls_gp* g) {
     }
     SLS_HIP(hipMemsetAsync(c->d_info, 0, 64, c->stream));
     launch_fill(c->stream, g->Linv.p, (long)Np * Np, 0.0);
-    {
-        ProfScope ps(c, "potrf");
-        c->potrf_tick_rearm();
-        launch_potrf(c->stream, g->L.p, Np, g->Linv.p, c->d_info, 0, c->potrf_lookahead(Np), c->potrf_df_sync(Np));
-    }
-    {
-        ProfScope ps(c, "trtri");
-        launch_trtri(c->stream, g->L.p, Np, g->Linv.p, g->Kinv.p, g->U.p);
-    }
-    {
-        ProfScope ps(c, "lauum");
-        launch_lauum(c->stream, g->U.p, Np, g->Kinv.p);
+    c->potrf_tick_rearm();
+    int* df_sync = c->potrf_df_sync(Np);
+    if (potri_fused_applies(Np, df_sync != nullptr)) {
+        // N <= 4096: factorisation, L^-1, its transpose and K_y^-1 in ONE launch (the inverse is built behind the chain by the CUs the
+        // factorisation leaves idle)
+        ProfScope ps(c, "potri");
+        launch_potri(c->stream, g->L.p, Np, g->Linv.p, g->U.p, g->Kinv.p, c->d_info, c->potrf_lookahead(Np), df_sync);
+    } else {
+        {
+            ProfScope ps(c, "potrf");
+            launch_potrf(c->stream, g->L.p, Np, g->Linv.p, c->d_info, 0, c->potrf_lookahead(Np), df_sync);
+        }
+        {
+            ProfScope ps(c, "trtri");
+            launch_trtri(c->stream, g->L.p, Np, g->Linv.p, g->Kinv.p, g->U.p);
+        }
+        {
+            ProfScope ps(c, "lauum");
+            launch_lauum(c->stream, g->U.p, Np, g->Kinv.p);
+        }
     }
     // alpha = Linv^T (Linv y);  mu at the data points = y - b alpha;  x_best = first argmax  (regressor.cpp:29-43 hoisted)
     launch_gemv_n(c->stream, g->Linv.p, Np, g->y.p, g->tvec.p, g->gemv_part.p);
@@ -522,6 +553,7 @@ extern "C" int sls_gp_create(sls_ctx* ctx, const double* X, int D, int N, const 
     g->Xh.assign(X, X + (size_t)D * N);
     g->yh.assign(y, y + N);
     gp_setup(g.get());
+    slsk::ctx_retain(ctx);
     *out = g.release();
     SLS_CATCH
 }
@@ -546,10 +578,14 @@ extern "C" int sls_gp_refit_dev(sls_gp* g, const double* X_dev, const double* y_
 extern "C" int sls_gp_destroy(sls_gp* gp) {
     if (!gp) return SLS_OK;
     slsk::note_entry();
-    std::unique_lock<std::recursive_mutex> lock_(gp->ctx->mtx);
-    (void)hipSetDevice(gp->ctx->device);
-    (void)hipStreamSynchronize(gp->ctx->stream);
-    delete gp;
+    sls_ctx* c = gp->ctx;
+    {
+        std::unique_lock<std::recursive_mutex> lock_(c->mtx);
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        delete gp;
+    }
+    slsk::ctx_release(c);
     return SLS_OK;
 }
 

@@ -73,6 +73,7 @@ extern "C" int sls_nll_create(sls_ctx* ctx, const double* X, int D, int N, int k
     launch_fill(ctx->stream, h->ones.p, Np, 1.0);
     launch_fill(ctx->stream, h->y.p, Np, 0.0);
     SLS_HIP(hipStreamSynchronize(ctx->stream));
+    slsk::ctx_retain(ctx);
     *out = h.release();
     SLS_CATCH
 }
@@ -80,10 +81,14 @@ extern "C" int sls_nll_create(sls_ctx* ctx, const double* X, int D, int N, int k
 extern "C" int sls_nll_destroy(sls_nll* h) {
     if (!h) return SLS_OK;
     slsk::note_entry();
-    std::unique_lock<std::recursive_mutex> lock_(h->ctx->mtx);
-    (void)hipSetDevice(h->ctx->device);
-    (void)hipStreamSynchronize(h->ctx->stream);
-    delete h;
+    sls_ctx* c = h->ctx;
+    {
+        std::unique_lock<std::recursive_mutex> lock_(c->mtx);
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        delete h;
+    }
+    slsk::ctx_release(c);
     return SLS_OK;
 }
 
@@ -112,10 +117,9 @@ static bool nll_factor_enqueue(sls_nll* h, const double* theta, double b) {
     SLS_HIP(hipMemsetAsync(c->d_info, 0, 64, c->stream));
     launch_fill(c->stream, h->Linv.p, (long)Np * Np, 0.0);
     c->potrf_tick_rearm();
-    launch_potrf(c->stream, h->L.p, Np, h->Linv.p, c->d_info, 0, c->potrf_lookahead(Np), c->potrf_df_sync(Np));
     h->G.ensure((size_t)Np * Np);   // the gradient's weight matrix, written after the factorisation: holds (L^-1)^T until then
-    launch_trtri(c->stream, h->L.p, Np, h->Linv.p, h->Kinv.p, h->G.p);
-    launch_lauum(c->stream, h->G.p, Np, h->Kinv.p);
+    // N <= 4096: one launch for the factorisation and the inverse (launch_potri); otherwise potrf + trtri + lauum
+    launch_potri(c->stream, h->L.p, Np, h->Linv.p, h->G.p, h->Kinv.p, c->d_info, c->potrf_lookahead(Np), c->potrf_df_sync(Np));
     launch_logdet(c->stream, h->L.p, Np, N, h->scal.p + 4);
     return true;
 }

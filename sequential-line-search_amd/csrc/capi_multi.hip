@@ -154,6 +154,7 @@ extern "C" int sls_comm_create(sls_ctx* ctx, const char* id128, int rank, int wo
         ncclUniqueId id;
         std::memcpy(&id, id128, 128);
         SLS_NCCL(r->CommInitRank(&c->comm, world, id, rank));
+        slsk::ctx_retain(ctx);
         *out = c.release();
     } catch (const HipFail& f) { return f.code; }
     return SLS_OK;
@@ -161,10 +162,12 @@ extern "C" int sls_comm_create(sls_ctx* ctx, const char* id128, int rank, int wo
 
 extern "C" int sls_comm_destroy(sls_comm* c) {
     if (!c) return SLS_OK;
-    (void)hipSetDevice(c->ctx->device);
+    sls_ctx* ctx = c->ctx;
+    (void)hipSetDevice(ctx->device);
     if (c->comm && rccl()) (void)rccl()->CommDestroy(c->comm);
     if (c->d_buf) (void)hipFree(c->d_buf);
     delete c;
+    slsk::ctx_release(ctx);
     return SLS_OK;
 }
 

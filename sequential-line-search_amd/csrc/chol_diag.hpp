@@ -149,8 +149,11 @@ __device__ __forceinline__ void transpose_inverse_tiles(double* As, int fl, int 
 // 16x16 block rows/columns (nb16 = 8: the whole 128x128 block; smaller for the fused small-problem kernels, whose
 // identity padding needs no work).  On return (after the caller's barrier) the lower triangle of As holds L, the
 // strictly-upper tiles hold Linv^T and Ts the inverses of the diagonal tiles.
-template <bool FACTOR>
+// HAVE_T16 (with !FACTOR): Ts already holds the inverses of the diagonal tiles (the caller loaded the ones the factorisation
+// produced); wave 0 has no pivot chain to run and the block inverse is built around exactly those tiles.
+template <bool FACTOR, bool HAVE_T16 = false>
 __device__ __forceinline__ void chol_diag_steps(double* As, double* Ts, int* __restrict__ info, int global_off, int nb16) {
+    static_assert(!(FACTOR && HAVE_T16), "the factorisation produces the 16 x 16 inverses itself");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fl = lane & 15, fk = lane >> 4;
     // Per 16-column step kb (three barrier-separated phases; the strictly-upper tiles of As, unused by the factorisation,
@@ -166,7 +169,7 @@ __device__ __forceinline__ void chol_diag_steps(double* As, double* Ts, int* __r
 #endif
         DIAG_STAMP_T(0, 16 + 8 * kb + 0);
         if (wave == 0) {
-            diag16<FACTOR>(As, Ts + 256 * kb, c0, lane, info, global_off);
+            if constexpr (!HAVE_T16) diag16<FACTOR>(As, Ts + 256 * kb, c0, lane, info, global_off);
             DIAG_STAMP_T(0, 16 + 8 * kb + 1);
         } else {
             // tile j costs kb - j MFMA groups: waves 1..3 take j = {0, 5, 6}, {1, 4}, {2, 3} (10 / 9 / 9 groups at kb = 7)

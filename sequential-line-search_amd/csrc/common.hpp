@@ -88,6 +88,11 @@ struct sls_ctx {
     // One stream, one info word, one profiling table per context: every entry point that touches the device takes this
     // lock, so a context (and all handles created from it) may be used from several host threads, one call at a time.
     std::recursive_mutex mtx;
+    // handles (sls_gp, sls_nll, sls_comm) created from this context and still alive.  sls_ctx_destroy with live handles only marks
+    // the context: the last handle to go frees it (garbage-collected bindings destroy context and handles in no particular order,
+    // and a handle's destructor takes this lock).
+    int live_handles = 0;
+    bool destroy_requested = false;
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -128,6 +133,8 @@ struct sls_ctx {
 };
 
 namespace slsk {
+void ctx_retain(sls_ctx* c);     // a handle was created (caller holds c->mtx)
+void ctx_release(sls_ctx* c);    // a handle is gone (caller does NOT hold c->mtx: this may free the context)
 // RAII kernel-timing scope: records HIP events on the context's stream when profiling is enabled.
 struct ProfScope {
     sls_ctx* c;

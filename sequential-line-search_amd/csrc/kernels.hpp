@@ -257,6 +257,16 @@ bool launch_potrf_dataflow(hipStream_t s, double* A, int Np, double* Linv, int* 
 int potrf_dataflow_max_problems(int Np);
 bool launch_potrf_dataflow_batch(hipStream_t s, double* A, int Np, double* Linv, int* info, int* sync, int nprob, long strideA,
                                  long stride_sync, bool block_inverses, long long* trace = nullptr);
+// The same launch with a second team of workgroups that builds Linv = L^-1, U = Linv^T and Kinv = A^-1 behind the factorisation
+// (N <= 4096; kernels_chol.hip: potri_team).  launch_potri picks it when it applies and falls back to launch_potrf + launch_trtri
+// + launch_lauum otherwise (SLS_POTRI_FUSED=0: always); returns true when the fused launch ran.
+struct PotriFused {
+    double* U;
+    double* Kinv;
+};
+bool launch_potri_dataflow(hipStream_t s, double* A, int Np, double* Linv, double* U, double* Kinv, int* info, int* sync);
+bool potri_fused_applies(int Np, bool have_sync);   // sizes / switches only: the launch itself may still decline (too few CUs)
+bool launch_potri(hipStream_t s, double* A, int Np, double* Linv, double* U, double* Kinv, int* info, PotrfAux* aux, int* dataflow_sync);
 int potrf_default_mode(int Np);
 // side stream restricted by a CU mask that leaves `free_per_xcd` CUs of each of the 8 XCDs to other streams (0: plain stream)
 void potrf_aux_create(PotrfAux* aux, int free_per_xcd);

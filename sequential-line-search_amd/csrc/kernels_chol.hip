@@ -22,6 +22,9 @@
 #ifndef SLS_POTRF_MODE_DEFAULT
 #define SLS_POTRF_MODE_DEFAULT 3
 #endif
+#ifndef SLS_POTRF_STREAM_DEFAULT
+#define SLS_POTRF_STREAM_DEFAULT 0
+#endif
 
 namespace slsk {
 
@@ -208,7 +211,9 @@ void launch_gemm_splitk_nt(hipStream_t s, const double* A, long lda, const doubl
 // (chol_diag_kernel) and the single-launch persistent factorisation (potrf_persistent_kernel).
 // LOAD = false: the caller has already built the LDS image As (lower tiles of A, upper tiles zero) and passed a barrier.
 // WT: write-through (sc1) stores for L and T -- the caller publishes them with a drained flag instead of a release fence.
-template <bool FACTOR, bool LOAD = true, bool WT = false>
+// HAVE_T16 (!FACTOR, LOAD): the diagonal 16 x 16 tiles of Tout already hold the inverses of L's diagonal tiles (written by the
+// factorisation, and possibly still being read by its panel solves): they are loaded, not recomputed, and not stored again.
+template <bool FACTOR, bool LOAD = true, bool WT = false, bool HAVE_T16 = false>
 __device__ __forceinline__ void diag_block(double* __restrict__ A, long lda, double* __restrict__ Tout, long ldt,
                                            int* __restrict__ info, int global_off, char* smem) {
     double* As = reinterpret_cast<double*>(smem);   // [i + j*DL]
@@ -226,13 +231,20 @@ __device__ __forceinline__ void diag_block(double* __restrict__ A, long lda, dou
             if ((i2 >> 4) < (j >> 4)) v = d2_t{0.0, 0.0};
             *reinterpret_cast<d2_t*>(As + i2 + j * DL) = v;
         }
+        if (HAVE_T16) {
+            for (int q2 = tid; q2 < 1024; q2 += 256) {            // 8 tiles x 16 columns x 8 row pairs
+                const int t16i = q2 >> 7, c = (q2 >> 3) & 15, r2 = 2 * (q2 & 7);
+                *reinterpret_cast<d2_t*>(Ts + 256 * t16i + r2 + 16 * c) =
+                    *reinterpret_cast<const d2_t*>(Tout + (16 * t16i + r2) + (long)(16 * t16i + c) * ldt);
+            }
+        }
         __syncthreads();
     }
     DIAG_STAMP(2);
     auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(A, 0, 0x7fffffff, 0x00020000);
     auto rsrcT = __builtin_amdgcn_make_buffer_rsrc(Tout, 0, 0x7fffffff, 0x00020000);
 
-    chol_diag_steps<FACTOR>(As, Ts, info, global_off, 8);
+    chol_diag_steps<FACTOR, HAVE_T16>(As, Ts, info, global_off, 8);
     __syncthreads();
     DIAG_STAMP(3);
 #ifdef SLS_DIAG_SKIP_STOREL
@@ -273,7 +285,10 @@ __device__ __forceinline__ void diag_block(double* __restrict__ A, long lda, dou
             const int j = 4 * p + jc, tj = j >> 4;
             d2_t v = {0.0, 0.0};
             if (ti > tj) v = *reinterpret_cast<const d2_t*>(As + i2 + j * DL);
-            else if (ti == tj) v = *reinterpret_cast<const d2_t*>(Ts + 256 * ti + (i2 & 15) + 16 * (j & 15));
+            else if (ti == tj) {
+                if (HAVE_T16) continue;                           // already there, bit for bit
+                v = *reinterpret_cast<const d2_t*>(Ts + 256 * ti + (i2 & 15) + 16 * (j & 15));
+            }
             if (WT) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rsrcT, (int)((i2 + (long)j * ldt) * 8), 0, 16);
             else *reinterpret_cast<d2_t*>(Tout + (long)i2 + (long)j * ldt) = v;
         }
@@ -317,9 +332,20 @@ struct PersistArgs {
     int nprob;
     long strideA;
     long stride_sync;
+    // fused inverse (potri_team below; nprob == 1): workgroups [g1, gridDim.x) build X = L^-1 (Linv), U = X^T and K^-1 = U U^T
+    // behind the factorisation, inside the same launch.  g1 = 0: factorisation only.
+    int g1;
+    double* U;
+    double* Kinv;
+    int inv_cx, inv_ck;   // 128-blocks of the contraction per X / K^-1 accumulation task (fixed chunking)
+    // streamed panel tiles (stream_trsm): nchain = 2 adds the FOLLOWER workgroup, which solves the chain's panel tile (j+1, j)
+    // against the column blocks of L_jj while the chain is still factoring them; stream_rows: worker panel tiles (i, k) with
+    // i <= k + 1 + stream_rows are solved the same way.  nchain = 1: the round-3 chain (solve on the chain itself).
+    int nchain, stream_rows;
 };
 #define PK_STAMP(slot) do { if (a.trace && threadIdx.x == 0) a.trace[16 * j + (slot)] = wall_clock64(); } while (0)
 
+__device__ __forceinline__ int df_flag(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // one lane: spin (RELAXED polls -- an acquire load at agent scope would invalidate the XCD's L2 on every poll) until
 // *p >= target; false = aborted / timed out
 __device__ __forceinline__ bool pk_spin(int* p, int target, int* abort_flag, long long timeout) {
@@ -370,8 +396,11 @@ __device__ __forceinline__ void gemm_tile_deep(Acc& acc, const double* __restric
 // From the image every wave moves whole 1 KB columns with 16-byte accesses, all loads of a half tile in flight at once.
 // SUB: C -= acc, otherwise C = acc.  WT: write-through (sc1) stores -- the tile is read by other CUs next (the caller drains
 // and raises a flag), otherwise plain stores.  Values are only moved.
-template <bool SUB, bool WT>
+// MODE: 0 C = acc, 1 C -= acc, 2 C = -acc, 3 C += acc.  KEEP: the values stored are also written back into the image (the caller
+// then transposes it in place for the mirror tile: image_transpose_inplace).
+template <int MODE, bool WT, bool KEEP = false>
 __device__ __forceinline__ void tile_commit(double* __restrict__ C, long ld, const Acc& acc, double* img) {
+    constexpr bool SUB = MODE == 1 || MODE == 3;      // C is read
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -392,9 +421,43 @@ __device__ __forceinline__ void tile_commit(double* __restrict__ C, long ld, con
         for (int q = 0; q < 16; ++q) {
             const int c = w + 4 * (16 * h + q);
             d2_t v = *reinterpret_cast<const d2_t*>(img + 2 * lane + c * DL);
-            if (SUB) v = cv[q] - v;
+            if (MODE == 1) v = cv[q] - v;
+            else if (MODE == 2) v = -v;
+            else if (MODE == 3) v = cv[q] + v;
+            if (KEEP) *reinterpret_cast<d2_t*>(img + 2 * lane + c * DL) = v;
             if (WT) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rsrc, (int)((2 * lane + (long)c * ld) * 8), 0, 16);
             else *reinterpret_cast<d2_t*>(C + 2 * lane + (long)c * ld) = v;
+        }
+    }
+}
+
+// 128 x 128 LDS image [m + n DL] -> its transpose, in place.  The 36 units (28 pairs of 16 x 16 tiles (ti, tj) / (tj, ti) and the 8
+// diagonal tiles) are dealt to the four waves; inside a tile every 16-lane group walks a wrapped diagonal (row fl, column
+// fl + fk + 4 q mod 16), so the reads (column-major) and the writes (of the transposed positions) both touch 16 different banks
+// -- a straight transpose makes one side a 16-way conflict (transpose_inverse_tiles, chol_diag.hpp, uses the same walk).  A unit
+// touches only its own two tiles and reads both completely before it writes: no barrier inside; the caller brackets the call
+// with barriers.
+__device__ __forceinline__ void image_transpose_inplace(double* img) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fl = lane & 15, fk = lane >> 4;
+    for (int n = 0; n < 9; ++n) {
+        const int u = 4 * n + wave;
+        int ti = 0;
+        while ((ti + 1) * (ti + 2) / 2 <= u) ++ti;
+        const int tj = u - ti * (ti + 1) / 2;
+        double va[4], vb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int wr = (fl + fk + 4 * q) & 15;
+            va[q] = img[(16 * ti + fl) + (16 * tj + wr) * DL];      // tile (ti, tj), element (fl, wr)
+            vb[q] = img[(16 * tj + fl) + (16 * ti + wr) * DL];      // tile (tj, ti), element (fl, wr)
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // every read of the unit before its first write
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int wr = (fl + fk + 4 * q) & 15;
+            img[(16 * tj + wr) + (16 * ti + fl) * DL] = va[q];      // tile (tj, ti), element (wr, fl)
+            img[(16 * ti + wr) + (16 * tj + fl) * DL] = vb[q];      // tile (ti, tj), element (wr, fl)
         }
     }
 }
@@ -485,11 +548,152 @@ __device__ __forceinline__ void chain_trsm(ChainAcc& V, const double* __restrict
     __syncthreads();                                     // LDS free for the next user
 }
 
+// ---- streamed panel tiles ----------------------------------------------------------------------------------
+// The diagonal block publishes its column blocks WHILE it factors (StreamPublish below: column block s of L_jj and T16_s leave
+// right behind the panel tiles of its step s, `flag` counts 3 arrivals per block); a panel tile that is already complete can be
+// solved against them block by block instead of waiting for the whole diagonal block: X_s only needs the column blocks <= s.
+// Same arithmetic as chain_trsm (same slabs, same MFMA order: same bits); what differs is where the L slabs come from: slab s
+// is requested when its block is published (A slabs: three ahead, as before), a slab that is already published when the
+// previous step starts is requested one step early.  LDS: A ring 4 x 18 KB, L slabs 2 x 18 KB, T16 2 x 2 KB (behind the image).
+// false: the wait was aborted (another workgroup gave up or the bounded wait expired); the caller leaves the kernel.
+__device__ __forceinline__ bool stream_wait(int* flag, int target, int* abort_flag, long long timeout) {
+    int ok = 1;
+    if ((threadIdx.x & 63) == 0) ok = pk_spin(flag, target, abort_flag, timeout) ? 1 : 0;
+    return __builtin_amdgcn_readfirstlane(ok) != 0;
+}
+__device__ __forceinline__ bool stream_trsm(ChainAcc& V, const double* __restrict__ A, long lda, const double* __restrict__ L, long ldl,
+                                            const double* __restrict__ T, long ldt, int* flag, int* abort_flag, long long timeout,
+                                            double* lds) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fl = lane & 15, fk = lane >> 4;
+    const int mi[2] = {wave, 7 - wave};
+    constexpr int SLAB = GEMM_LDS_TILE;
+    double* Lbuf = lds + 4 * SLAB;                       // [2][SLAB]
+    double* Tbuf = lds + 128 * DL;                       // [2][256]: behind the image area (the workers keep scheduler state in the image's padding rows)
+    auto issueA = [&](int s) {
+        double* base = lds + (s & 3) * SLAB;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * wave + r;
+            slab_row_to_lds(A + 2 * lane + (long)(16 * s + row) * lda, base + row * GEMM_LDS_MC_LD);
+        }
+    };
+    auto issueL = [&](int s) {                           // this wave's four k-rows of column block s + (waves 0, 1) half of T16_s
+        double* base = Lbuf + (s & 1) * SLAB;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * wave + r;
+            slab_row_to_lds(L + 2 * lane + (long)(16 * s + row) * ldl, base + row * GEMM_LDS_MC_LD);
+        }
+        if (wave < 2)                                    // 8 columns x 128 bytes: lane -> (column 8 wave + lane / 8, row pair lane % 8)
+            slab_row_to_lds(T + (16 * s + 2 * (lane & 7)) + (long)(16 * s + 8 * wave + (lane >> 3)) * ldt, Tbuf + (s & 1) * 256 + 128 * wave);
+    };
+    V.zero();
+    issueA(0); issueA(1); issueA(2);
+    int issuedL = 0;                                     // column blocks this wave has requested
+    bool ok = true;
+    auto step = [&](auto S) {
+        constexpr int s = decltype(S)::value;
+        if (!ok) return;
+        if (issuedL <= s) {
+            if (!stream_wait(flag, 3 * (s + 1), abort_flag, timeout)) { ok = false; return; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            issueL(s);
+            issuedL = s + 1;
+        }
+        ring_wait_barrier<0>();                          // slab s of A and of L in LDS (every wave's part); slab s - 1 no longer read
+        if (s + 3 < 8) issueA(s + 3);                    // into the buffer of slab s - 1
+        if (s + 1 < 8) {                                 // the next block is already published: request it now, behind this step's compute
+            int have = 0;
+            if (lane == 0) have = df_flag(flag) >= 3 * (s + 2) ? 1 : 0;
+            if (__builtin_amdgcn_readfirstlane(have)) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                issueL(s + 1);
+                issuedL = s + 2;
+            }
+        }
+        const double* la = lds + (s & 3) * SLAB;         // A[:, 16 s ..]: element (m, kk) at la[kk * LD + m]
+        const double* lb = Lbuf + (s & 1) * SLAB;        // L[:, 16 s ..]
+        const double* tb = Tbuf + (s & 1) * 256;
+        double tf[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) tf[kk] = tb[fl + 16 * (4 * kk + fk)];   // T16_s[n = fl][k]
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            d4_t r;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r[q] = la[(fk + 4 * q) * GEMM_LDS_MC_LD + 16 * mi[a] + fl] - V.v[a][s][q];
+            d4_t x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) x = __builtin_amdgcn_mfma_f64_16x16x4f64(tf[kk], r[kk], x, 0, 0, 0);
+            V.v[a][s] = x;
+#pragma unroll
+            for (int c = s + 1; c < 8; ++c) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const double bf = lb[(fk + 4 * kk) * GEMM_LDS_MC_LD + 16 * c + fl];
+                    V.v[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf, x[kk], V.v[a][c], 0, 0, 0);
+                }
+            }
+        }
+    };
+    step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
+    step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+    step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
+    if (!ok) return false;
+    __syncthreads();                                     // LDS free for the next user
+    return true;
+}
+
+// chol_factor_steps' publish hook for the streamed panel tiles: run by waves 1-3 (192 threads) as soon as column block kb of the
+// LDS-resident factor is final.  Column block kb of L (16 columns, zeros above the diagonal) and T16_kb go to global memory
+// write-through; `flag` += 1 per wave and block once that wave's stores have drained.  The first three blocks are flagged one
+// step late (their stores have drained by then without a stall: waves 1-3 are the longer path in the first steps), the others
+// at once.
+struct StreamPublish {
+    double* A; long lda;
+    double* T; long ldt;
+    const double* As;
+    const double* Ts;
+    int* flag;
+    int flagged;
+    __device__ __forceinline__ void raise(int upto) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (flagged < upto) {
+            if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(flag, upto - flagged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            flagged = upto;
+        }
+    }
+    __device__ __forceinline__ void operator()(int kb) {
+        const int t = (int)threadIdx.x - 64;             // 0 .. 191
+        raise(kb);                                       // the blocks before this one: issued at least a step ago
+        auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(A, 0, 0x7fffffff, 0x00020000);
+        auto rsrcT = __builtin_amdgcn_make_buffer_rsrc(T, 0, 0x7fffffff, 0x00020000);
+        for (int idx = t; idx < 1024; idx += 192) {      // 16 columns x 64 row pairs
+            const int j = 16 * kb + (idx >> 6), i2 = 2 * (idx & 63);
+            d2_t v = *reinterpret_cast<const d2_t*>(As + i2 + j * DL);
+            if (i2 < j) v[0] = 0.0;
+            if (i2 + 1 < j) v[1] = 0.0;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rsrcA, (int)((i2 + (long)j * lda) * 8), 0, 16);
+        }
+        if (t < 128) {                                   // T16_kb: 16 columns x 8 row pairs
+            const int c = t >> 3, r2 = 2 * (t & 7);
+            const d2_t v = *reinterpret_cast<const d2_t*>(Ts + 256 * kb + r2 + 16 * c);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rsrcT, (int)(((16 * kb + r2) + (long)(16 * kb + c) * ldt) * 8), 0, 16);
+        }
+        if (kb >= 3) raise(kb + 1);
+    }
+};
+
 // Diagonal block of the TRSM form: factor only (chol_factor_steps), L stored write-through, and the eight 16 x 16 inverses
 // into the diagonal tiles of Tout (= their final place inside T_jj; the rest of T_jj comes from launch_diag_inverse).
+// stream_flag != nullptr: the column blocks are published as they become final (StreamPublish; *stream_flag = 24 on return)
+// instead of stored after the last step.
 template <bool LOAD>
 __device__ __forceinline__ void diag_block_factor(double* __restrict__ A, long lda, double* __restrict__ Tout, long ldt,
-                                                  int* __restrict__ info, int global_off, char* smem) {
+                                                  int* __restrict__ info, int global_off, char* smem, int* stream_flag = nullptr) {
     double* As = reinterpret_cast<double*>(smem);
     double* Ts = As + 128 * DL;
     const int tid = threadIdx.x;
@@ -503,6 +707,12 @@ __device__ __forceinline__ void diag_block_factor(double* __restrict__ A, long l
             *reinterpret_cast<d2_t*>(As + i2 + j * DL) = v;
         }
         __syncthreads();
+    }
+    if (stream_flag) {
+        StreamPublish pub{A, lda, Tout, ldt, As, Ts, stream_flag, 0};
+        chol_factor_steps(As, Ts, info, global_off, pub);
+        __syncthreads();
+        return;
     }
     chol_factor_steps(As, Ts, info, global_off);
     __syncthreads();
@@ -666,7 +876,6 @@ __device__ __forceinline__ int df_chunk_end(int k, int j0, int target, int nbo, 
     int j1 = (bj < bk && !(bj == bk - 1 && k - bk * nbo < near)) ? (bj + 1) * nbo : j0 + 1;
     return min(j1, target);
 }
-__device__ __forceinline__ int df_flag(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // every wave drains its write-through stores, then ONE flag operation
 __device__ __forceinline__ void df_publish_store(int* p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -679,11 +888,192 @@ __device__ __forceinline__ void df_publish_add(int* p) {
     if (threadIdx.x == 0) __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Fused inverse: K^-1 = (L L^T)^-1 inside the factorisation's launch (N <= 4096).
+//
+// A factorisation of this size is bound by its serial chain (48 us per 128 columns) and leaves most of the chip idle; the
+// separate trtri (recursive doubling: 3 launches per level) and lauum launches that followed it cost 0.43 ms at N = 2048 and
+// 1.0 ms at N = 4096 -- more than half of the factorisation itself.  Here a second team of workgroups (blockIdx >= g1) consumes the
+// factorisation's own flags and builds the inverse BEHIND the chain, tile by tile:
+//   T(j)     T_jj = L_jj^-1 (diag_block<false>), U_jj = T_jj^T                                   needs factored[j]
+//   X(i, j)  M = -(sum_{k=j}^{i-1} U_jk L_ik^T)  accumulated in the (unused) block (j, i) of U in fixed chunks of inv_cx blocks,
+//            then U_ji = M T_ii^T and X_ij = U_ji^T                                               needs xdone[k][j], panel_done[i][k], T(i)
+//   K(i, j)  K^-1_ij = sum_{k >= i} U_ik U_jk^T in fixed chunks of inv_ck blocks (+ the mirror tile)   needs xdone[k][i], xdone[k][j]
+// (block forward substitution X_ij = -T_ii sum_k L_ik X_kj, written for the transposes so that every product has both operands
+// M-contiguous: gemm_tile_mc).  One owner per item, fixed chunk boundaries: the bits do not depend on timing.  Items are dealt
+// round-robin in ONE global order -- T / X by row, then K by row -- that is consistent with the dependencies, so the globally
+// first unfinished item is always the first unfinished item of its owner: no circular wait.  The inverse's wavefront follows the
+// chain about one step behind (37-40 us per row against the chain's 48); after the last diagonal block remain T(nb-1), the last
+// row's products and the last chunk of every K^-1 tile (~75 us).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void potri_team(const PersistArgs& a, int b2, int G2, double* lds, char* smem) {
+    const int nb = a.nb;
+    const long ld = a.ld;
+    int* factored = a.sync + DF_FACT;
+    int* panel_done = a.sync + DF_FACT + 2 * nb;          // [i + j nb]
+    int* xdone = a.sync + DF_FACT + 2 * nb + nb * nb;     // [k + j nb], k >= j: X_kj / U_jk stored (k == j: T_jj / U_jj)
+    auto SW = [&](int arr, int k) -> int& { return reinterpret_cast<int*>(lds + k * DL + 128)[arr]; };
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        int nt = 0, turn = 0;                             // turn: position of the next item in the round-robin deal
+        auto deal = [&](int type, int i, int j) {
+            if (turn == b2 && nt < DF_MAXT) {
+                SW(0, nt) = i; SW(1, nt) = j; SW(2, nt) = 0; SW(3, nt) = 0; SW(6, nt) = type;
+                ++nt;
+            }
+            if (++turn == G2) turn = 0;
+        };
+        for (int r = 0; r < nb; ++r) {
+            deal(0, r, r);
+            for (int j = 0; j < r; ++j) deal(1, r, j);
+        }
+        for (int r = 0; r < nb; ++r)
+            for (int j = 0; j <= r; ++j) deal(2, r, j);
+        SW(5, 0) = nt;
+    }
+    __syncthreads();
+    const int nt = SW(5, 0);
+    if (nt <= 0) return;
+    int first = 0;
+    long long t_progress = wall_clock64();
+    const int slot = tid >> 4, l = tid & 15;
+    const int cx = a.inv_cx, ck = a.inv_ck;
+    for (;;) {
+        while (first < nt && SW(3, first)) ++first;
+        if (first >= nt) break;
+        {
+            const int t = first + slot;
+            const bool valid = t < nt && !SW(3, t);
+            bool ok = true;
+            if (valid) {
+                const int i = SW(0, t), j = SW(1, t), d = SW(2, t), type = SW(6, t);
+                if (type == 0) {
+                    if (l == 0) ok = df_flag(factored + i) >= (a.nchain == 2 ? 24 : 1);
+                } else if (type == 1) {
+                    if (d < i - j) {
+                        const int k0 = j + d, k1 = min(k0 + cx, i), k = k0 + (l & 7);
+                        if (k < k1) ok = df_flag(l < 8 ? xdone + k + (long)j * nb : panel_done + i + (long)k * nb) != 0;
+                    } else if (l == 0) {
+                        ok = df_flag(xdone + i + (long)i * nb) != 0;
+                    }
+                } else {
+                    const int k0 = i + d, k1 = min(k0 + ck, nb), k = k0 + (l & 7);
+                    if (k < k1) ok = df_flag(xdone + k + (long)(l < 8 ? i : j) * nb) != 0;
+                }
+            }
+            const unsigned long long m = __ballot(ok);
+            const unsigned grp = (unsigned)(m >> (16 * ((tid >> 4) & 3))) & 0xffffu;
+            if (l == 0) SW(4, slot) = (valid && grp == 0xffffu) ? 1 : 0;
+        }
+        __syncthreads();
+        int sel = -1;
+#pragma unroll
+        for (int q = DF_WIN - 1; q >= 0; --q)
+            if (SW(4, q)) sel = q;
+        __syncthreads();
+        if (sel < 0) {
+            if (__hip_atomic_load(a.info + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+            if (wall_clock64() - t_progress > a.timeout) {
+                if (tid == 0) __hip_atomic_store(a.info + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            __builtin_amdgcn_s_sleep(16);
+            continue;
+        }
+        if (tid < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
+        const int t = first + sel;
+        const int i = SW(0, t), j = SW(1, t), d = SW(2, t), type = SW(6, t);
+        if (type == 0) {
+            // T_jj around the eight 16 x 16 diagonal inverses the chain left (loaded, not recomputed: panel solves of the
+            // factorisation may still be reading them, and the bits must not depend on who comes first) and U_jj = T_jj^T.  After
+            // diag_block the strictly-upper tiles of the LDS image still hold the transposed inverse tiles, Ts the diagonal ones.
+            double* Ljj = a.A + (long)i * NB * (ld + 1);
+            double* Tjj = a.Linv + (long)i * NB * (ld + 1);
+            double* Ujj = a.U + (long)i * NB * (ld + 1);
+            diag_block<false, true, true, true>(Ljj, ld, Tjj, ld, nullptr, 0, smem);
+            const double* As = lds;
+            const double* Ts = lds + 128 * DL;
+            auto rsrcU = __builtin_amdgcn_make_buffer_rsrc(Ujj, 0, 0x7fffffff, 0x00020000);
+            const int i2 = 2 * (tid & 63), jc = tid >> 6, tr = i2 >> 4;
+#pragma unroll 8
+            for (int p = 0; p < 32; ++p) {
+                const int c = 4 * p + jc, tc = c >> 4;
+                d2_t v = {0.0, 0.0};
+                if (tr < tc) v = *reinterpret_cast<const d2_t*>(As + i2 + c * DL);
+                else if (tr == tc) {                           // U[r][c] = T16[c & 15][r & 15]: zero for r > c by construction
+                    v[0] = Ts[256 * tc + (c & 15) + 16 * (i2 & 15)];
+                    v[1] = Ts[256 * tc + (c & 15) + 16 * ((i2 + 1) & 15)];
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rsrcU, (int)((i2 + (long)c * ld) * 8), 0, 16);
+            }
+            df_publish_store(xdone + i + (long)i * nb);
+            if (tid == 0) SW(3, t) = 1;
+        } else if (type == 1) {
+            double* Mji = a.U + (long)j * NB + (long)i * NB * ld;              // block (j, i) of U: M until the last step, then U_ji
+            if (d < i - j) {
+                const int k0 = j + d, k1 = min(k0 + cx, i);
+                Acc acc;
+                acc.zero();
+                gemm_tile_mc<4, true>(acc, a.U + (long)j * NB + (long)k0 * NB * ld, ld, a.A + (long)i * NB + (long)k0 * NB * ld, ld, 0,
+                                      (k1 - k0) * NB, lds);
+                if (d == 0) tile_commit<2, false>(Mji, ld, acc, lds);
+                else tile_commit<1, false>(Mji, ld, acc, lds);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) SW(2, t) = k1 - j;
+            } else {
+                const double* Tii = a.Linv + (long)i * NB * (ld + 1);
+                Acc acc;
+                acc.zero();
+                gemm_tile_mc<4, true>(acc, Mji, ld, Tii, ld, 0, NB, lds);      // U_ji = M T_ii^T
+                tile_commit<0, true>(Mji, ld, acc, lds);
+                lds_barrier();
+                image_transpose_inplace(lds);
+                lds_barrier();
+                chain_image_store_wt(a.Linv + (long)i * NB + (long)j * NB * ld, ld, lds);   // X_ij = U_ji^T
+                df_publish_store(xdone + i + (long)j * nb);
+                if (tid == 0) SW(3, t) = 1;
+            }
+        } else {
+            const int k0 = i + d, k1 = min(k0 + ck, nb);
+            double* Kij = a.Kinv + (long)i * NB + (long)j * NB * ld;
+            Acc acc;
+            acc.zero();
+            gemm_tile_mc<4, true>(acc, a.U + (long)i * NB + (long)k0 * NB * ld, ld, a.U + (long)j * NB + (long)k0 * NB * ld, ld, 0,
+                                  (k1 - k0) * NB, lds);
+            if (k1 < nb) {
+                if (d == 0) tile_commit<0, false>(Kij, ld, acc, lds);
+                else tile_commit<3, false>(Kij, ld, acc, lds);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) SW(2, t) = k1 - i;
+            } else {
+                if (d == 0) tile_commit<0, false, true>(Kij, ld, acc, lds);
+                else tile_commit<3, false, true>(Kij, ld, acc, lds);
+                if (i != j) {                                                  // the mirror tile (K^-1 is used as a full matrix)
+                    lds_barrier();
+                    image_transpose_inplace(lds);
+                    lds_barrier();
+                    chain_image_store_wt(a.Kinv + (long)j * NB + (long)i * NB * ld, ld, lds);
+                }
+                if (tid == 0) SW(3, t) = 1;
+            }
+        }
+        __syncthreads();
+        t_progress = wall_clock64();
+    }
+}
+
 __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
+    if (a.g1 > 0 && (int)blockIdx.x >= a.g1) {
+        potri_team(a, (int)blockIdx.x - a.g1, (int)gridDim.x - a.g1, lds, smem);
+        return;
+    }
     // several independent problems share the launch: this workgroup's problem, its rank inside it, the problem's buffers
-    const int G = gridDim.x / a.nprob, q = blockIdx.x / G, b = blockIdx.x - q * G, nb = a.nb, nbo = a.nbo;
+    const int G = a.g1 > 0 ? a.g1 : gridDim.x / a.nprob, q = blockIdx.x / G, b = blockIdx.x - q * G, nb = a.nb, nbo = a.nbo;
     a.A += q * a.strideA;
     a.Linv += q * a.strideA;
     a.sync += q * a.stride_sync;
@@ -693,7 +1083,57 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
     int* factored = a.sync + DF_FACT;
     int* chain_ready = a.sync + DF_FACT + nb;
     int* panel_done = a.sync + DF_FACT + 2 * nb;        // [i + j nb]
-    constexpr int nchain = 1;
+    const int nchain = a.nchain;
+    if (b == 0 && nchain == 2) {
+        // ---- the chain, streamed form: diagonal blocks + the product L L^T; the panel tile comes from the follower ----
+        diag_block_factor<true>(a.A, ld, a.Linv, ld, a.info, 0, smem, factored + 0);
+        for (int j = 0; j <= nb - 2; ++j) {
+            double* Ajj = a.A + (long)j * NB * (ld + 1);
+            double* Tjj = a.Linv + (long)j * NB * (ld + 1);
+            double* Asub = Ajj + NB;                           // tile (j+1, j)
+            double* Anext = Ajj + (long)NB * (ld + 1);         // tile (j+1, j+1)
+            PK_STAMP(0);
+            if (!pk_wait_count(panel_done + (j + 1) + (long)j * nb, 1, a)) return;   // L_{j+1,j} stored by the follower
+            if (!pk_wait_count(chain_ready + j, 2, a)) return;                       // (j+1, j+1) carries its owner's updates
+            PK_STAMP(1);
+            {   // L_{j+1,j} -> LDS image: 128 columns of 1 KB, LDS-direct
+                const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll 8
+                for (int q = 0; q < 32; ++q) {
+                    const int c = w + 4 * q;
+                    slab_row_to_lds(Asub + 2 * lane + (long)c * ld, lds + c * DL);
+                }
+                ring_wait_barrier<0>();
+            }
+            PK_STAMP(2);
+            chain_syrk_inplace(lds);
+            PK_STAMP(8);
+            lds_barrier();
+            PK_STAMP(9);
+            chain_image_rsub(Anext, ld, lds);
+            __syncthreads();
+            PK_STAMP(3);
+            diag_block_factor<false>(Anext, ld, Tjj + (long)NB * (ld + 1), ld, a.info, (j + 1) * NB, smem, factored + j + 1);
+            PK_STAMP(4);
+        }
+        return;
+    }
+    if (b == 1 && nchain == 2) {
+        // ---- the follower: panel tile (j+1, j), solved block by block behind the chain's diagonal block j ----
+        for (int j = 0; j <= nb - 2; ++j) {
+            double* Ajj = a.A + (long)j * NB * (ld + 1);
+            double* Tjj = a.Linv + (long)j * NB * (ld + 1);
+            double* Asub = Ajj + NB;
+            if (!pk_wait_count(chain_ready + j, 2, a)) return; // tile (j+1, j) carries its owner's updates (steps < j)
+            ChainAcc ca;
+            if (!stream_trsm(ca, Asub, ld, Ajj, ld, Tjj, ld, factored + j, a.info + 1, a.timeout, lds)) return;
+            chain_acc_to_image<true>(ca, lds);
+            lds_barrier();
+            chain_image_store_wt(Asub, ld, lds);
+            df_publish_store(panel_done + (j + 1) + (long)j * nb);
+        }
+        return;
+    }
     if (b == 0) {
         // ---- the chain ----
         // Everything between two diagonal blocks stays in LDS: the panel tile L_{j+1,j} = A_{j+1,j} T_jj^T goes accumulators ->
@@ -798,7 +1238,10 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
                     const int j = j0 + (l & 7);
                     if (j < j1 && !(l >= 8 && i == k)) ok = df_flag(panel_done + (l < 8 ? i : k) + (long)j * nb) != 0;
                 } else if (i > k + 1) {
-                    if (l == 0) ok = df_flag(factored + k) != 0;
+                    // the whole diagonal block (24 = 3 waves x 8 column blocks in the streamed form, 1 otherwise), or its first
+                    // column block for the tiles that are solved block by block behind it
+                    const int need = nchain == 2 ? (i <= k + 1 + a.stream_rows ? 3 : 24) : 1;
+                    if (l == 0) ok = df_flag(factored + k) >= need;
                 }
             }
             const unsigned long long m = __ballot(ok);
@@ -839,10 +1282,10 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             const bool last = j1 == target;
             const bool to_chain = last && i <= k + 1;         // (k+1, k) and (k, k) go to the chain after their last update
             if (to_chain) {
-                tile_commit<true, true>(Cik, ld, acc, lds);
+                tile_commit<1, true>(Cik, ld, acc, lds);
                 df_publish_add(chain_ready + (i == k ? k - 1 : k));
             } else {
-                tile_commit<true, false>(Cik, ld, acc, lds);
+                tile_commit<1, false>(Cik, ld, acc, lds);
                 if (a.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st_rmw += wall_clock64() - st_g; }
                 __syncthreads();
             }
@@ -853,7 +1296,15 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             ++st_n_upd;
         } else if (i > k + 1) {
             ++st_n_panel;
-            {
+            if (nchain == 2 && i <= k + 1 + a.stream_rows) {
+                ChainAcc ca;
+                if (!stream_trsm(ca, Cik, ld, a.A + (long)k * NB * (ld + 1), ld, a.Linv + (long)k * NB * (ld + 1), ld, factored + k,
+                                 a.info + 1, a.timeout, lds))
+                    return;
+                chain_acc_to_image<true>(ca, lds);
+                lds_barrier();
+                chain_image_store_wt(Cik, ld, lds);
+            } else {
                 const double* Lkk = a.A + (long)k * NB * (ld + 1);
                 const double* Tkk = a.Linv + (long)k * NB * (ld + 1);              // its diagonal 16 x 16 tiles hold the small inverses
                 double* Ts = lds + 128 * DL;                                       // the eight small inverses -> LDS (16 KB)
@@ -962,7 +1413,7 @@ int potrf_dataflow_nbo(int Np) {
 // ints of device scratch the dataflow form needs per problem
 size_t potrf_dataflow_sync_ints(int Np) {
     const size_t nb = Np / NB;
-    return DF_FACT + 2 * nb + nb * nb;               // factored, chain_ready, panel_done[nb][nb]
+    return DF_FACT + 2 * nb + 2 * nb * nb;           // factored, chain_ready, panel_done[nb][nb], xdone[nb][nb] (fused inverse)
 }
 // How many independent Np x Np factorisations share one launch well: a problem keeps the chip busy with about nb^2 / 14.5 workers
 // (its ~nb^3 / 6 tile tasks of ~20 us against a chain of nb steps of ~48 us); the rest of the CUs can factor other problems.
@@ -977,9 +1428,11 @@ int potrf_dataflow_max_problems(int Np) {
 }
 // nprob problems (A + q strideA, Linv + q strideA, sync + q stride_sync ints, info + 2 q) in one launch.
 // false: not applicable (too few blocks / too many tiles per worker / the kernel cannot be resident once per CU) -- the caller
-// uses another schedule
-bool launch_potrf_dataflow_batch(hipStream_t s, double* A, int Np, double* Linv, int* info, int* sync, int nprob, long strideA,
-                                 long stride_sync, bool block_inverses, long long* trace) {
+// uses another schedule.
+// inv != nullptr (nprob == 1): the fused inverse (potri_team) -- Linv, inv->U and inv->Kinv are complete when the launch ends;
+// false if the matrix is too large for it (N > 4096: the chip is busy with the factorisation itself) or too few CUs remain.
+static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double* Linv, int* info, int* sync, int nprob, long strideA,
+                                       long stride_sync, bool block_inverses, long long* trace, const PotriFused* inv) {
     ensure_dyn_lds((const void*)potrf_dataflow_kernel, DIAG_LDS_BYTES);
     const int nb = Np / NB;
     PersistSerial& ps = persist_serial_of_current_device();
@@ -994,10 +1447,26 @@ bool launch_potrf_dataflow_batch(hipStream_t s, double* A, int Np, double* Linv,
     // (a second chain workgroup that followed the factorisation with a streamed solve was measured again in round 4 -- 0.384 / 0.767 /
     // 1.661 / 4.37 ms against 0.395 / 0.781 / 1.599 / 4.09 ms at N = 1024 / 2048 / 4096 / 8192, profiles/r04_potrf_chain2.log -- and
     // removed: the step is bound by the owners' panel + update path, not by the chain alone)
-    constexpr int nchain = 1;
-    const int Gp = std::max(nchain + 1, std::min(n_cu / nprob, nchain + tiles));   // workgroups per problem
+    // streamed panel tiles: a follower workgroup next to the chain (SLS_POTRF_STREAM=0: the chain solves its panel tile itself)
+    const int nchain = envi("SLS_POTRF_STREAM", SLS_POTRF_STREAM_DEFAULT) != 0 && nb >= 4 ? 2 : 1;
+    int Gp = std::max(nchain + 1, std::min(n_cu / nprob, nchain + tiles));   // workgroups per problem
+    int G2 = 0;
+    if (inv) {
+        if (nprob != 1 || nb < 3 || nb > 32 || !inv->U || !inv->Kinv) return false;
+        // the factorisation's team: the chain bounds a factorisation of this size, ~nb^2 / 14.5 workers keep up with it; the rest of
+        // the chip builds the inverse.  Measured (tools/probes/potri_scan.sh; ms, factor + inverse): N = 4096: 96 workers 2.12,
+        // 80: 2.22, 112: 2.26, 136: 2.56, 48: 3.05 (separate launches: 2.62); N = 3072: 1.46-1.50 for 80-112 (1.92);
+        // N = 2048: 0.84-0.86 for 80-112, 0.89 for 135 (1.18); same bits for every split
+        const int w1_dflt = std::min(tiles, std::max(3 * n_cu / 8, 3 * nb));
+        const int W1 = std::max(1, std::min(tiles, envi("SLS_POTRI_W1", w1_dflt)));
+        Gp = nchain + W1;
+        G2 = n_cu * ps.resident_per_cu - Gp;
+        const int items = nb + nb * nb;
+        if (G2 < 8 || (items + G2 - 1) / G2 > DF_MAXT) return false;
+        G2 = std::min(G2, items);
+    }
     const int W = Gp - nchain;
-    if (Gp * nprob > n_cu * ps.resident_per_cu || (tiles + W - 1) / W > DF_MAXT) return false;
+    if (Gp * nprob + G2 > n_cu * ps.resident_per_cu || (tiles + W - 1) / W > DF_MAXT) return false;
     const size_t sync_ints = potrf_dataflow_sync_ints(Np);
     if (nprob > 1 && (size_t)stride_sync < sync_ints) return false;
     for (int q = 0; q < nprob; ++q) (void)hipMemsetAsync(sync + q * stride_sync, 0, sync_ints * sizeof(int), s);
@@ -1008,17 +1477,33 @@ bool launch_potrf_dataflow_batch(hipStream_t s, double* A, int Np, double* Linv,
     a.nbo = potrf_dataflow_nbo(Np);
     a.near = envi("SLS_POTRF_DNEAR", Np >= 16384 ? 3 : 0);
     a.nprob = nprob; a.strideA = strideA; a.stride_sync = stride_sync;
+    a.g1 = inv ? Gp : 0;
+    a.U = inv ? inv->U : nullptr;
+    a.Kinv = inv ? inv->Kinv : nullptr;
+    a.nchain = nchain;
+    a.stream_rows = std::max(0, envi("SLS_POTRF_STREAM_ROWS", 1));
+    a.inv_cx = std::max(1, std::min(8, envi("SLS_POTRI_CX", nb > 16 ? 2 : 1)));
+    a.inv_ck = std::max(1, std::min(8, envi("SLS_POTRI_CK", nb > 16 ? 2 : 1)));
     {
         PersistSerialScope serial(ps, s);
-        hipLaunchKernelGGL(potrf_dataflow_kernel, dim3(Gp * nprob), dim3(256), DIAG_LDS_BYTES, s, a);
+        hipLaunchKernelGGL(potrf_dataflow_kernel, dim3(Gp * nprob + G2), dim3(256), DIAG_LDS_BYTES, s, a);
     }
-    // T_jj for every diagonal block, off the factorisation's serial chain (callers that only need the factor skip it)
-    if (block_inverses)
+    // T_jj for every diagonal block, off the factorisation's serial chain (callers that only need the factor skip it; the fused
+    // inverse builds them itself)
+    if (block_inverses && !inv)
         for (int q = 0; q < nprob; ++q) launch_diag_inverse(s, A + q * strideA, Np, Linv + q * strideA);
     return true;
 }
+bool launch_potrf_dataflow_batch(hipStream_t s, double* A, int Np, double* Linv, int* info, int* sync, int nprob, long strideA,
+                                 long stride_sync, bool block_inverses, long long* trace) {
+    return launch_potrf_dataflow_impl(s, A, Np, Linv, info, sync, nprob, strideA, stride_sync, block_inverses, trace, nullptr);
+}
 bool launch_potrf_dataflow(hipStream_t s, double* A, int Np, double* Linv, int* info, int* sync, long long* trace) {
-    return launch_potrf_dataflow_batch(s, A, Np, Linv, info, sync, 1, 0, 0, true, trace);
+    return launch_potrf_dataflow_impl(s, A, Np, Linv, info, sync, 1, 0, 0, true, trace, nullptr);
+}
+bool launch_potri_dataflow(hipStream_t s, double* A, int Np, double* Linv, double* U, double* Kinv, int* info, int* sync) {
+    const PotriFused inv{U, Kinv};
+    return launch_potrf_dataflow_impl(s, A, Np, Linv, info, sync, 1, 0, 0, false, nullptr, &inv);
 }
 
 // Two-level right-looking factorisation.  Outer blocks of `nbo` 128-columns: inside an outer block every 128-step is
@@ -1232,6 +1717,25 @@ void launch_lauum(hipStream_t s, const double* U, int Np, double* Kinv) {
     if (narrow) launch_tri_gemm_mc_half(s, g, 1);
     else launch_tri_gemm<false, false>(s, g, 1);
     hipLaunchKernelGGL(symmetrize_kernel, dim3(Np / 32, Np / 32), dim3(256), 0, s, Kinv, Np);
+}
+
+// A (SPD, lower triangle read) -> L in place, Linv = L^-1, U = Linv^T (blocks on and above the diagonal), Kinv = A^-1 (full).
+// N <= 4096 with the single-launch schedule available: ONE launch (factorisation + fused inverse, potri_team); otherwise
+// launch_potrf + launch_trtri + launch_lauum.  SLS_POTRI_FUSED=0 forces the separate launches (A/B, tests).  Returns true when
+// the fused launch was used.  As with launch_potrf, info[1] != 0 afterwards means the single launch gave up: repeat on the
+// multi-launch schedule (dataflow_sync = nullptr).
+bool potri_fused_applies(int Np, bool have_sync) {
+    const int nb = Np / NB;
+    const char* e = getenv("SLS_POTRI_FUSED");
+    return (!e || atoi(e) != 0) && have_sync && nb >= 3 && nb <= 32 && potrf_default_mode(Np) == 3;
+}
+bool launch_potri(hipStream_t s, double* A, int Np, double* Linv, double* U, double* Kinv, int* info, PotrfAux* aux, int* dataflow_sync) {
+    if (potri_fused_applies(Np, dataflow_sync != nullptr) && launch_potri_dataflow(s, A, Np, Linv, U, Kinv, info, dataflow_sync))
+        return true;
+    launch_potrf(s, A, Np, Linv, info, 0, aux, dataflow_sync);
+    launch_trtri(s, A, Np, Linv, Kinv, U);
+    launch_lauum(s, U, Np, Kinv);
+    return false;
 }
 
 // B <- (L L^T)^-1 B, B is Np x Rp (ld = Np).  Block forward / backward substitution, each step two tile GEMMs.

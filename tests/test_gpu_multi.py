@@ -205,3 +205,29 @@ def test_map_objective_batch_over_logical_shards_is_bit_identical(oracle, N):
     mg.close()
     c.close()
     assert np.array_equal(one, three)
+
+
+def test_handles_may_outlive_their_context(oracle):
+    """A garbage-collected binding destroys context and handles in no particular order (interpreter exit: the weak references
+    Context.close walks are already dead): sls_ctx_destroy with live handles only marks the context, the handles keep working, and
+    the last one to be destroyed frees it -- before, the handle's destructor locked a freed mutex."""
+    m = sls()
+    lib = m.lib()
+    X, y, theta, b = synth_problem(oracle, 4, 200)
+    Xs = synth_candidates(oracle, 4, 16)
+    c = m.Context(0)
+    g = m.GP(c, X, y, theta, b, 1)
+    h = m.Nll(c, X, 1)
+    mu0, s0 = g.predict(Xs)
+    assert lib.sls_ctx_destroy(c.h) == 0          # the context goes first
+    c.h = None
+    mu1, s1 = g.predict(Xs)                          # ... and its handles still work
+    assert np.array_equal(mu0, mu1) and np.array_equal(s0, s1)
+    v, _ = h.gp_objective(y, np.concatenate([[0.5, 0.01], np.full(4, 0.5)]))
+    assert np.isfinite(v)
+    g.close()
+    h.close()                                        # the last handle frees the context
+    c2 = m.Context(0)                                # and the device is still usable
+    g2 = m.GP(c2, X, y, theta, b, 1)
+    assert np.array_equal(g2.predict(Xs)[0], mu0)
+    g2.close(); c2.close()

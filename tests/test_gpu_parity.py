@@ -107,6 +107,83 @@ def test_potrf_schedules_agree(N, monkeypatch):
     close(res["multi2"], res["multi"], rtol=1e-12, atol=1e-13)
 
 
+@pytest.mark.parametrize("N,D", [(300, 4), (640, 7), (1500, 16), (2304, 5)])
+def test_fused_inverse_matches_separate_launches(oracle, N, D, monkeypatch):
+    """N <= 4096: ONE launch factors K_y and builds L^-1, its transpose and K_y^-1 behind the factorisation's chain (kernels_chol.hip:
+    potri_team), in place of potrf + trtri + lauum (src/gaussian-process-regressor.cpp:159, 211, 231: MatrixXd::inverse()).  The
+    factor must have the bits of the factorisation alone (who shares the chip never changes a tile's arithmetic), the inverse
+    must agree with the separate launches to rounding (block forward substitution vs recursive doubling) and with LAPACK, the result
+    must not depend on how the chip is split between the two teams, and a forced give-up of the launch must end in the
+    multi-launch recomputation."""
+    m = sls()
+    X, y, theta, b = synth_problem(oracle, D, N)
+    Xs = synth_candidates(oracle, D, 96)
+    out = {}
+    for name, env in (("fused", {}), ("separate", {"SLS_POTRI_FUSED": "0"}), ("fused_small_team", {"SLS_POTRI_W1": "7"}),
+                      ("fused_chunks", {"SLS_POTRI_CX": "3", "SLS_POTRI_CK": "2"})):
+        for k in ("SLS_POTRI_FUSED", "SLS_POTRI_W1", "SLS_POTRI_CX", "SLS_POTRI_CK"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = m.Context(0)
+        c.prof_enable(True)
+        g = m.GP(c, X, y, theta, b, 1)
+        mu, sg = g.predict(Xs)
+        out[name] = dict(L=g.matrix(m.GP_CHOL_L), Kinv=g.matrix(m.GP_K_Y_INV), alpha=g.matrix(m.GP_ALPHA), mu=mu, sg=sg,
+                         K=g.matrix(m.GP_K_Y), launches=c.prof_get("potri")[1], logdet=g.summary()["logdet"])
+        assert c.prof_get("potrf_fallbacks")[1] == 0
+        g.close(); c.close()
+    f, s = out["fused"], out["separate"]
+    assert f["launches"] == 1 and s["launches"] == 0                       # the fused launch really ran / really did not
+    assert np.array_equal(f["L"], s["L"]) and f["logdet"] == s["logdet"]
+    scale = np.abs(s["Kinv"]).max()
+    close(f["Kinv"], s["Kinv"], rtol=1e-9, atol=1e-11 * scale)
+    assert np.array_equal(f["Kinv"], f["Kinv"].T)
+    close(f["alpha"], s["alpha"], rtol=1e-8, atol=1e-10 * np.abs(s["alpha"]).max())
+    close(f["mu"], s["mu"], rtol=1e-9, atol=1e-12)
+    close(f["sg"], s["sg"], rtol=1e-7, atol=1e-12)
+    # against LAPACK: K_y K_y^-1 = I
+    R = f["K"] @ f["Kinv"] - np.eye(N)
+    assert np.abs(R).max() < 1e-9 * np.linalg.cond(f["K"]) ** 0.5 + 1e-10, np.abs(R).max()
+    close(f["Kinv"], np.linalg.inv(f["K"]), rtol=0, atol=1e-9 * scale)
+    # another split of the chip: same bits; another (fixed) chunking of the accumulations: rounding only
+    for key in ("L", "Kinv", "alpha", "mu", "sg"):
+        assert np.array_equal(out["fused_small_team"][key], f[key]), key
+    close(out["fused_chunks"]["Kinv"], f["Kinv"], rtol=1e-9, atol=1e-11 * scale)
+    # forced expiry of the device-side waits: the fit is recomputed with separate launches
+    for k in ("SLS_POTRI_FUSED", "SLS_POTRI_W1", "SLS_POTRI_CX", "SLS_POTRI_CK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("SLS_POTRF_TIMEOUT_TICKS", "1")
+    c = m.Context(0)
+    g = m.GP(c, X, y, theta, b, 1)
+    Kg = g.matrix(m.GP_K_Y_INV)
+    assert c.prof_get("potrf_fallbacks")[1] == 1
+    close(Kg, s["Kinv"], rtol=1e-9, atol=1e-11 * scale)
+    g.close(); c.close()
+
+
+@pytest.mark.parametrize("N,D", [(700, 5), (2100, 12)])
+def test_fused_inverse_inside_the_map_objective(oracle, N, D, monkeypatch):
+    """The GP MAP objective + gradient (sls_gp_nll_grad, src/gaussian-process-regressor.cpp:36-193) on the fused factor + inverse
+    launch against the same evaluation on separate launches."""
+    m = sls()
+    X, y, _, _ = synth_problem(oracle, D, N)
+    x = np.concatenate([[0.6, 0.01], np.linspace(0.4, 0.9, D)])
+    res = {}
+    for name, env in (("fused", {}), ("separate", {"SLS_POTRI_FUSED": "0"})):
+        monkeypatch.delenv("SLS_POTRI_FUSED", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = m.Context(0)
+        h = m.Nll(c, X, 1)
+        res[name] = h.gp_objective(y, x)
+        assert c.prof_get("potrf_fallbacks")[1] == 0
+        h.close(); c.close()
+    np.testing.assert_allclose(res["fused"][0], res["separate"][0], rtol=1e-11)
+    g0 = res["separate"][1]
+    np.testing.assert_allclose(res["fused"][1], g0, rtol=1e-7, atol=1e-9 * np.abs(g0).max())
+
+
 def test_potrf_rejects_indefinite(ctx):
     A = np.eye(200)
     A[150, 150] = -1.0

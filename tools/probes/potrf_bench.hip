@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdio>
 #include <set>
+#include <string>
 #include <vector>
 
 __global__ void fill_spd(double* A, int Np) {
@@ -152,6 +153,66 @@ int main(int argc, char** argv) {
                 hipFree(tr);
             }
             hipFree(dsync);
+        }
+        if (getenv("POTRF_BENCH_POTRI")) {
+            // factor + inverse: separate launches (potrf dataflow + diag inverses + trtri + lauum) against the fused single launch
+            // (launch_potri_dataflow); max deviations of L^-1 (lower), U = (L^-1)^T (blocks on / above the diagonal) and K^-1 (full)
+            double *X1, *U1, *K1, *X2, *U2, *K2;
+            hipMalloc(&X1, bytes); hipMalloc(&U1, bytes); hipMalloc(&K1, bytes); hipMalloc(&X2, bytes); hipMalloc(&U2, bytes); hipMalloc(&K2, bytes);
+            int* dsync; hipMalloc(&dsync, potrf_dataflow_sync_ints(Np) * sizeof(int));
+            auto timeit = [&](bool fused, double* X, double* U, double* K) {
+                float best = 1e30f; bool ok = true;
+                for (int rep = 0; rep < 5 && ok; ++rep) {
+                    hipMemcpyAsync(A, A0, bytes, hipMemcpyDeviceToDevice, s);
+                    hipMemsetAsync(info, 0, 64, s);
+                    hipMemsetAsync(X, 0, bytes, s);
+                    hipMemsetAsync(U, fused ? 0xff : 0, bytes, s);      // the fused form must not depend on the contents of U / K
+                    hipMemsetAsync(K, fused ? 0xff : 0, bytes, s);
+                    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+                    hipEventRecord(e0, s);
+                    if (fused) ok = launch_potri_dataflow(s, A, Np, X, U, K, info, dsync);
+                    else {
+                        ok = launch_potrf_dataflow(s, A, Np, X, info, dsync);
+                        launch_trtri(s, A, Np, X, K, U);
+                        launch_lauum(s, U, Np, K);
+                    }
+                    hipEventRecord(e1, s); hipEventSynchronize(e1);
+                    float ms; hipEventElapsedTime(&ms, e0, e1);
+                    if (rep > 0 && ms < best) best = ms;
+                }
+                int inf2[2] = {0, 0}; hipMemcpy(inf2, info, 8, hipMemcpyDeviceToHost);
+                printf("N=%5d %-34s %8.3f ms  info=%d abort=%d applicable=%d\n", Np, fused ? "potri fused single launch" : "potrf + trtri + lauum", best,
+                       inf2[0], inf2[1], (int)ok);
+                return ok;
+            };
+            timeit(false, X1, U1, K1);
+            if (timeit(true, X2, U2, K2)) {
+                std::vector<double> hx1((size_t)Np * Np), hx2((size_t)Np * Np);
+                auto cmp = [&](const double* d1, const double* d2, int mode, const char* name) {   // mode 0 lower, 1 upper blocks, 2 full
+                    hipMemcpy(hx1.data(), d1, bytes, hipMemcpyDeviceToHost); hipMemcpy(hx2.data(), d2, bytes, hipMemcpyDeviceToHost);
+                    double md = 0.0, mx = 0.0; long bad = 0;
+                    for (long j = 0; j < Np; ++j)
+                        for (long i = 0; i < Np; ++i) {
+                            if (mode == 0 && i < j) continue;
+                            if (mode == 1 && (i / 128) > (j / 128)) continue;
+                            const double a = hx1[i + j * Np], b = hx2[i + j * Np];
+                            if (!(fabs(a - b) <= 1e300)) { ++bad; continue; }
+                            md = fmax(md, fabs(a - b)); mx = fmax(mx, fabs(a));
+                        }
+                    printf("    %-6s max|fused - separate| = %.3e (max |value| %.3e, non-finite %ld)\n", name, md, mx, bad);
+                };
+                cmp(X1, X2, 0, "L^-1"); cmp(U1, U2, 1, "U"); cmp(K1, K2, 2, "K^-1");
+                // the fused form once more with another split of the chip between the two teams: must give the same bits
+                const char* w1 = getenv("SLS_POTRI_W1");
+                const std::string keep = w1 ? w1 : "";
+                setenv("SLS_POTRI_W1", Np <= 1024 ? "5" : "71", 1);
+                if (timeit(true, X1, U1, K1)) {
+                    printf("  same bits with another team split?\n");
+                    cmp(X1, X2, 0, "L^-1"); cmp(U1, U2, 1, "U"); cmp(K1, K2, 2, "K^-1");
+                }
+                if (w1) setenv("SLS_POTRI_W1", keep.c_str(), 1); else unsetenv("SLS_POTRI_W1");
+            }
+            hipFree(X1); hipFree(U1); hipFree(K1); hipFree(X2); hipFree(U2); hipFree(K2); hipFree(dsync);
         }
         if (getenv("POTRF_BENCH_BATCH")) {
             // P independent factorisations of the same matrix in ONE launch, each on 1/P of the chip's workgroups, against P launches

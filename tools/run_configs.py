@@ -1,6 +1,7 @@
 """All five BASELINE.json configs on one MI355X (C4 itself is bench.py): wall-clock timings -> gpurun_out/configs.json
 (copied to profiles/r0N_configs.json)."""
-import json, os, re, subprocess, sys, time
+import faulthandler, json, os, re, subprocess, sys, time
+faulthandler.dump_traceback_later(150, exit=True)      # a stuck device call shows where
 os.environ.setdefault("OMP_NUM_THREADS", "64")
 import numpy as np
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.join(R, "tests")); sys.path.insert(0, R)
@@ -35,7 +36,7 @@ out["C2_gp_fit_predict_N2048_D16_M4096"] = {"fit_ms_wall_incl_upload": wall(lamb
                                             "predict_ms_wall_incl_pcie": wall(lambda: gp.predict(Xs))}
 ctx.prof_enable(True); ctx.prof_reset()
 for _ in range(3): m.GP(ctx, X, y, theta, b, 0).close()
-out["C2_gp_fit_predict_N2048_D16_M4096"]["fit_device_ms_by_stage"] = {k: ctx.prof_get(k)[0] / 3 for k in ("gram", "potrf", "trtri", "lauum")}
+out["C2_gp_fit_predict_N2048_D16_M4096"]["fit_device_ms_by_stage"] = {k: ctx.prof_get(k)[0] / 3 for k in ("gram", "potri", "potrf", "trtri", "lauum")}   # potri: the fused factor + inverse launch
 ctx.prof_enable(False)
 t0 = time.perf_counter(); ref = oracle.Regressor(X, y, theta, b, kernel=0); t1 = time.perf_counter(); ref.predict_batch(Xs); t2 = time.perf_counter()
 out["C2_gp_fit_predict_N2048_D16_M4096"]["cpu_oracle_fit_s"] = t1 - t0
@@ -154,3 +155,6 @@ for n in (32, 64, 128, 256, 512):
 out["crossover_N_gpu_faster_than_cpu_oracle"] = cross
 json.dump(out, open(os.path.join(R, "gpurun_out", "configs.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
+stamp("results written")
+h.close(); stamp("nll handle closed")
+ctx.close(); stamp("context closed")
