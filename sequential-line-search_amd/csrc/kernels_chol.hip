@@ -23,7 +23,7 @@
 #define SLS_POTRF_MODE_DEFAULT 3
 #endif
 #ifndef SLS_POTRF_STREAM_DEFAULT
-#define SLS_POTRF_STREAM_DEFAULT 0
+#define SLS_POTRF_STREAM_DEFAULT 1
 #endif
 
 namespace slsk {
@@ -338,10 +338,14 @@ struct PersistArgs {
     double* U;
     double* Kinv;
     int inv_cx, inv_ck;   // 128-blocks of the contraction per X / K^-1 accumulation task (fixed chunking)
+    int inv_ksplit;       // K^-1 tiles of the rows >= inv_ksplit are accumulated by the factorisation's workers (potri_k_task)
     // streamed panel tiles (stream_trsm): nchain = 2 adds the FOLLOWER workgroup, which solves the chain's panel tile (j+1, j)
     // against the column blocks of L_jj while the chain is still factoring them; stream_rows: worker panel tiles (i, k) with
     // i <= k + 1 + stream_rows are solved the same way.  nchain = 1: the round-3 chain (solve on the chain itself).
     int nchain, stream_rows;
+    // split_sub: the sub-diagonal tiles (k+1, k) -- whose last update sits between the follower's solve of step k-1 and its solve
+    // of step k -- have one owner per 64-column half (gemm_tile_mc<2>: same slabs, same k order, same bits)
+    int split_sub;
 };
 #define PK_STAMP(slot) do { if (a.trace && threadIdx.x == 0) a.trace[16 * j + (slot)] = wall_clock64(); } while (0)
 
@@ -428,6 +432,38 @@ __device__ __forceinline__ void tile_commit(double* __restrict__ C, long ld, con
             if (WT) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rsrc, (int)((2 * lane + (long)c * ld) * 8), 0, 16);
             else *reinterpret_cast<d2_t*>(C + 2 * lane + (long)c * ld) = v;
         }
+    }
+}
+
+// The same for HALF a tile: the 64 columns [64 nhalf, 64 nhalf + 64) that gemm_tile_mc<2> leaves in acc.v[.][0..1] (wave (wm, sub):
+// 64 rows x 32 columns at column 64 nhalf + 32 sub).  Sub-diagonal tiles of the streamed factorisation have one owner per half.
+template <int MODE, bool WT>
+__device__ __forceinline__ void tile_commit_half(double* __restrict__ C, long ld, const Acc& acc, double* img, int nhalf) {
+    constexpr bool SUB = MODE == 1 || MODE == 3;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n0 = 64 * nhalf + (w >> 1) * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) img[acc_m(i) + (n0 + 16 * jj + (lane >> 4) + 4 * r) * DL] = acc.v[i][jj][r];
+    lds_barrier();
+    auto rsrc = __builtin_amdgcn_make_buffer_rsrc(C, 0, 0x7fffffff, 0x00020000);
+    d2_t cv[16];
+    if (SUB) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) cv[q] = *reinterpret_cast<const d2_t*>(C + 2 * lane + (long)(64 * nhalf + w + 4 * q) * ld);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int c = 64 * nhalf + w + 4 * q;
+        d2_t v = *reinterpret_cast<const d2_t*>(img + 2 * lane + c * DL);
+        if (MODE == 1) v = cv[q] - v;
+        else if (MODE == 2) v = -v;
+        else if (MODE == 3) v = cv[q] + v;
+        if (WT) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rsrc, (int)((2 * lane + (long)c * ld) * 8), 0, 16);
+        else *reinterpret_cast<d2_t*>(C + 2 * lane + (long)c * ld) = v;
     }
 }
 
@@ -554,7 +590,7 @@ __device__ __forceinline__ void chain_trsm(ChainAcc& V, const double* __restrict
 // solved against them block by block instead of waiting for the whole diagonal block: X_s only needs the column blocks <= s.
 // Same arithmetic as chain_trsm (same slabs, same MFMA order: same bits); what differs is where the L slabs come from: slab s
 // is requested when its block is published (A slabs: three ahead, as before), a slab that is already published when the
-// previous step starts is requested one step early.  LDS: A ring 4 x 18 KB, L slabs 2 x 18 KB, T16 2 x 2 KB (behind the image).
+// previous step starts is requested one step early.  LDS: A ring 4 x 18 KB, L slabs 2 x 18 KB, T16 2 x 2 KB (behind the image area).
 // false: the wait was aborted (another workgroup gave up or the bounded wait expired); the caller leaves the kernel.
 __device__ __forceinline__ bool stream_wait(int* flag, int target, int* abort_flag, long long timeout) {
     int ok = 1;
@@ -863,7 +899,8 @@ __device__ __forceinline__ void chain_image_rsub(const double* __restrict__ C, l
 // the block's earlier steps as one shorter chunk (the barrier form ran the whole K = 128 nbo product on the chain there).
 // Bit-identical to the one-level multi-launch schedule for nbo = 1; agreement to rounding for nbo > 1.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int DF_FACT = 32;          // sync: [DF_FACT + j] factored, [DF_FACT + nb + j] chain_ready, [DF_FACT + 2 nb + i + j nb] panel_done
+constexpr int DF_FACT = 32;          // sync: [DF_FACT + j] factored, [DF_FACT + nb + j] chain_ready, [DF_FACT + 2 nb + i + j nb] panel_done,
+                                     // then xdone[nb][nb] (fused inverse) and diag_ready[nb]
 constexpr int DF_MAXT = 120;         // owned tiles per worker (launcher checks; state lives in the LDS padding of columns 0 .. DF_MAXT - 1): N <= ~31 000
 constexpr int DF_WIN = 16;           // tiles examined per scheduling round (16 lanes each)
 
@@ -906,6 +943,37 @@ __device__ __forceinline__ void df_publish_add(int* p) {
 // chain about one step behind (37-40 us per row against the chain's 48); after the last diagonal block remain T(nb-1), the last
 // row's products and the last chunk of every K^-1 tile (~75 us).
 // ---------------------------------------------------------------------------------------------------------
+// One accumulation task of K^-1_ij = sum_{k >= i} U_ik U_jk^T: the blocks [i + d, min(i + d + ck, nb)) of the contraction; behind the
+// last one the mirror tile (j, i) is written too.  Returns the end of the range.  Shared by the inverse's team and by the
+// factorisation's workers, which take the tiles of the LATE rows (i >= inv_ksplit) when they have nothing else to do: those tiles
+// only become available during the last third of the factorisation, when the trailing matrix -- the workers' own work -- has
+// shrunk to a few tiles and more than half of the inverse's flops are still to come.
+__device__ __forceinline__ int potri_k_task(const PersistArgs& a, int i, int j, int d, int ck, double* lds) {
+    const int nb = a.nb;
+    const long ld = a.ld;
+    const int k0 = i + d, k1 = min(k0 + ck, nb);
+    double* Kij = a.Kinv + (long)i * NB + (long)j * NB * ld;
+    Acc acc;
+    acc.zero();
+    gemm_tile_mc<4, true>(acc, a.U + (long)i * NB + (long)k0 * NB * ld, ld, a.U + (long)j * NB + (long)k0 * NB * ld, ld, 0,
+                          (k1 - k0) * NB, lds);
+    if (k1 < nb) {
+        if (d == 0) tile_commit<0, false>(Kij, ld, acc, lds);
+        else tile_commit<3, false>(Kij, ld, acc, lds);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    } else {
+        if (d == 0) tile_commit<0, false, true>(Kij, ld, acc, lds);
+        else tile_commit<3, false, true>(Kij, ld, acc, lds);
+        if (i != j) {                                                  // the mirror tile (K^-1 is used as a full matrix)
+            lds_barrier();
+            image_transpose_inplace(lds);
+            lds_barrier();
+            chain_image_store_wt(a.Kinv + (long)j * NB + (long)i * NB * ld, ld, lds);
+        }
+    }
+    return k1;
+}
 __device__ __forceinline__ void potri_team(const PersistArgs& a, int b2, int G2, double* lds, char* smem) {
     const int nb = a.nb;
     const long ld = a.ld;
@@ -927,7 +995,7 @@ __device__ __forceinline__ void potri_team(const PersistArgs& a, int b2, int G2,
             deal(0, r, r);
             for (int j = 0; j < r; ++j) deal(1, r, j);
         }
-        for (int r = 0; r < nb; ++r)
+        for (int r = 0; r < min(nb, a.inv_ksplit); ++r)             // the later rows: the factorisation's workers
             for (int j = 0; j <= r; ++j) deal(2, r, j);
         SW(5, 0) = nt;
     }
@@ -1036,28 +1104,10 @@ __device__ __forceinline__ void potri_team(const PersistArgs& a, int b2, int G2,
                 if (tid == 0) SW(3, t) = 1;
             }
         } else {
-            const int k0 = i + d, k1 = min(k0 + ck, nb);
-            double* Kij = a.Kinv + (long)i * NB + (long)j * NB * ld;
-            Acc acc;
-            acc.zero();
-            gemm_tile_mc<4, true>(acc, a.U + (long)i * NB + (long)k0 * NB * ld, ld, a.U + (long)j * NB + (long)k0 * NB * ld, ld, 0,
-                                  (k1 - k0) * NB, lds);
-            if (k1 < nb) {
-                if (d == 0) tile_commit<0, false>(Kij, ld, acc, lds);
-                else tile_commit<3, false>(Kij, ld, acc, lds);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (tid == 0) SW(2, t) = k1 - i;
-            } else {
-                if (d == 0) tile_commit<0, false, true>(Kij, ld, acc, lds);
-                else tile_commit<3, false, true>(Kij, ld, acc, lds);
-                if (i != j) {                                                  // the mirror tile (K^-1 is used as a full matrix)
-                    lds_barrier();
-                    image_transpose_inplace(lds);
-                    lds_barrier();
-                    chain_image_store_wt(a.Kinv + (long)j * NB + (long)i * NB * ld, ld, lds);
-                }
-                if (tid == 0) SW(3, t) = 1;
+            const int k1 = potri_k_task(a, i, j, d, ck, lds);
+            if (tid == 0) {
+                SW(2, t) = k1 - i;
+                if (k1 == nb) SW(3, t) = 1;
             }
         }
         __syncthreads();
@@ -1083,6 +1133,10 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
     int* factored = a.sync + DF_FACT;
     int* chain_ready = a.sync + DF_FACT + nb;
     int* panel_done = a.sync + DF_FACT + 2 * nb;        // [i + j nb]
+    // chain_ready[j]: tile (j+1, j) carries every update its owner(s) apply (1, or 2 with one owner per half); diag_ready[j]: tile
+    // (j+1, j+1) does.  Separate words: in the streamed form the follower only needs the first -- the diagonal tile's last update
+    // comes ~6 us later and is only needed by the chain, behind the follower's solve
+    int* diag_ready = a.sync + DF_FACT + 2 * nb + 2 * nb * nb;
     const int nchain = a.nchain;
     if (b == 0 && nchain == 2) {
         // ---- the chain, streamed form: diagonal blocks + the product L L^T; the panel tile comes from the follower ----
@@ -1093,8 +1147,23 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             double* Asub = Ajj + NB;                           // tile (j+1, j)
             double* Anext = Ajj + (long)NB * (ld + 1);         // tile (j+1, j+1)
             PK_STAMP(0);
+            if (!pk_wait_count(diag_ready + j, 1, a)) return;                        // (j+1, j+1) carries its owner's updates
+            // A_{j+1,j+1} (lower blocks) into registers while the follower is still solving: the subtraction behind the product
+            // then needs no global load
+            d2_t cv[2][16];
+            {
+                const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+                const int ti = lane >> 3;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int c = w + 4 * (16 * h + q);
+                        cv[h][q] = d2_t{0.0, 0.0};
+                        if (ti >= (c >> 4)) cv[h][q] = *reinterpret_cast<const d2_t*>(Anext + 2 * lane + (long)c * ld);
+                    }
+            }
             if (!pk_wait_count(panel_done + (j + 1) + (long)j * nb, 1, a)) return;   // L_{j+1,j} stored by the follower
-            if (!pk_wait_count(chain_ready + j, 2, a)) return;                       // (j+1, j+1) carries its owner's updates
             PK_STAMP(1);
             {   // L_{j+1,j} -> LDS image: 128 columns of 1 KB, LDS-direct
                 const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1110,7 +1179,19 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             PK_STAMP(8);
             lds_barrier();
             PK_STAMP(9);
-            chain_image_rsub(Anext, ld, lds);
+            {   // image <- A_{j+1,j+1} - image on the lower blocks, zero above (chain_image_rsub with the tile already in registers)
+                const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+                const int ti = lane >> 3;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int c = w + 4 * (16 * h + q);
+                        d2_t v = d2_t{0.0, 0.0};
+                        if (ti >= (c >> 4)) v = cv[h][q] - *reinterpret_cast<const d2_t*>(lds + 2 * lane + c * DL);
+                        *reinterpret_cast<d2_t*>(lds + 2 * lane + c * DL) = v;
+                    }
+            }
             __syncthreads();
             PK_STAMP(3);
             diag_block_factor<false>(Anext, ld, Tjj + (long)NB * (ld + 1), ld, a.info, (j + 1) * NB, smem, factored + j + 1);
@@ -1124,13 +1205,17 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             double* Ajj = a.A + (long)j * NB * (ld + 1);
             double* Tjj = a.Linv + (long)j * NB * (ld + 1);
             double* Asub = Ajj + NB;
-            if (!pk_wait_count(chain_ready + j, 2, a)) return; // tile (j+1, j) carries its owner's updates (steps < j)
+            PK_STAMP(10);
+            if (!pk_wait_count(chain_ready + j, 1 + a.split_sub, a)) return;   // tile (j+1, j) carries its owners' updates (steps < j)
+            PK_STAMP(11);
             ChainAcc ca;
             if (!stream_trsm(ca, Asub, ld, Ajj, ld, Tjj, ld, factored + j, a.info + 1, a.timeout, lds)) return;
+            PK_STAMP(12);
             chain_acc_to_image<true>(ca, lds);
             lds_barrier();
             chain_image_store_wt(Asub, ld, lds);
             df_publish_store(panel_done + (j + 1) + (long)j * nb);
+            PK_STAMP(13);
         }
         return;
     }
@@ -1148,7 +1233,8 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             double* Asub = Ajj + NB;                           // tile (j+1, j)
             double* Anext = Ajj + (long)NB * (ld + 1);         // tile (j+1, j+1)
             PK_STAMP(0);
-            if (!pk_wait_count(chain_ready + j, 2, a)) return; // both tiles carry their owners' updates (steps < j)
+            if (!pk_wait_count(chain_ready + j, 1, a)) return; // both tiles carry their owners' updates (steps < j)
+            if (!pk_wait_count(diag_ready + j, 1, a)) return;
             PK_STAMP(1);
             {
                 ChainAcc ca;
@@ -1199,14 +1285,29 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
         if (ok) {
             // tiles in column-major order (without (0, 0)) dealt round-robin: even in total work and at every stage (a cyclic
             // PR x PC owner grid left 1.4x the mean work on some owners: 5.7 vs 5.0 ms at N = 8192, round 3)
+            // split_sub: column k carries one more item, the second half of its sub-diagonal tile (k+1, k)
             int k = 0;
-            long off = 0;                                    // tiles before column k
+            long off = 0;                                    // items before column k
+            auto cnt = [&](int kk) { return nb - kk + (a.split_sub && kk <= nb - 2 ? 1 : 0); };
             for (long t = widx; nt < DF_MAXT; t += W) {
                 const long tt = t + 1;                       // skip (0, 0)
-                while (k < nb && tt >= off + (nb - k)) { off += nb - k; ++k; }
+                while (k < nb && tt >= off + cnt(k)) { off += cnt(k); ++k; }
                 if (k >= nb) break;
-                SW(0, nt) = k + (int)(tt - off); SW(1, nt) = k; SW(2, nt) = 0; SW(3, nt) = 0;
+                const int e = (int)(tt - off);
+                const bool second = e == nb - k;             // the extra item
+                SW(0, nt) = second ? k + 1 : k + e; SW(1, nt) = k; SW(2, nt) = 0; SW(3, nt) = 0;
+                SW(6, nt) = second ? 2 : (a.split_sub && e == 1 ? 1 : 0);      // 0 whole tile, 1 / 2: columns 0-63 / 64-127
                 ++nt;
+            }
+            if (a.g1 > 0) {
+                // fused inverse: the K^-1 tiles of the late rows, behind this worker's own tiles (nothing waits for them)
+                long t = 0;
+                for (int r = a.inv_ksplit; r < nb; ++r)
+                    for (int jj = 0; jj <= r; ++jj, ++t)
+                        if (t % W == widx && nt < DF_MAXT) {
+                            SW(0, nt) = r; SW(1, nt) = jj; SW(2, nt) = 0; SW(3, nt) = 0; SW(6, nt) = 3;
+                            ++nt;
+                        }
             }
         }
         SW(5, 0) = ok ? nt : -1;
@@ -1229,7 +1330,12 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             const int t = first + slot;
             bool valid = t < nt && !SW(3, t);
             bool ok = true;
-            if (valid) {
+            if (valid && SW(6, t) == 3) {                      // a K^-1 tile of the fused inverse (potri_k_task)
+                const int i = SW(0, t), jj = SW(1, t), d = SW(2, t);
+                const int* xdone = a.sync + DF_FACT + 2 * nb + nb * nb;
+                const int k0 = i + d, k1 = min(k0 + a.inv_ck, nb), kk = k0 + (l & 7);
+                if (kk < k1) ok = df_flag(xdone + kk + (long)(l < 8 ? i : jj) * nb) != 0;
+            } else if (valid) {
                 const int i = SW(0, t), k = SW(1, t), d = SW(2, t);
                 const int target = i == k ? k - 1 : k;         // steps the owner applies (the chain applies step k-1 to (k, k))
                 if (d < target) {
@@ -1271,19 +1377,38 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
         const int i = SW(0, t), k = SW(1, t), d = SW(2, t);
         const int target = i == k ? k - 1 : k;
         double* Cik = a.A + (long)i * NB + (long)k * NB * ld;
-        if (d < target) {
+        if (SW(6, t) == 3) {
+            const int k1 = potri_k_task(a, i, k, d, a.inv_ck, lds);
+            if (tid == 0) {
+                SW(2, t) = k1 - i;
+                if (k1 == nb) SW(3, t) = 1;
+            }
+        } else if (d < target) {
             const int j0 = d;
             const int j1 = df_chunk_end(k, j0, target, nbo, a.near);
+            const int half = SW(6, t);
             Acc acc;
             acc.zero();
-            gemm_tile_deep(acc, a.A + (long)i * NB + (long)j0 * NB * ld, ld, a.A + (long)k * NB + (long)j0 * NB * ld, ld, (j1 - j0) * NB, lds);
+            if (half == 0)
+                gemm_tile_deep(acc, a.A + (long)i * NB + (long)j0 * NB * ld, ld, a.A + (long)k * NB + (long)j0 * NB * ld, ld, (j1 - j0) * NB, lds);
+            else
+                gemm_tile_mc<2, true>(acc, a.A + (long)i * NB + (long)j0 * NB * ld, ld, a.A + (long)k * NB + (long)j0 * NB * ld, ld, 0,
+                                      (j1 - j0) * NB, lds, half - 1);
             const long long st_g = a.trace ? wall_clock64() : 0;
             st_gemm += st_g - st_task0;
             const bool last = j1 == target;
             const bool to_chain = last && i <= k + 1;         // (k+1, k) and (k, k) go to the chain after their last update
-            if (to_chain) {
+            if (half != 0) {                                  // a half of a sub-diagonal tile
+                if (to_chain) {
+                    tile_commit_half<1, true>(Cik, ld, acc, lds, half - 1);
+                    df_publish_add(chain_ready + k);
+                } else {
+                    tile_commit_half<1, false>(Cik, ld, acc, lds, half - 1);
+                    __syncthreads();
+                }
+            } else if (to_chain) {
                 tile_commit<1, true>(Cik, ld, acc, lds);
-                df_publish_add(chain_ready + (i == k ? k - 1 : k));
+                df_publish_add(i == k ? diag_ready + k - 1 : chain_ready + k);
             } else {
                 tile_commit<1, false>(Cik, ld, acc, lds);
                 if (a.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st_rmw += wall_clock64() - st_g; }
@@ -1324,7 +1449,7 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
         } else {
             // no update to apply at all: tiles (1, 0) and (1, 1)
             if (tid == 0) {
-                __hip_atomic_fetch_add(chain_ready + (i == k ? k - 1 : k), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(i == k ? diag_ready + k - 1 : chain_ready + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 SW(3, t) = 1;
             }
         }
@@ -1413,7 +1538,7 @@ int potrf_dataflow_nbo(int Np) {
 // ints of device scratch the dataflow form needs per problem
 size_t potrf_dataflow_sync_ints(int Np) {
     const size_t nb = Np / NB;
-    return DF_FACT + 2 * nb + 2 * nb * nb;           // factored, chain_ready, panel_done[nb][nb], xdone[nb][nb] (fused inverse)
+    return DF_FACT + 3 * nb + 2 * nb * nb;           // factored, chain_ready, panel_done[nb][nb], xdone[nb][nb] (fused inverse), diag_ready
 }
 // How many independent Np x Np factorisations share one launch well: a problem keeps the chip busy with about nb^2 / 14.5 workers
 // (its ~nb^3 / 6 tile tasks of ~20 us against a chain of nb steps of ~48 us); the rest of the CUs can factor other problems.
@@ -1443,12 +1568,17 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
     }
     if (ps.resident_per_cu < 1 || nprob < 1 || nprob > 8) return false;
     const int n_cu = ps.n_cu;
-    const int tiles = nb * (nb + 1) / 2 - 1;
+    const int tiles_whole = nb * (nb + 1) / 2 - 1;
     // (a second chain workgroup that followed the factorisation with a streamed solve was measured again in round 4 -- 0.384 / 0.767 /
     // 1.661 / 4.37 ms against 0.395 / 0.781 / 1.599 / 4.09 ms at N = 1024 / 2048 / 4096 / 8192, profiles/r04_potrf_chain2.log -- and
     // removed: the step is bound by the owners' panel + update path, not by the chain alone)
-    // streamed panel tiles: a follower workgroup next to the chain (SLS_POTRF_STREAM=0: the chain solves its panel tile itself)
-    const int nchain = envi("SLS_POTRF_STREAM", SLS_POTRF_STREAM_DEFAULT) != 0 && nb >= 4 ? 2 : 1;
+    // streamed panel tiles: a follower workgroup next to the chain (SLS_POTRF_STREAM=0: the chain solves its panel tile itself).
+    // Measured (tools/probes/stream_scan.sh, ms; round-3 chain -> follower + streamed worker solves + half-tile owners):
+    // N = 512: 0.202 -> 0.173, 1024: 0.396 -> 0.334, 2048: 0.789 -> 0.685, 3072: 1.199 -> 1.034, 4096: 1.645 -> 1.422; at N = 8192
+    // the workers are as busy as the chain (4.16 -> 4.10-4.17): the round-3 form stays from N > 5120
+    const int nchain = envi("SLS_POTRF_STREAM", nb <= 40 ? SLS_POTRF_STREAM_DEFAULT : 0) != 0 && nb >= 4 ? 2 : 1;
+    const int split_sub = nchain == 2 && envi("SLS_POTRF_SPLIT", 1) != 0 ? 1 : 0;
+    const int tiles = tiles_whole + (split_sub ? nb - 1 : 0);                // items dealt to the workers
     int Gp = std::max(nchain + 1, std::min(n_cu / nprob, nchain + tiles));   // workgroups per problem
     int G2 = 0;
     if (inv) {
@@ -1461,8 +1591,10 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
         const int W1 = std::max(1, std::min(tiles, envi("SLS_POTRI_W1", w1_dflt)));
         Gp = nchain + W1;
         G2 = n_cu * ps.resident_per_cu - Gp;
-        const int items = nb + nb * nb;
-        if (G2 < 8 || (items + G2 - 1) / G2 > DF_MAXT) return false;
+        const int ksplit = std::max(1, std::min(nb, envi("SLS_POTRI_KSPLIT", nb)));
+        const int k_late = nb * (nb + 1) / 2 - ksplit * (ksplit + 1) / 2;          // K^-1 tiles the factorisation's workers take
+        const int items = nb + nb * (nb - 1) / 2 + ksplit * (ksplit + 1) / 2;      // T, X and the early K^-1 tiles
+        if (G2 < 8 || (items + G2 - 1) / G2 > DF_MAXT || (tiles + k_late + W1 - 1) / W1 + 1 > DF_MAXT) return false;
         G2 = std::min(G2, items);
     }
     const int W = Gp - nchain;
@@ -1481,7 +1613,9 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
     a.U = inv ? inv->U : nullptr;
     a.Kinv = inv ? inv->Kinv : nullptr;
     a.nchain = nchain;
-    a.stream_rows = std::max(0, envi("SLS_POTRF_STREAM_ROWS", 1));
+    a.split_sub = split_sub;
+    a.stream_rows = std::max(0, envi("SLS_POTRF_STREAM_ROWS", 1 << 20));   // every panel tile (only the next row: 0.725 instead of 0.685 ms at N = 2048)
+    a.inv_ksplit = std::max(1, std::min(nb, envi("SLS_POTRI_KSPLIT", nb)));
     a.inv_cx = std::max(1, std::min(8, envi("SLS_POTRI_CX", nb > 16 ? 2 : 1)));
     a.inv_ck = std::max(1, std::min(8, envi("SLS_POTRI_CK", nb > 16 ? 2 : 1)));
     {

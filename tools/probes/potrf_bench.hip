@@ -150,6 +150,16 @@ int main(int argc, char** argv) {
                                us(g[5]), us(g[6]), us(g[7]), us(g[2]), us(g[8]), us(g[9]), us(g[3]));
                 }
                 printf("  chain waited %.1f us in total for its tiles\n", waited);
+                if (getenv("POTRF_BENCH_FOLLOWER")) {
+                    // streamed form: per step, relative to the END of the chain's diagonal block j (= start of its step j): when the
+                    // follower's tiles (j+1, j), (j+1, j+1) had their updates, when its solve was done, when L_{j+1,j} was published
+                    printf("  follower (us after diagonal block j finished): step: tiles ready / solve done / published | chain's wait\n");
+                    for (int j = 0; j < nb - 1; ++j) {
+                        const long long* g = ht.data() + 16 * j; const double t0 = (double)g[0];
+                        auto us = [&](long long v) { return v ? ((double)v - t0) / 100.0 : -1.0; };
+                        printf("   %2d: %6.1f %6.1f %6.1f | %5.1f\n", j, us(g[11]), us(g[12]), us(g[13]), us(g[1]));
+                    }
+                }
                 hipFree(tr);
             }
             hipFree(dsync);
