@@ -54,6 +54,9 @@ int sls_version(void);
 
 /* ---- context ------------------------------------------------------------ */
 int sls_ctx_create(int device, sls_ctx** out);
+/* Handles created from a context (sls_gp, sls_nll, sls_comm) may be destroyed after it: with live handles sls_ctx_destroy only
+ * marks the context, the handles keep working, and the last one to go frees it (garbage-collected bindings finalise
+ * objects in no particular order). */
 int sls_ctx_destroy(sls_ctx* ctx);
 /* Run on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL restores the own stream. */
 int sls_ctx_set_stream(sls_ctx* ctx, void* hip_stream);

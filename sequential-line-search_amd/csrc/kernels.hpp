@@ -264,7 +264,8 @@ struct PotriFused {
     double* U;
     double* Kinv;
 };
-bool launch_potri_dataflow(hipStream_t s, double* A, int Np, double* Linv, double* U, double* Kinv, int* info, int* sync);
+bool launch_potri_dataflow(hipStream_t s, double* A, int Np, double* Linv, double* U, double* Kinv, int* info, int* sync,
+                           long long* trace = nullptr);
 bool potri_fused_applies(int Np, bool have_sync);   // sizes / switches only: the launch itself may still decline (too few CUs)
 bool launch_potri(hipStream_t s, double* A, int Np, double* Linv, double* U, double* Kinv, int* info, PotrfAux* aux, int* dataflow_sync);
 int potrf_default_mode(int Np);

@@ -338,6 +338,8 @@ struct PersistArgs {
     double* U;
     double* Kinv;
     int inv_cx, inv_ck;   // 128-blocks of the contraction per X / K^-1 accumulation task (fixed chunking)
+    int inv_plast;        // 1: the term of the row just above is split off (P_i, one product per row on the column wavefront); 0: every
+                          // term is accumulated, then U_ji = M T_ii^T (two products per row, no P task: shorter tail for few rows)
     int inv_ksplit;       // K^-1 tiles of the rows >= inv_ksplit are accumulated by the factorisation's workers (potri_k_task)
     // streamed panel tiles (stream_trsm): nchain = 2 adds the FOLLOWER workgroup, which solves the chain's panel tile (j+1, j)
     // against the column blocks of L_jj while the chain is still factoring them; stream_rows: worker panel tiles (i, k) with
@@ -933,15 +935,18 @@ __device__ __forceinline__ void df_publish_add(int* p) {
 // 1.0 ms at N = 4096 -- more than half of the factorisation itself.  Here a second team of workgroups (blockIdx >= g1) consumes the
 // factorisation's own flags and builds the inverse BEHIND the chain, tile by tile:
 //   T(j)     T_jj = L_jj^-1 (diag_block<false>), U_jj = T_jj^T                                   needs factored[j]
-//   X(i, j)  M = -(sum_{k=j}^{i-1} U_jk L_ik^T)  accumulated in the (unused) block (j, i) of U in fixed chunks of inv_cx blocks,
-//            then U_ji = M T_ii^T and X_ij = U_ji^T                                               needs xdone[k][j], panel_done[i][k], T(i)
+//   P(i)     P_i = T_ii L_{i,i-1}  (L^T through an LDS transpose; kept in block (i, i-1) of U: its strictly-lower blocks are unused)   needs T(i), panel_done[i][i-1]
+//   X(i, j)  M = -(sum_{k=j}^{i-2} U_jk L_ik^T) accumulated in the (unused) block (j, i) of U in fixed chunks of inv_cx blocks,
+//            Q = M T_ii^T (needs T(i)), and LAST  U_ji = Q - U_{j,i-1} P_i^T,  X_ij = U_ji^T        needs xdone[i-1][j], P(i)
 //   K(i, j)  K^-1_ij = sum_{k >= i} U_ik U_jk^T in fixed chunks of inv_ck blocks (+ the mirror tile)   needs xdone[k][i], xdone[k][j]
 // (block forward substitution X_ij = -T_ii sum_k L_ik X_kj, written for the transposes so that every product has both operands
-// M-contiguous: gemm_tile_mc).  One owner per item, fixed chunk boundaries: the bits do not depend on timing.  Items are dealt
+// M-contiguous: gemm_tile_mc).  The term of the row just above is split off -- X_ij = -T_ii S'_ij - P_i X_{i-1,j} with everything
+// but the last product available a row earlier --, so the column wavefront advances by ONE product per row (~22 us) instead of
+// two (~45 us, as slow as the chain itself: the first form finished 0.7 ms behind the factorisation at N = 4096).  One owner per item, fixed chunk boundaries: the bits do not depend on timing.  Items are dealt
 // round-robin in ONE global order -- T / X by row, then K by row -- that is consistent with the dependencies, so the globally
 // first unfinished item is always the first unfinished item of its owner: no circular wait.  The inverse's wavefront follows the
-// chain about one step behind (37-40 us per row against the chain's 48); after the last diagonal block remain T(nb-1), the last
-// row's products and the last chunk of every K^-1 tile (~75 us).
+// chain about one step behind; after the last diagonal block remain T(nb-1), P(nb-1), the last row's products and the last chunk
+// of every K^-1 tile (~75 us).
 // ---------------------------------------------------------------------------------------------------------
 // One accumulation task of K^-1_ij = sum_{k >= i} U_ik U_jk^T: the blocks [i + d, min(i + d + ck, nb)) of the contraction; behind the
 // last one the mirror tile (j, i) is written too.  Returns the end of the range.  Shared by the inverse's team and by the
@@ -986,13 +991,14 @@ __device__ __forceinline__ void potri_team(const PersistArgs& a, int b2, int G2,
         int nt = 0, turn = 0;                             // turn: position of the next item in the round-robin deal
         auto deal = [&](int type, int i, int j) {
             if (turn == b2 && nt < DF_MAXT) {
-                SW(0, nt) = i; SW(1, nt) = j; SW(2, nt) = 0; SW(3, nt) = 0; SW(6, nt) = type;
+                SW(0, nt) = i; SW(1, nt) = j; SW(2, nt) = (type == 1 && j == i - 1 && a.inv_plast) ? 1 : 0; SW(3, nt) = 0; SW(6, nt) = type;
                 ++nt;
             }
             if (++turn == G2) turn = 0;
         };
         for (int r = 0; r < nb; ++r) {
             deal(0, r, r);
+            if (r > 0 && a.inv_plast) deal(4, r, r - 1);
             for (int j = 0; j < r; ++j) deal(1, r, j);
         }
         for (int r = 0; r < min(nb, a.inv_ksplit); ++r)             // the later rows: the factorisation's workers
@@ -1006,6 +1012,7 @@ __device__ __forceinline__ void potri_team(const PersistArgs& a, int b2, int G2,
     long long t_progress = wall_clock64();
     const int slot = tid >> 4, l = tid & 15;
     const int cx = a.inv_cx, ck = a.inv_ck;
+    long long st_task = 0, st_t0 = t_progress, st_n = 0, st_last = 0;       // probes: ticks in tasks, task count, end of the last task
     for (;;) {
         while (first < nt && SW(3, first)) ++first;
         if (first >= nt) break;
@@ -1018,12 +1025,20 @@ __device__ __forceinline__ void potri_team(const PersistArgs& a, int b2, int G2,
                 if (type == 0) {
                     if (l == 0) ok = df_flag(factored + i) >= (a.nchain == 2 ? 24 : 1);
                 } else if (type == 1) {
-                    if (d < i - j) {
-                        const int k0 = j + d, k1 = min(k0 + cx, i), k = k0 + (l & 7);
+                    // d: terms applied (k = j .. i - 1 - plast), then nterms -> Q pending, nterms + 1 -> last step pending (plast)
+                    const int nterms = i - j - a.inv_plast;
+                    if (d < nterms) {
+                        const int k0 = j + d, k1 = min(k0 + cx, j + nterms), k = k0 + (l & 7);
                         if (k < k1) ok = df_flag(l < 8 ? xdone + k + (long)j * nb : panel_done + i + (long)k * nb) != 0;
-                    } else if (l == 0) {
-                        ok = df_flag(xdone + i + (long)i * nb) != 0;
+                    } else if (d == nterms) {
+                        if (l == 0) ok = df_flag(xdone + i + (long)i * nb) != 0;
+                    } else {
+                        if (l == 0) ok = df_flag(xdone + (i - 1) + (long)j * nb) != 0;
+                        else if (l == 1) ok = df_flag(xdone + (i - 1) + (long)i * nb) != 0;        // P(i): the unused entry (i-1, i)
                     }
+                } else if (type == 4) {
+                    if (l == 0) ok = df_flag(xdone + i + (long)i * nb) != 0;
+                    else if (l == 1) ok = df_flag(panel_done + i + (long)j * nb) != 0;
                 } else {
                     const int k0 = i + d, k1 = min(k0 + ck, nb), k = k0 + (l & 7);
                     if (k < k1) ok = df_flag(xdone + k + (long)(l < 8 ? i : j) * nb) != 0;
@@ -1050,6 +1065,7 @@ __device__ __forceinline__ void potri_team(const PersistArgs& a, int b2, int G2,
         }
         if (tid < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __syncthreads();
+        const long long st_task0 = a.trace ? wall_clock64() : 0;
         const int t = first + sel;
         const int i = SW(0, t), j = SW(1, t), d = SW(2, t), type = SW(6, t);
         if (type == 0) {
@@ -1077,10 +1093,41 @@ __device__ __forceinline__ void potri_team(const PersistArgs& a, int b2, int G2,
             }
             df_publish_store(xdone + i + (long)i * nb);
             if (tid == 0) SW(3, t) = 1;
+        } else if (type == 4) {
+            // P_i = T_ii L_{i,i-1}.  L's contraction index is its contiguous one, so the tile goes through an LDS transpose first
+            // (image -> in place -> scratch block, read back as an M-contiguous operand); scratch = block (i, i-1) of U: nothing
+            // else reads or writes U's strictly-lower blocks.  (Not a block of K^-1: its mirror tiles are written as soon as the two
+            // columns they depend on are complete, while another column may still need P_i.)
+            const double* Lsub = a.A + (long)i * NB + (long)j * NB * ld;
+            const double* Tii = a.Linv + (long)i * NB * (ld + 1);
+            double* Pi = a.U + (long)i * NB + (long)j * NB * ld;
+            {
+                const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll 8
+                for (int q = 0; q < 32; ++q) {
+                    const int c = w + 4 * q;
+                    slab_row_to_lds(Lsub + 2 * lane + (long)c * ld, lds + c * DL);
+                }
+                ring_wait_barrier<0>();
+            }
+            image_transpose_inplace(lds);
+            lds_barrier();
+            chain_image_store_wt(Pi, ld, lds);                                 // L_{i,i-1}^T
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // this CU reads the block back through its L1
+            __syncthreads();
+            Acc acc;
+            acc.zero();
+            gemm_tile_mc<4, true>(acc, Tii, ld, Pi, ld, 0, NB, lds);           // P[m][n] = sum_k T_ii[m][k] L^T[n][k]
+            tile_commit<0, true>(Pi, ld, acc, lds);
+            df_publish_store(xdone + j + (long)i * nb);                        // entry (i-1, i)
+            if (tid == 0) SW(3, t) = 1;
         } else if (type == 1) {
-            double* Mji = a.U + (long)j * NB + (long)i * NB * ld;              // block (j, i) of U: M until the last step, then U_ji
-            if (d < i - j) {
-                const int k0 = j + d, k1 = min(k0 + cx, i);
+            double* Mji = a.U + (long)j * NB + (long)i * NB * ld;              // block (j, i) of U: M, then Q, then U_ji
+            const int nterms = i - j - a.inv_plast;
+            if (d < nterms) {
+                const int k0 = j + d, k1 = min(k0 + cx, j + nterms);
                 Acc acc;
                 acc.zero();
                 gemm_tile_mc<4, true>(acc, a.U + (long)j * NB + (long)k0 * NB * ld, ld, a.A + (long)i * NB + (long)k0 * NB * ld, ld, 0,
@@ -1090,17 +1137,35 @@ __device__ __forceinline__ void potri_team(const PersistArgs& a, int b2, int G2,
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 if (tid == 0) SW(2, t) = k1 - j;
-            } else {
+            } else if (d == nterms) {
                 const double* Tii = a.Linv + (long)i * NB * (ld + 1);
                 Acc acc;
                 acc.zero();
-                gemm_tile_mc<4, true>(acc, Mji, ld, Tii, ld, 0, NB, lds);      // U_ji = M T_ii^T
-                tile_commit<0, true>(Mji, ld, acc, lds);
+                gemm_tile_mc<4, true>(acc, Mji, ld, Tii, ld, 0, NB, lds);      // Q = M T_ii^T
+                if (a.inv_plast) {
+                    tile_commit<0, false>(Mji, ld, acc, lds);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    if (tid == 0) SW(2, t) = nterms + 1;
+                } else {                                                       // every term is in: Q is U_ji
+                    tile_commit<0, true>(Mji, ld, acc, lds);
+                    df_publish_store(xdone + i + (long)j * nb);
+                    image_transpose_inplace(lds);
+                    lds_barrier();
+                    chain_image_store_wt(a.Linv + (long)i * NB + (long)j * NB * ld, ld, lds);
+                    if (tid == 0) SW(3, t) = 1;
+                }
+            } else {
+                const double* Pi = a.U + (long)i * NB + (long)(i - 1) * NB * ld;
+                Acc acc;
+                acc.zero();
+                gemm_tile_mc<4, true>(acc, a.U + (long)j * NB + (long)(i - 1) * NB * ld, ld, Pi, ld, 0, NB, lds);   // U_{j,i-1} P_i^T
+                if (j == i - 1) tile_commit<2, true, true>(Mji, ld, acc, lds);                                     // no Q: U_ji = -acc
+                else tile_commit<1, true, true>(Mji, ld, acc, lds);                                                // U_ji = Q - acc
+                df_publish_store(xdone + i + (long)j * nb);                    // U_ji is what the other tasks read
+                image_transpose_inplace(lds);                                  // X_ij = U_ji^T: an output only
                 lds_barrier();
-                image_transpose_inplace(lds);
-                lds_barrier();
-                chain_image_store_wt(a.Linv + (long)i * NB + (long)j * NB * ld, ld, lds);   // X_ij = U_ji^T
-                df_publish_store(xdone + i + (long)j * nb);
+                chain_image_store_wt(a.Linv + (long)i * NB + (long)j * NB * ld, ld, lds);
                 if (tid == 0) SW(3, t) = 1;
             }
         } else {
@@ -1112,6 +1177,11 @@ __device__ __forceinline__ void potri_team(const PersistArgs& a, int b2, int G2,
         }
         __syncthreads();
         t_progress = wall_clock64();
+        if (a.trace) { st_task += t_progress - st_task0; ++st_n; st_last = t_progress; }
+    }
+    if (a.trace && tid == 0) {
+        long long* o = a.trace + 16 * (long)nb + 16 * (long)(a.g1 - 1 + b2);
+        o[0] = st_task; o[2] = st_last - st_t0; o[3] = st_n; o[6] = -nt; o[9] = st_t0; o[10] = st_last;
     }
 }
 
@@ -1402,6 +1472,10 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
                 if (to_chain) {
                     tile_commit_half<1, true>(Cik, ld, acc, lds, half - 1);
                     df_publish_add(chain_ready + k);
+                    if (a.trace && tid == 0 && k >= 1) {      // probes: the last update of tile (k+1, k), first half: begin / end
+                        a.trace[16 * (k - 1) + 14 + 0] = half == 1 ? st_task0 : a.trace[16 * (k - 1) + 14];
+                        if (half == 1) a.trace[16 * (k - 1) + 15] = wall_clock64();
+                    }
                 } else {
                     tile_commit_half<1, false>(Cik, ld, acc, lds, half - 1);
                     __syncthreads();
@@ -1576,7 +1650,9 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
     // Measured (tools/probes/stream_scan.sh, ms; round-3 chain -> follower + streamed worker solves + half-tile owners):
     // N = 512: 0.202 -> 0.173, 1024: 0.396 -> 0.334, 2048: 0.789 -> 0.685, 3072: 1.199 -> 1.034, 4096: 1.645 -> 1.422; at N = 8192
     // the workers are as busy as the chain (4.16 -> 4.10-4.17): the round-3 form stays from N > 5120
-    const int nchain = envi("SLS_POTRF_STREAM", nb <= 40 ? SLS_POTRF_STREAM_DEFAULT : 0) != 0 && nb >= 4 ? 2 : 1;
+    // Several problems per launch are bound by their workers, not by their chains (8 value-only evaluations at N = 4096: 6.4 ms on
+    // the round-3 chain, 7.3 ms streamed): the round-3 form there too.
+    const int nchain = envi("SLS_POTRF_STREAM", nb <= 40 && nprob == 1 ? SLS_POTRF_STREAM_DEFAULT : 0) != 0 && nb >= 4 ? 2 : 1;
     const int split_sub = nchain == 2 && envi("SLS_POTRF_SPLIT", 1) != 0 ? 1 : 0;
     const int tiles = tiles_whole + (split_sub ? nb - 1 : 0);                // items dealt to the workers
     int Gp = std::max(nchain + 1, std::min(n_cu / nprob, nchain + tiles));   // workgroups per problem
@@ -1593,7 +1669,7 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
         G2 = n_cu * ps.resident_per_cu - Gp;
         const int ksplit = std::max(1, std::min(nb, envi("SLS_POTRI_KSPLIT", nb)));
         const int k_late = nb * (nb + 1) / 2 - ksplit * (ksplit + 1) / 2;          // K^-1 tiles the factorisation's workers take
-        const int items = nb + nb * (nb - 1) / 2 + ksplit * (ksplit + 1) / 2;      // T, X and the early K^-1 tiles
+        const int items = 2 * nb - 1 + nb * (nb - 1) / 2 + ksplit * (ksplit + 1) / 2;   // T, P, X and the early K^-1 tiles
         if (G2 < 8 || (items + G2 - 1) / G2 > DF_MAXT || (tiles + k_late + W1 - 1) / W1 + 1 > DF_MAXT) return false;
         G2 = std::min(G2, items);
     }
@@ -1616,6 +1692,9 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
     a.split_sub = split_sub;
     a.stream_rows = std::max(0, envi("SLS_POTRF_STREAM_ROWS", 1 << 20));   // every panel tile (only the next row: 0.725 instead of 0.685 ms at N = 2048)
     a.inv_ksplit = std::max(1, std::min(nb, envi("SLS_POTRI_KSPLIT", nb)));
+    // measured (ms, factor + inverse; two products per row -> one): N = 384: 0.209 -> 0.234, 1024: 0.405 -> 0.411, 2048: 0.759 -> 0.753,
+    // 3072: 1.466 -> 1.32, 4096: 2.15 -> 2.15 (there the two teams are short of CUs, not of time on the wavefront)
+    a.inv_plast = envi("SLS_POTRI_PLAST", nb >= 12 ? 1 : 0) != 0 ? 1 : 0;
     a.inv_cx = std::max(1, std::min(8, envi("SLS_POTRI_CX", nb > 16 ? 2 : 1)));
     a.inv_ck = std::max(1, std::min(8, envi("SLS_POTRI_CK", nb > 16 ? 2 : 1)));
     {
@@ -1635,9 +1714,9 @@ bool launch_potrf_dataflow_batch(hipStream_t s, double* A, int Np, double* Linv,
 bool launch_potrf_dataflow(hipStream_t s, double* A, int Np, double* Linv, int* info, int* sync, long long* trace) {
     return launch_potrf_dataflow_impl(s, A, Np, Linv, info, sync, 1, 0, 0, true, trace, nullptr);
 }
-bool launch_potri_dataflow(hipStream_t s, double* A, int Np, double* Linv, double* U, double* Kinv, int* info, int* sync) {
+bool launch_potri_dataflow(hipStream_t s, double* A, int Np, double* Linv, double* U, double* Kinv, int* info, int* sync, long long* trace) {
     const PotriFused inv{U, Kinv};
-    return launch_potrf_dataflow_impl(s, A, Np, Linv, info, sync, 1, 0, 0, false, nullptr, &inv);
+    return launch_potrf_dataflow_impl(s, A, Np, Linv, info, sync, 1, 0, 0, false, trace, &inv);
 }
 
 // Two-level right-looking factorisation.  Outer blocks of `nbo` 128-columns: inside an outer block every 128-step is

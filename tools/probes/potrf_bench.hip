@@ -153,11 +153,12 @@ int main(int argc, char** argv) {
                 if (getenv("POTRF_BENCH_FOLLOWER")) {
                     // streamed form: per step, relative to the END of the chain's diagonal block j (= start of its step j): when the
                     // follower's tiles (j+1, j), (j+1, j+1) had their updates, when its solve was done, when L_{j+1,j} was published
-                    printf("  follower (us after diagonal block j finished): step: tiles ready / solve done / published | chain's wait\n");
+                    printf("  follower (us after diagonal block j finished): step: tiles ready / solve done / published | chain's wait | last update of "
+                           "tile (j+2, j+1), first half: begin / end\n");
                     for (int j = 0; j < nb - 1; ++j) {
                         const long long* g = ht.data() + 16 * j; const double t0 = (double)g[0];
                         auto us = [&](long long v) { return v ? ((double)v - t0) / 100.0 : -1.0; };
-                        printf("   %2d: %6.1f %6.1f %6.1f | %5.1f\n", j, us(g[11]), us(g[12]), us(g[13]), us(g[1]));
+                        printf("   %2d: %6.1f %6.1f %6.1f | %5.1f | %6.1f %6.1f\n", j, us(g[11]), us(g[12]), us(g[13]), us(g[1]), us(g[14]), us(g[15]));
                     }
                 }
                 hipFree(tr);
@@ -196,6 +197,32 @@ int main(int argc, char** argv) {
                 return ok;
             };
             timeit(false, X1, U1, K1);
+            if (getenv("POTRF_BENCH_TRACE")) {
+                // where the fused launch spends its time: the chain's end, the factorisation's workers, the inverse's team
+                const int nb = Np / 128;
+                const size_t trn = (size_t)nb * 16 + 16 * 512;
+                long long* tr; hipMalloc(&tr, trn * 8); hipMemset(tr, 0, trn * 8);
+                hipMemcpyAsync(A, A0, bytes, hipMemcpyDeviceToDevice, s);
+                hipMemsetAsync(info, 0, 64, s); hipMemsetAsync(X2, 0, bytes, s);
+                launch_potri_dataflow(s, A, Np, X2, U2, K2, info, dsync, tr);
+                hipStreamSynchronize(s);
+                std::vector<long long> ht(trn); hipMemcpy(ht.data(), tr, trn * 8, hipMemcpyDeviceToHost);
+                const double t_start = (double)ht[0], t_chain_end = (double)ht[16 * (nb - 2) + 4];
+                int n1 = 0, n2 = 0; double busy1 = 0, busy2 = 0, life2 = 0, end2_max = 0, end2_mean = 0; long tasks2 = 0;
+                for (int w = 0; w < 512; ++w) {
+                    const long long* o = ht.data() + 16 * nb + 16 * w;
+                    if (o[6] > 0) { ++n1; busy1 += o[0] / 100.0; }
+                    else if (o[6] < 0) {
+                        ++n2; busy2 += o[0] / 100.0; life2 += o[2] / 100.0; tasks2 += o[3];
+                        const double e = ((double)o[10] - t_start) / 100.0; end2_max = fmax(end2_max, e); end2_mean += e;
+                    }
+                }
+                printf("  fused trace N=%d: chain ends at %.0f us; factorisation's workers: %d, mean busy %.0f us; inverse team: %d workgroups, %ld tasks, "
+                       "mean busy %.0f us (mean task %.1f us), mean life %.0f us, last task ends at mean %.0f / max %.0f us\n",
+                       Np, (t_chain_end - t_start) / 100.0, n1, n1 ? busy1 / n1 : 0.0, n2, tasks2, n2 ? busy2 / n2 : 0.0, tasks2 ? busy2 / tasks2 : 0.0,
+                       n2 ? life2 / n2 : 0.0, n2 ? end2_mean / n2 : 0.0, end2_max);
+                hipFree(tr);
+            }
             if (timeit(true, X2, U2, K2)) {
                 std::vector<double> hx1((size_t)Np * Np), hx2((size_t)Np * Np);
                 auto cmp = [&](const double* d1, const double* d2, int mode, const char* name) {   // mode 0 lower, 1 upper blocks, 2 full
