@@ -102,6 +102,14 @@ __device__ __forceinline__ void slab_row_to_lds(const double* g, double* l) {
                                      0);
 }
 
+// The same with an agent-scope load (sc1): coherent across the XCDs' L2s without an invalidate before it -- for data another
+// workgroup published a moment ago (the streamed column blocks of the Cholesky's diagonal block): a `buffer_inv sc1` per block and
+// wave instead drops the whole L2 of the XCD every time.
+__device__ __forceinline__ void slab_row_to_lds_sc1(const double* g, double* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0,
+                                     16);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // gemm_tile_mc: both operands M-contiguous (the acquisition GEMM, the variance GEMM, the Gram products, most of the
 // Cholesky chain).  A k-row of a slab is 128 contiguous doubles = 64 lanes x 16 B, exactly what one LDS-direct load

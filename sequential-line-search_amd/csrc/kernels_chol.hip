@@ -346,8 +346,12 @@ struct PersistArgs {
     // i <= k + 1 + stream_rows are solved the same way.  nchain = 1: the round-3 chain (solve on the chain itself).
     int nchain, stream_rows;
     // split_sub: the sub-diagonal tiles (k+1, k) -- whose last update sits between the follower's solve of step k-1 and its solve
-    // of step k -- have one owner per 64-column half (gemm_tile_mc<2>: same slabs, same k order, same bits)
-    int split_sub;
+    // of step k -- have one owner per 64-column half (gemm_tile_mc<2>: same slabs, same k order, same bits).  split_band: so do
+    // the tiles (i, k) with 1 <= i - k <= split_band: every row runs the cycle "panel tile solved behind diagonal block k-1 ->
+    // update of (i, k) with it -> panel tile (i, k) solved behind diagonal block k", which is as long as the chain's own step when
+    // the update is a whole-tile product (14 + 3 + 21 us against 39): a row that falls behind once never catches up, and sooner
+    // or later it is the sub-diagonal one.  The first half's owner solves the tile once the second half has reported (upd_done).
+    int split_sub, split_band;
 };
 #define PK_STAMP(slot) do { if (a.trace && threadIdx.x == 0) a.trace[16 * j + (slot)] = wall_clock64(); } while (0)
 
@@ -622,10 +626,10 @@ __device__ __forceinline__ bool stream_trsm(ChainAcc& V, const double* __restric
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 4 * wave + r;
-            slab_row_to_lds(L + 2 * lane + (long)(16 * s + row) * ldl, base + row * GEMM_LDS_MC_LD);
+            slab_row_to_lds_sc1(L + 2 * lane + (long)(16 * s + row) * ldl, base + row * GEMM_LDS_MC_LD);
         }
         if (wave < 2)                                    // 8 columns x 128 bytes: lane -> (column 8 wave + lane / 8, row pair lane % 8)
-            slab_row_to_lds(T + (16 * s + 2 * (lane & 7)) + (long)(16 * s + 8 * wave + (lane >> 3)) * ldt, Tbuf + (s & 1) * 256 + 128 * wave);
+            slab_row_to_lds_sc1(T + (16 * s + 2 * (lane & 7)) + (long)(16 * s + 8 * wave + (lane >> 3)) * ldt, Tbuf + (s & 1) * 256 + 128 * wave);
     };
     V.zero();
     issueA(0); issueA(1); issueA(2);
@@ -636,8 +640,7 @@ __device__ __forceinline__ bool stream_trsm(ChainAcc& V, const double* __restric
         if (!ok) return;
         if (issuedL <= s) {
             if (!stream_wait(flag, 3 * (s + 1), abort_flag, timeout)) { ok = false; return; }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            issueL(s);
+            issueL(s);                                   // agent-scope loads: no invalidate needed in front of them
             issuedL = s + 1;
         }
         ring_wait_barrier<0>();                          // slab s of A and of L in LDS (every wave's part); slab s - 1 no longer read
@@ -646,7 +649,6 @@ __device__ __forceinline__ bool stream_trsm(ChainAcc& V, const double* __restric
             int have = 0;
             if (lane == 0) have = df_flag(flag) >= 3 * (s + 2) ? 1 : 0;
             if (__builtin_amdgcn_readfirstlane(have)) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 issueL(s + 1);
                 issuedL = s + 2;
             }
@@ -1207,6 +1209,7 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
     // (j+1, j+1) does.  Separate words: in the streamed form the follower only needs the first -- the diagonal tile's last update
     // comes ~6 us later and is only needed by the chain, behind the follower's solve
     int* diag_ready = a.sync + DF_FACT + 2 * nb + 2 * nb * nb;
+    int* upd_done = diag_ready + nb;                    // [i + k nb]: the second half of tile (i, k) carries all its updates
     const int nchain = a.nchain;
     if (b == 0 && nchain == 2) {
         // ---- the chain, streamed form: diagonal blocks + the product L L^T; the panel tile comes from the follower ----
@@ -1355,18 +1358,19 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
         if (ok) {
             // tiles in column-major order (without (0, 0)) dealt round-robin: even in total work and at every stage (a cyclic
             // PR x PC owner grid left 1.4x the mean work on some owners: 5.7 vs 5.0 ms at N = 8192, round 3)
-            // split_sub: column k carries one more item, the second half of its sub-diagonal tile (k+1, k)
+            // split_band: column k carries extra items, the second halves of its tiles (k+1, k) .. (k+band, k)
             int k = 0;
             long off = 0;                                    // items before column k
-            auto cnt = [&](int kk) { return nb - kk + (a.split_sub && kk <= nb - 2 ? 1 : 0); };
+            const int band = a.split_band;
+            auto cnt = [&](int kk) { return nb - kk + min(band, nb - 1 - kk); };
             for (long t = widx; nt < DF_MAXT; t += W) {
                 const long tt = t + 1;                       // skip (0, 0)
                 while (k < nb && tt >= off + cnt(k)) { off += cnt(k); ++k; }
                 if (k >= nb) break;
                 const int e = (int)(tt - off);
-                const bool second = e == nb - k;             // the extra item
-                SW(0, nt) = second ? k + 1 : k + e; SW(1, nt) = k; SW(2, nt) = 0; SW(3, nt) = 0;
-                SW(6, nt) = second ? 2 : (a.split_sub && e == 1 ? 1 : 0);      // 0 whole tile, 1 / 2: columns 0-63 / 64-127
+                const bool second = e >= nb - k;             // an extra item: second half of tile (k + 1 + (e - (nb - k)), k)
+                SW(0, nt) = second ? k + 1 + (e - (nb - k)) : k + e; SW(1, nt) = k; SW(2, nt) = 0; SW(3, nt) = 0;
+                SW(6, nt) = second ? 2 : (e >= 1 && e <= band ? 1 : 0);        // 0 whole tile, 1 / 2: columns 0-63 / 64-127
                 ++nt;
             }
             if (a.g1 > 0) {
@@ -1413,11 +1417,12 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
                     const int j1 = df_chunk_end(k, j0, target, nbo, a.near);
                     const int j = j0 + (l & 7);
                     if (j < j1 && !(l >= 8 && i == k)) ok = df_flag(panel_done + (l < 8 ? i : k) + (long)j * nb) != 0;
-                } else if (i > k + 1) {
+                } else if (i > k + 1 && SW(6, t) != 2) {
                     // the whole diagonal block (24 = 3 waves x 8 column blocks in the streamed form, 1 otherwise), or its first
-                    // column block for the tiles that are solved block by block behind it
+                    // column block for the tiles that are solved block by block behind it; a tile with two owners: the other half
                     const int need = nchain == 2 ? (i <= k + 1 + a.stream_rows ? 3 : 24) : 1;
                     if (l == 0) ok = df_flag(factored + k) >= need;
+                    else if (l == 1 && SW(6, t) == 1) ok = df_flag(upd_done + i + (long)k * nb) != 0;
                 }
             }
             const unsigned long long m = __ballot(ok);
@@ -1476,6 +1481,9 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
                         a.trace[16 * (k - 1) + 14 + 0] = half == 1 ? st_task0 : a.trace[16 * (k - 1) + 14];
                         if (half == 1) a.trace[16 * (k - 1) + 15] = wall_clock64();
                     }
+                } else if (last && half == 2) {               // second half of a tile that is solved by the first half's owner
+                    tile_commit_half<1, true>(Cik, ld, acc, lds, 1);
+                    df_publish_store(upd_done + i + (long)k * nb);
                 } else {
                     tile_commit_half<1, false>(Cik, ld, acc, lds, half - 1);
                     __syncthreads();
@@ -1490,19 +1498,29 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             }
             if (tid == 0) {
                 SW(2, t) = j1;
-                if (to_chain) SW(3, t) = 1;
+                if (to_chain || (last && half == 2)) SW(3, t) = 1;
             }
             ++st_n_upd;
+        } else if (i > k + 1 && SW(6, t) == 2) {
+            // second half with no update to apply (column 0): report at once
+            if (tid == 0) {
+                __hip_atomic_store(upd_done + i + (long)k * nb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                SW(3, t) = 1;
+            }
         } else if (i > k + 1) {
             ++st_n_panel;
             if (nchain == 2 && i <= k + 1 + a.stream_rows) {
+                const bool stamp = a.trace && tid == 0 && i == k + 2;      // probes: the panel tile right below the follower's
+                if (stamp) a.trace[16 * k + 5] = st_task0;
                 ChainAcc ca;
                 if (!stream_trsm(ca, Cik, ld, a.A + (long)k * NB * (ld + 1), ld, a.Linv + (long)k * NB * (ld + 1), ld, factored + k,
                                  a.info + 1, a.timeout, lds))
                     return;
+                if (stamp) a.trace[16 * k + 6] = wall_clock64();
                 chain_acc_to_image<true>(ca, lds);
                 lds_barrier();
                 chain_image_store_wt(Cik, ld, lds);
+                if (stamp) a.trace[16 * k + 7] = wall_clock64();
             } else {
                 const double* Lkk = a.A + (long)k * NB * (ld + 1);
                 const double* Tkk = a.Linv + (long)k * NB * (ld + 1);              // its diagonal 16 x 16 tiles hold the small inverses
@@ -1612,7 +1630,7 @@ int potrf_dataflow_nbo(int Np) {
 // ints of device scratch the dataflow form needs per problem
 size_t potrf_dataflow_sync_ints(int Np) {
     const size_t nb = Np / NB;
-    return DF_FACT + 3 * nb + 2 * nb * nb;           // factored, chain_ready, panel_done[nb][nb], xdone[nb][nb] (fused inverse), diag_ready
+    return DF_FACT + 3 * nb + 3 * nb * nb;           // factored, chain_ready, panel_done[nb][nb], xdone[nb][nb] (fused inverse), diag_ready, upd_done[nb][nb]
 }
 // How many independent Np x Np factorisations share one launch well: a problem keeps the chip busy with about nb^2 / 14.5 workers
 // (its ~nb^3 / 6 tile tasks of ~20 us against a chain of nb steps of ~48 us); the rest of the CUs can factor other problems.
@@ -1653,8 +1671,16 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
     // Several problems per launch are bound by their workers, not by their chains (8 value-only evaluations at N = 4096: 6.4 ms on
     // the round-3 chain, 7.3 ms streamed): the round-3 form there too.
     const int nchain = envi("SLS_POTRF_STREAM", nb <= 40 && nprob == 1 ? SLS_POTRF_STREAM_DEFAULT : 0) != 0 && nb >= 4 ? 2 : 1;
-    const int split_sub = nchain == 2 && envi("SLS_POTRF_SPLIT", 1) != 0 ? 1 : 0;
-    const int tiles = tiles_whole + (split_sub ? nb - 1 : 0);                // items dealt to the workers
+    // SLS_POTRF_SPLIT = band: the tiles (i, k) with 1 <= i - k <= band have one owner per 64-column half (0: whole tiles only)
+    // Measured (tools/probes: ms at N = 2048 / 3072 / 4096): factorisation alone: band 1: 0.655 / 0.992 / 1.363, 4: 0.645 / 0.999 / 1.353,
+    // all: 0.654 / 1.000 / 1.345 -- what matters is that every row's cycle is shorter than the chain's step, the follower then finds
+    // its tile 14-22 us before the diagonal block ends at EVERY step (before: -4 .. +6 us at every third one).  With the fused
+    // inverse sharing the chip: band 1: 0.742 / 1.284 / 2.158, all: 0.733 / 1.344 / 2.518 (CUs are short from N = 3072).
+    const int split_band = nchain == 2 ? std::max(0, std::min(nb - 1, envi("SLS_POTRF_SPLIT", (nb <= 16 || !inv) ? nb : 1))) : 0;
+    const int split_sub = split_band >= 1 ? 1 : 0;
+    int n_second = 0;
+    for (int kk = 0; kk < nb; ++kk) n_second += std::min(split_band, nb - 1 - kk);
+    const int tiles = tiles_whole + n_second;                                 // items dealt to the workers
     int Gp = std::max(nchain + 1, std::min(n_cu / nprob, nchain + tiles));   // workgroups per problem
     int G2 = 0;
     if (inv) {
@@ -1690,6 +1716,7 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
     a.Kinv = inv ? inv->Kinv : nullptr;
     a.nchain = nchain;
     a.split_sub = split_sub;
+    a.split_band = split_band;
     a.stream_rows = std::max(0, envi("SLS_POTRF_STREAM_ROWS", 1 << 20));   // every panel tile (only the next row: 0.725 instead of 0.685 ms at N = 2048)
     a.inv_ksplit = std::max(1, std::min(nb, envi("SLS_POTRI_KSPLIT", nb)));
     // measured (ms, factor + inverse; two products per row -> one): N = 384: 0.209 -> 0.234, 1024: 0.405 -> 0.411, 2048: 0.759 -> 0.753,

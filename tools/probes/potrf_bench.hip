@@ -158,7 +158,7 @@ int main(int argc, char** argv) {
                     for (int j = 0; j < nb - 1; ++j) {
                         const long long* g = ht.data() + 16 * j; const double t0 = (double)g[0];
                         auto us = [&](long long v) { return v ? ((double)v - t0) / 100.0 : -1.0; };
-                        printf("   %2d: %6.1f %6.1f %6.1f | %5.1f | %6.1f %6.1f\n", j, us(g[11]), us(g[12]), us(g[13]), us(g[1]), us(g[14]), us(g[15]));
+                        printf("   %2d: %6.1f %6.1f %6.1f | %5.1f | %6.1f %6.1f | panel tile (j+2, j): task start %6.1f solve done %6.1f stores issued %6.1f\n", j, us(g[11]), us(g[12]), us(g[13]), us(g[1]), us(g[14]), us(g[15]), us(g[5]), us(g[6]), us(g[7]));
                     }
                 }
                 hipFree(tr);
