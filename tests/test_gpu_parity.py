@@ -88,6 +88,8 @@ def test_potrf_schedules_agree(N, monkeypatch):
                       ("dataflow1_nostream", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "1", "SLS_POTRF_STREAM": "0"}),
                       ("dataflow1_rows0", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "1", "SLS_POTRF_STREAM_ROWS": "0"}),
                       ("dataflow1_rows1_nosplit", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "1", "SLS_POTRF_STREAM_ROWS": "1", "SLS_POTRF_SPLIT": "0"}),
+                      ("dataflow1_band1", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "1", "SLS_POTRF_SPLIT": "1"}),
+                      ("dataflow1_band3", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "1", "SLS_POTRF_SPLIT": "3"}),
                       ("dataflow2", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "2"}),
                       ("dataflow4near", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "4", "SLS_POTRF_DNEAR": "2"})):
         for k in [k for k in os.environ if k.startswith("SLS_POTRF_")]:
@@ -110,7 +112,7 @@ def test_potrf_schedules_agree(N, monkeypatch):
     close(res["dataflow4near"], res["multi"], rtol=1e-12, atol=1e-13)
     assert np.array_equal(res["multi2"], res["multi2look"])        # the side stream changes the schedule, not the arithmetic
     # ... and so do the follower workgroup, the streamed solves and the half-tile owners (same slabs, same MFMA order)
-    for name in ("dataflow1_nostream", "dataflow1_rows0", "dataflow1_rows1_nosplit"):
+    for name in ("dataflow1_nostream", "dataflow1_rows0", "dataflow1_rows1_nosplit", "dataflow1_band1", "dataflow1_band3"):
         assert np.array_equal(res[name], res["dataflow1"]), name
     close(res["multi2"], res["multi"], rtol=1e-12, atol=1e-13)
 
