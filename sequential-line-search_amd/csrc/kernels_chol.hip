@@ -981,12 +981,161 @@ __device__ __forceinline__ int potri_k_task(const PersistArgs& a, int i, int j, 
     }
     return k1;
 }
-__device__ __forceinline__ void potri_team(const PersistArgs& a, int b2, int G2, double* lds, char* smem) {
+// One item of the fused inverse (type 0 T(j), 4 P(i), 1 X(i, j), 2 K(i, j); d = its progress): are the inputs of its next task there?
+// Called by the 16 lanes of a scheduling slot, one flag per lane (l = lane in the slot); the caller combines the answers.
+__device__ __forceinline__ bool potri_item_ready(const PersistArgs& a, int type, int i, int j, int d, int l) {
+    const int nb = a.nb;
+    const int* factored = a.sync + DF_FACT;
+    const int* panel_done = a.sync + DF_FACT + 2 * nb;
+    const int* xdone = a.sync + DF_FACT + 2 * nb + nb * nb;     // [k + j nb], k >= j: X_kj / U_jk stored (k == j: T_jj / U_jj)
+    const int cx = a.inv_cx, ck = a.inv_ck;
+    bool ok = true;
+    if (type == 0) {
+        if (l == 0) ok = df_flag(factored + i) >= (a.nchain == 2 ? 24 : 1);
+    } else if (type == 1) {
+        // d: terms applied (k = j .. i - 1 - plast), then nterms -> Q pending, nterms + 1 -> last step pending (plast)
+        const int nterms = i - j - a.inv_plast;
+        if (d < nterms) {
+            const int k0 = j + d, k1 = min(k0 + cx, j + nterms), k = k0 + (l & 7);
+            if (k < k1) ok = df_flag(l < 8 ? xdone + k + (long)j * nb : panel_done + i + (long)k * nb) != 0;
+        } else if (d == nterms) {
+            if (l == 0) ok = df_flag(xdone + i + (long)i * nb) != 0;
+        } else {
+            if (l == 0) ok = df_flag(xdone + (i - 1) + (long)j * nb) != 0;
+            else if (l == 1) ok = df_flag(xdone + (i - 1) + (long)i * nb) != 0;        // P(i): the unused entry (i-1, i)
+        }
+    } else if (type == 4) {
+        if (l == 0) ok = df_flag(xdone + i + (long)i * nb) != 0;
+        else if (l == 1) ok = df_flag(panel_done + i + (long)j * nb) != 0;
+    } else {
+        const int k0 = i + d, k1 = min(k0 + ck, nb), k = k0 + (l & 7);
+        if (k < k1) ok = df_flag(xdone + k + (long)(l < 8 ? i : j) * nb) != 0;
+    }
+    return ok;
+}
+struct PotriStep {
+    int d;          // the item's progress after the task
+    bool done;      // the item is finished
+};
+// ... and the task itself (whole workgroup).  Shared by the inverse's own team (potri_team) and by the factorisation's workers when
+// the launch runs as ONE pool (N > 2048: see launch_potrf_dataflow_impl).
+__device__ __forceinline__ PotriStep potri_item_task(const PersistArgs& a, int type, int i, int j, int d, double* lds, char* smem) {
     const int nb = a.nb;
     const long ld = a.ld;
-    int* factored = a.sync + DF_FACT;
-    int* panel_done = a.sync + DF_FACT + 2 * nb;          // [i + j nb]
-    int* xdone = a.sync + DF_FACT + 2 * nb + nb * nb;     // [k + j nb], k >= j: X_kj / U_jk stored (k == j: T_jj / U_jj)
+    int* xdone = a.sync + DF_FACT + 2 * nb + nb * nb;
+    const int tid = threadIdx.x;
+    const int cx = a.inv_cx, ck = a.inv_ck;
+    PotriStep res{d, false};
+    if (type == 0) {
+        // T_jj around the eight 16 x 16 diagonal inverses the chain left (loaded, not recomputed: panel solves of the
+        // factorisation may still be reading them, and the bits must not depend on who comes first) and U_jj = T_jj^T.  After
+        // diag_block the strictly-upper tiles of the LDS image still hold the transposed inverse tiles, Ts the diagonal ones.
+        double* Ljj = a.A + (long)i * NB * (ld + 1);
+        double* Tjj = a.Linv + (long)i * NB * (ld + 1);
+        double* Ujj = a.U + (long)i * NB * (ld + 1);
+        diag_block<false, true, true, true>(Ljj, ld, Tjj, ld, nullptr, 0, smem);
+        const double* As = lds;
+        const double* Ts = lds + 128 * DL;
+        auto rsrcU = __builtin_amdgcn_make_buffer_rsrc(Ujj, 0, 0x7fffffff, 0x00020000);
+        const int i2 = 2 * (tid & 63), jc = tid >> 6, tr = i2 >> 4;
+#pragma unroll 8
+        for (int p = 0; p < 32; ++p) {
+            const int c = 4 * p + jc, tc = c >> 4;
+            d2_t v = {0.0, 0.0};
+            if (tr < tc) v = *reinterpret_cast<const d2_t*>(As + i2 + c * DL);
+            else if (tr == tc) {                           // U[r][c] = T16[c & 15][r & 15]: zero for r > c by construction
+                v[0] = Ts[256 * tc + (c & 15) + 16 * (i2 & 15)];
+                v[1] = Ts[256 * tc + (c & 15) + 16 * ((i2 + 1) & 15)];
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rsrcU, (int)((i2 + (long)c * ld) * 8), 0, 16);
+        }
+        df_publish_store(xdone + i + (long)i * nb);
+        res.done = true;
+    } else if (type == 4) {
+        // P_i = T_ii L_{i,i-1}.  L's contraction index is its contiguous one, so the tile goes through an LDS transpose first
+        // (image -> in place -> scratch block, read back as an M-contiguous operand); scratch = block (i, i-1) of U: nothing
+        // else reads or writes U's strictly-lower blocks.  (Not a block of K^-1: its mirror tiles are written as soon as the two
+        // columns they depend on are complete, while another column may still need P_i.)
+        const double* Lsub = a.A + (long)i * NB + (long)j * NB * ld;
+        const double* Tii = a.Linv + (long)i * NB * (ld + 1);
+        double* Pi = a.U + (long)i * NB + (long)j * NB * ld;
+        {
+            const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll 8
+            for (int q = 0; q < 32; ++q) {
+                const int c = w + 4 * q;
+                slab_row_to_lds(Lsub + 2 * lane + (long)c * ld, lds + c * DL);
+            }
+            ring_wait_barrier<0>();
+        }
+        image_transpose_inplace(lds);
+        lds_barrier();
+        chain_image_store_wt(Pi, ld, lds);                                 // L_{i,i-1}^T
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // this CU reads the block back through its L1
+        __syncthreads();
+        Acc acc;
+        acc.zero();
+        gemm_tile_mc<4, true>(acc, Tii, ld, Pi, ld, 0, NB, lds);           // P[m][n] = sum_k T_ii[m][k] L^T[n][k]
+        tile_commit<0, true>(Pi, ld, acc, lds);
+        df_publish_store(xdone + j + (long)i * nb);                        // entry (i-1, i)
+        res.done = true;
+    } else if (type == 1) {
+        double* Mji = a.U + (long)j * NB + (long)i * NB * ld;              // block (j, i) of U: M, then Q, then U_ji
+        const int nterms = i - j - a.inv_plast;
+        if (d < nterms) {
+            const int k0 = j + d, k1 = min(k0 + cx, j + nterms);
+            Acc acc;
+            acc.zero();
+            gemm_tile_mc<4, true>(acc, a.U + (long)j * NB + (long)k0 * NB * ld, ld, a.A + (long)i * NB + (long)k0 * NB * ld, ld, 0,
+                                  (k1 - k0) * NB, lds);
+            if (d == 0) tile_commit<2, false>(Mji, ld, acc, lds);
+            else tile_commit<1, false>(Mji, ld, acc, lds);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            res.d = k1 - j;
+        } else if (d == nterms) {
+            const double* Tii = a.Linv + (long)i * NB * (ld + 1);
+            Acc acc;
+            acc.zero();
+            gemm_tile_mc<4, true>(acc, Mji, ld, Tii, ld, 0, NB, lds);      // Q = M T_ii^T
+            if (a.inv_plast) {
+                tile_commit<0, false>(Mji, ld, acc, lds);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                res.d = nterms + 1;
+            } else {                                                       // every term is in: Q is U_ji
+                tile_commit<0, true>(Mji, ld, acc, lds);
+                df_publish_store(xdone + i + (long)j * nb);
+                image_transpose_inplace(lds);
+                lds_barrier();
+                chain_image_store_wt(a.Linv + (long)i * NB + (long)j * NB * ld, ld, lds);
+                res.done = true;
+            }
+        } else {
+            const double* Pi = a.U + (long)i * NB + (long)(i - 1) * NB * ld;
+            Acc acc;
+            acc.zero();
+            gemm_tile_mc<4, true>(acc, a.U + (long)j * NB + (long)(i - 1) * NB * ld, ld, Pi, ld, 0, NB, lds);   // U_{j,i-1} P_i^T
+            if (j == i - 1) tile_commit<2, true, true>(Mji, ld, acc, lds);                                     // no Q: U_ji = -acc
+            else tile_commit<1, true, true>(Mji, ld, acc, lds);                                                // U_ji = Q - acc
+            df_publish_store(xdone + i + (long)j * nb);                    // U_ji is what the other tasks read
+            image_transpose_inplace(lds);                                  // X_ij = U_ji^T: an output only
+            lds_barrier();
+            chain_image_store_wt(a.Linv + (long)i * NB + (long)j * NB * ld, ld, lds);
+            res.done = true;
+        }
+    } else {
+        const int k1 = potri_k_task(a, i, j, d, ck, lds);
+        res.d = k1 - i;
+        res.done = k1 == nb;
+    }
+    return res;
+}
+
+__device__ __forceinline__ void potri_team(const PersistArgs& a, int b2, int G2, double* lds, char* smem) {
+    const int nb = a.nb;
     auto SW = [&](int arr, int k) -> int& { return reinterpret_cast<int*>(lds + k * DL + 128)[arr]; };
     const int tid = threadIdx.x;
     if (tid == 0) {
@@ -1013,7 +1162,6 @@ __device__ __forceinline__ void potri_team(const PersistArgs& a, int b2, int G2,
     int first = 0;
     long long t_progress = wall_clock64();
     const int slot = tid >> 4, l = tid & 15;
-    const int cx = a.inv_cx, ck = a.inv_ck;
     long long st_task = 0, st_t0 = t_progress, st_n = 0, st_last = 0;       // probes: ticks in tasks, task count, end of the last task
     for (;;) {
         while (first < nt && SW(3, first)) ++first;
@@ -1024,27 +1172,7 @@ __device__ __forceinline__ void potri_team(const PersistArgs& a, int b2, int G2,
             bool ok = true;
             if (valid) {
                 const int i = SW(0, t), j = SW(1, t), d = SW(2, t), type = SW(6, t);
-                if (type == 0) {
-                    if (l == 0) ok = df_flag(factored + i) >= (a.nchain == 2 ? 24 : 1);
-                } else if (type == 1) {
-                    // d: terms applied (k = j .. i - 1 - plast), then nterms -> Q pending, nterms + 1 -> last step pending (plast)
-                    const int nterms = i - j - a.inv_plast;
-                    if (d < nterms) {
-                        const int k0 = j + d, k1 = min(k0 + cx, j + nterms), k = k0 + (l & 7);
-                        if (k < k1) ok = df_flag(l < 8 ? xdone + k + (long)j * nb : panel_done + i + (long)k * nb) != 0;
-                    } else if (d == nterms) {
-                        if (l == 0) ok = df_flag(xdone + i + (long)i * nb) != 0;
-                    } else {
-                        if (l == 0) ok = df_flag(xdone + (i - 1) + (long)j * nb) != 0;
-                        else if (l == 1) ok = df_flag(xdone + (i - 1) + (long)i * nb) != 0;        // P(i): the unused entry (i-1, i)
-                    }
-                } else if (type == 4) {
-                    if (l == 0) ok = df_flag(xdone + i + (long)i * nb) != 0;
-                    else if (l == 1) ok = df_flag(panel_done + i + (long)j * nb) != 0;
-                } else {
-                    const int k0 = i + d, k1 = min(k0 + ck, nb), k = k0 + (l & 7);
-                    if (k < k1) ok = df_flag(xdone + k + (long)(l < 8 ? i : j) * nb) != 0;
-                }
+                ok = potri_item_ready(a, type, i, j, d, l);
             }
             const unsigned long long m = __ballot(ok);
             const unsigned grp = (unsigned)(m >> (16 * ((tid >> 4) & 3))) & 0xffffu;
@@ -1070,112 +1198,10 @@ __device__ __forceinline__ void potri_team(const PersistArgs& a, int b2, int G2,
         const long long st_task0 = a.trace ? wall_clock64() : 0;
         const int t = first + sel;
         const int i = SW(0, t), j = SW(1, t), d = SW(2, t), type = SW(6, t);
-        if (type == 0) {
-            // T_jj around the eight 16 x 16 diagonal inverses the chain left (loaded, not recomputed: panel solves of the
-            // factorisation may still be reading them, and the bits must not depend on who comes first) and U_jj = T_jj^T.  After
-            // diag_block the strictly-upper tiles of the LDS image still hold the transposed inverse tiles, Ts the diagonal ones.
-            double* Ljj = a.A + (long)i * NB * (ld + 1);
-            double* Tjj = a.Linv + (long)i * NB * (ld + 1);
-            double* Ujj = a.U + (long)i * NB * (ld + 1);
-            diag_block<false, true, true, true>(Ljj, ld, Tjj, ld, nullptr, 0, smem);
-            const double* As = lds;
-            const double* Ts = lds + 128 * DL;
-            auto rsrcU = __builtin_amdgcn_make_buffer_rsrc(Ujj, 0, 0x7fffffff, 0x00020000);
-            const int i2 = 2 * (tid & 63), jc = tid >> 6, tr = i2 >> 4;
-#pragma unroll 8
-            for (int p = 0; p < 32; ++p) {
-                const int c = 4 * p + jc, tc = c >> 4;
-                d2_t v = {0.0, 0.0};
-                if (tr < tc) v = *reinterpret_cast<const d2_t*>(As + i2 + c * DL);
-                else if (tr == tc) {                           // U[r][c] = T16[c & 15][r & 15]: zero for r > c by construction
-                    v[0] = Ts[256 * tc + (c & 15) + 16 * (i2 & 15)];
-                    v[1] = Ts[256 * tc + (c & 15) + 16 * ((i2 + 1) & 15)];
-                }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rsrcU, (int)((i2 + (long)c * ld) * 8), 0, 16);
-            }
-            df_publish_store(xdone + i + (long)i * nb);
-            if (tid == 0) SW(3, t) = 1;
-        } else if (type == 4) {
-            // P_i = T_ii L_{i,i-1}.  L's contraction index is its contiguous one, so the tile goes through an LDS transpose first
-            // (image -> in place -> scratch block, read back as an M-contiguous operand); scratch = block (i, i-1) of U: nothing
-            // else reads or writes U's strictly-lower blocks.  (Not a block of K^-1: its mirror tiles are written as soon as the two
-            // columns they depend on are complete, while another column may still need P_i.)
-            const double* Lsub = a.A + (long)i * NB + (long)j * NB * ld;
-            const double* Tii = a.Linv + (long)i * NB * (ld + 1);
-            double* Pi = a.U + (long)i * NB + (long)j * NB * ld;
-            {
-                const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-#pragma unroll 8
-                for (int q = 0; q < 32; ++q) {
-                    const int c = w + 4 * q;
-                    slab_row_to_lds(Lsub + 2 * lane + (long)c * ld, lds + c * DL);
-                }
-                ring_wait_barrier<0>();
-            }
-            image_transpose_inplace(lds);
-            lds_barrier();
-            chain_image_store_wt(Pi, ld, lds);                                 // L_{i,i-1}^T
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // this CU reads the block back through its L1
-            __syncthreads();
-            Acc acc;
-            acc.zero();
-            gemm_tile_mc<4, true>(acc, Tii, ld, Pi, ld, 0, NB, lds);           // P[m][n] = sum_k T_ii[m][k] L^T[n][k]
-            tile_commit<0, true>(Pi, ld, acc, lds);
-            df_publish_store(xdone + j + (long)i * nb);                        // entry (i-1, i)
-            if (tid == 0) SW(3, t) = 1;
-        } else if (type == 1) {
-            double* Mji = a.U + (long)j * NB + (long)i * NB * ld;              // block (j, i) of U: M, then Q, then U_ji
-            const int nterms = i - j - a.inv_plast;
-            if (d < nterms) {
-                const int k0 = j + d, k1 = min(k0 + cx, j + nterms);
-                Acc acc;
-                acc.zero();
-                gemm_tile_mc<4, true>(acc, a.U + (long)j * NB + (long)k0 * NB * ld, ld, a.A + (long)i * NB + (long)k0 * NB * ld, ld, 0,
-                                      (k1 - k0) * NB, lds);
-                if (d == 0) tile_commit<2, false>(Mji, ld, acc, lds);
-                else tile_commit<1, false>(Mji, ld, acc, lds);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (tid == 0) SW(2, t) = k1 - j;
-            } else if (d == nterms) {
-                const double* Tii = a.Linv + (long)i * NB * (ld + 1);
-                Acc acc;
-                acc.zero();
-                gemm_tile_mc<4, true>(acc, Mji, ld, Tii, ld, 0, NB, lds);      // Q = M T_ii^T
-                if (a.inv_plast) {
-                    tile_commit<0, false>(Mji, ld, acc, lds);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-                    if (tid == 0) SW(2, t) = nterms + 1;
-                } else {                                                       // every term is in: Q is U_ji
-                    tile_commit<0, true>(Mji, ld, acc, lds);
-                    df_publish_store(xdone + i + (long)j * nb);
-                    image_transpose_inplace(lds);
-                    lds_barrier();
-                    chain_image_store_wt(a.Linv + (long)i * NB + (long)j * NB * ld, ld, lds);
-                    if (tid == 0) SW(3, t) = 1;
-                }
-            } else {
-                const double* Pi = a.U + (long)i * NB + (long)(i - 1) * NB * ld;
-                Acc acc;
-                acc.zero();
-                gemm_tile_mc<4, true>(acc, a.U + (long)j * NB + (long)(i - 1) * NB * ld, ld, Pi, ld, 0, NB, lds);   // U_{j,i-1} P_i^T
-                if (j == i - 1) tile_commit<2, true, true>(Mji, ld, acc, lds);                                     // no Q: U_ji = -acc
-                else tile_commit<1, true, true>(Mji, ld, acc, lds);                                                // U_ji = Q - acc
-                df_publish_store(xdone + i + (long)j * nb);                    // U_ji is what the other tasks read
-                image_transpose_inplace(lds);                                  // X_ij = U_ji^T: an output only
-                lds_barrier();
-                chain_image_store_wt(a.Linv + (long)i * NB + (long)j * NB * ld, ld, lds);
-                if (tid == 0) SW(3, t) = 1;
-            }
-        } else {
-            const int k1 = potri_k_task(a, i, j, d, ck, lds);
-            if (tid == 0) {
-                SW(2, t) = k1 - i;
-                if (k1 == nb) SW(3, t) = 1;
-            }
+        const PotriStep step = potri_item_task(a, type, i, j, d, lds, smem);
+        if (tid == 0) {
+            SW(2, t) = step.d;
+            if (step.done) SW(3, t) = 1;
         }
         __syncthreads();
         t_progress = wall_clock64();
