@@ -22,6 +22,9 @@
 #ifndef SLS_POTRF_MODE_DEFAULT
 #define SLS_POTRF_MODE_DEFAULT 3
 #endif
+#ifndef SLS_POTRI_POOL_DEFAULT
+#define SLS_POTRI_POOL_DEFAULT(nb) 0
+#endif
 #ifndef SLS_POTRF_STREAM_DEFAULT
 #define SLS_POTRF_STREAM_DEFAULT 1
 #endif
@@ -340,6 +343,8 @@ struct PersistArgs {
     int inv_cx, inv_ck;   // 128-blocks of the contraction per X / K^-1 accumulation task (fixed chunking)
     int inv_plast;        // 1: the term of the row just above is split off (P_i, one product per row on the column wavefront); 0: every
                           // term is accumulated, then U_ji = M T_ii^T (two products per row, no P task: shorter tail for few rows)
+    int inv_pool;         // 1: no team of its own -- the factorisation's workers own the inverse's items too, behind their tiles (ONE pool:
+                          // a worker runs the first ready item of its list, so a tile of the factorisation always goes first)
     int inv_ksplit;       // K^-1 tiles of the rows >= inv_ksplit are accumulated by the factorisation's workers (potri_k_task)
     // streamed panel tiles (stream_trsm): nchain = 2 adds the FOLLOWER workgroup, which solves the chain's panel tile (j+1, j)
     // against the column blocks of L_jj while the chain is still factoring them; stream_rows: worker panel tiles (i, k) with
@@ -1400,14 +1405,26 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
                 ++nt;
             }
             if (a.g1 > 0) {
-                // fused inverse: the K^-1 tiles of the late rows, behind this worker's own tiles (nothing waits for them)
-                long t = 0;
-                for (int r = a.inv_ksplit; r < nb; ++r)
-                    for (int jj = 0; jj <= r; ++jj, ++t)
-                        if (t % W == widx && nt < DF_MAXT) {
-                            SW(0, nt) = r; SW(1, nt) = jj; SW(2, nt) = 0; SW(3, nt) = 0; SW(6, nt) = 3;
-                            ++nt;
-                        }
+                // fused inverse, behind this worker's own tiles (type 10 + the item type of potri_item_ready / _task): as ONE pool every
+                // item of the inverse in its global order (T / P / X by row, then K); with a team of its own for the inverse only the
+                // K^-1 tiles of the late rows (nothing waits for them)
+                int turn = 0;
+                auto deal = [&](int type, int i, int jj) {
+                    if (turn == widx && nt < DF_MAXT) {
+                        SW(0, nt) = i; SW(1, nt) = jj; SW(2, nt) = (type == 1 && jj == i - 1 && a.inv_plast) ? 1 : 0; SW(3, nt) = 0;
+                        SW(6, nt) = 10 + type;
+                        ++nt;
+                    }
+                    if (++turn == W) turn = 0;
+                };
+                if (a.inv_pool)
+                    for (int r = 0; r < nb; ++r) {
+                        deal(0, r, r);
+                        if (r > 0 && a.inv_plast) deal(4, r, r - 1);
+                        for (int jj = 0; jj < r; ++jj) deal(1, r, jj);
+                    }
+                for (int r = a.inv_pool ? 0 : a.inv_ksplit; r < nb; ++r)
+                    for (int jj = 0; jj <= r; ++jj) deal(2, r, jj);
             }
         }
         SW(5, 0) = ok ? nt : -1;
@@ -1430,11 +1447,8 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             const int t = first + slot;
             bool valid = t < nt && !SW(3, t);
             bool ok = true;
-            if (valid && SW(6, t) == 3) {                      // a K^-1 tile of the fused inverse (potri_k_task)
-                const int i = SW(0, t), jj = SW(1, t), d = SW(2, t);
-                const int* xdone = a.sync + DF_FACT + 2 * nb + nb * nb;
-                const int k0 = i + d, k1 = min(k0 + a.inv_ck, nb), kk = k0 + (l & 7);
-                if (kk < k1) ok = df_flag(xdone + kk + (long)(l < 8 ? i : jj) * nb) != 0;
+            if (valid && SW(6, t) >= 10) {                     // an item of the fused inverse
+                ok = potri_item_ready(a, SW(6, t) - 10, SW(0, t), SW(1, t), SW(2, t), l);
             } else if (valid) {
                 const int i = SW(0, t), k = SW(1, t), d = SW(2, t);
                 const int target = i == k ? k - 1 : k;         // steps the owner applies (the chain applies step k-1 to (k, k))
@@ -1478,11 +1492,11 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
         const int i = SW(0, t), k = SW(1, t), d = SW(2, t);
         const int target = i == k ? k - 1 : k;
         double* Cik = a.A + (long)i * NB + (long)k * NB * ld;
-        if (SW(6, t) == 3) {
-            const int k1 = potri_k_task(a, i, k, d, a.inv_ck, lds);
+        if (SW(6, t) >= 10) {
+            const PotriStep step = potri_item_task(a, SW(6, t) - 10, i, k, d, lds, smem);
             if (tid == 0) {
-                SW(2, t) = k1 - i;
-                if (k1 == nb) SW(3, t) = 1;
+                SW(2, t) = step.d;
+                if (step.done) SW(3, t) = 1;
             }
         } else if (d < target) {
             const int j0 = d;
@@ -1708,7 +1722,7 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
     for (int kk = 0; kk < nb; ++kk) n_second += std::min(split_band, nb - 1 - kk);
     const int tiles = tiles_whole + n_second;                                 // items dealt to the workers
     int Gp = std::max(nchain + 1, std::min(n_cu / nprob, nchain + tiles));   // workgroups per problem
-    int G2 = 0;
+    int G2 = 0, inv_pool = 0;
     if (inv) {
         if (nprob != 1 || nb < 3 || nb > 32 || !inv->U || !inv->Kinv) return false;
         // the factorisation's team: the chain bounds a factorisation of this size, ~nb^2 / 14.5 workers keep up with it; the rest of
@@ -1716,14 +1730,25 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
         // 80: 2.22, 112: 2.26, 136: 2.56, 48: 3.05 (separate launches: 2.62); N = 3072: 1.46-1.50 for 80-112 (1.92);
         // N = 2048: 0.84-0.86 for 80-112, 0.89 for 135 (1.18); same bits for every split
         const int w1_dflt = std::min(tiles, std::max(3 * n_cu / 8, 3 * nb));
-        const int W1 = std::max(1, std::min(tiles, envi("SLS_POTRI_W1", w1_dflt)));
+        int W1 = std::max(1, std::min(tiles, envi("SLS_POTRI_W1", w1_dflt)));
+        inv_pool = envi("SLS_POTRI_POOL", SLS_POTRI_POOL_DEFAULT(nb)) != 0 ? 1 : 0;
+        if (inv_pool) {
+            // ONE pool: every workgroup but the chain's is a worker of the factorisation AND owns items of the inverse
+            W1 = std::max(1, std::min(tiles, n_cu * ps.resident_per_cu - nchain));
+            const int items_all = 2 * nb - 1 + nb * nb;
+            if ((tiles + items_all + W1 - 1) / W1 + 2 > DF_MAXT) return false;
+            Gp = nchain + W1;
+            G2 = 0;
+        }
         Gp = nchain + W1;
-        G2 = n_cu * ps.resident_per_cu - Gp;
+        if (!inv_pool) G2 = n_cu * ps.resident_per_cu - Gp;
         const int ksplit = std::max(1, std::min(nb, envi("SLS_POTRI_KSPLIT", nb)));
         const int k_late = nb * (nb + 1) / 2 - ksplit * (ksplit + 1) / 2;          // K^-1 tiles the factorisation's workers take
         const int items = 2 * nb - 1 + nb * (nb - 1) / 2 + ksplit * (ksplit + 1) / 2;   // T, P, X and the early K^-1 tiles
-        if (G2 < 8 || (items + G2 - 1) / G2 > DF_MAXT || (tiles + k_late + W1 - 1) / W1 + 1 > DF_MAXT) return false;
-        G2 = std::min(G2, items);
+        if (!inv_pool) {
+            if (G2 < 8 || (items + G2 - 1) / G2 > DF_MAXT || (tiles + k_late + W1 - 1) / W1 + 1 > DF_MAXT) return false;
+            G2 = std::min(G2, items);
+        }
     }
     const int W = Gp - nchain;
     if (Gp * nprob + G2 > n_cu * ps.resident_per_cu || (tiles + W - 1) / W > DF_MAXT) return false;
@@ -1744,6 +1769,7 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
     a.split_sub = split_sub;
     a.split_band = split_band;
     a.stream_rows = std::max(0, envi("SLS_POTRF_STREAM_ROWS", 1 << 20));   // every panel tile (only the next row: 0.725 instead of 0.685 ms at N = 2048)
+    a.inv_pool = inv_pool;
     a.inv_ksplit = std::max(1, std::min(nb, envi("SLS_POTRI_KSPLIT", nb)));
     // measured (ms, factor + inverse; two products per row -> one): N = 384: 0.209 -> 0.234, 1024: 0.405 -> 0.411, 2048: 0.759 -> 0.753,
     // 3072: 1.466 -> 1.32, 4096: 2.15 -> 2.15 (there the two teams are short of CUs, not of time on the wavefront)

@@ -36,7 +36,8 @@ def best_of(f, reps, sync):
 
 def test_c2_fit_and_predict_budget(ctx, oracle):
     """C2: N = 2048, D = 16, ARD-SE: Gram + Cholesky + K^-1 + alpha, wall time including the upload of X / y; 4096-point predict
-    including the PCIe transfers.  Measured: 1.43 ms / 0.52 ms."""
+    including the PCIe transfers.  Measured: 1.0 ms / 0.52 ms (first session of round 4, three launches for factor and inverse
+    on the unstreamed chain: 1.43 ms)."""
     D, N, M = 16, 2048, 4096
     X, y, theta, b = synth_problem(oracle, D, N)
     Xs = synth_candidates(oracle, D, M)
@@ -46,8 +47,27 @@ def test_c2_fit_and_predict_budget(ctx, oracle):
     pred = best_of(lambda: gp.predict(Xs), 5, ctx.synchronize)
     gp.close()
     record("budget", config="C2", fit_ms=fit, predict_ms=pred)
-    assert fit <= 2.5, fit
+    assert fit <= 1.7, fit
     assert pred <= 1.2, pred
+
+
+def test_factor_and_inverse_device_time_budget(oracle):
+    """Factor + L^-1 + K^-1 of a fit, device time from the library's own HIP-event scopes (sls_prof_get): ONE launch up to
+    N = 4096 (kernels_chol.hip: streamed chain + fused inverse).  Measured: 0.74-0.78 ms at N = 2048 (first session of round 4:
+    potrf 0.79 + trtri 0.27 + lauum 0.14 = 1.2 ms), 2.16-2.2 ms at N = 4096 (2.62)."""
+    m = sls()
+    for N, budget in ((2048, 1.2), (4096, 3.2)):
+        X, y, theta, b = synth_problem(oracle, 16, N)
+        c = m.Context(0)
+        m.GP(c, X, y, theta, b, 0).close()            # code objects, buffers
+        c.prof_enable(True); c.prof_reset()
+        for _ in range(3):
+            m.GP(c, X, y, theta, b, 0).close()
+        ms, launches = c.prof_get("potri")
+        assert launches == 3 and c.prof_get("potrf")[1] == 0 and c.prof_get("potrf_fallbacks")[1] == 0
+        record("budget", config="factor+inverse", N=N, device_ms=ms / 3)
+        assert ms / 3 <= budget, (N, ms / 3)
+        c.close()
 
 
 def test_c3_submit_feedback_budget():
@@ -64,9 +84,9 @@ def test_c3_submit_feedback_budget():
 
 
 def test_c5_evaluation_and_batch_budget(ctx, oracle):
-    """C5: Matern-5/2 MAP objective + gradient at N = 4096, D = 128 (measured 3.1-3.4 ms), and the value-only evaluations of a
-    DIRECT iteration: eight parameter sets through sls_gp_nll_batch (concurrent bordered factorisations, measured 6.5 ms) against
-    one full evaluation after the other (SLS_NLL_BATCH=0, 23.6 ms): at least 1.8x."""
+    """C5: Matern-5/2 MAP objective + gradient at N = 4096, D = 128 (measured 2.9 ms; first session of round 4: 3.4), and the
+    value-only evaluations of a DIRECT iteration: eight parameter sets through sls_gp_nll_batch (concurrent bordered
+    factorisations, measured 6.4-6.6 ms) against one full evaluation after the other (SLS_NLL_BATCH=0, 19.8 ms): at least 1.8x."""
     D, N = 128, 4096
     X, y, theta, b = synth_problem(oracle, D, N)
     h = sls().Nll(ctx, X, 1)
@@ -87,7 +107,7 @@ def test_c5_evaluation_and_batch_budget(ctx, oracle):
         del os.environ["SLS_NLL_BATCH"]
     h.close()
     record("budget", config="C5", ms_per_evaluation=ms_eval, batch8_ms=ms_batch, sequential8_ms=ms_seq, speedup=ms_seq / ms_batch)
-    assert ms_eval <= 4.5, ms_eval
+    assert ms_eval <= 4.0, ms_eval
     assert ms_seq / ms_batch >= 1.8, (ms_seq, ms_batch)
 
 

@@ -129,13 +129,15 @@ def test_fused_inverse_matches_separate_launches(oracle, N, D, monkeypatch):
     X, y, theta, b = synth_problem(oracle, D, N)
     Xs = synth_candidates(oracle, D, 96)
     out = {}
-    knobs = ("SLS_POTRI_FUSED", "SLS_POTRI_W1", "SLS_POTRI_CX", "SLS_POTRI_CK", "SLS_POTRI_PLAST", "SLS_POTRI_KSPLIT")
+    knobs = ("SLS_POTRI_FUSED", "SLS_POTRI_W1", "SLS_POTRI_CX", "SLS_POTRI_CK", "SLS_POTRI_PLAST", "SLS_POTRI_KSPLIT", "SLS_POTRI_POOL")
     for name, env in (("fused", {}), ("separate", {"SLS_POTRI_FUSED": "0"}), ("fused_small_team", {"SLS_POTRI_W1": "7"}),
                       ("fused_chunks", {"SLS_POTRI_CX": "3", "SLS_POTRI_CK": "2"}),
                       # the last term of every row split off (one product per row on the column wavefront) / not
                       ("fused_plast0", {"SLS_POTRI_PLAST": "0"}), ("fused_plast1", {"SLS_POTRI_PLAST": "1"}),
                       # the K^-1 tiles of the rows >= 2 accumulated by the factorisation's workers
-                      ("fused_ksplit", {"SLS_POTRI_KSPLIT": "2"})):
+                      ("fused_ksplit", {"SLS_POTRI_KSPLIT": "2"}),
+                      # no team of its own for the inverse: the factorisation's workers own its items too
+                      ("fused_pool", {"SLS_POTRI_POOL": "1"})):
         for k in knobs:
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -164,8 +166,9 @@ def test_fused_inverse_matches_separate_launches(oracle, N, D, monkeypatch):
     # another split of the chip: same bits; another (fixed) chunking of the accumulations: rounding only
     for key in ("L", "Kinv", "alpha", "mu", "sg"):
         assert np.array_equal(out["fused_small_team"][key], f[key]), key
-    for key in ("L", "Kinv", "alpha", "mu", "sg"):                     # who accumulates a K^-1 tile does not change its bits
+    for key in ("L", "Kinv", "alpha", "mu", "sg"):                     # who runs an item of the inverse does not change its bits
         assert np.array_equal(out["fused_ksplit"][key], f[key]), key
+        assert np.array_equal(out["fused_pool"][key], f[key]), key
     for name in ("fused_chunks", "fused_plast0", "fused_plast1"):
         close(out[name]["Kinv"], f["Kinv"], rtol=1e-9, atol=1e-11 * scale)
         assert np.array_equal(out[name]["L"], f["L"])
