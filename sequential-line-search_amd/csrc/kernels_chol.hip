@@ -22,9 +22,6 @@
 #ifndef SLS_POTRF_MODE_DEFAULT
 #define SLS_POTRF_MODE_DEFAULT 3
 #endif
-#ifndef SLS_POTRI_POOL_DEFAULT
-#define SLS_POTRI_POOL_DEFAULT(nb) 0
-#endif
 #ifndef SLS_POTRF_STREAM_DEFAULT
 #define SLS_POTRF_STREAM_DEFAULT 1
 #endif
@@ -343,13 +340,10 @@ struct PersistArgs {
     int inv_cx, inv_ck;   // 128-blocks of the contraction per X / K^-1 accumulation task (fixed chunking)
     int inv_plast;        // 1: the term of the row just above is split off (P_i, one product per row on the column wavefront); 0: every
                           // term is accumulated, then U_ji = M T_ii^T (two products per row, no P task: shorter tail for few rows)
-    int inv_pool;         // 1: no team of its own -- the factorisation's workers own the inverse's items too, behind their tiles (ONE pool:
-                          // a worker runs the first ready item of its list, so a tile of the factorisation always goes first)
-    int inv_ksplit;       // K^-1 tiles of the rows >= inv_ksplit are accumulated by the factorisation's workers (potri_k_task)
     // streamed panel tiles (stream_trsm): nchain = 2 adds the FOLLOWER workgroup, which solves the chain's panel tile (j+1, j)
-    // against the column blocks of L_jj while the chain is still factoring them; stream_rows: worker panel tiles (i, k) with
-    // i <= k + 1 + stream_rows are solved the same way.  nchain = 1: the round-3 chain (solve on the chain itself).
-    int nchain, stream_rows;
+    // against the column blocks of L_jj while the chain is still factoring them; the workers' panel tiles are solved the same
+    // way.  nchain = 1: the round-3 chain (solve on the chain itself).
+    int nchain;
     // split_sub: the sub-diagonal tiles (k+1, k) -- whose last update sits between the follower's solve of step k-1 and its solve
     // of step k -- have one owner per 64-column half (gemm_tile_mc<2>: same slabs, same k order, same bits).  split_band: so do
     // the tiles (i, k) with 1 <= i - k <= split_band: every row runs the cycle "panel tile solved behind diagonal block k-1 ->
@@ -956,10 +950,7 @@ __device__ __forceinline__ void df_publish_add(int* p) {
 // of every K^-1 tile (~75 us).
 // ---------------------------------------------------------------------------------------------------------
 // One accumulation task of K^-1_ij = sum_{k >= i} U_ik U_jk^T: the blocks [i + d, min(i + d + ck, nb)) of the contraction; behind the
-// last one the mirror tile (j, i) is written too.  Returns the end of the range.  Shared by the inverse's team and by the
-// factorisation's workers, which take the tiles of the LATE rows (i >= inv_ksplit) when they have nothing else to do: those tiles
-// only become available during the last third of the factorisation, when the trailing matrix -- the workers' own work -- has
-// shrunk to a few tiles and more than half of the inverse's flops are still to come.
+// last one the mirror tile (j, i) is written too.  Returns the end of the range.
 __device__ __forceinline__ int potri_k_task(const PersistArgs& a, int i, int j, int d, int ck, double* lds) {
     const int nb = a.nb;
     const long ld = a.ld;
@@ -1022,8 +1013,7 @@ struct PotriStep {
     int d;          // the item's progress after the task
     bool done;      // the item is finished
 };
-// ... and the task itself (whole workgroup).  Shared by the inverse's own team (potri_team) and by the factorisation's workers when
-// the launch runs as ONE pool (N > 2048: see launch_potrf_dataflow_impl).
+// ... and the task itself (whole workgroup).
 __device__ __forceinline__ PotriStep potri_item_task(const PersistArgs& a, int type, int i, int j, int d, double* lds, char* smem) {
     const int nb = a.nb;
     const long ld = a.ld;
@@ -1157,7 +1147,7 @@ __device__ __forceinline__ void potri_team(const PersistArgs& a, int b2, int G2,
             if (r > 0 && a.inv_plast) deal(4, r, r - 1);
             for (int j = 0; j < r; ++j) deal(1, r, j);
         }
-        for (int r = 0; r < min(nb, a.inv_ksplit); ++r)             // the later rows: the factorisation's workers
+        for (int r = 0; r < nb; ++r)
             for (int j = 0; j <= r; ++j) deal(2, r, j);
         SW(5, 0) = nt;
     }
@@ -1404,28 +1394,6 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
                 SW(6, nt) = second ? 2 : (e >= 1 && e <= band ? 1 : 0);        // 0 whole tile, 1 / 2: columns 0-63 / 64-127
                 ++nt;
             }
-            if (a.g1 > 0) {
-                // fused inverse, behind this worker's own tiles (type 10 + the item type of potri_item_ready / _task): as ONE pool every
-                // item of the inverse in its global order (T / P / X by row, then K); with a team of its own for the inverse only the
-                // K^-1 tiles of the late rows (nothing waits for them)
-                int turn = 0;
-                auto deal = [&](int type, int i, int jj) {
-                    if (turn == widx && nt < DF_MAXT) {
-                        SW(0, nt) = i; SW(1, nt) = jj; SW(2, nt) = (type == 1 && jj == i - 1 && a.inv_plast) ? 1 : 0; SW(3, nt) = 0;
-                        SW(6, nt) = 10 + type;
-                        ++nt;
-                    }
-                    if (++turn == W) turn = 0;
-                };
-                if (a.inv_pool)
-                    for (int r = 0; r < nb; ++r) {
-                        deal(0, r, r);
-                        if (r > 0 && a.inv_plast) deal(4, r, r - 1);
-                        for (int jj = 0; jj < r; ++jj) deal(1, r, jj);
-                    }
-                for (int r = a.inv_pool ? 0 : a.inv_ksplit; r < nb; ++r)
-                    for (int jj = 0; jj <= r; ++jj) deal(2, r, jj);
-            }
         }
         SW(5, 0) = ok ? nt : -1;
     }
@@ -1447,9 +1415,7 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             const int t = first + slot;
             bool valid = t < nt && !SW(3, t);
             bool ok = true;
-            if (valid && SW(6, t) >= 10) {                     // an item of the fused inverse
-                ok = potri_item_ready(a, SW(6, t) - 10, SW(0, t), SW(1, t), SW(2, t), l);
-            } else if (valid) {
+            if (valid) {
                 const int i = SW(0, t), k = SW(1, t), d = SW(2, t);
                 const int target = i == k ? k - 1 : k;         // steps the owner applies (the chain applies step k-1 to (k, k))
                 if (d < target) {
@@ -1458,9 +1424,9 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
                     const int j = j0 + (l & 7);
                     if (j < j1 && !(l >= 8 && i == k)) ok = df_flag(panel_done + (l < 8 ? i : k) + (long)j * nb) != 0;
                 } else if (i > k + 1 && SW(6, t) != 2) {
-                    // the whole diagonal block (24 = 3 waves x 8 column blocks in the streamed form, 1 otherwise), or its first
-                    // column block for the tiles that are solved block by block behind it; a tile with two owners: the other half
-                    const int need = nchain == 2 ? (i <= k + 1 + a.stream_rows ? 3 : 24) : 1;
+                    // the diagonal block (round-3 chain), or its first column block (3 = one arrival per publishing wave) in the streamed
+                    // form, where the tile is solved block by block behind it; a tile with two owners: the other half
+                    const int need = nchain == 2 ? 3 : 1;
                     if (l == 0) ok = df_flag(factored + k) >= need;
                     else if (l == 1 && SW(6, t) == 1) ok = df_flag(upd_done + i + (long)k * nb) != 0;
                 }
@@ -1492,13 +1458,7 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
         const int i = SW(0, t), k = SW(1, t), d = SW(2, t);
         const int target = i == k ? k - 1 : k;
         double* Cik = a.A + (long)i * NB + (long)k * NB * ld;
-        if (SW(6, t) >= 10) {
-            const PotriStep step = potri_item_task(a, SW(6, t) - 10, i, k, d, lds, smem);
-            if (tid == 0) {
-                SW(2, t) = step.d;
-                if (step.done) SW(3, t) = 1;
-            }
-        } else if (d < target) {
+        if (d < target) {
             const int j0 = d;
             const int j1 = df_chunk_end(k, j0, target, nbo, a.near);
             const int half = SW(6, t);
@@ -1549,7 +1509,7 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             }
         } else if (i > k + 1) {
             ++st_n_panel;
-            if (nchain == 2 && i <= k + 1 + a.stream_rows) {
+            if (nchain == 2) {
                 const bool stamp = a.trace && tid == 0 && i == k + 2;      // probes: the panel tile right below the follower's
                 if (stamp) a.trace[16 * k + 5] = st_task0;
                 ChainAcc ca;
@@ -1722,7 +1682,7 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
     for (int kk = 0; kk < nb; ++kk) n_second += std::min(split_band, nb - 1 - kk);
     const int tiles = tiles_whole + n_second;                                 // items dealt to the workers
     int Gp = std::max(nchain + 1, std::min(n_cu / nprob, nchain + tiles));   // workgroups per problem
-    int G2 = 0, inv_pool = 0;
+    int G2 = 0;
     if (inv) {
         if (nprob != 1 || nb < 3 || nb > 32 || !inv->U || !inv->Kinv) return false;
         // the factorisation's team: the chain bounds a factorisation of this size, ~nb^2 / 14.5 workers keep up with it; the rest of
@@ -1730,25 +1690,12 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
         // 80: 2.22, 112: 2.26, 136: 2.56, 48: 3.05 (separate launches: 2.62); N = 3072: 1.46-1.50 for 80-112 (1.92);
         // N = 2048: 0.84-0.86 for 80-112, 0.89 for 135 (1.18); same bits for every split
         const int w1_dflt = std::min(tiles, std::max(3 * n_cu / 8, 3 * nb));
-        int W1 = std::max(1, std::min(tiles, envi("SLS_POTRI_W1", w1_dflt)));
-        inv_pool = envi("SLS_POTRI_POOL", SLS_POTRI_POOL_DEFAULT(nb)) != 0 ? 1 : 0;
-        if (inv_pool) {
-            // ONE pool: every workgroup but the chain's is a worker of the factorisation AND owns items of the inverse
-            W1 = std::max(1, std::min(tiles, n_cu * ps.resident_per_cu - nchain));
-            const int items_all = 2 * nb - 1 + nb * nb;
-            if ((tiles + items_all + W1 - 1) / W1 + 2 > DF_MAXT) return false;
-            Gp = nchain + W1;
-            G2 = 0;
-        }
+        const int W1 = std::max(1, std::min(tiles, envi("SLS_POTRI_W1", w1_dflt)));
         Gp = nchain + W1;
-        if (!inv_pool) G2 = n_cu * ps.resident_per_cu - Gp;
-        const int ksplit = std::max(1, std::min(nb, envi("SLS_POTRI_KSPLIT", nb)));
-        const int k_late = nb * (nb + 1) / 2 - ksplit * (ksplit + 1) / 2;          // K^-1 tiles the factorisation's workers take
-        const int items = 2 * nb - 1 + nb * (nb - 1) / 2 + ksplit * (ksplit + 1) / 2;   // T, P, X and the early K^-1 tiles
-        if (!inv_pool) {
-            if (G2 < 8 || (items + G2 - 1) / G2 > DF_MAXT || (tiles + k_late + W1 - 1) / W1 + 1 > DF_MAXT) return false;
-            G2 = std::min(G2, items);
-        }
+        G2 = n_cu * ps.resident_per_cu - Gp;
+        const int items = 2 * nb - 1 + nb * nb;                                         // T, P, X and K^-1 items
+        if (G2 < 8 || (items + G2 - 1) / G2 > DF_MAXT) return false;
+        G2 = std::min(G2, items);
     }
     const int W = Gp - nchain;
     if (Gp * nprob + G2 > n_cu * ps.resident_per_cu || (tiles + W - 1) / W > DF_MAXT) return false;
@@ -1768,9 +1715,6 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
     a.nchain = nchain;
     a.split_sub = split_sub;
     a.split_band = split_band;
-    a.stream_rows = std::max(0, envi("SLS_POTRF_STREAM_ROWS", 1 << 20));   // every panel tile (only the next row: 0.725 instead of 0.685 ms at N = 2048)
-    a.inv_pool = inv_pool;
-    a.inv_ksplit = std::max(1, std::min(nb, envi("SLS_POTRI_KSPLIT", nb)));
     // measured (ms, factor + inverse; two products per row -> one): N = 384: 0.209 -> 0.234, 1024: 0.405 -> 0.411, 2048: 0.759 -> 0.753,
     // 3072: 1.466 -> 1.32, 4096: 2.15 -> 2.15 (there the two teams are short of CUs, not of time on the wavefront)
     a.inv_plast = envi("SLS_POTRI_PLAST", nb >= 12 ? 1 : 0) != 0 ? 1 : 0;

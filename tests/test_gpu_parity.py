@@ -83,11 +83,10 @@ def test_potrf_schedules_agree(N, monkeypatch):
                       ("multi2", {"SLS_POTRF_MODE": "0", "SLS_POTRF_NBO": "2", "SLS_POTRF_LOOKAHEAD": "0"}),
                       ("multi2look", {"SLS_POTRF_MODE": "0", "SLS_POTRF_NBO": "2", "SLS_POTRF_LOOKAHEAD": "4"}),
                       ("dataflow1", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "1"}),
-                      # the round-3 chain (solve of the panel tile (j+1, j) on the chain itself), the follower alone, the follower
-                      # with only the next row's panel tiles streamed, and without the half-tile owners of the sub-diagonal tiles
+                      # the round-3 chain (solve of the panel tile (j+1, j) on the chain itself); the streamed form without the
+                      # half-tile owners, with them for the sub-diagonal tiles only, and for a band of three
                       ("dataflow1_nostream", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "1", "SLS_POTRF_STREAM": "0"}),
-                      ("dataflow1_rows0", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "1", "SLS_POTRF_STREAM_ROWS": "0"}),
-                      ("dataflow1_rows1_nosplit", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "1", "SLS_POTRF_STREAM_ROWS": "1", "SLS_POTRF_SPLIT": "0"}),
+                      ("dataflow1_nosplit", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "1", "SLS_POTRF_SPLIT": "0"}),
                       ("dataflow1_band1", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "1", "SLS_POTRF_SPLIT": "1"}),
                       ("dataflow1_band3", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "1", "SLS_POTRF_SPLIT": "3"}),
                       ("dataflow2", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "2"}),
@@ -112,7 +111,7 @@ def test_potrf_schedules_agree(N, monkeypatch):
     close(res["dataflow4near"], res["multi"], rtol=1e-12, atol=1e-13)
     assert np.array_equal(res["multi2"], res["multi2look"])        # the side stream changes the schedule, not the arithmetic
     # ... and so do the follower workgroup, the streamed solves and the half-tile owners (same slabs, same MFMA order)
-    for name in ("dataflow1_nostream", "dataflow1_rows0", "dataflow1_rows1_nosplit", "dataflow1_band1", "dataflow1_band3"):
+    for name in ("dataflow1_nostream", "dataflow1_nosplit", "dataflow1_band1", "dataflow1_band3"):
         assert np.array_equal(res[name], res["dataflow1"]), name
     close(res["multi2"], res["multi"], rtol=1e-12, atol=1e-13)
 
@@ -129,15 +128,11 @@ def test_fused_inverse_matches_separate_launches(oracle, N, D, monkeypatch):
     X, y, theta, b = synth_problem(oracle, D, N)
     Xs = synth_candidates(oracle, D, 96)
     out = {}
-    knobs = ("SLS_POTRI_FUSED", "SLS_POTRI_W1", "SLS_POTRI_CX", "SLS_POTRI_CK", "SLS_POTRI_PLAST", "SLS_POTRI_KSPLIT", "SLS_POTRI_POOL")
+    knobs = ("SLS_POTRI_FUSED", "SLS_POTRI_W1", "SLS_POTRI_CX", "SLS_POTRI_CK", "SLS_POTRI_PLAST")
     for name, env in (("fused", {}), ("separate", {"SLS_POTRI_FUSED": "0"}), ("fused_small_team", {"SLS_POTRI_W1": "7"}),
                       ("fused_chunks", {"SLS_POTRI_CX": "3", "SLS_POTRI_CK": "2"}),
                       # the last term of every row split off (one product per row on the column wavefront) / not
-                      ("fused_plast0", {"SLS_POTRI_PLAST": "0"}), ("fused_plast1", {"SLS_POTRI_PLAST": "1"}),
-                      # the K^-1 tiles of the rows >= 2 accumulated by the factorisation's workers
-                      ("fused_ksplit", {"SLS_POTRI_KSPLIT": "2"}),
-                      # no team of its own for the inverse: the factorisation's workers own its items too
-                      ("fused_pool", {"SLS_POTRI_POOL": "1"})):
+                      ("fused_plast0", {"SLS_POTRI_PLAST": "0"}), ("fused_plast1", {"SLS_POTRI_PLAST": "1"})):
         for k in knobs:
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -166,9 +161,6 @@ def test_fused_inverse_matches_separate_launches(oracle, N, D, monkeypatch):
     # another split of the chip: same bits; another (fixed) chunking of the accumulations: rounding only
     for key in ("L", "Kinv", "alpha", "mu", "sg"):
         assert np.array_equal(out["fused_small_team"][key], f[key]), key
-    for key in ("L", "Kinv", "alpha", "mu", "sg"):                     # who runs an item of the inverse does not change its bits
-        assert np.array_equal(out["fused_ksplit"][key], f[key]), key
-        assert np.array_equal(out["fused_pool"][key], f[key]), key
     for name in ("fused_chunks", "fused_plast0", "fused_plast1"):
         close(out[name]["Kinv"], f["Kinv"], rtol=1e-9, atol=1e-11 * scale)
         assert np.array_equal(out[name]["L"], f["L"])
