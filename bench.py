@@ -320,7 +320,7 @@ def main():
         # roofline.traffic is null: HBM traffic needs a separate rocprofv3 --pmc pass (MI355X_MICROARCH.md) and is not measured in
         # this run.  The last PMC pass of the same launch shape is quoted beside it, labelled as what it is.
         traffic_ref = None
-        for name in ("r04_pmc_acq_gemm.json", "r03_pmc_acq_gemm.json", "r02_pmc_acq_gemm.json"):
+        for name in ("r04b_pmc_acq_gemm.json", "r04_pmc_acq_gemm.json", "r03_pmc_acq_gemm.json", "r02_pmc_acq_gemm.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc) and (N, D) == (8192, 64):
                 try:

@@ -340,11 +340,11 @@ struct PersistArgs {
     int inv_cx, inv_ck;   // 128-blocks of the contraction per X / K^-1 accumulation task (fixed chunking)
     int inv_plast;        // 1: the term of the row just above is split off (P_i, one product per row on the column wavefront); 0: every
                           // term is accumulated, then U_ji = M T_ii^T (two products per row, no P task: shorter tail for few rows)
-    // streamed panel tiles (stream_trsm): nchain = 2 adds the FOLLOWER workgroup, which solves the chain's panel tile (j+1, j)
-    // against the column blocks of L_jj while the chain is still factoring them; the workers' panel tiles are solved the same
-    // way.  nchain = 1: the round-3 chain (solve on the chain itself).
+    // streamed panel tiles (stream_trsm): nchain = 2: two chain workgroups take turns -- while one factors diagonal block j, the other
+    // solves the panel tile (j+1, j) against the column blocks it publishes, then multiplies and factors block j+1; the workers'
+    // panel tiles are solved the same way.  nchain = 1: the round-3 chain (one workgroup, one thing after the other).
     int nchain;
-    // split_sub: the sub-diagonal tiles (k+1, k) -- whose last update sits between the follower's solve of step k-1 and its solve
+    // split_sub: the sub-diagonal tiles (k+1, k) -- whose last update sits between the chain's solve of step k-1 and its solve
     // of step k -- have one owner per 64-column half (gemm_tile_mc<2>: same slabs, same k order, same bits).  split_band: so do
     // the tiles (i, k) with 1 <= i - k <= split_band: every row runs the cycle "panel tile solved behind diagonal block k-1 ->
     // update of (i, k) with it -> panel tile (i, k) solved behind diagonal block k", which is as long as the chain's own step when
@@ -815,8 +815,12 @@ __device__ __forceinline__ void chain_image_store_wt(double* __restrict__ C, lon
 // the chain's products are bounded by their LDS reads (11.0 us for 7.7 us of MFMA work; 12.4 us with 18 reads per nine MFMAs).
 // Every block still sums its k in ascending order: same bits.  Result -> image in place (one barrier inside: every wave has
 // read the operand before anybody overwrites it).
-template <int W>
-__device__ __forceinline__ void chain_syrk_inplace_wave(double* img) {
+struct NoSlabHook {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+// before_slab(s): called by every thread before slab s (columns 16 s .. 16 s + 15 of the operand) is read.
+template <int W, class F>
+__device__ __forceinline__ void chain_syrk_inplace_wave(double* img, F&& before_slab) {
     constexpr int NB9[4][9][2] = {
         {{5, 0}, {5, 1}, {5, 2}, {6, 0}, {6, 1}, {6, 2}, {7, 0}, {7, 1}, {7, 2}},
         {{5, 3}, {5, 4}, {5, 5}, {6, 3}, {6, 4}, {6, 5}, {7, 3}, {7, 4}, {7, 5}},
@@ -829,6 +833,7 @@ __device__ __forceinline__ void chain_syrk_inplace_wave(double* img) {
     for (int p = 0; p < 9; ++p) acc[p] = d4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
+        before_slab(s);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const double* la = img + s * GEMM_LDS_TILE + 4 * kk * GEMM_LDS_MC_LD + l0;
@@ -851,12 +856,13 @@ __device__ __forceinline__ void chain_syrk_inplace_wave(double* img) {
         for (int r = 0; r < 4; ++r)
             img[(16 * NB9[W][p][1] + (lane >> 4) + 4 * r) * DL + 16 * NB9[W][p][0] + (lane & 15)] = acc[p][r];
 }
-__device__ __forceinline__ void chain_syrk_inplace(double* img) {
+template <class F = NoSlabHook>
+__device__ __forceinline__ void chain_syrk_inplace(double* img, F&& before_slab = NoSlabHook{}) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave == 0) chain_syrk_inplace_wave<0>(img);
-    else if (wave == 1) chain_syrk_inplace_wave<1>(img);
-    else if (wave == 2) chain_syrk_inplace_wave<2>(img);
-    else chain_syrk_inplace_wave<3>(img);
+    if (wave == 0) chain_syrk_inplace_wave<0>(img, before_slab);
+    else if (wave == 1) chain_syrk_inplace_wave<1>(img, before_slab);
+    else if (wave == 2) chain_syrk_inplace_wave<2>(img, before_slab);
+    else chain_syrk_inplace_wave<3>(img, before_slab);
 }
 // image <- (global tile) - image on the lower 16 x 16 blocks, zero above: diag_block's input, built in place
 __device__ __forceinline__ void chain_image_rsub(const double* __restrict__ C, long ld, double* img) {
@@ -1227,49 +1233,72 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
     int* chain_ready = a.sync + DF_FACT + nb;
     int* panel_done = a.sync + DF_FACT + 2 * nb;        // [i + j nb]
     // chain_ready[j]: tile (j+1, j) carries every update its owner(s) apply (1, or 2 with one owner per half); diag_ready[j]: tile
-    // (j+1, j+1) does.  Separate words: in the streamed form the follower only needs the first -- the diagonal tile's last update
-    // comes ~6 us later and is only needed by the chain, behind the follower's solve
+    // (j+1, j+1) does.  Separate words: in the streamed form the solve only needs the first -- the diagonal tile's last update
+    // comes ~6 us later and is only needed behind the solve
     int* diag_ready = a.sync + DF_FACT + 2 * nb + 2 * nb * nb;
     int* upd_done = diag_ready + nb;                    // [i + k nb]: the second half of tile (i, k) carries all its updates
     const int nchain = a.nchain;
-    if (b == 0 && nchain == 2) {
-        // ---- the chain, streamed form: diagonal blocks + the product L L^T; the panel tile comes from the follower ----
-        diag_block_factor<true>(a.A, ld, a.Linv, ld, a.info, 0, smem, factored + 0);
-        for (int j = 0; j <= nb - 2; ++j) {
+    if (b < 2 && nchain == 2) {
+        // ---- the chain, streamed form: TWO workgroups taking turns ----
+        // Workgroup c factors the diagonal blocks j = c, c + 2, ... and publishes their column blocks while it does (StreamPublish).
+        // Meanwhile the OTHER one solves the panel tile (j+1, j) block by block behind it (stream_trsm): when diagonal block j ends,
+        // seven eighths of that solve are done; it then stores the tile for the workers, forms A_{j+1,j+1} - L L^T in place in its
+        // LDS image (the tile's owner-updated values wait in registers) and factors diagonal block j+1 from there -- the next
+        // diagonal block never leaves the CU that built it.  (First form of this session: a chain that only factored and
+        // multiplied, and a follower that only solved: the panel tile went follower -> global memory -> chain, 3.9 us for the
+        // store, its drain and the flag + 1.4 us for the load, per step.)
+        if (b == 0) diag_block_factor<true>(a.A, ld, a.Linv, ld, a.info, 0, smem, factored + 0);
+        for (int j = 1 - b; j <= nb - 2; j += 2) {
             double* Ajj = a.A + (long)j * NB * (ld + 1);
             double* Tjj = a.Linv + (long)j * NB * (ld + 1);
             double* Asub = Ajj + NB;                           // tile (j+1, j)
             double* Anext = Ajj + (long)NB * (ld + 1);         // tile (j+1, j+1)
-            PK_STAMP(0);
-            if (!pk_wait_count(diag_ready + j, 1, a)) return;                        // (j+1, j+1) carries its owner's updates
-            // A_{j+1,j+1} (lower blocks) into registers while the follower is still solving: the subtraction behind the product
-            // then needs no global load
-            d2_t cv[2][16];
+            PK_STAMP(10);
+            if (!pk_wait_count(chain_ready + j, 1 + a.split_sub, a)) return;   // tile (j+1, j) carries its owners' updates (steps < j)
+            PK_STAMP(11);
+            d2_t cv[2][16];                                    // A_{j+1,j+1} (lower blocks), for the subtraction behind the product
             {
+                ChainAcc ca;
+                if (!stream_trsm(ca, Asub, ld, Ajj, ld, Tjj, ld, factored + j, a.info + 1, a.timeout, lds)) return;
+                PK_STAMP(12);
+                PK_STAMP(0);                                   // diagonal block j has ended (on the other workgroup) a moment ago
+                chain_acc_to_image<true>(ca, lds);
+            }
+            int* ctl = reinterpret_cast<int*>(lds + 128 * DL);               // a word behind the image (the T16 buffers of the solve: dead)
+            if (threadIdx.x == 0) *ctl = df_flag(diag_ready + j) >= 1 ? 1 : 0;   // one decision for the workgroup, see below
+            lds_barrier();
+            chain_image_store_wt(Asub, ld, lds);
+            {
+                // The diagonal tile's owner finished its updates long since (its last one comes ~6 us after the sub-diagonal
+                // tile's, i.e. ~10 us before this point): a relaxed look at its flag (the full wait only if it is not up yet), then
+                // agent-scope loads -- no invalidate -- that travel together with the panel tile's stores: one drain for both.
+                const int up = *ctl;
+                if (!up && !pk_wait_count(diag_ready + j, 1, a)) return;
                 const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
                 const int ti = lane >> 3;
+                auto rsrcN = __builtin_amdgcn_make_buffer_rsrc(Anext, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
                         const int c = w + 4 * (16 * h + q);
                         cv[h][q] = d2_t{0.0, 0.0};
-                        if (ti >= (c >> 4)) cv[h][q] = *reinterpret_cast<const d2_t*>(Anext + 2 * lane + (long)c * ld);
+                        if (ti >= (c >> 4))
+                            cv[h][q] = __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(rsrcN, (int)((2 * lane + (long)c * ld) * 8), 0, 16));
                     }
             }
-            if (!pk_wait_count(panel_done + (j + 1) + (long)j * nb, 1, a)) return;   // L_{j+1,j} stored by the follower
+            // The product starts at once: the stores have left the image (it is only overwritten behind the product), and their
+            // drain -- 3.3 us for 128 KB of write-through stores + the 64 KB of loads above -- would sit on the chain's path.  The
+            // flag for the workers goes up behind the product's second slab, when the drain is over anyway.
             PK_STAMP(1);
-            {   // L_{j+1,j} -> LDS image: 128 columns of 1 KB, LDS-direct
-                const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-#pragma unroll 8
-                for (int q = 0; q < 32; ++q) {
-                    const int c = w + 4 * q;
-                    slab_row_to_lds(Asub + 2 * lane + (long)c * ld, lds + c * DL);
-                }
-                ring_wait_barrier<0>();
-            }
             PK_STAMP(2);
-            chain_syrk_inplace(lds);
+            int* xflag = panel_done + (j + 1) + (long)j * nb;
+            chain_syrk_inplace(lds, [&](int sblk) {
+                if (sblk == 2) {
+                    df_publish_store(xflag);
+                    PK_STAMP(13);
+                }
+            });
             PK_STAMP(8);
             lds_barrier();
             PK_STAMP(9);
@@ -1290,26 +1319,6 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             PK_STAMP(3);
             diag_block_factor<false>(Anext, ld, Tjj + (long)NB * (ld + 1), ld, a.info, (j + 1) * NB, smem, factored + j + 1);
             PK_STAMP(4);
-        }
-        return;
-    }
-    if (b == 1 && nchain == 2) {
-        // ---- the follower: panel tile (j+1, j), solved block by block behind the chain's diagonal block j ----
-        for (int j = 0; j <= nb - 2; ++j) {
-            double* Ajj = a.A + (long)j * NB * (ld + 1);
-            double* Tjj = a.Linv + (long)j * NB * (ld + 1);
-            double* Asub = Ajj + NB;
-            PK_STAMP(10);
-            if (!pk_wait_count(chain_ready + j, 1 + a.split_sub, a)) return;   // tile (j+1, j) carries its owners' updates (steps < j)
-            PK_STAMP(11);
-            ChainAcc ca;
-            if (!stream_trsm(ca, Asub, ld, Ajj, ld, Tjj, ld, factored + j, a.info + 1, a.timeout, lds)) return;
-            PK_STAMP(12);
-            chain_acc_to_image<true>(ca, lds);
-            lds_barrier();
-            chain_image_store_wt(Asub, ld, lds);
-            df_publish_store(panel_done + (j + 1) + (long)j * nb);
-            PK_STAMP(13);
         }
         return;
     }
@@ -1510,7 +1519,7 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
         } else if (i > k + 1) {
             ++st_n_panel;
             if (nchain == 2) {
-                const bool stamp = a.trace && tid == 0 && i == k + 2;      // probes: the panel tile right below the follower's
+                const bool stamp = a.trace && tid == 0 && i == k + 2;      // probes: the panel tile right below the chain's
                 if (stamp) a.trace[16 * k + 5] = st_task0;
                 ChainAcc ca;
                 if (!stream_trsm(ca, Cik, ld, a.A + (long)k * NB * (ld + 1), ld, a.Linv + (long)k * NB * (ld + 1), ld, factored + k,
@@ -1664,16 +1673,17 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
     // (a second chain workgroup that followed the factorisation with a streamed solve was measured again in round 4 -- 0.384 / 0.767 /
     // 1.661 / 4.37 ms against 0.395 / 0.781 / 1.599 / 4.09 ms at N = 1024 / 2048 / 4096 / 8192, profiles/r04_potrf_chain2.log -- and
     // removed: the step is bound by the owners' panel + update path, not by the chain alone)
-    // streamed panel tiles: a follower workgroup next to the chain (SLS_POTRF_STREAM=0: the chain solves its panel tile itself).
-    // Measured (tools/probes/stream_scan.sh, ms; round-3 chain -> follower + streamed worker solves + half-tile owners):
-    // N = 512: 0.202 -> 0.173, 1024: 0.396 -> 0.334, 2048: 0.789 -> 0.685, 3072: 1.199 -> 1.034, 4096: 1.645 -> 1.422; at N = 8192
+    // streamed panel tiles: two chain workgroups taking turns (SLS_POTRF_STREAM=0: the round-3 chain, one workgroup that factors, then
+    // solves its panel tile, then multiplies).
+    // Measured (tools/probes/stream_scan.sh, ms; round-3 chain -> streamed chain + streamed worker solves + half-tile owners):
+    // N = 512: 0.202 -> 0.170, 1024: 0.396 -> 0.321, 2048: 0.789 -> 0.634, 3072: 1.199 -> 0.98, 4096: 1.645 -> 1.325; at N = 8192
     // the workers are as busy as the chain (4.16 -> 4.10-4.17): the round-3 form stays from N > 5120
     // Several problems per launch are bound by their workers, not by their chains (8 value-only evaluations at N = 4096: 6.4 ms on
     // the round-3 chain, 7.3 ms streamed): the round-3 form there too.
     const int nchain = envi("SLS_POTRF_STREAM", nb <= 40 && nprob == 1 ? SLS_POTRF_STREAM_DEFAULT : 0) != 0 && nb >= 4 ? 2 : 1;
     // SLS_POTRF_SPLIT = band: the tiles (i, k) with 1 <= i - k <= band have one owner per 64-column half (0: whole tiles only)
     // Measured (tools/probes: ms at N = 2048 / 3072 / 4096): factorisation alone: band 1: 0.655 / 0.992 / 1.363, 4: 0.645 / 0.999 / 1.353,
-    // all: 0.654 / 1.000 / 1.345 -- what matters is that every row's cycle is shorter than the chain's step, the follower then finds
+    // all: 0.654 / 1.000 / 1.345 -- what matters is that every row's cycle is shorter than the chain's step, the solving workgroup then finds
     // its tile 14-22 us before the diagonal block ends at EVERY step (before: -4 .. +6 us at every third one).  With the fused
     // inverse sharing the chip: band 1: 0.742 / 1.284 / 2.158, all: 0.733 / 1.344 / 2.518 (CUs are short from N = 3072).
     const int split_band = nchain == 2 ? std::max(0, std::min(nb - 1, envi("SLS_POTRF_SPLIT", (nb <= 16 || !inv) ? nb : 1))) : 0;

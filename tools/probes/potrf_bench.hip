@@ -249,6 +249,37 @@ int main(int argc, char** argv) {
                 }
                 if (w1) setenv("SLS_POTRI_W1", keep.c_str(), 1); else unsetenv("SLS_POTRI_W1");
             }
+            if (const char* st = getenv("POTRF_BENCH_STRESS")) {
+                // the fused launch over and over (with a changing split of the chip): every repetition must reproduce the first one's
+                // factor, inverse factor and inverse bit for bit -- a tile read before it was complete shows up here
+                const int reps = atoi(st);
+                double* red2; hipMalloc(&red2, 1024 * 8);
+                auto maxdiff = [&](const double* p1, const double* p2) {
+                    hipLaunchKernelGGL(maxdiff_lower, dim3(1024), dim3(256), 0, s, p1, p2, Np, red2);
+                    std::vector<double> h(1024); hipStreamSynchronize(s); hipMemcpy(h.data(), red2, 1024 * 8, hipMemcpyDeviceToHost);
+                    double md = 0.0; for (double v : h) md = fmax(md, v != v ? 1e300 : v);
+                    return md;
+                };
+                double *L0; hipMalloc(&L0, bytes);
+                int bad = 0, aborted = 0;
+                for (int rep = 0; rep <= reps; ++rep) {
+                    char w1[16]; snprintf(w1, sizeof w1, "%d", 40 + 13 * (rep % 9));
+                    if (rep % 3 == 1) setenv("SLS_POTRI_W1", w1, 1); else unsetenv("SLS_POTRI_W1");
+                    hipMemcpyAsync(A, A0, bytes, hipMemcpyDeviceToDevice, s);
+                    hipMemsetAsync(info, 0, 64, s);
+                    hipMemsetAsync(X1, 0, bytes, s); hipMemsetAsync(U1, 0x7f, bytes, s); hipMemsetAsync(K1, 0x7f, bytes, s);
+                    if (!launch_potri_dataflow(s, A, Np, X1, U1, K1, info, dsync)) { printf("  stress: not applicable\n"); break; }
+                    hipStreamSynchronize(s);
+                    int inf2[2]; hipMemcpy(inf2, info, 8, hipMemcpyDeviceToHost);
+                    if (inf2[0] || inf2[1]) { ++aborted; continue; }
+                    if (rep == 0) { hipMemcpy(L0, A, bytes, hipMemcpyDeviceToDevice); hipMemcpy(X2, X1, bytes, hipMemcpyDeviceToDevice); hipMemcpy(K2, K1, bytes, hipMemcpyDeviceToDevice); continue; }
+                    // K^-1 is full and symmetric: its lower triangle is the whole information
+                    if (maxdiff(A, L0) != 0.0 || maxdiff(X1, X2) != 0.0 || maxdiff(K1, K2) != 0.0) ++bad;
+                }
+                unsetenv("SLS_POTRI_W1");
+                printf("N=%5d stress: %d fused launches, %d differ from the first one, %d gave up\n", Np, reps, bad, aborted);
+                hipFree(L0); hipFree(red2);
+            }
             hipFree(X1); hipFree(U1); hipFree(K1); hipFree(X2); hipFree(U2); hipFree(K2); hipFree(dsync);
         }
         if (getenv("POTRF_BENCH_BATCH")) {
