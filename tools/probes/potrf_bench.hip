@@ -272,9 +272,16 @@ int main(int argc, char** argv) {
                     hipStreamSynchronize(s);
                     int inf2[2]; hipMemcpy(inf2, info, 8, hipMemcpyDeviceToHost);
                     if (inf2[0] || inf2[1]) { ++aborted; continue; }
-                    if (rep == 0) { hipMemcpy(L0, A, bytes, hipMemcpyDeviceToDevice); hipMemcpy(X2, X1, bytes, hipMemcpyDeviceToDevice); hipMemcpy(K2, K1, bytes, hipMemcpyDeviceToDevice); continue; }
+                    if (rep == 0) {   // on the SAME stream: a device-to-device hipMemcpy may return before it is done, and the next repetition's memsets run on s
+                        hipMemcpyAsync(L0, A, bytes, hipMemcpyDeviceToDevice, s); hipMemcpyAsync(X2, X1, bytes, hipMemcpyDeviceToDevice, s);
+                        hipMemcpyAsync(K2, K1, bytes, hipMemcpyDeviceToDevice, s); hipStreamSynchronize(s);
+                        continue;
+                    }
                     // K^-1 is full and symmetric: its lower triangle is the whole information
-                    if (maxdiff(A, L0) != 0.0 || maxdiff(X1, X2) != 0.0 || maxdiff(K1, K2) != 0.0) ++bad;
+                    const double dl = maxdiff(A, L0), dx = maxdiff(X1, X2), dk = maxdiff(K1, K2);
+                    if (dl != 0.0 || dx != 0.0 || dk != 0.0) {
+                        if (++bad <= 5) printf("  stress rep %d (W1 %s): max|dL| %.3e  max|dL^-1| %.3e  max|dK^-1| %.3e\n", rep, rep % 3 == 1 ? w1 : "default", dl, dx, dk);
+                    }
                 }
                 unsetenv("SLS_POTRI_W1");
                 printf("N=%5d stress: %d fused launches, %d differ from the first one, %d gave up\n", Np, reps, bad, aborted);
