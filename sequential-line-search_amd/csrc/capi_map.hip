@@ -46,7 +46,10 @@ struct sls_nll {
     double* mo_out_dev = nullptr;
     char* mo_stage = nullptr;          // page-locked
     size_t mo_stage_bytes = 0;
+    double* il_stage = nullptr;        // page-locked: the inverse length scales of the evaluation in flight (no synchronisation behind their upload)
+    size_t il_stage_bytes = 0;
     ~sls_nll() {   // page-locked blocks go back to the context (sls_nll_destroy holds its lock)
+        ctx->host_give(il_stage, il_stage_bytes, false);
         ctx->host_give(small_host, small_host_bytes, true);
         ctx->host_give(mo_out, mo_out_bytes, true);
         ctx->host_give(mo_stage, mo_stage_bytes, false);
@@ -104,13 +107,16 @@ static bool nll_factor_enqueue(sls_nll* h, const double* theta, double b) {
         return false;
     h->have_factor = false;
     SLS_REQUIRE(theta[0] > 0.0, "signal variance must be positive");
-    std::vector<double> il(h->Dcols, 0.0);
+    // Staged in a page-locked block of the handle: the upload is enqueued like everything else (a local buffer needed a
+    // synchronisation here, in the middle of the evaluation).  The previous evaluation on this handle ended with one, so the block is free.
+    if (!h->il_stage) h->il_stage = static_cast<double*>(c->host_take((size_t)h->Dcols * 8, false, &h->il_stage_bytes));
+    double* il = h->il_stage;
+    for (int d = 0; d < h->Dcols; ++d) il[d] = 0.0;
     for (int d = 0; d < D; ++d) {
         SLS_REQUIRE(theta[1 + d] > 0.0, "length scale %d must be positive", d);
         il[d] = 1.0 / theta[1 + d];
     }
-    SLS_HIP(hipMemcpyAsync(h->inv_ell.p, il.data(), h->Dcols * 8, hipMemcpyHostToDevice, c->stream));
-    SLS_HIP(hipStreamSynchronize(c->stream));     // `il` is a local: the copy has left it (the stream is idle here)
+    SLS_HIP(hipMemcpyAsync(h->inv_ell.p, il, h->Dcols * 8, hipMemcpyHostToDevice, c->stream));
     KernelSpec ks{h->kernel, theta[0]};
     launch_prep_points(c->stream, h->X.p, D, N, h->inv_ell.p, h->XT.p, Np, Np, h->Dcols, h->nx.p);
     launch_gram_sym(c->stream, h->XT.p, Np, h->Dp, h->nx.p, Np, N, ks, b, h->L.p, true);
