@@ -397,6 +397,7 @@ struct sls_gp {
     int D = 0, N = 0, Np = 0, Dp = 0, Dcols = 0, kernel = 0;
     double a = 0, b = 0;
     std::vector<double> theta, Xh, yh;
+    std::vector<double> il_h, ypad_h;   // upload staging that lives with the handle: no synchronisation between the uploads and the fit
     bool host_stale = false;   // sls_gp_refit_dev replaced the device X / y: Xh / yh are refreshed before their next use
     DBuf X, y, inv_ell, XT, XaT, nx, L, Linv, Kinv, U, alpha, tvec, mu_data, scal, gemv_part;   // U = (L^-1)^T, needed by the fit only
     long* d_idx = nullptr;
@@ -524,15 +525,15 @@ static void gp_setup(sls_gp* g) {
     g->gemv_part.ensure((Np / 128) * Np);
     g->ws_chunk = 0;   // the evaluation workspace depends on Np
     if (!g->d_idx) SLS_HIP(hipMalloc((void**)&g->d_idx, 64));
-    std::vector<double> il(g->Dcols, 0.0), ypad(Np, 0.0);
-    for (int d = 0; d < D; ++d) il[d] = 1.0 / g->theta[1 + d];
-    std::copy(g->yh.begin(), g->yh.end(), ypad.begin());
+    g->il_h.assign(g->Dcols, 0.0);
+    g->ypad_h.assign(Np, 0.0);
+    for (int d = 0; d < D; ++d) g->il_h[d] = 1.0 / g->theta[1 + d];
+    std::copy(g->yh.begin(), g->yh.end(), g->ypad_h.begin());
     h2d(ctx, g->X.p, g->Xh.data(), (size_t)D * N);
-    h2d(ctx, g->y.p, ypad.data(), Np);
-    h2d(ctx, g->inv_ell.p, il.data(), g->Dcols);
-    sync(ctx);   // host staging vectors go out of scope
-    gp_fit_device(g);
-    gp_fetch_summary(g);
+    h2d(ctx, g->y.p, g->ypad_h.data(), Np);
+    h2d(ctx, g->inv_ell.p, g->il_h.data(), g->Dcols);
+    gp_fit_device(g);            // enqueued behind the uploads; the staging vectors are members
+    gp_fetch_summary(g);         // the one synchronisation of the fit
 }
 
 extern "C" int sls_gp_create(sls_ctx* ctx, const double* X, int D, int N, const double* y, const double* theta, double b,
