@@ -275,7 +275,9 @@ int sls_gp_map_fit(sls_nll* h, const double* y, const double* z0, const double* 
 
 /* ---- instrumentation ------------------------------------------------------ */
 /* Per-kernel accumulated device time (ms, HIP events on the context's stream) and launch counts since the last reset.
- * Names: "gram", "potrf", "trtri", "lauum", "cross_gram", "acq_gemm", "grad_gemm", "finalize", "lbfgs". */
+ * Names: "gram", "potri" (N <= 4096: factor + L^-1 + K^-1 in one launch) or "potrf", "trtri", "lauum" (larger N, or
+ * SLS_POTRI_FUSED=0), "fit_small" (N <= 128: the whole fit in one launch), "cross_gram", "acq_gemm", "grad_gemm", "finalize",
+ * "lbfgs"; "potrf_fallbacks": launches = how often a single-launch factorisation gave up and was recomputed. */
 int sls_prof_enable(sls_ctx* ctx, int on);
 int sls_prof_reset(sls_ctx* ctx);
 int sls_prof_get(sls_ctx* ctx, const char* name, double* total_ms, long* launches);
