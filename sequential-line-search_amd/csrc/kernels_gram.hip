@@ -162,8 +162,9 @@ __global__ __launch_bounds__(256, 2) void cross_gram_kernel(const double* __rest
             smu[e] += al * k;
             sca[e] += al * c;
         }
-        *reinterpret_cast<d2_t*>(Ks + (long)(m0 + row) + (long)gi * ldk) = kv;
-        if (MATERN) *reinterpret_cast<d2_t*>(Cs + (long)(m0 + row) + (long)gi * ldk) = cv;
+        // streamed out, read back by acq_gemm from HBM / the Infinity Cache much later: non-temporal stores
+        __builtin_nontemporal_store(kv, reinterpret_cast<d2_t*>(Ks + (long)(m0 + row) + (long)gi * ldk));
+        if (MATERN) __builtin_nontemporal_store(cv, reinterpret_cast<d2_t*>(Cs + (long)(m0 + row) + (long)gi * ldk));
     });
     if (alpha) {
         __syncthreads();
