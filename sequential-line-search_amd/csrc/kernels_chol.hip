@@ -819,8 +819,12 @@ struct NoSlabHook {
     __device__ __forceinline__ void operator()(int) const {}
 };
 // before_slab(s): called by every thread before slab s (columns 16 s .. 16 s + 15 of the operand) is read.
+// Csub != nullptr: the image receives Csub - A A^T instead (Csub: the 128 x 128 tile the product is subtracted from, in global
+// memory; its lower 16 x 16 blocks are loaded in the ACCUMULATOR layout -- agent-scope loads, in flight behind the product -- so
+// the subtraction happens in the write-back, without a pass of its own over the image).  The same single subtraction of the
+// complete sum: same bits as image <- product, image <- Csub - image.
 template <int W, class F>
-__device__ __forceinline__ void chain_syrk_inplace_wave(double* img, F&& before_slab) {
+__device__ __forceinline__ void chain_syrk_inplace_wave(double* img, F&& before_slab, const double* __restrict__ Csub = nullptr, long ldc = 0) {
     constexpr int NB9[4][9][2] = {
         {{5, 0}, {5, 1}, {5, 2}, {6, 0}, {6, 1}, {6, 2}, {7, 0}, {7, 1}, {7, 2}},
         {{5, 3}, {5, 4}, {5, 5}, {6, 3}, {6, 4}, {6, 5}, {7, 3}, {7, 4}, {7, 5}},
@@ -828,9 +832,19 @@ __device__ __forceinline__ void chain_syrk_inplace_wave(double* img, F&& before_
         {{0, 0}, {1, 0}, {1, 1}, {3, 3}, {4, 3}, {4, 4}, {6, 6}, {7, 6}, {7, 7}}};
     const int lane = threadIdx.x & 63;
     const int l0 = (lane >> 4) * GEMM_LDS_MC_LD + (lane & 15);
-    d4_t acc[9];
+    d4_t acc[9], c0[9];
 #pragma unroll
     for (int p = 0; p < 9; ++p) acc[p] = d4_t{0.0, 0.0, 0.0, 0.0};
+    if (Csub) {
+        auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Csub), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int p = 0; p < 9; ++p)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long off = (16 * NB9[W][p][0] + (lane & 15)) + (long)(16 * NB9[W][p][1] + (lane >> 4) + 4 * r) * ldc;
+                c0[p][r] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(off * 8), 0, 16));
+            }
+    }
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         before_slab(s);
@@ -854,15 +868,16 @@ __device__ __forceinline__ void chain_syrk_inplace_wave(double* img, F&& before_
     for (int p = 0; p < 9; ++p)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            img[(16 * NB9[W][p][1] + (lane >> 4) + 4 * r) * DL + 16 * NB9[W][p][0] + (lane & 15)] = acc[p][r];
+            img[(16 * NB9[W][p][1] + (lane >> 4) + 4 * r) * DL + 16 * NB9[W][p][0] + (lane & 15)] = Csub ? c0[p][r] - acc[p][r] : acc[p][r];
 }
 template <class F = NoSlabHook>
-__device__ __forceinline__ void chain_syrk_inplace(double* img, F&& before_slab = NoSlabHook{}) {
+__device__ __forceinline__ void chain_syrk_inplace(double* img, F&& before_slab = NoSlabHook{}, const double* __restrict__ Csub = nullptr,
+                                                   long ldc = 0) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave == 0) chain_syrk_inplace_wave<0>(img, before_slab);
-    else if (wave == 1) chain_syrk_inplace_wave<1>(img, before_slab);
-    else if (wave == 2) chain_syrk_inplace_wave<2>(img, before_slab);
-    else chain_syrk_inplace_wave<3>(img, before_slab);
+    if (wave == 0) chain_syrk_inplace_wave<0>(img, before_slab, Csub, ldc);
+    else if (wave == 1) chain_syrk_inplace_wave<1>(img, before_slab, Csub, ldc);
+    else if (wave == 2) chain_syrk_inplace_wave<2>(img, before_slab, Csub, ldc);
+    else chain_syrk_inplace_wave<3>(img, before_slab, Csub, ldc);
 }
 // image <- (global tile) - image on the lower 16 x 16 blocks, zero above: diag_block's input, built in place
 __device__ __forceinline__ void chain_image_rsub(const double* __restrict__ C, long ld, double* img) {
@@ -1256,7 +1271,6 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             PK_STAMP(10);
             if (!pk_wait_count(chain_ready + j, 1 + a.split_sub, a)) return;   // tile (j+1, j) carries its owners' updates (steps < j)
             PK_STAMP(11);
-            d2_t cv[2][16];                                    // A_{j+1,j+1} (lower blocks), for the subtraction behind the product
             {
                 ChainAcc ca;
                 if (!stream_trsm(ca, Asub, ld, Ajj, ld, Tjj, ld, factored + j, a.info + 1, a.timeout, lds)) return;
@@ -1270,22 +1284,9 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             chain_image_store_wt(Asub, ld, lds);
             {
                 // The diagonal tile's owner finished its updates long since (its last one comes ~6 us after the sub-diagonal
-                // tile's, i.e. ~10 us before this point): a relaxed look at its flag (the full wait only if it is not up yet), then
-                // agent-scope loads -- no invalidate -- that travel together with the panel tile's stores: one drain for both.
+                // tile's, i.e. ~10 us before this point): a relaxed look at its flag, the full wait only if it is not up yet.
                 const int up = *ctl;
                 if (!up && !pk_wait_count(diag_ready + j, 1, a)) return;
-                const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-                const int ti = lane >> 3;
-                auto rsrcN = __builtin_amdgcn_make_buffer_rsrc(Anext, 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const int c = w + 4 * (16 * h + q);
-                        cv[h][q] = d2_t{0.0, 0.0};
-                        if (ti >= (c >> 4))
-                            cv[h][q] = __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(rsrcN, (int)((2 * lane + (long)c * ld) * 8), 0, 16));
-                    }
             }
             // The product starts at once: the stores have left the image (it is only overwritten behind the product), and their
             // drain -- 3.3 us for 128 KB of write-through stores + the 64 KB of loads above -- would sit on the chain's path.  The
@@ -1293,28 +1294,16 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             PK_STAMP(1);
             PK_STAMP(2);
             int* xflag = panel_done + (j + 1) + (long)j * nb;
+            // image <- A_{j+1,j+1} - L L^T on the lower blocks (the tile comes in the accumulator layout, agent-scope loads in flight
+            // behind the product; what stands above the diagonal blocks is never read by the factorisation)
             chain_syrk_inplace(lds, [&](int sblk) {
                 if (sblk == 2) {
                     df_publish_store(xflag);
                     PK_STAMP(13);
                 }
-            });
+            }, Anext, ld);
             PK_STAMP(8);
-            lds_barrier();
             PK_STAMP(9);
-            {   // image <- A_{j+1,j+1} - image on the lower blocks, zero above (chain_image_rsub with the tile already in registers)
-                const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-                const int ti = lane >> 3;
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const int c = w + 4 * (16 * h + q);
-                        d2_t v = d2_t{0.0, 0.0};
-                        if (ti >= (c >> 4)) v = cv[h][q] - *reinterpret_cast<const d2_t*>(lds + 2 * lane + c * DL);
-                        *reinterpret_cast<d2_t*>(lds + 2 * lane + c * DL) = v;
-                    }
-            }
             __syncthreads();
             PK_STAMP(3);
             diag_block_factor<false>(Anext, ld, Tjj + (long)NB * (ld + 1), ld, a.info, (j + 1) * NB, smem, factored + j + 1);
@@ -1676,7 +1665,7 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
     // streamed panel tiles: two chain workgroups taking turns (SLS_POTRF_STREAM=0: the round-3 chain, one workgroup that factors, then
     // solves its panel tile, then multiplies).
     // Measured (tools/probes/stream_scan.sh, ms; round-3 chain -> streamed chain + streamed worker solves + half-tile owners):
-    // N = 512: 0.202 -> 0.170, 1024: 0.396 -> 0.321, 2048: 0.789 -> 0.634, 3072: 1.199 -> 0.98, 4096: 1.645 -> 1.325; at N = 8192
+    // N = 512: 0.202 -> 0.164, 1024: 0.396 -> 0.309, 2048: 0.789 -> 0.61, 3072: 1.199 -> 0.96, 4096: 1.645 -> 1.29; at N = 8192
     // the workers are as busy as the chain (4.16 -> 4.10-4.17): the round-3 form stays from N > 5120
     // Several problems per launch are bound by their workers, not by their chains (8 value-only evaluations at N = 4096: 6.4 ms on
     // the round-3 chain, 7.3 ms streamed): the round-3 form there too.
