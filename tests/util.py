@@ -66,7 +66,7 @@ def record(kind, **payload):
 
 
 def assert_starts_agree(rg, ro, min_frac=0.95, margin_tol=1e-6, basin_rtol=1e-3, label="", max_divergent=None, allow_basin=False,
-                        ulp_probe=None):
+                        ulp_probe=None, atol_scale=1e-12):
     """Per-start end values of the HIP maximiser (rg) against the oracle run with diag=True (ro).
 
     Both sides run the same bounded L-BFGS statement by statement; they differ only in summation order.  A start can end
@@ -84,7 +84,9 @@ def assert_starts_agree(rg, ro, min_frac=0.95, margin_tol=1e-6, basin_rtol=1e-3,
     a record (count, indices, margins of the divergent starts) in the session's evidence file, so that a drift of the
     divergence rate is visible from run to run."""
     scale = max(np.abs(ro["y_stars"]).max(), 1e-300)
-    agree = np.isclose(rg["y_stars"], ro["y_stars"], rtol=1e-6, atol=1e-12 * scale)
+    # atol_scale: absolute floor relative to the LARGEST end value.  EI = sigma (u Phi(u) + phi(u)) cancels for u << 0: an end point
+    # whose value is 1e-5 of the largest one carries the posterior's 1e-11 as 1e-6 of its own value (randomised sweeps pass 1e-10)
+    agree = np.isclose(rg["y_stars"], ro["y_stars"], rtol=1e-6, atol=atol_scale * scale)
     bad = np.nonzero(~agree)[0]
     record("starts_agree", label=label, starts=int(agree.size), divergent=int(bad.size), indices=[int(i) for i in bad[:32]],
            armijo_margins=[float(ro["armijo_margin"][i]) for i in bad[:32]],
