@@ -24,7 +24,7 @@ using namespace slsk;
 struct sls_nll {
     sls_ctx* ctx = nullptr;
     int D = 0, N = 0, Np = 0, Dp = 0, Dcols = 0, kernel = 0;
-    DBuf X, y, inv_ell, XT, nx, L, Linv, Kinv, alpha, tvec, G, Y, svec, ones, parts, scal, gl, gemv_part, small_in, small_out, small_info;
+    DBuf X, y, XT, nx, L, Linv, Kinv, alpha, G, Y, svec, parts, gemv_part, small_in, small_out, small_info;
     std::vector<double> cached_theta;
     double cached_b = -1.0;
     bool have_factor = false;
@@ -46,10 +46,19 @@ struct sls_nll {
     double* mo_out_dev = nullptr;
     char* mo_stage = nullptr;          // page-locked
     size_t mo_stage_bytes = 0;
-    double* il_stage = nullptr;        // page-locked: the inverse length scales of the evaluation in flight (no synchronisation behind their upload)
+    // Page-locked, device-MAPPED block of the tiled evaluation in flight: [Dcols] inverse length scales, [Np] targets, [8 + Dcols]
+    // results.  The kernels read the length scales from it and write the results into it directly, and the targets are uploaded
+    // only when they change (a MAP fit evaluates the same y hundreds of times): in steady state an evaluation makes no copy call
+    // at all.  (With pageable buffers every hipMemcpyAsync was a blocking staged copy: two up, four or five back per evaluation.)
+    double* il_stage = nullptr;        // host address
+    double* il_stage_dev = nullptr;    // the same memory as the device sees it
     size_t il_stage_bytes = 0;
+    bool y_on_device = false;          // y.p holds y_stage()'s contents
+    double* y_stage() const { return il_stage + Dcols; }
+    double* res_stage() const { return il_stage + Dcols + Np; }
+    double* res_dev() const { return il_stage_dev + Dcols + Np; }
     ~sls_nll() {   // page-locked blocks go back to the context (sls_nll_destroy holds its lock)
-        ctx->host_give(il_stage, il_stage_bytes, false);
+        ctx->host_give(il_stage, il_stage_bytes, true);
         ctx->host_give(small_host, small_host_bytes, true);
         ctx->host_give(mo_out, mo_out_bytes, true);
         ctx->host_give(mo_stage, mo_stage_bytes, false);
@@ -67,13 +76,13 @@ extern "C" int sls_nll_create(sls_ctx* ctx, const double* X, int D, int N, int k
     h->ctx = ctx; h->D = D; h->N = N; h->kernel = kernel;
     h->Np = round_up(N, 128); h->Dp = round_up(D, 16); h->Dcols = round_up(D, 128);
     const size_t Np = h->Np;
-    h->X.ensure((size_t)D * N); h->y.ensure(Np); h->inv_ell.ensure(h->Dcols);
+    h->X.ensure((size_t)D * N); h->y.ensure(Np);
     h->XT.ensure(Np * h->Dcols); h->nx.ensure(Np);
     h->L.ensure(Np * Np); h->Linv.ensure(Np * Np); h->Kinv.ensure(Np * Np);
-    h->alpha.ensure(Np); h->tvec.ensure(Np); h->svec.ensure(Np); h->ones.ensure(Np);
-    h->scal.ensure(8); h->gl.ensure(h->Dcols); h->gemv_part.ensure((Np / 128) * Np);
+    h->alpha.ensure(Np); h->svec.ensure(Np);
+    // results (res_stage): [0..2] sums, [4] log|K_y|, [5..6] the factorisation's two info words, [8..] length-scale gradient
+    h->gemv_part.ensure((Np / 128) * Np);
     SLS_HIP(hipMemcpyAsync(h->X.p, X, (size_t)D * N * 8, hipMemcpyHostToDevice, ctx->stream));
-    launch_fill(ctx->stream, h->ones.p, Np, 1.0);
     launch_fill(ctx->stream, h->y.p, Np, 0.0);
     SLS_HIP(hipStreamSynchronize(ctx->stream));
     slsk::ctx_retain(ctx);
@@ -99,6 +108,12 @@ extern "C" int sls_nll_destroy(sls_nll* h) {
 // Nothing is read back here -- the caller appends the rest of the evaluation, copies (d_info, log-det) back together with its
 // own results and hands them to nll_factor_accept: one host synchronisation per evaluation instead of two (the one in the
 // middle left the GPU idle for 40-100 us of a 3.1 ms evaluation at N = 4096).  false: (theta, b) is the cached factor.
+static void nll_stage_ensure(sls_nll* h) {
+    if (h->il_stage) return;
+    h->il_stage = static_cast<double*>(h->ctx->host_take((size_t)(2 * h->Dcols + h->Np + 8) * 8, true, &h->il_stage_bytes));
+    SLS_HIP(hipHostGetDevicePointer((void**)&h->il_stage_dev, h->il_stage, 0));
+    h->y_on_device = false;
+}
 static bool nll_factor_enqueue(sls_nll* h, const double* theta, double b) {
     sls_ctx* c = h->ctx;
     const int D = h->D, N = h->N, Np = h->Np;
@@ -109,25 +124,25 @@ static bool nll_factor_enqueue(sls_nll* h, const double* theta, double b) {
     SLS_REQUIRE(theta[0] > 0.0, "signal variance must be positive");
     // Staged in a page-locked block of the handle: the upload is enqueued like everything else (a local buffer needed a
     // synchronisation here, in the middle of the evaluation).  The previous evaluation on this handle ended with one, so the block is free.
-    if (!h->il_stage) h->il_stage = static_cast<double*>(c->host_take((size_t)h->Dcols * 8, false, &h->il_stage_bytes));
+    nll_stage_ensure(h);
     double* il = h->il_stage;
     for (int d = 0; d < h->Dcols; ++d) il[d] = 0.0;
     for (int d = 0; d < D; ++d) {
         SLS_REQUIRE(theta[1 + d] > 0.0, "length scale %d must be positive", d);
         il[d] = 1.0 / theta[1 + d];
     }
-    SLS_HIP(hipMemcpyAsync(h->inv_ell.p, il, h->Dcols * 8, hipMemcpyHostToDevice, c->stream));
+    // no upload: the kernels read the mapped block (1 KB; the previous evaluation on this handle ended with a synchronisation)
     KernelSpec ks{h->kernel, theta[0]};
-    launch_prep_points(c->stream, h->X.p, D, N, h->inv_ell.p, h->XT.p, Np, Np, h->Dcols, h->nx.p);
+    launch_prep_points(c->stream, h->X.p, D, N, h->il_stage_dev, h->XT.p, Np, Np, h->Dcols, h->nx.p);
     launch_gram_sym(c->stream, h->XT.p, Np, h->Dp, h->nx.p, Np, N, ks, b, h->L.p, true);
     SLS_HIP(hipMemsetAsync(c->d_info, 0, 64, c->stream));
-    launch_fill(c->stream, h->Linv.p, (long)Np * Np, 0.0);
     c->potrf_tick_rearm();
     h->G.ensure((size_t)Np * Np);   // the gradient's weight matrix, written after the factorisation: holds (L^-1)^T until then
-    // N <= 4096: one launch for the factorisation and the inverse (launch_potri); otherwise potrf + trtri + lauum
-    launch_potri(c->stream, h->L.p, Np, h->Linv.p, h->G.p, h->Kinv.p, c->d_info, c->potrf_lookahead(Np), c->potrf_df_sync(Np));
-    launch_logdet(c->stream, h->L.p, Np, N, h->scal.p + 4);
-    return true;
+    // N <= 4096: one launch for the factorisation and the inverse (launch_potri); otherwise potrf + trtri + lauum.
+    // L^-1's buffer is not cleared here: only the separate launches need that (and do it themselves); nothing in this file reads the
+    // tiles above its diagonal (134 MB, 18 us at N = 4096).
+    launch_potri(c->stream, h->L.p, Np, h->Linv.p, h->G.p, h->Kinv.p, c->d_info, c->potrf_lookahead(Np), c->potrf_df_sync(Np), false);
+    return true;   // log|K_y| (result word 4) comes out of nll_scalars, which every evaluation launches anyway
 }
 // info2 = the two words of d_info behind the enqueued factorisation (pivot failure, single-launch Cholesky gave up).
 // true: accepted (cached from now on); false: run the evaluation once more (the context has switched to the multi-launch
@@ -232,42 +247,56 @@ static void nll_eval_impl(sls_nll* h, const double* y, const double* theta, doub
     }
     const bool want_grad = grad_theta || grad_b;
     const int nt = Np / 128;
-    std::vector<double> gl(D, 0.0);
-    double sc[3];
+    nll_stage_ensure(h);
+    const double* res = h->res_stage();
     for (int attempt = 0;; ++attempt) {
+        // the targets go up first (nothing before them on the stream), and only when they differ from what is there
+        if (!h->y_on_device || std::memcmp(h->y_stage(), y, sizeof(double) * N) != 0) {
+            std::memcpy(h->y_stage(), y, sizeof(double) * N);
+            SLS_HIP(hipMemcpyAsync(h->y.p, h->y_stage(), (size_t)N * 8, hipMemcpyHostToDevice, c->stream));
+            h->y_on_device = true;
+        }
         const bool fresh = nll_factor_enqueue(h, theta, b);
-        SLS_HIP(hipMemcpyAsync(h->y.p, y, (size_t)N * 8, hipMemcpyHostToDevice, c->stream));
-        launch_gemv_n(c->stream, h->Linv.p, Np, h->y.p, h->tvec.p, h->gemv_part.p);
-        launch_gemv_t(c->stream, h->Linv.p, Np, h->tvec.p, h->alpha.p);
+        // alpha = K_y^-1 y from the explicit (symmetric, full) inverse the gradient's weights use anyway: one pass over one matrix
+        // (it was L^-1 twice: 69 -> 25 us at N = 4096)
+        launch_gemv_t(c->stream, h->Kinv.p, Np, h->y.p, h->alpha.p);
         if (want_grad) {
             h->G.ensure((size_t)Np * Np);
             h->Y.ensure((size_t)Np * h->Dcols * nll_y_chunks(nt, h->Dcols / 128));
             h->parts.ensure((size_t)nt * nt);
             launch_nll_weight(c->stream, h->XT.p, Np, h->Dp, h->nx.p, Np, N, KernelSpec{h->kernel, theta[0]}, h->alpha.p, h->Kinv.p,
-                              h->G.p, h->parts.p);
+                              h->G.p, h->parts.p, grad_theta ? h->gemv_part.p : nullptr);
         } else {
             h->parts.ensure(1);
         }
-        launch_nll_scalars(c->stream, h->parts.p, want_grad ? nt * nt : 0, h->alpha.p, h->y.p, h->Kinv.p, Np, N, h->scal.p);
+        // the sums, and behind a fresh factorisation log|K_y| and its two info words (pivot failure, single launch gave up): a
+        // workgroup of the last launch when there is a length-scale gradient, a launch of their own otherwise
+        const double* Lf = fresh ? h->L.p : nullptr;
+        const int* inf = fresh ? c->d_info : nullptr;
+        const int nparts = want_grad ? nt * nt : 0;
         if (grad_theta) {
-            launch_gemv_n(c->stream, h->G.p, Np, h->ones.p, h->svec.p, h->gemv_part.p);
             // Y = G X~ has only nt x Dcols/128 output tiles: split the contraction so that the launch fills the chip
             const int yc = nll_y_chunks(nt, h->Dcols / 128);
             launch_gemm_splitk_nt(c->stream, h->G.p, Np, h->XT.p, Np, h->Y.p, Np, (long)Np * h->Dcols, nt, h->Dcols / 128, Np, yc);
-            launch_sum_chunks(c->stream, h->Y.p, (long)Np * h->Dcols, yc, (long)Np * h->Dcols);
-            launch_lengthscale_grad(c->stream, h->XT.p, h->Y.p, h->svec.p, h->inv_ell.p, Np, N, D, h->gl.p);
-            SLS_HIP(hipMemcpyAsync(gl.data(), h->gl.p, (size_t)D * 8, hipMemcpyDeviceToHost, c->stream));
+            // the partial products of Y and the partial row sums (G 1) left by nll_weight, both added in chunk order
+            launch_sum_chunks(c->stream, h->Y.p, (long)Np * h->Dcols, yc, (long)Np * h->Dcols, h->gemv_part.p, Np, nt, h->svec.p);
+            launch_lengthscale_grad(c->stream, h->XT.p, h->Y.p, h->svec.p, h->il_stage_dev, Np, N, D, h->res_dev() + 8, h->parts.p, nparts,
+                                    h->alpha.p, h->y.p, h->Kinv.p, Np, h->res_dev(), Lf, inf);
+        } else {
+            launch_nll_scalars(c->stream, h->parts.p, nparts, h->alpha.p, h->y.p, h->Kinv.p, Np, N, h->res_dev(), Lf, inf);
         }
-        int info2[2] = {0, 0};
-        if (fresh) {
-            SLS_HIP(hipMemcpyAsync(info2, c->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            SLS_HIP(hipMemcpyAsync(&h->logdet, h->scal.p + 4, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        }
-        SLS_HIP(hipMemcpyAsync(sc, h->scal.p, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        // the results are already in (mapped) host memory when the stream has drained: no copy back
         if (alpha) SLS_HIP(hipMemcpyAsync(alpha, h->alpha.p, (size_t)N * 8, hipMemcpyDeviceToHost, c->stream));
         SLS_HIP(hipStreamSynchronize(c->stream));
-        if (!fresh || nll_factor_accept(h, theta, b, info2, attempt)) break;   // else: once more on the multi-launch Cholesky
+        if (!fresh) break;
+        const int info2[2] = {(int)res[5], (int)res[6]};
+        if (nll_factor_accept(h, theta, b, info2, attempt)) {
+            h->logdet = res[4];
+            break;
+        }   // else: once more on the multi-launch Cholesky
     }
+    const double* sc = res;
+    const double* gl = res + 8;
     if (quad) *quad = sc[2];
     if (logdet) *logdet = h->logdet;
     if (grad_b) *grad_b = sc[1];
@@ -387,6 +416,7 @@ extern "C" int sls_gp_nll_batch(sls_nll* h, const double* y, const double* xs, i
             h->bt_P = Pmax;
         }
         SLS_HIP(hipMemcpyAsync(h->y.p, y, (size_t)N * 8, hipMemcpyHostToDevice, c->stream));
+        h->y_on_device = false;   // not through the staging block: the next gradient evaluation uploads its own
         std::vector<double> il((size_t)Dcols * Pmax), out(2 * Pmax);
         for (int k0 = 0; k0 < B;) {
             const int P = std::min(Pmax, B - k0);

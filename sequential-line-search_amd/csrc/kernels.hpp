@@ -267,7 +267,8 @@ struct PotriFused {
 bool launch_potri_dataflow(hipStream_t s, double* A, int Np, double* Linv, double* U, double* Kinv, int* info, int* sync,
                            long long* trace = nullptr);
 bool potri_fused_applies(int Np, bool have_sync);   // sizes / switches only: the launch itself may still decline (too few CUs)
-bool launch_potri(hipStream_t s, double* A, int Np, double* Linv, double* U, double* Kinv, int* info, PotrfAux* aux, int* dataflow_sync);
+bool launch_potri(hipStream_t s, double* A, int Np, double* Linv, double* U, double* Kinv, int* info, PotrfAux* aux, int* dataflow_sync,
+                  bool linv_zeroed = true);   // false: Linv was not cleared by the caller (only the separate launches need it: done inside)
 int potrf_default_mode(int Np);
 // side stream restricted by a CU mask that leaves `free_per_xcd` CUs of each of the 8 XCDs to other streams (0: plain stream)
 void potrf_aux_create(PotrfAux* aux, int free_per_xcd);
@@ -311,13 +312,19 @@ void launch_gemm_plain(hipStream_t s, const double* A, long lda, bool a_kc, cons
 // G[j + k*Np] = 1/2 (alpha_j alpha_k - Kinv_jk) c_jk  (0 in the padding);  wk_part[tile] = sum over the tile of
 // 1/2 (alpha_j alpha_k - Kinv_jk) kf_jk  (kf = kernel value without noise).  ntiles = (Np/128)^2 partials.
 void launch_nll_weight(hipStream_t s, const double* XT, long ld, int Dp, const double* nx, int Np, int N, KernelSpec ks,
-                       const double* alpha, const double* Kinv, double* G, double* wk_part);
+                       const double* alpha, const double* Kinv, double* G, double* wk_part, double* row_part);
+// row_part (nullptr: skip): [Np / 128][Np] partial row sums of G, one slice per tile column; launch_sum_chunks adds them in slice order
 // out[0] = sum_t part[t] (fixed order);  out[1] = 1/2 (alpha.alpha - tr Kinv);  out[2] = y.alpha
 void launch_nll_scalars(hipStream_t s, const double* part, int nparts, const double* alpha, const double* y,
-                        const double* Kinv, int Np, int N, double* out);
-// gl[p] = 2 * inv_ell[p] * sum_j XT[j,p] * (XT[j,p] * s_j - Y[j,p]),  p < D
+                        const double* Kinv, int Np, int N, double* out, const double* Lfac = nullptr,
+                        const int* info = nullptr);   // Lfac: out[4] = 2 sum log L_ii too;  info: out[5..6] = info[0..1]
+// gl[p] = 2 * inv_ell[p] * sum_j XT[j,p] * (XT[j,p] * s_j - Y[j,p]),  p < D;  one more workgroup of the same launch does what
+// launch_nll_scalars does (arguments from `part` on)
 void launch_lengthscale_grad(hipStream_t s, const double* XT, const double* Y, const double* svec, const double* inv_ell,
-                             long ld, int N, int D, double* gl);
-void launch_sum_chunks(hipStream_t s, double* Y, long n, int chunks, long stride);
+                             long ld, int N, int D, double* gl, const double* part, int nparts, const double* alpha, const double* y,
+                             const double* Kinv, int Np, double* out, const double* Lfac, const int* info);
+// Y = sum of `chunks` partial products `stride` apart (in place in the first), and svec = sum of `row_chunks` slices of row_part
+void launch_sum_chunks(hipStream_t s, double* Y, long n, int chunks, long stride, const double* row_part, int Np, int row_chunks,
+                       double* svec);
 
 }  // namespace slsk

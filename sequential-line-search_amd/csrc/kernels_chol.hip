@@ -1964,9 +1964,13 @@ bool potri_fused_applies(int Np, bool have_sync) {
     const char* e = getenv("SLS_POTRI_FUSED");
     return (!e || atoi(e) != 0) && have_sync && nb >= 3 && nb <= 32 && potrf_default_mode(Np) == 3;
 }
-bool launch_potri(hipStream_t s, double* A, int Np, double* Linv, double* U, double* Kinv, int* info, PotrfAux* aux, int* dataflow_sync) {
+// linv_zeroed = false: the caller has NOT cleared Linv (the fused launch does not need it: it writes the diagonal tiles in full and
+// the tiles below them, and leaves the tiles above the diagonal alone); the separate launches clear it here.
+bool launch_potri(hipStream_t s, double* A, int Np, double* Linv, double* U, double* Kinv, int* info, PotrfAux* aux, int* dataflow_sync,
+                  bool linv_zeroed) {
     if (potri_fused_applies(Np, dataflow_sync != nullptr) && launch_potri_dataflow(s, A, Np, Linv, U, Kinv, info, dataflow_sync))
         return true;
+    if (!linv_zeroed) launch_fill(s, Linv, (long)Np * Np, 0.0);
     launch_potrf(s, A, Np, Linv, info, 0, aux, dataflow_sync);
     launch_trtri(s, A, Np, Linv, Kinv, U);
     launch_lauum(s, U, Np, Kinv);

@@ -23,35 +23,80 @@ __device__ __forceinline__ void kernel_kc(int kernel, double a, double q, double
     }
 }
 
+// 64 points per workgroup.  Pass 1 (all 256 threads, 64 dimensions at a time): scaled coordinates out (64 consecutive doubles per
+// dimension) and into LDS; pass 2 (one thread per point): the squared norm, summed over the dimensions in index order -- the order,
+// and therefore the bits, of the one-thread-per-point loop this replaces (16 workgroups and 128 dependent strided loads per thread at
+// N = 4096, D = 128: 28 us; now 64 workgroups and coalesced accesses).
+constexpr int PREP_PTS = 64, PREP_DCH = 64, PREP_LD = PREP_DCH + 1;   // 33 KB of LDS
 template <bool CAND_MAJOR>
 __global__ __launch_bounds__(256) void prep_kernel(const double* __restrict__ X, long ldr, int D, int M,
                                                    const double* __restrict__ inv_ell, double* __restrict__ XT, long ld, int Mp,
                                                    int Dcols, double* __restrict__ norms) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= Mp) return;
+    __shared__ double vs[PREP_PTS * PREP_LD];
+    __shared__ double ils[PREP_DCH];   // this chunk's inverse length scales: read ONCE per workgroup (they may sit in mapped host memory)
+    const int i0 = blockIdx.x * PREP_PTS, tid = threadIdx.x;
+    const int p = tid & 63, w = tid >> 6, i = i0 + p;
     double s = 0.0;
-    if (i < M) {
-        for (int d = 0; d < D; ++d) {
-            const double raw = CAND_MAJOR ? X[i + (long)d * ldr] : X[d + (long)i * D];
-            const double v = (raw - 0.5) * inv_ell[d];
-            XT[i + (long)d * ld] = v;
-            s += v * v;
+    for (int d0 = 0; d0 < Dcols; d0 += PREP_DCH) {
+        if (tid < PREP_DCH) ils[tid] = d0 + tid < D ? inv_ell[d0 + tid] : 0.0;
+        double raw[PREP_DCH / 4];
+        // all 16 loads of a thread in flight together (constant trip count, unrolled), then the arithmetic
+        if (CAND_MAJOR) {          // X[i + d ldr]: points contiguous
+#pragma unroll
+            for (int k = 0; k < PREP_DCH / 4; ++k) {
+                const int d = d0 + w + 4 * k;
+                raw[k] = (i < M && d < D) ? X[i + (long)d * ldr] : 0.5;
+            }
+        } else {                   // X[d + i D]: dimensions contiguous -- read along d, written along i through LDS
+#pragma unroll
+            for (int k = 0; k < PREP_DCH / 4; ++k) {
+                const int pp = w + 4 * k, d = d0 + p, ii = i0 + pp;      // lane -> dimension, (wave, k) -> point
+                raw[k] = (ii < M && d < D) ? X[d + (long)ii * D] : 0.5;
+            }
         }
-        for (int d = D; d < Dcols; ++d) XT[i + (long)d * ld] = 0.0;
-    } else {
-        for (int d = 0; d < Dcols; ++d) XT[i + (long)d * ld] = 0.0;
+        __syncthreads();
+        if (CAND_MAJOR) {
+#pragma unroll
+            for (int k = 0; k < PREP_DCH / 4; ++k) {
+                const int dd = w + 4 * k, d = d0 + dd;
+                const double v = (i < M && d < D) ? (raw[k] - 0.5) * ils[dd] : 0.0;
+                if (i < Mp && d < Dcols) XT[i + (long)d * ld] = v;
+                vs[p * PREP_LD + dd] = v;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < PREP_DCH / 4; ++k) {
+                const int pp = w + 4 * k, ii = i0 + pp, d = d0 + p;
+                vs[pp * PREP_LD + p] = (ii < M && d < D) ? (raw[k] - 0.5) * ils[p] : 0.0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < PREP_DCH / 4; ++k) {
+                const int dd = w + 4 * k, d = d0 + dd;
+                if (i < Mp && d < Dcols) XT[i + (long)d * ld] = vs[p * PREP_LD + dd];
+            }
+        }
+        __syncthreads();
+        if (tid < PREP_PTS) {
+            const int dn = min(PREP_DCH, D - d0);
+            for (int dd = 0; dd < dn; ++dd) {
+                const double v = vs[tid * PREP_LD + dd];
+                s += v * v;
+            }
+        }
+        __syncthreads();
     }
-    norms[i] = s;
+    if (tid < PREP_PTS && i0 + tid < Mp) norms[i0 + tid] = s;
 }
 
 void launch_prep_points(hipStream_t s, const double* X, int D, int M, const double* inv_ell, double* XT, long ld, int Mp,
                         int Dcols, double* norms) {
-    hipLaunchKernelGGL(prep_kernel<false>, dim3((Mp + 255) / 256), dim3(256), 0, s, X, 0L, D, M, inv_ell, XT, ld, Mp, Dcols,
+    hipLaunchKernelGGL(prep_kernel<false>, dim3((Mp + PREP_PTS - 1) / PREP_PTS), dim3(256), 0, s, X, 0L, D, M, inv_ell, XT, ld, Mp, Dcols,
                        norms);
 }
 void launch_prep_cands(hipStream_t s, const double* xr, long ldr, int D, int M, const double* inv_ell, double* XT, long ld,
                        int Mp, int Dcols, double* norms) {
-    hipLaunchKernelGGL(prep_kernel<true>, dim3((Mp + 255) / 256), dim3(256), 0, s, xr, ldr, D, M, inv_ell, XT, ld, Mp, Dcols,
+    hipLaunchKernelGGL(prep_kernel<true>, dim3((Mp + PREP_PTS - 1) / PREP_PTS), dim3(256), 0, s, xr, ldr, D, M, inv_ell, XT, ld, Mp, Dcols,
                        norms);
 }
 

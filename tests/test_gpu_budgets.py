@@ -84,7 +84,8 @@ def test_c3_submit_feedback_budget():
 
 
 def test_c5_evaluation_and_batch_budget(ctx, oracle):
-    """C5: Matern-5/2 MAP objective + gradient at N = 4096, D = 128 (measured 2.9 ms; first session of round 4: 3.4), and the
+    """C5: Matern-5/2 MAP objective + gradient at N = 4096, D = 128 (measured 2.57-2.65 ms once the evaluation made no copy calls and its
+    small launches were merged; before that 2.75-2.9; first session of round 4: 3.4), and the
     value-only evaluations of a DIRECT iteration: eight parameter sets through sls_gp_nll_batch (concurrent bordered
     factorisations, measured 6.4-6.6 ms) against one full evaluation after the other (SLS_NLL_BATCH=0, 19.8 ms): at least 1.8x."""
     D, N = 128, 4096
@@ -107,7 +108,7 @@ def test_c5_evaluation_and_batch_budget(ctx, oracle):
         del os.environ["SLS_NLL_BATCH"]
     h.close()
     record("budget", config="C5", ms_per_evaluation=ms_eval, batch8_ms=ms_batch, sequential8_ms=ms_seq, speedup=ms_seq / ms_batch)
-    assert ms_eval <= 4.0, ms_eval
+    assert ms_eval <= 3.6, ms_eval
     assert ms_seq / ms_batch >= 1.8, (ms_seq, ms_batch)
 
 
