@@ -63,7 +63,7 @@ def ev():
     k[0] += 1
     xx = x.copy(); xx[2] *= (1 + 1e-3 * k[0])
     h.gp_objective(y, xx)
-ms_c5 = wall(ev)
+ms_c5 = wall(ev, reps=20)
 # the B independent value-only evaluations of a DIRECT iteration (sls_gp_nll_batch): concurrent bordered factorisations vs one
 # full evaluation after the other (SLS_NLL_BATCH=0)
 xsb = np.tile(x, (8, 1)); xsb[:, 2] *= 1 + 1e-3 * np.arange(8)
