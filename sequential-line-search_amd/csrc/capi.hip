@@ -399,8 +399,13 @@ struct sls_gp {
     std::vector<double> theta, Xh, yh;
     std::vector<double> il_h, ypad_h;   // upload staging that lives with the handle: no synchronisation between the uploads and the fit
     bool host_stale = false;   // sls_gp_refit_dev replaced the device X / y: Xh / yh are refreshed before their next use
-    DBuf X, y, inv_ell, XT, XaT, nx, L, Linv, Kinv, U, alpha, tvec, mu_data, scal, gemv_part;   // U = (L^-1)^T, needed by the fit only
-    long* d_idx = nullptr;
+    DBuf X, y, inv_ell, XT, XaT, nx, L, Linv, Kinv, U, alpha, tvec, mu_data, scal, gemv_part, idx_buf;   // U = (L^-1)^T, needed by the fit only
+    long* d_idx = nullptr;             // idx_buf's block (pooled: a hipMalloc / hipFree pair per handle synchronised the device)
+    // what the host reads after a fit -- max mu, log|K_y|, arg max, the factorisation's two info words -- in a page-locked block the
+    // last kernel of the fit writes directly (mapped): one synchronisation, no copies back (they were three blocking pageable copies)
+    double* sum_host = nullptr;
+    double* sum_dev = nullptr;
+    size_t sum_bytes = 0;
     int best_index = 0;
     double mu_best = 0, logdet = 0;
     // evaluation workspace (grown on demand)
@@ -422,8 +427,8 @@ struct sls_gp {
     double* zc_dev = nullptr;
     size_t zc_bytes = 0;
     ~sls_gp() {   // sls_gp_destroy holds the context's lock
-        if (d_idx) (void)hipFree(d_idx);
         if (lb_int) (void)hipFree(lb_int);
+        if (sum_host) ctx->host_give(sum_host, sum_bytes, true);
         if (zc_host) ctx->host_give(zc_host, zc_bytes, true);
     }
 };
@@ -444,6 +449,7 @@ static void gp_fit_device(sls_gp* g) {
         f.D = D; f.N = N; f.Dcols = g->Dcols; f.a = g->a; f.b = g->b;
         f.XT = g->XT.p; f.nx = g->nx.p; f.XaT = g->XaT.p; f.L = g->L.p; f.Linv = g->Linv.p; f.U = g->U.p; f.Kinv = g->Kinv.p;
         f.alpha = g->alpha.p; f.mu_data = g->mu_data.p; f.scal = g->scal.p; f.d_idx = g->d_idx; f.info = c->d_info;
+        f.summary = g->sum_dev;
         SLS_HIP(hipMemsetAsync(c->d_info, 0, 64, c->stream));
         ProfScope ps(c, "fit_small");
         launch_gp_fit_small(c->stream, g->kernel, f);
@@ -482,21 +488,16 @@ static void gp_fit_device(sls_gp* g) {
     launch_gemv_n(c->stream, g->Linv.p, Np, g->y.p, g->tvec.p, g->gemv_part.p);
     launch_gemv_t(c->stream, g->Linv.p, Np, g->tvec.p, g->alpha.p);
     launch_scale_rows(c->stream, g->XT.p, g->alpha.p, g->XaT.p, Np, Np, g->Dcols);
-    launch_mu_data(c->stream, g->y.p, g->alpha.p, g->b, N, g->mu_data.p);
-    launch_argmax(c->stream, g->mu_data.p, N, g->scal.p, g->d_idx);
-    launch_logdet(c->stream, g->L.p, Np, N, g->scal.p + 1);
     if (g->sigma_mode == 1) launch_transpose_full(c->stream, g->Linv.p, g->U.p, Np);   // every block of U = (L^-1)^T
+    // mu at the data points, its first maximum, log|K_y| and the info words: one launch, results straight into the mapped block
+    launch_fit_summary(c->stream, g->y.p, g->alpha.p, g->b, N, g->mu_data.p, g->L.p, Np, c->d_info, g->scal.p, g->d_idx, g->sum_dev);
 }
 
 static void gp_fetch_summary(sls_gp* g, int attempt = 0) {
     sls_ctx* c = g->ctx;
-    int info[16] = {0};
-    double sc[2];
-    long idx = 0;
-    SLS_HIP(hipMemcpyAsync(info, c->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    SLS_HIP(hipMemcpyAsync(sc, g->scal.p, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    SLS_HIP(hipMemcpyAsync(&idx, g->d_idx, sizeof(long), hipMemcpyDeviceToHost, c->stream));
-    sync(c);
+    sync(c);                         // the fit's last kernel has written the mapped block
+    const double* sm = g->sum_host;
+    const int info[2] = {(int)sm[3], (int)sm[4]};
     if (potrf_gave_up(c, info[1], attempt)) {
         gp_fit_device(g);            // once more, on the multi-launch schedule (the fit rebuilds K_y from X)
         gp_fetch_summary(g, 1);
@@ -506,11 +507,10 @@ static void gp_fetch_summary(sls_gp* g, int attempt = 0) {
         set_error("Cholesky failed: K_y is not positive definite (pivot %d)", info[0] - 1);
         throw HipFail{SLS_ERR_NOT_SPD};
     }
-    g->best_index = (int)idx;
-    g->mu_best = sc[0];
-    g->logdet = sc[1];
+    g->best_index = (int)sm[2];
+    g->mu_best = sm[0];
+    g->logdet = sm[1];
 }
-
 // (re)size every per-handle buffer for the host copies g->Xh / g->yh, upload and fit
 static void gp_setup(sls_gp* g) {
     sls_ctx* ctx = g->ctx;
@@ -524,7 +524,12 @@ static void gp_setup(sls_gp* g) {
     g->alpha.ensure(Np); g->tvec.ensure(Np); g->mu_data.ensure(Np); g->scal.ensure(8);
     g->gemv_part.ensure((Np / 128) * Np);
     g->ws_chunk = 0;   // the evaluation workspace depends on Np
-    if (!g->d_idx) SLS_HIP(hipMalloc((void**)&g->d_idx, 64));
+    g->idx_buf.ensure(8);
+    g->d_idx = reinterpret_cast<long*>(g->idx_buf.p);
+    if (!g->sum_host) {
+        g->sum_host = static_cast<double*>(ctx->host_take(64, true, &g->sum_bytes));
+        SLS_HIP(hipHostGetDevicePointer((void**)&g->sum_dev, g->sum_host, 0));
+    }
     g->il_h.assign(g->Dcols, 0.0);
     g->ypad_h.assign(Np, 0.0);
     for (int d = 0; d < D; ++d) g->il_h[d] = 1.0 / g->theta[1 + d];
@@ -1374,11 +1379,9 @@ extern "C" int sls_gp_append_point(sls_gp* g, const double* x, double y_new) {
     g->N = N + 1;
     launch_prep_points(c->stream, g->X.p, D, N + 1, g->inv_ell.p, g->XT.p, Np, Np, g->Dcols, g->nx.p);
     launch_scale_rows(c->stream, g->XT.p, g->alpha.p, g->XaT.p, Np, Np, g->Dcols);
-    launch_mu_data(c->stream, g->y.p, g->alpha.p, g->b, N + 1, g->mu_data.p);
-    launch_argmax(c->stream, g->mu_data.p, N + 1, g->scal.p, g->d_idx);
-    launch_logdet(c->stream, g->L.p, Np, N + 1, g->scal.p + 1);
     if (g->sigma_mode == 1) launch_transpose_full(c->stream, g->Linv.p, g->U.p, Np);   // the rank-1 growth does not maintain U
     SLS_HIP(hipMemsetAsync(c->d_info, 0, 64, c->stream));
+    launch_fit_summary(c->stream, g->y.p, g->alpha.p, g->b, N + 1, g->mu_data.p, g->L.p, Np, c->d_info, g->scal.p, g->d_idx, g->sum_dev);
     gp_fetch_summary(g);
     SLS_REQUIRE(std::isfinite(g->logdet), "sls_gp_append_point: the extended K_y is not positive definite");
     SLS_CATCH

@@ -89,6 +89,7 @@ struct GpFitSmallArgs {
     double *XT, *nx, *XaT, *L, *Linv, *U, *Kinv, *alpha, *mu_data, *scal;   // scal[0] = max_i mu(x_i), scal[1] = log|K_y|
     long* d_idx;                     // first arg max of mu over the data points
     int* info;                       // 1 + index of the first non-positive pivot, or 0
+    double* summary = nullptr;       // mapped host memory (or nullptr): [0] scal[0], [1] scal[1], [2] d_idx[0], [3] *info, [4] 0
 };
 void launch_gp_fit_small(hipStream_t s, int kernel, const GpFitSmallArgs& args);
 
@@ -197,7 +198,6 @@ void launch_gather_trials(hipStream_t s, const double* xt, long ld, int D, const
 void launch_clamp_starts(hipStream_t s, const double* starts /*D x S col-major*/, int D, int S, double* xt, long ld, int Sp);
 // first maximum of y[n] = -f[n]: out[0] = value, idx_out[0] = index
 void launch_argmax_neg(hipStream_t s, const double* f, int S, double* out_val, long* out_idx);
-void launch_argmax(hipStream_t s, const double* y, int n, double* out_val, long* out_idx);
 
 // ---- kernels_wave.hip: one wavefront per start, whole L-BFGS in one launch (small problems) ----
 struct WaveArgs {
@@ -288,8 +288,10 @@ void launch_gemv_t(hipStream_t s, const double* A, int Np, const double* x, doub
 void launch_zero_upper(hipStream_t s, double* A, int Np);
 void launch_fill(hipStream_t s, double* p, long n, double v);
 // mu_data[i] = y[i] - b*alpha[i] (i<N); out: first argmax + value; logdet = 2 sum log L_ii (i<N)
-void launch_mu_data(hipStream_t s, const double* y, const double* alpha, double b, int N, double* mu_data);
-void launch_logdet(hipStream_t s, const double* L, int Np, int N, double* out);
+// mu_data = y - b alpha, scal[0] = its first maximum, d_idx[0] = where, scal[1] = 2 sum log L_ii; summary (mapped host memory or
+// nullptr): [0] max, [1] log-det, [2] index, [3..4] info[0..1]
+void launch_fit_summary(hipStream_t s, const double* y, const double* alpha, double b, int N, double* mu_data, const double* L, int Np,
+                        const int* info, double* scal, long* d_idx, double* summary);
 // bordered factorisation (value-only MAP objective): row N of each of the nprob matrices A + q strideA <- (y^T, c); after the
 // factorisation out[2 q] = y^T K^-1 y (= |row N of L|^2) and out[2 q + 1] = log|K|
 void launch_border_row(hipStream_t s, double* A, long strideA, int nprob, int Np, int N, const double* y, double c);

@@ -1203,8 +1203,5 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const double* __restrict__
 void launch_argmax_neg(hipStream_t s, const double* f, int S, double* out_val, long* out_idx) {
     hipLaunchKernelGGL(argmax_kernel<true>, dim3(1), dim3(1024), 0, s, f, S, out_val, out_idx);
 }
-void launch_argmax(hipStream_t s, const double* y, int n, double* out_val, long* out_idx) {
-    hipLaunchKernelGGL(argmax_kernel<false>, dim3(1), dim3(1024), 0, s, y, n, out_val, out_idx);
-}
 
 }  // namespace slsk

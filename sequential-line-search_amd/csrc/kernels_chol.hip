@@ -2130,29 +2130,61 @@ void launch_fill(hipStream_t s, double* p, long n, double v) {
     hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, n, v);
 }
 
-__global__ __launch_bounds__(256) void mu_data_kernel(const double* __restrict__ y, const double* __restrict__ alpha, double b,
-                                                      int N, double* __restrict__ mu_data) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < N) mu_data[i] = y[i] - b * alpha[i];
-}
-void launch_mu_data(hipStream_t s, const double* y, const double* alpha, double b, int N, double* mu_data) {
-    hipLaunchKernelGGL(mu_data_kernel, dim3((N + 255) / 256), dim3(256), 0, s, y, alpha, b, N, mu_data);
-}
-
-__global__ __launch_bounds__(256) void logdet_kernel(const double* __restrict__ L, int Np, int N, double* __restrict__ out) {
+// The tail of a fit in ONE single-workgroup launch (it was mu_data + argmax + logdet, ~5-7 us of stream time each, and three blocking
+// pageable copies back): mu_data_i = y_i - b alpha_i (regressor.cpp:29-43 at the data points), its FIRST maximum (Eigen maxCoeff
+// semantics, argmax_kernel's comparisons and tree), log|K_y| = 2 sum log L_ii (256 partial sums, i mod 256, then a binary tree), and -- when
+// `summary` is given -- everything the host wants after the fit in one mapped block: [0] max mu, [1] log|K_y|, [2] arg max,
+// [3], [4] the factorisation's two info words.
+__global__ __launch_bounds__(1024) void fit_summary_kernel(const double* __restrict__ y, const double* __restrict__ alpha, double b, int N,
+                                                           double* __restrict__ mu_data, const double* __restrict__ L, int Np,
+                                                           const int* __restrict__ info, double* __restrict__ scal,
+                                                           long* __restrict__ d_idx, double* __restrict__ summary) {
+    __shared__ double sv[1024];
+    __shared__ int si[1024];
     __shared__ double red[256];
-    double s = 0.0;
-    for (int i = threadIdx.x; i < N; i += 256) s += log(L[(long)i * (Np + 1)]);
-    red[threadIdx.x] = s;
+    const int tid = threadIdx.x;
+    double bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < N; i += 1024) {
+        const double v = y[i] - b * alpha[i];
+        mu_data[i] = v;
+        if (v > bv) { bv = v; bi = i; }   // strictly greater: keeps the earliest index within this thread
+    }
+    sv[tid] = bv;
+    si[tid] = bi;
+    if (tid < 256) {
+        double s = 0.0;
+        for (int i = tid; i < N; i += 256) s += log(L[(long)i * (Np + 1)]);
+        red[tid] = s;
+    }
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    for (int s = 512; s > 0; s >>= 1) {
+        if (tid < s) {
+            const double ov = sv[tid + s];
+            const int oi = si[tid + s];
+            if (ov > sv[tid] || (ov == sv[tid] && oi < si[tid])) {
+                sv[tid] = ov;
+                si[tid] = oi;
+            }
+            if (s <= 128) red[tid] += red[tid + s];
+        }
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = 2.0 * red[0];
+    if (tid == 0) {
+        // all -inf / NaN: Eigen's maxCoeff returns index 0
+        const double best = (si[0] == 0x7fffffff) ? (y[0] - b * alpha[0]) : sv[0];
+        const long idx = (si[0] == 0x7fffffff) ? 0 : si[0];
+        const double ld = 2.0 * red[0];
+        scal[0] = best; scal[1] = ld; d_idx[0] = idx;
+        if (summary) {
+            summary[0] = best; summary[1] = ld; summary[2] = (double)idx;
+            summary[3] = (double)info[0]; summary[4] = (double)info[1];
+        }
+    }
 }
-void launch_logdet(hipStream_t s, const double* L, int Np, int N, double* out) {
-    hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(256), 0, s, L, Np, N, out);
+void launch_fit_summary(hipStream_t s, const double* y, const double* alpha, double b, int N, double* mu_data, const double* L, int Np,
+                        const int* info, double* scal, long* d_idx, double* summary) {
+    hipLaunchKernelGGL(fit_summary_kernel, dim3(1), dim3(1024), 0, s, y, alpha, b, N, mu_data, L, Np, info, scal, d_idx, summary);
 }
 
 // ---- bordered factorisation: quad = y^T K^-1 y and log|K| from the factor alone --------------------------------------------

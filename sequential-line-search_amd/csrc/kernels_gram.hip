@@ -100,15 +100,22 @@ void launch_prep_cands(hipStream_t s, const double* xr, long ldr, int D, int M, 
                        norms);
 }
 
+// XaT = diag(alpha) XT.  One thread per (row, 16 columns): the launch had Np / 256 workgroups with a Dcols-long loop per thread
+// (8 workgroups, 27 us at N = 2048, Dcols = 128).
 __global__ __launch_bounds__(256) void scale_rows_kernel(const double* __restrict__ XT, const double* __restrict__ alpha,
                                                          double* __restrict__ XaT, long ld, int Np, int Dcols) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= Np) return;
     const double al = alpha[i];
-    for (int d = 0; d < Dcols; ++d) XaT[i + (long)d * ld] = al * XT[i + (long)d * ld];
+    const int d0 = blockIdx.y * 16;
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = XT[i + (long)(d0 + k) * ld];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) XaT[i + (long)(d0 + k) * ld] = al * v[k];
 }
 void launch_scale_rows(hipStream_t s, const double* XT, const double* alpha, double* XaT, long ld, int Np, int Dcols) {
-    hipLaunchKernelGGL(scale_rows_kernel, dim3((Np + 255) / 256), dim3(256), 0, s, XT, alpha, XaT, ld, Np, Dcols);
+    hipLaunchKernelGGL(scale_rows_kernel, dim3((Np + 255) / 256, Dcols / 16), dim3(256), 0, s, XT, alpha, XaT, ld, Np, Dcols);
 }
 
 __global__ __launch_bounds__(256, 2) void gram_sym_kernel(const double* __restrict__ XT, long ld, int Dp,

@@ -97,7 +97,7 @@ __device__ __forceinline__ double block_sum_256(double v, double* red) {
 }
 
 // The three sums of an evaluation by ONE workgroup: out[0] = sum_t part[t] (fixed order), out[1] = 1/2 (alpha.alpha - tr Kinv),
-// out[2] = y.alpha.  Lfac != nullptr: out[4] = log|K_y| = 2 sum log L_ii as well (the summation tree of logdet_kernel: same bits);
+// out[2] = y.alpha.  Lfac != nullptr: out[4] = log|K_y| = 2 sum log L_ii as well (256 partial sums, i mod 256, then a binary tree: the order fit_summary_kernel uses);
 // info != nullptr: out[5], out[6] = the factorisation's two info words, so that the results of an evaluation sit in one block.
 struct NllScalarArgs {
     const double* part; int nparts;

@@ -780,6 +780,13 @@ __global__ __launch_bounds__(256) void gp_fit_small_kernel(const GpFitSmallArgs 
         p.scal[0] = bi == 0x7fffffff ? small_scratch(As, SC_BTL) : bv;
         p.d_idx[0] = bi == 0x7fffffff ? 0 : bi;
         p.scal[1] = 2.0 * ld;
+        if (p.summary) {   // what the host reads after the fit, in one mapped block: no copies back
+            p.summary[0] = bi == 0x7fffffff ? small_scratch(As, SC_BTL) : bv;
+            p.summary[1] = 2.0 * ld;
+            p.summary[2] = bi == 0x7fffffff ? 0.0 : (double)bi;
+            p.summary[3] = (double)__hip_atomic_load(p.info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            p.summary[4] = 0.0;
+        }
         (void)rv;
     }
 }

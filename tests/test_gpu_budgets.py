@@ -47,7 +47,7 @@ def test_c2_fit_and_predict_budget(ctx, oracle):
     pred = best_of(lambda: gp.predict(Xs), 5, ctx.synchronize)
     gp.close()
     record("budget", config="C2", fit_ms=fit, predict_ms=pred)
-    assert fit <= 1.7, fit
+    assert fit <= 1.5, fit   # measured 0.86-0.87 once the tail of the fit was one launch writing into mapped host memory
     assert pred <= 1.2, pred
 
 
