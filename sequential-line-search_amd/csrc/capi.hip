@@ -527,7 +527,8 @@ static void gp_setup(sls_gp* g) {
     g->idx_buf.ensure(8);
     g->d_idx = reinterpret_cast<long*>(g->idx_buf.p);
     if (!g->sum_host) {
-        g->sum_host = static_cast<double*>(ctx->host_take(64, true, &g->sum_bytes));
+        // [0..5) the fit's summary, [8..16 + D) the maximiser's best start
+        g->sum_host = static_cast<double*>(ctx->host_take((size_t)(16 + D) * 8, true, &g->sum_bytes));
         SLS_HIP(hipHostGetDevicePointer((void**)&g->sum_dev, g->sum_host, 0));
     }
     g->il_h.assign(g->Dcols, 0.0);
@@ -987,6 +988,7 @@ static void maximize_impl(sls_gp* g, sls_gp* gs, int acq_type, double ucb_h, con
     // Small problems: one wavefront per start runs the whole search in a single launch (kernels_wave.hip).  The choice
     // depends only on the fitted state and the start count, so repeated / sharded calls take the same path.
     bool used_wave = false;
+    const unsigned long long* wave_useful = nullptr;   // the one-wavefront-per-start run's count of useful evaluations (device)
     {
         const char* wenv = getenv("SLS_WAVE_PATH");
         const bool allow = wenv ? atoi(wenv) != 0 : true;
@@ -1015,16 +1017,15 @@ static void maximize_impl(sls_gp* g, sls_gp* gs, int acq_type, double ucb_h, con
                 ProfScope ps(c, "acq_wave");
                 launch_maximize_wave(c->stream, w);
             }
-            unsigned long long useful = 0;
-            SLS_HIP(hipMemcpyAsync(&useful, d_useful, sizeof(useful), hipMemcpyDeviceToHost, c->stream));
-            long long tr[9] = {};
-            if (d_trace) SLS_HIP(hipMemcpyAsync(tr, d_trace, sizeof(tr), hipMemcpyDeviceToHost, c->stream));
-            sync(c);
-            if (d_trace)
+            if (d_trace) {
+                long long tr[9] = {};
+                SLS_HIP(hipMemcpyAsync(tr, d_trace, sizeof(tr), hipMemcpyDeviceToHost, c->stream));
+                sync(c);
                 fprintf(stderr, "wave trace (us): S %d N %d D %d evals %lld | kvec %.1f  Kinv.k %.1f  sums %.1f  grad+acq %.1f  direction %.1f  "
                         "bookkeeping %.1f  total %.1f  (shader clock %.0f MHz)\n", S, g->N, D, tr[6], tr[0] * 0.01, tr[1] * 0.01, tr[2] * 0.01, tr[3] * 0.01, tr[4] * 0.01,
                         tr[5] * 0.01, tr[7] * 0.01, tr[7] > 0 ? (double)tr[8] / (tr[7] * 0.01) : 0.0);
-            g->stat_issued = (long)useful;
+            }
+            wave_useful = d_useful;   // read back with the best start, behind the one synchronisation of the run
             g->stat_rounds = n_local;
             used_wave = true;
         }
@@ -1075,18 +1076,15 @@ static void maximize_impl(sls_gp* g, sls_gp* gs, int acq_type, double ucb_h, con
         }
         g->stat_live_end = compact ? nlive : moving;
     }   // !used_wave
-    launch_argmax_neg(c->stream, st.f, S, g->scal.p + 2, g->d_idx + 1);
-    double bv = 0;
-    long bi = 0;
-    SLS_HIP(hipMemcpyAsync(&bv, g->scal.p + 2, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    SLS_HIP(hipMemcpyAsync(&bi, g->d_idx + 1, sizeof(long), hipMemcpyDeviceToHost, c->stream));
+    // best start and its coordinates: one launch into the handle's mapped block, one synchronisation, no copies
+    launch_argmax_neg_gather(c->stream, st.f, S, st.x, Sp, D, g->sum_dev + 8, wave_useful);
     sync(c);
-    if (val_out) *val_out = bv;
+    const double* best = g->sum_host + 8;
+    const long bi = (long)best[1];
+    if (wave_useful) g->stat_issued = (long)best[2];
+    if (val_out) *val_out = best[0];
     if (idx_out) *idx_out = bi + off;
-    if (x_out) {
-        SLS_HIP(hipMemcpy2DAsync(x_out, 8, st.x + bi, (size_t)Sp * 8, 8, D, hipMemcpyDeviceToHost, c->stream));
-        sync(c);
-    }
+    if (x_out) std::copy(best + 8, best + 8 + D, x_out);
     if (x_stars) download_cm(g, st.x, S, Sp, D, x_stars);
     if (y_stars) {
         download_cm(g, st.f, S, Sp, 1, y_stars);

@@ -197,7 +197,9 @@ void launch_gather_trials(hipStream_t s, const double* xt, long ld, int D, const
                           double* xc, long ldc);
 void launch_clamp_starts(hipStream_t s, const double* starts /*D x S col-major*/, int D, int S, double* xt, long ld, int Sp);
 // first maximum of y[n] = -f[n]: out[0] = value, idx_out[0] = index
-void launch_argmax_neg(hipStream_t s, const double* f, int S, double* out_val, long* out_idx);
+// best (mapped host memory): [0] max of -f, [1] its first index, [2] *counter (or 0), [8 .. 8 + D) = x[index + d ldx]
+void launch_argmax_neg_gather(hipStream_t s, const double* f, int S, const double* x, long ldx, int D, double* best,
+                              const unsigned long long* counter);
 
 // ---- kernels_wave.hip: one wavefront per start, whole L-BFGS in one launch (small problems) ----
 struct WaveArgs {

@@ -1169,16 +1169,21 @@ void launch_gather_trials(hipStream_t s, const double* xt, long ld, int D, const
     hipLaunchKernelGGL(gather_trials_kernel, dim3((np + 255) / 256), dim3(256), 0, s, xt, ld, D, live, count_dev, xc, ldc);
 }
 
-// first maximum (Eigen maxCoeff semantics, src/acquisition-function.cpp:146-153)
-template <bool NEG>
-__global__ __launch_bounds__(1024) void argmax_kernel(const double* __restrict__ y, int n, double* out_val, long* out_idx) {
+// first maximum: Eigen maxCoeff semantics (src/acquisition-function.cpp:146-153)
+// The end of a maximiser run in one launch: first minimum of f (= first maximum of the acquisition value, strictly-greater scan per
+// thread, then a tree that prefers the lower index on ties), and the winner's coordinates x[bi + d ldx] gathered behind it -- into `best` (mapped host memory):
+// [0] value, [1] index, [2] *counter (a statistics word of the run, or 0), [8 .. 8 + D) coordinates.  It was a launch, two or three
+// blocking copies, two or three synchronisations and a strided copy.
+__global__ __launch_bounds__(1024) void argmax_neg_gather_kernel(const double* __restrict__ f, int n, const double* __restrict__ x, long ldx,
+                                                                 int D, double* __restrict__ best,
+                                                                 const unsigned long long* __restrict__ counter) {
     __shared__ double sv[1024];
     __shared__ int si[1024];
     double bv = -INFINITY;
     int bi = 0x7fffffff;
     for (int i = threadIdx.x; i < n; i += 1024) {
-        const double v = NEG ? -y[i] : y[i];
-        if (v > bv) { bv = v; bi = i; }   // strictly greater: keeps the earliest index within this thread
+        const double v = -f[i];
+        if (v > bv) { bv = v; bi = i; }
     }
     sv[threadIdx.x] = bv;
     si[threadIdx.x] = bi;
@@ -1194,14 +1199,17 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const double* __restrict__
         }
         __syncthreads();
     }
+    const int win = (si[0] == 0x7fffffff) ? 0 : si[0];
     if (threadIdx.x == 0) {
-        // all -inf / NaN: Eigen's maxCoeff returns index 0
-        out_val[0] = (si[0] == 0x7fffffff) ? (NEG ? -y[0] : y[0]) : sv[0];
-        out_idx[0] = (si[0] == 0x7fffffff) ? 0 : si[0];
+        best[0] = (si[0] == 0x7fffffff) ? -f[0] : sv[0];
+        best[1] = (double)win;
+        best[2] = counter ? (double)counter[0] : 0.0;
     }
+    for (int d = threadIdx.x; d < D; d += 1024) best[8 + d] = x[win + (long)d * ldx];
 }
-void launch_argmax_neg(hipStream_t s, const double* f, int S, double* out_val, long* out_idx) {
-    hipLaunchKernelGGL(argmax_kernel<true>, dim3(1), dim3(1024), 0, s, f, S, out_val, out_idx);
+void launch_argmax_neg_gather(hipStream_t s, const double* f, int S, const double* x, long ldx, int D, double* best,
+                              const unsigned long long* counter) {
+    hipLaunchKernelGGL(argmax_neg_gather_kernel, dim3(1), dim3(1024), 0, s, f, S, x, ldx, D, best, counter);
 }
 
 }  // namespace slsk
