@@ -414,7 +414,8 @@ struct sls_gp {
     // L-BFGS state
     DBuf pair_mu, pair_sg, pair_dmu, pair_dsg;
     DBuf lb_x, lb_g, lb_dir, lb_xt, lb_scr, lb_S, lb_Y, lb_rho, lb_f, lb_t, lb_val, lb_grad, lb_xc;
-    int* lb_int = nullptr;    // hlen | hpos | nbt | done | live list A | live list B | live count (+ padding) | block counts
+    DBuf lb_int_buf;          // pooled (a hipMalloc / hipFree pair per handle cost ~0.2 ms per submit of the reference's demo and synchronised the device)
+    int* lb_int = nullptr;    // lb_int_buf's block: hlen | hpos | nbt | done | live list A | live list B | live count (+ padding) | block counts
     int lb_Sp = 0, lb_m = 0;
     // 0: sigma^2 = a - k^T K^-1 k with the explicit inverse (GaussianProcessRegressor); 1: a - |L^-1 k|^2, the Cholesky solve of
     // PreferenceRegressor (sls_gp_set_sigma_mode)
@@ -427,7 +428,6 @@ struct sls_gp {
     double* zc_dev = nullptr;
     size_t zc_bytes = 0;
     ~sls_gp() {   // sls_gp_destroy holds the context's lock
-        if (lb_int) (void)hipFree(lb_int);
         if (sum_host) ctx->host_give(sum_host, sum_bytes, true);
         if (zc_host) ctx->host_give(zc_host, zc_bytes, true);
     }
@@ -938,9 +938,8 @@ static void ensure_lbfgs(sls_gp* g, int Sp, int m) {
     const size_t Dh = D <= 16 ? 16 : (D <= 64 ? 64 : D);   // lbfgs_step_reg_kernel keeps rows of 4 DPL doubles per (start, pair)
     g->lb_S.ensure(S * Dh * m); g->lb_Y.ensure(S * Dh * m); g->lb_rho.ensure(S * m);
     g->lb_f.ensure(S); g->lb_t.ensure(S); g->lb_val.ensure(S); g->lb_grad.ensure(S * D); g->lb_xc.ensure(S * D);
-    if (g->lb_int) (void)hipFree(g->lb_int);
-    g->lb_int = nullptr;
-    SLS_HIP(hipMalloc((void**)&g->lb_int, (S * 6 + 128 + S / 1024 + 8) * sizeof(int)));   // ... | count (64) | block counts
+    g->lb_int_buf.ensure(((S * 6 + 128 + S / 1024 + 8) * sizeof(int) + 7) / 8);   // ... | count (64) | block counts
+    g->lb_int = reinterpret_cast<int*>(g->lb_int_buf.p);
     g->lb_Sp = Sp; g->lb_m = m;
 }
 
