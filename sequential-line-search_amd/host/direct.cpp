@@ -25,79 +25,172 @@ namespace sequential_line_search
     {
         namespace
         {
-            struct Rect
+            // 3^(-2 l) and 3^-(l + 1), tabulated once with the calls the untabulated code made (same values): the selection step
+            // needs every rectangle's size (1600 rectangles x 32 dimensions in sequential_line_search_nd: std::pow was most of the
+            // 1.9 ms DIRECT once spent on the host)
+            struct Pow3
             {
-                std::vector<double>        c;       // centre in the unit cube
-                std::vector<unsigned char> level;   // trisections per dimension: side_i = 3^-level_i
-                double                     g;       // value to MINIMISE (= -f)
+                double m2[256], m1[256];
+                Pow3()
+                {
+                    for (int l = 0; l < 256; ++l)
+                    {
+                        m2[l] = std::pow(3.0, -2.0 * l);
+                        m1[l] = std::pow(3.0, -(l + 1.0));
+                    }
+                }
             };
-
-            // 3^(-2 l), tabulated once: the selection step asks for every rectangle's size in every iteration (1600 rectangles x 32
-            // dimensions x 11 iterations in sequential_line_search_nd: std::pow was most of the 1.9 ms DIRECT spent on the host)
-            const double* Pow3m2()
+            const Pow3& Tables()
             {
-                static const std::vector<double> t = [] {
-                    std::vector<double> v(256);
-                    for (int l = 0; l < 256; ++l) v[l] = std::pow(3.0, -2.0 * l);
-                    return v;
-                }();
-                return t.data();
-            }
-            double HalfDiagonal(const Rect& r)
-            {
-                const double* t = Pow3m2();
-                double        s = 0.0;
-                for (unsigned char l : r.level) s += t[l];
-                return 0.5 * std::sqrt(s);
+                static const Pow3 t;
+                return t;
             }
 
             // keys: size classes are identified by the sorted multiset of levels; the half diagonal is a function of it.
             // Rounded to 12 significant digits so that equal multisets compare equal whatever the summation order.
             long long SizeKey(double d) { return std::llround(std::log(d) * 1e9); }
+
+            // The rectangles, structure-of-arrays (round 4: one Rect object with two heap vectors per rectangle, sizes recomputed and
+            // looked up in a std::map for every rectangle in every iteration, fresh vectors for every sample: 0.76 ms of host time
+            // per 1600-evaluation run at D = 32 where the device needs 0.13 ms for the evaluations; same trajectory, see
+            // tools/probes/direct_bench.cpp).  A rectangle's half diagonal and size class are computed when its levels change.
+            struct Rects
+            {
+                size_t                     n = 0;
+                std::vector<double>        c;       // [rect][n] centre in the unit cube
+                std::vector<unsigned char> level;   // [rect][n] trisections per dimension: side_i = 3^-level_i
+                std::vector<double>        g;       // value to MINIMISE (= -f)
+                std::vector<double>        diag;    // half diagonal
+                std::vector<int>           cls;     // size class id
+                std::map<long long, int>   cls_of_key;
+                size_t                     size() const { return g.size(); }
+                void                       Resize(size_t r) { diag.resize(r); cls.resize(r); }
+                void                       Classify(size_t r)
+                {
+                    const double*        t = Tables().m2;
+                    const unsigned char* l = level.data() + r * n;
+                    double               s = 0.0;
+                    for (size_t i = 0; i < n; ++i) s += t[l[i]];
+                    const double d = 0.5 * std::sqrt(s);
+                    diag[r]        = d;
+                    const auto ins = cls_of_key.emplace(SizeKey(d), static_cast<int>(cls_of_key.size()));
+                    cls[r]         = ins.first->second;
+                }
+                // copy of rectangle `src` (as it is now) with centre coordinate i moved by `shift` and value `value`; like = none:
+                // classify it, else: it has the levels, and therefore the size and class, of rectangle `like`
+                size_t Child(size_t src, size_t i, double shift, double value, size_t like)
+                {
+                    const size_t r = size();
+                    c.insert(c.end(), c.begin() + src * n, c.begin() + (src + 1) * n);
+                    level.insert(level.end(), level.begin() + src * n, level.begin() + (src + 1) * n);
+                    c[r * n + i] += shift;
+                    g.push_back(value);
+                    Resize(r + 1);
+                    if (like == static_cast<size_t>(-1)) Classify(r);
+                    else
+                    {
+                        diag[r] = diag[like];
+                        cls[r]  = cls[like];
+                    }
+                    return r;
+                }
+                void Clear(size_t dims)
+                {
+                    n = dims;
+                    c.clear(); level.clear(); g.clear(); diag.clear(); cls.clear(); cls_of_key.clear();
+                }
+            };
         } // namespace
 
         std::vector<double> DirectMaximize(const BatchObjective& f, const std::vector<double>& lower, const std::vector<double>& upper,
                                            int max_evals, double* best_value, int* evals_used)
         {
-            const size_t n = lower.size();
-            auto to_box = [&](const std::vector<double>& u) {
-                std::vector<double> x(n);
+            const size_t n      = lower.size();
+            const Pow3&  tables = Tables();
+            auto         to_box = [&](const double* u, std::vector<double>& x) {
+                x.resize(n);
                 for (size_t i = 0; i < n; ++i) x[i] = lower[i] + u[i] * (upper[i] - lower[i]);
-                return x;
             };
-            std::vector<Rect> rects;
-            int               evals = 0;
+            // storage kept between calls (per thread; a run touches ~0.5 MB at D = 32, 1600 evaluations); an objective that itself
+            // runs DIRECT on this thread gets storage of its own
+            thread_local Rects                            kept_rects;
+            thread_local std::vector<std::vector<double>> kept_xs, kept_spare;
+            thread_local bool                             kept_in_use = false;
+            const bool                                    own = kept_in_use;
+            Rects                                         own_rects;
+            std::vector<std::vector<double>>              own_xs, own_spare;
+            struct Release
             {
-                Rect r0;
-                r0.c.assign(n, 0.5);
-                r0.level.assign(n, 0);
-                std::vector<double> v;
-                f({to_box(r0.c)}, v);
-                r0.g = -v[0];
-                if (!std::isfinite(r0.g)) r0.g = std::numeric_limits<double>::max();
-                rects.push_back(r0);
+                bool* flag;
+                ~Release() { if (flag) *flag = false; }
+            } release{own ? nullptr : &kept_in_use};
+            if (!own) kept_in_use = true;
+            Rects& rects = own ? own_rects : kept_rects;
+            rects.Clear(n);
+            {
+                const size_t cap = static_cast<size_t>(std::max(max_evals, 1)) + 1;
+                rects.c.reserve(cap * n); rects.level.reserve(cap * n); rects.g.reserve(cap); rects.diag.reserve(cap); rects.cls.reserve(cap);
+            }
+            // sample points of an iteration: the vectors are kept and refilled (the batch interface wants a vector of vectors)
+            std::vector<std::vector<double>>& xs    = own ? own_xs : kept_xs;
+            std::vector<std::vector<double>>& spare = own ? own_spare : kept_spare;
+            auto                              next_x = [&]() -> std::vector<double>& {
+                if (spare.empty()) xs.emplace_back();
+                else
+                {
+                    xs.push_back(std::move(spare.back()));
+                    spare.pop_back();
+                }
+                return xs.back();
+            };
+            auto recycle_xs = [&]() {
+                while (!xs.empty())
+                {
+                    spare.push_back(std::move(xs.back()));
+                    xs.pop_back();
+                }
+            };
+            std::vector<double> vals;
+            int                 evals = 0;
+            recycle_xs();
+            {
+                rects.c.assign(n, 0.5);
+                rects.level.assign(n, 0);
+                to_box(rects.c.data(), next_x());
+                f(xs, vals);
+                double g0 = -vals[0];
+                if (!std::isfinite(g0)) g0 = std::numeric_limits<double>::max();
+                rects.g.push_back(g0);
+                rects.Resize(1);
+                rects.Classify(0);
                 evals = 1;
             }
             size_t best = 0;
+            // scratch of the iterations
+            struct Job { size_t rect, first, dims_begin, dims_end; };
+            std::vector<Job>                       jobs;
+            std::vector<size_t>                    job_dims, class_best, hull, order;
+            std::vector<std::pair<double, size_t>> pts;   // (size, rect), ascending size
+            std::vector<double>                    up, gp, gm, w;
+            const size_t                           none = std::numeric_limits<size_t>::max();
             while (evals < max_evals)
             {
-                // --- potentially optimal rectangles ---
-                std::map<long long, size_t> cls;   // size class -> index of its best rectangle (first one on ties)
+                // --- potentially optimal rectangles: the best rectangle of every size class (first one on ties) ---
+                class_best.assign(rects.cls_of_key.size(), none);
                 for (size_t i = 0; i < rects.size(); ++i)
                 {
-                    const long long k  = SizeKey(HalfDiagonal(rects[i]));
-                    auto            it = cls.find(k);
-                    if (it == cls.end()) cls[k] = i;
-                    else if (rects[i].g < rects[it->second].g) it->second = i;
+                    size_t& b = class_best[rects.cls[i]];
+                    if (b == none || rects.g[i] < rects.g[b]) b = i;
                 }
-                std::vector<std::pair<double, size_t>> pts;   // (size, rect), ascending size
-                for (const auto& kv : cls) pts.emplace_back(HalfDiagonal(rects[kv.second]), kv.second);
+                pts.clear();
+                for (size_t b : class_best)
+                    if (b != none) pts.emplace_back(rects.diag[b], b);
                 std::sort(pts.begin(), pts.end());
                 // start at the class holding the overall best value (largest such class), hull towards larger sizes
                 size_t start = 0;
                 for (size_t k = 0; k < pts.size(); ++k)
-                    if (rects[pts[k].second].g <= rects[pts[start].second].g) start = k;
-                std::vector<size_t> hull;   // indices into pts
+                    if (rects.g[pts[k].second] <= rects.g[pts[start].second]) start = k;
+                hull.clear();   // indices into pts
                 for (size_t k = start; k < pts.size(); ++k)
                 {
                     while (hull.size() >= 2)
@@ -106,8 +199,8 @@ namespace sequential_line_search
                         const auto& b = pts[hull.back()];
                         const auto& c = pts[k];
                         // b is above the chord a-c  ->  not on the lower hull
-                        const double cross = (b.first - a.first) * (rects[c.second].g - rects[a.second].g) -
-                                             (rects[b.second].g - rects[a.second].g) * (c.first - a.first);
+                        const double cross = (b.first - a.first) * (rects.g[c.second] - rects.g[a.second]) -
+                                             (rects.g[b.second] - rects.g[a.second]) * (c.first - a.first);
                         if (cross <= 0.0) hull.pop_back();
                         else break;
                     }
@@ -116,43 +209,50 @@ namespace sequential_line_search
                     hull.push_back(k);
                 }
                 // --- samples of this iteration (one batch) ---
-                struct Job { size_t rect; std::vector<size_t> dims; size_t first; };
-                std::vector<Job>                 jobs;
-                std::vector<std::vector<double>> xs;
+                jobs.clear();
+                job_dims.clear();
+                recycle_xs();
                 for (size_t hk : hull)
                 {
-                    const size_t ri = pts[hk].second;
-                    const Rect&  r  = rects[ri];
-                    unsigned char lmin = 255;
-                    for (unsigned char l : r.level) lmin = std::min(lmin, l);
+                    const size_t         ri = pts[hk].second;
+                    const unsigned char* lv = rects.level.data() + ri * n;
+                    unsigned char        lmin = 255;
+                    for (size_t i = 0; i < n; ++i) lmin = std::min(lmin, lv[i]);
                     if (lmin >= 30) continue;   // side 3^-30: nothing left to resolve
                     Job job;
-                    job.rect  = ri;
-                    job.first = xs.size();
+                    job.rect       = ri;
+                    job.first      = xs.size();
+                    job.dims_begin = job_dims.size();
                     for (size_t i = 0; i < n; ++i)
-                        if (r.level[i] == lmin) job.dims.push_back(i);
-                    const int need = 2 * static_cast<int>(job.dims.size());
-                    if (evals + static_cast<int>(xs.size()) + need > max_evals) break;   // the budget is a cap
-                    const double delta = std::pow(3.0, -(lmin + 1.0));
-                    for (size_t i : job.dims)
+                        if (lv[i] == lmin) job_dims.push_back(i);
+                    job.dims_end   = job_dims.size();
+                    const int need = 2 * static_cast<int>(job.dims_end - job.dims_begin);
+                    if (evals + static_cast<int>(xs.size()) + need > max_evals)   // the budget is a cap
                     {
-                        std::vector<double> up = r.c, dn = r.c;
-                        up[i] += delta;
-                        dn[i] -= delta;
-                        xs.push_back(to_box(up));
-                        xs.push_back(to_box(dn));
+                        job_dims.resize(job.dims_begin);
+                        break;
+                    }
+                    const double  delta = tables.m1[lmin];
+                    const double* cc    = rects.c.data() + ri * n;
+                    for (size_t d = job.dims_begin; d < job.dims_end; ++d)
+                    {
+                        const size_t i = job_dims[d];
+                        up.assign(cc, cc + n);
+                        up[i] = cc[i] + delta;
+                        to_box(up.data(), next_x());
+                        up[i] = cc[i] - delta;
+                        to_box(up.data(), next_x());
                     }
                     jobs.push_back(job);
                 }
                 if (jobs.empty()) break;
-                std::vector<double> vals;
                 f(xs, vals);
                 evals += static_cast<int>(xs.size());
                 // --- trisect ---
                 for (const Job& job : jobs)
                 {
-                    const size_t        m = job.dims.size();
-                    std::vector<double> gp(m), gm(m), w(m);
+                    const size_t m = job.dims_end - job.dims_begin;
+                    gp.resize(m); gm.resize(m); w.resize(m);
                     for (size_t k = 0; k < m; ++k)
                     {
                         gp[k] = -vals[job.first + 2 * k];
@@ -161,28 +261,28 @@ namespace sequential_line_search
                         if (!std::isfinite(gm[k])) gm[k] = std::numeric_limits<double>::max();
                         w[k] = std::min(gp[k], gm[k]);
                     }
-                    std::vector<size_t> order(m);
+                    order.resize(m);
                     std::iota(order.begin(), order.end(), 0);
                     std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return w[a] < w[b]; });
-                    const unsigned char lmin  = rects[job.rect].level[job.dims[0]];
-                    const double        delta = std::pow(3.0, -(lmin + 1.0));
+                    const unsigned char lmin  = rects.level[job.rect * n + job_dims[job.dims_begin]];
+                    const double        delta = tables.m1[lmin];
                     for (size_t k : order)
                     {
-                        const size_t i = job.dims[k];
-                        rects[job.rect].level[i] += 1;
-                        Rect up = rects[job.rect], dn = rects[job.rect];
-                        up.c[i] += delta; up.g = gp[k];
-                        dn.c[i] -= delta; dn.g = gm[k];
-                        rects.push_back(up);
-                        rects.push_back(dn);
+                        const size_t i = job_dims[job.dims_begin + k];
+                        rects.level[job.rect * n + i] += 1;
+                        const size_t first = rects.Child(job.rect, i, delta, gp[k], none);
+                        rects.Child(job.rect, i, -delta, gm[k], first);
                     }
+                    rects.Classify(job.rect);   // the parent has shrunk
                 }
                 for (size_t i = 0; i < rects.size(); ++i)
-                    if (rects[i].g < rects[best].g) best = i;
+                    if (rects.g[i] < rects.g[best]) best = i;
             }
-            if (best_value) *best_value = -rects[best].g;
+            if (best_value) *best_value = -rects.g[best];
             if (evals_used) *evals_used = evals;
-            return to_box(rects[best].c);
+            std::vector<double> x;
+            to_box(rects.c.data() + best * n, x);
+            return x;
         }
     } // namespace optim
 } // namespace sequential_line_search
