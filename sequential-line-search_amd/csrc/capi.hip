@@ -427,9 +427,26 @@ struct sls_gp {
     double* zc_host = nullptr;
     double* zc_dev = nullptr;
     size_t zc_bytes = 0;
+    // page-locked staging of host-supplied query points and their results (predict / acquisition entry points on the tiled path):
+    // uploads and downloads are truly asynchronous, one synchronisation per call (pageable buffers: blocking staged copies, a
+    // synchronisation behind each, and a fresh 0.5 MB temporary per transfer)
+    double* io_host = nullptr;
+    size_t io_bytes = 0;
+    double* io_stage(size_t doubles) {
+        if (doubles * 8 > io_bytes) {
+            if (io_host) {
+                (void)hipStreamSynchronize(ctx->stream);   // an upload from the old block may still be in flight (growth is rare)
+                ctx->host_give(io_host, io_bytes, false);
+            }
+            io_host = nullptr;
+            io_host = static_cast<double*>(ctx->host_take(doubles * 8, false, &io_bytes));
+        }
+        return io_host;
+    }
     ~sls_gp() {   // sls_gp_destroy holds the context's lock
         if (sum_host) ctx->host_give(sum_host, sum_bytes, true);
         if (zc_host) ctx->host_give(zc_host, zc_bytes, true);
+        if (io_host) ctx->host_give(io_host, io_bytes, false);
     }
 };
 
@@ -703,8 +720,9 @@ static bool tri_predict() {
     return !e || atoi(e) != 0;
 }
 
-// xr: raw candidate coordinates, candidate-major xr[n + d*ldr], S candidates.
-static void eval_candidates(sls_gp* g, const double* xr, long ldr, int S, const EvalOut& o) {
+// xr: raw candidate coordinates, S candidates: candidate-major xr[n + d*ldr], or (point_major) xr[d + n*D] as the host hands them
+// over (the device transposes: prep_kernel<false>, same arithmetic and same bits as the candidate-major form).
+static void eval_candidates(sls_gp* g, const double* xr, long ldr, int S, const EvalOut& o, bool point_major = false) {
     sls_ctx* c = g->ctx;
     const int Np = g->Np, N = g->N, D = g->D;
     const bool want_grad = o.dmu || o.dsigma || o.grad;
@@ -723,7 +741,8 @@ static void eval_candidates(sls_gp* g, const double* xr, long ldr, int S, const 
         double* cw_part = kw_part + (size_t)2 * nbt * ldk;
         {
             ProfScope ps(c, "cross_gram");
-            launch_prep_cands(c->stream, xr + s0, ldr, D, sc, g->inv_ell.p, g->XsT.p, ldk, Sp, g->Dcols, g->ns.p);
+            if (point_major) launch_prep_points(c->stream, xr + (size_t)s0 * D, D, sc, g->inv_ell.p, g->XsT.p, ldk, Sp, g->Dcols, g->ns.p);
+            else launch_prep_cands(c->stream, xr + s0, ldr, D, sc, g->inv_ell.p, g->XsT.p, ldk, Sp, g->Dcols, g->ns.p);
             launch_cross_gram(c->stream, g->XsT.p, ldk, g->ns.p, Sp, g->XT.p, Np, g->nx.p, Np, N, g->Dp, ks, g->alpha.p, g->Ks.p, Cs,
                               ldk, mu_part, ca_part);
         }
@@ -812,6 +831,10 @@ static void upload_candidates(sls_gp* g, const double* Xs, int M, DBuf& raw, int
     sync(c);
 }
 
+// Up to this many doubles of query points / results go through the handle's page-locked staging block (32 MB); larger calls take
+// the plain (pageable, blocking) copies.
+static const size_t IO_STAGE_MAX = (size_t)4 << 20;
+
 // evaluate M host-supplied query points (D x M column-major) into the candidate-major device outputs of `o`
 static void eval_host_points(sls_gp* g, const double* Xs, int M, int Mp, const EvalOut& o) {
     sls_ctx* c = g->ctx;
@@ -822,21 +845,51 @@ static void eval_host_points(sls_gp* g, const double* Xs, int M, int Mp, const E
         h2d(c, g->raw.p, Xs, (size_t)g->D * M);
         if (eval_small(g, g->raw.p, M, o)) return;
     }
+    const size_t n = (size_t)g->D * M;
+    const char* senv = getenv("SLS_IO_STAGE");   // 0: the transposing pageable upload of rounds 1-3 (A/B, tests)
+    if (n <= IO_STAGE_MAX && (!senv || atoi(senv) != 0)) {
+        // as handed over (point-major), through page-locked memory: no transposition on the host, no synchronisation behind the upload
+        double* st = g->io_stage(n);
+        std::memcpy(st, Xs, n * sizeof(double));
+        g->raw.ensure(n);
+        h2d(c, g->raw.p, st, n);
+        eval_candidates(g, g->raw.p, 0, M, o, true);
+        return;
+    }
     upload_candidates(g, Xs, M, g->raw, Mp);
     eval_candidates(g, g->raw.p, Mp, M, o);
 }
 
-static void download_cm(sls_gp* g, const double* dev, int M, int Mp, int rows, double* host /* rows x M col-major or M */) {
+// Results back to the host: up to two candidate-major device arrays (rows x Mp each; rows = 1: a vector, rows = D: transposed into
+// D x M column-major) with ONE synchronisation, through the page-locked staging block when they fit.
+static void download_cm2(sls_gp* g, const double* devA, double* hostA, const double* devB, double* hostB, int M, int Mp, int rows) {
     sls_ctx* c = g->ctx;
-    std::vector<double> t((size_t)Mp * rows);
-    d2h(c, t.data(), dev, (size_t)Mp * rows);
-    sync(c);
-    if (rows == 1) {
-        std::copy(t.begin(), t.begin() + M, host);
-    } else {
-        for (int m = 0; m < M; ++m)
-            for (int d = 0; d < rows; ++d) host[d + (size_t)m * rows] = t[(size_t)m + (size_t)d * Mp];
+    const size_t each = (size_t)Mp * rows;
+    const int cnt = (hostA ? 1 : 0) + (hostB ? 1 : 0);
+    if (cnt == 0) return;
+    std::vector<double> pageable;
+    double* t;
+    if (each * cnt <= IO_STAGE_MAX) t = g->io_stage(each * cnt);
+    else {
+        pageable.resize(each * cnt);
+        t = pageable.data();
     }
+    double* tA = t;
+    double* tB = hostA ? t + each : t;
+    if (hostA) d2h(c, tA, devA, each);
+    if (hostB) d2h(c, tB, devB, each);
+    sync(c);
+    auto out = [&](const double* src, double* host) {
+        if (rows == 1) std::copy(src, src + M, host);
+        else
+            for (int m = 0; m < M; ++m)
+                for (int d = 0; d < rows; ++d) host[d + (size_t)m * rows] = src[(size_t)m + (size_t)d * Mp];
+    };
+    if (hostA) out(tA, hostA);
+    if (hostB) out(tB, hostB);
+}
+static void download_cm(sls_gp* g, const double* dev, int M, int Mp, int rows, double* host /* rows x M col-major or M */) {
+    download_cm2(g, dev, host, nullptr, nullptr, M, Mp, rows);
 }
 
 extern "C" int sls_gp_predict(sls_gp* g, const double* Xs, int M, double* mu, double* sigma) {
@@ -853,8 +906,7 @@ extern "C" int sls_gp_predict(sls_gp* g, const double* Xs, int M, double* mu, do
     EvalOut o;
     o.ldo = Mp; o.mu = g->outm.p; o.sigma = g->outs.p;
     eval_host_points(g, Xs, M, Mp, o);
-    if (mu) download_cm(g, g->outm.p, M, Mp, 1, mu);
-    if (sigma) download_cm(g, g->outs.p, M, Mp, 1, sigma);
+    download_cm2(g, g->outm.p, mu, g->outs.p, sigma, M, Mp, 1);
     SLS_CATCH
 }
 
@@ -872,8 +924,7 @@ extern "C" int sls_gp_predict_grad(sls_gp* g, const double* Xs, int M, double* d
     EvalOut o;
     o.ldo = Mp; o.dmu = g->outv.p; o.dsigma = g->outg.p;
     eval_host_points(g, Xs, M, Mp, o);
-    if (dmu) download_cm(g, g->outv.p, M, Mp, D, dmu);
-    if (dsigma) download_cm(g, g->outg.p, M, Mp, D, dsigma);
+    download_cm2(g, g->outv.p, dmu, g->outg.p, dsigma, M, Mp, D);
     SLS_CATCH
 }
 

@@ -48,7 +48,7 @@ def test_c2_fit_and_predict_budget(ctx, oracle):
     gp.close()
     record("budget", config="C2", fit_ms=fit, predict_ms=pred)
     assert fit <= 1.5, fit   # measured 0.86-0.87 once the tail of the fit was one launch writing into mapped host memory
-    assert pred <= 1.2, pred
+    assert pred <= 1.0, pred   # measured 0.34-0.35 with the page-locked staging of query points and results
 
 
 def test_factor_and_inverse_device_time_budget(oracle):
