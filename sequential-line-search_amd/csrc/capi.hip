@@ -376,6 +376,9 @@ static void d2h(sls_ctx* c, double* dst, const double* src, size_t n) {
     SLS_HIP(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
 }
 static void sync(sls_ctx* c) { SLS_HIP(hipStreamSynchronize(c->stream)); }
+// Up to this many doubles of query points / results / matrices go through a handle's page-locked staging block (32 MB); larger
+// transfers take the plain (pageable, blocking) copies.
+static const size_t IO_STAGE_MAX = (size_t)4 << 20;
 
 static void check_theta(const double* theta, int D) {
     SLS_REQUIRE(theta != nullptr, "theta is NULL");
@@ -663,18 +666,50 @@ extern "C" int sls_gp_get_matrix(sls_gp* g, int what, double* out) {
     SLS_REQUIRE(g && out, "sls_gp_get_matrix: NULL argument");
     sls_ctx* c = g->ctx;
     const int N = g->N, Np = g->Np;
+    // Up to Np = 2048 the padded matrix comes back as ONE contiguous copy into the handle's page-locked staging block and the N x N
+    // part is taken out on the host (a strided copy into pageable memory is executed row by row, blocking; the factor's upper
+    // triangle is cleared on the way out instead of by a device copy + launch).  PreferenceRegressor fetches K and L after every fit.
+    const bool staged = (size_t)Np * Np <= IO_STAGE_MAX;
+    auto fetch_staged = [&](const double* dev, bool lower_only) {
+        double* st = g->io_stage((size_t)Np * Np);
+        d2h(c, st, dev, (size_t)Np * Np);
+        sync(c);
+        for (int j = 0; j < N; ++j) {
+            const double* col = st + (size_t)j * Np;
+            double* o = out + (size_t)j * N;
+            if (lower_only) {
+                std::fill(o, o + std::min(j, N), 0.0);
+                std::copy(col + j, col + N, o + j);
+            } else {
+                std::copy(col, col + N, o);
+            }
+        }
+    };
     switch (what) {
         case SLS_GP_K_Y: {
             // m_K_y is not kept resident (the Cholesky factor overwrites it): rebuild the full symmetric matrix
             DBuf K;
             K.ensure((size_t)Np * Np);
             launch_gram_sym(c->stream, g->XT.p, Np, g->Dp, g->nx.p, Np, N, KernelSpec{g->kernel, g->a}, g->b, K.p, false);
-            d2h_matrix(c, out, K.p, N, Np);
-            sync(c);
+            if (staged) fetch_staged(K.p, false);
+            else {
+                d2h_matrix(c, out, K.p, N, Np);
+                sync(c);
+            }
             break;
         }
-        case SLS_GP_K_Y_INV: d2h_matrix(c, out, g->Kinv.p, N, Np); sync(c); break;
+        case SLS_GP_K_Y_INV:
+            if (staged) fetch_staged(g->Kinv.p, false);
+            else {
+                d2h_matrix(c, out, g->Kinv.p, N, Np);
+                sync(c);
+            }
+            break;
         case SLS_GP_CHOL_L: {
+            if (staged) {
+                fetch_staged(g->L.p, true);
+                break;
+            }
             DBuf T;
             T.ensure((size_t)Np * Np);
             SLS_HIP(hipMemcpyAsync(T.p, g->L.p, (size_t)Np * Np * 8, hipMemcpyDeviceToDevice, c->stream));
@@ -830,10 +865,6 @@ static void upload_candidates(sls_gp* g, const double* Xs, int M, DBuf& raw, int
     h2d(c, raw.p, t.data(), (size_t)Mp * D);
     sync(c);
 }
-
-// Up to this many doubles of query points / results go through the handle's page-locked staging block (32 MB); larger calls take
-// the plain (pageable, blocking) copies.
-static const size_t IO_STAGE_MAX = (size_t)4 << 20;
 
 // evaluate M host-supplied query points (D x M column-major) into the candidate-major device outputs of `o`
 static void eval_host_points(sls_gp* g, const double* Xs, int M, int Mp, const EvalOut& o) {
