@@ -199,6 +199,50 @@ def test_fused_inverse_inside_the_map_objective(oracle, N, D, monkeypatch):
     np.testing.assert_allclose(res["fused"][1], g0, rtol=1e-7, atol=1e-9 * np.abs(g0).max())
 
 
+def test_map_objective_handle_reused_with_changing_targets_and_query_staging(ctx, oracle, monkeypatch):
+    """A MAP-objective handle uploads its targets only when they differ from what the device holds, reads the length scales from and
+    writes its results into a mapped block it keeps: evaluations on ONE handle with y1, y2, y1 again, a value-only batch (which
+    uploads y past the staging block) and y2 once more must equal the same evaluations on fresh handles, bit for bit; likewise a
+    predict call on the page-locked staging path against SLS_IO_STAGE=0 (host transposition, pageable copies)."""
+    m = sls()
+    D, N = 6, 700
+    X, y1, theta, b = synth_problem(oracle, D, N)
+    y2 = y1[::-1].copy() * 1.5 + 0.1
+    x1 = np.concatenate([[0.6, 0.01], np.linspace(0.4, 0.9, D)])
+    x2 = x1 * 1.1
+    def fresh(y, x):
+        h = m.Nll(ctx, X, 1)
+        r = h.gp_objective(y, x)
+        h.close()
+        return r
+    want = {("y1", "x1"): fresh(y1, x1), ("y2", "x1"): fresh(y2, x1), ("y2", "x2"): fresh(y2, x2), ("y1", "x2"): fresh(y1, x2)}
+    ys, xs = {"y1": y1, "y2": y2}, {"x1": x1, "x2": x2}
+    h = m.Nll(ctx, X, 1)
+    def check(yk, xk):
+        v, g = h.gp_objective(ys[yk].copy(), xs[xk])       # a copy: the comparison is by content, not by address
+        assert v == want[(yk, xk)][0], (yk, xk)
+        np.testing.assert_array_equal(g, want[(yk, xk)][1])
+    check("y1", "x1"); check("y2", "x1")                    # same factor (cached), new targets
+    check("y2", "x2"); check("y1", "x2"); check("y1", "x1")
+    batch = h.gp_objective_batch(y2, np.stack([x1, x2]))     # uploads y2 without the staging block
+    np.testing.assert_allclose(batch, [want[("y2", "x1")][0], want[("y2", "x2")][0]], rtol=1e-9)
+    check("y1", "x2"); check("y2", "x2")
+    h.close()
+    # query points through the staging block vs the pageable path
+    M = 333
+    Xs = synth_candidates(oracle, D, M)
+    gp = m.GP(ctx, X, y1, theta, b, 1)
+    mu1, sd1 = gp.predict(Xs)
+    dm1, ds1 = gp.predict_grad(Xs)
+    monkeypatch.setenv("SLS_IO_STAGE", "0")
+    mu0, sd0 = gp.predict(Xs)
+    dm0, ds0 = gp.predict_grad(Xs)
+    monkeypatch.delenv("SLS_IO_STAGE")
+    gp.close()
+    for a_, b_ in ((mu1, mu0), (sd1, sd0), (dm1, dm0), (ds1, ds0)):
+        np.testing.assert_array_equal(a_, b_)
+
+
 def test_potrf_rejects_indefinite(ctx):
     A = np.eye(200)
     A[150, 150] = -1.0
