@@ -220,10 +220,14 @@ int main()
         EXPECT((s.original_end_0 - p).norm() == 0.0);
         EXPECT(std::abs(l1 - std::max(1.25 * l0, 0.25)) < 1e-9);   // interior segment: scale 1.25, then the minimum length 0.25
     }
-    // ---- preference regressor + full sequential line search loop: residual shrinks on the bump objective ----
+    // ---- preference regressor + full sequential line search loop: residual shrinks on the bump objective; with the
+    // constructor's default (use_map_hyperparams = true, sequential-line-search.hpp:37: the reference demo's setting) and with
+    // fixed hyper-parameters ----
+    for (const bool use_map : {true, false})
     {
         const int D = 4;
-        SequentialLineSearchOptimizer opt(D, true, false, KernelType::ArdMatern52Kernel);
+        utils::SetRandomSeed(7);
+        SequentialLineSearchOptimizer opt = use_map ? SequentialLineSearchOptimizer(D) : SequentialLineSearchOptimizer(D, true, false, KernelType::ArdMatern52Kernel);
         opt.SetHyperparams(0.5, 0.5, 0.001, 0.1, 0.01);
         auto objective = [](const VectorXd& x) {
             double qd = 0.0;
@@ -246,7 +250,7 @@ int main()
             EXPECT(opt.GetPreferenceValueStdev(opt.GetMaximizer()) >= 0.0);
             EXPECT(opt.GetAcquisitionFuncValue(opt.GetSliderEnds().second) >= 0.0);
         }
-        std::cout << "SLS D=4: objective at maximiser " << first << " -> " << last << std::endl;
+        std::cout << "SLS D=4 (use_map_hyperparams " << use_map << "): objective at maximiser " << first << " -> " << last << std::endl;
         EXPECT(last >= first - 1e-9);
         EXPECT(last > 0.9);
     }
@@ -282,7 +286,7 @@ int main()
     {
         const int D = 3;
         utils::SetRandomSeed(11);
-        PreferentialBayesianOptimizer pbo(D, false);
+        PreferentialBayesianOptimizer pbo(D);   // the default: joint MAP estimation of the hyper-parameters
         pbo.SetHyperparams(0.5, 0.5, 0.001, 0.1, 0.01);
         auto objective = [](const VectorXd& x) {
             double qd = 0.0;

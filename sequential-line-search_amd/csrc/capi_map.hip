@@ -25,6 +25,7 @@ struct sls_nll {
     sls_ctx* ctx = nullptr;
     int D = 0, N = 0, Np = 0, Dp = 0, Dcols = 0, kernel = 0;
     DBuf X, y, XT, nx, L, Linv, Kinv, alpha, G, Y, svec, parts, gemv_part, small_in, small_out, small_info;
+    DBuf XTr, small_kc;   // one-workgroup path (N <= 128): the raw design matrix transposed [i + d * 128]; pair scratch of the gradient
     std::vector<double> cached_theta;
     double cached_b = -1.0;
     bool have_factor = false;
@@ -83,6 +84,14 @@ extern "C" int sls_nll_create(sls_ctx* ctx, const double* X, int D, int N, int k
     // results (res_stage): [0..2] sums, [4] log|K_y|, [5..6] the factorisation's two info words, [8..] length-scale gradient
     h->gemv_part.ensure((Np / 128) * Np);
     SLS_HIP(hipMemcpyAsync(h->X.p, X, (size_t)D * N * 8, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<double> xtr;   // must outlive the synchronisation below
+    if (N <= NLL_SMALL_MAX_N && D <= NLL_SMALL_MAX_D) {
+        xtr.assign((size_t)128 * D, 0.0);
+        for (int i = 0; i < N; ++i)
+            for (int d = 0; d < D; ++d) xtr[i + (size_t)d * 128] = X[d + (size_t)i * D];
+        h->XTr.ensure(xtr.size());
+        SLS_HIP(hipMemcpyAsync(h->XTr.p, xtr.data(), xtr.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
     launch_fill(ctx->stream, h->y.p, Np, 0.0);
     SLS_HIP(hipStreamSynchronize(ctx->stream));
     slsk::ctx_retain(ctx);
@@ -167,9 +176,8 @@ static int nll_y_chunks(int nt, int ncols) {
 }
 
 // N <= 128: the whole evaluation is one single-workgroup launch (kernels_small.hip); SLS_NLL_SMALL=0 forces the tiled path
-static bool nll_small_ok(const sls_nll* h, bool want_theta_grad) {
-    if (h->N > NLL_SMALL_MAX_N) return false;
-    if (want_theta_grad && h->D > NLL_SMALL_MAX_GRAD_D) return false;
+static bool nll_small_ok(const sls_nll* h) {
+    if (h->N > NLL_SMALL_MAX_N || h->D > NLL_SMALL_MAX_D) return false;
     const char* e = getenv("SLS_NLL_SMALL");
     return !e || atoi(e) != 0;
 }
@@ -182,15 +190,17 @@ static void nll_small_eval(sls_nll* h, const double* y, const double* theta, dou
     for (int d = 0; d < D; ++d) SLS_REQUIRE(theta[1 + d] > 0.0, "length scale %d must be positive", d);
     const bool want_grad = grad_theta || grad_b;
     NllSmallArgs args;
-    args.X = h->X.p; args.D = D; args.N = N; args.want_grad = want_grad ? 1 : 0;
+    args.X = h->X.p; args.XTr = h->XTr.p; args.D = D; args.N = N; args.want_grad = want_grad ? 1 : 0;
+    if (want_grad) h->small_kc.ensure(NLL_SMALL_KC_DOUBLES);
+    args.kc = h->small_kc.p;
     args.info = c->d_info;
     const char* zc_env = getenv("SLS_SMALL_ZEROCOPY");   // read per call, like the other A/B switches
     const bool zero_copy = zc_env ? atoi(zc_env) != 0 : true;
     if (zero_copy && !h->small_host) {
-        h->small_host = static_cast<double*>(c->host_take(160 * sizeof(double), true, &h->small_host_bytes));
+        h->small_host = static_cast<double*>(c->host_take(NLL_SMALL_OUT_DOUBLES * sizeof(double), true, &h->small_host_bytes));
         SLS_HIP(hipHostGetDevicePointer((void**)&h->small_host_dev, h->small_host, 0));
     }
-    h->small_out.ensure(160);
+    h->small_out.ensure(NLL_SMALL_OUT_DOUBLES);
     args.out = zero_copy ? h->small_host_dev : h->small_out.p;
     args.in_dev = nullptr;
     args.batch = 1; args.in_stride = 0; args.out_stride = 0;
@@ -209,9 +219,9 @@ static void nll_small_eval(sls_nll* h, const double* y, const double* theta, dou
         args.in_dev = h->small_in.p;
     }
     launch_nll_small(c->stream, h->kernel, args);
-    double out_stack[160];
+    double out_stack[NLL_SMALL_OUT_DOUBLES];
     const double* out = out_stack;
-    const int nout = alpha ? 32 + N : 32;
+    const int nout = alpha ? NLL_SMALL_OUT_ALPHA + N : NLL_SMALL_OUT_ALPHA;
     if (zero_copy) {
         SLS_HIP(hipStreamSynchronize(c->stream));
         out = h->small_host;
@@ -230,9 +240,9 @@ static void nll_small_eval(sls_nll* h, const double* y, const double* theta, dou
     if (grad_b) *grad_b = out[1];
     if (grad_theta) {
         grad_theta[0] = out[0] / theta[0];
-        for (int d = 0; d < D; ++d) grad_theta[1 + d] = out[8 + d];
+        for (int d = 0; d < D; ++d) grad_theta[1 + d] = out[NLL_SMALL_OUT_GL + d];
     }
-    if (alpha) std::memcpy(alpha, out + 32, sizeof(double) * N);
+    if (alpha) std::memcpy(alpha, out + NLL_SMALL_OUT_ALPHA, sizeof(double) * N);
 }
 
 static void nll_eval_impl(sls_nll* h, const double* y, const double* theta, double b, double* quad, double* logdet,
@@ -241,7 +251,7 @@ static void nll_eval_impl(sls_nll* h, const double* y, const double* theta, doub
     const int D = h->D, N = h->N, Np = h->Np;
     SLS_REQUIRE(y && theta, "sls_nll_eval: NULL argument");
     SLS_REQUIRE(b >= 0.0, "noise level must be >= 0");
-    if (nll_small_ok(h, grad_theta != nullptr)) {
+    if (nll_small_ok(h)) {
         nll_small_eval(h, y, theta, b, quad, logdet, alpha, grad_theta, grad_b);
         return;
     }
@@ -395,7 +405,7 @@ extern "C" int sls_gp_nll_batch(sls_nll* h, const double* y, const double* xs, i
         SLS_REQUIRE(x[0] > 0.0 && x[1] >= 0.0, "sls_gp_nll_batch: signal variance must be positive, noise level >= 0 (point %d)", k);
         for (int d = 0; d < D; ++d) SLS_REQUIRE(x[2 + d] > 0.0, "length scale %d must be positive (point %d)", d, k);
     }
-    if (!nll_small_ok(h, false)) {
+    if (!nll_small_ok(h)) {
         // N > 128: bordered factorisations (quad and log-det from the factor alone: no inverse), several parameter sets per
         // persistent launch, each on its own share of the chip -- one factorisation of this size is bound by its serial chain and
         // leaves most CUs idle.  SLS_NLL_BATCH=0: one full evaluation after the other (the round-3 path).
@@ -474,11 +484,11 @@ extern "C" int sls_gp_nll_batch(sls_nll* h, const double* y, const double* xs, i
         std::memcpy(o + 2 + D, y, sizeof(double) * N);
     }
     h->small_in.ensure(in.size());
-    h->small_out.ensure(std::max<size_t>(160, (size_t)B * out_stride));
+    h->small_out.ensure(std::max<size_t>(NLL_SMALL_OUT_DOUBLES, (size_t)B * out_stride));
     h->small_info.ensure(((size_t)B + 1) / 2 + 1);
     SLS_HIP(hipMemcpyAsync(h->small_in.p, in.data(), in.size() * 8, hipMemcpyHostToDevice, c->stream));
     NllSmallArgs args;
-    args.X = h->X.p; args.D = D; args.N = N; args.want_grad = 0;
+    args.X = h->X.p; args.XTr = h->XTr.p; args.kc = nullptr; args.D = D; args.N = N; args.want_grad = 0;
     args.info = reinterpret_cast<int*>(h->small_info.p);
     args.out = h->small_out.p; args.in_dev = h->small_in.p;
     args.batch = B; args.in_stride = (long)in_stride; args.out_stride = (long)out_stride;
@@ -505,11 +515,10 @@ struct MapOptProblem {
     int n_prefs = 0;
 };
 
-// N <= 128 (one LDS image), D <= 128 (1/l in the LDS scratch), hyper-parameter gradients for D <= 16 (small_grad);
+// N <= 128 (one LDS image), D <= 128 (1/l, l and the length-scale gradient in the LDS scratch), with or without hyper-parameters;
 // SLS_MAP_DEVICE=0 forces the host-driven optimiser / the host's BTL terms (A/B and tests)
-static bool map_opt_supported(const sls_nll* h, int nh) {
-    if (h->N > NLL_SMALL_MAX_N || h->D > 128) return false;
-    if (nh > 0 && h->D > NLL_SMALL_MAX_GRAD_D) return false;
+static bool map_opt_supported(const sls_nll* h) {
+    if (h->N > NLL_SMALL_MAX_N || h->D > NLL_SMALL_MAX_D) return false;
     const char* e = getenv("SLS_MAP_DEVICE");
     return !e || atoi(e) != 0;
 }
@@ -561,7 +570,7 @@ static void map_opt_run(sls_nll* h, const MapOptProblem& pb, const double* z0, c
         if (h->mo_idx.p != before) h->mo_idx_host.clear();   // a new block: what the old one held is gone
     }
     h->mo_vec.ensure(vec_doubles);
-    h->mo_state.ensure(MAP_OPT_STATE_DOUBLES + 8);   // + the optional section trace
+    h->mo_state.ensure(MAP_OPT_STATE_DOUBLES + MAP_OPT_TRACE_SLOTS);   // + the optional section trace
     h->mo_btl.ensure(std::max(F, 1));
     // the previous call's copies have completed (every call ends with a stream synchronisation): the staging block is free
     double* vst = reinterpret_cast<double*>(h->mo_stage);
@@ -578,7 +587,8 @@ static void map_opt_run(sls_nll* h, const MapOptProblem& pb, const double* z0, c
         h->mo_idx_host = idx;
     }
     MapOptArgs a;
-    a.X = h->X.p; a.D = D; a.N = N; a.ny = pb.ny; a.nh = pb.nh; a.log_hyper = pb.log_hyper; a.noiseless = pb.noiseless;
+    if (pb.nh > 0) h->small_kc.ensure(NLL_SMALL_KC_DOUBLES);
+    a.X = h->X.p; a.XTr = h->XTr.p; a.kc = h->small_kc.p; a.D = D; a.N = N; a.ny = pb.ny; a.nh = pb.nh; a.log_hyper = pb.log_hyper; a.noiseless = pb.noiseless;
     a.y_fixed = h->mo_vec.p + 3 * n;
     a.a0 = pb.a0; a.b0 = pb.b0; a.r0 = pb.r0;
     a.mu_a = pb.mu_a; a.mu_b = pb.mu_b; a.mu_r = pb.mu_r; a.s2_a = pb.s2_a; a.s2_b = pb.s2_b; a.s2_r = pb.s2_r;
@@ -596,7 +606,7 @@ static void map_opt_run(sls_nll* h, const MapOptProblem& pb, const double* z0, c
     a.trace = nullptr;
     if (getenv("SLS_MAP_TRACE") && !eval_only) {
         a.trace = reinterpret_cast<long long*>(h->mo_state.p + MAP_OPT_STATE_DOUBLES);
-        SLS_HIP(hipMemsetAsync(a.trace, 0, 8 * sizeof(long long), c->stream));
+        SLS_HIP(hipMemsetAsync(a.trace, 0, MAP_OPT_TRACE_SLOTS * sizeof(long long), c->stream));
     }
     const bool stepwise = !eval_only && evals_per_launch > 0 && evals_per_launch < max_evals;
     a.budget = stepwise ? evals_per_launch : a.max_evals;
@@ -609,10 +619,11 @@ static void map_opt_run(sls_nll* h, const MapOptProblem& pb, const double* z0, c
         a.fresh = 0;
     }
     if (a.trace) {
-        long long tr[8];
+        long long tr[MAP_OPT_TRACE_SLOTS];
         SLS_HIP(hipMemcpy(tr, a.trace, sizeof(tr), hipMemcpyDeviceToHost));
-        fprintf(stderr, "map_opt trace (us): N %d n %d prefs %d evals %lld | publish+factor %.1f  alpha %.1f  hyper-grad %.1f  btl %.1f  "
-                "value+gradient %.1f  optimiser %.1f  total %.1f\n", N, n, P, tr[6], tr[0] * 0.01, tr[1] * 0.01, tr[2] * 0.01, tr[3] * 0.01,
+        fprintf(stderr, "map_opt trace (us): N %d n %d prefs %d evals %lld | publish %.1f  gram %.1f  chol %.1f  logdet %.1f  inverse %.1f  "
+                "alpha %.1f  grad-weights %.1f  grad-contraction %.1f  btl %.1f  value+gradient %.1f  optimiser %.1f  total %.1f\n", N, n, P, tr[6],
+                tr[0] * 0.01, tr[8] * 0.01, tr[9] * 0.01, tr[10] * 0.01, tr[11] * 0.01, tr[1] * 0.01, tr[12] * 0.01, tr[13] * 0.01, tr[3] * 0.01,
                 tr[4] * 0.01, tr[5] * 0.01, tr[7] * 0.01);
     }
     h->have_factor = false;   // the tiled path's cached factor (L, Linv, Kinv buffers) was not refreshed
@@ -649,8 +660,8 @@ extern "C" int sls_pref_map_fit(sls_nll* h, const unsigned* prefs_flat, const in
     }
     SLS_REQUIRE(h && cfg && z0 && lower && upper && z_out && max_evals >= 1 && (n_prefs == 0 || (prefs_flat && pref_offsets)),
                 "sls_pref_map_fit: bad argument");
-    if (!map_opt_supported(h, cfg->use_map_hyperparams ? h->D + 2 : 0)) {
-        set_error("sls_pref_map_fit: N = %d, D = %d outside the device-resident optimiser (N <= 128; D <= 16 with hyper-parameters)", h->N, h->D);
+    if (!map_opt_supported(h)) {
+        set_error("sls_pref_map_fit: N = %d, D = %d outside the device-resident optimiser (N <= 128, D <= 128)", h->N, h->D);
         return SLS_ERR_UNSUPPORTED;
     }
     const MapOptProblem pb = pref_problem(h, prefs_flat, pref_offsets, n_prefs, cfg, true);
@@ -667,8 +678,8 @@ extern "C" int sls_gp_map_fit(sls_nll* h, const double* y, const double* z0, con
         (void)hipSetDevice(h->ctx->device);
     }
     SLS_REQUIRE(h && y && z0 && lower && upper && z_out && max_evals >= 1, "sls_gp_map_fit: bad argument");
-    if (!map_opt_supported(h, h->D + 2)) {
-        set_error("sls_gp_map_fit: N = %d, D = %d outside the device-resident optimiser (N <= 128, D <= 16)", h->N, h->D);
+    if (!map_opt_supported(h)) {
+        set_error("sls_gp_map_fit: N = %d, D = %d outside the device-resident optimiser (N <= 128, D <= 128)", h->N, h->D);
         return SLS_ERR_UNSUPPORTED;
     }
     MapOptProblem pb;
@@ -706,7 +717,7 @@ extern "C" int sls_pref_objective(sls_nll* h, const unsigned* prefs_flat, const 
     SLS_REQUIRE(h && x && cfg && (n_prefs == 0 || (prefs_flat && pref_offsets)), "sls_pref_objective: NULL argument");
     const int D = h->D, M = h->N;
     const bool use_map = cfg->use_map_hyperparams != 0;
-    if (map_opt_supported(h, use_map ? D + 2 : 0)) {
+    if (map_opt_supported(h)) {
         // one single-workgroup launch: BTL terms, GP term, priors and the whole gradient on the device (eval_only mode)
         if (use_map) {
             SLS_REQUIRE(x[M] > 0.0, "signal variance must be positive");

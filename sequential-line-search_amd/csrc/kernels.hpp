@@ -57,15 +57,22 @@ void launch_cross_gram(hipStream_t s, const double* XsT, long lds_, const double
                        long ldk, double* mu_part, double* ca_part);
 
 // ---- kernels_small.hip ---------------------------------------------------------
-// Whole MAP-objective evaluation for N <= 128 in one single-workgroup launch.  Inputs a, b, l_1..l_D, y_1..y_N travel in
-// the kernel argument block (D <= 16) or in in_dev = [a, b, l.., y..] (device).  out (device, 160 doubles):
-// [0] sum W.*K_f, [1] d/db, [2] y^T alpha, [3] logdet, [4] potrf info, [8..8+D) d/dl (only if want_grad and
-// D <= NLL_SMALL_MAX_GRAD_D), [32..32+N) alpha.  X: raw D x N column-major design matrix (device).
+// Whole MAP-objective evaluation for N <= 128, D <= 128 in one single-workgroup launch.  Inputs a, b, l_1..l_D, y_1..y_N travel
+// in the kernel argument block (D <= 32) or in in_dev = [a, b, l.., y..] (device).  out (device, NLL_SMALL_OUT_DOUBLES):
+// [0] sum W.*K_f, [1] d/db, [2] y^T alpha, [3] logdet, [4] potrf info, [8..8+D) d/dl (only if want_grad),
+// [136..136+N) alpha.  X: raw D x N column-major design matrix (device); XTr: its transpose [i + d * 128] (device);
+// kc (want_grad only): 2 x 128 x 128 doubles of scratch per launch (kernel values and derivative weights of the pairs, written by
+// the Gram pass and read back by the gradient pass of the same workgroup).
 constexpr int NLL_SMALL_MAX_N = 128;
-constexpr int NLL_SMALL_MAX_GRAD_D = 16;
+constexpr int NLL_SMALL_MAX_D = 128;
 constexpr int NLL_SMALL_MAX_ARG_D = 32;    // up to here the length scales travel in the kernel argument block (no upload)
+constexpr int NLL_SMALL_OUT_GL = 8, NLL_SMALL_OUT_ALPHA = 8 + NLL_SMALL_MAX_D, NLL_SMALL_OUT_DOUBLES = NLL_SMALL_OUT_ALPHA + NLL_SMALL_MAX_N;
+constexpr size_t NLL_SMALL_KC_DOUBLES = 2 * 128 * 128;
 struct NllSmallArgs {
     const double* X;
+    const double* XTr;
+    double* kc;
+    int x_lds = 1;            // 0: never stage the design matrix in LDS (A/B and tests: both paths agree to rounding)
     int D, N, want_grad;
     int* info;
     double* out;
@@ -83,13 +90,14 @@ void launch_nll_small(hipStream_t s, int kernel, const NllSmallArgs& args);
 // Whole fit of a GP handle for N <= 128 (Np = 128) in one single-workgroup launch (gp_fit_small_kernel): every output of
 // gp_fit_device (capi.hip).  All pointers device; matrices 128 x 128 column-major, XT / XaT [i + d * 128] with Dcols columns.
 struct GpFitSmallArgs {
-    const double *X, *y, *inv_ell;   // X: raw D x N column-major
+    const double *X, *y, *inv_ell;   // X: raw D x N column-major (its transpose passes through XaT before alpha o X~ lands there)
     int D, N, Dcols;
     double a, b;
     double *XT, *nx, *XaT, *L, *Linv, *U, *Kinv, *alpha, *mu_data, *scal;   // scal[0] = max_i mu(x_i), scal[1] = log|K_y|
     long* d_idx;                     // first arg max of mu over the data points
     int* info;                       // 1 + index of the first non-positive pivot, or 0
     double* summary = nullptr;       // mapped host memory (or nullptr): [0] scal[0], [1] scal[1], [2] d_idx[0], [3] *info, [4] 0
+    int x_lds = 1;                   // as NllSmallArgs::x_lds
 };
 void launch_gp_fit_small(hipStream_t s, int kernel, const GpFitSmallArgs& args);
 
@@ -97,14 +105,19 @@ void launch_gp_fit_small(hipStream_t s, int kernel, const GpFitSmallArgs& args);
 // (optim::MaximizeBounded) with the objective evaluated in place -- the preference objective of
 // src/preference-regressor.cpp:129-259 (Bradley-Terry-Luce terms from a CSR / CSC image of m_D, GP term, log-normal priors)
 // or the GP marginal-likelihood objective of src/gaussian-process-regressor.cpp:141-193.
-// Variables z (n = ny + nh <= 192):  z[0..ny) = goodness values y (ny = N or 0: y fixed = y_fixed);  z[ny..ny+nh) = (a, b,
-// l_1..l_D) (nh = D + 2 or 0: fixed a0, b0, r0), logarithms if log_hyper.
-constexpr int MAP_OPT_MAX_VARS = 192;
+// Variables z (n = ny + nh <= 320: N <= 128 goodness values + D + 2 <= 130 hyper-parameters):  z[0..ny) = goodness values y
+// (ny = N or 0: y fixed = y_fixed);  z[ny..ny+nh) = (a, b, l_1..l_D) (nh = D + 2 or 0: fixed a0, b0, r0), logarithms if log_hyper.
+// The optimiser state lives in registers, 64 variables per register: 3 per lane up to 192 variables (C3: 91 + 34), 5 beyond.
+constexpr int MAP_OPT_MAX_VARS = 320;
 constexpr int MAP_OPT_HIST = 8;
+constexpr int MAP_OPT_TRACE_SLOTS = 16;
 constexpr int MAP_OPT_STATE_DOUBLES = (4 + 2 * MAP_OPT_HIST) * MAP_OPT_MAX_VARS + 32;
 constexpr int MAP_OPT_OUT_X = 8, MAP_OPT_OUT_G = 8 + MAP_OPT_MAX_VARS, MAP_OPT_OUT_DOUBLES = 8 + 2 * MAP_OPT_MAX_VARS;
 struct MapOptArgs {
     const double* X;          // D x N column-major design matrix (device)
+    const double* XTr;        // its transpose [i + d * 128] (device)
+    double* kc;               // NLL_SMALL_KC_DOUBLES of scratch (nh > 0)
+    int x_lds = 1;            // as NllSmallArgs::x_lds
     int D, N, ny, nh, log_hyper, noiseless;
     const double* y_fixed;    // device, N (ny == 0)
     double a0, b0, r0;        // fixed hyper-parameters (nh == 0)
@@ -121,10 +134,11 @@ struct MapOptArgs {
     int fresh;                // 1: start from z0; 0: continue from `state`
     double* state;            // MAP_OPT_STATE_DOUBLES (device): optimiser state, stored at the end of every launch
     double* out;              // MAP_OPT_OUT_DOUBLES: [0] objective at x, [1] evaluations used, [2] finished, [3] last pivot info,
-                              // [8 .. 8+n) x, [8+192 .. 8+192+n) gradient (eval_only)
+                              // [8 .. 8+n) x, [8+320 .. 8+320+n) gradient (eval_only)
     int* info;
-    // optional (SLS_MAP_TRACE=1, probes): ticks of the 100 MHz clock thread 0 spent in [0] publishing the trial point + factorisation,
-    // [1] alpha, [2] hyper-parameter gradient, [3] BTL terms, [4] value + gradient slots, [5] optimiser, [6] evaluations, [7] kernel
+    // optional (SLS_MAP_TRACE=1, probes): MAP_OPT_TRACE_SLOTS ticks of the 100 MHz clock thread 0 spent in [0] publishing the trial
+    // point, [8] Gram, [9] Cholesky, [10] log-det, [11] inverse, [1] alpha, [12] gradient weights, [13] length-scale contraction,
+    // [3] BTL terms, [4] value + gradient slots, [5] optimiser, [6] evaluations, [7] kernel
     long long* trace;
 };
 void launch_map_opt(hipStream_t s, int kernel, const MapOptArgs& args);

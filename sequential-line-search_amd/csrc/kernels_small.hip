@@ -17,14 +17,15 @@
 
 namespace slsk {
 
-constexpr int SMALL_OUT_GL = 8;        // out[8 .. 8+D): length-scale gradient (D <= NLL_SMALL_MAX_GRAD_D)
-constexpr int SMALL_OUT_ALPHA = 32;    // out[32 .. 32+N): alpha
-
 // scratch map (2048 doubles in the padding rows of the LDS matrix):
-//   [0,128) alpha   [128,256) y   [256,384) 1/l   [384,1024) BTL contributions (map_opt)   [1024,1028) reduction slots
-//   [1028,1032) a, b (map_opt)    [1040,1056) l (map_opt)   [1296,1552) gradient wrt the optimiser's variables (map_opt)
+//   [0,128) alpha   [128,256) y   [256,384) 1/l   [384,1024) BTL contributions (map_opt) / the four waves' partial length-scale
+//   gradients (small_grad)   [1024,1028) reduction slots   [1028,1032) a, b (map_opt)   [1040,1168) l (map_opt)
+//   [1168,1296) length-scale gradient   [1296,1616) gradient wrt the optimiser's variables (map_opt)
+//   [1616,1744) squared norms of the scaled points
+//   [1872,2002) logarithms of a, b, l (map_opt)
 constexpr int SC_ALPHA = 0, SC_Y = 128, SC_INVL = 256, SC_BTL = 384, SC_BTL_MAX = 640, SC_RED = 1024, SC_AB = 1028,
-              SC_ELL = 1040, SC_GZ = 1296;
+              SC_ELL = 1040, SC_GL = 1168, SC_GZ = 1296, SC_NX = 1616, SC_LZ = 1872;
+static_assert(SC_GZ + MAP_OPT_MAX_VARS <= SC_NX && SC_LZ + 2 + NLL_SMALL_MAX_D <= 2048 && 4 * NLL_SMALL_MAX_D <= SC_BTL_MAX, "LDS scratch map");
 
 __device__ __forceinline__ double& small_scratch(double* As, int k) { return As[(k >> 4) * DL + 128 + (k & 15)]; }
 
@@ -35,6 +36,21 @@ __device__ __forceinline__ double small_block_sum(double v, double* As) {
     __syncthreads();
     return (small_scratch(As, SC_RED) + small_scratch(As, SC_RED + 1)) + (small_scratch(As, SC_RED + 2) + small_scratch(As, SC_RED + 3));
 }
+
+// optional section timing (SLS_MAP_TRACE=1): ticks of the 100 MHz clock per section, thread-private
+struct SmallTrace {
+    bool on = false;
+    long long t_prev = 0;
+    long long tr[MAP_OPT_TRACE_SLOTS] = {};
+    __device__ __forceinline__ void start() { if (on) t_prev = wall_clock64(); }
+    __device__ __forceinline__ void mark(int slot) {
+        if (on) {
+            const long long t_now = wall_clock64();
+            tr[slot] += t_now - t_prev;
+            t_prev = t_now;
+        }
+    }
+};
 
 template <bool MATERN>
 __device__ __forceinline__ void small_kern(double a, double q, double& k, double& c) {
@@ -48,10 +64,82 @@ __device__ __forceinline__ void small_kern(double a, double q, double& k, double
     }
 }
 
-__device__ __forceinline__ double small_pair_q(const double* __restrict__ X, int D, int i, int j, double* As) {
+// Where the design matrix is read from.  A single CU with one wave per SIMD cannot hide global-memory latency (measured: ~0.5 us
+// per dependent round trip) and even an LDS-resident copy read once per pair and dimension is bound by the LDS bandwidth (three
+// 512-byte reads per fused multiply-add), so whenever the N x N image leaves enough of the LDS block unused -- the columns right
+// of the leading Nb = 16 ceil(N / 16) ones -- the CENTRED design matrix x - 0.5 is staged there once per launch and the Gram
+// matrix and the length-scale gradient run on the matrix cores in the forms of the tiled pipeline (kernels_gram.hip,
+// kernels_map.hip):
+//     q_ij = |x~_i|^2 + |x~_j|^2 - 2 x~_i . x~_j,   x~ = (x - 0.5) / l      (one operand fragment scaled by 1 / l_d^2 on the fly)
+//     dL/dl_p = (2 / l_p) sum_j x~_jp (x~_jp s_j - Y_jp),   Y = G X~,  s = G 1,  G = 1/2 W o C  (zero diagonal)
+// Layout: point i, dimension d at offset d + i Dp of the free area, Dp = 16 ceil(D / 16) + 1, zero padded to Nb points and Dp - 1
+// dimensions: both fragment shapes (16 lanes over points, stride Dp odd; 16 lanes over dimensions, contiguous) are conflict free.
+// C3's shapes (N <= 96 at D = 32) always fit.  Otherwise the differences are formed directly: the Gram pass reads the transposed
+// copy XTr[i + d * 128] (the 16 rows of a tile are 128 contiguous bytes per dimension) and the length-scale contraction the
+// D x N original (a point's D values are contiguous).
+struct SmallPts {
+    const double* __restrict__ X;
+    const double* __restrict__ XTr;
+    int lds, base_col, Dp;
+    // the pair scratch of the gradient (kernel values and derivative weights of the lower tiles, tile t element e at t * 256 + e,
+    // e = 16 (j - 16 tj) + (i - 16 ti)) behind the points when that fits too: stash_off = its offset in the free area, or -1
+    int stash_off;
+};
+// element o of the free area (the columns right of the leading base_col ones, 128 rows each)
+__device__ __forceinline__ double& small_free(double* As, int base_col, int o) { return As[(base_col + (o >> 7)) * DL + (o & 127)]; }
+struct PtsLds {
+    const double* As;
+    int base_col, Dp;
+    __device__ __forceinline__ double operator()(int i, int d) const {
+        const int o = d + i * Dp;
+        return As[(base_col + (o >> 7)) * DL + (o & 127)];
+    }
+};
+struct PtsRows {   // XTr[i + d * 128]
+    const double* __restrict__ XTr;
+    __device__ __forceinline__ double operator()(int i, int d) const { return XTr[i + d * 128]; }
+};
+struct PtsCols {   // X[d + i * D]
+    const double* __restrict__ X;
+    int D;
+    __device__ __forceinline__ double operator()(int i, int d) const { return X[d + (long)i * D]; }
+};
+// all threads; the caller's next barrier publishes the copy
+__device__ __forceinline__ SmallPts small_pts_stage(double* As, const double* __restrict__ X, const double* __restrict__ XTr, int D, int N,
+                                                    bool allow) {
+    SmallPts p{X, XTr, 0, 16 * ((N + 15) >> 4), 16 * ((D + 15) >> 4) + 1, -1};
+    const int Nb = p.base_col, nb16 = Nb >> 4;
+    if (!allow || Nb * p.Dp > (128 - Nb) * 128) return p;
+    p.lds = 1;
+    if (Nb * p.Dp + nb16 * (nb16 + 1) * 256 <= (128 - Nb) * 128) p.stash_off = Nb * p.Dp;   // 2 arrays x nb16 (nb16 + 1) / 2 tiles
+    for (int o = threadIdx.x; o < Nb * p.Dp; o += 256) {
+        const int i = o / p.Dp, d = o - i * p.Dp;
+        As[(p.base_col + (o >> 7)) * DL + (o & 127)] = (i < N && d < D) ? X[d + (long)i * D] - 0.5 : 0.0;
+    }
+    return p;
+}
+
+// q_ij = sum_d ((x_id - x_jd) / l_d)^2 in dimension order, B dimensions' operands in flight at a time
+template <int B, class Pts>
+__device__ __forceinline__ double small_pair_q(const Pts& x, int D, int i, int j, double* As) {
     double q = 0.0;
-    for (int d = 0; d < D; ++d) {
-        const double t = (X[d + (long)i * D] - X[d + (long)j * D]) * small_scratch(As, SC_INVL + d);
+    int d = 0;
+    for (; d + B <= D; d += B) {
+        double xi[B], xj[B], il[B];
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+            xi[u] = x(i, d + u);
+            xj[u] = x(j, d + u);
+            il[u] = small_scratch(As, SC_INVL + d + u);
+        }
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+            const double t = (xi[u] - xj[u]) * il[u];
+            q = fma(t, t, q);
+        }
+    }
+    for (; d < D; ++d) {
+        const double t = (x(i, d) - x(j, d)) * small_scratch(As, SC_INVL + d);
         q = fma(t, t, q);
     }
     return q;
@@ -59,33 +147,104 @@ __device__ __forceinline__ double small_pair_q(const double* __restrict__ X, int
 
 // K_y = K_f(a, l) + b I into the LDS image (1/l in the scratch) and its Cholesky factorisation on the leading ceil(N/16) blocks: L in the
 // lower triangle of As, L^-T in its strictly-upper tiles, the inverses of the diagonal tiles in Ts.  Returns sum_i log L_ii.
+// kc != nullptr: the kernel values k_ij and the derivative weights c_ij of the pairs i > j are left in kc[i + j * 128] /
+// kc[128 * 128 + i + j * 128] for small_grad (same workgroup: visible behind the barriers in between).
 template <bool MATERN>
-__device__ __forceinline__ double small_build_factor(double* As, double* Ts, const double* __restrict__ X, int D, int N,
-                                                     double a, double b, int* __restrict__ info) {
+__device__ __forceinline__ double small_build_factor(double* As, double* Ts, const SmallPts& pts, int D, int N,
+                                                     double a, double b, int* __restrict__ info, double* __restrict__ kc, SmallTrace& st) {
     const int tid = threadIdx.x;
-    const int nb16 = (N + 15) >> 4, Nb = 16 * nb16;
-    // ---- K_y (lower triangle + full diagonal tiles), identity padding up to the next multiple of 16 ----
-    for (int idx = tid; idx < Nb * Nb; idx += 256) {
-        const int i = idx % Nb, j = idx / Nb;
-        if (i < j) continue;
-        double v;
-        if (i >= N) v = (i == j) ? 1.0 : 0.0;
-        else if (i == j) v = a + b;
-        else {
-            double k, c;
-            small_kern<MATERN>(a, small_pair_q(X, D, i, j, As), k, c);
-            v = k;
+    const int nb16 = (N + 15) >> 4;
+    // ---- K_y, one 16 x 16 tile per pass (lower tiles; diagonal tiles in full), identity padding up to the next multiple of 16 ----
+    auto gram = [&](auto&& pair_q) {
+        const int r = tid & 15, cc = tid >> 4;
+        for (int tj = 0; tj < nb16; ++tj)
+            for (int ti = tj; ti < nb16; ++ti) {
+                const int i = 16 * ti + r, j = 16 * tj + cc;
+                double v;
+                if (i >= N || j >= N) v = (i == j) ? 1.0 : 0.0;
+                else if (i == j) v = a + b;
+                else {
+                    double k, c;
+                    small_kern<MATERN>(a, pair_q(i, j), k, c);
+                    v = k;
+                    if (kc && i > j) {
+                        kc[i + j * 128] = k;
+                        if (MATERN) kc[128 * 128 + i + j * 128] = c;
+                    }
+                }
+                As[i + j * DL] = v;
+            }
+    };
+    if (pts.lds) {
+        // matrix-core form: squared norms (thread i), then one 16 x 16 tile of dot products per wave and pass
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fl = lane & 15, fk = lane >> 4;
+        const PtsLds xc{As, pts.base_col, pts.Dp};
+        if (tid < 16 * nb16) {
+            double n = 0.0;
+            for (int d = 0; d < D; ++d) {
+                const double t = xc(tid, d) * small_scratch(As, SC_INVL + d);
+                n = fma(t, t, n);
+            }
+            small_scratch(As, SC_NX + tid) = n;
         }
-        As[i + j * DL] = v;
-        if ((i >> 4) == (j >> 4)) As[j + i * DL] = v;
-    }
+        __syncthreads();
+        const int Dk = pts.Dp - 1;
+        int t = 0;
+        for (int tj = 0; tj < nb16; ++tj)
+            for (int ti = tj; ti < nb16; ++ti, ++t) {
+                if ((t & 3) != wave) continue;
+                d4_t acc = {0.0, 0.0, 0.0, 0.0};
+                for (int d0 = 0; d0 < Dk; d0 += 16) {
+                    double af[4], bf[4];
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const int d = d0 + 4 * kk + fk;
+                        const double il = d < D ? small_scratch(As, SC_INVL + d) : 0.0;
+                        af[kk] = xc(16 * ti + fl, d) * (il * il);
+                        bf[kk] = xc(16 * tj + fl, d);
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) acc = mfma16(bf[kk], af[kk], acc);
+                }
+                const int i = 16 * ti + fl;
+                const double ni = small_scratch(As, SC_NX + i);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int j = 16 * tj + fk + 4 * q;
+                    double v;
+                    if (i >= N || j >= N) v = (i == j) ? 1.0 : 0.0;
+                    else if (i == j) v = a + b;
+                    else {
+                        double qq = ni + small_scratch(As, SC_NX + j) - 2.0 * acc[q];
+                        qq = qq < 0.0 ? 0.0 : qq;
+                        double k, c;
+                        small_kern<MATERN>(a, qq, k, c);
+                        v = k;
+                        if (kc && i > j) {
+                            if (pts.stash_off >= 0) {
+                                const int e = pts.stash_off + 256 * t + 16 * (fk + 4 * q) + fl;
+                                small_free(As, pts.base_col, e) = k;
+                                if (MATERN) small_free(As, pts.base_col, e + 128 * nb16 * (nb16 + 1)) = c;
+                            } else {
+                                kc[i + j * 128] = k;
+                                if (MATERN) kc[128 * 128 + i + j * 128] = c;
+                            }
+                        }
+                    }
+                    As[i + j * DL] = v;
+                }
+            }
+    } else gram([&](int i, int j) { return small_pair_q<8>(PtsRows{pts.XTr}, D, i, j, As); });
     __syncthreads();
+    st.mark(8);
 
     chol_diag_steps<true>(As, Ts, info, 0, nb16);
     __syncthreads();
+    st.mark(9);
 
     // ---- log det ----
     const double ld = small_block_sum(tid < N ? log(As[tid + tid * DL]) : 0.0, As);
+    st.mark(10);
     return ld;
 }
 
@@ -103,13 +262,15 @@ __device__ __forceinline__ void small_inverse_in_place(double* As, double* Ts, i
                 if ((t & 3) != wave) continue;
                 d4_t c = {0.0, 0.0, 0.0, 0.0};
                 for (int k = i; k < nb16; ++k) {
+                    double af[4], bf[4];   // the eight fragment reads of a block in flight together (the sum keeps its order)
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) {
                         const int kq = 4 * kk + fk;
-                        const double af = (k == i) ? Ts[256 * i + kq + 16 * fl] : As[(16 * k + kq) * DL + 16 * i + fl];   // T[k][i] (kq, m)
-                        const double bf = (k == j) ? Ts[256 * j + kq + 16 * fl] : As[(16 * k + kq) * DL + 16 * j + fl];   // T[k][j] (kq, n)
-                        c = mfma16(bf, af, c);
+                        af[kk] = (k == i) ? Ts[256 * i + kq + 16 * fl] : As[(16 * k + kq) * DL + 16 * i + fl];   // T[k][i] (kq, m)
+                        bf[kk] = (k == j) ? Ts[256 * j + kq + 16 * fl] : As[(16 * k + kq) * DL + 16 * j + fl];   // T[k][j] (kq, n)
                     }
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) c = mfma16(bf[kk], af[kk], c);
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) As[(16 * j + fk + 4 * q) * DL + 16 * i + fl] = c[q];
@@ -136,10 +297,11 @@ __device__ __forceinline__ void small_inverse_in_place(double* As, double* Ts, i
 // K_y = K_f(a, l) + b I into the LDS image (1/l in the scratch), Cholesky + inverse on the leading ceil(N/16) blocks,
 // K_y^-1 as a full symmetric image over the dead factor.  Returns sum_i log L_ii (= logdet / 2) in every thread.
 template <bool MATERN>
-__device__ __forceinline__ double small_factor_inverse(double* As, double* Ts, const double* __restrict__ X, int D, int N,
-                                                       double a, double b, int* __restrict__ info) {
-    const double ld = small_build_factor<MATERN>(As, Ts, X, D, N, a, b, info);
+__device__ __forceinline__ double small_factor_inverse(double* As, double* Ts, const SmallPts& pts, int D, int N,
+                                                       double a, double b, int* __restrict__ info, double* __restrict__ kc, SmallTrace& st) {
+    const double ld = small_build_factor<MATERN>(As, Ts, pts, D, N, a, b, info, kc, st);
     small_inverse_in_place(As, Ts, N);
+    st.mark(11);
     return ld;
 }
 
@@ -176,46 +338,181 @@ __device__ __forceinline__ void small_alpha(double* As, int N, double& gb, doubl
     quad = small_block_sum(s2, As);
 }
 
-// gradient contractions over the pairs i >= j:  sa = sum W.*K_f,  gl[d] = (1/l_d) sum W_ij c_ij (x~_id - x~_jd)^2 (d < D <= 16)
+// Gradient contractions over the pairs i >= j with W = alpha alpha^T - K^-1 (src/gaussian-process-regressor.cpp:66-127 without
+// the (D + 1) N x N tensor of src/regressor.cpp:110-134):
+//   returns  sa = sum W.*K_f;  leaves  gl[d] = (1 / l_d) sum_{i>j} W_ij c_ij ((x_id - x_jd) / l_d)^2  in the scratch (SC_GL + d), d < D <= 128.
+// Two passes.  (1) one pair per thread, tile by tile like the Gram pass: w, sa, and G_ij = w c_ij into the MIRROR position (j, i) of
+// the image -- K^-1 is symmetric and nothing reads its upper triangle after small_alpha.  (2) lanes over the DIMENSIONS: a wave
+// takes whole rows i (dealt 0 1 2 3 3 2 1 0 over the waves), 64 / LP pairs of a row per step with LP = min(64, 2^ceil(log2 D))
+// lanes each (two dimensions per lane for D > 64), four steps' loads in flight; the point coordinates come from the D x N original
+// (a pair's D values are contiguous), G from LDS.  The per-wave partial sums are added over the lanes of a dimension by xor
+// butterflies and over the waves as (w0 + w1) + (w2 + w3): one fixed order.
 template <bool MATERN>
-__device__ __forceinline__ void small_grad(double* As, const double* __restrict__ X, int D, int N, double a, bool want_grad,
-                                           double& sa_t, double (&gl_t)[NLL_SMALL_MAX_GRAD_D]) {
-    const int tid = threadIdx.x;
+__device__ __forceinline__ double small_grad(double* As, const SmallPts& pts, const double* __restrict__ kc, int D, int N,
+                                             double a, bool want_grad, SmallTrace& st) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb16 = (N + 15) >> 4;
+    const bool mm = pts.lds != 0;   // matrix-core form: G = 1/2 W o C as a full symmetric matrix with zero diagonal over K^-1
     double sa = 0.0;
-    double gl[NLL_SMALL_MAX_GRAD_D];
-#pragma unroll
-    for (int d = 0; d < NLL_SMALL_MAX_GRAD_D; ++d) gl[d] = 0.0;
     if (want_grad) {
-        for (int idx = tid; idx < N * N; idx += 256) {
-            const int i = idx % N, j = idx / N;
-            if (i < j) continue;
-            const double w = (i == j ? 0.5 : 1.0) * (small_scratch(As, SC_ALPHA + i) * small_scratch(As, SC_ALPHA + j) - As[i + j * DL]);
-            double q = 0.0, dd[NLL_SMALL_MAX_GRAD_D];
+        // the pair scratch comes back from global memory: the loads of four tiles are issued together (every address is inside the
+        // 2 x 128 x 128 block, unused values are discarded by the selects below)
+        const int r = tid & 15, cc = tid >> 4;
+        constexpr int TB = 4;
+        for (int tj = 0, tcol = 0; tj < nb16; tcol += nb16 - tj, ++tj)   // tcol: index of tile (tj, tj) in the Gram pass's order
+            for (int ti0 = tj; ti0 < nb16; ti0 += TB) {
+                const int j = 16 * tj + cc;
+                double kv[TB], cv[TB];
 #pragma unroll
-            for (int d = 0; d < NLL_SMALL_MAX_GRAD_D; ++d) {
-                dd[d] = 0.0;
-                if (d < D) {
-                    const double t = (X[d + (long)i * D] - X[d + (long)j * D]) * small_scratch(As, SC_INVL + d);
-                    dd[d] = t * t;
-                    q += dd[d];
+                for (int u = 0; u < TB; ++u) {
+                    if (pts.stash_off >= 0) {   // LDS: any element of the free area may be read
+                        const int e = pts.stash_off + 256 * min(tcol + ti0 + u - tj, nb16 * (nb16 + 1) / 2 - 1) + tid;
+                        kv[u] = small_free(As, pts.base_col, e);
+                        cv[u] = MATERN ? small_free(As, pts.base_col, e + 128 * nb16 * (nb16 + 1)) : 0.0;
+                    } else {
+                        const int i = min(16 * (ti0 + u) + r, 127);
+                        kv[u] = kc[i + j * 128];
+                        cv[u] = MATERN ? kc[128 * 128 + i + j * 128] : 0.0;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < TB; ++u) {
+                    const int i = 16 * (ti0 + u) + r;
+                    if (ti0 + u >= nb16 || i < j || i >= 16 * nb16) continue;
+                    if (i >= N) {   // padding rows of the last block: no weight
+                        if (mm) As[i + j * DL] = As[j + i * DL] = 0.0;
+                        continue;
+                    }
+                    const double w = (i == j ? 0.5 : 1.0) * (small_scratch(As, SC_ALPHA + i) * small_scratch(As, SC_ALPHA + j) - As[i + j * DL]);
+                    if (i == j) {
+                        sa = fma(w, a, sa);
+                        if (mm) As[i + i * DL] = 0.0;
+                    } else {
+                        sa = fma(w, kv[u], sa);
+                        const double g = w * (MATERN ? cv[u] : kv[u]);
+                        if (mm) As[i + j * DL] = As[j + i * DL] = 0.5 * g;
+                        else As[j + i * DL] = g;
+                    }
                 }
             }
-            if (D > NLL_SMALL_MAX_GRAD_D) q = small_pair_q(X, D, i, j, As);   // length-scale gradient not requested for such D (host check)
-            if (i == j) q = 0.0;
-            double k, c;
-            small_kern<MATERN>(a, q, k, c);
-            sa = fma(w, k, sa);
-            const double g = w * c;
+    }
+    const double sa_t = small_block_sum(sa, As);   // its barriers publish G
+    st.mark(12);
+    if (!want_grad) return sa_t;
+
+    if (mm) {
+        const int fl = lane & 15, fk = lane >> 4;
+        const PtsLds xc{As, pts.base_col, pts.Dp};
+        // Y' = G (X - 0.5) tile by tile; lane (fl, fk) holds Y'(j = 16 tj + fl, p = 16 tp + fk + 4 q) and adds
+        // x_jp (x_jp s_j - Y'_jp) over the block rows tj of this wave (tj = wave, wave + 4); the 16 lanes of a row then hold the 16 j
+        // of a block.  s = G 1 comes out of the same fragments with the constant 1 as the other operand (first dimension tile only;
+        // every lane of row j receives s_j: no exchange).
+        const int ntp = (pts.Dp - 1) >> 4;
+        double sreg[2] = {0.0, 0.0};
+        for (int tp = 0; tp < ntp; ++tp) {
+            double part[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int d = 0; d < NLL_SMALL_MAX_GRAD_D; ++d) gl[d] = fma(g, dd[d], gl[d]);
+            for (int n = 0; n < 2; ++n) {
+                const int tj = wave + 4 * n;
+                if (tj >= nb16) break;
+                d4_t acc = {0.0, 0.0, 0.0, 0.0}, accs = {0.0, 0.0, 0.0, 0.0};
+                for (int k0 = 0; k0 < 16 * nb16; k0 += 16) {
+                    double af[4], bf[4];
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        af[kk] = As[(k0 + 4 * kk + fk) * DL + 16 * tj + fl];
+                        bf[kk] = xc(k0 + 4 * kk + fk, 16 * tp + fl);
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) acc = mfma16(bf[kk], af[kk], acc);
+                    if (tp == 0) {
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) accs = mfma16(1.0, af[kk], accs);
+                    }
+                }
+                if (tp == 0) sreg[n] = accs[0];
+                const int j = 16 * tj + fl;
+                const double sj = sreg[n];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double xv = xc(j, 16 * tp + fk + 4 * q);
+                    part[q] = fma(xv, fma(xv, sj, -acc[q]), part[q]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double v = row_sum(part[q]);
+                const int p = 16 * tp + fk + 4 * q;
+                if (fl == 0 && p < D) small_scratch(As, SC_BTL + wave * NLL_SMALL_MAX_D + p) = v;
+            }
+        }
+        __syncthreads();
+        if (tid < D) {
+            const double p = (small_scratch(As, SC_BTL + tid) + small_scratch(As, SC_BTL + NLL_SMALL_MAX_D + tid)) +
+                             (small_scratch(As, SC_BTL + 2 * NLL_SMALL_MAX_D + tid) + small_scratch(As, SC_BTL + 3 * NLL_SMALL_MAX_D + tid));
+            const double il = small_scratch(As, SC_INVL + tid);
+            small_scratch(As, SC_GL + tid) = 2.0 * il * (il * il) * p;
+        }
+        __syncthreads();
+        st.mark(13);
+        return sa_t;
+    }
+
+    int LP = 1;
+    while (LP < D && LP < 64) LP <<= 1;
+    const int PW = 64 / LP, dl = lane & (LP - 1), jj = lane / LP;
+    const bool wide = D > 64;
+    // lanes beyond D read dimension D - 1 and weigh it with 0
+    const int d0 = min(dl, D - 1), d1 = min(dl + 64, D - 1);
+    const bool v0 = dl < D, v1 = wide && dl + 64 < D;
+    const double il0 = v0 ? small_scratch(As, SC_INVL + d0) : 0.0, il1 = v1 ? small_scratch(As, SC_INVL + d1) : 0.0;
+    double acc0 = 0.0, acc1 = 0.0;
+    {
+        const PtsCols x{pts.X, D};
+        constexpr int U = 8;
+        for (int i = 1; i < N; ++i) {
+            const int r8 = i & 7;
+            if ((r8 < 4 ? r8 : 7 - r8) != wave) continue;
+            const double xi0 = x(i, d0), xi1 = wide ? x(i, d1) : 0.0;
+            for (int j0 = 0; j0 < i; j0 += U * PW) {
+                double gv[U], x0[U], x1[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int j = j0 + u * PW + jj, jc = min(j, i - 1);   // past the row's end: the last pair again, weight 0
+                    const double g = As[jc + i * DL];
+                    gv[u] = j < i ? g : 0.0;
+                    x0[u] = x(jc, d0);
+                    x1[u] = wide ? x(jc, d1) : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const double t0 = (xi0 - x0[u]) * il0;
+                    acc0 = fma(gv[u], t0 * t0, acc0);
+                    if (wide) {
+                        const double t1 = (xi1 - x1[u]) * il1;
+                        acc1 = fma(gv[u], t1 * t1, acc1);
+                    }
+                }
+            }
         }
     }
-    sa_t = small_block_sum(sa, As);
-#pragma unroll
-    for (int d = 0; d < NLL_SMALL_MAX_GRAD_D; ++d) {
-        gl_t[d] = 0.0;
-        if (want_grad && d < D) gl_t[d] = small_block_sum(gl[d], As) * small_scratch(As, SC_INVL + d);   // D uniform: all threads take part
+    for (int m = LP; m < 64; m <<= 1) {
+        acc0 += __shfl_xor(acc0, m);
+        if (wide) acc1 += __shfl_xor(acc1, m);
     }
+    if (jj == 0) {
+        if (v0) small_scratch(As, SC_BTL + wave * NLL_SMALL_MAX_D + dl) = acc0;
+        if (v1) small_scratch(As, SC_BTL + wave * NLL_SMALL_MAX_D + dl + 64) = acc1;
+    }
+    __syncthreads();
+    if (tid < D) {
+        const double p = (small_scratch(As, SC_BTL + tid) + small_scratch(As, SC_BTL + NLL_SMALL_MAX_D + tid)) +
+                         (small_scratch(As, SC_BTL + 2 * NLL_SMALL_MAX_D + tid) + small_scratch(As, SC_BTL + 3 * NLL_SMALL_MAX_D + tid));
+        small_scratch(As, SC_GL + tid) = p * small_scratch(As, SC_INVL + tid);
+    }
+    __syncthreads();
+    st.mark(13);
+    return sa_t;
 }
 
 template <bool MATERN>
@@ -235,20 +532,18 @@ __global__ __launch_bounds__(256) void nll_small_kernel(const NllSmallArgs args)
     for (int i = tid; i < 128; i += 256)
         small_scratch(As, SC_Y + i) = i < N ? (in_dev ? in_dev[2 + D + i] : args.y[i]) : 0.0;
     if (tid == 0) *info = 0;
+    const SmallPts pts = small_pts_stage(As, X, args.XTr, D, N, args.x_lds != 0);
     __syncthreads();
 
-    const double ld = small_factor_inverse<MATERN>(As, Ts, X, D, N, a, b, info);
+    double* __restrict__ kc = want_grad ? args.kc : nullptr;
+    SmallTrace st;
+    const double ld = small_factor_inverse<MATERN>(As, Ts, pts, D, N, a, b, info, kc, st);
     double gb, quad;
     small_alpha(As, N, gb, quad);
-    if (tid < N && args.batch <= 1) out[SMALL_OUT_ALPHA + tid] = small_scratch(As, SC_ALPHA + tid);   // batch mode: 8 output words per parameter set
-    double sa_t, gl_t[NLL_SMALL_MAX_GRAD_D];
-    small_grad<MATERN>(As, X, D, N, a, want_grad != 0, sa_t, gl_t);
+    if (tid < N && args.batch <= 1) out[NLL_SMALL_OUT_ALPHA + tid] = small_scratch(As, SC_ALPHA + tid);   // batch mode: 8 output words per parameter set
+    const double sa_t = small_grad<MATERN>(As, pts, kc, D, N, a, want_grad != 0, st);
+    if (want_grad && tid < D) out[NLL_SMALL_OUT_GL + tid] = small_scratch(As, SC_GL + tid);
     if (tid == 0) {
-        if (want_grad) {
-#pragma unroll
-            for (int d = 0; d < NLL_SMALL_MAX_GRAD_D; ++d)
-                if (d < D) out[SMALL_OUT_GL + d] = gl_t[d];
-        }
         out[0] = sa_t;
         out[1] = gb;
         out[2] = quad;
@@ -276,23 +571,24 @@ __global__ __launch_bounds__(256) void nll_small_kernel(const NllSmallArgs args)
 // `budget` < max_evals: the launch stops after `budget` evaluations and leaves the state in `state`; the next launch (fresh = 0)
 // continues from it with the same machine code -- the one-launch-per-evaluation form the tests compare the single launch with.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int KV = MAP_OPT_MAX_VARS / 64;
 constexpr int MH = MAP_OPT_HIST;
 
+template <int KV>
 __device__ __forceinline__ double wave_dot(const double (&u)[KV], const double (&v)[KV]) {
     double p = 0.0;
 #pragma unroll
     for (int k = 0; k < KV; ++k) p += u[k] * v[k];
     return wave_sum(p);
 }
-// mathtoolbox::GetLogOfLogNormalDist / ...Derivative
-__device__ __forceinline__ double dev_log_lognormal(double x, double mu, double s2) {
-    const double lx = log(x);
-    return -lx - 0.5 * log(2.0 * M_PI * s2) - (lx - mu) * (lx - mu) / (2.0 * s2);
+// mathtoolbox::GetLogOfLogNormalDist / ...Derivative with lx = log x supplied by the caller (the optimiser's
+// own variable when it runs in the logarithms) and hl = 1/2 log(2 pi s2) formed once per launch
+__device__ __forceinline__ double dev_log_lognormal(double lx, double mu, double s2, double hl) {
+    return -lx - hl - (lx - mu) * (lx - mu) / (2.0 * s2);
 }
-__device__ __forceinline__ double dev_log_lognormal_d(double x, double mu, double s2) { return (mu - s2 - log(x)) / (s2 * x); }
+__device__ __forceinline__ double dev_log_lognormal_d(double x, double lx, double mu, double s2) { return (mu - s2 - lx) / (s2 * x); }
 
-template <bool MATERN>
+// KV: optimiser variables per lane (64 KV >= n)
+template <bool MATERN, int KV>
 __global__ __launch_bounds__(256) void map_opt_kernel(const MapOptArgs args) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* As = reinterpret_cast<double*>(smem);
@@ -305,11 +601,11 @@ __global__ __launch_bounds__(256) void map_opt_kernel(const MapOptArgs args) {
     int* __restrict__ info = args.info;
     double* __restrict__ state = args.state;
     double* __restrict__ out = args.out;
-    long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const bool tracing = args.trace != nullptr;
-    const long long tr_begin = tracing ? wall_clock64() : 0;
-    long long t_prev = tr_begin;
-#define MAP_T(slot) do { if (tracing) { const long long t_now = wall_clock64(); tr[slot] += t_now - t_prev; t_prev = t_now; } } while (0)
+    SmallTrace st;
+    st.on = args.trace != nullptr;
+    const long long tr_begin = st.on ? wall_clock64() : 0;
+    st.t_prev = tr_begin;
+#define MAP_T(slot) st.mark(slot)
 
     // ---- optimiser state: one replica per wave ----
     double x[KV], g[KV], xt[KV], d[KV], lo[KV], hi[KV], S[MH][KV], Y[MH][KV], rho[MH];
@@ -353,6 +649,7 @@ __global__ __launch_bounds__(256) void map_opt_kernel(const MapOptArgs args) {
     if (nh == 0)
         for (int dd = tid; dd < D; dd += 256) small_scratch(As, SC_INVL + dd) = 1.0 / args.r0;
     if (tid == 0) *info = 0;
+    const SmallPts pts = small_pts_stage(As, X, args.XTr, D, N, args.x_lds != 0);
     // the first preference tuple of this thread and the first tuple memberships of data point `tid`: indices in registers
     constexpr int RC = 4;
     int po = 0, pm = 0, pidx0 = 0, pidx1 = 0, pidx2 = 0, pidx3 = 0, co = 0, cm = 0, cidx0 = 0, cidx1 = 0, cidx2 = 0, cidx3 = 0;
@@ -374,6 +671,7 @@ __global__ __launch_bounds__(256) void map_opt_kernel(const MapOptArgs args) {
     }
     __syncthreads();
 
+    const double hl_a = 0.5 * log(2.0 * M_PI * args.s2_a), hl_b = 0.5 * log(2.0 * M_PI * args.s2_b), hl_r = 0.5 * log(2.0 * M_PI * args.s2_r);
     bool have_factor = false, bad = false;
     double ld = 0.0, a = args.a0, b = args.noiseless ? 0.0 : args.b0;
     double f_last = 0.0;
@@ -389,6 +687,7 @@ __global__ __launch_bounds__(256) void map_opt_kernel(const MapOptArgs args) {
                 else if (e < n) {
                     const int hq = e - ny;
                     const double v = args.log_hyper ? exp(xt[k]) : xt[k];
+                    small_scratch(As, SC_LZ + hq) = args.log_hyper ? xt[k] : log(xt[k]);
                     if (hq == 0) small_scratch(As, SC_AB) = v;
                     else if (hq == 1) small_scratch(As, SC_AB + 1) = args.noiseless ? 0.0 : v;
                     else {
@@ -403,20 +702,19 @@ __global__ __launch_bounds__(256) void map_opt_kernel(const MapOptArgs args) {
             a = small_scratch(As, SC_AB);
             b = small_scratch(As, SC_AB + 1);
         }
+        MAP_T(0);
         if (nh || !have_factor) {
-            ld = small_factor_inverse<MATERN>(As, Ts, X, D, N, a, b, info);
+            ld = small_factor_inverse<MATERN>(As, Ts, pts, D, N, a, b, info, nh ? args.kc : nullptr, st);
             have_factor = true;
             bad = __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
         }
-        MAP_T(0);
         double gb, quad;
         small_alpha(As, N, gb, quad);
         MAP_T(1);
         if (bad && nh && tid == 0) *info = 0;   // every thread has read it (barriers of small_alpha); the next factorisation starts clean
-        double sa_t = 0.0, gl_t[NLL_SMALL_MAX_GRAD_D];
-        if (nh) small_grad<MATERN>(As, X, D, N, a, true, sa_t, gl_t);
+        double sa_t = 0.0;
+        if (nh) sa_t = small_grad<MATERN>(As, pts, args.kc, D, N, a, true, st);   // length-scale gradient -> scratch (SC_GL)
 
-        MAP_T(2);
         // ---- Bradley-Terry-Luce terms: tuple p on thread p (, p + 256, ...) ----
         // contrib: the per-member terms d BTL_p / BTL_p, in the LDS scratch (flat_len <= 640) or in global memory -- two
         // instantiations of the same code, not a run-time pointer choice (a pointer that may be LDS or global is a generic
@@ -482,41 +780,39 @@ __global__ __launch_bounds__(256) void map_opt_kernel(const MapOptArgs args) {
         // ---- value ----
         double f = btl_sum + (-0.5 * quad - 0.5 * (2.0 * ld) - 0.5 * N * log(2.0 * M_PI));
         if (nh) {
-            double reg = dev_log_lognormal(a, args.mu_a, args.s2_a);
-            if (!args.noiseless) reg += dev_log_lognormal(b, args.mu_b, args.s2_b);
-            for (int dd = 0; dd < D; ++dd) reg += dev_log_lognormal(small_scratch(As, SC_ELL + dd), args.mu_r, args.s2_r);
+            // log-normal priors (:175-192): the D length-scale terms one per thread, added by the block reduction
+            double reg = dev_log_lognormal(small_scratch(As, SC_LZ), args.mu_a, args.s2_a, hl_a);
+            if (!args.noiseless) reg += dev_log_lognormal(small_scratch(As, SC_LZ + 1), args.mu_b, args.s2_b, hl_b);
+            reg += small_block_sum(tid < D ? dev_log_lognormal(small_scratch(As, SC_LZ + 2 + tid), args.mu_r, args.s2_r, hl_r) : 0.0, As);
             f += reg;
         }
         f_last = f;
         // ---- gradient wrt the optimiser's variables (minimisation: phi = -f) ----
-        if (tid < n) {
+        for (int e = tid; e < n; e += 256) {   // n <= 320; ny <= 128: the goodness values are on the first trip, thread e
             double gz;
-            if (tid < ny) gz = gy;
+            if (e < ny) gz = gy;
             else {
-                const int hq = tid - ny;
+                const int hq = e - ny;
                 double gx, xv;
                 if (hq == 0) {
                     xv = a;
-                    gx = sa_t / a + dev_log_lognormal_d(a, args.mu_a, args.s2_a);
+                    gx = sa_t / a + dev_log_lognormal_d(a, small_scratch(As, SC_LZ), args.mu_a, args.s2_a);
                 } else if (hq == 1) {
                     xv = b;
-                    gx = args.noiseless ? 0.0 : gb + dev_log_lognormal_d(b, args.mu_b, args.s2_b);
+                    gx = args.noiseless ? 0.0 : gb + dev_log_lognormal_d(b, small_scratch(As, SC_LZ + 1), args.mu_b, args.s2_b);
                 } else {
                     xv = small_scratch(As, SC_ELL + hq - 2);
-                    double gl = 0.0;
-#pragma unroll
-                    for (int dd = 0; dd < NLL_SMALL_MAX_GRAD_D; ++dd) gl = (hq - 2 == dd) ? gl_t[dd] : gl;
-                    gx = gl + dev_log_lognormal_d(xv, args.mu_r, args.s2_r);
+                    gx = small_scratch(As, SC_GL + hq - 2) + dev_log_lognormal_d(xv, small_scratch(As, SC_LZ + hq), args.mu_r, args.s2_r);
                 }
                 gz = args.log_hyper ? gx * xv : gx;
             }
-            small_scratch(As, SC_GZ + tid) = -gz;
-            if (args.eval_only) out[MAP_OPT_OUT_G + tid] = gz;
+            small_scratch(As, SC_GZ + e) = -gz;
+            if (args.eval_only) out[MAP_OPT_OUT_G + e] = gz;
         }
         __syncthreads();
         MAP_T(4);
         ++evals;
-        tr[6] += 1;
+        st.tr[6] += 1;
         if (args.eval_only) {
             done = 1;
 #pragma unroll
@@ -644,9 +940,9 @@ __global__ __launch_bounds__(256) void map_opt_kernel(const MapOptArgs args) {
         }
         MAP_T(5);
     }
-    if (tracing && tid == 0) {
-        tr[7] = wall_clock64() - tr_begin;
-        for (int q = 0; q < 8; ++q) args.trace[q] += tr[q];
+    if (st.on && tid == 0) {
+        st.tr[7] = wall_clock64() - tr_begin;
+        for (int q = 0; q < MAP_OPT_TRACE_SLOTS; ++q) args.trace[q] += st.tr[q];
     }
 
     // ---- results and the state for a continuation ----
@@ -679,13 +975,16 @@ __global__ __launch_bounds__(256) void map_opt_kernel(const MapOptArgs args) {
     }
 }
 
+template <bool MATERN, int KV>
+static void launch_map_opt_as(hipStream_t s, const MapOptArgs& args) {
+    ensure_dyn_lds((const void*)map_opt_kernel<MATERN, KV>, DIAG_LDS_BYTES);
+    hipLaunchKernelGGL((map_opt_kernel<MATERN, KV>), dim3(1), dim3(256), DIAG_LDS_BYTES, s, args);
+}
 void launch_map_opt(hipStream_t s, int kernel, const MapOptArgs& args) {
-    ensure_dyn_lds((const void*)map_opt_kernel<false>, DIAG_LDS_BYTES);
-    ensure_dyn_lds((const void*)map_opt_kernel<true>, DIAG_LDS_BYTES);
-    if (kernel == SLS_KERNEL_ARD_MATERN52)
-        hipLaunchKernelGGL(map_opt_kernel<true>, dim3(1), dim3(256), DIAG_LDS_BYTES, s, args);
-    else
-        hipLaunchKernelGGL(map_opt_kernel<false>, dim3(1), dim3(256), DIAG_LDS_BYTES, s, args);
+    const bool matern = kernel == SLS_KERNEL_ARD_MATERN52;
+    static_assert(MAP_OPT_MAX_VARS == 64 * 5, "map_opt_kernel is instantiated for 3 and 5 variables per lane");
+    if (args.ny + args.nh <= 64 * 3) matern ? launch_map_opt_as<true, 3>(s, args) : launch_map_opt_as<false, 3>(s, args);
+    else matern ? launch_map_opt_as<true, 5>(s, args) : launch_map_opt_as<false, 5>(s, args);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -709,8 +1008,10 @@ __global__ __launch_bounds__(256) void gp_fit_small_kernel(const GpFitSmallArgs 
         double sq = 0.0;
         if (tid < N) {
             for (int d = 0; d < D; ++d) {
-                const double v = (p.X[d + (long)tid * D] - 0.5) * p.inv_ell[d];
+                const double xr = p.X[d + (long)tid * D];
+                const double v = (xr - 0.5) * p.inv_ell[d];
                 p.XT[tid + (long)d * Np] = v;
+                p.XaT[tid + (long)d * Np] = xr;   // the raw transpose for the Gram pass (Np = 128); alpha o X~ replaces it at the end
                 sq += v * v;
             }
             for (int d = D; d < Dcols; ++d) p.XT[tid + (long)d * Np] = 0.0;
@@ -722,9 +1023,11 @@ __global__ __launch_bounds__(256) void gp_fit_small_kernel(const GpFitSmallArgs 
     for (int d = tid; d < D; d += 256) small_scratch(As, SC_INVL + d) = p.inv_ell[d];
     for (int i = tid; i < 128; i += 256) small_scratch(As, SC_Y + i) = i < N ? p.y[i] : 0.0;
     if (tid == 0) *p.info = 0;
+    const SmallPts pts = small_pts_stage(As, p.X, p.XaT, D, N, p.x_lds != 0);
     __syncthreads();
 
-    const double ld = small_build_factor<MATERN>(As, Ts, p.X, D, N, p.a, p.b, p.info);
+    SmallTrace st;
+    const double ld = small_build_factor<MATERN>(As, Ts, pts, D, N, p.a, p.b, p.info, nullptr, st);
     // ---- L, L^-1 and (L^-1)^T to global memory (identity padding outside the leading Nb x Nb block, zeros above / below) ----
     for (int idx = tid; idx < Np * Np; idx += 256) {
         const int i = idx & (Np - 1), j = idx >> 7;

@@ -36,6 +36,14 @@ __device__ __forceinline__ void row_swap(double v, double& a, double& b) {
     a = __builtin_bit_cast(double, (long)(((unsigned long)ahi << 32) | alo));
     b = __builtin_bit_cast(double, (long)(((unsigned long)bhi << 32) | blo));
 }
+// sum over the 16 lanes of each row, every lane of the row receiving it
+__device__ __forceinline__ double row_sum(double v) {
+    v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);   // row_half_mirror
+    v += dpp_f64<0x140>(v);   // row_mirror
+    return v;
+}
 __device__ __forceinline__ double wave_sum(double v) {
 #ifdef SLS_SHFL_REDUCE
 #pragma unroll

@@ -173,6 +173,45 @@ def synth(rng, D, N):
     return X, y
 
 
+def make_pref_cases(rng, shapes, out, pref_cases):
+    """Preference-MAP cases (D, M, number of tuples) appended to out / pref_cases, consuming rng in order."""
+    for (D, M, npref) in shapes:
+        X, f = synth(rng, D, M)
+        prefs = []
+        for _ in range(npref):
+            idx = rng.choice(M, size=rng.integers(2, 4), replace=False)
+            idx = idx[np.argsort(-f[idx])]                  # the best one first
+            prefs.append([int(i) for i in idx])
+        flat = np.array([i for p in prefs for i in p], dtype=np.uint32)
+        offs = np.cumsum([0] + [len(p) for p in prefs]).astype(np.int32)
+        for kind in (0, 1):
+            for use_map in (0, 1):
+                name = f"pref_k{kind}_M{M}_D{D}_map{use_map}"
+                n = M + (2 + D if use_map else 0)
+                log_mask = np.zeros(n, bool)
+                log_mask[M:] = True
+                x_chk = np.concatenate([0.3 * rng.normal(size=M), [0.4, 4e-3], rng.uniform(0.3, 0.8, D)])[:n]
+                check_gradient(lambda x: pref_objective(kind, X, prefs, x, bool(use_map)), x_chk)
+
+                def fz(z):
+                    x = np.where(log_mask, np.exp(np.where(log_mask, z, 0.0)), z)
+                    v, g = pref_objective(kind, X, prefs, x, bool(use_map))
+                    return v, np.where(log_mask, g * x, g)
+                z0 = np.zeros(n)
+                if use_map:
+                    z0[M:] = np.log(np.concatenate([[0.5, 0.005], np.full(D, 0.5)]))
+                bounds = [(-10.0, 10.0)] * M + [(np.log(1e-8), np.log(10.0))] * (n - M)
+                v, z, method = _maximise(fz, [z0], bounds)          # the reference's x_ini only (one basin; map0 is concave)
+                x = np.where(log_mask, np.exp(np.where(log_mask, z, 0.0)), z)
+                lo = np.array([bb[0] for bb in bounds]); hi = np.array([bb[1] for bb in bounds])
+                pg = projected_grad_log(x, pref_objective(kind, X, prefs, x, bool(use_map))[1], lo, hi, log_mask)
+                pref_cases.append(name)
+                out[f"{name}/X"], out[f"{name}/prefs_flat"], out[f"{name}/offsets"] = X, flat, offs
+                out[f"{name}/kernel"], out[f"{name}/use_map"] = np.array(kind), np.array(use_map)
+                out[f"{name}/x_opt"], out[f"{name}/value"], out[f"{name}/pg_inf"] = x, np.array(v), np.array(np.max(np.abs(pg)))
+                print(name, "value %.9f" % v, method, "pg_inf %.2e" % np.max(np.abs(pg)), "hyp", x[M:M + 4] if use_map else "-")
+
+
 def main():
     rng = np.random.default_rng(20260929)
     out, gp_cases, pref_cases = {}, [], []
@@ -214,45 +253,26 @@ def main():
                 out[f"{name}/x_opt"], out[f"{name}/value"], out[f"{name}/pg_inf"] = x, np.array(v), np.array(np.max(np.abs(pg)))
                 print(name, "value %.9f" % v, method, "a %.4g b %.4g r[:3]" % (x[0], x[1]), x[2:5], "pg_inf %.2e" % np.max(np.abs(pg)),
                       "local optima:", np.round(out[f"{name}/local_values"], 4))
-    for (D, M, npref) in ((2, 25, 12), (6, 60, 30)):
-        X, f = synth(rng, D, M)
-        prefs = []
-        for _ in range(npref):
-            idx = rng.choice(M, size=rng.integers(2, 4), replace=False)
-            idx = idx[np.argsort(-f[idx])]                  # the best one first
-            prefs.append([int(i) for i in idx])
-        flat = np.array([i for p in prefs for i in p], dtype=np.uint32)
-        offs = np.cumsum([0] + [len(p) for p in prefs]).astype(np.int32)
-        for kind in (0, 1):
-            for use_map in (0, 1):
-                name = f"pref_k{kind}_M{M}_D{D}_map{use_map}"
-                n = M + (2 + D if use_map else 0)
-                log_mask = np.zeros(n, bool)
-                log_mask[M:] = True
-                x_chk = np.concatenate([0.3 * rng.normal(size=M), [0.4, 4e-3], rng.uniform(0.3, 0.8, D)])[:n]
-                check_gradient(lambda x: pref_objective(kind, X, prefs, x, bool(use_map)), x_chk)
-
-                def fz(z):
-                    x = np.where(log_mask, np.exp(np.where(log_mask, z, 0.0)), z)
-                    v, g = pref_objective(kind, X, prefs, x, bool(use_map))
-                    return v, np.where(log_mask, g * x, g)
-                z0 = np.zeros(n)
-                if use_map:
-                    z0[M:] = np.log(np.concatenate([[0.5, 0.005], np.full(D, 0.5)]))
-                bounds = [(-10.0, 10.0)] * M + [(np.log(1e-8), np.log(10.0))] * (n - M)
-                v, z, method = _maximise(fz, [z0], bounds)          # the reference's x_ini only (one basin; map0 is concave)
-                x = np.where(log_mask, np.exp(np.where(log_mask, z, 0.0)), z)
-                lo = np.array([bb[0] for bb in bounds]); hi = np.array([bb[1] for bb in bounds])
-                pg = projected_grad_log(x, pref_objective(kind, X, prefs, x, bool(use_map))[1], lo, hi, log_mask)
-                pref_cases.append(name)
-                out[f"{name}/X"], out[f"{name}/prefs_flat"], out[f"{name}/offsets"] = X, flat, offs
-                out[f"{name}/kernel"], out[f"{name}/use_map"] = np.array(kind), np.array(use_map)
-                out[f"{name}/x_opt"], out[f"{name}/value"], out[f"{name}/pg_inf"] = x, np.array(v), np.array(np.max(np.abs(pg)))
-                print(name, "value %.9f" % v, method, "pg_inf %.2e" % np.max(np.abs(pg)), "hyp", x[M:M + 4] if use_map else "-")
+    make_pref_cases(rng, ((2, 25, 12), (6, 60, 30)), out, pref_cases)
     out["gp_cases"], out["pref_cases"] = np.array(gp_cases), np.array(pref_cases)
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")
 
 
+def main_c3():
+    """Round 5: preference-MAP cases at BASELINE config 3's own shape (D = 32, M = 91 after 30 iterations), with and without the
+    joint hyper-parameter estimation (the reference's default: use_MAP_hyperparams = true,
+    include/sequential-line-search/sequential-line-search.hpp:37).  A file and a seed of their own, so that map_optima.npz stays
+    byte-identical.  Run:  python tests/golden/make_map_optima.py c3"""
+    rng = np.random.default_rng(20260930)
+    out, pref_cases = {}, []
+    make_pref_cases(rng, ((32, 91, 45), (32, 40, 20)), out, pref_cases)
+    out["pref_cases"] = np.array(pref_cases)
+    path = os.path.join(os.path.dirname(OUT), "map_optima_c3.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
-    main()
+    import sys
+    main_c3() if sys.argv[1:] == ["c3"] else main()

@@ -52,10 +52,12 @@ def host_path(fn):
 
 @pytest.mark.parametrize("kernel", [0, 1])
 @pytest.mark.parametrize("use_map", [False, True])
-@pytest.mark.parametrize("M,D,n_prefs", [(5, 1, 3), (40, 8, 30), (91, 16, 60), (128, 3, 300), (128, 32, 100)])
+@pytest.mark.parametrize("M,D,n_prefs", [(5, 1, 3), (40, 8, 30), (91, 16, 60), (128, 3, 300), (128, 32, 100), (91, 32, 30), (17, 33, 9),
+                                         (70, 64, 40), (64, 65, 40), (100, 100, 60), (128, 128, 100)])
 def test_device_btl_objective_and_gradient_vs_oracle(ctx, oracle, kernel, use_map, M, D, n_prefs):
-    if use_map and D > 16:
-        pytest.skip("hyper-parameter gradients on the device cover D <= 16; larger D runs the tiled path (tested in test_gpu_parity)")
+    """Round 5: the hyper-parameter gradient runs on the device for every D <= 128 (C3 as the reference runs it: M = 91, D = 32,
+    use_MAP_hyperparams = true); (64, 65), (100, 100) and (128, 128) have more than 192 variables (five per lane), D > 64 takes two
+    dimensions per lane in the length-scale contraction."""
     rng = np.random.default_rng(100 * M + D + 7 * kernel)
     X = rng.uniform(0, 1, (D, M))
     prefs = random_prefs(rng, M, n_prefs)
@@ -114,7 +116,8 @@ def pref_setup(rng, M, D, use_map):
 
 
 @pytest.mark.parametrize("kernel", [0, 1])
-@pytest.mark.parametrize("use_map,M,D", [(False, 30, 4), (False, 91, 32), (True, 30, 4), (True, 61, 16)])
+@pytest.mark.parametrize("use_map,M,D", [(False, 30, 4), (False, 91, 32), (True, 30, 4), (True, 61, 16), (True, 91, 32), (True, 48, 32),
+                                         (True, 90, 101)])
 def test_pref_fit_one_launch_equals_one_launch_per_evaluation(ctx, kernel, use_map, M, D):
     rng = np.random.default_rng(31 * M + D)
     X, prefs, z0, lo, hi = pref_setup(rng, M, D, use_map)
@@ -136,7 +139,7 @@ def test_pref_fit_one_launch_equals_one_launch_per_evaluation(ctx, kernel, use_m
 
 
 @pytest.mark.parametrize("kernel", [0, 1])
-@pytest.mark.parametrize("N,D", [(20, 1), (90, 8), (128, 16)])
+@pytest.mark.parametrize("N,D", [(20, 1), (90, 8), (128, 16), (60, 32), (100, 128)])
 def test_gp_fit_one_launch_equals_one_launch_per_evaluation(ctx, oracle, kernel, N, D):
     X, y, _, _ = synth_problem(oracle, D, N, seed=77 + N)
     z0 = np.log(np.concatenate([[0.5, 1e-4], np.full(D, 0.5)]))
@@ -232,9 +235,11 @@ def test_device_optimiser_reaches_the_host_driven_optimum(ctx, use_map, M, D):
     h.close()
 
 
-def test_pref_fit_matches_scipy_optima_through_the_c_abi(ctx):
-    """tests/golden/map_optima.npz (scipy TNC / L-BFGS-B on a numpy objective) against sls_pref_map_fit directly."""
-    z = np.load(os.path.join(ROOT, "tests", "golden", "map_optima.npz"))
+@pytest.mark.parametrize("fixture", ["map_optima.npz", "map_optima_c3.npz"])
+def test_pref_fit_matches_scipy_optima_through_the_c_abi(ctx, fixture):
+    """tests/golden/map_optima.npz (scipy TNC / L-BFGS-B on a numpy objective) against sls_pref_map_fit directly; map_optima_c3.npz
+    holds config 3's own shape (D = 32, M = 91 and 40), with and without the joint hyper-parameter estimation."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", fixture))
     for name in [str(n) for n in z["pref_cases"]]:
         c = {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith(name + "/")}
         X, kind, use_map = c["X"], int(c["kernel"]), bool(int(c["use_map"]))
@@ -262,10 +267,10 @@ def test_unsupported_sizes_are_reported_not_computed(ctx):
     with pytest.raises(sls().Unsupported):
         h.pref_map_fit([[0, 1]], np.zeros(130), np.full(130, -10.0), np.full(130, 10.0), 10)
     h.close()
-    X = rng.uniform(0, 1, (20, 30))
+    X = rng.uniform(0, 1, (130, 30))
     h = sls().Nll(ctx, X, 1)
     with pytest.raises(sls().Unsupported):
-        h.gp_map_fit(np.zeros(30), np.zeros(22), np.full(22, -18.0), np.full(22, 3.9), 10)
+        h.gp_map_fit(np.zeros(30), np.zeros(132), np.full(132, -18.0), np.full(132, 3.9), 10)
     h.close()
 
 

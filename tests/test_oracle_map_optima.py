@@ -9,10 +9,12 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 Z = np.load(os.path.join(ROOT, "tests", "golden", "map_optima.npz"))
+Z3 = np.load(os.path.join(ROOT, "tests", "golden", "map_optima_c3.npz"))     # config 3's shape: D = 32, M = 91 / 40 (round 5)
 
 
 def case(name):
-    return {k.split("/", 1)[1]: Z[k] for k in Z.files if k.startswith(name + "/")}
+    z = Z3 if name + "/X" in Z3.files else Z
+    return {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith(name + "/")}
 
 
 @pytest.mark.parametrize("name", [str(n) for n in Z["gp_cases"]])
@@ -36,7 +38,7 @@ def test_gp_map_objective_at_scipy_optima(oracle, name):
         np.testing.assert_allclose(ga, gh, rtol=1e-6, atol=1e-6 * max(1.0, np.abs(gh).max()))
 
 
-@pytest.mark.parametrize("name", [str(n) for n in Z["pref_cases"]])
+@pytest.mark.parametrize("name", [str(n) for n in Z["pref_cases"]] + [str(n) for n in Z3["pref_cases"]])
 def test_pref_objective_at_scipy_optima(oracle, name):
     c = case(name)
     X, kind, use_map = np.asfortranarray(c["X"]), int(c["kernel"]), bool(int(c["use_map"]))

@@ -43,15 +43,19 @@ out["C2_gp_fit_predict_N2048_D16_M4096"]["cpu_oracle_fit_s"] = t1 - t0
 out["C2_gp_fit_predict_N2048_D16_M4096"]["cpu_oracle_predict_s"] = t2 - t1
 gp.close()
 stamp("C2 done")
-# C3: sequential_line_search_nd D=32, 30 iterations (PreferenceRegressor MAP + EI acquisition per step)
-p = subprocess.run([os.path.join(BIN, "sequential_line_search_nd"), "32", "30", "1"], capture_output=True, text=True)
-ms = [float(v) for v in re.findall(r" ms ([-\d.e]+)", p.stdout)]
-res = [float(v) for v in re.findall(r"residual ([-\d.e]+)", p.stdout)]
-out["C3_sequential_line_search_nd_D32_30_iterations"] = {"ms_per_submit_mean": float(np.mean(ms)), "ms_per_submit_max": float(np.max(ms)),
-                                                         # the first submit carries the one-off initialisation (code objects, buffers)
-                                                         "ms_per_submit_mean_without_first": float(np.mean(ms[1:])), "ms_per_submit_median": float(np.median(ms)),
-                                                         "ms_per_submit_last": ms[-1],
-                                                         "residual_first": res[0], "residual_last": res[-1]}
+# C3: sequential_line_search_nd D=32, 30 iterations (PreferenceRegressor MAP + EI acquisition per step), as the reference runs it
+# (use_MAP_hyperparams = true: demos/sequential_line_search_nd/main.cpp:21, the constructor's default) and with fixed
+# hyper-parameters (K cached, src/preference-regressor.cpp:363-371)
+def c3_run(use_map):
+    p = subprocess.run([os.path.join(BIN, "sequential_line_search_nd"), "32", "30", "1", str(use_map)], capture_output=True, text=True)
+    ms = [float(v) for v in re.findall(r" ms ([-\d.e]+)", p.stdout)]
+    res = [float(v) for v in re.findall(r"residual ([-\d.e]+)", p.stdout)]
+    return {"use_map_hyperparams": bool(use_map), "ms_per_submit_mean": float(np.mean(ms)), "ms_per_submit_max": float(np.max(ms)),
+            # the first submit carries the one-off initialisation (code objects, buffers)
+            "ms_per_submit_mean_without_first": float(np.mean(ms[1:])), "ms_per_submit_median": float(np.median(ms)),
+            "ms_per_submit_last": ms[-1], "residual_first": res[0], "residual_last": res[-1]}
+out["C3_sequential_line_search_nd_D32_30_iterations"] = c3_run(1)
+out["C3_fixed_hyperparams_variant"] = c3_run(0)
 stamp("C3 done")
 # C5: Matern-5/2 MAP objective + gradient, N=4096, D=128
 D, N = 128, 4096
