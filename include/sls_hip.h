@@ -116,6 +116,10 @@ int sls_gp_set_sigma_mode(sls_gp* gp, int mode);
 /* best_index / x_best: PredictMaximumPointFromData (src/regressor.cpp:29-43); mu_best = PredictMu(x_best);
  * logdet = CalcLogDetOfSymmetricPositiveDefiniteMatrix(K_y).  Any out pointer may be NULL. */
 int sls_gp_get_summary(sls_gp* gp, int* best_index, double* mu_best, double* logdet);
+/* A number that changes whenever the predictor behind the handle changes (fit, sls_gp_refit_dev, sls_gp_append_point,
+ * sls_gp_set_sigma_mode) and is never repeated within the process, not even by a new handle at a recycled address: callers that
+ * cache something derived from the handle (the host layer's replicas on other GPUs) compare it instead of the pointer. */
+int sls_gp_generation(sls_gp* gp, long* generation);
 
 /* PredictMu / PredictSigma for M points (gaussian-process-regressor.cpp:234-255, preference-regressor.cpp:293-313). */
 int sls_gp_predict(sls_gp* gp, const double* Xs, int M, double* mu, double* sigma);
@@ -281,6 +285,10 @@ int sls_gp_map_fit(sls_nll* h, const double* y, const double* z0, const double* 
 int sls_prof_enable(sls_ctx* ctx, int on);
 int sls_prof_reset(sls_ctx* ctx);
 int sls_prof_get(sls_ctx* ctx, const char* name, double* total_ms, long* launches);
+
+/* The library's run-time switches (SLS_* environment variables: A/B runs and test hooks, DESIGN.md "Run-time switches") are
+ * parsed ONCE per process, at first use.  This re-reads the environment: for tests that switch paths inside one process. */
+int sls_tuning_reload(void);
 
 #ifdef __cplusplus
 }

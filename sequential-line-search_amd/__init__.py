@@ -55,8 +55,13 @@ EXPORTS = [
     "sls_pref_objective", "sls_pref_map_fit", "sls_gp_map_fit", "sls_gp_set_sigma_mode", "sls_acq_eval_pair", "sls_acq_maximize_pair", "sls_gp_append_point", "sls_acq_last_stats",
     "sls_multi_create", "sls_multi_destroy", "sls_multi_size", "sls_multi_exchange", "sls_multi_ctx", "sls_multi_gp_create", "sls_multi_gp_create_from",
     "sls_multi_gp_destroy", "sls_multi_gp_shard", "sls_multi_acq_maximize", "sls_multi_gp_predict", "sls_comm_unique_id", "sls_comm_create",
-    "sls_comm_destroy", "sls_comm_allgather_best", "sls_device_trim_cache",
+    "sls_comm_destroy", "sls_comm_allgather_best", "sls_device_trim_cache", "sls_tuning_reload", "sls_gp_generation",
 ]
+
+
+def tuning_reload():
+    """Re-read the SLS_* environment variables (the library parses them once per process)."""
+    lib().sls_tuning_reload()
 
 
 ERR_UNSUPPORTED = -5

@@ -6,7 +6,9 @@
 #include <atomic>
 #include <map>
 #include <memory>
+#include <condition_variable>
 #include <mutex>
+#include <shared_mutex>
 
 #include "common.hpp"
 #include "kernels.hpp"
@@ -47,12 +49,37 @@ Pool& pool_of(int dev) {
     return *p;
 }
 size_t pool_limit() {
-    const char* e = getenv("SLS_POOL_MB");
-    return (size_t)(e ? atol(e) : 16384) << 20;
+    return (size_t)tune(TUNE_POOL_MB, 16384) << 20;
 }
 }  // namespace
 
 void note_entry() { g_work_epoch.fetch_add(1); }
+
+// the run-time switches (tuning.hpp): parsed on first use, re-read by sls_tuning_reload()
+namespace {
+SlsTuning g_tuning;
+std::once_flag g_tuning_once;
+void tuning_parse() {
+    static const char* const names[TUNE_COUNT] = {
+#define SLS_TK(name) "SLS_" #name,
+        SLS_TUNING_KEYS(SLS_TK)
+#undef SLS_TK
+    };
+    for (int k = 0; k < TUNE_COUNT; ++k) {
+        const char* v = getenv(names[k]);
+        g_tuning.has[k] = v != nullptr;
+        g_tuning.val[k] = v ? atol(v) : 0;
+    }
+}
+}  // namespace
+const SlsTuning& tuning() {
+    std::call_once(g_tuning_once, tuning_parse);
+    return g_tuning;
+}
+void tuning_reload() {
+    (void)tuning();
+    tuning_parse();
+}
 
 void* pool_alloc(size_t bytes) {
     if (bytes == 0) bytes = 8;
@@ -169,8 +196,7 @@ void sls_ctx::prof_collect() {
 slsk::PotrfAux* sls_ctx::potrf_lookahead(int Np) {
     // SLS_POTRF_LOOKAHEAD = f > 0: side stream whose CU mask leaves f CUs per XCD free; 0: single-stream schedule.
     // Only the two-level schedule (N >= 8192 by default) has an outer update to overlap.
-    const char* e = getenv("SLS_POTRF_LOOKAHEAD");
-    const int f = e ? atoi(e) : SLS_POTRF_LOOKAHEAD_DEFAULT;
+    const int f = (int)tune(TUNE_POTRF_LOOKAHEAD, SLS_POTRF_LOOKAHEAD_DEFAULT);
     const int mode = slsk::potrf_default_mode(Np);
     if (f <= 0 || mode == 3 || (mode == 0 && slsk::potrf_default_nbo(Np) <= 1)) return nullptr;
     if (!potrf_aux.side) slsk::potrf_aux_create(&potrf_aux, f);
@@ -181,15 +207,24 @@ void sls_ctx::potrf_tick_rearm() {
     if (!potrf_persistent_ok && potrf_rearm > 0 && --potrf_rearm == 0) potrf_persistent_ok = true;
 }
 
+bool sls_ctx::potrf_df_available(int Np) const { return potrf_persistent_ok && slsk::potrf_default_mode(Np) == 3; }
 int* sls_ctx::potrf_df_sync(int Np) {
-    if (!potrf_persistent_ok || slsk::potrf_default_mode(Np) != 3) return nullptr;
+    if (!potrf_df_available(Np)) return nullptr;
     potrf_df.ensure((slsk::potrf_dataflow_sync_ints(Np) + 1) / 2);
+    potrf_single_pending = Np >= 384;   // smaller matrices never take the single-launch form (launch_potrf)
     return reinterpret_cast<int*>(potrf_df.p);
 }
 
 namespace slsk {
 bool potrf_gave_up(sls_ctx* c, int abort_flag, int attempt) {
-    if (abort_flag == 0) return false;
+    if (abort_flag == 0) {
+        // a single-launch factorisation ran to the end: the back-off of earlier give-ups starts over (a context that saw a few
+        // transient residency failures would otherwise sit on a 4096-fit back-off for the rest of its life)
+        if (c->potrf_single_pending && c->potrf_persistent_ok) c->potrf_rearm_next = 16;
+        c->potrf_single_pending = false;
+        return false;
+    }
+    c->potrf_single_pending = false;
     if (attempt > 0 || !c->potrf_persistent_ok) {
         set_error("Cholesky factorisation aborted: a device-side wait expired");
         throw HipFail{SLS_ERR_HIP};
@@ -304,6 +339,11 @@ static void ctx_destroy_now(sls_ctx* ctx) {
     if (ctx->d_info) (void)hipFree(ctx->d_info);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
+}
+
+extern "C" int sls_tuning_reload(void) {
+    slsk::tuning_reload();
+    return SLS_OK;
 }
 
 extern "C" int sls_device_trim_cache(int device) {
@@ -423,6 +463,9 @@ struct sls_gp {
     // 0: sigma^2 = a - k^T K^-1 k with the explicit inverse (GaussianProcessRegressor); 1: a - |L^-1 k|^2, the Cholesky solve of
     // PreferenceRegressor (sls_gp_set_sigma_mode)
     int sigma_mode = 0;
+    // changes whenever the predictor this handle stands for changes (fit, refit, appended point, sigma mode); process-wide unique, so
+    // a new handle at a recycled address never repeats a number (sls_gp_generation: the host layer keys its replicas on it)
+    long generation = 0;
     // statistics of the last sls_acq_maximize* call on this handle (sls_acq_last_stats)
     long stat_issued = 0, stat_cap = 0;
     int stat_rounds = 0, stat_live_end = 0;
@@ -433,6 +476,22 @@ struct sls_gp {
     // page-locked staging of host-supplied query points and their results (predict / acquisition entry points on the tiled path):
     // uploads and downloads are truly asynchronous, one synchronisation per call (pageable buffers: blocking staged copies, a
     // synchronisation behind each, and a fresh 0.5 MB temporary per transfer)
+    // Concurrent const evaluations (src/acquisition-function.cpp:125-144: Predict* of ONE regressor from hardware_concurrency worker
+    // threads).  A small evaluation (a few query points on a wave-path handle) does not take the context's lock: it borrows a SLOT of
+    // the handle -- a stream of its own and a page-locked, device-mapped block for the query points and the results -- under a
+    // SHARED lock on the fitted state; everything that changes the state (refit, appended point, sigma mode) holds it exclusively.
+    struct EvalSlot {
+        hipStream_t stream = nullptr;
+        double* host = nullptr;
+        double* dev = nullptr;
+        size_t bytes = 0;
+        bool busy = false;
+    };
+    std::shared_mutex state_mtx;
+    std::mutex slot_mtx;
+    std::condition_variable slot_cv;
+    std::vector<std::unique_ptr<EvalSlot>> slots;
+    static constexpr int MAX_SLOTS = 16;
     double* io_host = nullptr;
     size_t io_bytes = 0;
     double* io_stage(size_t doubles) {
@@ -447,6 +506,13 @@ struct sls_gp {
         return io_host;
     }
     ~sls_gp() {   // sls_gp_destroy holds the context's lock
+        for (auto& s : slots) {
+            if (s->stream) {
+                (void)hipStreamSynchronize(s->stream);
+                (void)hipStreamDestroy(s->stream);
+            }
+            if (s->host) ctx->host_give(s->host, s->bytes, true);
+        }
         if (sum_host) ctx->host_give(sum_host, sum_bytes, true);
         if (zc_host) ctx->host_give(zc_host, zc_bytes, true);
         if (io_host) ctx->host_give(io_host, io_bytes, false);
@@ -456,11 +522,12 @@ struct sls_gp {
 // N <= 128: the whole fit is one single-workgroup launch (kernels_small.hip); SLS_FIT_SMALL=0 forces the tiled pipeline (A/B, tests)
 static bool gp_fit_small_ok(const sls_gp* g) {
     if (g->N > NLL_SMALL_MAX_N || g->Np != 128 || g->D > 128) return false;
-    const char* e = getenv("SLS_FIT_SMALL");
-    return !e || atoi(e) != 0;
+    return tune_on(TUNE_FIT_SMALL);
 }
 
+static std::atomic<long> g_gp_generation{0};
 static void gp_fit_device(sls_gp* g) {
+    g->generation = ++g_gp_generation;
     sls_ctx* c = g->ctx;
     const int N = g->N, Np = g->Np, D = g->D;
     if (gp_fit_small_ok(g)) {
@@ -470,6 +537,7 @@ static void gp_fit_device(sls_gp* g) {
         f.XT = g->XT.p; f.nx = g->nx.p; f.XaT = g->XaT.p; f.L = g->L.p; f.Linv = g->Linv.p; f.U = g->U.p; f.Kinv = g->Kinv.p;
         f.alpha = g->alpha.p; f.mu_data = g->mu_data.p; f.scal = g->scal.p; f.d_idx = g->d_idx; f.info = c->d_info;
         f.summary = g->sum_dev;
+        f.x_lds = tune_on(TUNE_SMALL_XLDS) ? 1 : 0;
         SLS_HIP(hipMemsetAsync(c->d_info, 0, 64, c->stream));
         ProfScope ps(c, "fit_small");
         launch_gp_fit_small(c->stream, g->kernel, f);
@@ -489,7 +557,8 @@ static void gp_fit_device(sls_gp* g) {
         // N <= 4096: factorisation, L^-1, its transpose and K_y^-1 in ONE launch (the inverse is built behind the chain by the CUs the
         // factorisation leaves idle)
         ProfScope ps(c, "potri");
-        launch_potri(c->stream, g->L.p, Np, g->Linv.p, g->U.p, g->Kinv.p, c->d_info, c->potrf_lookahead(Np), df_sync);
+        if (!launch_potri(c->stream, g->L.p, Np, g->Linv.p, g->U.p, g->Kinv.p, c->d_info, c->potrf_lookahead(Np), df_sync))
+            ps.rename("potrf+trtri+lauum");   // the fused launch declined (too few CUs resident): the three separate launches ran
     } else {
         {
             ProfScope ps(c, "potrf");
@@ -593,6 +662,7 @@ extern "C" int sls_gp_refit_dev(sls_gp* g, const double* X_dev, const double* y_
         (void)hipSetDevice(g->ctx->device);   // the handle's device, whatever the caller's current device is
     }
     SLS_REQUIRE(g && X_dev && y_dev, "sls_gp_refit_dev: NULL argument");
+    std::unique_lock<std::shared_mutex> state_(g->state_mtx);
     sls_ctx* c = g->ctx;
     SLS_HIP(hipMemcpyAsync(g->X.p, X_dev, (size_t)g->D * g->N * 8, hipMemcpyDeviceToDevice, c->stream));
     SLS_HIP(hipMemcpyAsync(g->y.p, y_dev, (size_t)g->N * 8, hipMemcpyDeviceToDevice, c->stream));
@@ -613,6 +683,13 @@ extern "C" int sls_gp_destroy(sls_gp* gp) {
         delete gp;
     }
     slsk::ctx_release(c);
+    return SLS_OK;
+}
+
+extern "C" int sls_gp_generation(sls_gp* g, long* generation) {
+    if (!g || !generation) return SLS_ERR_INVALID;
+    std::unique_lock<std::recursive_mutex> lock_(g->ctx->mtx);
+    *generation = g->generation;
     return SLS_OK;
 }
 
@@ -650,9 +727,12 @@ extern "C" int sls_gp_set_sigma_mode(sls_gp* g, int mode) {
         (void)hipSetDevice(g->ctx->device);
     }
     SLS_REQUIRE(g && (mode == SLS_SIGMA_EXPLICIT_INVERSE || mode == SLS_SIGMA_CHOLESKY_SOLVE), "sls_gp_set_sigma_mode: bad argument");
+    std::unique_lock<std::shared_mutex> state_(g->state_mtx);
     if (mode == SLS_SIGMA_CHOLESKY_SOLVE && g->sigma_mode != mode)
         launch_transpose_full(g->ctx->stream, g->Linv.p, g->U.p, g->Np);   // every block of U = (L^-1)^T (trtri writes the upper ones only)
+    if (g->sigma_mode != mode) g->generation = ++g_gp_generation;
     g->sigma_mode = mode;
+    sync(g->ctx);   // slot streams are not ordered behind the context's stream: the state is complete before the lock goes
     SLS_CATCH
 }
 
@@ -751,8 +831,7 @@ struct EvalOut {
 
 // value-only evaluations take the triangular L^-1 contraction (half the flops); SLS_TRI_PREDICT=0 forces the K^-1 form
 static bool tri_predict() {
-    const char* e = getenv("SLS_TRI_PREDICT");
-    return !e || atoi(e) != 0;
+    return tune_on(TUNE_TRI_PREDICT);
 }
 
 // xr: raw candidate coordinates, S candidates: candidate-major xr[n + d*ldr], or (point_major) xr[d + n*D] as the host hands them
@@ -837,8 +916,7 @@ static void eval_candidates(sls_gp* g, const double* xr, long ldr, int S, const 
 // Small problems: one wavefront per query point (kernels_wave.hip, evaluation-only mode) instead of the tiled pipeline.
 // Xs_dev: D x M column-major device copy of the query points; outputs as in EvalOut.
 static bool eval_small(sls_gp* g, const double* Xs_dev, int M, const EvalOut& o) {
-    const char* wenv = getenv("SLS_WAVE_PATH");
-    const bool allow = wenv ? atoi(wenv) != 0 : true;
+    const bool allow = tune_on(TUNE_WAVE_PATH);
     if (!allow || g->Np > WAVE_PATH_MAX_NP || g->D > WAVE_PATH_MAX_D || M > 4096) return false;
     sls_ctx* c = g->ctx;
     WaveArgs w;
@@ -869,16 +947,19 @@ static void upload_candidates(sls_gp* g, const double* Xs, int M, DBuf& raw, int
 // evaluate M host-supplied query points (D x M column-major) into the candidate-major device outputs of `o`
 static void eval_host_points(sls_gp* g, const double* Xs, int M, int Mp, const EvalOut& o) {
     sls_ctx* c = g->ctx;
-    const char* wenv = getenv("SLS_WAVE_PATH");
-    const bool allow = wenv ? atoi(wenv) != 0 : true;
+    const bool allow = tune_on(TUNE_WAVE_PATH);
+    const size_t n = (size_t)g->D * M;
     if (allow && g->Np <= WAVE_PATH_MAX_NP && g->D <= WAVE_PATH_MAX_D && M <= 4096) {
-        g->raw.ensure((size_t)g->D * M);
-        h2d(c, g->raw.p, Xs, (size_t)g->D * M);
+        g->raw.ensure(n);
+        if (n <= IO_STAGE_MAX && tune_on(TUNE_IO_STAGE)) {   // through the page-locked block: a copy from pageable memory blocks the host
+            double* st = g->io_stage(n);
+            std::memcpy(st, Xs, n * sizeof(double));
+            h2d(c, g->raw.p, st, n);
+        } else
+            h2d(c, g->raw.p, Xs, n);
         if (eval_small(g, g->raw.p, M, o)) return;
     }
-    const size_t n = (size_t)g->D * M;
-    const char* senv = getenv("SLS_IO_STAGE");   // 0: the transposing pageable upload of rounds 1-3 (A/B, tests)
-    if (n <= IO_STAGE_MAX && (!senv || atoi(senv) != 0)) {
+    if (n <= IO_STAGE_MAX && tune_on(TUNE_IO_STAGE)) {   // SLS_IO_STAGE=0: the transposing pageable upload of rounds 1-3 (A/B, tests)
         // as handed over (point-major), through page-locked memory: no transposition on the host, no synchronisation behind the upload
         double* st = g->io_stage(n);
         std::memcpy(st, Xs, n * sizeof(double));
@@ -897,7 +978,10 @@ static void download_cm2(sls_gp* g, const double* devA, double* hostA, const dou
     sls_ctx* c = g->ctx;
     const size_t each = (size_t)Mp * rows;
     const int cnt = (hostA ? 1 : 0) + (hostB ? 1 : 0);
-    if (cnt == 0) return;
+    if (cnt == 0) {
+        sync(c);   // nothing to fetch, but the evaluation in flight reads the staging block the next call writes into
+        return;
+    }
     std::vector<double> pageable;
     double* t;
     if (each * cnt <= IO_STAGE_MAX) t = g->io_stage(each * cnt);
@@ -923,8 +1007,101 @@ static void download_cm(sls_gp* g, const double* dev, int M, int Mp, int rows, d
     download_cm2(g, dev, host, nullptr, nullptr, M, Mp, rows);
 }
 
+// ---- concurrent small evaluations (sls_gp::EvalSlot) ---------------------------------------------------------
+// What one call wants; any pointer may be NULL.  Row outputs (dmu, dsigma, grad) are D x M column-major on the host.
+struct SmallEvalOut {
+    double *mu = nullptr, *sigma = nullptr, *dmu = nullptr, *dsigma = nullptr, *val = nullptr, *grad = nullptr;
+    int acq = SLS_ACQ_EXPECTED_IMPROVEMENT;
+    double ucb_h = 1.0;
+};
+constexpr int SLOT_MAX_POINTS = 64;
+// true: evaluated (results are in the caller's arrays).  false: not applicable -- the caller takes the context's lock and the
+// general path.  Holds no lock of the context; the caller must NOT hold it either (a mutator waiting for the state lock would
+// then wait for this call, not the other way round -- there is no inversion, but the point of the path is to stay off that lock).
+static bool eval_in_slot(sls_gp* g, const double* Xs, int M, const SmallEvalOut& o) {
+    sls_ctx* c = g->ctx;
+    if (M < 1 || M > SLOT_MAX_POINTS || !tune_on(TUNE_EVAL_SLOTS) || !tune_on(TUNE_WAVE_PATH) || c->prof_on) return false;
+    std::shared_lock<std::shared_mutex> state_(g->state_mtx);
+    if (g->Np > WAVE_PATH_MAX_NP || g->D > WAVE_PATH_MAX_D) return false;
+    (void)hipSetDevice(c->device);
+    const int D = g->D;
+    const size_t n_in = (size_t)D * M, n_out = (size_t)(3 + 3 * D) * M;
+    // ---- borrow a slot ----
+    sls_gp::EvalSlot* slot = nullptr;
+    {
+        std::unique_lock<std::mutex> lk(g->slot_mtx);
+        for (;;) {
+            for (auto& s : g->slots)
+                if (!s->busy) { slot = s.get(); break; }
+            if (slot) break;
+            if ((int)g->slots.size() < sls_gp::MAX_SLOTS) {
+                g->slots.emplace_back(new sls_gp::EvalSlot());
+                slot = g->slots.back().get();
+                break;
+            }
+            g->slot_cv.wait(lk);
+        }
+        slot->busy = true;
+    }
+    struct Release {
+        sls_gp* g;
+        sls_gp::EvalSlot* s;
+        ~Release() {
+            {
+                std::lock_guard<std::mutex> lk(g->slot_mtx);
+                s->busy = false;
+            }
+            g->slot_cv.notify_one();
+        }
+    } release{g, slot};
+    if (!slot->stream) SLS_HIP(hipStreamCreateWithFlags(&slot->stream, hipStreamNonBlocking));
+    const size_t need = (n_in + n_out) * sizeof(double);
+    if (need > slot->bytes) {
+        std::lock_guard<std::recursive_mutex> ctx_lock(c->mtx);   // the context's page-locked pool is not thread safe; growth is rare
+        if (slot->host) c->host_give(slot->host, slot->bytes, true);
+        slot->host = nullptr;
+        slot->bytes = 0;
+        slot->host = static_cast<double*>(c->host_take(std::max(need, (size_t)(4 + 4 * D) * SLOT_MAX_POINTS * sizeof(double)), true, &slot->bytes));
+        SLS_HIP(hipHostGetDevicePointer((void**)&slot->dev, slot->host, 0));
+    }
+    std::memcpy(slot->host, Xs, n_in * sizeof(double));
+    double* od = slot->dev + n_in;       // device view of the outputs: mu | sigma | val | dmu | dsigma | grad, candidate-major, ld = M
+    double* oh = slot->host + n_in;
+    WaveArgs w;
+    w.S = M; w.D = D; w.N = g->N; w.Np = g->Np; w.m = 1; w.n_local = 0; w.acq = o.acq;
+    w.matern = g->kernel == SLS_KERNEL_ARD_MATERN52;
+    w.a = g->a; w.mu_best = g->mu_best; w.ucb_h = o.ucb_h; w.c1 = 0; w.shrink = 0; w.gtol = 0; w.max_backtracks = 0;
+    w.XT = g->XT.p; w.inv_ell = g->inv_ell.p; w.Kinv = g->Kinv.p; w.alpha = g->alpha.p; w.starts = slot->dev;
+    w.solve_sigma = g->sigma_mode == 1; w.Linv = g->Linv.p; w.U = g->U.p;
+    w.x_out = nullptr; w.f_out = nullptr; w.ld = M;
+    w.ev_mu = o.mu ? od : nullptr;
+    w.ev_sigma = o.sigma ? od + M : nullptr;
+    w.ev_val = o.val ? od + 2 * (size_t)M : nullptr;
+    w.ev_dmu = o.dmu ? od + 3 * (size_t)M : nullptr;
+    w.ev_dsigma = o.dsigma ? od + (size_t)(3 + D) * M : nullptr;
+    w.ev_grad = o.grad ? od + (size_t)(3 + 2 * D) * M : nullptr;
+    launch_maximize_wave(slot->stream, w);
+    SLS_HIP(hipStreamSynchronize(slot->stream));
+    auto vec = [&](double* host, size_t off) {
+        if (host) std::memcpy(host, oh + off, sizeof(double) * M);
+    };
+    auto rows = [&](double* host, size_t off) {
+        if (!host) return;
+        for (int m = 0; m < M; ++m)
+            for (int d = 0; d < D; ++d) host[d + (size_t)m * D] = oh[off + (size_t)m + (size_t)d * M];
+    };
+    vec(o.mu, 0); vec(o.sigma, M); vec(o.val, 2 * (size_t)M);
+    rows(o.dmu, 3 * (size_t)M); rows(o.dsigma, (size_t)(3 + D) * M); rows(o.grad, (size_t)(3 + 2 * D) * M);
+    return true;
+}
+
 extern "C" int sls_gp_predict(sls_gp* g, const double* Xs, int M, double* mu, double* sigma) {
     SLS_TRY
+    if (g && Xs && M >= 1 && M <= SLOT_MAX_POINTS) {
+        SmallEvalOut so;
+        so.mu = mu; so.sigma = sigma;
+        if (eval_in_slot(g, Xs, M, so)) return SLS_OK;
+    }
     std::unique_lock<std::recursive_mutex> lock_;
     if (g) {
         lock_ = std::unique_lock<std::recursive_mutex>(g->ctx->mtx);
@@ -943,6 +1120,11 @@ extern "C" int sls_gp_predict(sls_gp* g, const double* Xs, int M, double* mu, do
 
 extern "C" int sls_gp_predict_grad(sls_gp* g, const double* Xs, int M, double* dmu, double* dsigma) {
     SLS_TRY
+    if (g && Xs && M >= 1 && M <= SLOT_MAX_POINTS) {
+        SmallEvalOut so;
+        so.dmu = dmu; so.dsigma = dsigma;
+        if (eval_in_slot(g, Xs, M, so)) return SLS_OK;
+    }
     std::unique_lock<std::recursive_mutex> lock_;
     if (g) {
         lock_ = std::unique_lock<std::recursive_mutex>(g->ctx->mtx);
@@ -961,6 +1143,11 @@ extern "C" int sls_gp_predict_grad(sls_gp* g, const double* Xs, int M, double* d
 
 extern "C" int sls_acq_eval(sls_gp* g, int acq_type, double ucb_h, const double* Xs, int M, double* val, double* grad) {
     SLS_TRY
+    if (g && Xs && M >= 1 && M <= SLOT_MAX_POINTS && (acq_type == SLS_ACQ_EXPECTED_IMPROVEMENT || acq_type == SLS_ACQ_GP_UCB)) {
+        SmallEvalOut so;
+        so.val = val; so.grad = grad; so.acq = acq_type; so.ucb_h = ucb_h;
+        if (eval_in_slot(g, Xs, M, so)) return SLS_OK;
+    }
     std::unique_lock<std::recursive_mutex> lock_;
     if (g) {
         lock_ = std::unique_lock<std::recursive_mutex>(g->ctx->mtx);
@@ -975,9 +1162,7 @@ extern "C" int sls_acq_eval(sls_gp* g, int acq_type, double ucb_h, const double*
         // default global phase, src/acquisition-function.cpp:155-165) -- : the query points are read from, and the values written to,
         // a page-locked block the device maps: ONE launch + one synchronisation per call instead of upload + launch + download
         // (~60 -> ~30 us per call; ten calls per SubmitFeedbackData).  SLS_EVAL_ZEROCOPY=0: the copying path.
-        const char* wenv = getenv("SLS_WAVE_PATH");
-        const char* zenv = getenv("SLS_EVAL_ZEROCOPY");
-        if (!grad && val && (wenv ? atoi(wenv) != 0 : true) && (zenv ? atoi(zenv) != 0 : true) && g->Np <= WAVE_PATH_MAX_NP &&
+        if (!grad && val && tune_on(TUNE_WAVE_PATH) && tune_on(TUNE_EVAL_ZEROCOPY) && g->Np <= WAVE_PATH_MAX_NP &&
             D <= WAVE_PATH_MAX_D && M <= 4096) {
             sls_ctx* c = g->ctx;
             const size_t need = ((size_t)D * M + M) * sizeof(double);
@@ -1071,8 +1256,7 @@ static void maximize_impl(sls_gp* g, sls_gp* gs, int acq_type, double ucb_h, con
     bool used_wave = false;
     const unsigned long long* wave_useful = nullptr;   // the one-wavefront-per-start run's count of useful evaluations (device)
     {
-        const char* wenv = getenv("SLS_WAVE_PATH");
-        const bool allow = wenv ? atoi(wenv) != 0 : true;
+        const bool allow = tune_on(TUNE_WAVE_PATH);
         if (allow && !gs && g->Np <= WAVE_PATH_MAX_NP && D <= WAVE_PATH_MAX_D && S <= 4096) {
             WaveArgs w;
             w.S = S; w.D = D; w.N = g->N; w.Np = g->Np; w.m = o.history; w.n_local = n_local; w.acq = acq_type;
@@ -1089,7 +1273,7 @@ static void maximize_impl(sls_gp* g, sls_gp* gs, int acq_type, double ucb_h, con
             SLS_HIP(hipMemsetAsync(d_useful, 0, sizeof(unsigned long long), c->stream));
             w.useful = d_useful;
             long long* d_trace = nullptr;
-            if (getenv("SLS_WAVE_TRACE")) {
+            if (tune_set(TUNE_WAVE_TRACE)) {
                 d_trace = reinterpret_cast<long long*>(g->lb_int + 6 * (size_t)Sp + 64);
                 SLS_HIP(hipMemsetAsync(d_trace, 0, 9 * sizeof(long long), c->stream));
                 w.trace = d_trace;
@@ -1118,8 +1302,7 @@ static void maximize_impl(sls_gp* g, sls_gp* gs, int acq_type, double ucb_h, con
         // increasing order, into dense 128-wide tiles, so cross_gram / acq_gemm / grad_gemm only see live columns.  A
         // candidate's arithmetic does not depend on the column it occupies, so every start ends with the same bits as
         // in the uncompacted schedule (SLS_COMPACT=0: every start is re-evaluated every round; tests compare the two).
-        const char* cenv = getenv("SLS_COMPACT");
-        const bool compact = cenv ? atoi(cenv) != 0 : true;
+        const bool compact = tune_on(TUNE_COMPACT);
         int* live_a = g->lb_int + 4 * (size_t)Sp;
         int* live_b = live_a + Sp;
         int* d_count = live_b + Sp;
@@ -1416,6 +1599,7 @@ extern "C" int sls_gp_append_point(sls_gp* g, const double* x, double y_new) {
         (void)hipSetDevice(g->ctx->device);   // the handle's device, whatever the caller's current device is
     }
     SLS_REQUIRE(g && x, "sls_gp_append_point: NULL argument");
+    std::unique_lock<std::shared_mutex> state_(g->state_mtx);   // ends with gp_fetch_summary's synchronisation: the state is complete
     sls_ctx* c = g->ctx;
     const int D = g->D, N = g->N, Np = g->Np;
     if (g->host_stale) {   // the device copies are authoritative after sls_gp_refit_dev
@@ -1456,6 +1640,7 @@ extern "C" int sls_gp_append_point(sls_gp* g, const double* x, double y_new) {
     g->X.ensure((size_t)D * (N + 1));   // may reallocate: refill from the host copy
     SLS_HIP(hipMemcpyAsync(g->X.p, g->Xh.data(), (size_t)D * (N + 1) * 8, hipMemcpyHostToDevice, c->stream));
     g->N = N + 1;
+    g->generation = ++g_gp_generation;
     launch_prep_points(c->stream, g->X.p, D, N + 1, g->inv_ell.p, g->XT.p, Np, Np, g->Dcols, g->nx.p);
     launch_scale_rows(c->stream, g->XT.p, g->alpha.p, g->XaT.p, Np, Np, g->Dcols);
     if (g->sigma_mode == 1) launch_transpose_full(c->stream, g->Linv.p, g->U.p, Np);   // the rank-1 growth does not maintain U

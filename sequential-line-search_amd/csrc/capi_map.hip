@@ -178,8 +178,7 @@ static int nll_y_chunks(int nt, int ncols) {
 // N <= 128: the whole evaluation is one single-workgroup launch (kernels_small.hip); SLS_NLL_SMALL=0 forces the tiled path
 static bool nll_small_ok(const sls_nll* h) {
     if (h->N > NLL_SMALL_MAX_N || h->D > NLL_SMALL_MAX_D) return false;
-    const char* e = getenv("SLS_NLL_SMALL");
-    return !e || atoi(e) != 0;
+    return tune_on(TUNE_NLL_SMALL);
 }
 
 static void nll_small_eval(sls_nll* h, const double* y, const double* theta, double b, double* quad, double* logdet,
@@ -193,9 +192,9 @@ static void nll_small_eval(sls_nll* h, const double* y, const double* theta, dou
     args.X = h->X.p; args.XTr = h->XTr.p; args.D = D; args.N = N; args.want_grad = want_grad ? 1 : 0;
     if (want_grad) h->small_kc.ensure(NLL_SMALL_KC_DOUBLES);
     args.kc = h->small_kc.p;
+    args.x_lds = tune_on(TUNE_SMALL_XLDS) ? 1 : 0;
     args.info = c->d_info;
-    const char* zc_env = getenv("SLS_SMALL_ZEROCOPY");   // read per call, like the other A/B switches
-    const bool zero_copy = zc_env ? atoi(zc_env) != 0 : true;
+    const bool zero_copy = tune_on(TUNE_SMALL_ZEROCOPY);
     if (zero_copy && !h->small_host) {
         h->small_host = static_cast<double*>(c->host_take(NLL_SMALL_OUT_DOUBLES * sizeof(double), true, &h->small_host_bytes));
         SLS_HIP(hipHostGetDevicePointer((void**)&h->small_host_dev, h->small_host, 0));
@@ -409,14 +408,14 @@ extern "C" int sls_gp_nll_batch(sls_nll* h, const double* y, const double* xs, i
         // N > 128: bordered factorisations (quad and log-det from the factor alone: no inverse), several parameter sets per
         // persistent launch, each on its own share of the chip -- one factorisation of this size is bound by its serial chain and
         // leaves most CUs idle.  SLS_NLL_BATCH=0: one full evaluation after the other (the round-3 path).
-        const char* be = getenv("SLS_NLL_BATCH");
         const int Np2 = round_up(N + 1, 128);
-        const int Pmax = (be && atoi(be) == 0) ? 0 : potrf_dataflow_max_problems(Np2);
-        int* dfs = Pmax >= 1 ? c->potrf_df_sync(Np2) : nullptr;   // nullptr: the single-launch form is switched off
-        if (!dfs || Np2 / 128 < 3) {
+        const int Pmax = !tune_on(TUNE_NLL_BATCH) ? 0 : potrf_dataflow_max_problems(Np2);
+        if (Pmax < 1 || !c->potrf_df_available(Np2) || Np2 / 128 < 3) {   // the single-launch form is switched off, or too small for it
             sequential(0, B);
             return SLS_OK;
         }
+        // info words: two per problem, read back from the 64 bytes of d_info cleared below (d_info + 32 belongs to acq_gemm)
+        SLS_REQUIRE(Pmax <= 8, "sls_gp_nll_batch: %d problems per launch exceed the info block (8)", Pmax);
         const size_t mat = (size_t)Np2 * Np2, sync_ints = (potrf_dataflow_sync_ints(Np2) + 63) / 64 * 64;
         const int Dp = h->Dp, Dcols = h->Dcols;
         if (h->bt_P < Pmax) {
@@ -489,6 +488,7 @@ extern "C" int sls_gp_nll_batch(sls_nll* h, const double* y, const double* xs, i
     SLS_HIP(hipMemcpyAsync(h->small_in.p, in.data(), in.size() * 8, hipMemcpyHostToDevice, c->stream));
     NllSmallArgs args;
     args.X = h->X.p; args.XTr = h->XTr.p; args.kc = nullptr; args.D = D; args.N = N; args.want_grad = 0;
+    args.x_lds = tune_on(TUNE_SMALL_XLDS) ? 1 : 0;
     args.info = reinterpret_cast<int*>(h->small_info.p);
     args.out = h->small_out.p; args.in_dev = h->small_in.p;
     args.batch = B; args.in_stride = (long)in_stride; args.out_stride = (long)out_stride;
@@ -519,8 +519,7 @@ struct MapOptProblem {
 // SLS_MAP_DEVICE=0 forces the host-driven optimiser / the host's BTL terms (A/B and tests)
 static bool map_opt_supported(const sls_nll* h) {
     if (h->N > NLL_SMALL_MAX_N || h->D > NLL_SMALL_MAX_D) return false;
-    const char* e = getenv("SLS_MAP_DEVICE");
-    return !e || atoi(e) != 0;
+    return tune_on(TUNE_MAP_DEVICE);
 }
 
 // Runs the kernel: the whole fit in one launch (evals_per_launch <= 0 or >= max_evals), in launches of evals_per_launch
@@ -588,6 +587,7 @@ static void map_opt_run(sls_nll* h, const MapOptProblem& pb, const double* z0, c
     }
     MapOptArgs a;
     if (pb.nh > 0) h->small_kc.ensure(NLL_SMALL_KC_DOUBLES);
+    a.x_lds = tune_on(TUNE_SMALL_XLDS) ? 1 : 0;
     a.X = h->X.p; a.XTr = h->XTr.p; a.kc = h->small_kc.p; a.D = D; a.N = N; a.ny = pb.ny; a.nh = pb.nh; a.log_hyper = pb.log_hyper; a.noiseless = pb.noiseless;
     a.y_fixed = h->mo_vec.p + 3 * n;
     a.a0 = pb.a0; a.b0 = pb.b0; a.r0 = pb.r0;
@@ -604,7 +604,7 @@ static void map_opt_run(sls_nll* h, const MapOptProblem& pb, const double* z0, c
     a.out = h->mo_out_dev;
     a.info = c->d_info;
     a.trace = nullptr;
-    if (getenv("SLS_MAP_TRACE") && !eval_only) {
+    if (tune_set(TUNE_MAP_TRACE) && !eval_only) {
         a.trace = reinterpret_cast<long long*>(h->mo_state.p + MAP_OPT_STATE_DOUBLES);
         SLS_HIP(hipMemsetAsync(a.trace, 0, MAP_OPT_TRACE_SLOTS * sizeof(long long), c->stream));
     }

@@ -252,8 +252,7 @@ extern "C" int sls_multi_create(const int* devices, int n, sls_multi** out) {
             }
         }
         const bool distinct = std::set<int>(m->devices.begin(), m->devices.end()).size() == (size_t)n;
-        const char* env = getenv("SLS_MULTI_RCCL");
-        const bool want = env ? atoi(env) != 0 : true;
+        const bool want = tune_on(TUNE_MULTI_RCCL);
         if (!distinct) m->rccl_note = "host merge: a device is listed more than once (RCCL allows one rank per GPU)";
         else if (!want) m->rccl_note = "host merge: SLS_MULTI_RCCL=0";
         else if (!rccl()) m->rccl_note = "host merge: " + rccl_state().why;

@@ -113,6 +113,8 @@ struct sls_ctx {
     long potrf_fallbacks = 0;            // how often a single-launch factorisation gave up (sls_prof_get("potrf_fallbacks"))
     slsk::DBuf potrf_df;                 // flag tables of the dataflow form (grown on demand)
     int* potrf_df_sync(int Np);          // nullptr: single-launch form switched off for this context (no side effects)
+    bool potrf_df_available(int Np) const;   // the same question without allocating the flag tables
+    bool potrf_single_pending = false;   // a single-launch factorisation was handed its flag tables since the last verdict
 
     // page-locked host blocks (result blocks the small-problem kernels write directly, staging for uploads) handed out to the
     // handles of this context and taken back when a handle dies: hipHostMalloc + hipHostFree cost ~260 us per block (round 4, C3:
@@ -143,6 +145,7 @@ struct ProfScope {
     ProfScope(sls_ctx* c_, const char* n) : c(c_), name(n) {
         if (c->prof_on) c->prof_begin(name, e0);
     }
+    void rename(const char* n) { name = n; }   // the launch behind the scope turned out to be something else (fused form declined)
     ~ProfScope() {
         if (c->prof_on) c->prof_end(name, e0);
     }

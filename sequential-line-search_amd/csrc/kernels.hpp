@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <hip/hip_runtime.h>
 
+#include "tuning.hpp"
+
 #include <mutex>
 #include <map>
 #include <set>
@@ -158,10 +160,7 @@ void launch_var_gemm(hipStream_t s, const double* Ks, long ldk, int Sp, const do
 // Always, since round 3: four times as many workgroups of a quarter of the work each fill the 768 slots evenly at every active-set
 // size (C4: 85.9 -> 79.2 ms per step including grad_reduce4_kernel).  SLS_GRAD_SPLIT_TILES=t: split only launches of fewer than
 // t tiles (0: never) -- the tests run both forms against each other.
-inline bool grad_gemm_wants_split(int Sp) {
-    const char* e = getenv("SLS_GRAD_SPLIT_TILES");
-    return e == nullptr || 2 * (Sp / 128) < atoi(e);
-}
+inline bool grad_gemm_wants_split(int Sp) { return !tune_set(TUNE_GRAD_SPLIT_TILES) || 2 * (Sp / 128) < tune(TUNE_GRAD_SPLIT_TILES, 0); }
 void launch_grad_gemm(hipStream_t s, const double* P, const double* Cs, long ldk, int Sp, const double* XT, const double* XaT,
                       long ld, int Np, int Dcols, double* Gs, double* Gm, double* part = nullptr);
 struct FinalizeArgs {

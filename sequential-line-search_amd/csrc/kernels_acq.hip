@@ -193,14 +193,11 @@ int launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk,
     // SLS_PERSIST (0: one tile per workgroup, 1: persistent workgroups with generation gates, 2: persistent without gates;
     // default 1 with two workgroups per CU, 2 with one, see below) is read per call so that tests and A/B runs can switch
     // within one process
-    const char* ep = getenv("SLS_PERSIST");
-    const char* ew0 = getenv("SLS_ACQ_WG_PER_CU");
-    const int persist_env = ep ? atoi(ep) : ((ew0 && atoi(ew0) == 2) ? 1 : 2);
+    const int persist_env = (int)tune(TUNE_PERSIST, tune(TUNE_ACQ_WG_PER_CU, 1) == 2 ? 1 : 2);
     // SLS_GATE_PHASE: start offset (ticks of the 100 MHz clock) between the two gate groups of an XCD; 0: one gate per XCD.
     // Measured per 65 536-candidate launch: phase 0 124.8 ms / 77 GB (hit rate 0.856); phase 2000..8000 123.2-123.3 ms /
     // 112 GB (0.795: each group of 8 x 4 tiles shares 12 panels); ungated 124.9 ms / 333 GB (0.42).
-    const char* eph = getenv("SLS_GATE_PHASE");
-    const int phase = eph ? atoi(eph) : 2000;
+    const int phase = (int)tune(TUNE_GATE_PHASE, 2000);
     const int prio = 0;   // (wave priority for one of a CU's two workgroups was a switch in rounds 2-3: no measurable effect, removed)
     // persistent, generation-gated form when there are at least two generations of tiles (MI355X: 256 CUs x 2 = 512 slots)
     // SLS_ACQ_WG_PER_CU (default 1): one workgroup per CU (a 96 KB LDS request keeps a second one out).  One wave per SIMD has
@@ -211,8 +208,7 @@ int launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk,
     // fabric traffic per 65 536-candidate launch.  Persistent workgroups walking their tile lists without gates are another
     // 0.25 % faster than one workgroup per tile (4293 / 4298 -> 4285 / 4282 ms): no workgroup launch between tiles.
     // 2 = two per CU, generation-gated (the round-1 form).
-    const char* ew = getenv("SLS_ACQ_WG_PER_CU");
-    const int wg_per_cu = (ew && atoi(ew) == 2) ? 2 : 1;
+    const int wg_per_cu = tune(TUNE_ACQ_WG_PER_CU, 1) == 2 ? 2 : 1;
     const int cap = 256 * wg_per_cu;                                 // tiles the chip holds at a time
     const int lds_bytes = wg_per_cu == 1 ? 96 * 1024 : GEMM_LDS_BYTES;
     ensure_dyn_lds((const void*)acq_gemm_kernel<false>, lds_bytes);
@@ -224,8 +220,7 @@ int launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk,
     // Tail split (SLS_TAIL_SPLIT=0 disables): the chip holds 512 tiles at a time; if the last such generation is at most half
     // full its tiles run as half tiles on twice the workgroups in a second launch (same bits, half the time for that
     // generation: 663 -> 642 ms per step on the 8 192-start shard of an 8-GPU run).
-    const char* et = getenv("SLS_TAIL_SPLIT");
-    const bool tail_ok = et ? atoi(et) != 0 : true;
+    const bool tail_ok = tune_on(TUNE_TAIL_SPLIT);
     const int rem = nt % cap;
     const int tail = (tail_ok && rem > 0 && rem <= cap / 2) ? rem : 0;
     const int nmain = nt - tail;
@@ -1075,8 +1070,7 @@ __global__ __launch_bounds__(64) void lbfgs_step_reg_kernel(LbfgsState st, const
 
 void launch_lbfgs_step(hipStream_t s, const LbfgsState& st, const double* val, const double* grad, bool first) {
     if (st.nlive <= 0) return;
-    const char* renv = getenv("SLS_LBFGS_REG");
-    const bool use_reg = renv ? atoi(renv) != 0 : true;
+    const bool use_reg = tune_on(TUNE_LBFGS_REG);
     const dim3 grid((st.nlive + 15) / 16), block(64);
     if (use_reg && st.D <= 16) hipLaunchKernelGGL(lbfgs_step_reg_kernel<4>, grid, block, 0, s, st, val, grad, (int)first);
     else if (use_reg && st.D <= 64) hipLaunchKernelGGL(lbfgs_step_reg_kernel<16>, grid, block, 0, s, st, val, grad, (int)first);

@@ -152,8 +152,7 @@ static void launch_tri_gemm64(hipStream_t s, const GemmDesc& g, int batches) {
 // pipe to itself (see launch_acq_gemm); measured for trtri at N = 8192: 3.44 -> 3.19 ms, for lauum no difference.
 // SLS_TRI_WG_PER_CU=1 / 2 forces either for every launch (A/B switch).
 static int tri_lds_bytes(bool one_per_cu) {
-    const char* e = getenv("SLS_TRI_WG_PER_CU");
-    if (e) one_per_cu = atoi(e) == 1;
+    if (tune_set(TUNE_TRI_WG_PER_CU)) one_per_cu = tune(TUNE_TRI_WG_PER_CU, 0) == 1;
     return one_per_cu ? 96 * 1024 : GEMM_LDS_BYTES;
 }
 template <bool A_KC, bool B_KC>
@@ -1559,10 +1558,6 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
 // are therefore ordered per device ON THE DEVICE: a launch on another stream than the previous one first makes its stream wait
 // for that launch's completion event (no host synchronisation; the mutex only covers wait + launch + record).  Processes
 // sharing a GPU are not covered; there the fallback + re-arm path takes over.
-static int envi(const char* n, int dflt) {
-    const char* v = getenv(n);
-    return v ? atoi(v) : dflt;
-}
 namespace {
 struct PersistSerial {
     std::mutex m;
@@ -1613,13 +1608,11 @@ struct PersistSerialScope {
 // Read per call: tests and A/B runs switch within one process.
 int potrf_default_mode(int Np) {
     (void)Np;
-    const char* e = getenv("SLS_POTRF_MODE");
-    return (e && atoi(e) == 0) ? 0 : SLS_POTRF_MODE_DEFAULT;
+    return tune(TUNE_POTRF_MODE, SLS_POTRF_MODE_DEFAULT) == 0 ? 0 : SLS_POTRF_MODE_DEFAULT;
 }
 
 int potrf_dataflow_nbo(int Np) {
-    const char* e = getenv("SLS_POTRF_DNBO");
-    if (e && atoi(e) >= 1) return std::min(8, atoi(e));
+    if (tune(TUNE_POTRF_DNBO, 0) >= 1) return (int)std::min(8L, tune(TUNE_POTRF_DNBO, 0));
     // measured (tools/probes/df_scan2.sh, TRSM chain; ms): N = 8192: nbo 2: 4.31, 3: 4.83, 4: 5.15 (4.36 with near = 4), 8 + near 4:
     // 4.71; N = 16384 (the workers are the limit: fewer read-modify-write passes win): 2: 26.1, 4: 24.0, 8 + near 3: 23.6 (62
     // TFLOP/s = 0.79 of peak); N = 4096: 1: 1.69, 2: 1.83
@@ -1669,13 +1662,13 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
     // the workers are as busy as the chain (4.16 -> 4.10-4.17): the round-3 form stays from N > 5120
     // Several problems per launch are bound by their workers, not by their chains (8 value-only evaluations at N = 4096: 6.4 ms on
     // the round-3 chain, 7.3 ms streamed): the round-3 form there too.
-    const int nchain = envi("SLS_POTRF_STREAM", nb <= 40 && nprob == 1 ? SLS_POTRF_STREAM_DEFAULT : 0) != 0 && nb >= 4 ? 2 : 1;
+    const int nchain = (int)tune(TUNE_POTRF_STREAM, nb <= 40 && nprob == 1 ? SLS_POTRF_STREAM_DEFAULT : 0) != 0 && nb >= 4 ? 2 : 1;
     // SLS_POTRF_SPLIT = band: the tiles (i, k) with 1 <= i - k <= band have one owner per 64-column half (0: whole tiles only)
     // Measured (tools/probes: ms at N = 2048 / 3072 / 4096): factorisation alone: band 1: 0.655 / 0.992 / 1.363, 4: 0.645 / 0.999 / 1.353,
     // all: 0.654 / 1.000 / 1.345 -- what matters is that every row's cycle is shorter than the chain's step, the solving workgroup then finds
     // its tile 14-22 us before the diagonal block ends at EVERY step (before: -4 .. +6 us at every third one).  With the fused
     // inverse sharing the chip: band 1: 0.742 / 1.284 / 2.158, all: 0.733 / 1.344 / 2.518 (CUs are short from N = 3072).
-    const int split_band = nchain == 2 ? std::max(0, std::min(nb - 1, envi("SLS_POTRF_SPLIT", (nb <= 16 || !inv) ? nb : 1))) : 0;
+    const int split_band = nchain == 2 ? std::max(0, std::min(nb - 1, (int)tune(TUNE_POTRF_SPLIT, (nb <= 16 || !inv) ? nb : 1))) : 0;
     const int split_sub = split_band >= 1 ? 1 : 0;
     int n_second = 0;
     for (int kk = 0; kk < nb; ++kk) n_second += std::min(split_band, nb - 1 - kk);
@@ -1689,7 +1682,7 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
         // 80: 2.22, 112: 2.26, 136: 2.56, 48: 3.05 (separate launches: 2.62); N = 3072: 1.46-1.50 for 80-112 (1.92);
         // N = 2048: 0.84-0.86 for 80-112, 0.89 for 135 (1.18); same bits for every split
         const int w1_dflt = std::min(tiles, std::max(3 * n_cu / 8, 3 * nb));
-        const int W1 = std::max(1, std::min(tiles, envi("SLS_POTRI_W1", w1_dflt)));
+        const int W1 = std::max(1, std::min(tiles, (int)tune(TUNE_POTRI_W1, w1_dflt)));
         Gp = nchain + W1;
         G2 = n_cu * ps.resident_per_cu - Gp;
         const int items = 2 * nb - 1 + nb * nb;                                         // T, P, X and K^-1 items
@@ -1703,10 +1696,10 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
     for (int q = 0; q < nprob; ++q) (void)hipMemsetAsync(sync + q * stride_sync, 0, sync_ints * sizeof(int), s);
     PersistArgs a;
     a.A = A; a.ld = Np; a.nb = nb; a.Linv = Linv; a.info = info; a.sync = sync;
-    a.timeout = envi("SLS_POTRF_TIMEOUT_TICKS", 20000000);   // 0.2 s of the 100 MHz wall clock (test hook: 1 makes every wait expire)
+    a.timeout = (int)tune(TUNE_POTRF_TIMEOUT_TICKS, 20000000);   // 0.2 s of the 100 MHz wall clock (test hook: 1 makes every wait expire)
     a.trace = trace;
     a.nbo = potrf_dataflow_nbo(Np);
-    a.near = envi("SLS_POTRF_DNEAR", Np >= 16384 ? 3 : 0);
+    a.near = (int)tune(TUNE_POTRF_DNEAR, Np >= 16384 ? 3 : 0);
     a.nprob = nprob; a.strideA = strideA; a.stride_sync = stride_sync;
     a.g1 = inv ? Gp : 0;
     a.U = inv ? inv->U : nullptr;
@@ -1716,9 +1709,9 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
     a.split_band = split_band;
     // measured (ms, factor + inverse; two products per row -> one): N = 384: 0.209 -> 0.234, 1024: 0.405 -> 0.411, 2048: 0.759 -> 0.753,
     // 3072: 1.466 -> 1.32, 4096: 2.15 -> 2.15 (there the two teams are short of CUs, not of time on the wavefront)
-    a.inv_plast = envi("SLS_POTRI_PLAST", nb >= 12 ? 1 : 0) != 0 ? 1 : 0;
-    a.inv_cx = std::max(1, std::min(8, envi("SLS_POTRI_CX", nb > 16 ? 2 : 1)));
-    a.inv_ck = std::max(1, std::min(8, envi("SLS_POTRI_CK", nb > 16 ? 2 : 1)));
+    a.inv_plast = (int)tune(TUNE_POTRI_PLAST, nb >= 12 ? 1 : 0) != 0 ? 1 : 0;
+    a.inv_cx = std::max(1, std::min(8, (int)tune(TUNE_POTRI_CX, nb > 16 ? 2 : 1)));
+    a.inv_ck = std::max(1, std::min(8, (int)tune(TUNE_POTRI_CK, nb > 16 ? 2 : 1)));
     {
         PersistSerialScope serial(ps, s);
         hipLaunchKernelGGL(potrf_dataflow_kernel, dim3(Gp * nprob + G2), dim3(256), DIAG_LDS_BYTES, s, a);
@@ -1775,8 +1768,7 @@ void potrf_aux_destroy(PotrfAux* aux) {
 }
 
 int potrf_default_nbo(int Np) {
-    const char* e = getenv("SLS_POTRF_NBO");
-    if (e && atoi(e) >= 1) return atoi(e);
+    if (tune(TUNE_POTRF_NBO, 0) >= 1) return (int)tune(TUNE_POTRF_NBO, 0);
     return Np >= 8192 ? 4 : 1;   // measured (tools/probes/potrf_bench): two-level pays from N = 8192 (10.4 -> 9.5 ms), not below
 }
 
@@ -1941,11 +1933,7 @@ void launch_lauum(hipStream_t s, const double* U, int Np, double* Kinv) {
     g.kmode = 3;
     g.order = 1;            // rows from the top, longest k range first, no idle workgroups
     // small matrices leave most workgroup slots empty: half tiles double the count (SLS_LAUUM_N64=0/1 overrides)
-    static int n64_env = -2;
-    if (n64_env == -2) {
-        const char* e = getenv("SLS_LAUUM_N64");
-        n64_env = e ? atoi(e) : -1;
-    }
+    const int n64_env = (int)tune(TUNE_LAUUM_N64, -1);
     // measured inside the C5 evaluation (N = 4096): 3.41 -> 3.24 ms per evaluation with half tiles (the longest tile's k loop,
     // 32 slabs of 13.6 us on a shared CU, bounds the launch); at N = 8192 whole tiles win (2.9 ms, 0.80 of peak)
     const bool narrow = n64_env >= 0 ? n64_env != 0 : nb <= 32;
@@ -1961,8 +1949,7 @@ void launch_lauum(hipStream_t s, const double* U, int Np, double* Kinv) {
 // multi-launch schedule (dataflow_sync = nullptr).
 bool potri_fused_applies(int Np, bool have_sync) {
     const int nb = Np / NB;
-    const char* e = getenv("SLS_POTRI_FUSED");
-    return (!e || atoi(e) != 0) && have_sync && nb >= 3 && nb <= 32 && potrf_default_mode(Np) == 3;
+    return tune_on(TUNE_POTRI_FUSED) && have_sync && nb >= 3 && nb <= 32 && potrf_default_mode(Np) == 3;
 }
 // linv_zeroed = false: the caller has NOT cleared Linv (the fused launch does not need it: it writes the diagonal tiles in full and
 // the tiles below them, and leaves the tiles above the diagonal alone); the separate launches clear it here.

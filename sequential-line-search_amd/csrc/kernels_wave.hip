@@ -569,13 +569,11 @@ size_t wave_lds_bytes(int D, int Np, int m, int* lds_per_wave, int* Dr) {
 void launch_maximize_wave(hipStream_t s, WaveArgs a) {
     size_t bytes = wave_lds_bytes(a.D, a.Np, a.m, &a.lds_per_wave, &a.Dr);
     // staging only for launches that leave the chip idle anyway (<= 64 workgroups): with many starts the occupancy is worth more
-    const char* senv = getenv("SLS_WAVE_STAGE");
-    const bool allow = (senv ? atoi(senv) != 0 : true) && a.S <= 256 && a.n_local > 1;
+    const bool allow = tune_on(TUNE_WAVE_STAGE) && a.S <= 256 && a.n_local > 1;
     // ONE start (the local phase of the DIRECT -> L-BFGS branch) on a problem of at most 128 points: the four waves of the
     // workgroup share every long sum (COOP) instead of shadowing each other
     const int R = a.N <= 64 ? 1 : a.Np / 64;
-    const char* cenv = getenv("SLS_WAVE_COOP");
-    const bool coop = a.S == 1 && a.n_local > 1 && R <= 2 && (cenv ? atoi(cenv) != 0 : true);
+    const bool coop = a.S == 1 && a.n_local > 1 && R <= 2 && tune_on(TUNE_WAVE_COOP);
     a.xch = coop ? 4 * 64 * 4 : 0;
     bytes += (size_t)a.xch * 8;
     // staged first-pass matrix: 16 ceil(N / 16) columns of K^-1, or of the symmetric image of L^-1 / L^-T (solve-based sigma)

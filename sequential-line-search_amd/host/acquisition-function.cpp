@@ -180,7 +180,7 @@ namespace sequential_line_search
         sls_gp*        h       = RequireHandle(regressor);
         // SLS_HOST_TIMING: where the time of one call goes (stderr) -- DIRECT's own bookkeeping on the host, its batched device
         // evaluations, the local phase
-        const bool timing = std::getenv("SLS_HOST_TIMING") != nullptr;
+        static const bool timing = std::getenv("SLS_HOST_TIMING") != nullptr;   // read once per process
         using clk         = std::chrono::steady_clock;
         double ms_dev = 0.0;
         int    batches = 0;

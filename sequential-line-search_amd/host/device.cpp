@@ -38,10 +38,12 @@ namespace sequential_line_search
             {
                 std::shared_ptr<MultiGpHandle> replicas;
                 std::shared_ptr<MultiRef>      multi;
-                long                           n_points = 0;
+                long                           generation = -1;   // sls_gp_generation of the primary the replicas were built from
             };
             std::mutex                       g_replica_mtx;
-            std::map<sls_gp*, ReplicaEntry>  g_replicas;
+            // never destroyed: static destructors run after the HIP runtime may have shut down, and an entry of a leaked or static
+            // regressor would then destroy device handles on a dead runtime (entries of destroyed regressors are erased by ~GpHandle)
+            std::map<sls_gp*, ReplicaEntry>& g_replicas = *new std::map<sls_gp*, ReplicaEntry>();
             long                             g_replica_builds = 0;
 
             void LoadDevicesFromEnv()
@@ -115,13 +117,18 @@ namespace sequential_line_search
             std::shared_ptr<MultiRef> multi = Multi();
             if (!multi || !primary) return nullptr;
             std::lock_guard<std::mutex> lock(g_replica_mtx);
+            (void)n_points;
+            // the primary's predictor generation changes with every fit, in-place refit (sls_gp_refit_dev through GetDeviceHandle()),
+            // appended point and sigma-mode switch: replicas built from an earlier state are never reused
+            long generation = 0;
+            Check(sls_gp_generation(primary, &generation), "sls_gp_generation");
             ReplicaEntry& e = g_replicas[primary];
-            if (!e.replicas || e.multi != multi || e.n_points != n_points)
+            if (!e.replicas || e.multi != multi || e.generation != generation)
             {
                 e.replicas.reset();
-                e.replicas = std::make_shared<MultiGpHandle>(multi, primary);
-                e.multi    = multi;
-                e.n_points = n_points;
+                e.replicas   = std::make_shared<MultiGpHandle>(multi, primary);
+                e.multi      = multi;
+                e.generation = generation;
                 ++g_replica_builds;
             }
             return e.replicas;

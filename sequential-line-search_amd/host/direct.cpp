@@ -81,8 +81,11 @@ namespace sequential_line_search
                 size_t Child(size_t src, size_t i, double shift, double value, size_t like)
                 {
                     const size_t r = size();
-                    c.insert(c.end(), c.begin() + src * n, c.begin() + (src + 1) * n);
-                    level.insert(level.end(), level.begin() + src * n, level.begin() + (src + 1) * n);
+                    // grow first, then copy by index: inserting a range of the vector into itself is undefined behaviour
+                    c.resize((r + 1) * n);
+                    level.resize((r + 1) * n);
+                    std::copy_n(c.data() + src * n, n, c.data() + r * n);
+                    std::copy_n(level.data() + src * n, n, level.data() + r * n);
                     c[r * n + i] += shift;
                     g.push_back(value);
                     Resize(r + 1);

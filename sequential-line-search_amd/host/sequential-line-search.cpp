@@ -82,7 +82,7 @@ namespace sequential_line_search
 
         m_data->AddNewPoints(x_chosen, {x_prev_max, x_prev_ei}, true);
 
-        const bool timing = std::getenv("SLS_HOST_TIMING") != nullptr;   // stderr: ms in the MAP fit / in the acquisition maximiser
+        static const bool timing = std::getenv("SLS_HOST_TIMING") != nullptr;   // once per process; stderr: ms in the MAP fit / in the maximiser
         const auto t0     = std::chrono::steady_clock::now();
         m_regressor = std::make_shared<PreferenceRegressor>(m_data->GetX(), m_data->GetD(), m_use_map_hyperparams, m_kernel_signal_var,
                                                             m_kernel_length_scale, m_noise_level, m_kernel_hyperparams_prior_var,

@@ -27,6 +27,28 @@ def pytest_sessionfinish(session, exitstatus):
         pass
 
 
+@pytest.fixture(autouse=True)
+def _sls_tuning(monkeypatch):
+    """libsls_hip parses its SLS_* switches once per process (csrc/tuning.hpp); tests switch them with monkeypatch.setenv /
+    delenv (or os.environ + util.tuning_reload()).  Here: every change made through monkeypatch re-reads them at once, and every
+    test starts from the environment as it is (the previous test's changes are undone by then)."""
+    from util import tuning_reload
+    tuning_reload()
+    setenv, delenv = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv_and_reload(name, value, *a, **k):
+        setenv(name, value, *a, **k)
+        if name.startswith("SLS_"):
+            tuning_reload()
+
+    def delenv_and_reload(name, *a, **k):
+        delenv(name, *a, **k)
+        if name.startswith("SLS_"):
+            tuning_reload()
+    monkeypatch.setenv, monkeypatch.delenv = setenv_and_reload, delenv_and_reload
+    yield
+
+
 @pytest.fixture(scope="session")
 def fixtures():
     import json

@@ -10,7 +10,7 @@ import time
 import numpy as np
 import pytest
 
-from util import record, sls, synth_candidates, synth_problem
+from util import env_switch, record, sls, synth_candidates, synth_problem
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -106,11 +106,8 @@ def test_c5_evaluation_and_batch_budget(ctx, oracle):
     ms_eval = best_of(ev, 4, ctx.synchronize)
     xs = np.tile(x, (8, 1)); xs[:, 2] *= 1 + 1e-3 * np.arange(8)
     ms_batch = best_of(lambda: h.gp_objective_batch(y, xs), 3, ctx.synchronize)
-    os.environ["SLS_NLL_BATCH"] = "0"
-    try:
+    with env_switch("SLS_NLL_BATCH", 0):
         ms_seq = best_of(lambda: h.gp_objective_batch(y, xs), 1, ctx.synchronize)
-    finally:
-        del os.environ["SLS_NLL_BATCH"]
     h.close()
     record("budget", config="C5", ms_per_evaluation=ms_eval, batch8_ms=ms_batch, sequential8_ms=ms_seq, speedup=ms_seq / ms_batch)
     assert ms_eval <= 3.6, ms_eval

@@ -16,7 +16,7 @@ import os
 import numpy as np
 import pytest
 
-from util import sls, synth_problem
+from util import env_switch, sls, synth_problem
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -39,15 +39,8 @@ def random_prefs(rng, M, n_prefs, sizes=(2, 3, 4, 5)):
 
 def host_path(fn):
     """Run fn with SLS_MAP_DEVICE=0: BTL terms on the host, optimiser on the host (the pre-round-4 path)."""
-    old = os.environ.get("SLS_MAP_DEVICE")
-    os.environ["SLS_MAP_DEVICE"] = "0"
-    try:
+    with env_switch("SLS_MAP_DEVICE", 0):
         return fn()
-    finally:
-        if old is None:
-            del os.environ["SLS_MAP_DEVICE"]
-        else:
-            os.environ["SLS_MAP_DEVICE"] = old
 
 
 @pytest.mark.parametrize("kernel", [0, 1])
@@ -83,6 +76,49 @@ def test_device_btl_objective_and_gradient_vs_oracle(ctx, oracle, kernel, use_ma
         v_only = h.pref_objective(prefs, x, use_map=use_map, btl_scale=btl_scale, want_grad=False)
         assert v_only == v
     h.close()
+
+
+@pytest.mark.parametrize("kernel", [0, 1])
+@pytest.mark.parametrize("M,D", [(30, 4), (60, 32), (91, 32), (64, 100)])
+def test_matrix_core_form_and_direct_difference_form_agree(ctx, oracle, kernel, M, D):
+    """Round 5: when the centred design matrix fits beside the N x N image in LDS, the one-workgroup kernels build the Gram matrix
+    and the length-scale gradient on the matrix cores (norm expansion, Y = G X); otherwise -- and with SLS_SMALL_XLDS=0 -- they form
+    the coordinate differences directly from global memory.  Both against the oracle (1e-9) and against each other (1e-10): the
+    preference objective with hyper-parameters, the GP marginal likelihood, and the fitted predictor of a GP handle."""
+    rng = np.random.default_rng(7 * M + D + kernel)
+    X = rng.uniform(0, 1, (D, M))
+    prefs = random_prefs(rng, M, max(3, M // 2))
+    y = rng.normal(size=M) * 0.3
+    hyp = np.concatenate([[rng.uniform(0.2, 1.0), rng.uniform(1e-3, 1e-2)], rng.uniform(0.3, 1.5, D)])
+    x = np.concatenate([y, hyp])
+    Q = rng.uniform(0, 1, (D, 17))
+    theta = np.concatenate([[hyp[0]], hyp[2:]])
+
+    def run():
+        h = sls().Nll(ctx, X, kernel)
+        v, g = h.pref_objective(prefs, x, use_map=True)
+        vg, gg = h.gp_objective(y, hyp)
+        h.close()
+        gp = sls().GP(ctx, X, y, theta, hyp[1], kernel)
+        mu, sg = gp.predict(Q)
+        gp.close()
+        return v, g, vg, gg, mu, sg
+    fast = run()
+    with env_switch("SLS_SMALL_XLDS", 0):
+        direct = run()
+    vo, go = oracle.pref_objective(kernel, X, prefs, x, use_map=True)
+    vgo, ggo = oracle.gp_map_objective(kernel, X, y, hyp)
+    ref = oracle.Regressor(X, y, theta, hyp[1], kernel=kernel)
+    mu_o, sg_o = ref.predict_batch(Q)
+    for (v, g, vg, gg, mu, sg), tol in ((fast, 1e-9), (direct, 1e-9)):
+        assert abs(v - vo) <= tol * max(1.0, abs(vo)) and abs(vg - vgo) <= tol * max(1.0, abs(vgo))
+        np.testing.assert_allclose(g, go, rtol=tol, atol=tol * max(1.0, np.abs(go).max()))
+        np.testing.assert_allclose(gg, ggo, rtol=tol, atol=tol * max(1.0, np.abs(ggo).max()))
+        np.testing.assert_allclose(mu, mu_o, rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(sg, sg_o, rtol=1e-7, atol=1e-10)
+    assert abs(fast[0] - direct[0]) <= 1e-10 * max(1.0, abs(vo)) and abs(fast[2] - direct[2]) <= 1e-10 * max(1.0, abs(vgo))
+    np.testing.assert_allclose(fast[1], direct[1], rtol=1e-10, atol=1e-10 * max(1.0, np.abs(go).max()))
+    np.testing.assert_allclose(fast[3], direct[3], rtol=1e-10, atol=1e-10 * max(1.0, np.abs(ggo).max()))
 
 
 def test_device_btl_overflows_like_the_reference(ctx, oracle):
@@ -290,15 +326,8 @@ def test_value_only_batch_runs_concurrent_bordered_factorisations(ctx, oracle, k
     vals = h.gp_objective_batch(y, xs)
     single = np.array([h.gp_objective_batch(y, xs[k:k + 1])[0] for k in range(B)])
     assert np.array_equal(vals, single)
-    old = os.environ.get("SLS_NLL_BATCH")
-    os.environ["SLS_NLL_BATCH"] = "0"
-    try:
+    with env_switch("SLS_NLL_BATCH", 0):
         full = h.gp_objective_batch(y, xs)                   # one full evaluation (K^-1, alpha) after the other
-    finally:
-        if old is None:
-            del os.environ["SLS_NLL_BATCH"]
-        else:
-            os.environ["SLS_NLL_BATCH"] = old
     orc = np.array([oracle.gp_map_objective(kernel, X, y, xs[k], want_grad=False) for k in range(B)])
     scale = np.maximum(1.0, np.abs(orc))
     assert np.max(np.abs(vals - full) / scale) <= 1e-10, np.max(np.abs(vals - full) / scale)

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from util import assert_starts_agree, relerr, sls, synth_candidates, synth_problem
+from util import assert_starts_agree, oracle_end_value_sensitivity, relerr, sls, synth_candidates, synth_problem
 
 pytestmark = pytest.mark.gpu
 
@@ -466,10 +466,16 @@ def test_active_set_compaction_is_bit_identical(ctx, oracle, kernel, D, N, S, n_
         # same end points as the oracle's all-starts-every-round loop
         ro = oracle.Regressor(X, y, theta, b, kernel=kernel).acq_maximize(starts, n_local, diag=True) if N <= 300 else None
         if ro is not None:
-            # same-basin clause ON here, and only here in this module: the one start on record (profiles/r03_test_evidence.json,
-            # N = 300, Matern) ends 1.1e-6 (relative) from the oracle's value -- agreement just past the 1e-6 line after 30
-            # rounds of identical statements with different summation order, not another optimum (its Armijo margin is 4.9e-3)
-            assert_starts_agree(dict(y_stars=a[0]), ro, label=f"compaction N={N} kernel={kernel}", allow_basin=True, basin_rtol=1e-5)
+            # The one start on record here (N = 300, Matern, start 50: 8.2e-7 of the largest end value, 1.1e-6 of its own, from the
+            # oracle; Armijo margin 1.1e-2) was examined on the CPU in round 5 (profiles/r05_start50_probe.log): no discrete
+            # decision flips -- the trajectory bounces between faces of the box (its active set changes in 14 of the 30 rounds, it
+            # sits in a corner with all six bounds active at round 3) and is still climbing steeply when the budget ends (0.0796 ->
+            # 0.0814 in the last round); the ORACLE's own end value of this start moves by 2.4e-7 under one ulp of the start and by
+            # 7.0e-7 under 256 ulps of the signal variance, not monotonically.  The former "same basin" escape is replaced by that
+            # measurement: the gap must be within twice the band the oracle itself shows.
+            def probe(i):
+                return oracle_end_value_sensitivity(oracle, X, y, theta, b, kernel, starts, i, n_local, 0, 1.0, ro)
+            assert_starts_agree(dict(y_stars=a[0]), ro, label=f"compaction N={N} kernel={kernel}", ulp_probe=probe, max_divergent=2)
             close(a[2], ro["value"], rtol=RTOL)
     gp.close()
     if g2 is not None:

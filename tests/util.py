@@ -1,11 +1,40 @@
 """Synthetic inputs of SURVEY.md 8(d) / BASELINE.md 3 (same seeded SplitMix64 generator as the oracle's C side)."""
+import contextlib
 import importlib
+import os
 
 import numpy as np
 
 
 def sls():
     return importlib.import_module("sequential-line-search_amd")
+
+
+def tuning_reload():
+    """Make the library re-read its SLS_* environment switches (no-op when the library cannot be loaded: CPU-only oracle tests)."""
+    try:
+        sls().tuning_reload()
+    except OSError:
+        pass
+
+
+@contextlib.contextmanager
+def env_switch(name, value):
+    """Set (value = None: unset) one SLS_* switch for the duration of a with block; the library re-reads its switches on both edges."""
+    old = os.environ.get(name)
+    if value is None:
+        os.environ.pop(name, None)
+    else:
+        os.environ[name] = str(value)
+    tuning_reload()
+    try:
+        yield
+    finally:
+        if old is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = old
+        tuning_reload()
 
 
 def synth_problem(oracle, D, N, seed=1234, lengthscale=None):
@@ -65,24 +94,50 @@ def record(kind, **payload):
     EVIDENCE.append(dict(kind=kind, **payload))
 
 
-def assert_starts_agree(rg, ro, min_frac=0.95, margin_tol=1e-6, basin_rtol=1e-3, label="", max_divergent=None, allow_basin=False,
-                        ulp_probe=None, atol_scale=1e-12):
+def oracle_end_value_sensitivity(oracle, X, y, theta, b, kernel, starts, i, n_local, acq, ucb_h, ro, ulps=(1, 8, 64, 256)):
+    """How far the ORACLE's own end value of start i moves (relative to the largest end value) when (a) the start and (b) the model
+    (signal variance, noise level) change by a few units in the last place -- what a different summation order anywhere in the fit
+    or in an evaluation amounts to (sums over N terms differ by up to ~N ulps between the device and the oracle).  A start whose
+    trajectory runs along the box boundary (its active set changes every other round) or crawls along a flat ridge for its whole
+    budget does not reproduce its end value to 1e-6 under such changes although none of its Armijo tests is near its threshold:
+    measured for start 50 of the compaction case N = 300, Matern (14 active-set changes in 30 rounds, value still tripling):
+    2.4e-7 (one ulp of the start) .. 7.0e-7 (256 ulps of the signal variance), not monotone in the size of the perturbation."""
+    scale = max(np.abs(ro["y_stars"]).max(), 1e-300)
+    base = ro["y_stars"][i]
+    ref = oracle.Regressor(X, y, theta, b, kernel=kernel)
+    worst = 0.0
+    for n_ulp in ulps:
+        for toward in (0.5, 2.0, -1.0):
+            s1 = starts[:, i:i + 1].copy()
+            for _ in range(n_ulp):
+                s1[:, 0] = np.nextafter(s1[:, 0], toward)
+            worst = max(worst, abs(ref.acq_maximize(s1, n_local, acq, ucb_h, diag=True)["y_stars"][0] - base) / scale)
+        for which, toward in ((0, 2.0), (0, 0.0), (1, 1.0), (1, 0.0)):
+            th1, b1 = np.array(theta, dtype=float), float(b)
+            for _ in range(n_ulp):
+                if which == 0:
+                    th1[0] = np.nextafter(th1[0], toward)
+                else:
+                    b1 = float(np.nextafter(b1, toward))
+            r1 = oracle.Regressor(X, y, th1, b1, kernel=kernel).acq_maximize(starts[:, i:i + 1], n_local, acq, ucb_h, diag=True)
+            worst = max(worst, abs(r1["y_stars"][0] - base) / scale)
+    return worst
+
+
+def assert_starts_agree(rg, ro, min_frac=0.95, margin_tol=1e-6, label="", max_divergent=None, ulp_probe=None, atol_scale=1e-12):
     """Per-start end values of the HIP maximiser (rg) against the oracle run with diag=True (ro).
 
     Both sides run the same bounded L-BFGS statement by statement; they differ only in summation order.  A start can end
     elsewhere only where a DISCRETE decision of the algorithm sat within rounding of its threshold and the two sides took
-    different branches: the Armijo test  ft <= f + c1 g.s  (measured on MI355X: 1 of 96 starts, margin 3.5e-9;
-    tools/diverging_starts.py), or a clamp / active-bound / curvature test of a start that runs along the box boundary.
+    different branches -- the Armijo test  ft <= f + c1 g.s  (measured on MI355X: 1 of 96 starts, margin 3.5e-9;
+    tools/diverging_starts.py) -- or where the trajectory itself amplifies rounding (a start that bounces between faces of the box).
     Asserted: at least `min_frac` of the starts agree to 1e-6 (and at most `max_divergent` differ, when given); a start that
-    does not agree has a near-threshold Armijo test on the oracle side (relative margin < margin_tol) or -- only where the
-    caller asks for it with `allow_basin=True` and says why (round 4: off by default) -- still ends in the same basin (within
-    basin_rtol).  The chosen maximiser itself is held to 1e-6 by the
-    callers.  `ulp_probe(i)` (randomised sweeps): the largest relative change of the ORACLE's own end value of start i when the
-    start moves by one ulp -- a start whose trajectory runs along the box boundary can be rounding-sensitive through its clamp /
-    active-bound / curvature tests, which the Armijo margin does not see; it is accepted if the oracle itself does not
-    reproduce its end value to 1e-6 under that perturbation (seed 181 of tests/test_gpu_stress.py: 2.8e-3).  Every call leaves
-    a record (count, indices, margins of the divergent starts) in the session's evidence file, so that a drift of the
-    divergence rate is visible from run to run."""
+    does not agree has a near-threshold Armijo test on the oracle side (relative margin < margin_tol), or -- when the caller
+    supplies `ulp_probe(i)` = oracle_end_value_sensitivity of start i -- the ORACLE does not reproduce its own end value any
+    better under last-place changes of the start and the model: the gap to the device must be within twice that band (or the band
+    itself beyond 1e-6).  There is no "same basin" escape (round 5: removed).  The chosen maximiser itself is held to 1e-6 by the
+    callers.  Every call leaves a record (count, indices, margins, probe results of the divergent starts) in the session's
+    evidence file, so that a drift of the divergence rate is visible from run to run."""
     scale = max(np.abs(ro["y_stars"]).max(), 1e-300)
     # atol_scale: absolute floor relative to the LARGEST end value.  EI = sigma (u Phi(u) + phi(u)) cancels for u << 0: an end point
     # whose value is 1e-5 of the largest one carries the posterior's 1e-11 as 1e-6 of its own value (randomised sweeps pass 1e-10)
@@ -95,14 +150,15 @@ def assert_starts_agree(rg, ro, min_frac=0.95, margin_tol=1e-6, basin_rtol=1e-3,
     if max_divergent is not None:
         assert bad.size <= max_divergent, f"{bad.size} divergent starts (bound {max_divergent}): {bad[:16]}"
     for i in bad:
-        near = allow_basin and np.isclose(rg["y_stars"][i], ro["y_stars"][i], rtol=basin_rtol, atol=1e-9 * scale)
-        if not (ro["armijo_margin"][i] < margin_tol or near) and ulp_probe is not None:
+        if ro["armijo_margin"][i] < margin_tol:
+            continue
+        gap = float(abs(rg["y_stars"][i] - ro["y_stars"][i]) / scale)
+        if ulp_probe is not None:
             sens = float(ulp_probe(int(i)))
-            record("starts_ulp_probe", label=label, start=int(i), oracle_change_under_one_ulp=sens,
-                   rel_gap=float(abs(rg["y_stars"][i] - ro["y_stars"][i]) / scale))
-            if sens > 1e-6:
+            record("starts_ulp_probe", label=label, start=int(i), oracle_change_under_last_place_perturbations=sens, rel_gap=gap)
+            if sens > 1e-6 or gap <= 2.0 * sens:
                 continue
-        assert ro["armijo_margin"][i] < margin_tol or near, (
-            f"start {i} ends at {rg['y_stars'][i]!r} vs oracle {ro['y_stars'][i]!r}: " + ("not the same basin, and " if allow_basin else "")
-            + f"no Armijo test was closer than {ro['armijo_margin'][i]:.2e} to its threshold")
+        assert False, (f"start {i} ends at {rg['y_stars'][i]!r} vs oracle {ro['y_stars'][i]!r} (gap {gap:.2e} of the largest value): no Armijo "
+                       f"test was closer than {ro['armijo_margin'][i]:.2e} to its threshold" +
+                       ("" if ulp_probe is None else " and the oracle reproduces its own end value better than that under last-place changes"))
     return agree

@@ -27,6 +27,7 @@ sls = importlib.import_module("sequential-line-search_amd")
 
 def analyse(ctx, D, N, S, n_local, kernel, acq, wave):
     os.environ["SLS_WAVE_PATH"] = "1" if wave else "0"
+    sls.tuning_reload()
     X, y, theta, b = synth_problem(orc, D, N)
     starts = synth_candidates(orc, D, S)
     ref = orc.Regressor(X, y, theta, b, kernel=kernel)

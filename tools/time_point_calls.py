@@ -7,7 +7,7 @@ X, y, theta, b = synth_problem(oracle, 8, 60)
 gp = m.GP(ctx, X, y, theta, b, 1)
 xs1 = synth_candidates(oracle, 8, 1); xs = synth_candidates(oracle, 8, 1000)
 for flag in ("1", "0"):
-    os.environ["SLS_WAVE_PATH"] = flag
+    os.environ["SLS_WAVE_PATH"] = flag; m.tuning_reload()
     for name, f in (("predict M=1", lambda: gp.predict(xs1)), ("acq_eval+grad M=1", lambda: gp.acq_eval(xs1)), ("acq_eval+grad M=1000", lambda: gp.acq_eval(xs))):
         f(); t0 = time.perf_counter()
         for _ in range(200): f()
