@@ -48,6 +48,9 @@ def parse():
     p.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                    help="collective backend; gloo + --same-device exercises the N>1 path on a 1-GPU box (tests only)")
     p.add_argument("--same-device", action="store_true", help="all ranks use GPU 0 (tests only; never a bench line)")
+    p.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes behind roofline.traffic")
+    p.add_argument("--traffic-child", action="store_true",
+                   help="internal: what measure_traffic() runs under rocprofv3 (one fit + a few full-shape rounds of the maximiser)")
     return p.parse_args()
 
 
@@ -110,6 +113,77 @@ def parity_vs_oracle(sls, ctx, kernel_id, o):
     return out, max(out["mu"], out["sigma"], out["y_stars"], out["best_value"])
 
 
+def traffic_child(args):
+    """One fit + a 4-evaluation maximiser run of the SAME library, shapes and launch parameters as the timed region, with
+    SLS_COMPACT=0 (set by the parent): every acq_gemm launch has the full candidate shape.  Runs under rocprofv3 --pmc."""
+    import torch
+    sls = importlib.import_module("sequential-line-search_amd")
+    kernel_id = sls.KERNEL_MATERN52 if args.kernel == "matern52" else sls.KERNEL_SE
+    X, y, theta, b, starts = synth(args.d, args.n, args.starts)
+    torch.cuda.set_device(0)
+    ctx = sls.Context(0)
+    ctx.set_candidate_chunk(args.chunk)
+    gp = sls.GP(ctx, X, y, theta, b, kernel_id)
+    gp.acq_maximize(starts, 4)
+    gp.close()
+    ctx.close()
+
+
+def measure_traffic(args):
+    """roofline.traffic: memory-side bytes of ONE full-shape acq_gemm launch, from two rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE do not fit one pass: MI355X_MICROARCH.md "rocprofv3 PMC slots") over a child run of this same script and library.
+    Corrections as that guide prescribes: FETCH_SIZE (KB) x 2 on gfx950 for wide coalesced reads (the kernel's loads are
+    global_load_lds_dwordx4, 16 B per lane), WRITE_SIZE (KB) as reported.  The counters sit on the L2's fabric side: Infinity-Cache
+    hits are included, so the figure is an upper bound on DRAM traffic.  Returns (bytes or None, detail dict)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, {"skipped": "rocprofv3 not found"}
+    raw, dur, n_launch = {}, [], 0
+    child = [sys.executable, os.path.abspath(__file__), "--traffic-child", "--num-train", str(args.n), "--dims", str(args.d),
+             "--starts", str(args.starts), "--kernel", args.kernel, "--chunk", str(args.chunk)]
+    env = dict(os.environ, SLS_COMPACT="0", TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="sls_pmc_", dir="/tmp")
+        try:
+            p = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "pmc", "--output-format", "csv", "--"] + child,
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if p.returncode != 0 or not files:
+                return None, {"skipped": f"rocprofv3 --pmc {counter} failed (rc {p.returncode}): {(p.stderr or p.stdout)[-300:]}"}
+            per = {}
+            for r in csv.DictReader(open(files[0])):
+                if "acq_gemm_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                    k = r["Dispatch_Id"]
+                    e = per.setdefault(k, [0.0, int(r["Grid_Size"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])])
+                    e[0] += float(r["Counter_Value"])
+            if not per:
+                return None, {"skipped": f"no acq_gemm_kernel dispatch in the {counter} pass"}
+            gmax = max(v[1] for v in per.values())
+            full = [v for v in per.values() if v[1] == gmax]
+            raw[counter] = sum(v[0] for v in full) / len(full)
+            dur += [v[2] for v in full]
+            n_launch = len(full)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    N = args.n
+    cand = min(args.chunk, (args.starts + 127) // 128 * 128)
+    fetch_b, write_b = raw["FETCH_SIZE"] * 1024.0 * 2.0, raw["WRITE_SIZE"] * 1024.0
+    alg = 2.0 * cand * N * 8 + N * N * 8.0 + cand * N * 8.0        # read K*, C*; read K^-1 once; write P (DESIGN.md 4)
+    detail = {"candidates_per_launch": cand, "launches_measured": n_launch, "avg_launch_ms_under_profiler": sum(dur) / len(dur) / 1e6,
+              "FETCH_SIZE_KB_raw": raw["FETCH_SIZE"], "WRITE_SIZE_KB_raw": raw["WRITE_SIZE"], "fetch_bytes_corrected": fetch_b,
+              "write_bytes": write_b, "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": (fetch_b + write_b) / alg,
+              "correction": "FETCH_SIZE x 2 (gfx950, 16 B/lane coalesced reads), WRITE_SIZE as reported; fabric-side counters: "
+                            "Infinity-Cache hits included (upper bound on DRAM traffic)",
+              "command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE> --kernel-trace -- python bench.py --traffic-child ... (SLS_COMPACT=0: "
+                         "every launch has the full candidate shape), run by this bench.py after its timed region"}
+    return fetch_b + write_b, detail
+
+
 def baseline_metric():
     """BASELINE.json's metric string, verbatim (value = its candidate-evals/sec part, ms_per_step = its step-time part)."""
     try:
@@ -158,7 +232,8 @@ def canonical_argv(args):
     out = ["--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--num-train", str(args.n),
            "--dims", str(args.d), "--starts", str(args.starts), "--n-local", str(args.n_local), "--kernel", args.kernel,
            "--chunk", str(args.chunk), "--backend", args.backend]
-    return out + (["--no-cpu-baseline"] if args.no_cpu_baseline else []) + (["--same-device"] if args.same_device else [])
+    return (out + (["--no-cpu-baseline"] if args.no_cpu_baseline else []) + (["--same-device"] if args.same_device else []) +
+            (["--no-traffic"] if args.no_traffic else []))
 
 
 def self_spawn(args):
@@ -179,6 +254,8 @@ def self_spawn(args):
 
 def main():
     args = parse()
+    if args.traffic_child:
+        return traffic_child(args)
     import torch
     import torch.distributed as dist
 
@@ -317,19 +394,10 @@ def main():
         flops_total = 2.0 * N * N * issued_rank0
         achieved = flops_total / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         avg_ms = gemm_ms / max(gemm_launches, 1)
-        # roofline.traffic is null: HBM traffic needs a separate rocprofv3 --pmc pass (MI355X_MICROARCH.md) and is not measured in
-        # this run.  The last PMC pass of the same launch shape is quoted beside it, labelled as what it is.
-        traffic_ref = None
-        for name in ("r04b_pmc_acq_gemm.json", "r04_pmc_acq_gemm.json", "r03_pmc_acq_gemm.json", "r02_pmc_acq_gemm.json"):
-            pmc = os.path.join(ROOT, "profiles", name)
-            if os.path.exists(pmc) and (N, D) == (8192, 64):
-                try:
-                    pj = json.load(open(pmc))
-                    traffic_ref = {"hbm_bytes_per_launch": pj.get("hbm_bytes_per_launch"), "candidates_per_launch": pj.get("candidates_per_launch"),
-                                   "source": f"profiles/{name} (separate PMC pass, NOT this run)"}
-                    break
-                except Exception:
-                    traffic_ref = None
+        # roofline.traffic: measured by THIS run, behind the timed region: two rocprofv3 --pmc passes over a child that runs the same
+        # library at the same shapes (measure_traffic); bytes per full-shape launch (achieved is per launch of the timed region,
+        # whose launches shrink with the active set: traffic_detail.candidates_per_launch says what the figure belongs to)
+        traffic, traffic_detail = (None, {"skipped": "--no-traffic / multi-GPU run"}) if (args.no_traffic or world > 1) else measure_traffic(args)
         out = {
             "metric": baseline_metric(),
             "value": evals_issued / (ms_per_step * 1e-3), "unit": "candidate-evals/s", "n_gpus": world, "steps": args.steps,
@@ -343,10 +411,11 @@ def main():
                        "evals_cap_per_step": evals_cap, "evals_issued_per_step": evals_issued,
                        "evals_semantics": "n_local is a cap per start (NLopt max_evals); finished starts leave the batch",
                        "acq_gemm_form": ("2 workgroups per CU, persistent, generation-gated" if os.environ.get("SLS_ACQ_WG_PER_CU") == "2"
-                                         else "1 workgroup per CU, persistent, ungated") + " (SLS_ACQ_WG_PER_CU / SLS_PERSIST)"},
+                                         else "1 workgroup per CU, persistent, gated every 16th generation")
+                                        + " (defaults; SLS_ACQ_WG_PER_CU / SLS_PERSIST / SLS_GATE_EVERY)"},
             "roofline": {"bound": "mfma", "kernel": "acq_gemm_kernel", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
-                         "traffic_reference": traffic_ref, "avg_launch_ms": avg_ms, "launches": gemm_launches,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "bytes per full-shape launch", "traffic_detail": traffic_detail, "avg_launch_ms": avg_ms, "launches": gemm_launches,
                          "flops_total": flops_total, "candidates_per_launch_avg": issued_rank0 / max(gemm_launches, 1)},
             "stage_ms_per_step": {n: prof[n][0] / args.steps for n in names},
             "stage_rooflines": stage_rooflines(prof, N, D, Np, issued_rank0 / max(prof["cross_gram"][1], 1), args.kernel == "matern52"),

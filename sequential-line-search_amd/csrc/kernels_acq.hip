@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256, 1) void acq_gemm_kernel(const double* __restri
                                                           int Sp, const double* __restrict__ Kinv, int Np,
                                                           double* __restrict__ P, double* __restrict__ kw_part,
                                                           double* __restrict__ cw_part, int* __restrict__ sync,
-                                                          int phase, int ntiles, int prio) {
+                                                          int phase, int ntiles, int prio, int gate_every) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
     const int ntm = Sp / GEMM_BM, ntn = Np / GEMM_BN;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256, 1) void acq_gemm_kernel(const double* __restri
     }
     int gen = 0;
     for (int c = xcd; c < nchunks; c += 8, ++gen) {
-        if (gen > 0 && phase >= 0) {   // phase < 0: persistent but ungated (SLS_PERSIST=2)
+        if (gen > 0 && phase >= 0 && gen % gate_every == 0) {   // phase < 0: persistent but ungated (SLS_PERSIST=2)
             if (threadIdx.x == 0) {
                 const int target = per_gen * gen;
                 const long long t0 = wall_clock64();
@@ -193,19 +193,25 @@ int launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk,
     // SLS_PERSIST (0: one tile per workgroup, 1: persistent workgroups with generation gates, 2: persistent without gates;
     // default 1 with two workgroups per CU, 2 with one, see below) is read per call so that tests and A/B runs can switch
     // within one process
-    const int persist_env = (int)tune(TUNE_PERSIST, tune(TUNE_ACQ_WG_PER_CU, 1) == 2 ? 1 : 2);
+    const int persist_env = (int)tune(TUNE_PERSIST, 1);
     // SLS_GATE_PHASE: start offset (ticks of the 100 MHz clock) between the two gate groups of an XCD; 0: one gate per XCD.
     // Measured per 65 536-candidate launch: phase 0 124.8 ms / 77 GB (hit rate 0.856); phase 2000..8000 123.2-123.3 ms /
     // 112 GB (0.795: each group of 8 x 4 tiles shares 12 panels); ungated 124.9 ms / 333 GB (0.42).
-    const int phase = (int)tune(TUNE_GATE_PHASE, 2000);
+    const int phase = (int)tune(TUNE_GATE_PHASE, tune(TUNE_ACQ_WG_PER_CU, 1) == 2 ? 2000 : 0);
+    // SLS_GATE_EVERY: the workgroups of an XCD meet at a gate only every n-th generation.  Round 5, one workgroup per CU, per
+    // 65 536-candidate launch (bench.py's own measurement, tools/ab_acq_gemm_forms.sh): ungated 4198.6 ms per step / 164 GB of
+    // fabric traffic; gated every generation 4235 / 116; every 4th 4230 / 116; every 16th 4199.5 / 116.2; every 32nd 4200 / 118;
+    // every 64th 4202 / 128.  The sharers of a panel drift apart slowly: meeting every 16 tiles keeps them inside the L2 window
+    // (-29 % traffic) and costs nothing measurable.
+    const int gate_every = std::max(1, (int)tune(TUNE_GATE_EVERY, tune(TUNE_ACQ_WG_PER_CU, 1) == 2 ? 1 : 16));
     const int prio = 0;   // (wave priority for one of a CU's two workgroups was a switch in rounds 2-3: no measurable effect, removed)
     // persistent, generation-gated form when there are at least two generations of tiles (MI355X: 256 CUs x 2 = 512 slots)
     // SLS_ACQ_WG_PER_CU (default 1): one workgroup per CU (a 96 KB LDS request keeps a second one out).  One wave per SIMD has
     // the MFMA pipe to itself -- two waves alternating on it lose ~3 % to the switches (gemm_probe_ring, 16384 x 8192 x 8192:
     // 76.8 TFLOP/s = the MFMA-only loop's rate, against 75.0 with two workgroups per CU).  The tile epilogues are then hidden by
-    // nobody, which is why this form runs UNGATED (with generation gates 0.9455 of peak, without 0.9587; two workgroups per
-    // CU, gated: 0.9502; bench step 4349 -> 4311 ms, 8 192-start shard 584.7 -> 574.9 ms), at 156-161 instead of 120 GB of
-    // fabric traffic per 65 536-candidate launch.  Persistent workgroups walking their tile lists without gates are another
+    // nobody, which is why a gate in front of EVERY tile costs this form 0.3-1.4 % (rounds 3-4 therefore ran it ungated, at
+    // 156-164 instead of 116 GB of fabric traffic per 65 536-candidate launch); round 5: a gate every 16th tile (SLS_GATE_EVERY)
+    // keeps the traffic of the gated form at the speed of the ungated one.  Persistent workgroups walking their tile lists without gates are another
     // 0.25 % faster than one workgroup per tile (4293 / 4298 -> 4285 / 4282 ms): no workgroup launch between tiles.
     // 2 = two per CU, generation-gated (the round-1 form).
     const int wg_per_cu = tune(TUNE_ACQ_WG_PER_CU, 1) == 2 ? 2 : 1;
@@ -235,10 +241,10 @@ int launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk,
     if (nmain > 0) {
         if (matern)
             hipLaunchKernelGGL(acq_gemm_kernel<true>, dim3(grid), dim3(GEMM_THREADS), lds_bytes, s, Ks, Cs, ldk, Sp, Kinv, Np, P,
-                               kw_part, cw_part, sy, phase_k, nmain, prio);
+                               kw_part, cw_part, sy, phase_k, nmain, prio, gate_every);
         else
             hipLaunchKernelGGL(acq_gemm_kernel<false>, dim3(grid), dim3(GEMM_THREADS), lds_bytes, s, Ks, Cs, ldk, Sp, Kinv, Np, P,
-                               kw_part, cw_part, sy, phase_k, nmain, prio);
+                               kw_part, cw_part, sy, phase_k, nmain, prio, gate_every);
     }
     if (tail > 0) {
         if (matern)

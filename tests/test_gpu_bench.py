@@ -15,7 +15,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # long option names: torch.distributed.run would prefix-match "--n" / "--d" against its own options
-SMALL = ["--num-train", "640", "--dims", "8", "--starts", "3000", "--n-local", "8", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+SMALL = ["--num-train", "640", "--dims", "8", "--starts", "3000", "--n-local", "8", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-traffic"]
 REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
             "vs_baseline", "dtype", "data", "config", "roofline"]
 
@@ -44,7 +44,7 @@ def test_bench_line_contract_and_two_rank_merge():
     assert abs(one["value"] - c["evals_issued_per_step"] / (one["ms_per_step"] * 1e-3)) < 1e-6 * one["value"]
     for name, st in one["stage_rooflines"].items():          # a fraction above 1 is an accounting error, not evidence
         assert 0 < st["frac"] < 1, (name, st)
-    assert "fit_pipeline" in one["stage_rooflines"] and r["traffic"] is None and "traffic_reference" in r
+    assert "fit_pipeline" in one["stage_rooflines"] and r["traffic"] is None and "skipped" in r["traffic_detail"]   # --no-traffic here
     assert one["potrf_fallbacks"] == 0
 
     two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
@@ -60,7 +60,7 @@ def test_bench_gpus_n_without_a_launcher_spawns_its_own_ranks():
     """`python bench.py --gpus 2 ...` invoked PLAINLY (no torch.distributed.run around it, short option names and all) must
     not die: it starts the two ranks itself and prints the one JSON line, with the single-rank winner bit for bit
     (multi-start loop of src/acquisition-function.cpp:121-153 sharded over ranks)."""
-    short = ["--n", "640", "--d", "8", "--starts", "3000", "--n-local", "8", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    short = ["--n", "640", "--d", "8", "--starts", "3000", "--n-local", "8", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-traffic"]
     one = run([sys.executable, "bench.py", "--gpus", "1"] + short)
     two = run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--same-device"] + short)
     assert two["n_gpus"] == 2 and two["config"]["starts_per_gpu"] == 1500
@@ -68,6 +68,20 @@ def test_bench_gpus_n_without_a_launcher_spawns_its_own_ranks():
     assert two["result"]["best_index"] == one["result"]["best_index"]
     assert two["result"]["best_value"] == one["result"]["best_value"]
     np.testing.assert_array_equal(two["result"]["best_x"], one["result"]["best_x"])
+
+
+@pytest.mark.gpu
+def test_bench_line_carries_measured_traffic():
+    """roofline.traffic is measured by the run itself (two rocprofv3 --pmc passes over a child of the same script and library
+    behind the timed region), not quoted from a file: a number, with the launch shape and the correction it belongs to."""
+    if not (os.path.exists("/opt/rocm/bin/rocprofv3")):
+        pytest.skip("rocprofv3 not installed")
+    small = [a for a in SMALL if a != "--no-traffic"]
+    j = run([sys.executable, "bench.py", "--gpus", "1"] + small)
+    r = j["roofline"]
+    assert isinstance(r["traffic"], float) and r["traffic"] > 0, r
+    d = r["traffic_detail"]
+    assert d["launches_measured"] >= 1 and d["candidates_per_launch"] == 3072 and d["traffic_over_algorithmic"] > 0.5, d
 
 
 def test_bench_self_spawn_arguments_round_trip(monkeypatch):

@@ -241,7 +241,9 @@ def test_acq_gemm_scheduling_variants_agree(ctx, oracle, kernel, monkeypatch):
     ctx.set_candidate_chunk(16384)
     monkeypatch.setenv("SLS_WAVE_PATH", "0")
     base = None
-    for env in ({"SLS_ACQ_WG_PER_CU": "1", "SLS_PERSIST": "2", "SLS_GATE_PHASE": "2000"},     # the default
+    for env in ({"SLS_ACQ_WG_PER_CU": "1", "SLS_PERSIST": "1", "SLS_GATE_PHASE": "0", "SLS_GATE_EVERY": "16"},   # the default (round 5)
+                {"SLS_ACQ_WG_PER_CU": "1", "SLS_PERSIST": "1", "SLS_GATE_PHASE": "0", "SLS_GATE_EVERY": "1"},
+                {"SLS_ACQ_WG_PER_CU": "1", "SLS_PERSIST": "2", "SLS_GATE_PHASE": "2000"},                          # ungated (rounds 3-4)
                 {"SLS_ACQ_WG_PER_CU": "1", "SLS_PERSIST": "0", "SLS_GATE_PHASE": "2000"},
                 {"SLS_ACQ_WG_PER_CU": "1", "SLS_PERSIST": "1", "SLS_GATE_PHASE": "2000"},
                 {"SLS_ACQ_WG_PER_CU": "2", "SLS_PERSIST": "0", "SLS_GATE_PHASE": "2000"},

@@ -8,7 +8,7 @@ out = {"note": "single-GPU runs of one rank's share of the 65 536-start workload
        "exchange": "not measured", "shards": []}
 full = None
 for gpus, starts in ((1, 65536), (2, 32768), (4, 16384), (8, 8192)):
-    p = subprocess.run([sys.executable, os.path.join(R, "bench.py"), "--starts", str(starts), "--no-cpu-baseline", "--steps", "3", "--warmup", "1"],
+    p = subprocess.run([sys.executable, os.path.join(R, "bench.py"), "--starts", str(starts), "--no-cpu-baseline", "--no-traffic", "--steps", "3", "--warmup", "1"],
                        capture_output=True, text=True, timeout=900)
     j = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     st = j["stage_ms_per_step"]
