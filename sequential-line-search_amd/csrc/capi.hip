@@ -55,31 +55,6 @@ size_t pool_limit() {
 
 void note_entry() { g_work_epoch.fetch_add(1); }
 
-// the run-time switches (tuning.hpp): parsed on first use, re-read by sls_tuning_reload()
-namespace {
-SlsTuning g_tuning;
-std::once_flag g_tuning_once;
-void tuning_parse() {
-    static const char* const names[TUNE_COUNT] = {
-#define SLS_TK(name) "SLS_" #name,
-        SLS_TUNING_KEYS(SLS_TK)
-#undef SLS_TK
-    };
-    for (int k = 0; k < TUNE_COUNT; ++k) {
-        const char* v = getenv(names[k]);
-        g_tuning.has[k] = v != nullptr;
-        g_tuning.val[k] = v ? atol(v) : 0;
-    }
-}
-}  // namespace
-const SlsTuning& tuning() {
-    std::call_once(g_tuning_once, tuning_parse);
-    return g_tuning;
-}
-void tuning_reload() {
-    (void)tuning();
-    tuning_parse();
-}
 
 void* pool_alloc(size_t bytes) {
     if (bytes == 0) bytes = 8;
@@ -331,6 +306,14 @@ extern "C" int sls_ctx_destroy(sls_ctx* ctx) {
 static void ctx_destroy_now(sls_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    for (auto& s : ctx->slots) {   // the evaluation slots: their streams, their mapped blocks back to the pool that is freed next
+        if (s->stream) {
+            (void)hipStreamSynchronize(s->stream);
+            (void)hipStreamDestroy(s->stream);
+        }
+        if (s->host) ctx->host_give(s->host, s->bytes, true);
+    }
+    ctx->slots.clear();
     for (auto& b : ctx->host_free) (void)hipHostFree(b.p);
     ctx->host_free.clear();
     ctx->prof_collect();
@@ -480,18 +463,8 @@ struct sls_gp {
     // threads).  A small evaluation (a few query points on a wave-path handle) does not take the context's lock: it borrows a SLOT of
     // the handle -- a stream of its own and a page-locked, device-mapped block for the query points and the results -- under a
     // SHARED lock on the fitted state; everything that changes the state (refit, appended point, sigma mode) holds it exclusively.
-    struct EvalSlot {
-        hipStream_t stream = nullptr;
-        double* host = nullptr;
-        double* dev = nullptr;
-        size_t bytes = 0;
-        bool busy = false;
-    };
+    // The slots belong to the CONTEXT (sls_ctx::slots): a stream costs ~1 ms to create and the facade builds a new handle per submit.
     std::shared_mutex state_mtx;
-    std::mutex slot_mtx;
-    std::condition_variable slot_cv;
-    std::vector<std::unique_ptr<EvalSlot>> slots;
-    static constexpr int MAX_SLOTS = 16;
     double* io_host = nullptr;
     size_t io_bytes = 0;
     double* io_stage(size_t doubles) {
@@ -506,13 +479,6 @@ struct sls_gp {
         return io_host;
     }
     ~sls_gp() {   // sls_gp_destroy holds the context's lock
-        for (auto& s : slots) {
-            if (s->stream) {
-                (void)hipStreamSynchronize(s->stream);
-                (void)hipStreamDestroy(s->stream);
-            }
-            if (s->host) ctx->host_give(s->host, s->bytes, true);
-        }
         if (sum_host) ctx->host_give(sum_host, sum_bytes, true);
         if (zc_host) ctx->host_give(zc_host, zc_bytes, true);
         if (io_host) ctx->host_give(io_host, io_bytes, false);
@@ -1027,33 +993,33 @@ static bool eval_in_slot(sls_gp* g, const double* Xs, int M, const SmallEvalOut&
     const int D = g->D;
     const size_t n_in = (size_t)D * M, n_out = (size_t)(3 + 3 * D) * M;
     // ---- borrow a slot ----
-    sls_gp::EvalSlot* slot = nullptr;
+    sls_ctx::EvalSlot* slot = nullptr;
     {
-        std::unique_lock<std::mutex> lk(g->slot_mtx);
+        std::unique_lock<std::mutex> lk(c->slot_mtx);
         for (;;) {
-            for (auto& s : g->slots)
+            for (auto& s : c->slots)
                 if (!s->busy) { slot = s.get(); break; }
             if (slot) break;
-            if ((int)g->slots.size() < sls_gp::MAX_SLOTS) {
-                g->slots.emplace_back(new sls_gp::EvalSlot());
-                slot = g->slots.back().get();
+            if ((int)c->slots.size() < sls_ctx::MAX_SLOTS) {
+                c->slots.emplace_back(new sls_ctx::EvalSlot());
+                slot = c->slots.back().get();
                 break;
             }
-            g->slot_cv.wait(lk);
+            c->slot_cv.wait(lk);
         }
         slot->busy = true;
     }
     struct Release {
-        sls_gp* g;
-        sls_gp::EvalSlot* s;
+        sls_ctx* c;
+        sls_ctx::EvalSlot* s;
         ~Release() {
             {
-                std::lock_guard<std::mutex> lk(g->slot_mtx);
+                std::lock_guard<std::mutex> lk(c->slot_mtx);
                 s->busy = false;
             }
-            g->slot_cv.notify_one();
+            c->slot_cv.notify_one();
         }
-    } release{g, slot};
+    } release{c, slot};
     if (!slot->stream) SLS_HIP(hipStreamCreateWithFlags(&slot->stream, hipStreamNonBlocking));
     const size_t need = (n_in + n_out) * sizeof(double);
     if (need > slot->bytes) {

@@ -4,6 +4,7 @@
 #include <type_traits>
 
 #include "gemm_f64.hpp"
+#include "wave_reduce.hpp"
 
 namespace slsk {
 
@@ -74,8 +75,77 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // from registers, waves 1-3 meeting on an LDS counter instead of the second barrier): 57 500 vs 57 900 cycles per block --
 // waves 1-3 (trailing update ~600 cycles per 16 x 16 tile, S tiles) are then the longer path; three tiles in flight per wave
 // did not shorten them (not latency-bound either), and a k-interleaved S phase compiled into a branch per MFMA (80 000).
+// Round 5 form of the factoring diagonal tile.  Former form: every lane keeps its whole row (16 columns, the same in all four
+// 16-lane groups) and every pivot updates all later columns with a broadcast + fma pair each: ~660 instructions on the serial path
+// of a 16-column step.  Now only the CURRENT group of four columns is kept that way (cur[]); the later columns are DEALT to the
+// four lane groups -- lane (row, g) keeps columns g + 4 q -- which is the operand layout of v_mfma_f64_16x16x4: after the four
+// pivots of a group the rank-4 update of all later columns is ONE matrix instruction with the group's columns as both operands
+// (every lane receives the updates of exactly its own columns).  The next group's four columns reach all lanes through the LDS
+// tile itself (one dealt store, four reads).  Values above the diagonal are garbage exactly as before and never reach a result
+// (an output of the matrix instruction depends on row m and row n of its operands only).  The factor differs from the former
+// one in the last bits (four rank-1 terms are summed before they are subtracted).
+// (First attempt, measured and dropped: all 16 columns dealt and the pivot column sent to all four lane groups with
+// v_permlane16/32_swap -- 12 instructions per pivot with the copies the swaps need: 4600 cycles against the former 4400.)
+__device__ __forceinline__ void diag16_dealt(double* As, double* Tk, int c0, int lane, int* info, int global_off) {
+    const int row = lane & 15, g = lane >> 4;
+    double cur[4], sl[4], bq[4];
+    double own_inv = 1.0;
+    int bad = 16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        cur[r] = As[c0 + row + (c0 + r) * DL];
+        sl[r] = r > 0 ? As[c0 + row + (c0 + 4 * r + g) * DL] : 0.0;
+        bq[r] = (row == 4 * r + g) ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int G = 0; G < 4; ++G) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int k = 4 * G + c;
+            const double d = bcast(cur[c], k);              // the pivot
+            bad = (!(d > 0.0) && bad == 16) ? k : bad;
+            const double inv = rsqrt_nr(d);
+            const double lik = cur[c] * inv;                // L[row][k] (rows < k: unused values)
+            cur[c] = lik;
+#pragma unroll
+            for (int c2 = c + 1; c2 < 4; ++c2) cur[c2] -= lik * bcast(lik, 4 * G + c2);
+            own_inv = (row == k) ? inv : own_inv;
+            const double ck = (row > k) ? lik * inv : 0.0;
+#pragma unroll
+            for (int r = 0; r <= k / 4; ++r) bq[r] = fma(-ck, bcast(bq[r], k), bq[r]);
+        }
+        // lane (row, g) takes column 4 G + g of the finished group: the matrix instruction's operand and what goes back to LDS
+        double op = cur[0];
+        op = (g == 1) ? cur[1] : op;
+        op = (g == 2) ? cur[2] : op;
+        op = (g == 3) ? cur[3] : op;
+        As[c0 + row + (c0 + 4 * G + g) * DL] = (4 * G + g <= row) ? op : 0.0;
+        if (G < 3) {
+            d4_t u = {0.0, 0.0, 0.0, 0.0};
+            u = mfma16(op, op, u);                          // u[q] at lane (row, g): sum_k L[row][4G+k] L[4q+g][4G+k]
+#pragma unroll
+            for (int q = G + 1; q < 4; ++q) sl[q] -= u[q];
+            // the next group's columns to every lane, through the tile's own LDS image (DS operations of a wave execute in order)
+            As[c0 + row + (c0 + 4 * (G + 1) + g) * DL] = sl[G + 1];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int c = 0; c < 4; ++c) cur[c] = As[c0 + row + (c0 + 4 * (G + 1) + c) * DL];
+        }
+    }
+    if (bad < 16 && lane == 0 && info) atomicCAS(info, 0, global_off + c0 + bad + 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int col = 4 * r + g;
+        Tk[row + 16 * col] = (col <= row) ? bq[r] * own_inv : 0.0;
+    }
+}
+
 template <bool FACTOR>
 __device__ __forceinline__ void diag16(double* As, double* Tk, int c0, int lane, int* info, int global_off) {
+    if constexpr (FACTOR) {
+        diag16_dealt(As, Tk, c0, lane, info, global_off);
+        return;
+    }
     const int row = lane & 15, g = lane >> 4;
     double a[16];
     double own_inv = 1.0;

@@ -1,5 +1,7 @@
 // Run-time switches of the device library (A/B runs and test hooks; every default is the measured best).
 #pragma once
+#include <cstdlib>
+#include <mutex>
 
 namespace slsk {
 // ONE table for every SLS_* environment variable the device library understands, parsed once (first use) instead of a getenv per
@@ -21,8 +23,34 @@ struct SlsTuning {
     bool has[TUNE_COUNT];
     long val[TUNE_COUNT];
 };
-const SlsTuning& tuning();   // capi.hip
-void tuning_reload();
+namespace tuning_detail {
+inline SlsTuning& table() {
+    static SlsTuning t;
+    return t;
+}
+inline void parse() {
+    static const char* const names[TUNE_COUNT] = {
+#define SLS_TK(name) "SLS_" #name,
+        SLS_TUNING_KEYS(SLS_TK)
+#undef SLS_TK
+    };
+    SlsTuning& t = table();
+    for (int k = 0; k < TUNE_COUNT; ++k) {
+        const char* v = getenv(names[k]);
+        t.has[k] = v != nullptr;
+        t.val[k] = v ? atol(v) : 0;
+    }
+}
+}  // namespace tuning_detail
+inline const SlsTuning& tuning() {
+    static std::once_flag once;
+    std::call_once(once, tuning_detail::parse);
+    return tuning_detail::table();
+}
+inline void tuning_reload() {
+    (void)tuning();
+    tuning_detail::parse();
+}
 inline long tune(TuneKey k, long dflt) {
     const SlsTuning& t = tuning();
     return t.has[k] ? t.val[k] : dflt;
