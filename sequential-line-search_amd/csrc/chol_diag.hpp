@@ -249,14 +249,20 @@ __device__ __forceinline__ void chol_diag_steps(double* As, double* Ts, int* __r
                 if (j >= kb) continue;
                 d4_t c = {0.0, 0.0, 0.0, 0.0};
                 for (int k = j; k < kb; ++k) {
+                    // the eight fragment reads of a block issued together, then the four products (round 5: the scheduler paired
+                    // every read with its use: read - wait - product, four times over; the sums keep their order)
+                    double af[4], bf[4];
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) {
                         const int kq = 4 * kk + fk;
-                        const double af = As[(16 * k + kq) * DL + c0 + fl];   // L[kb][k] (row m = fl, col kq)
+                        af[kk] = As[(16 * k + kq) * DL + c0 + fl];   // L[kb][k] (row m = fl, col kq)
                         // T[k][j] (row kq, col n = fl): diagonal inverse in Ts for k == j, transposed upper slot otherwise
-                        const double bf = (k == j) ? Ts[256 * j + kq + 16 * fl] : As[(16 * k + kq) * DL + 16 * j + fl];
-                        c = mfma16(af, bf, c);   // operands swapped: lane holds S (m = fk + 4q, n = fl), stores run along n
+                        bf[kk] = (k == j) ? Ts[256 * j + kq + 16 * fl] : As[(16 * k + kq) * DL + 16 * j + fl];
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) c = mfma16(af[kk], bf[kk], c);   // operands swapped: lane holds S (m = fk + 4q, n = fl), stores run along n
+                    __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) As[(c0 + fk + 4 * q) * DL + 16 * j + fl] = c[q];   // S -> slot (j, kb)
@@ -273,25 +279,33 @@ __device__ __forceinline__ void chol_diag_steps(double* As, double* Ts, int* __r
             if (t < kb) {
                 const int j = t;
                 d4_t c = {0.0, 0.0, 0.0, 0.0};
+                double af[4], bf[4];
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     const int kq = 4 * kk + fk;
-                    const double af = -Tk[fl + 16 * kq];                        // -T16 (row m = fl, col kq)
-                    const double bf = As[(c0 + kq) * DL + 16 * j + fl];         // S (row kq, col n = fl)
-                    c = mfma16(af, bf, c);   // swapped as for S
+                    af[kk] = -Tk[fl + 16 * kq];                        // -T16 (row m = fl, col kq)
+                    bf[kk] = As[(c0 + kq) * DL + 16 * j + fl];         // S (row kq, col n = fl)
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) c = mfma16(af[kk], bf[kk], c);   // swapped as for S
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) As[(c0 + fk + 4 * q) * DL + 16 * j + fl] = c[q];
             } else if (FACTOR) {
                 const int r = t + 1;   // panel: L_r = A_r T16^T
                 d4_t acc = {0.0, 0.0, 0.0, 0.0};
+                double af[4], bf[4];
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     const int k = 4 * kk + fk;
-                    const double af = As[(c0 + k) * DL + 16 * r + fl];   // A_r[m = fl][k]
-                    const double bf = Tk[fl + 16 * k];                    // T[n = fl][k]
-                    acc = mfma16(bf, af, acc);
+                    af[kk] = As[(c0 + k) * DL + 16 * r + fl];   // A_r[m = fl][k]
+                    bf[kk] = Tk[fl + 16 * k];                    // T[n = fl][k]
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) acc = mfma16(bf[kk], af[kk], acc);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) As[(c0 + fk + 4 * q) * DL + 16 * r + fl] = acc[q];
             }
@@ -304,15 +318,19 @@ __device__ __forceinline__ void chol_diag_steps(double* As, double* Ts, int* __r
         // the S tiles of the next step, all hidden behind the chain.
         auto update_tile = [&](int i, int j) {
             d4_t acc;
+            double af[4], bf[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[q] = As[(16 * j + fk + 4 * q) * DL + 16 * i + fl];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const int k = c0 + 4 * kk + fk;
-                const double af = -As[k * DL + 16 * i + fl];
-                const double bf = As[k * DL + 16 * j + fl];
-                acc = mfma16(bf, af, acc);
+                af[kk] = -As[k * DL + 16 * i + fl];
+                bf[kk] = As[k * DL + 16 * j + fl];
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc = mfma16(bf[kk], af[kk], acc);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) As[(16 * j + fk + 4 * q) * DL + 16 * i + fl] = acc[q];
         };
@@ -373,13 +391,17 @@ __device__ __forceinline__ void chol_factor_steps(double* As, double* Ts, int* _
         const double* Tk = Ts + 256 * kb;
         auto panel_tile = [&](int r) {                // L_r = A_r T16^T, in place
             d4_t acc = {0.0, 0.0, 0.0, 0.0};
+            double af[4], bf[4];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const int k = 4 * kk + fk;
-                const double af = As[(c0 + k) * DL + 16 * r + fl];   // A_r[m = fl][k]
-                const double bf = Tk[fl + 16 * k];                    // T[n = fl][k]
-                acc = mfma16(bf, af, acc);
+                af[kk] = As[(c0 + k) * DL + 16 * r + fl];   // A_r[m = fl][k]
+                bf[kk] = Tk[fl + 16 * k];                    // T[n = fl][k]
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc = mfma16(bf[kk], af[kk], acc);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) As[(c0 + fk + 4 * q) * DL + 16 * r + fl] = acc[q];
             return acc;
@@ -413,15 +435,19 @@ __device__ __forceinline__ void chol_factor_steps(double* As, double* Ts, int* _
             advance(wave);
             while (j < nb16) {
                 d4_t acc;
+                double af[4], bf[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[q] = As[(16 * j + fk + 4 * q) * DL + 16 * i + fl];
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     const int k = c0 + 4 * kk + fk;
-                    const double af = -As[k * DL + 16 * i + fl];
-                    const double bf = As[k * DL + 16 * j + fl];
-                    acc = mfma16(bf, af, acc);
+                    af[kk] = -As[k * DL + 16 * i + fl];
+                    bf[kk] = As[k * DL + 16 * j + fl];
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) acc = mfma16(bf[kk], af[kk], acc);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) As[(16 * j + fk + 4 * q) * DL + 16 * i + fl] = acc[q];
                 advance(3);

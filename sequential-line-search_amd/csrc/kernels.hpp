@@ -112,7 +112,7 @@ void launch_gp_fit_small(hipStream_t s, int kernel, const GpFitSmallArgs& args);
 // The optimiser state lives in registers, 64 variables per register: 3 per lane up to 192 variables (C3: 91 + 34), 5 beyond.
 constexpr int MAP_OPT_MAX_VARS = 320;
 constexpr int MAP_OPT_HIST = 8;
-constexpr int MAP_OPT_TRACE_SLOTS = 16;
+constexpr int MAP_OPT_TRACE_SLOTS = 24;
 constexpr int MAP_OPT_STATE_DOUBLES = (4 + 2 * MAP_OPT_HIST) * MAP_OPT_MAX_VARS + 32;
 constexpr int MAP_OPT_OUT_X = 8, MAP_OPT_OUT_G = 8 + MAP_OPT_MAX_VARS, MAP_OPT_OUT_DOUBLES = 8 + 2 * MAP_OPT_MAX_VARS;
 struct MapOptArgs {

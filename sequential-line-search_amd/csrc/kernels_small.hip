@@ -203,8 +203,10 @@ __device__ __forceinline__ double small_build_factor(double* As, double* Ts, con
                         af[kk] = xc(16 * ti + fl, d) * (il * il);
                         bf[kk] = xc(16 * tj + fl, d);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) acc = mfma16(bf[kk], af[kk], acc);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 const int i = 16 * ti + fl;
                 const double ni = small_scratch(As, SC_NX + i);
@@ -250,7 +252,7 @@ __device__ __forceinline__ double small_build_factor(double* As, double* Ts, con
 
 // K^-1 = L^-T L^-1 as a full symmetric image over the dead factor (after small_build_factor: L in the lower triangle of As, L^-T in its
 // strictly-upper tiles, the inverses of the diagonal tiles in Ts)
-__device__ __forceinline__ void small_inverse_in_place(double* As, double* Ts, int N) {
+__device__ __forceinline__ void small_inverse_in_place(double* As, double* Ts, int N, SmallTrace* stp = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fl = lane & 15, fk = lane >> 4;
     const int nb16 = (N + 15) >> 4;
@@ -269,14 +271,18 @@ __device__ __forceinline__ void small_inverse_in_place(double* As, double* Ts, i
                         af[kk] = (k == i) ? Ts[256 * i + kq + 16 * fl] : As[(16 * k + kq) * DL + 16 * i + fl];   // T[k][i] (kq, m)
                         bf[kk] = (k == j) ? Ts[256 * j + kq + 16 * fl] : As[(16 * k + kq) * DL + 16 * j + fl];   // T[k][j] (kq, n)
                     }
+                    __builtin_amdgcn_sched_barrier(0);   // all eight reads issued before the first product (the scheduler pairs each read with its use)
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) c = mfma16(bf[kk], af[kk], c);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) As[(16 * j + fk + 4 * q) * DL + 16 * i + fl] = c[q];
             }
     }
+    if (stp) stp->mark(16);
     __syncthreads();
+    if (stp) stp->mark(17);
     // mirror the strictly-lower tiles into the upper triangle (L^-T is no longer needed): K^-1 becomes a full symmetric image
     {
         int t = 0;
@@ -300,7 +306,7 @@ template <bool MATERN>
 __device__ __forceinline__ double small_factor_inverse(double* As, double* Ts, const SmallPts& pts, int D, int N,
                                                        double a, double b, int* __restrict__ info, double* __restrict__ kc, SmallTrace& st) {
     const double ld = small_build_factor<MATERN>(As, Ts, pts, D, N, a, b, info, kc, st);
-    small_inverse_in_place(As, Ts, N);
+    small_inverse_in_place(As, Ts, N, &st);
     st.mark(11);
     return ld;
 }
@@ -396,6 +402,7 @@ __device__ __forceinline__ double small_grad(double* As, const SmallPts& pts, co
                 }
             }
     }
+    st.mark(18);
     const double sa_t = small_block_sum(sa, As);   // its barriers publish G
     st.mark(12);
     if (!want_grad) return sa_t;
@@ -423,12 +430,14 @@ __device__ __forceinline__ double small_grad(double* As, const SmallPts& pts, co
                         af[kk] = As[(k0 + 4 * kk + fk) * DL + 16 * tj + fl];
                         bf[kk] = xc(k0 + 4 * kk + fk, 16 * tp + fl);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) acc = mfma16(bf[kk], af[kk], acc);
                     if (tp == 0) {
 #pragma unroll
                         for (int kk = 0; kk < 4; ++kk) accs = mfma16(1.0, af[kk], accs);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 if (tp == 0) sreg[n] = accs[0];
                 const int j = 16 * tj + fl;
@@ -446,7 +455,9 @@ __device__ __forceinline__ double small_grad(double* As, const SmallPts& pts, co
                 if (fl == 0 && p < D) small_scratch(As, SC_BTL + wave * NLL_SMALL_MAX_D + p) = v;
             }
         }
+        st.mark(19);
         __syncthreads();
+        st.mark(20);
         if (tid < D) {
             const double p = (small_scratch(As, SC_BTL + tid) + small_scratch(As, SC_BTL + NLL_SMALL_MAX_D + tid)) +
                              (small_scratch(As, SC_BTL + 2 * NLL_SMALL_MAX_D + tid) + small_scratch(As, SC_BTL + 3 * NLL_SMALL_MAX_D + tid));
