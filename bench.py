@@ -157,12 +157,12 @@ def measure_traffic(args):
                 return None, {"skipped": f"rocprofv3 --pmc {counter} failed (rc {p.returncode}): {(p.stderr or p.stdout)[-300:]}"}
             per = {}
             for r in csv.DictReader(open(files[0])):
-                if "acq_gemm_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                if "acq_gemm" in r["Kernel_Name"] and r["Counter_Name"] == counter:   # acq_gemm_kernel, or acq_gemm_half_kernel for a small launch
                     k = r["Dispatch_Id"]
                     e = per.setdefault(k, [0.0, int(r["Grid_Size"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])])
                     e[0] += float(r["Counter_Value"])
             if not per:
-                return None, {"skipped": f"no acq_gemm_kernel dispatch in the {counter} pass"}
+                return None, {"skipped": f"no acq_gemm dispatch in the {counter} pass"}
             gmax = max(v[1] for v in per.values())
             full = [v for v in per.values() if v[1] == gmax]
             raw[counter] = sum(v[0] for v in full) / len(full)

@@ -15,9 +15,6 @@
 
 using namespace slsk;
 
-#ifndef SLS_POTRF_LOOKAHEAD_DEFAULT
-#define SLS_POTRF_LOOKAHEAD_DEFAULT 4
-#endif
 
 namespace slsk {
 static thread_local char g_err[512] = "";
@@ -168,16 +165,6 @@ void sls_ctx::prof_collect() {
     }
 }
 
-slsk::PotrfAux* sls_ctx::potrf_lookahead(int Np) {
-    // SLS_POTRF_LOOKAHEAD = f > 0: side stream whose CU mask leaves f CUs per XCD free; 0: single-stream schedule.
-    // Only the two-level schedule (N >= 8192 by default) has an outer update to overlap.
-    const int f = (int)tune(TUNE_POTRF_LOOKAHEAD, SLS_POTRF_LOOKAHEAD_DEFAULT);
-    const int mode = slsk::potrf_default_mode(Np);
-    if (f <= 0 || mode == 3 || (mode == 0 && slsk::potrf_default_nbo(Np) <= 1)) return nullptr;
-    if (!potrf_aux.side) slsk::potrf_aux_create(&potrf_aux, f);
-    return &potrf_aux;
-}
-
 void sls_ctx::potrf_tick_rearm() {
     if (!potrf_persistent_ok && potrf_rearm > 0 && --potrf_rearm == 0) potrf_persistent_ok = true;
 }
@@ -318,7 +305,6 @@ static void ctx_destroy_now(sls_ctx* ctx) {
     ctx->host_free.clear();
     ctx->prof_collect();
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
-    slsk::potrf_aux_destroy(&ctx->potrf_aux);
     if (ctx->d_info) (void)hipFree(ctx->d_info);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -523,12 +509,12 @@ static void gp_fit_device(sls_gp* g) {
         // N <= 4096: factorisation, L^-1, its transpose and K_y^-1 in ONE launch (the inverse is built behind the chain by the CUs the
         // factorisation leaves idle)
         ProfScope ps(c, "potri");
-        if (!launch_potri(c->stream, g->L.p, Np, g->Linv.p, g->U.p, g->Kinv.p, c->d_info, c->potrf_lookahead(Np), df_sync))
+        if (!launch_potri(c->stream, g->L.p, Np, g->Linv.p, g->U.p, g->Kinv.p, c->d_info, df_sync))
             ps.rename("potrf+trtri+lauum");   // the fused launch declined (too few CUs resident): the three separate launches ran
     } else {
         {
             ProfScope ps(c, "potrf");
-            launch_potrf(c->stream, g->L.p, Np, g->Linv.p, c->d_info, 0, c->potrf_lookahead(Np), df_sync);
+            launch_potrf(c->stream, g->L.p, Np, g->Linv.p, c->d_info, 0, df_sync);
         }
         {
             ProfScope ps(c, "trtri");
@@ -1494,7 +1480,7 @@ extern "C" int sls_potrf(sls_ctx* c, double* A, int N) {
         upload_padded_spd(c, Ad, A, N, Np);
         SLS_HIP(hipMemsetAsync(c->d_info, 0, 64, c->stream));
         c->potrf_tick_rearm();
-        launch_potrf(c->stream, Ad.p, Np, Li.p, c->d_info, 0, c->potrf_lookahead(Np), c->potrf_df_sync(Np));
+        launch_potrf(c->stream, Ad.p, Np, Li.p, c->d_info, 0, c->potrf_df_sync(Np));
         launch_zero_upper(c->stream, Ad.p, Np);
         SLS_HIP(hipMemcpyAsync(info2, c->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         d2h_matrix(c, out.data(), Ad.p, N, Np);

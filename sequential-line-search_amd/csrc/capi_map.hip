@@ -150,7 +150,7 @@ static bool nll_factor_enqueue(sls_nll* h, const double* theta, double b) {
     // N <= 4096: one launch for the factorisation and the inverse (launch_potri); otherwise potrf + trtri + lauum.
     // L^-1's buffer is not cleared here: only the separate launches need that (and do it themselves); nothing in this file reads the
     // tiles above its diagonal (134 MB, 18 us at N = 4096).
-    launch_potri(c->stream, h->L.p, Np, h->Linv.p, h->G.p, h->Kinv.p, c->d_info, c->potrf_lookahead(Np), c->potrf_df_sync(Np), false);
+    launch_potri(c->stream, h->L.p, Np, h->Linv.p, h->G.p, h->Kinv.p, c->d_info, c->potrf_df_sync(Np), false);
     return true;   // log|K_y| (result word 4) comes out of nll_scalars, which every evaluation launches anyway
 }
 // info2 = the two words of d_info behind the enqueued factorisation (pivot failure, single-launch Cholesky gave up).

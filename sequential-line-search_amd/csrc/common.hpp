@@ -105,9 +105,6 @@ struct sls_ctx {
     // scratch
     slsk::DBuf scratch;   // generic host<->device staging
     int* d_info = nullptr;  // device int[4]: potrf info etc.
-    // look-ahead schedule of the Cholesky factorisation: CU-masked side stream + events, created on first use
-    slsk::PotrfAux potrf_aux;
-    slsk::PotrfAux* potrf_lookahead(int Np);   // nullptr unless SLS_POTRF_LOOKAHEAD selects the two-stream schedule
     bool potrf_persistent_ok = true;     // cleared when a single-launch factorisation gave up (bounded wait expired)
     int potrf_rearm = 0;                 // fits left on the multi-launch schedule before the single-launch form is tried again
     int potrf_rearm_next = 16;           // ... and how many it will be after the next give-up (16, 64, 256, ... 4096)

@@ -246,17 +246,12 @@ void launch_maximize_wave(hipStream_t s, WaveArgs a);
 // ---- kernels_chol.hip ---------------------------------------------------------
 // In-place lower Cholesky of the Np x Np matrix A (ld = Np); Linv receives the 128x128 diagonal-block inverses
 // (rest of Linv untouched).  info (device int) gets 1 + index of the first non-positive pivot, or stays 0.
-// nbo: 128-columns per outer block (1 = one-level algorithm; default from potrf_default_nbo(Np)).  aux (optional): a side
-// stream + events for the look-ahead schedule (see kernels_chol.hip); nullptr = everything on s.
-struct PotrfAux {
-    static constexpr int NEV = 8;
-    hipStream_t side = nullptr;
-    hipEvent_t ev[NEV] = {};
-    hipEvent_t last_rest = nullptr;
-};
+// nbo: 128-columns per outer block of the multi-launch schedule (1 = one-level algorithm; default from potrf_default_nbo(Np)).
+constexpr int NB = 128;            // block size of the factorisation = the GEMM tile
 int potrf_default_nbo(int Np);
-void launch_potrf(hipStream_t s, double* A, int Np, double* Linv, int* info, int nbo = 0, PotrfAux* aux = nullptr,
-                  int* dataflow_sync = nullptr);
+// one 128 x 128 diagonal block: Cholesky in place + its inverse into Tout (kernels_chol.hip; the multi-launch schedule's step)
+void launch_chol_diag(hipStream_t s, double* A, long lda, double* Tout, long ldt, int* info, int global_off);
+void launch_potrf(hipStream_t s, double* A, int Np, double* Linv, int* info, int nbo = 0, int* dataflow_sync = nullptr);
 void launch_gemm_splitk_nt(hipStream_t s, const double* A, long lda, const double* B, long ldb, double* Cpart, long ldc,
                            long part_stride, int mt, int nt, int K, int chunks);
 // Single-launch factorisation (SLS_POTRF_MODE=3, default): per-tile ownership and ready flags, no grid barriers.  sync =
@@ -282,12 +277,9 @@ struct PotriFused {
 bool launch_potri_dataflow(hipStream_t s, double* A, int Np, double* Linv, double* U, double* Kinv, int* info, int* sync,
                            long long* trace = nullptr);
 bool potri_fused_applies(int Np, bool have_sync);   // sizes / switches only: the launch itself may still decline (too few CUs)
-bool launch_potri(hipStream_t s, double* A, int Np, double* Linv, double* U, double* Kinv, int* info, PotrfAux* aux, int* dataflow_sync,
+bool launch_potri(hipStream_t s, double* A, int Np, double* Linv, double* U, double* Kinv, int* info, int* dataflow_sync,
                   bool linv_zeroed = true);   // false: Linv was not cleared by the caller (only the separate launches need it: done inside)
 int potrf_default_mode(int Np);
-// side stream restricted by a CU mask that leaves `free_per_xcd` CUs of each of the 8 XCDs to other streams (0: plain stream)
-void potrf_aux_create(PotrfAux* aux, int free_per_xcd);
-void potrf_aux_destroy(PotrfAux* aux);
 // Linv <- L^-1 (lower) given L and the diagonal-block inverses already in Linv; tmp is an Np x Np scratch.
 void launch_trtri(hipStream_t s, const double* L, int Np, double* Linv, double* tmp, double* U);   // U <- (L^-1)^T
 void launch_transpose_full(hipStream_t s, const double* src, double* dst, int Np);   // dst = src^T (Np x Np)

@@ -28,182 +28,7 @@
 
 namespace slsk {
 
-constexpr int NB = 128;
 typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
-
-// ---------------------------------------------------------------------------------------------------------
-// generic tile GEMM with triangular k-ranges:  C = alpha * opA opB^T + beta * C
-// ---------------------------------------------------------------------------------------------------------
-struct GemmDesc {
-    const double* A; long lda; long strideA;   // batch strides in elements
-    const double* B; long ldb; long strideB;
-    double* C; long ldc; long strideC;
-    int mt, nt;        // tile grid
-    int K;             // full k extent (multiple of 16)
-    double alpha, beta;
-    int tri;           // 1: only tiles tm >= tn + tri_off
-    int tri_off;
-    int order;         // tile issue order (longest k range first): 0 blockIdx = tm + tn*mt; 1 lower triangle row by row from
-                       // tm = 0 (grid = mt (mt + 1) / 2, kmode 3); 2 rows from tm = mt - 1 down (kmode 2); 3 rows from tm = 0 (kmode 4)
-    int kmode;         // 0: [0,K)  1: [128 tn, K)  2: [0, 128 (tm+1))  3: [128 max(tm,tn), K)  4: [128 tm, K)
-    int vb_stride, vb_off, vb_limit;   // tile row (vb_on_n: tile column) valid iff batch*vb_stride + vb_off + tm (tn) < vb_limit
-    int vb_on_n;
-};
-
-// NJ = 4: one workgroup per 128 x 128 tile.  NJ = 2 (both operands M-contiguous only): two workgroups per tile, each the 64
-// columns [64 h, 64 h + 64) -- same slabs, fragments and k order (gemm_tile_mc), so the same bits at twice the workgroup count,
-// for launches whose 128 x 128 tiling leaves most of the chip's workgroup slots empty.
-template <bool A_KC, bool B_KC, int NJ = 4>
-__global__ __launch_bounds__(256, 2) void tri_gemm_kernel(GemmDesc g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* lds = reinterpret_cast<double*>(smem);
-    const int unit = NJ == 4 ? blockIdx.x : blockIdx.x >> 1;
-    const int nhalf = NJ == 4 ? 0 : blockIdx.x & 1;
-    int tm = unit % g.mt, tn = unit / g.mt;
-    if (g.order == 1) {          // row-major enumeration of the lower triangle: all tiles of row tm share one k length
-        int t = unit;
-        tm = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-        while (tm * (tm + 1) / 2 > t) --tm;
-        while ((tm + 1) * (tm + 2) / 2 <= t) ++tm;
-        tn = t - tm * (tm + 1) / 2;
-    } else if (g.order == 2) {
-        tm = g.mt - 1 - unit / g.nt;
-        tn = unit % g.nt;
-    } else if (g.order == 3) {
-        tm = unit / g.nt;
-        tn = unit % g.nt;
-    }
-    const int batch = blockIdx.y;
-    if (g.tri && tn + g.tri_off > tm) return;
-    if (batch * g.vb_stride + g.vb_off + (g.vb_on_n ? tn : tm) >= g.vb_limit) return;
-    const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
-    int kb = 0, ke = g.K;
-    if (g.kmode == 1) kb = NB * tn;
-    else if (g.kmode == 2) ke = min(g.K, NB * (tm + 1));
-    else if (g.kmode == 3) kb = NB * max(tm, tn);
-    else if (g.kmode == 4) kb = NB * tm;
-    const double* A = g.A + batch * g.strideA;
-    const double* B = g.B + batch * g.strideB;
-    double* C = g.C + batch * g.strideC;
-    const double* Ap = A_KC ? A + (long)m0 * g.lda : A + m0;
-    const double* Bp = B_KC ? B + (long)n0 * g.ldb : B + n0;
-    Acc acc;
-    acc.zero();
-    gemm_tile<A_KC, B_KC, NJ, true>(acc, Ap, g.lda, Bp, g.ldb, kb, ke, lds, nhalf);   // kb, ke multiples of 128
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ncol0 = NJ == 4 ? (wave >> 1) * 64 : 64 * nhalf + (wave >> 1) * 32;   // this wave's first column in the tile
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double* c = C + (long)(m0 + acc_m(i)) + (long)(n0 + ncol0 + 16 * j + (lane >> 4) + 4 * r) * g.ldc;
-                double v = g.alpha * acc.v[i][j][r];
-                if (g.beta != 0.0) v += g.beta * *c;
-                *c = v;
-            }
-}
-
-// Same product on 128 x 64 tiles (B K-contiguous only): twice as many workgroups for the levels of the
-// triangular inverse whose 128 x 128 tiling leaves most of the 512 workgroup slots empty (each tile is a long serial k loop,
-// so the level time is the time of ONE tile; halving the tile halves it).  g.nt still counts 128-wide block columns.
-template <bool A_KC>
-__global__ __launch_bounds__(256, 2) void tri_gemm64_kernel(GemmDesc g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* lds = reinterpret_cast<double*>(smem);
-    const int tm = blockIdx.x % g.mt, tn64 = blockIdx.x / g.mt, tn = tn64 >> 1;
-    const int batch = blockIdx.y;
-    if (g.tri && tn + g.tri_off > tm) return;
-    if (batch * g.vb_stride + g.vb_off + tm >= g.vb_limit) return;
-    const int m0 = tm * GEMM_BM, n0 = tn64 * 64;
-    int kb = 0, ke = g.K;
-    if (g.kmode == 1) kb = NB * tn;
-    else if (g.kmode == 2) ke = min(g.K, NB * (tm + 1));
-    else if (g.kmode == 3) kb = NB * max(tm, tn);
-    const double* A = g.A + batch * g.strideA + (A_KC ? (long)m0 * g.lda : (long)m0);
-    const double* B = g.B + batch * g.strideB + (long)n0 * g.ldb;
-    double* C = g.C + batch * g.strideC;
-    Acc64 acc;
-    acc.zero();
-    gemm_tile_n64<A_KC>(acc, A, g.lda, B, g.ldb, kb, ke, lds);
-    const int lane = threadIdx.x & 63, wm = (threadIdx.x >> 6) * 32;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double* c = C + (long)(m0 + wm + 16 * i + (lane & 15)) + (long)(n0 + 16 * j + (lane >> 4) + 4 * r) * g.ldc;
-                double v = g.alpha * acc.v[i][j][r];
-                if (g.beta != 0.0) v += g.beta * *c;
-                *c = v;
-            }
-}
-
-template <bool A_KC>
-static void launch_tri_gemm64(hipStream_t s, const GemmDesc& g, int batches) {
-    ensure_dyn_lds((const void*)tri_gemm64_kernel<A_KC>, GEMM_N64_LDS_BYTES);
-    if (g.mt <= 0 || g.nt <= 0 || batches <= 0) return;
-    hipLaunchKernelGGL(tri_gemm64_kernel<A_KC>, dim3(g.mt * g.nt * 2, batches), dim3(GEMM_THREADS), GEMM_N64_LDS_BYTES, s, g);
-}
-
-// LDS request of the tile kernels.  one_per_cu: 96 KB, so that only one workgroup fits a CU -- one wave per SIMD keeps the MFMA
-// pipe to itself (see launch_acq_gemm); measured for trtri at N = 8192: 3.44 -> 3.19 ms, for lauum no difference.
-// SLS_TRI_WG_PER_CU=1 / 2 forces either for every launch (A/B switch).
-static int tri_lds_bytes(bool one_per_cu) {
-    if (tune_set(TUNE_TRI_WG_PER_CU)) one_per_cu = tune(TUNE_TRI_WG_PER_CU, 0) == 1;
-    return one_per_cu ? 96 * 1024 : GEMM_LDS_BYTES;
-}
-template <bool A_KC, bool B_KC>
-static void launch_tri_gemm(hipStream_t s, const GemmDesc& g, int batches, bool one_per_cu = false) {
-    const int lds_bytes = tri_lds_bytes(one_per_cu);
-    ensure_dyn_lds((const void*)tri_gemm_kernel<A_KC, B_KC>, lds_bytes);
-    if (g.mt <= 0 || g.nt <= 0 || batches <= 0) return;
-    const int grid = g.order == 1 ? g.mt * (g.mt + 1) / 2 : g.mt * g.nt;
-    hipLaunchKernelGGL((tri_gemm_kernel<A_KC, B_KC>), dim3(grid, batches), dim3(GEMM_THREADS), lds_bytes, s, g);
-}
-// both operands M-contiguous, half tiles (two workgroups per 128 x 128 tile)
-static void launch_tri_gemm_mc_half(hipStream_t s, const GemmDesc& g, int batches, bool one_per_cu = false) {
-    const int lds_bytes = tri_lds_bytes(one_per_cu);
-    ensure_dyn_lds((const void*)tri_gemm_kernel<false, false, 2>, lds_bytes);
-    if (g.mt <= 0 || g.nt <= 0 || batches <= 0) return;
-    const int grid = g.order == 1 ? g.mt * (g.mt + 1) / 2 : g.mt * g.nt;
-    hipLaunchKernelGGL((tri_gemm_kernel<false, false, 2>), dim3(2 * grid, batches), dim3(GEMM_THREADS), lds_bytes, s, g);
-}
-
-static GemmDesc mkdesc(const double* A, long lda, const double* B, long ldb, double* C, long ldc, int mt, int nt, int K,
-                       double alpha, double beta) {
-    GemmDesc g;
-    g.A = A; g.lda = lda; g.strideA = 0;
-    g.B = B; g.ldb = ldb; g.strideB = 0;
-    g.C = C; g.ldc = ldc; g.strideC = 0;
-    g.mt = mt; g.nt = nt; g.K = K; g.alpha = alpha; g.beta = beta;
-    g.tri = 0; g.tri_off = 0; g.order = 0; g.kmode = 0; g.vb_stride = 0; g.vb_off = 0; g.vb_limit = 1 << 30; g.vb_on_n = 0;
-    return g;
-}
-
-void launch_gemm_plain(hipStream_t s, const double* A, long lda, bool a_kc, const double* B, long ldb, bool b_kc, double* C,
-                       long ldc, int mt, int nt, int K, double alpha, double beta) {
-    GemmDesc g = mkdesc(A, lda, B, ldb, C, ldc, mt, nt, K, alpha, beta);
-    if (!a_kc && !b_kc) launch_tri_gemm<false, false>(s, g, 1);
-    else if (!a_kc && b_kc) launch_tri_gemm<false, true>(s, g, 1);
-    else if (a_kc && b_kc) launch_tri_gemm<true, true>(s, g, 1);
-    else launch_tri_gemm<true, false>(s, g, 1);
-}
-
-// C_part[c] = A[:, K_c] * B[:, K_c]^T for `chunks` equal ranges K_c of the contraction (A M-contiguous, B K-contiguous): a tall
-// product with few output tiles (the MAP gradient's Y = G X~: N x D x N, N / 128 tiles) spread over chunks x as many workgroups.
-// The caller adds the partial results in chunk order (fixed order: deterministic).
-void launch_gemm_splitk_nt(hipStream_t s, const double* A, long lda, const double* B, long ldb, double* Cpart, long ldc,
-                           long part_stride, int mt, int nt, int K, int chunks) {
-    const int Kc = K / chunks;                        // multiple of 128 (caller)
-    GemmDesc g = mkdesc(A, lda, B, ldb, Cpart, ldc, mt, nt, Kc, 1.0, 0.0);
-    g.strideA = (long)Kc * lda;
-    g.strideB = Kc;
-    g.strideC = part_stride;
-    launch_tri_gemm<false, true>(s, g, chunks);
-}
 
 // Cholesky factor + inverse of ONE 128 x 128 diagonal block by the calling workgroup (256 threads, `smem` = DIAG_LDS_BYTES of
 // LDS): A (lower triangle read) -> L in place (FACTOR) and T = L^-1 into Tout.  Shared by the one-block launch
@@ -305,6 +130,10 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double* __restrict__ A, 
 static void diag_attr() {
     ensure_dyn_lds((const void*)chol_diag_kernel<true>, DIAG_LDS_BYTES);
     ensure_dyn_lds((const void*)chol_diag_kernel<false>, DIAG_LDS_BYTES);
+}
+void launch_chol_diag(hipStream_t s, double* A, long lda, double* Tout, long ldt, int* info, int global_off) {
+    diag_attr();
+    hipLaunchKernelGGL(chol_diag_kernel<true>, dim3(1), dim3(256), DIAG_LDS_BYTES, s, A, lda, Tout, ldt, info, global_off);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1734,106 +1563,6 @@ bool launch_potri_dataflow(hipStream_t s, double* A, int Np, double* Linv, doubl
     return launch_potrf_dataflow_impl(s, A, Np, Linv, info, sync, 1, 0, 0, false, trace, &inv);
 }
 
-// Two-level right-looking factorisation.  Outer blocks of `nbo` 128-columns: inside an outer block every 128-step is
-//   diag (one workgroup, LDS-resident)  ->  panel L_ij = A_ij T_jj^T for ALL rows below  ->  update of the REMAINING columns
-//   of the outer block only (K = 128, at most nbo - 1 tile columns: a short launch),
-// and the rest of the trailing matrix is updated once per outer block with K = 128 nbo (nbo x fewer read-modify-write
-// sweeps over the trailing matrix and a k loop long enough to run at the GEMM rate; with nbo = 1 this is the plain
-// one-level algorithm).
-// Look-ahead (aux != nullptr, nbo > 1): the outer update is split into the columns of the NEXT outer block (main stream,
-// the only part the next inner factorisation needs) and the rest (side stream).  The side stream is created with a CU mask
-// that leaves a few CUs per XCD free, so the single-workgroup diagonal kernel -- which needs a whole CU's LDS -- always
-// finds one while the bulk update runs; without the mask it would wait for the bulk grid to drain.
-// CU-mask convention of the amdgpu driver on multi-XCC parts: mask bit i addresses XCC i % 8, and bit i / 8 of that XCC's
-// own (SE-interleaved) CU sequence.  Clearing bits >= 8 (32 - f) therefore frees f CUs on every XCD (tools/probes/potrf_bench
-// prints the CUs a masked stream really uses).
-void potrf_aux_create(PotrfAux* aux, int free_per_xcd) {
-    if (aux->side) return;
-    if (free_per_xcd > 0 && free_per_xcd < 32) {
-        uint32_t mask[8];
-        for (int w = 0; w < 8; ++w) mask[w] = 0;
-        for (int b = 0; b < 8 * (32 - free_per_xcd); ++b) mask[b >> 5] |= 1u << (b & 31);
-        if (hipExtStreamCreateWithCUMask(&aux->side, 8, mask) != hipSuccess) aux->side = nullptr;
-    }
-    if (!aux->side) (void)hipStreamCreateWithFlags(&aux->side, hipStreamNonBlocking);
-    for (int i = 0; i < PotrfAux::NEV; ++i) (void)hipEventCreateWithFlags(&aux->ev[i], hipEventDisableTiming);
-    aux->last_rest = nullptr;
-}
-void potrf_aux_destroy(PotrfAux* aux) {
-    if (!aux->side) return;
-    (void)hipStreamSynchronize(aux->side);
-    (void)hipStreamDestroy(aux->side);
-    for (int i = 0; i < PotrfAux::NEV; ++i) (void)hipEventDestroy(aux->ev[i]);
-    aux->side = nullptr;
-}
-
-int potrf_default_nbo(int Np) {
-    if (tune(TUNE_POTRF_NBO, 0) >= 1) return (int)tune(TUNE_POTRF_NBO, 0);
-    return Np >= 8192 ? 4 : 1;   // measured (tools/probes/potrf_bench): two-level pays from N = 8192 (10.4 -> 9.5 ms), not below
-}
-
-void launch_potrf(hipStream_t s, double* A, int Np, double* Linv, int* info, int nbo, PotrfAux* aux, int* dataflow_sync) {
-    diag_attr();
-    const int nb = Np / NB;
-    const long ld = Np;
-    const int mode = potrf_default_mode(Np);
-    if (dataflow_sync && nb >= 3 && mode == 3 && launch_potrf_dataflow(s, A, Np, Linv, info, dataflow_sync)) return;
-    if (nbo < 1) nbo = potrf_default_nbo(Np);
-    const bool look = aux && aux->side && nbo > 1 && nb > 2 * nbo;
-    auto syrk = [&](hipStream_t st, int kcol0, int ktiles, int row0, int col0, int ncols) {
-        // A[row0.., col0 .. col0+ncols) -= L[row0.., kcol0 .. kcol0+ktiles) L[col0.., same]^T on lower tiles (row >= col)
-        const int mt = nb - row0;
-        if (mt <= 0 || ncols <= 0) return;
-        const double* Ap = A + (long)row0 * NB + (long)kcol0 * NB * ld;
-        const double* Bp = A + (long)col0 * NB + (long)kcol0 * NB * ld;
-        double* Cp = A + (long)row0 * NB + (long)col0 * NB * ld;
-        GemmDesc u = mkdesc(Ap, ld, Bp, ld, Cp, ld, mt, ncols, ktiles * NB, -1.0, 1.0);
-        u.tri = 1;
-        u.tri_off = col0 - row0;     // tile (tm, tn) is on or below the diagonal iff row0 + tm >= col0 + tn
-        launch_tri_gemm<false, false>(st, u, 1);
-    };
-    int ev_i = 0;
-    for (int J0 = 0; J0 < nb; J0 += nbo) {
-        const int J1 = std::min(J0 + nbo, nb);      // outer block = tile columns [J0, J1)
-        for (int j = J0; j < J1; ++j) {
-            double* Ajj = A + (long)j * NB * (ld + 1);
-            double* Tjj = Linv + (long)j * NB * (ld + 1);
-            hipLaunchKernelGGL(chol_diag_kernel<true>, dim3(1), dim3(256), DIAG_LDS_BYTES, s, Ajj, ld, Tjj, ld, info, j * NB);
-            const int rem = nb - j - 1;
-            if (rem <= 0) break;
-            double* Apan = Ajj + NB;   // rows below the diagonal block, same columns
-            // panel: L_ij = A_ij T_jj^T   (B operand elem(n,k) = T[n + k ld], M-contiguous)
-            GemmDesc p = mkdesc(Apan, ld, Tjj, ld, Apan, ld, rem, 1, NB, 1.0, 0.0);
-            launch_tri_gemm<false, false>(s, p, 1);
-            // inner update: the remaining columns of this outer block
-            syrk(s, j, 1, j + 1, j + 1, J1 - (j + 1));
-        }
-        if (J1 >= nb) break;
-        const int kt = J1 - J0;
-        if (!look) {
-            syrk(s, J0, kt, J1, J1, nb - J1);   // nbo == 1: the inner update above had no columns, this is the whole update
-            continue;
-        }
-        // look-ahead: next outer block's columns on the main stream, the rest on the side stream
-        const int N1 = std::min(J1 + nbo, nb);
-        hipEvent_t panel_done = aux->ev[ev_i % PotrfAux::NEV];
-        hipEvent_t rest_done = aux->ev[(ev_i + 1) % PotrfAux::NEV];
-        ev_i += 2;
-        (void)hipEventRecord(panel_done, s);
-        (void)hipStreamWaitEvent(aux->side, panel_done, 0);
-        if (N1 < nb) syrk(aux->side, J0, kt, N1, N1, nb - N1);          // in order after the previous rest on the side stream
-        (void)hipEventRecord(rest_done, aux->side);
-        // the next block's columns were also written by the PREVIOUS rest update (side stream): order after it
-        if (aux->last_rest) (void)hipStreamWaitEvent(s, aux->last_rest, 0);
-        syrk(s, J0, kt, J1, J1, N1 - J1);
-        aux->last_rest = rest_done;
-    }
-    if (look) {
-        if (aux->last_rest) (void)hipStreamWaitEvent(s, aux->last_rest, 0);   // join: later work on s sees the whole factor
-        aux->last_rest = nullptr;
-    }
-}
-
 __global__ __launch_bounds__(256) void diag_inverse_batched_kernel(const double* __restrict__ L, long ld, double* __restrict__ Linv) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const long off = (long)blockIdx.x * NB * (ld + 1);
@@ -1842,379 +1571,6 @@ __global__ __launch_bounds__(256) void diag_inverse_batched_kernel(const double*
 void launch_diag_inverse(hipStream_t s, const double* L, int Np, double* Linv) {
     ensure_dyn_lds((const void*)diag_inverse_batched_kernel, DIAG_LDS_BYTES);
     hipLaunchKernelGGL(diag_inverse_batched_kernel, dim3(Np / NB), dim3(256), DIAG_LDS_BYTES, s, L, (long)Np, Linv);
-}
-
-// dst block = (src block)^T for `batches` blocks of tr x tc 32 x 32 sub-tiles each (through a padded LDS tile: both sides
-// coalesced).  Blocks whose first tile row lies beyond the matrix are skipped (vb_*, as in GemmDesc).
-__global__ __launch_bounds__(256) void transpose_blocks_kernel(const double* __restrict__ src, double* __restrict__ dst, long ld,
-                                                               long stride, int vb_stride, int vb_off, int vb_limit) {
-    __shared__ double tile[32][33];
-    const int batch = blockIdx.z;
-    // rows of the source block beyond the matrix do not exist (last pair of a level): 128-row granularity
-    if (batch * vb_stride + vb_off + (int)(blockIdx.x / 4) >= vb_limit) return;
-    const double* S = src + batch * stride;
-    double* Dp = dst + batch * stride;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-    for (int r = ty; r < 32; r += 8) tile[r][tx] = S[(long)(32 * blockIdx.x + tx) + (long)(32 * blockIdx.y + r) * ld];   // tile[col][row]
-    __syncthreads();
-    for (int r = ty; r < 32; r += 8) Dp[(long)(32 * blockIdx.y + tx) + (long)(32 * blockIdx.x + r) * ld] = tile[tx][r];
-}
-
-// dst = src^T for a whole Np x Np matrix (handles with the solve-based sigma read EVERY block of U = (L^-1)^T; trtri leaves the
-// strictly-lower blocks of U unwritten, and the rank-1 growth of sls_gp_append_point does not maintain U at all)
-void launch_transpose_full(hipStream_t s, const double* src, double* dst, int Np) {
-    hipLaunchKernelGGL(transpose_blocks_kernel, dim3(Np / 32, Np / 32, 1), dim3(256), 0, s, src, dst, (long)Np, 0L, 0, 0, 1 << 30);
-}
-
-// Linv (diagonal blocks already inverted) <- full lower-triangular inverse X = L^-1, and U <- X^T (upper triangular), level by
-// level (recursive doubling).  Level with half-size h blocks, pair p = blocks F = [2hp, 2hp+h) | S = [2hp+h, min(2hp+2h, nb)):
-//     W (F x S) = U_FF L_SF^T        (= (L_SF X_FF)^T)         k >= 128 tm
-//     X_SF      = -X_SS W^T                                     k <  128 (tm + 1)
-//     U_FS      = X_SF^T                                        (transpose_blocks_kernel)
-// Keeping the transposed inverse next to the inverse makes BOTH products NT forms of column-major operands, i.e. both operands
-// M-contiguous: they run on gemm_tile_mc (LDS-direct loads, 0.95 of the MFMA peak) instead of the staged K-contiguous path
-// (0.6-0.7), and so does lauum (K^-1 = U U^T).  Every element is the same dot product in the same k order as in the NN form
-// (tmp = L_SF X_FF, X_SF = -X_SS tmp), so the results are bit-identical to it.  W lives in `tmp` (the K^-1 buffer, free until
-// lauum).  U's strictly-lower blocks are never read; its diagonal blocks are the transposed diagonal blocks of X.
-void launch_trtri(hipStream_t s, const double* L, int Np, double* Linv, double* tmp, double* U) {
-    const int nb = Np / NB;
-    const long ld = Np;
-    // diagonal blocks: U_jj = X_jj^T (zeros included)
-    hipLaunchKernelGGL(transpose_blocks_kernel, dim3(4, 4, nb), dim3(256), 0, s, Linv, U, ld, (long)NB * (ld + 1), 0, 0, 1 << 30);
-    for (int h = 1; h < nb; h *= 2) {
-        const int pairs = (nb + 2 * h - 1) / (2 * h);
-        const long pstride = (long)2 * h * NB * (ld + 1);
-        const long off21 = (long)h * NB;          // block (S, F): rows of the second half, columns of the first
-        const long off12 = (long)h * NB * ld;     // block (F, S)
-        const bool narrow = (long)h * h * pairs <= 512;   // fewer 128 x 128 tiles than workgroup slots: half tiles
-        // W = U_FF * L_SF^T : A = U_FF (M-contig, k >= 128 tm), B elem(n,k) = L_SF[n + k ld] (M-contig); columns n in S
-        GemmDesc g1 = mkdesc(U, ld, L + off21, ld, tmp + off12, ld, h, h, h * NB, 1.0, 0.0);
-        g1.strideA = g1.strideB = g1.strideC = pstride;
-        g1.kmode = 4;
-        g1.vb_stride = 2 * h; g1.vb_off = h; g1.vb_limit = nb; g1.vb_on_n = 1;
-        g1.order = 3;       // k >= 128 tm: long rows first
-        if (narrow) launch_tri_gemm_mc_half(s, g1, pairs, true);
-        else launch_tri_gemm<false, false>(s, g1, pairs, true);
-        // X_SF = -X_SS * W^T : A = X_SS (M-contig, k < 128 (tm+1)), B elem(n,k) = W[n + k ld] (M-contig); rows m in S
-        GemmDesc g2 = mkdesc(Linv + (long)h * NB * (ld + 1), ld, tmp + off12, ld, Linv + off21, ld, h, h, h * NB, -1.0, 0.0);
-        g2.strideA = g2.strideB = g2.strideC = pstride;
-        g2.kmode = 2;
-        g2.vb_stride = 2 * h; g2.vb_off = h; g2.vb_limit = nb;
-        g2.order = 2;       // k < 128 (tm + 1): long rows first
-        if (narrow) launch_tri_gemm_mc_half(s, g2, pairs, true);
-        else launch_tri_gemm<false, false>(s, g2, pairs, true);
-        // U_FS = X_SF^T
-        hipLaunchKernelGGL(transpose_blocks_kernel, dim3(4 * h, 4 * h, pairs), dim3(256), 0, s, Linv + off21, U + off12,
-                           ld, pstride, 2 * h, h, nb);
-    }
-}
-
-__global__ __launch_bounds__(256) void symmetrize_kernel(double* __restrict__ A, int Np) {
-    // copy the lower triangle into the upper one through a 32x33 LDS tile (both sides coalesced)
-    __shared__ double tile[32][33];
-    const int bi = blockIdx.x, bj = blockIdx.y;
-    if (bj > bi) return;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-    for (int r = ty; r < 32; r += 8) tile[r][tx] = A[(long)(32 * bi + tx) + (long)(32 * bj + r) * Np];   // tile[c][r_in]
-    __syncthreads();
-    for (int r = ty; r < 32; r += 8) {
-        const int gi = 32 * bj + tx, gj = 32 * bi + r;   // transposed position
-        if (gi < gj) A[(long)gi + (long)gj * Np] = tile[tx][r];
-    }
-}
-
-// K^-1 = X^T X = U U^T with U = X^T (launch_trtri): lower tiles, A elem(m,k) = U[m + k ld], B elem(n,k) = U[n + k ld] (both
-// M-contiguous), k >= 128 max(tm,tn) = 128 tm.
-void launch_lauum(hipStream_t s, const double* U, int Np, double* Kinv) {
-    const int nb = Np / NB;
-    const long ld = Np;
-    GemmDesc g = mkdesc(U, ld, U, ld, Kinv, ld, nb, nb, Np, 1.0, 0.0);
-    g.tri = 1;
-    g.kmode = 3;
-    g.order = 1;            // rows from the top, longest k range first, no idle workgroups
-    // small matrices leave most workgroup slots empty: half tiles double the count (SLS_LAUUM_N64=0/1 overrides)
-    const int n64_env = (int)tune(TUNE_LAUUM_N64, -1);
-    // measured inside the C5 evaluation (N = 4096): 3.41 -> 3.24 ms per evaluation with half tiles (the longest tile's k loop,
-    // 32 slabs of 13.6 us on a shared CU, bounds the launch); at N = 8192 whole tiles win (2.9 ms, 0.80 of peak)
-    const bool narrow = n64_env >= 0 ? n64_env != 0 : nb <= 32;
-    if (narrow) launch_tri_gemm_mc_half(s, g, 1);
-    else launch_tri_gemm<false, false>(s, g, 1);
-    hipLaunchKernelGGL(symmetrize_kernel, dim3(Np / 32, Np / 32), dim3(256), 0, s, Kinv, Np);
-}
-
-// A (SPD, lower triangle read) -> L in place, Linv = L^-1, U = Linv^T (blocks on and above the diagonal), Kinv = A^-1 (full).
-// N <= 4096 with the single-launch schedule available: ONE launch (factorisation + fused inverse, potri_team); otherwise
-// launch_potrf + launch_trtri + launch_lauum.  SLS_POTRI_FUSED=0 forces the separate launches (A/B, tests).  Returns true when
-// the fused launch was used.  As with launch_potrf, info[1] != 0 afterwards means the single launch gave up: repeat on the
-// multi-launch schedule (dataflow_sync = nullptr).
-bool potri_fused_applies(int Np, bool have_sync) {
-    const int nb = Np / NB;
-    return tune_on(TUNE_POTRI_FUSED) && have_sync && nb >= 3 && nb <= 32 && potrf_default_mode(Np) == 3;
-}
-// linv_zeroed = false: the caller has NOT cleared Linv (the fused launch does not need it: it writes the diagonal tiles in full and
-// the tiles below them, and leaves the tiles above the diagonal alone); the separate launches clear it here.
-bool launch_potri(hipStream_t s, double* A, int Np, double* Linv, double* U, double* Kinv, int* info, PotrfAux* aux, int* dataflow_sync,
-                  bool linv_zeroed) {
-    if (potri_fused_applies(Np, dataflow_sync != nullptr) && launch_potri_dataflow(s, A, Np, Linv, U, Kinv, info, dataflow_sync))
-        return true;
-    if (!linv_zeroed) launch_fill(s, Linv, (long)Np * Np, 0.0);
-    launch_potrf(s, A, Np, Linv, info, 0, aux, dataflow_sync);
-    launch_trtri(s, A, Np, Linv, Kinv, U);
-    launch_lauum(s, U, Np, Kinv);
-    return false;
-}
-
-// B <- (L L^T)^-1 B, B is Np x Rp (ld = Np).  Block forward / backward substitution, each step two tile GEMMs.
-void launch_potrs(hipStream_t s, const double* L, const double* Linv, int Np, double* B, int Rp) {
-    const int nb = Np / NB, rt = Rp / NB;
-    const long ld = Np;
-    for (int j = 0; j < nb; ++j) {   // forward: X_j = T_jj B_j ; B_i -= L_ij X_j (i > j)
-        const double* Tjj = Linv + (long)j * NB * (ld + 1);
-        double* Bj = B + (long)j * NB;
-        GemmDesc a = mkdesc(Tjj, ld, Bj, ld, Bj, ld, 1, rt, NB, 1.0, 0.0);   // B operand elem(n,k) = Bj[k + n ld]: K-contig
-        launch_tri_gemm<false, true>(s, a, 1);
-        const int rem = nb - j - 1;
-        if (rem > 0) {
-            GemmDesc u = mkdesc(L + (long)j * NB * (ld + 1) + NB, ld, Bj, ld, Bj + NB, ld, rem, rt, NB, -1.0, 1.0);
-            launch_tri_gemm<false, true>(s, u, 1);
-        }
-    }
-    for (int j = nb - 1; j >= 0; --j) {   // backward: X_j = T_jj^T B_j ; B_i -= L_ji^T X_j (i < j)
-        const double* Tjj = Linv + (long)j * NB * (ld + 1);
-        double* Bj = B + (long)j * NB;
-        GemmDesc a = mkdesc(Tjj, ld, Bj, ld, Bj, ld, 1, rt, NB, 1.0, 0.0);   // A elem(m,k) = T[k + m ld]: K-contig
-        launch_tri_gemm<true, true>(s, a, 1);
-        if (j > 0) {
-            // rows i < j: A elem(m,k) = L[(j NB + k) + m ld] over block row j of L, columns 0.. j NB
-            GemmDesc u = mkdesc(L + (long)j * NB, ld, Bj, ld, B, ld, j, rt, NB, -1.0, 1.0);
-            launch_tri_gemm<true, true>(s, u, 1);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// small helpers
-// ---------------------------------------------------------------------------------------------------------
-// y = A x (A column-major Np x Np): columns split into chunks over blockIdx.y so that the whole chip streams the matrix;
-// the per-chunk partials are summed in a fixed order by a second tiny kernel (deterministic).
-__global__ __launch_bounds__(256) void gemv_n_partial_kernel(const double* __restrict__ A, int Np, const double* __restrict__ x,
-                                                             double* __restrict__ part, int cols_per_chunk) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= Np) return;
-    const int j0 = blockIdx.y * cols_per_chunk;
-    double s = 0.0;
-#pragma unroll 4
-    for (int j = j0; j < j0 + cols_per_chunk; ++j) s += A[(long)i + (long)j * Np] * x[j];
-    part[(long)blockIdx.y * Np + i] = s;
-}
-__global__ __launch_bounds__(256) void gemv_n_reduce_kernel(const double* __restrict__ part, int Np, int chunks,
-                                                            double* __restrict__ y) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= Np) return;
-    double s = 0.0;
-    for (int c = 0; c < chunks; ++c) s += part[(long)c * Np + i];
-    y[i] = s;
-}
-void launch_gemv_n(hipStream_t s, const double* A, int Np, const double* x, double* y, double* part) {
-    const int chunks = Np / 128;                 // 128 columns per chunk
-    hipLaunchKernelGGL(gemv_n_partial_kernel, dim3((Np + 255) / 256, chunks), dim3(256), 0, s, A, Np, x, part, 128);
-    hipLaunchKernelGGL(gemv_n_reduce_kernel, dim3((Np + 255) / 256), dim3(256), 0, s, part, Np, chunks, y);
-}
-
-// y_j = sum_i A[i,j] x_i : one wave per column, wave-shuffle reduction
-__global__ __launch_bounds__(256) void gemv_t_kernel(const double* __restrict__ A, int Np, const double* __restrict__ x,
-                                                     double* __restrict__ y) {
-    const int lane = threadIdx.x & 63;
-    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (j >= Np) return;
-    double s = 0.0;
-    for (int i = lane; i < Np; i += 64) s += A[(long)i + (long)j * Np] * x[i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) y[j] = s;
-}
-void launch_gemv_t(hipStream_t s, const double* A, int Np, const double* x, double* y) {
-    hipLaunchKernelGGL(gemv_t_kernel, dim3((Np + 3) / 4), dim3(256), 0, s, A, Np, x, y);
-}
-
-__device__ __forceinline__ double block_sum256(double v, double* red) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
-}
-__global__ __launch_bounds__(256) void append_dots_kernel(const double* __restrict__ k, const double* __restrict__ u,
-                                                          const double* __restrict__ l, const double* __restrict__ y, int N,
-                                                          double* __restrict__ out) {
-    __shared__ double red[4];
-    double a = 0.0, b = 0.0, c = 0.0;
-    for (int i = threadIdx.x; i < N; i += 256) {
-        a += k[i] * u[i];
-        b += l[i] * l[i];
-        c += u[i] * y[i];
-    }
-    const double ta = block_sum256(a, red), tb = block_sum256(b, red), tc = block_sum256(c, red);
-    if (threadIdx.x == 0) { out[0] = ta; out[1] = tb; out[2] = tc; }
-}
-void launch_append_dots(hipStream_t s, const double* k, const double* u, const double* l, const double* y, int N, double* scal_out) {
-    hipLaunchKernelGGL(append_dots_kernel, dim3(1), dim3(256), 0, s, k, u, l, y, N, scal_out);
-}
-__global__ __launch_bounds__(256) void append_update_kernel(double* __restrict__ Kinv, double* __restrict__ L, double* __restrict__ Linv,
-                                                            double* __restrict__ alpha, int Np, int N, const double* __restrict__ u,
-                                                            const double* __restrict__ l, const double* __restrict__ scal, double kappa,
-                                                            double eta) {
-    // Schur complement s = kappa - k.K^-1 k (from the inverse) and lam^2 = kappa - l.l (from the factor) are the same number
-    const double sch = kappa - scal[0];
-    const double lam = sqrt(kappa - scal[1]);
-    const double uy = scal[2];
-    const int i = blockIdx.x * 256 + threadIdx.x;   // row
-    const int j = blockIdx.y;                       // column, 0..N
-    if (i > N) return;
-    if (j < N && i < N) {
-        Kinv[(long)i + (long)j * Np] += u[i] * u[j] / sch;
-    } else if (j == N) {
-        Kinv[(long)i + (long)N * Np] = (i < N) ? -u[i] / sch : 1.0 / sch;
-        if (i < N) {
-            Kinv[(long)N + (long)i * Np] = -u[i] / sch;
-            L[(long)N + (long)i * Np] = l[i];
-            Linv[(long)N + (long)i * Np] = -u[i] / lam;
-            alpha[i] += u[i] * (uy - eta) / sch;
-        } else {
-            L[(long)N * (Np + 1)] = lam;
-            Linv[(long)N * (Np + 1)] = 1.0 / lam;
-            alpha[N] = (eta - uy) / sch;
-        }
-    }
-}
-void launch_append_update(hipStream_t s, double* Kinv, double* L, double* Linv, double* alpha, int Np, int N, const double* u,
-                          const double* l, const double* scal, double kappa, double eta) {
-    hipLaunchKernelGGL(append_update_kernel, dim3((N + 1 + 255) / 256, N + 1), dim3(256), 0, s, Kinv, L, Linv, alpha, Np, N, u, l, scal,
-                       kappa, eta);
-}
-
-__global__ __launch_bounds__(256) void zero_upper_kernel(double* __restrict__ A, int Np) {
-    const long idx = blockIdx.x * 256L + threadIdx.x;
-    if (idx >= (long)Np * Np) return;
-    const int i = idx % Np, j = idx / Np;
-    if (i < j) A[idx] = 0.0;
-}
-void launch_zero_upper(hipStream_t s, double* A, int Np) {
-    const long n = (long)Np * Np;
-    hipLaunchKernelGGL(zero_upper_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, A, Np);
-}
-
-__global__ __launch_bounds__(256) void fill_kernel(double* __restrict__ p, long n, double v) {
-    long i = blockIdx.x * 256L + threadIdx.x;
-    const long stride = gridDim.x * 256L;
-    for (; i < n; i += stride) p[i] = v;
-}
-void launch_fill(hipStream_t s, double* p, long n, double v) {
-    if (n <= 0) return;
-    long blocks = (n + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, n, v);
-}
-
-// The tail of a fit in ONE single-workgroup launch (it was mu_data + argmax + logdet, ~5-7 us of stream time each, and three blocking
-// pageable copies back): mu_data_i = y_i - b alpha_i (regressor.cpp:29-43 at the data points), its FIRST maximum (Eigen maxCoeff
-// semantics, argmax_kernel's comparisons and tree), log|K_y| = 2 sum log L_ii (256 partial sums, i mod 256, then a binary tree), and -- when
-// `summary` is given -- everything the host wants after the fit in one mapped block: [0] max mu, [1] log|K_y|, [2] arg max,
-// [3], [4] the factorisation's two info words.
-__global__ __launch_bounds__(1024) void fit_summary_kernel(const double* __restrict__ y, const double* __restrict__ alpha, double b, int N,
-                                                           double* __restrict__ mu_data, const double* __restrict__ L, int Np,
-                                                           const int* __restrict__ info, double* __restrict__ scal,
-                                                           long* __restrict__ d_idx, double* __restrict__ summary) {
-    __shared__ double sv[1024];
-    __shared__ int si[1024];
-    __shared__ double red[256];
-    const int tid = threadIdx.x;
-    double bv = -INFINITY;
-    int bi = 0x7fffffff;
-    for (int i = tid; i < N; i += 1024) {
-        const double v = y[i] - b * alpha[i];
-        mu_data[i] = v;
-        if (v > bv) { bv = v; bi = i; }   // strictly greater: keeps the earliest index within this thread
-    }
-    sv[tid] = bv;
-    si[tid] = bi;
-    if (tid < 256) {
-        double s = 0.0;
-        for (int i = tid; i < N; i += 256) s += log(L[(long)i * (Np + 1)]);
-        red[tid] = s;
-    }
-    __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
-        if (tid < s) {
-            const double ov = sv[tid + s];
-            const int oi = si[tid + s];
-            if (ov > sv[tid] || (ov == sv[tid] && oi < si[tid])) {
-                sv[tid] = ov;
-                si[tid] = oi;
-            }
-            if (s <= 128) red[tid] += red[tid + s];
-        }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        // all -inf / NaN: Eigen's maxCoeff returns index 0
-        const double best = (si[0] == 0x7fffffff) ? (y[0] - b * alpha[0]) : sv[0];
-        const long idx = (si[0] == 0x7fffffff) ? 0 : si[0];
-        const double ld = 2.0 * red[0];
-        scal[0] = best; scal[1] = ld; d_idx[0] = idx;
-        if (summary) {
-            summary[0] = best; summary[1] = ld; summary[2] = (double)idx;
-            summary[3] = (double)info[0]; summary[4] = (double)info[1];
-        }
-    }
-}
-void launch_fit_summary(hipStream_t s, const double* y, const double* alpha, double b, int N, double* mu_data, const double* L, int Np,
-                        const int* info, double* scal, long* d_idx, double* summary) {
-    hipLaunchKernelGGL(fit_summary_kernel, dim3(1), dim3(1024), 0, s, y, alpha, b, N, mu_data, L, Np, info, scal, d_idx, summary);
-}
-
-// ---- bordered factorisation: quad = y^T K^-1 y and log|K| from the factor alone --------------------------------------------
-// Row N of the (identity-padded) matrix is replaced by (y^T, c): the factorisation then leaves t = L^-1 y in row N of L
-// (L_Nk = (y_k - sum_{m<k} L_Nm L_km) / L_kk is the forward substitution), so y^T K^-1 y = |t|^2 comes out of the ONE persistent
-// launch -- no inverse, no separate solve.  c only has to keep the last pivot c - |t|^2 positive; nothing else depends on it.
-// Workgroup q of the launch handles problem q (A + q strideA).
-__global__ __launch_bounds__(256) void border_row_kernel(double* __restrict__ A, long strideA, int Np, int N, const double* __restrict__ y,
-                                                         double c) {
-    double* Aq = A + blockIdx.x * strideA;
-    for (int k = threadIdx.x; k <= N; k += 256) Aq[N + (long)k * Np] = k < N ? y[k] : c;
-}
-void launch_border_row(hipStream_t s, double* A, long strideA, int nprob, int Np, int N, const double* y, double c) {
-    hipLaunchKernelGGL(border_row_kernel, dim3(nprob), dim3(256), 0, s, A, strideA, Np, N, y, c);
-}
-// out[2 q] = y^T K^-1 y = sum_k L_Nk^2, out[2 q + 1] = log|K| = 2 sum_{i<N} log L_ii  (fixed summation order)
-__global__ __launch_bounds__(256) void border_reduce_kernel(const double* __restrict__ L, long strideA, int Np, int N,
-                                                            double* __restrict__ out) {
-    __shared__ double red[2][256];
-    const double* Lq = L + blockIdx.x * strideA;
-    double q = 0.0, ld = 0.0;
-    for (int k = threadIdx.x; k < N; k += 256) {
-        const double t = Lq[N + (long)k * Np];
-        q = fma(t, t, q);
-        ld += log(Lq[(long)k * (Np + 1)]);
-    }
-    red[0][threadIdx.x] = q;
-    red[1][threadIdx.x] = ld;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) {
-            red[0][threadIdx.x] += red[0][threadIdx.x + o];
-            red[1][threadIdx.x] += red[1][threadIdx.x + o];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        out[2 * blockIdx.x] = red[0][0];
-        out[2 * blockIdx.x + 1] = 2.0 * red[1][0];
-    }
-}
-void launch_border_reduce(hipStream_t s, const double* L, long strideA, int nprob, int Np, int N, double* out) {
-    hipLaunchKernelGGL(border_reduce_kernel, dim3(nprob), dim3(256), 0, s, L, strideA, Np, N, out);
 }
 
 }  // namespace slsk

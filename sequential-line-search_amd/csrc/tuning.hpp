@@ -8,7 +8,7 @@ namespace slsk {
 // call site and call.  sls_tuning_reload() (C ABI; the Python binding's tuning_reload()) re-reads the environment: tests switch
 // paths inside one process.  tune(K, dflt): the variable's integer value, dflt when it is not set.  DESIGN.md lists the meanings.
 #define SLS_TUNING_KEYS(X)                                                                                                      \
-    X(POOL_MB) X(POTRF_LOOKAHEAD) X(FIT_SMALL) X(TRI_PREDICT) X(WAVE_PATH) X(IO_STAGE) X(EVAL_ZEROCOPY) X(WAVE_TRACE) X(COMPACT) \
+    X(POOL_MB) X(FIT_SMALL) X(TRI_PREDICT) X(WAVE_PATH) X(IO_STAGE) X(EVAL_ZEROCOPY) X(WAVE_TRACE) X(COMPACT) \
     X(NLL_SMALL) X(SMALL_ZEROCOPY) X(NLL_BATCH) X(MAP_DEVICE) X(MAP_TRACE) X(SMALL_XLDS) X(MULTI_RCCL) X(PERSIST)                \
     X(ACQ_WG_PER_CU) X(GATE_PHASE) X(TAIL_SPLIT) X(LBFGS_REG) X(TRI_WG_PER_CU) X(POTRF_MODE) X(POTRF_DNBO) X(POTRF_NBO)          \
     X(LAUUM_N64) X(POTRI_FUSED) X(POTRF_STREAM) X(POTRF_SPLIT) X(POTRI_W1) X(POTRF_TIMEOUT_TICKS) X(POTRF_DNEAR) X(POTRI_PLAST)  \

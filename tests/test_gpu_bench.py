@@ -79,7 +79,7 @@ def test_bench_line_carries_measured_traffic():
     small = [a for a in SMALL if a != "--no-traffic"]
     j = run([sys.executable, "bench.py", "--gpus", "1"] + small)
     r = j["roofline"]
-    assert isinstance(r["traffic"], float) and r["traffic"] > 0, r
+    assert isinstance(r["traffic"], float) and r["traffic"] > 0, r["traffic_detail"]
     d = r["traffic_detail"]
     assert d["launches_measured"] >= 1 and d["candidates_per_launch"] == 3072 and d["traffic_over_algorithmic"] > 0.5, d
 

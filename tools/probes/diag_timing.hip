@@ -1,6 +1,8 @@
 // cycle stamps of chol_diag_kernel phases + residual check + rsqrt seed accuracy (debug tool, not shipped)
 #define SLS_DIAG_TIMING 1
 #include "../../sequential-line-search_amd/csrc/kernels_chol.hip"
+#include "../../sequential-line-search_amd/csrc/kernels_tri.hip"
+#include "../../sequential-line-search_amd/csrc/kernels_vec.hip"
 #include <cmath>
 #include <cstring>
 #include <cstdio>

@@ -2,6 +2,8 @@
 // dimension of U (is the distance of lauum from the list-schedule bound a power-of-two-stride effect?), as a full square
 // product for reference.  usage: lauum_bench N [pad ...]
 #include "../../sequential-line-search_amd/csrc/kernels_chol.hip"
+#include "../../sequential-line-search_amd/csrc/kernels_tri.hip"
+#include "../../sequential-line-search_amd/csrc/kernels_vec.hip"
 #include <cstdio>
 #include <vector>
 
@@ -42,7 +44,7 @@ int main(int argc, char** argv) {
                 hipMemsetAsync(Li, 0, bytes, s);
                 hipStreamSynchronize(s);
                 hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-                if (mode == 1) launch_potrf(s, A, Np, Li, info, 0, nullptr, info + 64);
+                if (mode == 1) launch_potrf(s, A, Np, Li, info, 0, info + 64);
                 hipEventRecord(e0, s);
                 launch_tri_gemm<false, false>(s, g, 1, false);
                 hipEventRecord(e1, s); hipEventSynchronize(e1);

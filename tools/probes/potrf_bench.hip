@@ -1,6 +1,8 @@
 // potrf schedule experiments (debug tool, not shipped): one-level vs two-level blocking, look-ahead on a CU-masked side
 // stream.  usage: potrf_bench [N ...]   env: none.  Prints ms per factorisation and the max deviation from the one-level L.
 #include "../../sequential-line-search_amd/csrc/kernels_chol.hip"
+#include "../../sequential-line-search_amd/csrc/kernels_tri.hip"
+#include "../../sequential-line-search_amd/csrc/kernels_vec.hip"
 #include <cmath>
 #include <cstdio>
 #include <set>
@@ -47,38 +49,20 @@ int main(int argc, char** argv) {
     hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
     int* info; hipMalloc(&info, 8192);
     const bool quick = getenv("POTRF_BENCH_QUICK") != nullptr;
-    // which CUs does a masked stream use?
-    for (int f : {0, 2, 4, 8}) {
-        if (quick) break;
-        PotrfAux aux;
-        potrf_aux_create(&aux, f);
-        int* d; hipMalloc(&d, 4096 * 4);
-        hipLaunchKernelGGL(where_kernel, dim3(2048), dim3(256), 0, aux.side, d);
-        hipStreamSynchronize(aux.side);
-        std::vector<int> h(2048); hipMemcpy(h.data(), d, 2048 * 4, hipMemcpyDeviceToHost);
-        std::set<int> cus; int per_xcd[8] = {0};
-        for (int v : h) cus.insert(v);
-        for (int v : cus) per_xcd[(v >> 16) & 7]++;
-        printf("mask free_per_xcd=%d: %zu distinct CUs used; per XCD:", f, cus.size());
-        for (int x = 0; x < 8; ++x) printf(" %d", per_xcd[x]);
-        printf("\n");
-        hipFree(d);
-        potrf_aux_destroy(&aux);
-    }
     for (int Np : sizes) {
         double *A0, *A, *Lref, *Linv, *red;
         const size_t bytes = (size_t)Np * Np * 8;
         hipMalloc(&A0, bytes); hipMalloc(&A, bytes); hipMalloc(&Lref, bytes); hipMalloc(&Linv, bytes); hipMalloc(&red, 1024 * 8);
         hipLaunchKernelGGL(fill_spd, dim3((unsigned)(((long)Np * Np + 255) / 256)), dim3(256), 0, s, A0, Np);
         hipMemsetAsync(Linv, 0, bytes, s);
-        auto run = [&](int nbo, PotrfAux* aux, const char* label, bool is_ref) {
+        auto run = [&](int nbo, const char* label, bool is_ref) {
             float best = 1e30f;
             for (int rep = 0; rep < 4; ++rep) {
                 hipMemcpyAsync(A, A0, bytes, hipMemcpyDeviceToDevice, s);
                 hipMemsetAsync(info, 0, 64, s);
                 hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
                 hipEventRecord(e0, s);
-                launch_potrf(s, A, Np, Linv, info, nbo, aux, nullptr);
+                launch_potrf(s, A, Np, Linv, info, nbo, nullptr);
                 hipEventRecord(e1, s); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 if (rep > 0 && ms < best) best = ms;
@@ -97,7 +81,7 @@ int main(int argc, char** argv) {
             const double tf = (double)Np * Np * Np / 3.0 / (best * 1e-3) / 1e12;
             printf("N=%5d %-34s %8.3f ms  %6.2f TFLOP/s  info=%d  max|L - L_ref|=%.2e\n", Np, label, best, tf, inf, md);
         };
-        run(1, nullptr, "one-level (nbo=1)", true);
+        run(1, "one-level (nbo=1)", true);
         {   // dataflow form (SLS_POTRF_DNBO / SLS_POTRF_DPR from the environment)
             int* dsync; hipMalloc(&dsync, potrf_dataflow_sync_ints(Np) * sizeof(int));
             float best = 1e30f; bool ok = true;
@@ -325,17 +309,8 @@ int main(int argc, char** argv) {
         for (int nbo : {2, 4, 8}) {
             char lab[96];
             snprintf(lab, sizeof lab, "two-level nbo=%d", nbo);
-            run(nbo, nullptr, lab, false);
+            run(nbo, lab, false);
         }
-        for (int f : {0, 2, 4, 8})
-            for (int nbo : {2, 4, 8}) {
-                PotrfAux aux;
-                potrf_aux_create(&aux, f);
-                char lab[96];
-                snprintf(lab, sizeof lab, "look-ahead nbo=%d free/xcd=%d", nbo, f);
-                run(nbo, &aux, lab, false);
-                potrf_aux_destroy(&aux);
-            }
         hipFree(A0); hipFree(A); hipFree(Lref); hipFree(Linv); hipFree(red);
     }
     return 0;
