@@ -263,7 +263,7 @@ typedef struct sls_pref_cfg {
 int sls_pref_objective(sls_nll* h, const unsigned* prefs_flat, const int* pref_offsets, int n_prefs, const double* x,
                        const sls_pref_cfg* cfg, double* value, double* grad);
 /* PreferenceRegressor::PerformMapEstimation (src/preference-regressor.cpp:332-403) as ONE device launch for M <= 128 data points
- * (with use_map_hyperparams: D <= 16): the objective above -- Bradley-Terry-Luce terms included -- is maximised on the device by
+ * and D <= 128 dimensions, with or without use_map_hyperparams: the objective above -- Bradley-Terry-Luce terms included -- is maximised on the device by
  * the bounded L-BFGS that stands in for nloptutil::solve(..., LD_TNEWTON, ..., num_iters) (:377).  Variables z = (y_1..y_M
  * [, log a, log b, log r_1..log r_D]); z0 / lower / upper / z_out have that length; max_evals = NLopt's max_evals.
  * evals_per_launch: 0 = the whole fit in one launch; k > 0 = launches of k evaluations each, continued from device-resident
@@ -273,7 +273,7 @@ int sls_pref_map_fit(sls_nll* h, const unsigned* prefs_flat, const int* pref_off
                      const double* z0, const double* lower, const double* upper, int max_evals, int evals_per_launch,
                      double* z_out, double* value, int* evals_used);
 /* Local phase of GaussianProcessRegressor::PerformMapEstimation (src/gaussian-process-regressor.cpp:295: TNEWTON from the DIRECT
- * point) in one launch for N <= 128, D <= 16: maximises sls_gp_nll_grad's objective over z = (log a, log b, log r_1..log r_D). */
+ * point) in one launch for N <= 128, D <= 128: maximises sls_gp_nll_grad's objective over z = (log a, log b, log r_1..log r_D). */
 int sls_gp_map_fit(sls_nll* h, const double* y, const double* z0, const double* lower, const double* upper, int max_evals,
                    int evals_per_launch, double* z_out, double* value, int* evals_used);
 

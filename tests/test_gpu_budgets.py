@@ -47,8 +47,9 @@ def test_c2_fit_and_predict_budget(ctx, oracle):
     pred = best_of(lambda: gp.predict(Xs), 5, ctx.synchronize)
     gp.close()
     record("budget", config="C2", fit_ms=fit, predict_ms=pred)
-    assert fit <= 1.5, fit   # measured 0.86-0.87 once the tail of the fit was one launch writing into mapped host memory
-    assert pred <= 1.0, pred   # measured 0.34-0.35 with the page-locked staging of query points and results
+    # round 5: bounds at 1.25x the measured values (0.86 ms and 0.35-0.38 ms): a regression to the round-3 chain or to pageable copies fails
+    assert fit <= 1.1, fit
+    assert pred <= 0.5, pred
 
 
 def test_factor_and_inverse_device_time_budget(oracle):
@@ -56,7 +57,7 @@ def test_factor_and_inverse_device_time_budget(oracle):
     N = 4096 (kernels_chol.hip: streamed chain + fused inverse).  Measured: 0.74-0.78 ms at N = 2048 (first session of round 4:
     potrf 0.79 + trtri 0.27 + lauum 0.14 = 1.2 ms), 2.16-2.2 ms at N = 4096 (2.62)."""
     m = sls()
-    for N, budget in ((2048, 1.2), (4096, 3.2)):
+    for N, budget in ((2048, 0.9), (4096, 2.7)):       # 1.25x the measured 0.68-0.70 / 2.15-2.2 ms (round 5)
         X, y, theta, b = synth_problem(oracle, 16, N)
         c = m.Context(0)
         m.GP(c, X, y, theta, b, 0).close()            # code objects, buffers
@@ -64,13 +65,14 @@ def test_factor_and_inverse_device_time_budget(oracle):
         for _ in range(3):
             m.GP(c, X, y, theta, b, 0).close()
         ms, launches = c.prof_get("potri")
-        assert launches == 3 and c.prof_get("potrf")[1] == 0 and c.prof_get("potrf_fallbacks")[1] == 0
+        # ONE fused launch per fit: a silent fall-back to potrf + trtri + lauum shows up under another scope name and fails here
+        assert launches == 3 and c.prof_get("potrf")[1] == 0 and c.prof_get("potrf+trtri+lauum")[1] == 0 and c.prof_get("potrf_fallbacks")[1] == 0
         record("budget", config="factor+inverse", N=N, device_ms=ms / 3)
         assert ms / 3 <= budget, (N, ms / 3)
         c.close()
 
 
-@pytest.mark.parametrize("use_map,budget_ms", [(1, 6.0), (0, 4.5)])
+@pytest.mark.parametrize("use_map,budget_ms", [(1, 6.0), (0, 3.2)])     # ~1.25x (MAP on: 4.7-4.9 ms) and 1.45x (fixed: 2.2 ms, trajectory dependent) the measured means
 def test_c3_submit_feedback_budget(use_map, budget_ms):
     """C3: sequential_line_search_nd, D = 32, 30 iterations: wall time of SubmitFeedbackData (preference MAP fit on the device +
     DIRECT -> L-BFGS acquisition maximisation), steady state (the first submit carries the one-off initialisation).
@@ -110,7 +112,7 @@ def test_c5_evaluation_and_batch_budget(ctx, oracle):
         ms_seq = best_of(lambda: h.gp_objective_batch(y, xs), 1, ctx.synchronize)
     h.close()
     record("budget", config="C5", ms_per_evaluation=ms_eval, batch8_ms=ms_batch, sequential8_ms=ms_seq, speedup=ms_seq / ms_batch)
-    assert ms_eval <= 3.6, ms_eval
+    assert ms_eval <= 3.2, ms_eval     # 1.25x the measured 2.5-2.6 ms
     assert ms_seq / ms_batch >= 1.8, (ms_seq, ms_batch)
 
 
