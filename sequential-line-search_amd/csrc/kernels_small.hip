@@ -571,7 +571,7 @@ __global__ __launch_bounds__(256) void nll_small_kernel(const NllSmallArgs args)
 //     - 1/2 y^T K^-1 y - 1/2 log|K| - N/2 log 2 pi           :165-170  /  src/gaussian-process-regressor.cpp:174-180
 //     + log-normal priors of a, b, l_d (nh > 0)              :175-192  /  :181-192
 //   df/dy = sum_p dBTL_p / BTL_p - K^-1 y                    :199-221, utils.hpp:31-52
-//   df/d(a, b, l)                                            :53-115   /  :66-127   (small_grad, D <= 16)
+//   df/d(a, b, l)                                            :53-115   /  :66-127   (small_grad, D <= 128)
 // Optimiser: optim::MaximizeBounded of host/device.cpp statement by statement (projected gradient, two-loop recursion over
 // the last 8 pairs, Armijo backtracking by halving, at most 31 trials per direction) as a flat state machine with one
 // objective evaluation per turn.  The optimiser state (x, g, direction, history) is REPLICATED in the registers of each of

@@ -154,7 +154,7 @@ namespace sequential_line_search
         // local phase: bounded quasi-Newton in log-parameters from the global phase's point (reference: TNEWTON, 1000
         // evaluations, :295; same bounds)
         const std::vector<double> lower(D + 2, lo), upper(D + 2, hi);
-        // N <= 128, D <= 16: the whole local phase is one launch (sls_gp_map_fit); otherwise one device objective call per evaluation
+        // N <= 128, D <= 128: the whole local phase is one launch (sls_gp_map_fit); otherwise one device objective call per evaluation
         std::vector<double> z(D + 2);
         const int rc_fit = sls_gp_map_fit(nll.h, m_y.data(), best.data(), lower.data(), upper.data(), 1000, 0, z.data(),
                                           &m_map_stats.final_value, &m_map_stats.evals_local);

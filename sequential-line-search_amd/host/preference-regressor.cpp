@@ -150,7 +150,7 @@ namespace sequential_line_search
             return v;
         };
 
-        // M <= 128 (and D <= 16 with hyper-parameters): the whole fit is ONE launch -- objective, BTL terms and the optimiser run
+        // M <= 128, D <= 128 (with or without hyper-parameters): the whole fit is ONE launch -- objective, BTL terms and the optimiser run
         // on the device (sls_pref_map_fit); otherwise the same optimiser runs here with one sls_pref_objective call per evaluation
         std::vector<double> z(opt_dim);
         const int rc_fit = sls_pref_map_fit(nll.h, flat.data(), offs.data(), static_cast<int>(m_D.size()), &cfg, z0.data(), lower.data(),
