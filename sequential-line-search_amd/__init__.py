@@ -189,6 +189,12 @@ class GP:
         """SIGMA_EXPLICIT_INVERSE (GaussianProcessRegressor, default) or SIGMA_CHOLESKY_SOLVE (PreferenceRegressor)."""
         _ck(lib().sls_gp_set_sigma_mode(self.h, int(mode)))
 
+    def generation(self):
+        """A number that changes whenever the predictor behind the handle changes (fit, refit, appended point, sigma mode)."""
+        g = C.c_long(0)
+        _ck(lib().sls_gp_generation(self.h, C.byref(g)))
+        return int(g.value)
+
     def append_point(self, x, y):
         x = _f(x)
         assert x.shape == (self.D,)
