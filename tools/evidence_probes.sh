@@ -24,6 +24,6 @@ B=./sequential-line-search_amd/bin/sequential_line_search_nd
   echo "== concurrent PredictMu"
   ./sequential-line-search_amd/bin/test_host | grep -i "concurrent\|HOST TESTS"
 } > $O/${TAG}_c3_trace.log 2>&1
-python -m pytest tests -m gpu -q 2>&1 | tail -5 > $O/${TAG}_pytest_gpu.log
+python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -5 > $O/${TAG}_pytest_gpu.log
 cp gpurun_out/test_evidence.json $O/${TAG}_test_evidence.json 2>/dev/null
 tail -3 $O/${TAG}_pytest_gpu.log; grep "steady mean" $O/${TAG}_c3_trace.log
