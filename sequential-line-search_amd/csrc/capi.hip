@@ -973,10 +973,12 @@ constexpr int SLOT_MAX_POINTS = 64;
 static bool eval_in_slot(sls_gp* g, const double* Xs, int M, const SmallEvalOut& o) {
     sls_ctx* c = g->ctx;
     if (M < 1 || M > SLOT_MAX_POINTS || !tune_on(TUNE_EVAL_SLOTS) || !tune_on(TUNE_WAVE_PATH) || c->prof_on) return false;
-    std::shared_lock<std::shared_mutex> state_(g->state_mtx);
-    if (g->Np > WAVE_PATH_MAX_NP || g->D > WAVE_PATH_MAX_D) return false;
+    if (g->D > WAVE_PATH_MAX_D) return false;          // D never changes for a handle
     (void)hipSetDevice(c->device);
     const int D = g->D;
+    // Lock order: the slot (and, for the rare growth of its block, the context's lock, released again) FIRST, the shared lock on the
+    // fitted state LAST and on its own.  Mutators hold the context's lock and then the state lock exclusively: taking the context's
+    // lock under the shared state lock here would deadlock against them.
     const size_t n_in = (size_t)D * M, n_out = (size_t)(3 + 3 * D) * M;
     // ---- borrow a slot ----
     sls_ctx::EvalSlot* slot = nullptr;
@@ -1016,6 +1018,8 @@ static bool eval_in_slot(sls_gp* g, const double* Xs, int M, const SmallEvalOut&
         slot->host = static_cast<double*>(c->host_take(std::max(need, (size_t)(4 + 4 * D) * SLOT_MAX_POINTS * sizeof(double)), true, &slot->bytes));
         SLS_HIP(hipHostGetDevicePointer((void**)&slot->dev, slot->host, 0));
     }
+    std::shared_lock<std::shared_mutex> state_(g->state_mtx);
+    if (g->Np > WAVE_PATH_MAX_NP) return false;        // grown past the wave path by appended points: the general path
     std::memcpy(slot->host, Xs, n_in * sizeof(double));
     double* od = slot->dev + n_in;       // device view of the outputs: mu | sigma | val | dmu | dsigma | grad, candidate-major, ld = M
     double* oh = slot->host + n_in;
