@@ -116,11 +116,9 @@ def parity_vs_oracle(sls, ctx, kernel_id, o):
 def traffic_child(args):
     """One fit + a 4-evaluation maximiser run of the SAME library, shapes and launch parameters as the timed region, with
     SLS_COMPACT=0 (set by the parent): every acq_gemm launch has the full candidate shape.  Runs under rocprofv3 --pmc."""
-    import torch
-    sls = importlib.import_module("sequential-line-search_amd")
+    sls = importlib.import_module("sequential-line-search_amd")          # no torch here: the library owns the device
     kernel_id = sls.KERNEL_MATERN52 if args.kernel == "matern52" else sls.KERNEL_SE
     X, y, theta, b, starts = synth(args.d, args.n, args.starts)
-    torch.cuda.set_device(0)
     ctx = sls.Context(0)
     ctx.set_candidate_chunk(args.chunk)
     gp = sls.GP(ctx, X, y, theta, b, kernel_id)
