@@ -141,6 +141,8 @@ def measure_traffic(args):
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
         return None, {"skipped": "rocprofv3 not found"}
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or os.environ.get("HSA_TOOLS_LIB"):
+        return None, {"skipped": "this run is itself under a profiler: no nested counter collection"}
     raw, dur, n_launch = {}, [], 0
     child = [sys.executable, os.path.abspath(__file__), "--traffic-child", "--num-train", str(args.n), "--dims", str(args.d),
              "--starts", str(args.starts), "--kernel", args.kernel, "--chunk", str(args.chunk)]
