@@ -881,6 +881,7 @@ __global__ __launch_bounds__(256) void map_opt_kernel(const MapOptArgs args) {
                 need_dir = true;
             } else {
                 t *= 0.5;
+                st.tr[21] += 1;   // rejected trial points (probe)
                 if (++bt > 30) done = 1;
             }
         }
