@@ -221,8 +221,13 @@ __device__ __forceinline__ void transpose_inverse_tiles(double* As, int fl, int 
 // strictly-upper tiles hold Linv^T and Ts the inverses of the diagonal tiles.
 // HAVE_T16 (with !FACTOR): Ts already holds the inverses of the diagonal tiles (the caller loaded the ones the factorisation
 // produced); wave 0 has no pivot chain to run and the block inverse is built around exactly those tiles.
-template <bool FACTOR, bool HAVE_T16 = false>
-__device__ __forceinline__ void chol_diag_steps(double* As, double* Ts, int* __restrict__ info, int global_off, int nb16) {
+// idle0: work of the caller's that needs neither the image nor a barrier, run by waves 1-3 during the pivot chain of the FIRST
+// diagonal tile, when they have no S tiles to form (map_opt_kernel: the Bradley-Terry-Luce terms of the trial point).
+struct NoIdleWork {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <bool FACTOR, bool HAVE_T16 = false, class Idle = NoIdleWork>
+__device__ __forceinline__ void chol_diag_steps(double* As, double* Ts, int* __restrict__ info, int global_off, int nb16, Idle&& idle0 = Idle{}) {
     static_assert(!(FACTOR && HAVE_T16), "the factorisation produces the 16 x 16 inverses itself");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fl = lane & 15, fk = lane >> 4;
@@ -242,6 +247,7 @@ __device__ __forceinline__ void chol_diag_steps(double* As, double* Ts, int* __r
             if constexpr (!HAVE_T16) diag16<FACTOR>(As, Ts + 256 * kb, c0, lane, info, global_off);
             DIAG_STAMP_T(0, 16 + 8 * kb + 1);
         } else {
+            if (kb == 0) idle0();
             // tile j costs kb - j MFMA groups: waves 1..3 take j = {0, 5, 6}, {1, 4}, {2, 3} (10 / 9 / 9 groups at kb = 7)
             const int js[3] = {wave - 1, 6 - wave, wave == 1 ? 6 : 8};
             for (int n = 0; n < 3; ++n) {

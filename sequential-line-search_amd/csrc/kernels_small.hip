@@ -21,13 +21,16 @@ namespace slsk {
 //   [0,128) alpha   [128,256) y   [256,384) 1/l   [384,1024) BTL contributions (map_opt) / the four waves' partial length-scale
 //   gradients (small_grad)   [1024,1028) reduction slots   [1028,1032) a, b (map_opt)   [1040,1168) l (map_opt)
 //   [1168,1296) length-scale gradient   [1296,1616) gradient wrt the optimiser's variables (map_opt)
-//   [1616,1744) squared norms of the scaled points
+//   [1616,1744) squared norms of the scaled points   [1744,1768) section timers (only when tracing)
 //   [1872,2002) logarithms of a, b, l (map_opt)
 constexpr int SC_ALPHA = 0, SC_Y = 128, SC_INVL = 256, SC_BTL = 384, SC_BTL_MAX = 640, SC_RED = 1024, SC_AB = 1028,
-              SC_ELL = 1040, SC_GL = 1168, SC_GZ = 1296, SC_NX = 1616, SC_LZ = 1872;
-static_assert(SC_GZ + MAP_OPT_MAX_VARS <= SC_NX && SC_LZ + 2 + NLL_SMALL_MAX_D <= 2048 && 4 * NLL_SMALL_MAX_D <= SC_BTL_MAX, "LDS scratch map");
+              SC_ELL = 1040, SC_GL = 1168, SC_GZ = 1296, SC_NX = 1616, SC_TRACE = 1744, SC_LZ = 1872;
+static_assert(SC_TRACE + MAP_OPT_TRACE_SLOTS <= SC_LZ && SC_GZ + MAP_OPT_MAX_VARS <= SC_NX && SC_LZ + 2 + NLL_SMALL_MAX_D <= 2048 && 4 * NLL_SMALL_MAX_D <= SC_BTL_MAX, "LDS scratch map");
 
-__device__ __forceinline__ double& small_scratch(double* As, int k) { return As[(k >> 4) * DL + 128 + (k & 15)]; }
+// (k >> 4) DL + 128 + (k & 15) with DL = 144 = 128 + 16: a shift and two adds instead of shift, mask, multiply, two adds -- these
+// addresses are formed thousands of times per evaluation by waves that are alone on their SIMD (every instruction counts)
+static_assert(DL == 144, "scratch / free-area addressing assumes DL = 128 + 16");
+__device__ __forceinline__ double& small_scratch(double* As, int k) { return As[128 + k + ((k >> 4) << 7)]; }
 
 __device__ __forceinline__ double small_block_sum(double v, double* As) {
     v = wave_sum(v);
@@ -37,18 +40,22 @@ __device__ __forceinline__ double small_block_sum(double v, double* As) {
     return (small_scratch(As, SC_RED) + small_scratch(As, SC_RED + 1)) + (small_scratch(As, SC_RED + 2) + small_scratch(As, SC_RED + 3));
 }
 
-// optional section timing (SLS_MAP_TRACE=1): ticks of the 100 MHz clock per section, thread-private
+// optional section timing (SLS_MAP_TRACE=1): ticks of the 100 MHz clock per section, kept by thread 0 in the LDS scratch (24 running
+// totals in registers cost the untraced kernel ~50 scalar registers it does not have: spills)
 struct SmallTrace {
     bool on = false;
     long long t_prev = 0;
-    long long tr[MAP_OPT_TRACE_SLOTS] = {};
-    __device__ __forceinline__ void start() { if (on) t_prev = wall_clock64(); }
+    double* As = nullptr;
+    __device__ __forceinline__ long long& slot_ref(int slot) { return reinterpret_cast<long long&>(small_scratch(As, SC_TRACE + slot)); }
     __device__ __forceinline__ void mark(int slot) {
         if (on) {
             const long long t_now = wall_clock64();
-            tr[slot] += t_now - t_prev;
+            if (threadIdx.x == 0) slot_ref(slot) += t_now - t_prev;
             t_prev = t_now;
         }
+    }
+    __device__ __forceinline__ void count(int slot) {
+        if (on && threadIdx.x == 0) slot_ref(slot) += 1;
     }
 };
 
@@ -81,18 +88,54 @@ struct SmallPts {
     const double* __restrict__ X;
     const double* __restrict__ XTr;
     int lds, base_col, Dp;
-    // the pair scratch of the gradient (kernel values and derivative weights of the lower tiles, tile t element e at t * 256 + e,
-    // e = 16 (j - 16 tj) + (i - 16 ti)) behind the points when that fits too: stash_off = its offset in the free area, or -1
+    // the pair scratch of the gradient beyond the slots a thread keeps in registers (see Fold / SmallPairs), behind the points when
+    // that fits too: stash_off = its offset in the free area, or -1 (then global memory)
     int stash_off;
 };
+
+// The elements (i, j), j <= i < N, of the lower triangle dealt evenly over the 256 threads: columns j and N - 1 - j together hold
+// N + 1 elements, so slot e = c + r (N + 1) of the folded rectangle [ceil(N / 2)] x [N + 1] is element (r + c, r) for c < N - r and
+// (c - 1, N - 1 - r) beyond.  Thread t owns slots t, t + 256, ...: consecutive lanes walk down a column (conflict-free in the
+// column-major image).  The kernel-function pass and the gradient-weight pass walk the same slots, so a pair's kernel value and
+// derivative weight stay with their thread: the first SMALL_SR slots in registers, the rest in the pair scratch (slot order).
+constexpr int SMALL_SR = 8;
+struct SmallPairs {
+    double k[SMALL_SR], c[SMALL_SR];
+};
+__device__ __forceinline__ int small_stash_len(int N) {
+    const int total = ((N + 1) >> 1) * (N + 1);
+    return total > SMALL_SR * 256 ? ((total - SMALL_SR * 256 + 127) & ~127) : 0;   // per array, whole LDS columns
+}
+struct Fold {
+    int N, W, H, dr, dc, r, c;
+    __device__ __forceinline__ explicit Fold(int N_) : N(N_), W(N_ + 1), H((N_ + 1) >> 1) {
+        dr = 256 / W;
+        dc = 256 - dr * W;
+        r = (int)threadIdx.x / W;
+        c = (int)threadIdx.x - r * W;
+    }
+    __device__ __forceinline__ int total() const { return H * W; }
+    // the element of this thread's current slot (0, 0 and false beyond the triangle; odd N: the middle column pairs with itself and
+    // its second copy is dropped), then on to the thread's next slot
+    __device__ __forceinline__ bool next(int& i, int& j) {
+        const bool first = c < N - r;
+        const bool live = r < H && !(!first && 2 * r == N - 1);
+        i = live ? (first ? r + c : c - 1) : 0;
+        j = live ? (first ? r : N - 1 - r) : 0;
+        c += dc;
+        r += dr;
+        if (c >= W) { c -= W; ++r; }
+        return live;
+    }
+};
 // element o of the free area (the columns right of the leading base_col ones, 128 rows each)
-__device__ __forceinline__ double& small_free(double* As, int base_col, int o) { return As[(base_col + (o >> 7)) * DL + (o & 127)]; }
+__device__ __forceinline__ double& small_free(double* As, int base_col, int o) { return As[base_col * DL + o + ((o >> 7) << 4)]; }   // (base_col + (o >> 7)) DL + (o & 127)
 struct PtsLds {
     const double* As;
     int base_col, Dp;
     __device__ __forceinline__ double operator()(int i, int d) const {
         const int o = d + i * Dp;
-        return As[(base_col + (o >> 7)) * DL + (o & 127)];
+        return As[base_col * DL + o + ((o >> 7) << 4)];
     }
 };
 struct PtsRows {   // XTr[i + d * 128]
@@ -108,13 +151,15 @@ struct PtsCols {   // X[d + i * D]
 __device__ __forceinline__ SmallPts small_pts_stage(double* As, const double* __restrict__ X, const double* __restrict__ XTr, int D, int N,
                                                     bool allow) {
     SmallPts p{X, XTr, 0, 16 * ((N + 15) >> 4), 16 * ((D + 15) >> 4) + 1, -1};
-    const int Nb = p.base_col, nb16 = Nb >> 4;
+    const int Nb = p.base_col;
+    // 1 / l of the padding dimensions D .. 127: zeros, written once (the fragment loads of the Gram pass read them unconditionally)
+    for (int d = D + (int)threadIdx.x; d < 128; d += 256) small_scratch(As, SC_INVL + d) = 0.0;
     if (!allow || Nb * p.Dp > (128 - Nb) * 128) return p;
     p.lds = 1;
-    if (Nb * p.Dp + nb16 * (nb16 + 1) * 256 <= (128 - Nb) * 128) p.stash_off = Nb * p.Dp;   // 2 arrays x nb16 (nb16 + 1) / 2 tiles
+    if (Nb * p.Dp + 2 * small_stash_len(N) <= (128 - Nb) * 128) p.stash_off = Nb * p.Dp;
     for (int o = threadIdx.x; o < Nb * p.Dp; o += 256) {
         const int i = o / p.Dp, d = o - i * p.Dp;
-        As[(p.base_col + (o >> 7)) * DL + (o & 127)] = (i < N && d < D) ? X[d + (long)i * D] - 0.5 : 0.0;
+        small_free(As, p.base_col, o) = (i < N && d < D) ? X[d + (long)i * D] - 0.5 : 0.0;
     }
     return p;
 }
@@ -145,49 +190,74 @@ __device__ __forceinline__ double small_pair_q(const Pts& x, int D, int i, int j
     return q;
 }
 
+// One batch of up to four slots of the kernel-function pass: q_ij from qf, the kernel value into the image (a + b on the diagonal), the
+// pair (k, c) to put(u, k, c).  No branches around the evaluations: sqrt and exp of the four elements interleave.
+template <bool MATERN, class QF, class Put>
+__device__ __forceinline__ void small_gram_batch(double* As, double a, double b, Fold& fold, QF&& qf, Put&& put) {
+    int iq[4], jq[4];
+    bool live[4];
+    double dq[4], kq[4], cq[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        live[u] = fold.next(iq[u], jq[u]);
+        dq[u] = qf(iq[u], jq[u]);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // every load of the batch before its first store (dead slots all read element (0, 0))
+#pragma unroll
+    for (int u = 0; u < 4; ++u) small_kern<MATERN>(a, dq[u] < 0.0 ? 0.0 : dq[u], kq[u], cq[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (live[u]) As[iq[u] + jq[u] * DL] = (iq[u] == jq[u]) ? a + b : kq[u];
+        put(u, live[u], kq[u], cq[u]);
+    }
+}
+
 // K_y = K_f(a, l) + b I into the LDS image (1/l in the scratch) and its Cholesky factorisation on the leading ceil(N/16) blocks: L in the
 // lower triangle of As, L^-T in its strictly-upper tiles, the inverses of the diagonal tiles in Ts.  Returns sum_i log L_ii.
-// kc != nullptr: the kernel values k_ij and the derivative weights c_ij of the pairs i > j are left in kc[i + j * 128] /
-// kc[128 * 128 + i + j * 128] for small_grad (same workgroup: visible behind the barriers in between).
-template <bool MATERN>
-__device__ __forceinline__ double small_build_factor(double* As, double* Ts, const SmallPts& pts, int D, int N,
-                                                     double a, double b, int* __restrict__ info, double* __restrict__ kc, SmallTrace& st) {
+// Only the lower triangle of K_y is formed (nothing reads the upper halves of the diagonal tiles: what the factorisation computes
+// from them never reaches a result).
+// pairs != nullptr: the kernel values k_ij and derivative weights c_ij stay with their threads for small_grad -- *pairs for a
+// thread's first SMALL_SR slots, the pair scratch (LDS behind the points, or kc in global memory) beyond.
+template <bool MATERN, class Idle = NoIdleWork>
+__device__ __forceinline__ double small_build_factor(double* As, double* Ts, const SmallPts& pts, const Fold& fold0, int D, int N, double a,
+                                                     double b, int* __restrict__ info, SmallPairs* pairs, double* __restrict__ kc,
+                                                     SmallTrace& st, Idle&& idle0 = Idle{}) {
     const int tid = threadIdx.x;
     const int nb16 = (N + 15) >> 4;
-    // ---- K_y, one 16 x 16 tile per pass (lower tiles; diagonal tiles in full), identity padding up to the next multiple of 16 ----
-    auto gram = [&](auto&& pair_q) {
-        const int r = tid & 15, cc = tid >> 4;
-        for (int tj = 0; tj < nb16; ++tj)
-            for (int ti = tj; ti < nb16; ++ti) {
-                const int i = 16 * ti + r, j = 16 * tj + cc;
-                double v;
-                if (i >= N || j >= N) v = (i == j) ? 1.0 : 0.0;
-                else if (i == j) v = a + b;
-                else {
-                    double k, c;
-                    small_kern<MATERN>(a, pair_q(i, j), k, c);
-                    v = k;
-                    if (kc && i > j) {
-                        kc[i + j * 128] = k;
-                        if (MATERN) kc[128 * 128 + i + j * 128] = c;
-                    }
+    const int slen = small_stash_len(N);
+    // the kernel function over this thread's slots: registers first, then the pair scratch
+    auto elements = [&](auto&& qf) {
+        Fold fold = fold0;
+        const int total = fold.total();
+#pragma unroll
+        for (int s0 = 0; s0 < SMALL_SR; s0 += 4) {
+            if (s0 * 256 >= total) break;
+            small_gram_batch<MATERN>(As, a, b, fold, qf, [&](int u, bool, double k, double c) {
+                if (pairs) {
+                    pairs->k[s0 + u] = k;
+                    pairs->c[s0 + u] = c;
                 }
-                As[i + j * DL] = v;
-            }
+            });
+        }
+        for (int e0 = SMALL_SR * 256; e0 < total; e0 += 4 * 256)
+            small_gram_batch<MATERN>(As, a, b, fold, qf, [&](int u, bool live, double k, double c) {
+                const int q = e0 - SMALL_SR * 256 + 256 * u + tid;
+                if (!pairs || !live) return;
+                if (pts.stash_off >= 0) {
+                    small_free(As, pts.base_col, pts.stash_off + q) = k;
+                    if (MATERN) small_free(As, pts.base_col, pts.stash_off + slen + q) = c;
+                } else {
+                    kc[q] = k;
+                    if (MATERN) kc[128 * 128 + q] = c;
+                }
+            });
     };
     if (pts.lds) {
-        // matrix-core form: squared norms (thread i), then one 16 x 16 tile of dot products per wave and pass
+        // Matrix-core form.  (1) The dot products x~_i . x~_j / l^2 of the lower tiles, one 16 x 16 tile per wave and trip, straight
+        // into the image; the diagonal of a diagonal tile is |x~_i|^2 and goes to the scratch (SC_NX).  (2) q_ij from the norm
+        // expansion and the kernel function per element.
         const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fl = lane & 15, fk = lane >> 4;
         const PtsLds xc{As, pts.base_col, pts.Dp};
-        if (tid < 16 * nb16) {
-            double n = 0.0;
-            for (int d = 0; d < D; ++d) {
-                const double t = xc(tid, d) * small_scratch(As, SC_INVL + d);
-                n = fma(t, t, n);
-            }
-            small_scratch(As, SC_NX + tid) = n;
-        }
-        __syncthreads();
         const int Dk = pts.Dp - 1;
         int t = 0;
         for (int tj = 0; tj < nb16; ++tj)
@@ -199,7 +269,7 @@ __device__ __forceinline__ double small_build_factor(double* As, double* Ts, con
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) {
                         const int d = d0 + 4 * kk + fk;
-                        const double il = d < D ? small_scratch(As, SC_INVL + d) : 0.0;
+                        const double il = small_scratch(As, SC_INVL + d);   // zeros beyond D
                         af[kk] = xc(16 * ti + fl, d) * (il * il);
                         bf[kk] = xc(16 * tj + fl, d);
                     }
@@ -208,39 +278,32 @@ __device__ __forceinline__ double small_build_factor(double* As, double* Ts, con
                     for (int kk = 0; kk < 4; ++kk) acc = mfma16(bf[kk], af[kk], acc);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                const int i = 16 * ti + fl;
-                const double ni = small_scratch(As, SC_NX + i);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int j = 16 * tj + fk + 4 * q;
-                    double v;
-                    if (i >= N || j >= N) v = (i == j) ? 1.0 : 0.0;
-                    else if (i == j) v = a + b;
-                    else {
-                        double qq = ni + small_scratch(As, SC_NX + j) - 2.0 * acc[q];
-                        qq = qq < 0.0 ? 0.0 : qq;
-                        double k, c;
-                        small_kern<MATERN>(a, qq, k, c);
-                        v = k;
-                        if (kc && i > j) {
-                            if (pts.stash_off >= 0) {
-                                const int e = pts.stash_off + 256 * t + 16 * (fk + 4 * q) + fl;
-                                small_free(As, pts.base_col, e) = k;
-                                if (MATERN) small_free(As, pts.base_col, e + 128 * nb16 * (nb16 + 1)) = c;
-                            } else {
-                                kc[i + j * 128] = k;
-                                if (MATERN) kc[128 * 128 + i + j * 128] = c;
-                            }
-                        }
-                    }
-                    As[i + j * DL] = v;
+                    As[16 * ti + fl + (16 * tj + fk + 4 * q) * DL] = acc[q];
+                    if (ti == tj && fl == fk + 4 * q) small_scratch(As, SC_NX + 16 * ti + fl) = acc[q];
                 }
             }
-    } else gram([&](int i, int j) { return small_pair_q<8>(PtsRows{pts.XTr}, D, i, j, As); });
+        __syncthreads();
+        // identity padding of the last block: the padded points are zero rows, so rows N .. 16 nb16 - 1 of the lower triangle hold
+        // zeros already; ones on their diagonal (pass (2) does not touch these rows)
+        {
+            const int i = N + (tid >> 4);   // at most 15 padding rows
+            if (i < 16 * nb16 && (tid & 15) == 0) As[i + i * DL] = 1.0;
+        }
+        elements([&](int i, int j) { return small_scratch(As, SC_NX + i) + small_scratch(As, SC_NX + j) - 2.0 * As[i + j * DL]; });
+    } else {
+        // direct differences from the transposed copy in global memory; identity padding of the last block written out
+        for (int idx = tid; idx < (16 * nb16 - N) * 16 * nb16; idx += 256) {
+            const int i = N + idx / (16 * nb16), j = idx % (16 * nb16);
+            if (j <= i) As[i + j * DL] = (i == j) ? 1.0 : 0.0;
+        }
+        elements([&](int i, int j) { return small_pair_q<8>(PtsRows{pts.XTr}, D, i, j, As); });
+    }
     __syncthreads();
     st.mark(8);
 
-    chol_diag_steps<true>(As, Ts, info, 0, nb16);
+    chol_diag_steps<true, false>(As, Ts, info, 0, nb16, idle0);
     __syncthreads();
     st.mark(9);
 
@@ -248,6 +311,29 @@ __device__ __forceinline__ double small_build_factor(double* As, double* Ts, con
     const double ld = small_block_sum(tid < N ? log(As[tid + tid * DL]) : 0.0, As);
     st.mark(10);
     return ld;
+}
+
+// The strictly-lower tiles of the leading nb16 blocks copied into their mirror positions, one tile per wave and trip.  Each 16-lane
+// group walks a wrapped diagonal of the tile (column fl, row fl + fk + 4 q), so both the row-major reads and the column-major writes
+// touch 16 different banks.  DIAG: the strictly-lower halves of the diagonal tiles as well (a tile's reads precede its writes, and
+// the halves are disjoint).  The caller's barriers order the pass against its neighbours.
+template <bool DIAG>
+__device__ __forceinline__ void small_mirror_lower(double* As, int nb16) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fl = lane & 15, fk = lane >> 4;
+    int t = 0;
+    for (int i = DIAG ? 0 : 1; i < nb16; ++i)
+        for (int j = 0; j < (DIAG ? i + 1 : i); ++j, ++t) {
+            if ((t & 3) != wave) continue;
+            double v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = As[(16 * j + fl) * DL + 16 * i + ((fl + fk + 4 * q) & 15)];   // (row 16i + r, col 16j + fl)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = (fl + fk + 4 * q) & 15;
+                if (!DIAG || i != j || r > fl) As[(16 * i + r) * DL + 16 * j + fl] = v[q];                      // (row 16j + fl, col 16i + r)
+            }
+        }
 }
 
 // K^-1 = L^-T L^-1 as a full symmetric image over the dead factor (after small_build_factor: L in the lower triangle of As, L^-T in its
@@ -284,37 +370,31 @@ __device__ __forceinline__ void small_inverse_in_place(double* As, double* Ts, i
     __syncthreads();
     if (stp) stp->mark(17);
     // mirror the strictly-lower tiles into the upper triangle (L^-T is no longer needed): K^-1 becomes a full symmetric image
-    {
-        int t = 0;
-        for (int i = 1; i < nb16; ++i)
-            for (int j = 0; j < i; ++j, ++t) {
-                if ((t & 3) != wave) continue;
-                double v[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = As[(16 * j + fl) * DL + 16 * i + ((fl + fk + 4 * q) & 15)];   // (row 16i + r, col 16j + fl)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) As[(16 * i + ((fl + fk + 4 * q) & 15)) * DL + 16 * j + fl] = v[q];   // (row 16j + fl, col 16i + r)
-            }
-    }
+    small_mirror_lower<false>(As, nb16);
     __syncthreads();
 }
 
 
 // K_y = K_f(a, l) + b I into the LDS image (1/l in the scratch), Cholesky + inverse on the leading ceil(N/16) blocks,
 // K_y^-1 as a full symmetric image over the dead factor.  Returns sum_i log L_ii (= logdet / 2) in every thread.
-template <bool MATERN>
-__device__ __forceinline__ double small_factor_inverse(double* As, double* Ts, const SmallPts& pts, int D, int N,
-                                                       double a, double b, int* __restrict__ info, double* __restrict__ kc, SmallTrace& st) {
-    const double ld = small_build_factor<MATERN>(As, Ts, pts, D, N, a, b, info, kc, st);
+template <bool MATERN, class Idle = NoIdleWork>
+__device__ __forceinline__ double small_factor_inverse(double* As, double* Ts, const SmallPts& pts, const Fold& fold0, int D, int N, double a,
+                                                       double b, int* __restrict__ info, SmallPairs* pairs, double* __restrict__ kc,
+                                                       SmallTrace& st, Idle&& idle0 = Idle{}) {
+    const double ld = small_build_factor<MATERN>(As, Ts, pts, fold0, D, N, a, b, info, pairs, kc, st, idle0);
     small_inverse_in_place(As, Ts, N, &st);
     st.mark(11);
     return ld;
 }
 
 // alpha = K^-1 y (y in the scratch) into the scratch; gb = 1/2 (alpha.alpha - tr K^-1), quad = y.alpha in every thread
-__device__ __forceinline__ void small_alpha(double* As, int N, double& gb, double& quad) {
+// side: work of the caller's for the upper two waves while the lower two form the product (it may write scratch that nobody reads
+// before the barrier below)
+template <class Side = NoIdleWork>
+__device__ __forceinline__ void small_alpha(double* As, int N, double& gb, double& quad, Side&& side = Side{}) {
     const int tid = threadIdx.x;
-    if (tid < 128) {
+    if (tid >= 128) side();
+    else {
         // eight LDS operand pairs in flight, then their fused multiply-adds in column order: the same sum as the plain loop (a
         // loop of dependent load -> fma trips ran at ~150 ns per column on the otherwise idle CU).  Columns N .. 8 ceil(N / 8) - 1
         // exist in the image (identity padding, inside the 16-aligned block) and meet y = 0 there.
@@ -347,65 +427,76 @@ __device__ __forceinline__ void small_alpha(double* As, int N, double& gb, doubl
 // Gradient contractions over the pairs i >= j with W = alpha alpha^T - K^-1 (src/gaussian-process-regressor.cpp:66-127 without
 // the (D + 1) N x N tensor of src/regressor.cpp:110-134):
 //   returns  sa = sum W.*K_f;  leaves  gl[d] = (1 / l_d) sum_{i>j} W_ij c_ij ((x_id - x_jd) / l_d)^2  in the scratch (SC_GL + d), d < D <= 128.
-// Two passes.  (1) one pair per thread, tile by tile like the Gram pass: w, sa, and G_ij = w c_ij into the MIRROR position (j, i) of
-// the image -- K^-1 is symmetric and nothing reads its upper triangle after small_alpha.  (2) lanes over the DIMENSIONS: a wave
-// takes whole rows i (dealt 0 1 2 3 3 2 1 0 over the waves), 64 / LP pairs of a row per step with LP = min(64, 2^ceil(log2 D))
-// lanes each (two dimensions per lane for D > 64), four steps' loads in flight; the point coordinates come from the D x N original
-// (a pair's D values are contiguous), G from LDS.  The per-wave partial sums are added over the lanes of a dimension by xor
-// butterflies and over the waves as (w0 + w1) + (w2 + w3): one fixed order.
+// (1) One pair per slot, the slots of the kernel-function pass (same thread, pair values from *pairs / the pair scratch): w, sa, and
+// G_ij = 1/2 w c_ij over K^-1 in the lower triangle; then the mirror pass: G becomes a full symmetric image with zero diagonal
+// (nothing reads K^-1 after small_alpha).  (2) The contraction: on the matrix cores (points staged in LDS) or with lanes over the
+// DIMENSIONS: a wave takes whole rows i (dealt 0 1 2 3 3 2 1 0 over the waves), 64 / LP pairs of a row per step with
+// LP = min(64, 2^ceil(log2 D)) lanes each (two dimensions per lane for D > 64), four steps' loads in flight; the point coordinates
+// come from the D x N original (a pair's D values are contiguous), G from LDS.  The per-wave partial sums are added over the lanes of
+// a dimension by xor butterflies and over the waves as (w0 + w1) + (w2 + w3): one fixed order.
 template <bool MATERN>
-__device__ __forceinline__ double small_grad(double* As, const SmallPts& pts, const double* __restrict__ kc, int D, int N,
-                                             double a, bool want_grad, SmallTrace& st) {
+__device__ __forceinline__ double small_grad(double* As, const SmallPts& pts, const Fold& fold0, const SmallPairs* pairs,
+                                             const double* __restrict__ kc, int D, int N, double a, bool want_grad, SmallTrace& st) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nb16 = (N + 15) >> 4;
-    const bool mm = pts.lds != 0;   // matrix-core form: G = 1/2 W o C as a full symmetric matrix with zero diagonal over K^-1
+    const bool mm = pts.lds != 0;   // matrix-core contraction
     double sa = 0.0;
     if (want_grad) {
-        // the pair scratch comes back from global memory: the loads of four tiles are issued together (every address is inside the
-        // 2 x 128 x 128 block, unused values are discarded by the selects below)
-        const int r = tid & 15, cc = tid >> 4;
-        constexpr int TB = 4;
-        for (int tj = 0, tcol = 0; tj < nb16; tcol += nb16 - tj, ++tj)   // tcol: index of tile (tj, tj) in the Gram pass's order
-            for (int ti0 = tj; ti0 < nb16; ti0 += TB) {
-                const int j = 16 * tj + cc;
-                double kv[TB], cv[TB];
+        // one batch of four slots, without branches around the loads: alpha_i, alpha_j, K^-1_ij of the four first
+        Fold fold = fold0;
+        const int total = fold.total(), slen = small_stash_len(N);
+        auto batch = [&](auto&& get) {
+            int iq[4], jq[4];
+            bool live[4];
+            double ai[4], aj[4], kinv[4], kv[4], cv[4];
 #pragma unroll
-                for (int u = 0; u < TB; ++u) {
-                    if (pts.stash_off >= 0) {   // LDS: any element of the free area may be read
-                        const int e = pts.stash_off + 256 * min(tcol + ti0 + u - tj, nb16 * (nb16 + 1) / 2 - 1) + tid;
-                        kv[u] = small_free(As, pts.base_col, e);
-                        cv[u] = MATERN ? small_free(As, pts.base_col, e + 128 * nb16 * (nb16 + 1)) : 0.0;
-                    } else {
-                        const int i = min(16 * (ti0 + u) + r, 127);
-                        kv[u] = kc[i + j * 128];
-                        cv[u] = MATERN ? kc[128 * 128 + i + j * 128] : 0.0;
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < TB; ++u) {
-                    const int i = 16 * (ti0 + u) + r;
-                    if (ti0 + u >= nb16 || i < j || i >= 16 * nb16) continue;
-                    if (i >= N) {   // padding rows of the last block: no weight
-                        if (mm) As[i + j * DL] = As[j + i * DL] = 0.0;
-                        continue;
-                    }
-                    const double w = (i == j ? 0.5 : 1.0) * (small_scratch(As, SC_ALPHA + i) * small_scratch(As, SC_ALPHA + j) - As[i + j * DL]);
-                    if (i == j) {
-                        sa = fma(w, a, sa);
-                        if (mm) As[i + i * DL] = 0.0;
-                    } else {
-                        sa = fma(w, kv[u], sa);
-                        const double g = w * (MATERN ? cv[u] : kv[u]);
-                        if (mm) As[i + j * DL] = As[j + i * DL] = 0.5 * g;
-                        else As[j + i * DL] = g;
-                    }
-                }
+            for (int u = 0; u < 4; ++u) {
+                live[u] = fold.next(iq[u], jq[u]);
+                ai[u] = small_scratch(As, SC_ALPHA + iq[u]);
+                aj[u] = small_scratch(As, SC_ALPHA + jq[u]);
+                kinv[u] = As[iq[u] + jq[u] * DL];
+                get(u, kv[u], cv[u]);
             }
+            __builtin_amdgcn_sched_barrier(0);   // dead slots read element (0, 0): before its owner's store
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool diag = iq[u] == jq[u];
+                const double w = (diag ? 0.5 : 1.0) * (ai[u] * aj[u] - kinv[u]);
+                sa = live[u] ? fma(w, diag ? a : kv[u], sa) : sa;
+                if (live[u]) As[iq[u] + jq[u] * DL] = diag ? 0.0 : 0.5 * (w * (MATERN ? cv[u] : kv[u]));
+            }
+        };
+#pragma unroll
+        for (int s0 = 0; s0 < SMALL_SR; s0 += 4) {
+            if (s0 * 256 >= total) break;
+            batch([&](int u, double& k, double& c) {
+                k = pairs->k[s0 + u];
+                c = pairs->c[s0 + u];
+            });
+        }
+        for (int e0 = SMALL_SR * 256; e0 < total; e0 += 4 * 256)
+            batch([&](int u, double& k, double& c) {
+                const int q = min(e0 - SMALL_SR * 256 + 256 * u + tid, slen - 1);   // any address inside the scratch may be read
+                if (pts.stash_off >= 0) {
+                    k = small_free(As, pts.base_col, pts.stash_off + q);
+                    c = MATERN ? small_free(As, pts.base_col, pts.stash_off + slen + q) : 0.0;
+                } else {
+                    k = kc[q];
+                    c = MATERN ? kc[128 * 128 + q] : 0.0;
+                }
+            });
+        // padding rows of the last block: K^-1 is the identity there, G has no weight
+        {
+            const int i = N + (tid >> 4);
+            if (i < 16 * nb16 && (tid & 15) == 0) As[i + i * DL] = 0.0;
+        }
     }
     st.mark(18);
-    const double sa_t = small_block_sum(sa, As);   // its barriers publish G
+    const double sa_t = small_block_sum(sa, As);   // its barriers publish the lower triangle of G
     st.mark(12);
     if (!want_grad) return sa_t;
+    small_mirror_lower<true>(As, nb16);
+    __syncthreads();
 
     if (mm) {
         const int fl = lane & 15, fk = lane >> 4;
@@ -519,7 +610,7 @@ __device__ __forceinline__ double small_grad(double* As, const SmallPts& pts, co
     if (tid < D) {
         const double p = (small_scratch(As, SC_BTL + tid) + small_scratch(As, SC_BTL + NLL_SMALL_MAX_D + tid)) +
                          (small_scratch(As, SC_BTL + 2 * NLL_SMALL_MAX_D + tid) + small_scratch(As, SC_BTL + 3 * NLL_SMALL_MAX_D + tid));
-        small_scratch(As, SC_GL + tid) = p * small_scratch(As, SC_INVL + tid);
+        small_scratch(As, SC_GL + tid) = 2.0 * p * small_scratch(As, SC_INVL + tid);   // G = 1/2 w c
     }
     __syncthreads();
     st.mark(13);
@@ -548,11 +639,13 @@ __global__ __launch_bounds__(256) void nll_small_kernel(const NllSmallArgs args)
 
     double* __restrict__ kc = want_grad ? args.kc : nullptr;
     SmallTrace st;
-    const double ld = small_factor_inverse<MATERN>(As, Ts, pts, D, N, a, b, info, kc, st);
+    const Fold fold0(N);
+    SmallPairs pr;
+    const double ld = small_factor_inverse<MATERN>(As, Ts, pts, fold0, D, N, a, b, info, want_grad ? &pr : nullptr, kc, st);
     double gb, quad;
     small_alpha(As, N, gb, quad);
     if (tid < N && args.batch <= 1) out[NLL_SMALL_OUT_ALPHA + tid] = small_scratch(As, SC_ALPHA + tid);   // batch mode: 8 output words per parameter set
-    const double sa_t = small_grad<MATERN>(As, pts, kc, D, N, a, want_grad != 0, st);
+    const double sa_t = small_grad<MATERN>(As, pts, fold0, &pr, kc, D, N, a, want_grad != 0, st);
     if (want_grad && tid < D) out[NLL_SMALL_OUT_GL + tid] = small_scratch(As, SC_GL + tid);
     if (tid == 0) {
         out[0] = sa_t;
@@ -614,6 +707,9 @@ __global__ __launch_bounds__(256) void map_opt_kernel(const MapOptArgs args) {
     double* __restrict__ out = args.out;
     SmallTrace st;
     st.on = args.trace != nullptr;
+    st.As = As;
+    if (st.on && tid == 0)
+        for (int q = 0; q < MAP_OPT_TRACE_SLOTS; ++q) st.slot_ref(q) = 0;
     const long long tr_begin = st.on ? wall_clock64() : 0;
     st.t_prev = tr_begin;
 #define MAP_T(slot) st.mark(slot)
@@ -661,12 +757,14 @@ __global__ __launch_bounds__(256) void map_opt_kernel(const MapOptArgs args) {
         for (int dd = tid; dd < D; dd += 256) small_scratch(As, SC_INVL + dd) = 1.0 / args.r0;
     if (tid == 0) *info = 0;
     const SmallPts pts = small_pts_stage(As, X, args.XTr, D, N, args.x_lds != 0);
+    const Fold fold0(N);
     // the first preference tuple of this thread and the first tuple memberships of data point `tid`: indices in registers
     constexpr int RC = 4;
     int po = 0, pm = 0, pidx0 = 0, pidx1 = 0, pidx2 = 0, pidx3 = 0, co = 0, cm = 0, cidx0 = 0, cidx1 = 0, cidx2 = 0, cidx3 = 0;
-    if (tid < P) {
-        po = args.pref_off[tid];
-        pm = args.pref_off[tid + 1] - po;
+    const int tq = tid - 128;   // tuple tq (, tq + 128, ...) on thread 128 + tq: the upper two waves, see btl_tuples below
+    if (tq >= 0 && tq < P) {
+        po = args.pref_off[tq];
+        pm = args.pref_off[tq + 1] - po;
         pidx0 = args.pref_flat[po];
         if (pm > 1) pidx1 = args.pref_flat[po + 1];
         if (pm > 2) pidx2 = args.pref_flat[po + 2];
@@ -714,25 +812,14 @@ __global__ __launch_bounds__(256) void map_opt_kernel(const MapOptArgs args) {
             b = small_scratch(As, SC_AB + 1);
         }
         MAP_T(0);
-        if (nh || !have_factor) {
-            ld = small_factor_inverse<MATERN>(As, Ts, pts, D, N, a, b, info, nh ? args.kc : nullptr, st);
-            have_factor = true;
-            bad = __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-        }
-        double gb, quad;
-        small_alpha(As, N, gb, quad);
-        MAP_T(1);
-        if (bad && nh && tid == 0) *info = 0;   // every thread has read it (barriers of small_alpha); the next factorisation starts clean
-        double sa_t = 0.0;
-        if (nh) sa_t = small_grad<MATERN>(As, pts, args.kc, D, N, a, true, st);   // length-scale gradient -> scratch (SC_GL)
-
-        // ---- Bradley-Terry-Luce terms: tuple p on thread p (, p + 256, ...) ----
+        // ---- Bradley-Terry-Luce terms: tuple q on thread 128 + q (, + 128, ...).  They need the published goodness values only, so
+        // the upper two waves form them where they would otherwise wait: during the pivot chain of the first diagonal tile when the
+        // matrix is rebuilt (hyper-parameters among the variables), beside the product K^-1 y of the lower two waves otherwise.
         // contrib: the per-member terms d BTL_p / BTL_p, in the LDS scratch (flat_len <= 640) or in global memory -- two
         // instantiations of the same code, not a run-time pointer choice (a pointer that may be LDS or global is a generic
         // pointer: flat loads / stores)
-        double btl_sum = 0.0, gy = 0.0;
-        auto btl_terms = [&](auto&& contrib) {
-            double lsum = 0.0;
+        double lsum = 0.0, gsum = 0.0, gy = 0.0;
+        auto btl_tuples_in = [&](auto&& contrib) {
             const double bs = args.btl_scale;
             // one tuple: o = its offset in the flat list, m = its size, (m0 .. m3) = its first RC members
             auto tuple_terms = [&](int o, int m, int m0, int m1, int m2, int m3) {
@@ -762,15 +849,20 @@ __global__ __launch_bounds__(256) void map_opt_kernel(const MapOptArgs args) {
                 for (int i = 1; i < m; ++i) contrib(o + i) = (tmp * contrib(o + i)) / v;
             };
             static_assert(RC == 4, "tuple_terms takes four register members");
-            if (tid < P) tuple_terms(po, pm, pidx0, pidx1, pidx2, pidx3);
-            for (int p = tid + 256; p < P; p += 256) {       // more than 256 tuples: indices from global memory
+            if (tq >= 0 && tq < P) tuple_terms(po, pm, pidx0, pidx1, pidx2, pidx3);
+            for (int p = tq + 128; tq >= 0 && p < P; p += 128) {       // more than 128 tuples: indices from global memory
                 const int o = args.pref_off[p], m = args.pref_off[p + 1] - o;
                 tuple_terms(o, m, args.pref_flat[o], m > 1 ? args.pref_flat[o + 1] : 0, m > 2 ? args.pref_flat[o + 2] : 0,
                             m > 3 ? args.pref_flat[o + 3] : 0);
             }
-            btl_sum = small_block_sum(lsum, As);   // its barriers also publish the contributions (LDS or global, one CU)
+        };
+        auto btl_tuples = [&]() {
+            if (btl_lds) btl_tuples_in([&](int q) -> double& { return small_scratch(As, SC_BTL + q); });
+            else btl_tuples_in([&](int q) -> double& { return args.btl_scratch[q]; });
+        };
+        auto btl_gather_in = [&](auto&& contrib) {
             if (tid < ny) {
-                for (int i = 0; i < cm; ++i) {                                                                      // :202-216, in tuple order
+                for (int i = 0; i < cm; ++i) {
                     int e;
                     if (i >= RC) e = args.csc_ent[co + i];
                     else {
@@ -779,13 +871,31 @@ __global__ __launch_bounds__(256) void map_opt_kernel(const MapOptArgs args) {
                         e = (i == 2) ? cidx2 : e;
                         e = (i == 3) ? cidx3 : e;
                     }
-                    gy += contrib(e);
+                    gsum += contrib(e);
                 }
-                gy -= small_scratch(As, SC_ALPHA + tid);                                                            // :219
             }
         };
-        if (btl_lds) btl_terms([&](int q) -> double& { return small_scratch(As, SC_BTL + q); });
-        else btl_terms([&](int q) -> double& { return args.btl_scratch[q]; });
+        const bool rebuild = nh || !have_factor;
+        SmallPairs pr;   // kernel values and derivative weights of this thread's pairs, from the kernel-function pass to the gradient's
+        if (rebuild) {
+            ld = small_factor_inverse<MATERN>(As, Ts, pts, fold0, D, N, a, b, info, nh ? &pr : nullptr, args.kc, st, btl_tuples);
+            have_factor = true;
+            bad = __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        }
+        double gb, quad;
+        if (rebuild) small_alpha(As, N, gb, quad);
+        else small_alpha(As, N, gb, quad, btl_tuples);
+        MAP_T(1);
+        if (bad && nh && tid == 0) *info = 0;   // every thread has read it (barriers of small_alpha); the next factorisation starts clean
+        // the contributions are published (barriers of small_alpha): gathered now, small_grad reuses their scratch
+        if (btl_lds) btl_gather_in([&](int q) -> double& { return small_scratch(As, SC_BTL + q); });
+        else btl_gather_in([&](int q) -> double& { return args.btl_scratch[q]; });
+        double sa_t = 0.0;
+        if (nh) sa_t = small_grad<MATERN>(As, pts, fold0, &pr, args.kc, D, N, a, true, st);   // length-scale gradient -> scratch (SC_GL)
+
+        // ---- gradient of the BTL terms wrt the goodness values: the contributions gathered in tuple order (:202-216), minus alpha (:219) ----
+        const double btl_sum = small_block_sum(lsum, As);
+        if (tid < ny) gy = gsum - small_scratch(As, SC_ALPHA + tid);
         MAP_T(3);
 
         // ---- value ----
@@ -823,7 +933,7 @@ __global__ __launch_bounds__(256) void map_opt_kernel(const MapOptArgs args) {
         __syncthreads();
         MAP_T(4);
         ++evals;
-        st.tr[6] += 1;
+        st.count(6);
         if (args.eval_only) {
             done = 1;
 #pragma unroll
@@ -881,7 +991,7 @@ __global__ __launch_bounds__(256) void map_opt_kernel(const MapOptArgs args) {
                 need_dir = true;
             } else {
                 t *= 0.5;
-                st.tr[21] += 1;   // rejected trial points (probe)
+                st.count(21);   // rejected trial points (probe)
                 if (++bt > 30) done = 1;
             }
         }
@@ -953,8 +1063,8 @@ __global__ __launch_bounds__(256) void map_opt_kernel(const MapOptArgs args) {
         MAP_T(5);
     }
     if (st.on && tid == 0) {
-        st.tr[7] = wall_clock64() - tr_begin;
-        for (int q = 0; q < MAP_OPT_TRACE_SLOTS; ++q) args.trace[q] += st.tr[q];
+        st.slot_ref(7) = wall_clock64() - tr_begin;
+        for (int q = 0; q < MAP_OPT_TRACE_SLOTS; ++q) args.trace[q] += st.slot_ref(q);
     }
 
     // ---- results and the state for a continuation ----
@@ -994,8 +1104,13 @@ static void launch_map_opt_as(hipStream_t s, const MapOptArgs& args) {
 }
 void launch_map_opt(hipStream_t s, int kernel, const MapOptArgs& args) {
     const bool matern = kernel == SLS_KERNEL_ARD_MATERN52;
-    static_assert(MAP_OPT_MAX_VARS == 64 * 5, "map_opt_kernel is instantiated for 3 and 5 variables per lane");
-    if (args.ny + args.nh <= 64 * 3) matern ? launch_map_opt_as<true, 3>(s, args) : launch_map_opt_as<false, 3>(s, args);
+    // variables per lane: the smallest instantiation that holds n (padding lanes carry zeros: the sums have the same bits in every
+    // instantiation; the optimiser's vector work, its history registers and the publishing step scale with KV)
+    static_assert(MAP_OPT_MAX_VARS == 64 * 5, "map_opt_kernel is instantiated for 1, 2, 3 and 5 variables per lane");
+    const int n = args.ny + args.nh;
+    if (n <= 64) matern ? launch_map_opt_as<true, 1>(s, args) : launch_map_opt_as<false, 1>(s, args);
+    else if (n <= 64 * 2) matern ? launch_map_opt_as<true, 2>(s, args) : launch_map_opt_as<false, 2>(s, args);
+    else if (n <= 64 * 3) matern ? launch_map_opt_as<true, 3>(s, args) : launch_map_opt_as<false, 3>(s, args);
     else matern ? launch_map_opt_as<true, 5>(s, args) : launch_map_opt_as<false, 5>(s, args);
 }
 
@@ -1039,7 +1154,7 @@ __global__ __launch_bounds__(256) void gp_fit_small_kernel(const GpFitSmallArgs 
     __syncthreads();
 
     SmallTrace st;
-    const double ld = small_build_factor<MATERN>(As, Ts, pts, D, N, p.a, p.b, p.info, nullptr, st);
+    const double ld = small_build_factor<MATERN>(As, Ts, pts, Fold(N), D, N, p.a, p.b, p.info, nullptr, nullptr, st);
     // ---- L, L^-1 and (L^-1)^T to global memory (identity padding outside the leading Nb x Nb block, zeros above / below) ----
     for (int idx = tid; idx < Np * Np; idx += 256) {
         const int i = idx & (Np - 1), j = idx >> 7;

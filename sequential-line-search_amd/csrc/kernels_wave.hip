@@ -436,6 +436,13 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
     double f = -val, g0 = -gr0, g1 = -gr1;       // minimise phi = -acq
     double dir0 = 0.0, dir1 = 0.0, t = 1.0;
     int hlen = 0, hpos = 0, nbt = 0;
+    double sy_last = 0.0, yy_last = 1.0;
+    // slot of the h-th newest pair in the circular history (0 <= hpos < m, h < hlen <= m): a conditional add -- the history position
+    // lives in a vector register, and an integer remainder by the run-time m there is ~35 instructions, 13 times per direction
+    auto hist_slot = [&](int h) {
+        const int i = hpos - 1 - h;
+        return i < 0 ? i + m : i;
+    };
     bool done = false, need_dir = true;
     int n_useful = 1;                            // evaluations this start needed (the first one included)
 
@@ -462,7 +469,7 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
                 for (int h = 0; h < 8; ++h) {
                     al[h] = 0.0;
                     if (h < hlen) {
-                        const int idx = (hpos - 1 - h + 2 * m) % m;
+                        const int idx = hist_slot(h);
                         const double s0 = has0 ? Sh[idx * p.Dr + d0] : 0.0, s1 = has1 ? Sh[idx * p.Dr + d1] : 0.0;
                         const double y0 = has0 ? Yh[idx * p.Dr + d0] : 0.0, y1 = has1 ? Yh[idx * p.Dr + d1] : 0.0;
                         al[h] = rho[idx] * wave_sum(s0 * q0 + s1 * q1);
@@ -472,10 +479,7 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
                 }
                 double gamma;
                 if (hlen > 0) {
-                    const int idx = (hpos - 1 + m) % m;
-                    const double s0 = has0 ? Sh[idx * p.Dr + d0] : 0.0, s1 = has1 ? Sh[idx * p.Dr + d1] : 0.0;
-                    const double y0 = has0 ? Yh[idx * p.Dr + d0] : 0.0, y1 = has1 ? Yh[idx * p.Dr + d1] : 0.0;
-                    gamma = wave_sum(s0 * y0 + s1 * y1) / wave_sum(y0 * y0 + y1 * y1);
+                    gamma = sy_last / yy_last;   // s.y / y.y of the newest pair: the sums formed when it was stored (same terms, same order)
                 } else {
                     const double nn = sqrt(pgn2);
                     gamma = 1.0 / (nn > 1.0 ? nn : 1.0);
@@ -485,7 +489,7 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
 #pragma unroll
                 for (int h = 7; h >= 0; --h) {
                     if (h < hlen) {
-                        const int idx = (hpos - 1 - h + 2 * m) % m;
+                        const int idx = hist_slot(h);
                         const double s0 = has0 ? Sh[idx * p.Dr + d0] : 0.0, s1 = has1 ? Sh[idx * p.Dr + d1] : 0.0;
                         const double y0 = has0 ? Yh[idx * p.Dr + d0] : 0.0, y1 = has1 ? Yh[idx * p.Dr + d1] : 0.0;
                         const double beta = rho[idx] * wave_sum(y0 * q0 + y1 * q1);
@@ -530,7 +534,9 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
                 if (has1) { Sh[hpos * p.Dr + d1] = sd1; Yh[hpos * p.Dr + d1] = yd1; }
                 if (sy > 1e-10 * yy && sy > 0.0) {
                     if (lane == 0) rho[hpos] = 1.0 / sy;
-                    hpos = (hpos + 1) % m;
+                    sy_last = sy;
+                    yy_last = yy;
+                    hpos = hpos + 1 == m ? 0 : hpos + 1;
                     if (hlen < m) hlen += 1;
                 }
                 x0 = xt0; x1 = xt1;
