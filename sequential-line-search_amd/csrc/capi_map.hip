@@ -626,7 +626,8 @@ static void map_opt_run(sls_nll* h, const MapOptProblem& pb, const double* z0, c
                 tr[0] * 0.01, tr[8] * 0.01, tr[9] * 0.01, tr[10] * 0.01, tr[11] * 0.01, tr[1] * 0.01, tr[12] * 0.01, tr[13] * 0.01, tr[3] * 0.01,
                 tr[4] * 0.01, tr[5] * 0.01, tr[7] * 0.01);
         fprintf(stderr, "   fine: inverse products %.1f barrier %.1f (mirror+barrier = rest) | grad-weights loop %.1f (block sum = rest) | contraction Y pass %.1f "
-                "barrier %.1f (final = rest) | rejected trials %lld\n", tr[16] * 0.01, tr[17] * 0.01, tr[18] * 0.01, tr[19] * 0.01, tr[20] * 0.01, tr[21]);
+                "barrier %.1f (final = rest; row sums %.1f of the pass) | Gram dot products %.1f (elements = rest) | rejected trials %lld\n",
+                tr[16] * 0.01, tr[17] * 0.01, tr[18] * 0.01, tr[19] * 0.01, tr[20] * 0.01, tr[22] * 0.01, tr[23] * 0.01, tr[21]);
     }
     h->have_factor = false;   // the tiled path's cached factor (L, Linv, Kinv buffers) was not refreshed
     if (value) *value = out[0];

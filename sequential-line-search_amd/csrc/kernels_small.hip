@@ -21,10 +21,10 @@ namespace slsk {
 //   [0,128) alpha   [128,256) y   [256,384) 1/l   [384,1024) BTL contributions (map_opt) / the four waves' partial length-scale
 //   gradients (small_grad)   [1024,1028) reduction slots   [1028,1032) a, b (map_opt)   [1040,1168) l (map_opt)
 //   [1168,1296) length-scale gradient   [1296,1616) gradient wrt the optimiser's variables (map_opt)
-//   [1616,1744) squared norms of the scaled points   [1744,1768) section timers (only when tracing)
+//   [1616,1744) squared norms of the scaled points   [1744,1768) section timers (only when tracing)   [1768,1780) slots of the triple sum
 //   [1872,2002) logarithms of a, b, l (map_opt)
 constexpr int SC_ALPHA = 0, SC_Y = 128, SC_INVL = 256, SC_BTL = 384, SC_BTL_MAX = 640, SC_RED = 1024, SC_AB = 1028,
-              SC_ELL = 1040, SC_GL = 1168, SC_GZ = 1296, SC_NX = 1616, SC_TRACE = 1744, SC_LZ = 1872;
+              SC_ELL = 1040, SC_GL = 1168, SC_GZ = 1296, SC_NX = 1616, SC_TRACE = 1744, SC_RED3 = 1768, SC_LZ = 1872;
 static_assert(SC_TRACE + MAP_OPT_TRACE_SLOTS <= SC_LZ && SC_GZ + MAP_OPT_MAX_VARS <= SC_NX && SC_LZ + 2 + NLL_SMALL_MAX_D <= 2048 && 4 * NLL_SMALL_MAX_D <= SC_BTL_MAX, "LDS scratch map");
 
 // (k >> 4) DL + 128 + (k & 15) with DL = 144 = 128 + 16: a shift and two adds instead of shift, mask, multiply, two adds -- these
@@ -38,6 +38,27 @@ __device__ __forceinline__ double small_block_sum(double v, double* As) {
     if ((threadIdx.x & 63) == 0) small_scratch(As, SC_RED + (threadIdx.x >> 6)) = v;
     __syncthreads();
     return (small_scratch(As, SC_RED) + small_scratch(As, SC_RED + 1)) + (small_scratch(As, SC_RED + 2) + small_scratch(As, SC_RED + 3));
+}
+
+// three sums behind one pair of barriers (each in the order of small_block_sum: lanes, then (w0 + w1) + (w2 + w3))
+__device__ __forceinline__ void small_block_sum3(double& v0, double& v1, double& v2, double* As) {
+    v0 = wave_sum(v0);
+    v1 = wave_sum(v1);
+    v2 = wave_sum(v2);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        small_scratch(As, SC_RED3 + w) = v0;
+        small_scratch(As, SC_RED3 + 4 + w) = v1;
+        small_scratch(As, SC_RED3 + 8 + w) = v2;
+    }
+    __syncthreads();
+    auto total = [&](int q) {
+        return (small_scratch(As, SC_RED3 + q) + small_scratch(As, SC_RED3 + q + 1)) + (small_scratch(As, SC_RED3 + q + 2) + small_scratch(As, SC_RED3 + q + 3));
+    };
+    v0 = total(0);
+    v1 = total(4);
+    v2 = total(8);
 }
 
 // optional section timing (SLS_MAP_TRACE=1): ticks of the 100 MHz clock per section, kept by thread 0 in the LDS scratch (24 running
@@ -58,6 +79,37 @@ struct SmallTrace {
         if (on && threadIdx.x == 0) slot_ref(slot) += 1;
     }
 };
+
+// A wave's sequence of matrix-core steps (eight to twelve fragment reads, then four to eight products), software-pipelined: the
+// fragments of step s + 1 are requested before the products of step s are issued, in the same basic block, into the other of two
+// fragment sets (no copies: a copy would wait for the reads it copies).  One wave per SIMD has nothing else to hide the LDS latency
+// behind, and a step of 8 reads + 4 dependent products took ~900 cycles back to back (measured, N = 58) against 256 of products.
+//   It: done(), last() (the step completes a tile / unit), advance(); past the end an iterator keeps valid coordinates (the
+//   prefetch of a step that does not exist reads addresses of the last one).   load(it, frag)  mma(it, frag)  fin(it)
+struct SmallFrag {
+    double a[4], b[4], c[4];
+};
+template <class It, class Load, class Mma, class Fin>
+__device__ __forceinline__ void small_mfma_steps(It it, Load&& load, Mma&& mma, Fin&& fin) {
+    if (it.done()) return;
+    SmallFrag f0, f1;
+    load(it, f0);
+    for (;;) {
+        It n1 = it;
+        n1.advance();
+        load(n1, f1);
+        mma(it, f0);
+        if (it.last()) fin(it);
+        if (n1.done()) break;
+        It n2 = n1;
+        n2.advance();
+        load(n2, f0);
+        mma(n1, f1);
+        if (n1.last()) fin(n1);
+        if (n2.done()) break;
+        it = n2;
+    }
+}
 
 template <bool MATERN>
 __device__ __forceinline__ void small_kern(double a, double q, double& k, double& c) {
@@ -213,7 +265,7 @@ __device__ __forceinline__ void small_gram_batch(double* As, double a, double b,
 }
 
 // K_y = K_f(a, l) + b I into the LDS image (1/l in the scratch) and its Cholesky factorisation on the leading ceil(N/16) blocks: L in the
-// lower triangle of As, L^-T in its strictly-upper tiles, the inverses of the diagonal tiles in Ts.  Returns sum_i log L_ii.
+// lower triangle of As, L^-T in its strictly-upper tiles, the inverses of the diagonal tiles in Ts.  Returns log L_ii in thread i (0 beyond N).
 // Only the lower triangle of K_y is formed (nothing reads the upper halves of the diagonal tiles: what the factorisation computes
 // from them never reaches a result).
 // pairs != nullptr: the kernel values k_ij and derivative weights c_ij stay with their threads for small_grad -- *pairs for a
@@ -259,32 +311,58 @@ __device__ __forceinline__ double small_build_factor(double* As, double* Ts, con
         const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fl = lane & 15, fk = lane >> 4;
         const PtsLds xc{As, pts.base_col, pts.Dp};
         const int Dk = pts.Dp - 1;
-        int t = 0;
-        for (int tj = 0; tj < nb16; ++tj)
-            for (int ti = tj; ti < nb16; ++ti, ++t) {
-                if ((t & 3) != wave) continue;
-                d4_t acc = {0.0, 0.0, 0.0, 0.0};
-                for (int d0 = 0; d0 < Dk; d0 += 16) {
-                    double af[4], bf[4];
+        // tile t of the lower tiles (column by column) belongs to wave t & 3; a step = 16 dimensions of a tile
+        struct It {
+            int ti, tj, d0, nb, Dk;
+            bool fin;
+            __device__ __forceinline__ bool done() const { return fin; }
+            __device__ __forceinline__ bool last() const { return d0 + 16 >= Dk; }
+            __device__ __forceinline__ void skip(int n) {   // n tiles on, n <= 4: at most four column changes
+                int i = ti + n, j = tj;
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        const int d = d0 + 4 * kk + fk;
-                        const double il = small_scratch(As, SC_INVL + d);   // zeros beyond D
-                        af[kk] = xc(16 * ti + fl, d) * (il * il);
-                        bf[kk] = xc(16 * tj + fl, d);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) acc = mfma16(bf[kk], af[kk], acc);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    As[16 * ti + fl + (16 * tj + fk + 4 * q) * DL] = acc[q];
-                    if (ti == tj && fl == fk + 4 * q) small_scratch(As, SC_NX + 16 * ti + fl) = acc[q];
-                }
+                for (int r = 0; r < 4; ++r)
+                    if (j < nb && i >= nb) { i = i - nb + j + 1; ++j; }
+                if (j >= nb || i >= nb) { fin = true; return; }
+                ti = i;
+                tj = j;
+                d0 = 0;
             }
+            __device__ __forceinline__ void advance() {
+                if (!last()) { d0 += 16; return; }
+                skip(4);
+            }
+        };
+        It it0{0, 0, 0, nb16, Dk, false};
+        if (wave) it0.skip(wave);
+        d4_t acc = {0.0, 0.0, 0.0, 0.0};
+        small_mfma_steps(
+            it0,
+            [&](const It& q, SmallFrag& f) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int d = q.d0 + 4 * kk + fk;
+                    f.c[kk] = small_scratch(As, SC_INVL + d);   // zeros beyond D
+                    f.a[kk] = xc(16 * q.ti + fl, d);
+                    f.b[kk] = xc(16 * q.tj + fl, d);
+                }
+            },
+            [&](const It&, const SmallFrag& f) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) acc = mfma16(f.b[kk], f.a[kk] * (f.c[kk] * f.c[kk]), acc);
+            },
+            [&](const It& q) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    As[16 * q.ti + fl + (16 * q.tj + fk + 4 * r) * DL] = acc[r];
+                    if (q.ti == q.tj && fl == fk + 4 * r) small_scratch(As, SC_NX + 16 * q.ti + fl) = acc[r];
+                    acc[r] = 0.0;
+                }
+            });
         __syncthreads();
+        if (st.on) {   // probe: pass (1) (slot 23), counted inside the Gram slot 8 as well
+            const long long t_now = wall_clock64();
+            if (tid == 0) st.slot_ref(23) += t_now - st.t_prev;
+        }
         // identity padding of the last block: the padded points are zero rows, so rows N .. 16 nb16 - 1 of the lower triangle hold
         // zeros already; ones on their diagonal (pass (2) does not touch these rows)
         {
@@ -307,10 +385,8 @@ __device__ __forceinline__ double small_build_factor(double* As, double* Ts, con
     __syncthreads();
     st.mark(9);
 
-    // ---- log det ----
-    const double ld = small_block_sum(tid < N ? log(As[tid + tid * DL]) : 0.0, As);
-    st.mark(10);
-    return ld;
+    // ---- log det: thread i's term log L_ii (the caller adds them up, small_alpha together with its own sums) ----
+    return tid < N ? log(As[tid + tid * DL]) : 0.0;
 }
 
 // The strictly-lower tiles of the leading nb16 blocks copied into their mirror positions, one tile per wave and trip.  Each 16-lane
@@ -343,28 +419,56 @@ __device__ __forceinline__ void small_inverse_in_place(double* As, double* Ts, i
     const int fl = lane & 15, fk = lane >> 4;
     const int nb16 = (N + 15) >> 4;
     // ---- K^-1 = L^-T L^-1, lower tiles (i >= j) into the lower triangle (L is no longer needed) ----
+    // tile t (row-major over the lower tiles) belongs to wave t & 3; a step = one block k = i .. nb16 - 1 of the tile's sum (the sum
+    // keeps its order).  Inputs live in the strictly-upper tiles and in Ts, results go to the lower tiles: a tile may be stored while
+    // the next one's fragments are in flight.
     {
-        int t = 0;
-        for (int i = 0; i < nb16; ++i)
-            for (int j = 0; j <= i; ++j, ++t) {
-                if ((t & 3) != wave) continue;
-                d4_t c = {0.0, 0.0, 0.0, 0.0};
-                for (int k = i; k < nb16; ++k) {
-                    double af[4], bf[4];   // the eight fragment reads of a block in flight together (the sum keeps its order)
+        struct It {
+            int i, j, k, nb;
+            bool fin;
+            __device__ __forceinline__ bool done() const { return fin; }
+            __device__ __forceinline__ bool last() const { return k == nb - 1; }
+            __device__ __forceinline__ void skip(int n) {   // n tiles on, n <= 4: at most four row changes
+                int r = i, c = j + n;
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        const int kq = 4 * kk + fk;
-                        af[kk] = (k == i) ? Ts[256 * i + kq + 16 * fl] : As[(16 * k + kq) * DL + 16 * i + fl];   // T[k][i] (kq, m)
-                        bf[kk] = (k == j) ? Ts[256 * j + kq + 16 * fl] : As[(16 * k + kq) * DL + 16 * j + fl];   // T[k][j] (kq, n)
-                    }
-                    __builtin_amdgcn_sched_barrier(0);   // all eight reads issued before the first product (the scheduler pairs each read with its use)
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) c = mfma16(bf[kk], af[kk], c);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) As[(16 * j + fk + 4 * q) * DL + 16 * i + fl] = c[q];
+                for (int q = 0; q < 4; ++q)
+                    if (c > r) { c -= r + 1; ++r; }
+                if (r >= nb) { fin = true; return; }
+                i = r;
+                j = c;
+                k = r;
             }
+            __device__ __forceinline__ void advance() {
+                if (!last()) { ++k; return; }
+                skip(4);
+            }
+        };
+        It it0{0, 0, 0, nb16, false};
+        if (wave) it0.skip(wave);
+        d4_t c = {0.0, 0.0, 0.0, 0.0};
+        constexpr int TS = 128 * DL;   // Ts = As + TS
+        small_mfma_steps(
+            it0,
+            [&](const It& q, SmallFrag& f) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int kq = 4 * kk + fk;
+                    const int row = (16 * q.k + kq) * DL + fl, tile = TS + kq + 16 * fl;
+                    f.a[kk] = As[q.k == q.i ? tile + 256 * q.i : row + 16 * q.i];   // T[k][i] (kq, m)
+                    f.b[kk] = As[q.k == q.j ? tile + 256 * q.j : row + 16 * q.j];   // T[k][j] (kq, n)
+                }
+            },
+            [&](const It&, const SmallFrag& f) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) c = mfma16(f.b[kk], f.a[kk], c);
+            },
+            [&](const It& q) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    As[(16 * q.j + fk + 4 * r) * DL + 16 * q.i + fl] = c[r];
+                    c[r] = 0.0;
+                }
+            });
     }
     if (stp) stp->mark(16);
     __syncthreads();
@@ -376,22 +480,23 @@ __device__ __forceinline__ void small_inverse_in_place(double* As, double* Ts, i
 
 
 // K_y = K_f(a, l) + b I into the LDS image (1/l in the scratch), Cholesky + inverse on the leading ceil(N/16) blocks,
-// K_y^-1 as a full symmetric image over the dead factor.  Returns sum_i log L_ii (= logdet / 2) in every thread.
+// K_y^-1 as a full symmetric image over the dead factor.  Returns log L_ii in thread i (their sum = logdet / 2: small_alpha).
 template <bool MATERN, class Idle = NoIdleWork>
 __device__ __forceinline__ double small_factor_inverse(double* As, double* Ts, const SmallPts& pts, const Fold& fold0, int D, int N, double a,
                                                        double b, int* __restrict__ info, SmallPairs* pairs, double* __restrict__ kc,
                                                        SmallTrace& st, Idle&& idle0 = Idle{}) {
-    const double ld = small_build_factor<MATERN>(As, Ts, pts, fold0, D, N, a, b, info, pairs, kc, st, idle0);
+    const double lg = small_build_factor<MATERN>(As, Ts, pts, fold0, D, N, a, b, info, pairs, kc, st, idle0);
     small_inverse_in_place(As, Ts, N, &st);
     st.mark(11);
-    return ld;
+    return lg;
 }
 
-// alpha = K^-1 y (y in the scratch) into the scratch; gb = 1/2 (alpha.alpha - tr K^-1), quad = y.alpha in every thread
+// alpha = K^-1 y (y in the scratch) into the scratch; gb = 1/2 (alpha.alpha - tr K^-1), quad = y.alpha and ld = the sum of the
+// threads' lg (log L_ii from small_factor_inverse: logdet / 2) in every thread -- one pair of barriers for the three sums
 // side: work of the caller's for the upper two waves while the lower two form the product (it may write scratch that nobody reads
 // before the barrier below)
 template <class Side = NoIdleWork>
-__device__ __forceinline__ void small_alpha(double* As, int N, double& gb, double& quad, Side&& side = Side{}) {
+__device__ __forceinline__ void small_alpha(double* As, int N, double lg, double& ld, double& gb, double& quad, Side&& side = Side{}) {
     const int tid = threadIdx.x;
     if (tid >= 128) side();
     else {
@@ -420,8 +525,10 @@ __device__ __forceinline__ void small_alpha(double* As, int N, double& gb, doubl
         s1 = al * al - As[tid + tid * DL];
         s2 = small_scratch(As, SC_Y + tid) * al;
     }
-    gb = 0.5 * small_block_sum(s1, As);
-    quad = small_block_sum(s2, As);
+    small_block_sum3(s1, s2, lg, As);
+    gb = 0.5 * s1;
+    quad = s2;
+    ld = lg;
 }
 
 // Gradient contractions over the pairs i >= j with W = alpha alpha^T - K^-1 (src/gaussian-process-regressor.cpp:66-127 without
@@ -434,9 +541,11 @@ __device__ __forceinline__ void small_alpha(double* As, int N, double& gb, doubl
 // LP = min(64, 2^ceil(log2 D)) lanes each (two dimensions per lane for D > 64), four steps' loads in flight; the point coordinates
 // come from the D x N original (a pair's D values are contiguous), G from LDS.  The per-wave partial sums are added over the lanes of
 // a dimension by xor butterflies and over the waves as (w0 + w1) + (w2 + w3): one fixed order.
+// e1, e2: two more per-thread addends of the caller's, summed over the workgroup behind the same barriers as sa (in place).
 template <bool MATERN>
 __device__ __forceinline__ double small_grad(double* As, const SmallPts& pts, const Fold& fold0, const SmallPairs* pairs,
-                                             const double* __restrict__ kc, int D, int N, double a, bool want_grad, SmallTrace& st) {
+                                             const double* __restrict__ kc, int D, int N, double a, bool want_grad, SmallTrace& st,
+                                             double& e1, double& e2) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nb16 = (N + 15) >> 4;
     const bool mm = pts.lds != 0;   // matrix-core contraction
@@ -492,60 +601,97 @@ __device__ __forceinline__ double small_grad(double* As, const SmallPts& pts, co
         }
     }
     st.mark(18);
-    const double sa_t = small_block_sum(sa, As);   // its barriers publish the lower triangle of G
+    small_block_sum3(sa, e1, e2, As);   // its barriers publish the lower triangle of G
+    const double sa_t = sa;
     st.mark(12);
     if (!want_grad) return sa_t;
-    small_mirror_lower<true>(As, nb16);
-    __syncthreads();
 
     if (mm) {
+        // With G symmetric, sum_j x_jp (x_jp s_j - (G X~)_jp) needs the strictly-lower triangle Gl only:
+        //     P_p = sum_j [ x_jp^2 r_j + (Gl X~^2)_jp - 2 x_jp (Gl X~)_jp ],   r = Gl 1 (row sums),  X~^2 elementwise
+        // (the column sums of Gl weigh x_jp^2 exactly as Gl weighs the squares of the other factor) -- no mirror image of G, half
+        // the block products.  (a) r: thread (j, part) adds its quarter (half for N > 64) of row j, parts combined in a fixed order.
+        // (b) the products on the matrix cores: a unit = (block row tj, dimension tile tp), tj + 1 column blocks (steps) each; the
+        // units, ordered by descending cost, are dealt forwards and backwards over the waves (u mod 8 = w or 7 - w: 1 + 4, 2 + 3
+        // blocks ...).  Lane (fl, fk) holds (j = 16 tj + fl, p = 16 tp + fk + 4 q); a unit's sums over its 16 j go to the wave's
+        // own partial array.
         const int fl = lane & 15, fk = lane >> 4;
         const PtsLds xc{As, pts.base_col, pts.Dp};
-        // Y' = G (X - 0.5) tile by tile; lane (fl, fk) holds Y'(j = 16 tj + fl, p = 16 tp + fk + 4 q) and adds
-        // x_jp (x_jp s_j - Y'_jp) over the block rows tj of this wave (tj = wave, wave + 4); the 16 lanes of a row then hold the 16 j
-        // of a block.  s = G 1 comes out of the same fragments with the constant 1 as the other operand (first dimension tile only;
-        // every lane of row j receives s_j: no exchange).
-        const int ntp = (pts.Dp - 1) >> 4;
-        double sreg[2] = {0.0, 0.0};
-        for (int tp = 0; tp < ntp; ++tp) {
-            double part[4] = {0.0, 0.0, 0.0, 0.0};
+        const int Nb = 16 * nb16;
+        const int shift = Nb <= 64 ? 6 : 7, parts = 256 >> shift, ck = Nb >> (8 - shift);   // ck = Nb / parts
+        {
+            const int j = tid & ((1 << shift) - 1), part = tid >> shift;
+            double r = 0.0;
+            for (int k0 = part * ck; k0 < (part + 1) * ck; k0 += 8) {
+                double g[8];
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const int tj = wave + 4 * n;
-                if (tj >= nb16) break;
-                d4_t acc = {0.0, 0.0, 0.0, 0.0}, accs = {0.0, 0.0, 0.0, 0.0};
-                for (int k0 = 0; k0 < 16 * nb16; k0 += 16) {
-                    double af[4], bf[4];
+                for (int u = 0; u < 8; ++u) g[u] = As[min(j, Nb - 1) + min(k0 + u, Nb - 1) * DL];
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        af[kk] = As[(k0 + 4 * kk + fk) * DL + 16 * tj + fl];
-                        bf[kk] = xc(k0 + 4 * kk + fk, 16 * tp + fl);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) acc = mfma16(bf[kk], af[kk], acc);
-                    if (tp == 0) {
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) accs = mfma16(1.0, af[kk], accs);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (tp == 0) sreg[n] = accs[0];
-                const int j = 16 * tj + fl;
-                const double sj = sreg[n];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const double xv = xc(j, 16 * tp + fk + 4 * q);
-                    part[q] = fma(xv, fma(xv, sj, -acc[q]), part[q]);
-                }
+                for (int u = 0; u < 8; ++u) r += (k0 + u < (part + 1) * ck && k0 + u < j) ? g[u] : 0.0;
             }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const double v = row_sum(part[q]);
-                const int p = 16 * tp + fk + 4 * q;
-                if (fl == 0 && p < D) small_scratch(As, SC_BTL + wave * NLL_SMALL_MAX_D + p) = v;
-            }
+            small_scratch(As, SC_GZ + (part << shift) + j) = r;   // 256 partial sums: the optimiser-gradient slots, rewritten after this pass
         }
+        small_scratch(As, SC_BTL + wave * NLL_SMALL_MAX_D + lane) = 0.0;
+        small_scratch(As, SC_BTL + wave * NLL_SMALL_MAX_D + 64 + lane) = 0.0;
+        __syncthreads();
+        if (st.on) {   // probe: the row-sum step (slot 22), counted inside the pass's slot 19 as well
+            const long long t_now = wall_clock64();
+            if (tid == 0) st.slot_ref(22) += t_now - st.t_prev;
+        }
+        struct It {
+            int tj, tp, kb, ntp, w;
+            bool odd, fin;
+            __device__ __forceinline__ bool done() const { return fin; }
+            __device__ __forceinline__ bool last() const { return kb == tj; }
+            __device__ __forceinline__ void skip(int n) {   // n units on
+                int p = tp + n, j = tj;
+                while (p >= ntp) { p -= ntp; --j; }
+                if (j < 0) { fin = true; return; }
+                tp = p;
+                tj = j;
+                kb = 0;
+            }
+            __device__ __forceinline__ void advance() {
+                if (!last()) { ++kb; return; }
+                skip(odd ? 1 + 2 * w : 7 - 2 * w);
+                odd = !odd;
+            }
+        };
+        It it0{nb16 - 1, 0, 0, (pts.Dp - 1) >> 4, wave, false, false};
+        if (wave) it0.skip(wave);
+        d4_t accy = {0.0, 0.0, 0.0, 0.0}, accz = {0.0, 0.0, 0.0, 0.0};
+        small_mfma_steps(
+            it0,
+            [&](const It& q, SmallFrag& f) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    f.a[kk] = As[(16 * q.kb + 4 * kk + fk) * DL + 16 * q.tj + fl];
+                    f.b[kk] = xc(16 * q.kb + 4 * kk + fk, 16 * q.tp + fl);
+                }
+            },
+            [&](const It& q, const SmallFrag& f) {
+                const bool diag = q.kb == q.tj;   // the diagonal block: its strictly-lower half
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const double g = (!diag || 4 * kk + fk < fl) ? f.a[kk] : 0.0;
+                    accy = mfma16(f.b[kk], g, accy);
+                    accz = mfma16(f.b[kk] * f.b[kk], g, accz);
+                }
+            },
+            [&](const It& q) {
+                const int j = 16 * q.tj + fl;
+                double rj = small_scratch(As, SC_GZ + j) + small_scratch(As, SC_GZ + (1 << shift) + j);
+                if (parts == 4) rj += small_scratch(As, SC_GZ + 128 + j) + small_scratch(As, SC_GZ + 192 + j);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double xv = xc(j, 16 * q.tp + fk + 4 * r);
+                    const double v = row_sum(fma(xv, fma(xv, rj, -2.0 * accy[r]), accz[r]));
+                    const int p = 16 * q.tp + fk + 4 * r;
+                    if (fl == 0 && p < D) small_scratch(As, SC_BTL + wave * NLL_SMALL_MAX_D + p) += v;
+                    accy[r] = 0.0;
+                    accz[r] = 0.0;
+                }
+            });
         st.mark(19);
         __syncthreads();
         st.mark(20);
@@ -581,7 +727,7 @@ __device__ __forceinline__ double small_grad(double* As, const SmallPts& pts, co
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int j = j0 + u * PW + jj, jc = min(j, i - 1);   // past the row's end: the last pair again, weight 0
-                    const double g = As[jc + i * DL];
+                    const double g = As[i + jc * DL];   // the lower triangle (all lanes of a pair read one address)
                     gv[u] = j < i ? g : 0.0;
                     x0[u] = x(jc, d0);
                     x1[u] = wide ? x(jc, d1) : 0.0;
@@ -641,11 +787,11 @@ __global__ __launch_bounds__(256) void nll_small_kernel(const NllSmallArgs args)
     SmallTrace st;
     const Fold fold0(N);
     SmallPairs pr;
-    const double ld = small_factor_inverse<MATERN>(As, Ts, pts, fold0, D, N, a, b, info, want_grad ? &pr : nullptr, kc, st);
-    double gb, quad;
-    small_alpha(As, N, gb, quad);
+    const double lg = small_factor_inverse<MATERN>(As, Ts, pts, fold0, D, N, a, b, info, want_grad ? &pr : nullptr, kc, st);
+    double ld, gb, quad, e1 = 0.0, e2 = 0.0;
+    small_alpha(As, N, lg, ld, gb, quad);
     if (tid < N && args.batch <= 1) out[NLL_SMALL_OUT_ALPHA + tid] = small_scratch(As, SC_ALPHA + tid);   // batch mode: 8 output words per parameter set
-    const double sa_t = small_grad<MATERN>(As, pts, fold0, &pr, kc, D, N, a, want_grad != 0, st);
+    const double sa_t = small_grad<MATERN>(As, pts, fold0, &pr, kc, D, N, a, want_grad != 0, st, e1, e2);
     if (want_grad && tid < D) out[NLL_SMALL_OUT_GL + tid] = small_scratch(As, SC_GL + tid);
     if (tid == 0) {
         out[0] = sa_t;
@@ -788,9 +934,10 @@ __global__ __launch_bounds__(256) void map_opt_kernel(const MapOptArgs args) {
     while (budget > 0 && !done) {
         --budget;
         // ---- publish the trial point: y into the scratch, hyper-parameters in linear space ----
-        if (wave == 0) {
+        // (every wave holds the same replica: wave k & 3 publishes variables 64 k .. 64 k + 63)
 #pragma unroll
-            for (int k = 0; k < KV; ++k) {
+        for (int k = 0; k < KV; ++k) {
+            if ((k & 3) == wave) {
                 const int e = lane + 64 * k;
                 if (e < ny) small_scratch(As, SC_Y + e) = xt[k];
                 else if (e < n) {
@@ -877,34 +1024,38 @@ __global__ __launch_bounds__(256) void map_opt_kernel(const MapOptArgs args) {
         };
         const bool rebuild = nh || !have_factor;
         SmallPairs pr;   // kernel values and derivative weights of this thread's pairs, from the kernel-function pass to the gradient's
+        double lg = 0.0, ld_now, gb, quad;
         if (rebuild) {
-            ld = small_factor_inverse<MATERN>(As, Ts, pts, fold0, D, N, a, b, info, nh ? &pr : nullptr, args.kc, st, btl_tuples);
+            lg = small_factor_inverse<MATERN>(As, Ts, pts, fold0, D, N, a, b, info, nh ? &pr : nullptr, args.kc, st, btl_tuples);
             have_factor = true;
             bad = __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-        }
-        double gb, quad;
-        if (rebuild) small_alpha(As, N, gb, quad);
-        else small_alpha(As, N, gb, quad, btl_tuples);
+            small_alpha(As, N, lg, ld_now, gb, quad);
+            ld = ld_now;
+        } else small_alpha(As, N, lg, ld_now, gb, quad, btl_tuples);
         MAP_T(1);
         if (bad && nh && tid == 0) *info = 0;   // every thread has read it (barriers of small_alpha); the next factorisation starts clean
         // the contributions are published (barriers of small_alpha): gathered now, small_grad reuses their scratch
         if (btl_lds) btl_gather_in([&](int q) -> double& { return small_scratch(As, SC_BTL + q); });
         else btl_gather_in([&](int q) -> double& { return args.btl_scratch[q]; });
-        double sa_t = 0.0;
-        if (nh) sa_t = small_grad<MATERN>(As, pts, fold0, &pr, args.kc, D, N, a, true, st);   // length-scale gradient -> scratch (SC_GL)
+        // the sum of the tuples' log-likelihoods and (hyper-parameters among the variables) of the D length-scale prior terms, one per
+        // thread (:175-192), ride on the barriers of small_grad's own sum
+        double sa_t = 0.0, btl_sum = lsum, reg_l = 0.0;
+        if (nh) {
+            reg_l = tid < D ? dev_log_lognormal(small_scratch(As, SC_LZ + 2 + tid), args.mu_r, args.s2_r, hl_r) : 0.0;
+            sa_t = small_grad<MATERN>(As, pts, fold0, &pr, args.kc, D, N, a, true, st, btl_sum, reg_l);   // length-scale gradient -> scratch (SC_GL)
+        } else btl_sum = small_block_sum(lsum, As);
 
         // ---- gradient of the BTL terms wrt the goodness values: the contributions gathered in tuple order (:202-216), minus alpha (:219) ----
-        const double btl_sum = small_block_sum(lsum, As);
         if (tid < ny) gy = gsum - small_scratch(As, SC_ALPHA + tid);
         MAP_T(3);
 
         // ---- value ----
         double f = btl_sum + (-0.5 * quad - 0.5 * (2.0 * ld) - 0.5 * N * log(2.0 * M_PI));
         if (nh) {
-            // log-normal priors (:175-192): the D length-scale terms one per thread, added by the block reduction
+            // log-normal priors (:175-192)
             double reg = dev_log_lognormal(small_scratch(As, SC_LZ), args.mu_a, args.s2_a, hl_a);
             if (!args.noiseless) reg += dev_log_lognormal(small_scratch(As, SC_LZ + 1), args.mu_b, args.s2_b, hl_b);
-            reg += small_block_sum(tid < D ? dev_log_lognormal(small_scratch(As, SC_LZ + 2 + tid), args.mu_r, args.s2_r, hl_r) : 0.0, As);
+            reg += reg_l;
             f += reg;
         }
         f_last = f;
@@ -1154,7 +1305,7 @@ __global__ __launch_bounds__(256) void gp_fit_small_kernel(const GpFitSmallArgs 
     __syncthreads();
 
     SmallTrace st;
-    const double ld = small_build_factor<MATERN>(As, Ts, pts, Fold(N), D, N, p.a, p.b, p.info, nullptr, nullptr, st);
+    const double lg = small_build_factor<MATERN>(As, Ts, pts, Fold(N), D, N, p.a, p.b, p.info, nullptr, nullptr, st);
     // ---- L, L^-1 and (L^-1)^T to global memory (identity padding outside the leading Nb x Nb block, zeros above / below) ----
     for (int idx = tid; idx < Np * Np; idx += 256) {
         const int i = idx & (Np - 1), j = idx >> 7;
@@ -1176,8 +1327,8 @@ __global__ __launch_bounds__(256) void gp_fit_small_kernel(const GpFitSmallArgs 
         const int i = idx & (Np - 1), j = idx >> 7;
         p.Kinv[idx] = (i < Nb && j < Nb) ? As[i + j * DL] : (i == j ? 1.0 : 0.0);
     }
-    double gb, quad;
-    small_alpha(As, N, gb, quad);
+    double ld, gb, quad;
+    small_alpha(As, N, lg, ld, gb, quad);
     // ---- alpha, alpha o X~, the posterior mean at the data points (mu(x_i) = y_i - b alpha_i) and its first maximum ----
     double mv = -INFINITY;
     int mi = 0x7fffffff;
