@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
 #pragma unroll
             for (int k = 0; k < K; ++k)
                 out[k] = combine4(xch[(0 * K + k) * 64 + lane], xch[(1 * K + k) * 64 + lane], xch[(2 * K + k) * 64 + lane], xch[(3 * K + k) * 64 + lane]);
-            __syncthreads();
+            __syncthreads();   // (measured: 40 cycles with the waves in step; a variant without it for N > 64 lost bit-identity with the one-wave form)
         };
         // chain c of  sum_d (xs_d - X~_id)^2  for row i
         auto kvec_chain = [&](int i, int c) {
@@ -404,6 +404,9 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
     };
 
     auto clamp01 = [](double v) { return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); };
+    // a lane's two terms of a dot product over d, d + 64 with the contraction written out: left to the compiler, the instantiations
+    // of this kernel (one wave per start / cooperative) may fuse different halves and round differently
+    auto dot2 = [](double a0, double b0, double a1, double b1) { return fma(a0, b0, a1 * b1); };
 
     double val, gr0, gr1;
     if (p.n_local == 0) {
@@ -459,22 +462,40 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
             if (!has0) pg0 = 0.0;
             if (!has1) pg1 = 0.0;
             const double pgmax = wave_max(fmax(fabs(pg0), fabs(pg1)));
-            const double pgn2 = wave_sum(pg0 * pg0 + pg1 * pg1);
+            const double pgn2 = wave_sum(dot2(pg0, pg0, pg1, pg1));
             if (!(pgmax > p.gtol)) {
                 done = true;
             } else {
                 double q0 = pg0, q1 = pg1;
                 double al[8];
+                // the whole history into registers first: one LDS round trip for all pairs instead of one per pair on the chain of
+                // dependent sums (slots beyond hlen are read from slot 0 and not used)
+                double hs0[8], hs1[8], hy0[8], hy1[8], hrho[8];
+                const int d0c = has0 ? d0 : 0, d1c = has1 ? d1 : 0;
+                const bool wide = D > 64;
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    const int idx = h < hlen ? hist_slot(h) : 0;
+                    hs0[h] = Sh[idx * p.Dr + d0c];
+                    hy0[h] = Yh[idx * p.Dr + d0c];
+                    hs1[h] = wide ? Sh[idx * p.Dr + d1c] : 0.0;
+                    hy1[h] = wide ? Yh[idx * p.Dr + d1c] : 0.0;
+                    hrho[h] = rho[idx];
+                }
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    hs0[h] = has0 ? hs0[h] : 0.0;
+                    hy0[h] = has0 ? hy0[h] : 0.0;
+                    hs1[h] = has1 ? hs1[h] : 0.0;
+                    hy1[h] = has1 ? hy1[h] : 0.0;
+                }
 #pragma unroll
                 for (int h = 0; h < 8; ++h) {
                     al[h] = 0.0;
                     if (h < hlen) {
-                        const int idx = hist_slot(h);
-                        const double s0 = has0 ? Sh[idx * p.Dr + d0] : 0.0, s1 = has1 ? Sh[idx * p.Dr + d1] : 0.0;
-                        const double y0 = has0 ? Yh[idx * p.Dr + d0] : 0.0, y1 = has1 ? Yh[idx * p.Dr + d1] : 0.0;
-                        al[h] = rho[idx] * wave_sum(s0 * q0 + s1 * q1);
-                        q0 -= al[h] * y0;
-                        q1 -= al[h] * y1;
+                        al[h] = hrho[h] * wave_sum(dot2(hs0[h], q0, hs1[h], q1));
+                        q0 -= al[h] * hy0[h];
+                        q1 -= al[h] * hy1[h];
                     }
                 }
                 double gamma;
@@ -489,24 +510,21 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
 #pragma unroll
                 for (int h = 7; h >= 0; --h) {
                     if (h < hlen) {
-                        const int idx = hist_slot(h);
-                        const double s0 = has0 ? Sh[idx * p.Dr + d0] : 0.0, s1 = has1 ? Sh[idx * p.Dr + d1] : 0.0;
-                        const double y0 = has0 ? Yh[idx * p.Dr + d0] : 0.0, y1 = has1 ? Yh[idx * p.Dr + d1] : 0.0;
-                        const double beta = rho[idx] * wave_sum(y0 * q0 + y1 * q1);
-                        q0 += s0 * (al[h] - beta);
-                        q1 += s1 * (al[h] - beta);
+                        const double beta = hrho[h] * wave_sum(dot2(hy0[h], q0, hy1[h], q1));
+                        q0 += hs0[h] * (al[h] - beta);
+                        q1 += hs1[h] * (al[h] - beta);
                     }
                 }
                 dir0 = (pg0 == 0.0) ? 0.0 : -q0;
                 dir1 = (pg1 == 0.0) ? 0.0 : -q1;
-                double gd = wave_sum(pg0 * dir0 + pg1 * dir1);
+                double gd = wave_sum(dot2(pg0, dir0, pg1, dir1));
                 if (!(gd < 0.0)) {
                     hlen = 0;
                     const double nn = sqrt(pgn2);
                     gamma = 1.0 / (nn > 1.0 ? nn : 1.0);
                     dir0 = -gamma * pg0;
                     dir1 = -gamma * pg1;
-                    gd = wave_sum(pg0 * dir0 + pg1 * dir1);
+                    gd = wave_sum(dot2(pg0, dir0, pg1, dir1));
                     if (!(gd < 0.0)) done = true;
                 }
                 if (!done) { t = 1.0; nbt = 0; }
@@ -522,14 +540,14 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
             ++n_useful;
             const double ft = -val;
             const double sd0 = has0 ? xt0 - x0 : 0.0, sd1 = has1 ? xt1 - x1 : 0.0;
-            const double gs = wave_sum(g0 * sd0 + g1 * sd1);
-            const double ss = wave_sum(sd0 * sd0 + sd1 * sd1);
+            const double gs = wave_sum(dot2(g0, sd0, g1, sd1));
+            const double ss = wave_sum(dot2(sd0, sd0, sd1, sd1));
             if (ss == 0.0) {
                 done = true;
             } else if (ft <= f + p.c1 * gs) {
                 const double yd0 = has0 ? -gr0 - g0 : 0.0, yd1 = has1 ? -gr1 - g1 : 0.0;
-                const double sy = wave_sum(sd0 * yd0 + sd1 * yd1);
-                const double yy = wave_sum(yd0 * yd0 + yd1 * yd1);
+                const double sy = wave_sum(dot2(sd0, yd0, sd1, yd1));
+                const double yy = wave_sum(dot2(yd0, yd0, yd1, yd1));
                 if (has0) { Sh[hpos * p.Dr + d0] = sd0; Yh[hpos * p.Dr + d0] = yd0; }
                 if (has1) { Sh[hpos * p.Dr + d1] = sd1; Yh[hpos * p.Dr + d1] = yd1; }
                 if (sy > 1e-10 * yy && sy > 0.0) {

@@ -72,7 +72,9 @@ def test_factor_and_inverse_device_time_budget(oracle):
         c.close()
 
 
-@pytest.mark.parametrize("use_map,budget_ms", [(1, 6.0), (0, 3.2)])     # ~1.25x (MAP on: 4.7-4.9 ms) and 1.45x (fixed: 2.2 ms, trajectory dependent) the measured means
+# ~1.25x the measured means (MAP on: 3.75-4.2 ms, fixed: 2.3-2.45 ms; both depend on the trajectory: a local phase that runs into
+# its cap of 320 evaluations costs 2.2 ms, one that converges 0.5 ms, and last-place changes of the arithmetic move that)
+@pytest.mark.parametrize("use_map,budget_ms", [(1, 5.2), (0, 3.0)])
 def test_c3_submit_feedback_budget(use_map, budget_ms):
     """C3: sequential_line_search_nd, D = 32, 30 iterations: wall time of SubmitFeedbackData (preference MAP fit on the device +
     DIRECT -> L-BFGS acquisition maximisation), steady state (the first submit carries the one-off initialisation).
