@@ -1158,8 +1158,9 @@ __global__ __launch_bounds__(256) void map_opt_kernel(const MapOptArgs args) {
                     pm_ = fmax(pm_, fabs(v));
                     pn += v * v;
                 }
-                const double pgmax = wave_max(pm_), pgn2 = wave_sum(pn);
-                if (!(pgmax > 0.0)) done = 1;
+                // max |projected gradient| > 0 somewhere?  A vote instead of the wave-wide maximum (only its sign is used; a dependent
+                // reduction is ~180 cycles on this chain, tools/probes/lat_probe)
+                if (!__any(pm_ > 0.0)) done = 1;
                 else {
                     double al[MH];
 #pragma unroll
@@ -1173,7 +1174,7 @@ __global__ __launch_bounds__(256) void map_opt_kernel(const MapOptArgs args) {
                             for (int k = 0; k < KV; ++k) d[k] -= al[h] * Y[h][k];
                         }
                     }
-                    double gamma = cnt > 0 ? sy_last / yy_last : 1.0 / fmax(1.0, sqrt(pgn2));
+                    double gamma = cnt > 0 ? sy_last / yy_last : 1.0 / fmax(1.0, sqrt(wave_sum(pn)));   // |pg|^2 only where it is used
 #pragma unroll
                     for (int k = 0; k < KV; ++k) d[k] *= gamma;
 #pragma unroll
@@ -1188,7 +1189,7 @@ __global__ __launch_bounds__(256) void map_opt_kernel(const MapOptArgs args) {
                     double gd = wave_dot(pg, d);
                     if (!(gd < 0.0)) {
                         cnt = 0;
-                        gamma = 1.0 / fmax(1.0, sqrt(pgn2));
+                        gamma = 1.0 / fmax(1.0, sqrt(wave_sum(pn)));
 #pragma unroll
                         for (int k = 0; k < KV; ++k) d[k] = -gamma * pg[k];
                         gd = wave_dot(pg, d);
@@ -1208,7 +1209,10 @@ __global__ __launch_bounds__(256) void map_opt_kernel(const MapOptArgs args) {
                     xt[k] = fmin(hi[k], fmax(lo[k], x[k] + t * d[k]));
                     dv[k] = xt[k] - x[k];
                 }
-                if (wave_dot(dv, dv) == 0.0) done = 1;
+                double dd = 0.0;   // the lane's part of dv . dv: the sum of these non-negative terms is zero exactly when every one is
+#pragma unroll
+                for (int k = 0; k < KV; ++k) dd += dv[k] * dv[k];
+                if (!__any(dd != 0.0)) done = 1;
             }
         }
         MAP_T(5);

@@ -461,9 +461,9 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
             if ((x1 <= 0.0 && pg1 > 0.0) || (x1 >= 1.0 && pg1 < 0.0)) pg1 = 0.0;
             if (!has0) pg0 = 0.0;
             if (!has1) pg1 = 0.0;
-            const double pgmax = wave_max(fmax(fabs(pg0), fabs(pg1)));
-            const double pgn2 = wave_sum(dot2(pg0, pg0, pg1, pg1));
-            if (!(pgmax > p.gtol)) {
+            const bool pg_above = __any(fmax(fabs(pg0), fabs(pg1)) > p.gtol);   // max |pg| > gtol, by vote (no dependent reduction)
+            const double pgn2_lane = dot2(pg0, pg0, pg1, pg1);   // |pg|^2 is summed only where it is used (no history, or a direction that does not descend)
+            if (!pg_above) {
                 done = true;
             } else {
                 double q0 = pg0, q1 = pg1;
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
                 if (hlen > 0) {
                     gamma = sy_last / yy_last;   // s.y / y.y of the newest pair: the sums formed when it was stored (same terms, same order)
                 } else {
-                    const double nn = sqrt(pgn2);
+                    const double nn = sqrt(wave_sum(pgn2_lane));
                     gamma = 1.0 / (nn > 1.0 ? nn : 1.0);
                 }
                 q0 *= gamma;
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
                 double gd = wave_sum(dot2(pg0, dir0, pg1, dir1));
                 if (!(gd < 0.0)) {
                     hlen = 0;
-                    const double nn = sqrt(pgn2);
+                    const double nn = sqrt(wave_sum(pgn2_lane));
                     gamma = 1.0 / (nn > 1.0 ? nn : 1.0);
                     dir0 = -gamma * pg0;
                     dir1 = -gamma * pg1;
@@ -541,8 +541,7 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
             const double ft = -val;
             const double sd0 = has0 ? xt0 - x0 : 0.0, sd1 = has1 ? xt1 - x1 : 0.0;
             const double gs = wave_sum(dot2(g0, sd0, g1, sd1));
-            const double ss = wave_sum(dot2(sd0, sd0, sd1, sd1));
-            if (ss == 0.0) {
+            if (!__any(dot2(sd0, sd0, sd1, sd1) != 0.0)) {   // |step|^2 == 0: a sum of non-negative terms is zero exactly when every term is
                 done = true;
             } else if (ft <= f + p.c1 * gs) {
                 const double yd0 = has0 ? -gr0 - g0 : 0.0, yd1 = has1 ? -gr1 - g1 : 0.0;
