@@ -498,32 +498,43 @@ __device__ __forceinline__ double small_factor_inverse(double* As, double* Ts, c
 template <class Side = NoIdleWork>
 __device__ __forceinline__ void small_alpha(double* As, int N, double lg, double& ld, double& gb, double& quad, Side&& side = Side{}) {
     const int tid = threadIdx.x;
+    // N <= 64: two threads per row (waves 0 and 1), each with one half of the columns -- one wave alone took ~2000 cycles for its
+    // 8-column trips; the halves are added as p0 + p1
+    const bool split = N <= 64;
     if (tid >= 128) side();
     else {
-        // eight LDS operand pairs in flight, then their fused multiply-adds in column order: the same sum as the plain loop (a
-        // loop of dependent load -> fma trips ran at ~150 ns per column on the otherwise idle CU).  Columns N .. 8 ceil(N / 8) - 1
-        // exist in the image (identity padding, inside the 16-aligned block) and meet y = 0 there.
+        // eight LDS operand pairs in flight, then their fused multiply-adds in column order (a loop of dependent load -> fma trips
+        // ran at ~150 ns per column on the otherwise idle CU).  Columns N .. 8 ceil(N / 8) - 1 exist in the image (identity padding,
+        // inside the 16-aligned block) and meet y = 0 there.
+        const int i = split ? (tid & 63) : tid, part = split ? (tid >> 6) : 0;
+        const int n8 = (N + 7) >> 3, h8 = split ? (n8 + 1) >> 1 : n8;
         double s = 0.0;
-        if (tid < N) {
-            for (int j0 = 0; j0 < N; j0 += 8) {
+        if (i < N) {
+            for (int j0 = 8 * part * h8; j0 < 8 * min(n8, (part + 1) * h8); j0 += 8) {
                 double av[8], yv[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    av[u] = As[tid + (j0 + u) * DL];
+                    av[u] = As[i + (j0 + u) * DL];
                     yv[u] = small_scratch(As, SC_Y + j0 + u);
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) s = fma(av[u], yv[u], s);
             }
         }
-        small_scratch(As, SC_ALPHA + tid) = s;
+        small_scratch(As, (part ? SC_GZ : SC_ALPHA) + i) = s;   // the second halves: the optimiser-gradient slots (dead between evaluations)
     }
     __syncthreads();
     double s1 = 0.0, s2 = 0.0;
-    if (tid < N) {
-        const double al = small_scratch(As, SC_ALPHA + tid);
-        s1 = al * al - As[tid + tid * DL];
-        s2 = small_scratch(As, SC_Y + tid) * al;
+    if (tid < 128) {
+        double al = small_scratch(As, SC_ALPHA + tid);
+        if (split && tid < 64) {
+            al += small_scratch(As, SC_GZ + tid);
+            small_scratch(As, SC_ALPHA + tid) = al;   // read by others behind the barriers of the sums below
+        }
+        if (tid < N) {
+            s1 = al * al - As[tid + tid * DL];
+            s2 = small_scratch(As, SC_Y + tid) * al;
+        }
     }
     small_block_sum3(s1, s2, lg, As);
     gb = 0.5 * s1;

@@ -36,7 +36,10 @@ template <int STAGE, int R, bool SOLVE, bool COOP = false>
 __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* smem = reinterpret_cast<double*>(smem_raw);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the wave index as a SCALAR: everything derived from it (the wave's LDS arrays, the chain a wave takes in the cooperative form, its
+    // exchange slots) is then addressed with scalar arithmetic -- left in a vector register, every term of the cooperative chains
+    // carried ~10 vector instructions of index arithmetic (v_min, v_mul_lo_u32, v_cmp, v_cndmask) for one multiply-add
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool tracing = p.trace != nullptr;
     const long long tr_begin = tracing ? wall_clock64() : 0;
