@@ -79,7 +79,11 @@ def test_device_btl_objective_and_gradient_vs_oracle(ctx, oracle, kernel, use_ma
 
 
 @pytest.mark.parametrize("kernel", [0, 1])
-@pytest.mark.parametrize("M,D", [(30, 4), (60, 32), (91, 32), (64, 100), (112, 5), (100, 16), (16, 128), (33, 1)])
+# (63 .. 65, 128: the element slots of the kernel-function / gradient-weight passes fill the eight register slots exactly, spill one
+# element into the pair scratch, and (N = 128) fill the whole LDS image so that the pair scratch is global memory; odd N: the middle
+# column of the folded triangle pairs with itself; 1, 2: degenerate triangles)
+@pytest.mark.parametrize("M,D", [(30, 4), (60, 32), (91, 32), (64, 100), (112, 5), (100, 16), (16, 128), (33, 1), (63, 7), (64, 32), (65, 32),
+                                 (128, 4), (127, 16), (2, 3), (1, 2)])
 def test_matrix_core_form_and_direct_difference_form_agree(ctx, oracle, kernel, M, D):
     """Round 5: when the centred design matrix fits beside the N x N image in LDS, the one-workgroup kernels build the Gram matrix
     and the length-scale gradient on the matrix cores (norm expansion, Y = G X); otherwise -- and with SLS_SMALL_XLDS=0 -- they form
