@@ -391,24 +391,19 @@ __device__ __forceinline__ double small_build_factor(double* As, double* Ts, con
 
 // The strictly-lower tiles of the leading nb16 blocks copied into their mirror positions, one tile per wave and trip.  Each 16-lane
 // group walks a wrapped diagonal of the tile (column fl, row fl + fk + 4 q), so both the row-major reads and the column-major writes
-// touch 16 different banks.  DIAG: the strictly-lower halves of the diagonal tiles as well (a tile's reads precede its writes, and
-// the halves are disjoint).  The caller's barriers order the pass against its neighbours.
-template <bool DIAG>
+// touch 16 different banks.  The caller's barriers order the pass against its neighbours.
 __device__ __forceinline__ void small_mirror_lower(double* As, int nb16) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fl = lane & 15, fk = lane >> 4;
     int t = 0;
-    for (int i = DIAG ? 0 : 1; i < nb16; ++i)
-        for (int j = 0; j < (DIAG ? i + 1 : i); ++j, ++t) {
+    for (int i = 1; i < nb16; ++i)
+        for (int j = 0; j < i; ++j, ++t) {
             if ((t & 3) != wave) continue;
             double v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = As[(16 * j + fl) * DL + 16 * i + ((fl + fk + 4 * q) & 15)];   // (row 16i + r, col 16j + fl)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = (fl + fk + 4 * q) & 15;
-                if (!DIAG || i != j || r > fl) As[(16 * i + r) * DL + 16 * j + fl] = v[q];                      // (row 16j + fl, col 16i + r)
-            }
+            for (int q = 0; q < 4; ++q) As[(16 * i + ((fl + fk + 4 * q) & 15)) * DL + 16 * j + fl] = v[q];   // (row 16j + fl, col 16i + r)
         }
 }
 
@@ -474,7 +469,7 @@ __device__ __forceinline__ void small_inverse_in_place(double* As, double* Ts, i
     __syncthreads();
     if (stp) stp->mark(17);
     // mirror the strictly-lower tiles into the upper triangle (L^-T is no longer needed): K^-1 becomes a full symmetric image
-    small_mirror_lower<false>(As, nb16);
+    small_mirror_lower(As, nb16);
     __syncthreads();
 }
 
