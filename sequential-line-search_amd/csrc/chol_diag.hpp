@@ -90,7 +90,6 @@ __device__ __forceinline__ void diag16_dealt(double* As, double* Tk, int c0, int
     const int row = lane & 15, g = lane >> 4;
     double cur[4], sl[4], bq[4];
     double own_inv = 1.0;
-    int bad = 16;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         cur[r] = As[c0 + row + (c0 + r) * DL];
@@ -103,7 +102,6 @@ __device__ __forceinline__ void diag16_dealt(double* As, double* Tk, int c0, int
         for (int c = 0; c < 4; ++c) {
             const int k = 4 * G + c;
             const double d = bcast(cur[c], k);              // the pivot
-            bad = (!(d > 0.0) && bad == 16) ? k : bad;
             const double inv = rsqrt_nr(d);
             const double lik = cur[c] * inv;                // L[row][k] (rows < k: unused values)
             cur[c] = lik;
@@ -132,7 +130,15 @@ __device__ __forceinline__ void diag16_dealt(double* As, double* Tk, int c0, int
             for (int c = 0; c < 4; ++c) cur[c] = As[c0 + row + (c0 + 4 * (G + 1) + c) * DL];
         }
     }
-    if (bad < 16 && lane == 0 && info) atomicCAS(info, 0, global_off + c0 + bad + 1);
+    // The failure report is taken off the pivot chain (the wave is alone on its SIMD: every instruction there is paid in full --
+    // three per pivot for a flag that is almost never set): a pivot that is not positive makes its own L_kk and everything behind
+    // it NaN (rsq of a non-positive number times that number), so the first row whose L_rr, read back from the finished tile, is
+    // not positive IS the first failed pivot.  (1 / L_rr for the inverse stays the chain's own 1 / sqrt(d): taking it from the tile
+    // as well changed last bits that the ill-conditioned sigma-gradient cases of the test-suite amplify to their tolerance.)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const double lrr = As[c0 + row + (c0 + row) * DL];
+    const unsigned long long failed = __ballot(!(lrr > 0.0)) & 0xffffull;   // lanes 0 .. 15: rows 0 .. 15
+    if (failed && lane == 0 && info) atomicCAS(info, 0, global_off + c0 + (__ffsll((long long)failed) - 1) + 1);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int col = 4 * r + g;
