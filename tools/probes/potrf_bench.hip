@@ -176,8 +176,9 @@ int main(int argc, char** argv) {
                     if (rep > 0 && ms < best) best = ms;
                 }
                 int inf2[2] = {0, 0}; hipMemcpy(inf2, info, 8, hipMemcpyDeviceToHost);
-                printf("N=%5d %-34s %8.3f ms  info=%d abort=%d applicable=%d\n", Np, fused ? "potri fused single launch" : "potrf + trtri + lauum", best,
-                       inf2[0], inf2[1], (int)ok);
+                if (!ok) printf("N=%5d %-34s not applicable at this size (the fused form serves N <= 4096)\n", Np, fused ? "potri fused single launch" : "potrf + trtri + lauum");
+                else printf("N=%5d %-34s %8.3f ms  info=%d abort=%d applicable=%d\n", Np, fused ? "potri fused single launch" : "potrf + trtri + lauum", best,
+                            inf2[0], inf2[1], (int)ok);
                 return ok;
             };
             timeit(false, X1, U1, K1);
