@@ -130,7 +130,7 @@ __device__ __forceinline__ void small_kern(double a, double q, double& k, double
 // matrix and the length-scale gradient run on the matrix cores in the forms of the tiled pipeline (kernels_gram.hip,
 // kernels_map.hip):
 //     q_ij = |x~_i|^2 + |x~_j|^2 - 2 x~_i . x~_j,   x~ = (x - 0.5) / l      (one operand fragment scaled by 1 / l_d^2 on the fly)
-//     dL/dl_p = (2 / l_p) sum_j x~_jp (x~_jp s_j - Y_jp),   Y = G X~,  s = G 1,  G = 1/2 W o C  (zero diagonal)
+//     dL/dl_p = (2 / l_p) sum_j [x~_jp^2 r_j + (Gl X~^2)_jp - 2 x~_jp (Gl X~)_jp],   Gl = strictly-lower 1/2 W o C,  r = Gl 1  (small_grad)
 // Layout: point i, dimension d at offset d + i Dp of the free area, Dp = 16 ceil(D / 16) + 1, zero padded to Nb points and Dp - 1
 // dimensions: both fragment shapes (16 lanes over points, stride Dp odd; 16 lanes over dimensions, contiguous) are conflict free.
 // C3's shapes (N <= 96 at D = 32) always fit.  Otherwise the differences are formed directly: the Gram pass reads the transposed
@@ -541,8 +541,8 @@ __device__ __forceinline__ void small_alpha(double* As, int N, double lg, double
 // the (D + 1) N x N tensor of src/regressor.cpp:110-134):
 //   returns  sa = sum W.*K_f;  leaves  gl[d] = (1 / l_d) sum_{i>j} W_ij c_ij ((x_id - x_jd) / l_d)^2  in the scratch (SC_GL + d), d < D <= 128.
 // (1) One pair per slot, the slots of the kernel-function pass (same thread, pair values from *pairs / the pair scratch): w, sa, and
-// G_ij = 1/2 w c_ij over K^-1 in the lower triangle; then the mirror pass: G becomes a full symmetric image with zero diagonal
-// (nothing reads K^-1 after small_alpha).  (2) The contraction: on the matrix cores (points staged in LDS) or with lanes over the
+// G_ij = 1/2 w c_ij over K^-1 in the lower triangle, zeros on its diagonal (nothing reads K^-1 after small_alpha; both contractions
+// read the lower triangle only).  (2) The contraction: on the matrix cores (points staged in LDS) or with lanes over the
 // DIMENSIONS: a wave takes whole rows i (dealt 0 1 2 3 3 2 1 0 over the waves), 64 / LP pairs of a row per step with
 // LP = min(64, 2^ceil(log2 D)) lanes each (two dimensions per lane for D > 64), four steps' loads in flight; the point coordinates
 // come from the D x N original (a pair's D values are contiguous), G from LDS.  The per-wave partial sums are added over the lanes of
