@@ -332,6 +332,52 @@ __device__ __forceinline__ double small_build_factor(double* As, double* Ts, con
                 skip(4);
             }
         };
+        if (nb16 <= 4) {
+            // N <= 64 (at most ten tiles, three per wave): the wave's tiles t = wave, wave + 4, wave + 8 advance TOGETHER through the
+            // dimensions -- straight-line code per 16 dimensions (the 1 / l fragment once, eight reads and four products per tile on
+            // independent accumulators), no step bookkeeping between the products.  Tile slots beyond the last tile repeat tile 0 and
+            // are not stored.  (The generic stepper below spent ~1200 cycles per step of four products, 800 of them on its own
+            // scalar and address arithmetic, each in full on the one wave of its SIMD.)
+            const int ntile = nb16 * (nb16 + 1) / 2;
+            int ti3[3], tj3[3];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                int rem = wave + 4 * m < ntile ? wave + 4 * m : 0, j = 0;
+                while (rem >= nb16 - j) { rem -= nb16 - j; ++j; }
+                tj3[m] = j;
+                ti3[m] = j + rem;
+            }
+            d4_t acc3[3] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+            for (int d0 = 0; d0 < Dk; d0 += 16) {
+                double il2[4], a3[3][4], b3[3][4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int d = d0 + 4 * kk + fk;
+                    il2[kk] = small_scratch(As, SC_INVL + d);   // zeros beyond D
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+                        a3[m][kk] = xc(16 * ti3[m] + fl, d);
+                        b3[m][kk] = xc(16 * tj3[m] + fl, d);
+                    }
+                }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) il2[kk] *= il2[kk];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) acc3[m] = mfma16(b3[m][kk], a3[m][kk] * il2[kk], acc3[m]);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                if (wave + 4 * m >= ntile) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    As[16 * ti3[m] + fl + (16 * tj3[m] + fk + 4 * r) * DL] = acc3[m][r];
+                    if (ti3[m] == tj3[m] && fl == fk + 4 * r) small_scratch(As, SC_NX + 16 * ti3[m] + fl) = acc3[m][r];
+                }
+            }
+        } else {
         It it0{0, 0, 0, nb16, Dk, false};
         if (wave) it0.skip(wave);
         d4_t acc = {0.0, 0.0, 0.0, 0.0};
@@ -358,6 +404,7 @@ __device__ __forceinline__ double small_build_factor(double* As, double* Ts, con
                     acc[r] = 0.0;
                 }
             });
+        }
         __syncthreads();
         if (st.on) {   // probe: pass (1) (slot 23), counted inside the Gram slot 8 as well
             const long long t_now = wall_clock64();
@@ -438,10 +485,10 @@ __device__ __forceinline__ void small_inverse_in_place(double* As, double* Ts, i
                 skip(4);
             }
         };
+        constexpr int TS = 128 * DL;   // Ts = As + TS
         It it0{0, 0, 0, nb16, false};
         if (wave) it0.skip(wave);
         d4_t c = {0.0, 0.0, 0.0, 0.0};
-        constexpr int TS = 128 * DL;   // Ts = As + TS
         small_mfma_steps(
             it0,
             [&](const It& q, SmallFrag& f) {
@@ -663,6 +710,25 @@ __device__ __forceinline__ double small_grad(double* As, const SmallPts& pts, co
                 odd = !odd;
             }
         };
+        // a finished unit: x^2 r - 2 x Y + Z summed over its 16 rows j, into the wave's partial array
+        auto finish = [&](int tj, int tp, d4_t& ay, d4_t& az) {
+            const int j = 16 * tj + fl;
+            double rj = small_scratch(As, SC_GZ + j) + small_scratch(As, SC_GZ + (1 << shift) + j);
+            if (parts == 4) rj += small_scratch(As, SC_GZ + 128 + j) + small_scratch(As, SC_GZ + 192 + j);
+            double v[4];   // the four row sums first (independent: they interleave), then the four updates
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double xv = xc(j, 16 * tp + fk + 4 * r);
+                v[r] = row_sum(fma(xv, fma(xv, rj, -2.0 * ay[r]), az[r]));
+                ay[r] = 0.0;
+                az[r] = 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int p = 16 * tp + fk + 4 * r;
+                if (fl == 0 && p < D) small_scratch(As, SC_BTL + wave * NLL_SMALL_MAX_D + p) += v[r];
+            }
+        };
         It it0{nb16 - 1, 0, 0, (pts.Dp - 1) >> 4, wave, false, false};
         if (wave) it0.skip(wave);
         d4_t accy = {0.0, 0.0, 0.0, 0.0}, accz = {0.0, 0.0, 0.0, 0.0};
@@ -684,20 +750,7 @@ __device__ __forceinline__ double small_grad(double* As, const SmallPts& pts, co
                     accz = mfma16(f.b[kk] * f.b[kk], g, accz);
                 }
             },
-            [&](const It& q) {
-                const int j = 16 * q.tj + fl;
-                double rj = small_scratch(As, SC_GZ + j) + small_scratch(As, SC_GZ + (1 << shift) + j);
-                if (parts == 4) rj += small_scratch(As, SC_GZ + 128 + j) + small_scratch(As, SC_GZ + 192 + j);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double xv = xc(j, 16 * q.tp + fk + 4 * r);
-                    const double v = row_sum(fma(xv, fma(xv, rj, -2.0 * accy[r]), accz[r]));
-                    const int p = 16 * q.tp + fk + 4 * r;
-                    if (fl == 0 && p < D) small_scratch(As, SC_BTL + wave * NLL_SMALL_MAX_D + p) += v;
-                    accy[r] = 0.0;
-                    accz[r] = 0.0;
-                }
-            });
+            [&](const It& q) { finish(q.tj, q.tp, accy, accz); });
         st.mark(19);
         __syncthreads();
         st.mark(20);
