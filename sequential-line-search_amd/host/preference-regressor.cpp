@@ -1,4 +1,5 @@
 // PreferenceRegressor over the C ABI (reference: src/preference-regressor.cpp).
+#include <chrono>
 #include <cmath>
 #include <fstream>
 #include <sequential-line-search/preference-regressor.hpp>
@@ -43,13 +44,17 @@ namespace sequential_line_search
     {
         if (X.cols() == 0 || D.size() == 0) return;
 
+        static const bool timing = std::getenv("SLS_HOST_TIMING") != nullptr;   // once per process; stderr: where the constructor's time goes
+        const auto        t0     = std::chrono::steady_clock::now();
         PerformMapEstimation(num_map_estimation_iters);
+        const auto t1 = std::chrono::steady_clock::now();
 
         // final K, its Cholesky factor and the predictive state live on the device; the public members are copies
         m_handle = std::make_shared<device::GpHandle>(m_X, m_y, m_kernel_hyperparams, m_noise_hyperparam, KernelId(m_kernel_type));
         // PredictSigma / PredictSigmaDerivative of this class solve with the Cholesky factor (:299-313, :323-330); the explicit
         // inverse is GaussianProcessRegressor's formula
         device::Check(sls_gp_set_sigma_mode(m_handle->h, SLS_SIGMA_CHOLESKY_SOLVE), "sls_gp_set_sigma_mode");
+        const auto t2 = std::chrono::steady_clock::now();
         const long M = m_X.cols();
         m_K          = MatrixXd(M, M);
         MatrixXd L(M, M);
@@ -60,6 +65,12 @@ namespace sequential_line_search
 #else
         m_K_llt = Eigen::LLT<MatrixXd>(m_K);
 #endif
+        if (timing)
+        {
+            const auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            std::fprintf(stderr, "  PreferenceRegressor: MAP estimation %.3f ms, predictor handle %.3f ms, K and L copies %.3f ms\n", ms(t0, t1), ms(t1, t2),
+                         ms(t2, std::chrono::steady_clock::now()));
+        }
     }
 
     sls_gp* PreferenceRegressor::GetDeviceHandle() const { return m_handle ? m_handle->h : nullptr; }
