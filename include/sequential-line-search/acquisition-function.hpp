@@ -36,6 +36,15 @@ namespace sequential_line_search
         void                 SetGlobalSearchStrategy(GlobalSearchStrategy strategy);
         GlobalSearchStrategy GetGlobalSearchStrategy();
 
+        /// Relative stopping tolerances of the local (L-BFGS) searches.  Every search of the reference goes through
+        /// nloptutil::solve, whose defaults are relative_func_tolerance = relative_param_tolerance = 1e-6 (NLopt's ftol_rel /
+        /// xtol_rel): a local search ends with the first accepted step that changes the value, or every
+        /// coordinate, by less than that fraction -- long before the evaluation cap on most of C3's acquisition landscapes (the
+        /// cap only polishes the 7th to 10th digit).  Initial values 1e-6 / 1e-6; SLS_LOCAL_SEARCH_TOL=<v> sets both (0 = off: run
+        /// to the cap, the behaviour before round 5's last revision).
+        void SetLocalSearchTolerances(double relative_func_tolerance, double relative_param_tolerance);
+        void GetLocalSearchTolerances(double* relative_func_tolerance, double* relative_param_tolerance);
+
         /// Acquisition value at x (0 if the regressor holds no data).  `..._hyperparam` is the GP-UCB trade-off weight
         /// (ignored for EI).
         double CalcAcquisitionValue(const Regressor& regressor, const Eigen::VectorXd& x, const AcquisitionFuncType func_type,

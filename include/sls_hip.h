@@ -141,6 +141,14 @@ typedef struct sls_lbfgs_opts {
     double shrink;      /* backtracking factor, default 0.5 */
     double gtol;        /* projected-gradient inf-norm stop, default 0 */
     int max_backtracks; /* default 20 */
+    /* NLopt's relative stopping tests (nlopt/src/util/stop.c, relstop), applied to every ACCEPTED step x -> x', f -> f'; 0 = off
+     * (the default of this ABI: a start then runs until it cannot move or reaches its cap).  The reference's searches go through
+     * nloptutil::solve, whose defaults are ftol_rel = xtol_rel = 1e-6: the host layer passes those.
+     *   ftol_rel: stop when |f' - f| < ftol_rel (|f'| + |f|) / 2 or f' == f
+     *   xtol_rel: stop when for every d  |x'_d - x_d| < xtol_rel (|x'_d| + |x_d|) / 2 or x'_d == x_d
+     * The accepted point is kept; the start leaves the batch. */
+    double ftol_rel;
+    double xtol_rel;
 } sls_lbfgs_opts;
 void sls_lbfgs_default_opts(sls_lbfgs_opts* o);
 int sls_acq_maximize(sls_gp* gp, int acq_type, double ucb_h, const double* starts, int S, int n_local,

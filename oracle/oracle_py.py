@@ -242,19 +242,25 @@ class Regressor:
         lib().slso_acq_eval_batch(self.h, _p(Xs), M, acq, C.c_double(ucb_h), _p(val), _p(grad) if want_grad else None)
         return (val, grad) if want_grad else val
 
-    def acq_maximize(self, starts, n_local, acq=ACQ_EI, ucb_h=1.0, n_threads=0, diag=False):
+    def acq_maximize(self, starts, n_local, acq=ACQ_EI, ucb_h=1.0, n_threads=0, diag=False, ftol_rel=0.0, xtol_rel=0.0):
         """diag=True adds 'armijo_margin' / 'armijo_eval' (per start: the closest any Armijo test came to its threshold,
         relative, and the evaluation number) -- see slso_acq_maximize_diag."""
         starts = _f(starts)
         S = starts.shape[1]
         x_out, val = np.empty(self.D), C.c_double()
         x_stars, y_stars = np.empty((self.D, S), order="F"), np.empty(S)
+        opts = None
+        if ftol_rel or xtol_rel:
+            opts = LbfgsOpts()
+            lib().slso_lbfgs_default_opts(C.byref(opts))
+            opts.ftol_rel, opts.xtol_rel = float(ftol_rel), float(xtol_rel)
+            opts = C.byref(opts)
         if not diag:
-            idx = lib().slso_acq_maximize(self.h, acq, C.c_double(ucb_h), _p(starts), S, int(n_local), None, _p(x_out),
+            idx = lib().slso_acq_maximize(self.h, acq, C.c_double(ucb_h), _p(starts), S, int(n_local), opts, _p(x_out),
                                           C.byref(val), _p(x_stars), _p(y_stars), int(n_threads))
             return dict(index=idx, x=x_out, value=val.value, x_stars=x_stars, y_stars=y_stars)
         margin, ev = np.empty(S), np.empty(S, dtype=np.int32)
-        idx = lib().slso_acq_maximize_diag(self.h, acq, C.c_double(ucb_h), _p(starts), S, int(n_local), None, _p(x_out),
+        idx = lib().slso_acq_maximize_diag(self.h, acq, C.c_double(ucb_h), _p(starts), S, int(n_local), opts, _p(x_out),
                                            C.byref(val), _p(x_stars), _p(y_stars), int(n_threads), _p(margin),
                                            ev.ctypes.data_as(C.POINTER(C.c_int)))
         return dict(index=idx, x=x_out, value=val.value, x_stars=x_stars, y_stars=y_stars, armijo_margin=margin, armijo_eval=ev)
@@ -266,6 +272,11 @@ def gp_map_objective(ktype, X, y, x, want_grad=True, as_written=False):
     g = np.empty(D + 2) if want_grad else None
     v = lib().slso_gp_map_objective(ktype, _p(X), D, N, _p(y), _p(x), _p(g) if want_grad else None, int(as_written))
     return (v, g) if want_grad else v
+
+
+class LbfgsOpts(C.Structure):   # slso_lbfgs_opts
+    _fields_ = [("history", C.c_int), ("c1", C.c_double), ("shrink", C.c_double), ("gtol", C.c_double), ("max_backtracks", C.c_int),
+                ("ftol_rel", C.c_double), ("xtol_rel", C.c_double)]
 
 
 class PrefCfg(C.Structure):

@@ -593,7 +593,7 @@ void slso_acq_eval_batch(const slso_regressor* r, const double* Xs, int M, int a
 /* ------------------------------------------------------------------------- */
 
 void slso_lbfgs_default_opts(slso_lbfgs_opts* o) {
-    o->history = 6; o->c1 = 1e-4; o->shrink = 0.5; o->gtol = 0.0; o->max_backtracks = 20;
+    o->history = 6; o->c1 = 1e-4; o->shrink = 0.5; o->gtol = 0.0; o->max_backtracks = 20; o->ftol_rel = 0.0; o->xtol_rel = 0.0;
 }
 
 typedef struct {
@@ -733,6 +733,16 @@ static int acq_maximize_impl(const slso_regressor* r, int acq, double ucb_h, con
                     s->rho[idx] = 1.0 / sy;
                     s->hpos = (s->hpos + 1) % m;
                     if (s->hlen < m) s->hlen++;
+                }
+                /* NLopt's relative stopping tests on the accepted step */
+                if (o.ftol_rel > 0.0 && (fabs(ft - s->f) < o.ftol_rel * 0.5 * (fabs(ft) + fabs(s->f)) || ft == s->f)) s->done = 1;
+                if (o.xtol_rel > 0.0) {
+                    int moved = 0;
+                    for (int d = 0; d < D; ++d) {
+                        const double xo = s->x[d], xn = s->xt[d];
+                        if (!(fabs(xn - xo) < o.xtol_rel * 0.5 * (fabs(xn) + fabs(xo)) || xn == xo)) moved = 1;
+                    }
+                    if (!moved) s->done = 1;
                 }
                 for (int d = 0; d < D; ++d) { s->x[d] = s->xt[d]; s->g[d] = -grad[d + (long)i * D]; }
                 s->f = ft;

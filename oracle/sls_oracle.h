@@ -113,6 +113,10 @@ typedef struct slso_lbfgs_opts {
     double shrink;       /* backtracking factor, default 0.5 */
     double gtol;         /* projected-gradient inf-norm stop, default 0 (never) */
     int    max_backtracks; /* default 20 */
+    /* NLopt's relative stopping tests on every accepted step (nlopt/src/util/stop.c: relstop); 0 = off.  nloptutil::solve's
+     * defaults, which every search of the reference runs with, are 1e-6 for both. */
+    double ftol_rel;     /* |f' - f| < ftol_rel (|f'| + |f|) / 2 or f' == f */
+    double xtol_rel;     /* every d: |x'_d - x_d| < xtol_rel (|x'_d| + |x_d|) / 2 or x'_d == x_d */
 } slso_lbfgs_opts;
 void slso_lbfgs_default_opts(slso_lbfgs_opts* o);
 int  slso_acq_maximize(const slso_regressor* r, int acq, double ucb_h, const double* starts, int S, int n_local,

@@ -81,6 +81,12 @@ PYBIND11_MODULE(pySequentialLineSearch, m)
         .value("ParallelMultiStart", GlobalSearchStrategy::ParallelMultiStart);
     m.def("set_global_search_strategy", &acquisition_func::SetGlobalSearchStrategy, "strategy"_a);
     m.def("get_global_search_strategy", &acquisition_func::GetGlobalSearchStrategy);
+    m.def("set_local_search_tolerances", &acquisition_func::SetLocalSearchTolerances, "relative_func_tolerance"_a, "relative_param_tolerance"_a);
+    m.def("get_local_search_tolerances", [] {
+        double f = 0.0, x = 0.0;
+        acquisition_func::GetLocalSearchTolerances(&f, &x);
+        return std::make_pair(f, x);
+    });
     m.def("set_devices", &device::SetDevices, "devices"_a);
     m.def("get_devices", [] { return device::Devices(); });
 

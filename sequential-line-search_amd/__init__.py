@@ -30,7 +30,7 @@ class SlsError(RuntimeError):
 
 class LbfgsOpts(C.Structure):
     _fields_ = [("history", C.c_int), ("c1", C.c_double), ("shrink", C.c_double), ("gtol", C.c_double),
-                ("max_backtracks", C.c_int)]
+                ("max_backtracks", C.c_int), ("ftol_rel", C.c_double), ("xtol_rel", C.c_double)]
 
 
 def lib():

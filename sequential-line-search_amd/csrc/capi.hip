@@ -1151,7 +1151,7 @@ extern "C" int sls_acq_eval(sls_gp* g, int acq_type, double ucb_h, const double*
 
 // ---- multi-start maximiser -------------------------------------------------------------------------------------
 extern "C" void sls_lbfgs_default_opts(sls_lbfgs_opts* o) {
-    o->history = 6; o->c1 = 1e-4; o->shrink = 0.5; o->gtol = 0.0; o->max_backtracks = 20;
+    o->history = 6; o->c1 = 1e-4; o->shrink = 0.5; o->gtol = 0.0; o->max_backtracks = 20; o->ftol_rel = 0.0; o->xtol_rel = 0.0;
 }
 
 static void ensure_lbfgs(sls_gp* g, int Sp, int m) {
@@ -1207,6 +1207,7 @@ static void maximize_impl(sls_gp* g, sls_gp* gs, int acq_type, double ucb_h, con
     st.Sh = g->lb_S.p; st.Yh = g->lb_Y.p; st.rho = g->lb_rho.p; st.f = g->lb_f.p; st.t = g->lb_t.p;
     st.hlen = g->lb_int; st.hpos = g->lb_int + Sp; st.nbt = g->lb_int + 2 * Sp; st.done = g->lb_int + 3 * Sp;
     st.c1 = o.c1; st.shrink = o.shrink; st.gtol = o.gtol; st.max_backtracks = o.max_backtracks;
+    st.ftol_rel = o.ftol_rel; st.xtol_rel = o.xtol_rel;
     // Small problems: one wavefront per start runs the whole search in a single launch (kernels_wave.hip).  The choice
     // depends only on the fitted state and the start count, so repeated / sharded calls take the same path.
     bool used_wave = false;
@@ -1219,6 +1220,7 @@ static void maximize_impl(sls_gp* g, sls_gp* gs, int acq_type, double ucb_h, con
             w.matern = g->kernel == SLS_KERNEL_ARD_MATERN52;
             w.a = g->a; w.mu_best = g->mu_best; w.ucb_h = ucb_h; w.c1 = o.c1; w.shrink = o.shrink; w.gtol = o.gtol;
             w.max_backtracks = o.max_backtracks;
+            w.ftol_rel = o.ftol_rel; w.xtol_rel = o.xtol_rel;
             w.XT = g->XT.p; w.inv_ell = g->inv_ell.p; w.Kinv = g->Kinv.p; w.alpha = g->alpha.p; w.starts = starts_dev;
             w.solve_sigma = g->sigma_mode == 1; w.Linv = g->Linv.p; w.U = g->U.p;
             w.x_out = st.x; w.f_out = st.f; w.ld = Sp;

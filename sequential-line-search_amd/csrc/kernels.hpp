@@ -192,6 +192,7 @@ struct LbfgsState {
     int *hlen, *hpos, *nbt, *done;    // [n]
     double c1, shrink, gtol;
     int max_backtracks;
+    double ftol_rel = 0.0, xtol_rel = 0.0;   // NLopt's relative stopping tests on accepted steps (sls_lbfgs_opts), 0 = off
     // Active set: this round evaluated `nlive` trial points; column j of (val, grad) belongs to start live[j]
     // (live == nullptr: identity, nlive == S).  ldv = leading dimension of grad.
     const int* live;
@@ -214,6 +215,16 @@ void launch_clamp_starts(hipStream_t s, const double* starts /*D x S col-major*/
 void launch_argmax_neg_gather(hipStream_t s, const double* f, int S, const double* x, long ldx, int D, double* best,
                               const unsigned long long* counter);
 
+// NLopt's relative stopping tests (nlopt/src/util/stop.c: relstop) as the maximisers apply them to an accepted step; tolerance 0 = off.
+//   lbfgs_f_stalled: |f' - f| < tol (|f'| + |f|) / 2 or f' == f
+//   lbfgs_x_moved:   1 when coordinate d still moved by more than its tolerance (summed over d: 0 = every coordinate stalled)
+__host__ __device__ inline bool lbfgs_f_stalled(double f_old, double f_new, double tol) {
+    return tol > 0.0 && (fabs(f_new - f_old) < tol * 0.5 * (fabs(f_new) + fabs(f_old)) || f_new == f_old);
+}
+__host__ __device__ inline double lbfgs_x_moved(double x_old, double x_new, double tol) {
+    return (fabs(x_new - x_old) < tol * 0.5 * (fabs(x_new) + fabs(x_old)) || x_new == x_old) ? 0.0 : 1.0;
+}
+
 // ---- kernels_wave.hip: one wavefront per start, whole L-BFGS in one launch (small problems) ----
 struct WaveArgs {
     int S, D, N, Np, m, n_local, acq, matern;
@@ -221,6 +232,7 @@ struct WaveArgs {
     int stage_kinv, stage_xt;             // filled by the launcher: K^-1 / XT copied into LDS behind the four waves' areas
     double a, mu_best, ucb_h, c1, shrink, gtol;
     int max_backtracks;
+    double ftol_rel = 0.0, xtol_rel = 0.0;   // as in LbfgsState
     const double *XT, *inv_ell, *Kinv, *alpha, *starts;   // XT [i + d*Np] scaled; starts D x S column-major (raw)
     // solve_sigma (handles of a PreferenceRegressor, sls_gp_set_sigma_mode): sigma^2 = a - |L^-1 k|^2 and w = L^-T (L^-1 k) as the
     // reference's k . LLT.solve(k) (src/preference-regressor.cpp:299-313,323-330) instead of the explicit K^-1 of

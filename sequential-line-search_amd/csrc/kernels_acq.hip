@@ -636,7 +636,7 @@ __global__ __launch_bounds__(64) void lbfgs_step_kernel(LbfgsState st, const dou
             return;
         }
         if (ft <= f_v + st.c1 * gs) {
-            double sy = 0.0, yy = 0.0;
+            double sy = 0.0, yy = 0.0, xmoved = 0.0;
             const int idx = hpos_v;
             double* __restrict__ Sh = ShA + (long)idx * D * ld;
             double* __restrict__ Yh = YhA + (long)idx * D * ld;
@@ -645,6 +645,7 @@ __global__ __launch_bounds__(64) void lbfgs_step_kernel(LbfgsState st, const dou
                 const double xtd = xt_[n + d * ld], gtd = -grad[j + d * ldv];
                 const double sd = xtd - x_[n + d * ld];
                 const double yd = gtd - g_[n + d * ld];
+                xmoved += lbfgs_x_moved(x_[n + d * ld], xtd, st.xtol_rel);
                 Sh[n + d * ld] = sd;
                 Yh[n + d * ld] = yd;
                 sy += sd * yd;
@@ -661,6 +662,7 @@ __global__ __launch_bounds__(64) void lbfgs_step_kernel(LbfgsState st, const dou
                 hpos_v = (idx + 1) % m;
                 if (hlen_v < m) hlen_v += 1;
             }
+            if (lbfgs_f_stalled(f_v, ft, st.ftol_rel) || (st.xtol_rel > 0.0 && gsum(xmoved) == 0.0)) done = true;   // NLopt's relative tests
             f_v = ft;
             need_dir = true;
         } else {
@@ -878,7 +880,7 @@ __global__ __launch_bounds__(64) void lbfgs_step_reg_kernel(LbfgsState st, const
             return;
         }
         if (ft <= f_v + st.c1 * gs) {
-            double sy = 0.0, yy = 0.0;
+            double sy = 0.0, yy = 0.0, xmoved = 0.0;
             const int idx = hpos_v;
 #pragma unroll
             for (int e = 0; e < DPL; ++e) {
@@ -887,6 +889,7 @@ __global__ __launch_bounds__(64) void lbfgs_step_reg_kernel(LbfgsState st, const
                     const double xtd = xtr[e], gtd = -grad[j + d * ldv];
                     const double sd = xtd - xr[e];
                     const double yd = gtd - gr[e];
+                    xmoved += lbfgs_x_moved(xr[e], xtd, st.xtol_rel);
                     sn[e] = sd;
                     yn[e] = yd;
                     sy += sd * yd;
@@ -915,6 +918,7 @@ __global__ __launch_bounds__(64) void lbfgs_step_reg_kernel(LbfgsState st, const
                 hpos_v = (idx + 1) % m;
                 if (hlen_v < m) hlen_v += 1;
             }
+            if (lbfgs_f_stalled(f_v, ft, st.ftol_rel) || (st.xtol_rel > 0.0 && gsum(xmoved) == 0.0)) done = true;   // NLopt's relative tests
             f_v = ft;
             need_dir = true;
         } else {

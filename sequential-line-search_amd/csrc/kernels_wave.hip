@@ -559,6 +559,10 @@ __global__ __launch_bounds__(256) void maximize_wave_kernel(WaveArgs p) {
                     hpos = hpos + 1 == m ? 0 : hpos + 1;
                     if (hlen < m) hlen += 1;
                 }
+                // NLopt's relative stopping tests on the accepted step (sls_lbfgs_opts; 0 = off)
+                if (lbfgs_f_stalled(f, ft, p.ftol_rel) ||
+                    (p.xtol_rel > 0.0 && !__any((has0 && lbfgs_x_moved(x0, xt0, p.xtol_rel) != 0.0) || (has1 && lbfgs_x_moved(x1, xt1, p.xtol_rel) != 0.0))))
+                    done = true;
                 x0 = xt0; x1 = xt1;
                 g0 = -gr0; g1 = -gr1;
                 f = ft;

@@ -87,6 +87,40 @@ namespace sequential_line_search
         }
     } // namespace
 
+    namespace
+    {
+        // nloptutil::solve's default tolerances (see the header); the environment variable is read once per process
+        std::atomic<double> g_ftol_rel{-1.0}, g_xtol_rel{-1.0};
+        void                InitTolerances()
+        {
+            if (g_ftol_rel.load() >= 0.0) return;
+            const char*  e = std::getenv("SLS_LOCAL_SEARCH_TOL");
+            const double v = e ? std::max(0.0, std::atof(e)) : 1e-6;
+            g_xtol_rel.store(v);
+            g_ftol_rel.store(v);
+        }
+        sls_lbfgs_opts LocalSearchOpts()
+        {
+            sls_lbfgs_opts o;
+            sls_lbfgs_default_opts(&o);
+            InitTolerances();
+            o.ftol_rel = g_ftol_rel.load();
+            o.xtol_rel = g_xtol_rel.load();
+            return o;
+        }
+    } // namespace
+    void acquisition_func::SetLocalSearchTolerances(double f, double x)
+    {
+        g_xtol_rel.store(std::max(0.0, x));
+        g_ftol_rel.store(std::max(0.0, f));
+    }
+    void acquisition_func::GetLocalSearchTolerances(double* f, double* x)
+    {
+        InitTolerances();
+        if (f) *f = g_ftol_rel.load();
+        if (x) *x = g_xtol_rel.load();
+    }
+
     void acquisition_func::SetGlobalSearchStrategy(GlobalSearchStrategy strategy) { g_strategy.store(static_cast<int>(strategy)); }
     GlobalSearchStrategy acquisition_func::GetGlobalSearchStrategy()
     {
@@ -153,17 +187,18 @@ namespace sequential_line_search
         // the fitted state, and the per-device winners meet in ONE ncclAllGather.  The replicas belong to the regressor's device
         // handle: they are built on the first call (the shard on the primary's device IS the primary: no second fit there) and
         // reused by every later one.
+        const sls_lbfgs_opts lopts = LocalSearchOpts();   // nloptutil::solve's relative tolerances
         if (std::shared_ptr<device::MultiGpHandle> replicas = device::ReplicasFor(RequireHandle(regressor), regressor.GetLargeX().cols()))
         {
             device::Check(sls_multi_acq_maximize(replicas->h, AcqId(func_type), hyperparam, starts.data(),
-                                                 static_cast<int>(starts.cols()), static_cast<int>(num_local_search_iters), nullptr,
+                                                 static_cast<int>(starts.cols()), static_cast<int>(num_local_search_iters), &lopts,
                                                  x.data(), &v, &idx, nullptr),
                           "sls_multi_acq_maximize");
             if (value) *value = v;
             return x;
         }
         device::Check(sls_acq_maximize(RequireHandle(regressor), AcqId(func_type), hyperparam, starts.data(),
-                                       static_cast<int>(starts.cols()), static_cast<int>(num_local_search_iters), nullptr, 0, x.data(),
+                                       static_cast<int>(starts.cols()), static_cast<int>(num_local_search_iters), &lopts, 0, x.data(),
                                        &v, &idx, nullptr, nullptr),
                       "sls_acq_maximize");
         if (value) *value = v;
@@ -220,7 +255,8 @@ namespace sequential_line_search
         VectorXd x(num_dim);
         double   v   = 0.0;
         long     idx = 0;
-        device::Check(sls_acq_maximize(h, AcqId(func_type), hyperparam, start.data(), 1, static_cast<int>(num_local_search_iters), nullptr,
+        const sls_lbfgs_opts lopts = LocalSearchOpts();   // nloptutil::solve's relative tolerances
+        device::Check(sls_acq_maximize(h, AcqId(func_type), hyperparam, start.data(), 1, static_cast<int>(num_local_search_iters), &lopts,
                                        0, x.data(), &v, &idx, nullptr, nullptr),
                       "sls_acq_maximize");
         if (value) *value = v;
@@ -284,9 +320,10 @@ namespace sequential_line_search
             VectorXd x_star(num_dim);
             double   v   = 0.0;
             long     idx = 0;
+            const sls_lbfgs_opts lopts = LocalSearchOpts();   // nloptutil::solve's relative tolerances
             device::Check(sls_acq_maximize_pair(mean_handle, temp->GetDeviceHandle(), AcqId(func_type), hyperparam, starts.data(),
                                                 static_cast<int>(starts.cols()),
-                                                std::max(1, static_cast<int>(num_local_search_iters)), nullptr, x_star.data(), &v, &idx),
+                                                std::max(1, static_cast<int>(num_local_search_iters)), &lopts, x_star.data(), &v, &idx),
                           "sls_acq_maximize_pair");
             points.push_back(x_star);
             if (points.size() != num_points)
