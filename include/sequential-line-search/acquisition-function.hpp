@@ -41,7 +41,8 @@ namespace sequential_line_search
         /// xtol_rel): a local search ends with the first accepted step that changes the value, or every
         /// coordinate, by less than that fraction -- long before the evaluation cap on most of C3's acquisition landscapes (the
         /// cap only polishes the 7th to 10th digit).  Initial values 1e-6 / 1e-6; SLS_LOCAL_SEARCH_TOL=<v> sets both (0 = off: run
-        /// to the cap, the behaviour before round 5's last revision).
+        /// to the cap, the behaviour before round 5's last revision).  The MAP fits keep running to convergence or their caps
+        /// (their optima are this layer's parity anchors; SLS_MAP_FIT_TOL opts in, see host/device.hpp).
         void SetLocalSearchTolerances(double relative_func_tolerance, double relative_param_tolerance);
         void GetLocalSearchTolerances(double* relative_func_tolerance, double* relative_param_tolerance);
 

@@ -234,6 +234,12 @@ int sls_comm_allgather_best(sls_comm* c, double value, long index, const double*
 typedef struct sls_nll sls_nll;
 int sls_nll_create(sls_ctx* ctx, const double* X, int D, int N, int kernel, sls_nll** out);
 int sls_nll_destroy(sls_nll* h);
+/* NLopt's relative stopping tests for the MAP fits of this handle (sls_gp_map_fit, sls_pref_map_fit): applied to every accepted step
+ * exactly as sls_lbfgs_opts.ftol_rel / xtol_rel are in the acquisition maximiser (on the optimiser's own variables: the logarithms of
+ * the hyper-parameters).  0 = off, the default of a new handle; the reference's fits run through nloptutil::solve with 1e-6 / 1e-6
+ * (SURVEY.md Appendix A), which the host layer sets.  A GP fit reaches its optimum to machine precision within 20-40 evaluations
+ * and then backtracks for another 40-300 before it can no longer move; with the tests it ends there. */
+int sls_nll_set_tolerances(sls_nll* h, double ftol_rel, double xtol_rel);
 /* Core of both MAP objectives, for K_y = K_f(theta) + b I and a vector y (N):
  *   quad = y^T K_y^-1 y, logdet = log|K_y| (CalcLogDetOfSymmetricPositiveDefiniteMatrix), alpha = K_y^-1 y (may be NULL),
  *   grad_theta[p] = 1/2 alpha^T (dK/dtheta_p) alpha - 1/2 tr(K_y^-1 dK/dtheta_p), p = 0..D  (may be NULL)

@@ -50,7 +50,7 @@ EXPORTS = [
     "sls_ctx_set_candidate_chunk", "sls_gram", "sls_gram_cross", "sls_potrf", "sls_potrs", "sls_potri", "sls_gp_create",
     "sls_gp_destroy", "sls_gp_get_matrix", "sls_gp_get_summary", "sls_gp_predict", "sls_gp_predict_grad", "sls_acq_eval",
     "sls_lbfgs_default_opts", "sls_acq_maximize", "sls_acq_maximize_dev", "sls_gp_refit_dev", "sls_prof_enable",
-    "sls_prof_reset", "sls_prof_get", "sls_nll_create", "sls_nll_destroy", "sls_nll_eval", "sls_gp_nll_grad", "sls_gp_nll_batch", "sls_multi_nll_create", "sls_multi_nll_destroy",
+    "sls_prof_reset", "sls_prof_get", "sls_nll_create", "sls_nll_destroy", "sls_nll_set_tolerances", "sls_nll_eval", "sls_gp_nll_grad", "sls_gp_nll_batch", "sls_multi_nll_create", "sls_multi_nll_destroy",
     "sls_multi_gp_nll_batch",
     "sls_pref_objective", "sls_pref_map_fit", "sls_gp_map_fit", "sls_gp_set_sigma_mode", "sls_acq_eval_pair", "sls_acq_maximize_pair", "sls_gp_append_point", "sls_acq_last_stats",
     "sls_multi_create", "sls_multi_destroy", "sls_multi_size", "sls_multi_exchange", "sls_multi_ctx", "sls_multi_gp_create", "sls_multi_gp_create_from",
@@ -344,6 +344,10 @@ class Nll:
                                      len(prefs), _p(x), C.byref(cfg), C.byref(val), _p(g) if want_grad else None))
         return (val.value, g) if want_grad else val.value
 
+
+    def set_tolerances(self, ftol_rel, xtol_rel):
+        """NLopt's relative stopping tests for this handle's MAP fits (sls_nll_set_tolerances); 0 = off (the default)."""
+        _ck(lib().sls_nll_set_tolerances(self.h, C.c_double(ftol_rel), C.c_double(xtol_rel)))
 
     def pref_map_fit(self, prefs, z0, lower, upper, max_evals, evals_per_launch=0, use_map=False, a=0.5, r=0.5, b=0.005,
                      prior_var=0.25, btl_scale=0.01, noiseless=False):

@@ -30,6 +30,7 @@ struct sls_nll {
     double cached_b = -1.0;
     bool have_factor = false;
     double logdet = 0.0;
+    double ftol_rel = 0.0, xtol_rel = 0.0;   // sls_nll_set_tolerances
     // results of the one-workgroup evaluation (kernels_small.hip): page-locked host memory the kernel writes DIRECTLY (mapped),
     // read after the stream synchronisation -- no device-to-host copy call per evaluation
     double* small_host = nullptr;      // host address
@@ -97,6 +98,14 @@ extern "C" int sls_nll_create(sls_ctx* ctx, const double* X, int D, int N, int k
     slsk::ctx_retain(ctx);
     *out = h.release();
     SLS_CATCH
+}
+
+extern "C" int sls_nll_set_tolerances(sls_nll* h, double ftol_rel, double xtol_rel) {
+    if (!h) return SLS_ERR_INVALID;
+    std::unique_lock<std::recursive_mutex> lock_(h->ctx->mtx);
+    h->ftol_rel = ftol_rel > 0.0 ? ftol_rel : 0.0;
+    h->xtol_rel = xtol_rel > 0.0 ? xtol_rel : 0.0;
+    return SLS_OK;
 }
 
 extern "C" int sls_nll_destroy(sls_nll* h) {
@@ -599,6 +608,8 @@ static void map_opt_run(sls_nll* h, const MapOptProblem& pb, const double* z0, c
     a.btl_scratch = h->mo_btl.p;
     a.z0 = h->mo_vec.p; a.lower = h->mo_vec.p + n; a.upper = h->mo_vec.p + 2 * n;
     a.max_evals = eval_only ? 1 : max_evals;
+    a.ftol_rel = h->ftol_rel;
+    a.xtol_rel = h->xtol_rel;
     a.eval_only = eval_only ? 1 : 0;
     a.state = h->mo_state.p;
     a.out = h->mo_out_dev;

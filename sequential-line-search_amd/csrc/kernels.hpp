@@ -131,6 +131,7 @@ struct MapOptArgs {
     double* btl_scratch;               // flat_len doubles (device); used when flat_len > 640 (else the LDS scratch)
     const double *z0, *lower, *upper;  // device, n each
     int max_evals;            // cap on objective evaluations of the whole fit
+    double ftol_rel, xtol_rel;   // NLopt's relative stopping tests on accepted steps (sls_nll_set_tolerances), 0 = off
     int budget;               // evaluations performed by THIS launch (>= max_evals: the whole fit in one launch)
     int eval_only;            // 1: evaluate at z0, write value and gradient, stop
     int fresh;                // 1: start from z0; 0: continue from `state`

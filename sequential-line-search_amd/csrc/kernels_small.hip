@@ -1195,6 +1195,14 @@ __global__ __launch_bounds__(256) void map_opt_kernel(const MapOptArgs args) {
                     sy_last = sy;
                     yy_last = yy;
                 }
+                // NLopt's relative stopping tests on the accepted step (sls_nll_set_tolerances; 0 = off)
+                if (lbfgs_f_stalled(fx, ft, args.ftol_rel)) done = 1;
+                if (args.xtol_rel > 0.0) {
+                    bool moved = false;
+#pragma unroll
+                    for (int k = 0; k < KV; ++k) moved = moved || (lane + 64 * k < n && lbfgs_x_moved(x[k], xt[k], args.xtol_rel) != 0.0);
+                    if (!__any(moved)) done = 1;
+                }
 #pragma unroll
                 for (int k = 0; k < KV; ++k) { x[k] = xt[k]; g[k] = gt[k]; }
                 fx = ft;

@@ -89,37 +89,16 @@ namespace sequential_line_search
 
     namespace
     {
-        // nloptutil::solve's default tolerances (see the header); the environment variable is read once per process
-        std::atomic<double> g_ftol_rel{-1.0}, g_xtol_rel{-1.0};
-        void                InitTolerances()
-        {
-            if (g_ftol_rel.load() >= 0.0) return;
-            const char*  e = std::getenv("SLS_LOCAL_SEARCH_TOL");
-            const double v = e ? std::max(0.0, std::atof(e)) : 1e-6;
-            g_xtol_rel.store(v);
-            g_ftol_rel.store(v);
-        }
         sls_lbfgs_opts LocalSearchOpts()
         {
             sls_lbfgs_opts o;
             sls_lbfgs_default_opts(&o);
-            InitTolerances();
-            o.ftol_rel = g_ftol_rel.load();
-            o.xtol_rel = g_xtol_rel.load();
+            optim::SearchTolerances(&o.ftol_rel, &o.xtol_rel);   // nloptutil::solve's defaults unless changed
             return o;
         }
     } // namespace
-    void acquisition_func::SetLocalSearchTolerances(double f, double x)
-    {
-        g_xtol_rel.store(std::max(0.0, x));
-        g_ftol_rel.store(std::max(0.0, f));
-    }
-    void acquisition_func::GetLocalSearchTolerances(double* f, double* x)
-    {
-        InitTolerances();
-        if (f) *f = g_ftol_rel.load();
-        if (x) *x = g_xtol_rel.load();
-    }
+    void acquisition_func::SetLocalSearchTolerances(double f, double x) { optim::SetSearchTolerances(f, x); }
+    void acquisition_func::GetLocalSearchTolerances(double* f, double* x) { optim::SearchTolerances(f, x); }
 
     void acquisition_func::SetGlobalSearchStrategy(GlobalSearchStrategy strategy) { g_strategy.store(static_cast<int>(strategy)); }
     GlobalSearchStrategy acquisition_func::GetGlobalSearchStrategy()

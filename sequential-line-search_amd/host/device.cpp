@@ -1,5 +1,6 @@
 #include "device.hpp"
 
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <map>
@@ -173,9 +174,45 @@ namespace sequential_line_search
 
     namespace optim
     {
-        std::vector<double> MaximizeBounded(const Objective& f, std::vector<double> x, const std::vector<double>& lo,
-                                            const std::vector<double>& hi, int max_evals, double* best_value, int* evals_used)
+        namespace
         {
+            std::atomic<double> g_ftol_rel{-1.0}, g_xtol_rel{-1.0};
+            void                InitTolerances()
+            {
+                if (g_ftol_rel.load() >= 0.0) return;
+                const char*  e = std::getenv("SLS_LOCAL_SEARCH_TOL");   // read once per process
+                const double v = e ? std::max(0.0, std::atof(e)) : 1e-6;
+                g_xtol_rel.store(v);
+                g_ftol_rel.store(v);
+            }
+        } // namespace
+        void SetSearchTolerances(double f, double x)
+        {
+            g_xtol_rel.store(std::max(0.0, x));
+            g_ftol_rel.store(std::max(0.0, f));
+        }
+        void SearchTolerances(double* f, double* x)
+        {
+            InitTolerances();
+            if (f) *f = g_ftol_rel.load();
+            if (x) *x = g_xtol_rel.load();
+        }
+
+        void MapFitTolerances(double* f, double* x)
+        {
+            static const double v = [] {   // read once per process
+                const char* e = std::getenv("SLS_MAP_FIT_TOL");
+                return e ? std::max(0.0, std::atof(e)) : 0.0;
+            }();
+            if (f) *f = v;
+            if (x) *x = v;
+        }
+
+        std::vector<double> MaximizeBounded(const Objective& f, std::vector<double> x, const std::vector<double>& lo,
+                                            const std::vector<double>& hi, int max_evals, double* best_value, int* evals_used,
+                                            double ftol_rel, double xtol_rel)
+        {
+            bool stalled = false;   // NLopt's relative tests fired on an accepted step
             const size_t n = x.size();
             const int    m = 8;
             auto clampv = [&](std::vector<double>& v) {
@@ -190,7 +227,7 @@ namespace sequential_line_search
             for (auto& v : g) v = -v;
             std::vector<std::vector<double>> S, Y;
             std::vector<double>              rho;
-            while (evals < max_evals)
+            while (evals < max_evals && !stalled)
             {
                 double pgmax = 0.0, pgn2 = 0.0;
                 for (size_t i = 0; i < n; ++i)
@@ -282,6 +319,15 @@ namespace sequential_line_search
                                 S.erase(S.begin()); Y.erase(Y.begin()); rho.erase(rho.begin());
                             }
                             S.push_back(s); Y.push_back(y); rho.push_back(1.0 / sy);
+                        }
+                        // NLopt's relative stopping tests (nlopt/src/util/stop.c: relstop) on the accepted step
+                        if (ftol_rel > 0.0 && (std::fabs(ft - fx) < ftol_rel * 0.5 * (std::fabs(ft) + std::fabs(fx)) || ft == fx)) stalled = true;
+                        if (xtol_rel > 0.0)
+                        {
+                            bool moved = false;
+                            for (size_t i = 0; i < n; ++i)
+                                if (!(std::fabs(xt[i] - x[i]) < xtol_rel * 0.5 * (std::fabs(xt[i]) + std::fabs(x[i])) || xt[i] == x[i])) moved = true;
+                            if (!moved) stalled = true;
                         }
                         x = xt; g = gt; fx = ft;
                         accepted = true;

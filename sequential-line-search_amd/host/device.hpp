@@ -92,9 +92,21 @@ namespace sequential_line_search
         /// Bounded L-BFGS MAXIMISER (projected gradient, Armijo backtracking, m = 8), at most max_evals objective
         /// evaluations.  Stand-in for nloptutil::solve(..., LD_LBFGS / LD_TNEWTON, ..., is_max = true, max_evals):
         /// NLopt is not available, so iterates differ from the reference while the optimum is the same.
+        /// ftol_rel / xtol_rel: NLopt's relative stopping tests on every accepted step (0 = off), see SearchTolerances.
         std::vector<double> MaximizeBounded(const Objective& f, std::vector<double> x0, const std::vector<double>& lower,
                                             const std::vector<double>& upper, int max_evals, double* best_value = nullptr,
-                                            int* evals_used = nullptr);
+                                            int* evals_used = nullptr, double ftol_rel = 0.0, double xtol_rel = 0.0);
+
+        /// The relative tolerances every search of this layer runs with: nloptutil::solve's defaults relative_func_tolerance =
+        /// relative_param_tolerance = 1e-6, SLS_LOCAL_SEARCH_TOL=<v> sets both (0 = off).  One setting for
+        /// the acquisition maximiser's local searches and the MAP fits (acquisition_func::SetLocalSearchTolerances is its setter).
+        void SetSearchTolerances(double ftol_rel, double xtol_rel);
+        void SearchTolerances(double* ftol_rel, double* xtol_rel);
+        /// The MAP fits do NOT take those by default: their optima are what pins this layer to independent implementations (scipy,
+        /// tests/golden/map_optima*.npz), and NLopt's tests look at ONE step -- on the slow tail of the joint preference fit a step
+        /// below 1e-6 still leaves 4e-4 of the objective on the table (tests/test_gpu_map_device.py).  SLS_MAP_FIT_TOL=<v> opts in
+        /// (both tolerances; what nloptutil::solve's defaults would do to the reference's fits is v = 1e-6).
+        void MapFitTolerances(double* ftol_rel, double* xtol_rel);
 
         /// values[k] = f(xs[k]) for a whole batch of points (one device call per batch).
         using BatchObjective = std::function<void(const std::vector<std::vector<double>>& xs, std::vector<double>& values)>;

@@ -105,6 +105,9 @@ namespace sequential_line_search
         const int         D = static_cast<int>(m_X.rows());
         const auto        t_start = std::chrono::steady_clock::now();
         device::NllHandle nll(m_X, KernelId(m_kernel_type));
+        double            ftol_rel = 0.0, xtol_rel = 0.0;   // off unless SLS_MAP_FIT_TOL is set (device.hpp: optim::MapFitTolerances)
+        optim::MapFitTolerances(&ftol_rel, &xtol_rel);
+        device::Check(sls_nll_set_tolerances(nll.h, ftol_rel, xtol_rel), "sls_nll_set_tolerances");
         const double      lo = std::log(1e-8), hi = std::log(5e+01);
 
         auto objective = [&](const std::vector<double>& z, std::vector<double>* grad) -> double {
@@ -159,7 +162,7 @@ namespace sequential_line_search
         const int rc_fit = sls_gp_map_fit(nll.h, m_y.data(), best.data(), lower.data(), upper.data(), 1000, 0, z.data(),
                                           &m_map_stats.final_value, &m_map_stats.evals_local);
         if (rc_fit == SLS_ERR_UNSUPPORTED)
-            z = optim::MaximizeBounded(objective, best, lower, upper, 1000, &m_map_stats.final_value, &m_map_stats.evals_local);
+            z = optim::MaximizeBounded(objective, best, lower, upper, 1000, &m_map_stats.final_value, &m_map_stats.evals_local, ftol_rel, xtol_rel);
         else
             device::Check(rc_fit, "sls_gp_map_fit");
         m_map_stats.seconds         = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();

@@ -130,6 +130,9 @@ namespace sequential_line_search
         cfg.noiseless = 0;
 #endif
         device::NllHandle nll(m_X, KernelId(m_kernel_type));
+        double            ftol_rel = 0.0, xtol_rel = 0.0;   // off unless SLS_MAP_FIT_TOL is set (device.hpp: optim::MapFitTolerances)
+        optim::MapFitTolerances(&ftol_rel, &xtol_rel);
+        device::Check(sls_nll_set_tolerances(nll.h, ftol_rel, xtol_rel), "sls_nll_set_tolerances");
 
         const int           opt_dim = m_use_map_hyperparams ? M + 2 + d : M;
         std::vector<double> lower(opt_dim, -1e+01), upper(opt_dim, +1e+01), z0(opt_dim, 0.0);
@@ -167,7 +170,7 @@ namespace sequential_line_search
         const int rc_fit = sls_pref_map_fit(nll.h, flat.data(), offs.data(), static_cast<int>(m_D.size()), &cfg, z0.data(), lower.data(),
                                             upper.data(), static_cast<int>(num_iters), 0, z.data(), &m_map_objective, nullptr);
         if (rc_fit == SLS_ERR_UNSUPPORTED)
-            z = optim::MaximizeBounded(objective, z0, lower, upper, static_cast<int>(num_iters), &m_map_objective);
+            z = optim::MaximizeBounded(objective, z0, lower, upper, static_cast<int>(num_iters), &m_map_objective, nullptr, ftol_rel, xtol_rel);
         else
             device::Check(rc_fit, "sls_pref_map_fit");
 

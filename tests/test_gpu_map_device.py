@@ -200,14 +200,15 @@ def test_gp_fit_one_launch_equals_one_launch_per_evaluation(ctx, oracle, kernel,
     h.close()
 
 
-def host_driven_maximise(f, z0, lo, hi, max_evals):
+def host_driven_maximise(f, z0, lo, hi, max_evals, ftol_rel=0.0, xtol_rel=0.0):
     """optim::MaximizeBounded (host/device.cpp) restated in numpy: the optimiser the device kernel implements, driven with one
     objective call per evaluation."""
     x = np.clip(z0, lo, hi)
     v, g = f(x)
     fx, g, evals = -v, -g, 1
     S, Y, rho = [], [], []
-    while evals < max_evals:
+    stalled = False
+    while evals < max_evals and not stalled:
         pg = g.copy()
         pg[((x <= lo) & (g > 0)) | ((x >= hi) & (g < 0))] = 0.0
         if not np.abs(pg).max() > 0:
@@ -238,6 +239,11 @@ def host_driven_maximise(f, z0, lo, hi, max_evals):
                 s, yv = xt - x, gt - g
                 if s.dot(yv) > 1e-10 * yv.dot(yv) and s.dot(yv) > 0:
                     S, Y, rho = (S + [s])[-8:], (Y + [yv])[-8:], (rho + [1.0 / s.dot(yv)])[-8:]
+                # NLopt's relative stopping tests on the accepted step (sls_nll_set_tolerances)
+                if ftol_rel > 0 and (abs(ft - fx) < ftol_rel * 0.5 * (abs(ft) + abs(fx)) or ft == fx):
+                    stalled = True
+                if xtol_rel > 0 and np.all((np.abs(xt - x) < xtol_rel * 0.5 * (np.abs(xt) + np.abs(x))) | (xt == x)):
+                    stalled = True
                 x, g, fx, accepted = xt, gt, ft, True
                 break
             t *= 0.5
@@ -272,6 +278,53 @@ def test_device_optimiser_reaches_the_host_driven_optimum(ctx, use_map, M, D):
     x5, v5, _ = host_driven_maximise(f, z0, lo, hi, 5)
     assert abs(dev5["value"] - v5) <= 1e-9 * max(1.0, abs(v5))
     np.testing.assert_allclose(dev5["z"], x5, rtol=1e-8, atol=1e-9)
+    h.close()
+
+
+@pytest.mark.parametrize("use_map,M,D", [(False, 40, 6), (True, 40, 6), (True, 61, 32)])
+def test_relative_stopping_tests_of_nlopt_end_the_map_fits(ctx, oracle, use_map, M, D):
+    """sls_nll_set_tolerances (round 5): NLopt's relative tests on every accepted step of the device-resident MAP fits -- what
+    nloptutil::solve's defaults (1e-6 / 1e-6, SURVEY.md Appendix A) do to the reference's fits and what the host layer sets.  The
+    device fit must stop where the host-driven optimiser with the same tests stops (to within the steps that hover around the
+    threshold), end within the tolerance's reach of the converged optimum, use far fewer
+    evaluations than the run to convergence, and tolerances of 0 must restore that run.  Likewise the GP marginal-likelihood fit."""
+    rng = np.random.default_rng(19 + M)
+    X, prefs, z0, lo, hi = pref_setup(rng, M, D, use_map)
+    h = sls().Nll(ctx, X, 1)
+
+    def f(z):
+        x = z.copy()
+        if use_map:
+            x[M:] = np.exp(x[M:])
+        v, g = h.pref_objective(prefs, x, use_map=use_map)
+        if use_map:
+            g = g.copy()
+            g[M:] *= x[M:]
+        return v, g
+    full = h.pref_map_fit(prefs, z0, lo, hi, 5000, 0, use_map=use_map)
+    h.set_tolerances(1e-6, 1e-6)
+    dev = h.pref_map_fit(prefs, z0, lo, hi, 5000, 0, use_map=use_map)
+    xh, vh, eh = host_driven_maximise(f, z0, lo, hi, 5000, 1e-6, 1e-6)
+    # (on the slow tail successive steps hover around the threshold: which of them is the first below it may differ between two
+    # implementations that round differently -- by a dozen evaluations and as many times 1e-6 of the value, measured)
+    assert abs(dev["evals"] - eh) <= max(5, 0.15 * eh) and dev["evals"] < 0.7 * full["evals"], (dev["evals"], eh, full["evals"])
+    scale = max(1.0, abs(full["value"]))
+    # (the tests look at ONE step: on the slow tail of the joint fit a step below 1e-6 still leaves 4e-4 of the objective on the table
+    # -- measured here; the reference's fits, which run with the same tests, stop there as well)
+    assert abs(dev["value"] - vh) <= 5e-5 * scale and full["value"] - dev["value"] <= 2e-3 * scale and dev["value"] <= full["value"] + 1e-9 * scale
+    stepwise = h.pref_map_fit(prefs, z0, lo, hi, 5000, 1, use_map=use_map)          # one launch per evaluation: the same machine
+    assert stepwise["evals"] == dev["evals"] and stepwise["value"] == dev["value"]
+    h.set_tolerances(0.0, 0.0)
+    again = h.pref_map_fit(prefs, z0, lo, hi, 5000, 0, use_map=use_map)
+    assert again["evals"] == full["evals"] and again["value"] == full["value"]
+    # GP marginal likelihood on the same points
+    y = np.sin(3.0 * X.sum(axis=0)) + 0.05 * rng.normal(size=M)
+    zg = np.log(np.concatenate([[0.5, 0.01], np.full(D, 0.5)]))
+    lg, hg = np.full(D + 2, np.log(1e-8)), np.full(D + 2, np.log(10.0))
+    gfull = h.gp_map_fit(y, zg, lg, hg, 1000)
+    h.set_tolerances(1e-6, 1e-6)
+    gtol = h.gp_map_fit(y, zg, lg, hg, 1000)
+    assert gtol["evals"] < 0.7 * gfull["evals"] and abs(gtol["value"] - gfull["value"]) <= 1e-5 * max(1.0, abs(gfull["value"])), (gtol, gfull)
     h.close()
 
 
