@@ -965,15 +965,14 @@ __global__ __launch_bounds__(256) void map_opt_kernel(const MapOptArgs args) {
     const Fold fold0(N);
     // the first preference tuple of this thread and the first tuple memberships of data point `tid`: indices in registers
     constexpr int RC = 4;
-    int po = 0, pm = 0, pidx0 = 0, pidx1 = 0, pidx2 = 0, pidx3 = 0, co = 0, cm = 0, cidx0 = 0, cidx1 = 0, cidx2 = 0, cidx3 = 0;
-    const int tq = tid - 128;   // tuple tq (, tq + 128, ...) on thread 128 + tq: the upper two waves, see btl_tuples below
+    int po = 0, pm = 0, pmem = 0, co = 0, cm = 0, cidx0 = 0, cidx1 = 0, cidx2 = 0, cidx3 = 0;
+    // tuple tq (, tq + 32, ...) on the QUAD of threads 128 + 4 tq .. + 3 of the upper two waves, one member per lane (see btl_tuples):
+    // offset, size and this lane's member of the quad's first tuple in registers
+    const int tq = tid >= 128 ? (tid - 128) >> 2 : -1, ti = tid & 3;
     if (tq >= 0 && tq < P) {
         po = args.pref_off[tq];
         pm = args.pref_off[tq + 1] - po;
-        pidx0 = args.pref_flat[po];
-        if (pm > 1) pidx1 = args.pref_flat[po + 1];
-        if (pm > 2) pidx2 = args.pref_flat[po + 2];
-        if (pm > 3) pidx3 = args.pref_flat[po + 3];
+        pmem = args.pref_flat[po + min(ti, pm - 1)];
     }
     if (tid < ny && P > 0) {
         co = args.csc_off[tid];
@@ -1054,12 +1053,39 @@ __global__ __launch_bounds__(256) void map_opt_kernel(const MapOptArgs args) {
                 contrib(o) = (tmp * (-sum2)) / v;
                 for (int i = 1; i < m; ++i) contrib(o + i) = (tmp * contrib(o + i)) / v;
             };
-            static_assert(RC == 4, "tuple_terms takes four register members");
-            if (tq >= 0 && tq < P) tuple_terms(po, pm, pidx0, pidx1, pidx2, pidx3);
-            for (int p = tq + 128; tq >= 0 && p < P; p += 128) {       // more than 128 tuples: indices from global memory
-                const int o = args.pref_off[p], m = args.pref_off[p + 1] - o;
-                tuple_terms(o, m, args.pref_flat[o], m > 1 ? args.pref_flat[o + 1] : 0, m > 2 ? args.pref_flat[o + 2] : 0,
-                            m > 3 ? args.pref_flat[o + 3] : 0);
+            // Up to four members: one per lane of the quad.  The exponentials of the members run side by side (an exp is ~120
+            // cycles of issue on its wave, a log 480: a tuple's six exponentials, its logarithm and five divisions one after the other
+            // were ~2000 cycles), the two sums are butterflies inside the quad -- (e0 + e1) + (e2 + e3), the reference's order
+            // e0 + e1 + e2 for the three members of a line search's tuples -- and lane 0's values reach the others by quad
+            // broadcast.  Larger tuples: lane 0 of the quad alone, member by member.
+            auto quad_terms = [&](int o, int m, int mem) {
+                const bool act = ti < m;
+                const double yi = small_scratch(As, SC_Y + mem);
+                const double f0 = dpp_f64<0x00>(yi);                                    // quad_perm [0,0,0,0]
+                const double e = act ? exp(yi / bs) : 0.0;
+                const double r = (act && ti >= 1) ? exp((yi - f0) / bs) : 0.0;          // used twice by the reference: once here
+                double sum = e, sum2 = r;
+                sum += dpp_f64<0xB1>(sum);
+                sum2 += dpp_f64<0xB1>(sum2);
+                sum += dpp_f64<0x4E>(sum);
+                sum2 += dpp_f64<0x4E>(sum2);
+                const double v = dpp_f64<0x00>(e) / sum;                                 // CalcBtl: exp(f0 / bs) / sum
+                if (ti == 0) lsum += log(v);                                             // calc_log_likelihood
+                const double tmp = -v * v / bs;                                          // CalcBtlDerivative
+                if (act) contrib(o + ti) = ti == 0 ? (tmp * (-sum2)) / v : (tmp * r) / v;
+            };
+            if (tq >= 0) {
+                for (int p = tq; p < P; p += 32) {          // (the quad's lanes run the same trips)
+                    int o = po, m = pm, mem = pmem;
+                    if (p != tq) {                          // more than 32 tuples: indices from global memory
+                        o = args.pref_off[p];
+                        m = args.pref_off[p + 1] - o;
+                        mem = args.pref_flat[o + min(ti, m - 1)];
+                    }
+                    if (m <= RC) quad_terms(o, m, mem);
+                    else if (ti == 0)
+                        tuple_terms(o, m, args.pref_flat[o], args.pref_flat[o + 1], args.pref_flat[o + 2], args.pref_flat[o + 3]);
+                }
             }
         };
         auto btl_tuples = [&]() {
