@@ -651,52 +651,72 @@ struct NoSlabHook {
 // memory; its lower 16 x 16 blocks are loaded in the ACCUMULATOR layout -- agent-scope loads, in flight behind the product -- so
 // the subtraction happens in the write-back, without a pass of its own over the image).  The same single subtraction of the
 // complete sum: same bits as image <- product, image <- Csub - image.
-template <int W, class F>
-__device__ __forceinline__ void chain_syrk_inplace_wave(double* img, F&& before_slab, const double* __restrict__ Csub = nullptr, long ldc = 0) {
-    constexpr int NB9[4][9][2] = {
+// The pieces of the product, shared by the in-place form below and by the form fused into the streamed solve (stream_trsm_syrk):
+// the 3 x 3 deal, the tile the product is subtracted from in the accumulator layout, ONE slab of the sum, the write-back.
+template <int W>
+struct SyrkDeal {
+    static constexpr int NB9[4][9][2] = {
         {{5, 0}, {5, 1}, {5, 2}, {6, 0}, {6, 1}, {6, 2}, {7, 0}, {7, 1}, {7, 2}},
         {{5, 3}, {5, 4}, {5, 5}, {6, 3}, {6, 4}, {6, 5}, {7, 3}, {7, 4}, {7, 5}},
         {{2, 0}, {2, 1}, {2, 2}, {3, 0}, {3, 1}, {3, 2}, {4, 0}, {4, 1}, {4, 2}},
         {{0, 0}, {1, 0}, {1, 1}, {3, 3}, {4, 3}, {4, 4}, {6, 6}, {7, 6}, {7, 7}}};
-    const int lane = threadIdx.x & 63;
-    const int l0 = (lane >> 4) * GEMM_LDS_MC_LD + (lane & 15);
-    d4_t acc[9], c0[9];
-#pragma unroll
-    for (int p = 0; p < 9; ++p) acc[p] = d4_t{0.0, 0.0, 0.0, 0.0};
-    if (Csub) {
-        auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Csub), 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-        for (int p = 0; p < 9; ++p)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long off = (16 * NB9[W][p][0] + (lane & 15)) + (long)(16 * NB9[W][p][1] + (lane >> 4) + 4 * r) * ldc;
-                c0[p][r] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(off * 8), 0, 16));
-            }
+    static constexpr int row(int p) { return NB9[W][p][0]; }
+    static constexpr int col(int p) { return NB9[W][p][1]; }
+    static constexpr bool used(int b) {
+        bool u = false;
+        for (int p = 0; p < 9; ++p) u = u || NB9[W][p][0] == b || NB9[W][p][1] == b;
+        return u;
     }
+};
+template <int W>
+__device__ __forceinline__ void syrk_load_c0(d4_t (&c0)[9], const double* __restrict__ Csub, long ldc, int lane) {
+    auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Csub), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        before_slab(s);
+    for (int p = 0; p < 9; ++p)
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const double* la = img + s * GEMM_LDS_TILE + 4 * kk * GEMM_LDS_MC_LD + l0;
-            double f[8];
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                bool used = false;
-#pragma unroll
-                for (int p = 0; p < 9; ++p) used = used || NB9[W][p][0] == b || NB9[W][p][1] == b;
-                if (used) f[b] = la[16 * b];
-            }
-#pragma unroll
-            for (int p = 0; p < 9; ++p) acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[NB9[W][p][1]], f[NB9[W][p][0]], acc[p], 0, 0, 0);
+        for (int r = 0; r < 4; ++r) {
+            const long off = (16 * SyrkDeal<W>::row(p) + (lane & 15)) + (long)(16 * SyrkDeal<W>::col(p) + (lane >> 4) + 4 * r) * ldc;
+            c0[p][r] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(off * 8), 0, 16));
         }
+}
+// acc += (slab)(slab)^T on this wave's nine blocks; slab: 16 k-rows of the operand, element (m, k) at slab[k GEMM_LDS_MC_LD + m]
+template <int W>
+__device__ __forceinline__ void syrk_slab(d4_t (&acc)[9], const double* slab, int lane) {
+    const int l0 = (lane >> 4) * GEMM_LDS_MC_LD + (lane & 15);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const double* la = slab + 4 * kk * GEMM_LDS_MC_LD + l0;
+        double f[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+            if (SyrkDeal<W>::used(b)) f[b] = la[16 * b];
+#pragma unroll
+        for (int p = 0; p < 9; ++p) acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[SyrkDeal<W>::col(p)], f[SyrkDeal<W>::row(p)], acc[p], 0, 0, 0);
     }
-    lds_barrier();
+}
+template <int W, bool SUB>
+__device__ __forceinline__ void syrk_to_image(double* img, const d4_t (&acc)[9], const d4_t (&c0)[9], int lane) {
 #pragma unroll
     for (int p = 0; p < 9; ++p)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            img[(16 * NB9[W][p][1] + (lane >> 4) + 4 * r) * DL + 16 * NB9[W][p][0] + (lane & 15)] = Csub ? c0[p][r] - acc[p][r] : acc[p][r];
+            img[(16 * SyrkDeal<W>::col(p) + (lane >> 4) + 4 * r) * DL + 16 * SyrkDeal<W>::row(p) + (lane & 15)] = SUB ? c0[p][r] - acc[p][r] : acc[p][r];
+}
+template <int W, class F>
+__device__ __forceinline__ void chain_syrk_inplace_wave(double* img, F&& before_slab, const double* __restrict__ Csub = nullptr, long ldc = 0) {
+    const int lane = threadIdx.x & 63;
+    d4_t acc[9], c0[9];
+#pragma unroll
+    for (int p = 0; p < 9; ++p) acc[p] = d4_t{0.0, 0.0, 0.0, 0.0};
+    if (Csub) syrk_load_c0<W>(c0, Csub, ldc, lane);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        before_slab(s);
+        syrk_slab<W>(acc, img + s * GEMM_LDS_TILE, lane);
+    }
+    lds_barrier();
+    if (Csub) syrk_to_image<W, true>(img, acc, c0, lane);
+    else syrk_to_image<W, false>(img, acc, c0, lane);
 }
 template <class F = NoSlabHook>
 __device__ __forceinline__ void chain_syrk_inplace(double* img, F&& before_slab = NoSlabHook{}, const double* __restrict__ Csub = nullptr,
@@ -728,6 +748,266 @@ __device__ __forceinline__ void chain_image_rsub(const double* __restrict__ C, l
             *reinterpret_cast<d2_t*>(img + 2 * lane + c * DL) = v;
         }
     }
+}
+
+// ---- the streamed solve with the next diagonal tile's update folded in (round 6) -----------------------------
+// The chain's step used to be serial behind the solve: tile -> image -> global memory, THEN the 128 x 128 x 128 product L L^T on one
+// CU (10.7 us), THEN the diagonal block.  But L L^T = sum_s X_s X_s^T over the 16-column blocks of the panel tile, and block s is final at
+// step s of the solve -- while the workgroup is waiting for the other one to publish column block s + 1 of the diagonal block it is
+// still factoring.  So every finished block goes to an LDS slab (two of them, behind the solve's rings), from where it leaves for
+// global memory (whole 1 KB columns, write-through: the panel tile is stored BY the solve) and enters the product as ONE slab of
+// chain_syrk_inplace's sum -- same deal of the 36 lower blocks, same k order, same single subtraction from the tile at the end:
+// same bits.  Behind the last published block only remain: X_7 (eight products), its slab, one slab of the product (36 per wave)
+// and the write-back into the image.
+// LDS: A ring slabs 0-3, L slabs 4-5, X slabs 6-7 of the image area, T16 buffers behind it -- the whole 160 KB.
+// On return the image holds Csub - X X^T on its lower 16 x 16 blocks (diag_block_factor<false>'s input, behind the caller's
+// barrier) and the tile X has been stored (the caller drains and raises the flag).
+// ready(): called once, uniformly, before the tile Csub is first read (its owner's last update must have landed); false = give up.
+template <class Ready>
+__device__ __forceinline__ bool stream_trsm_syrk(double* __restrict__ A, long lda, const double* __restrict__ L, long ldl,
+                                                 const double* __restrict__ T, long ldt, int* flag, int* abort_flag, long long timeout,
+                                                 const double* __restrict__ Csub, long ldc, Ready&& ready, int* xprog, long long* stamp, double* lds) {
+    // `lane` is made opaque here: everything derived from it -- some 300 LDS / global offsets of the four waves' deals -- is otherwise
+    // hoisted out of the chain's loop over the diagonal blocks and kept (spilled) across it
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fl = lane & 15, fk = lane >> 4;
+    const int mi[2] = {wave, 7 - wave};
+    constexpr int SLAB = GEMM_LDS_TILE;
+    double* Lbuf = lds + 4 * SLAB;                       // [2][SLAB]
+    double* Xbuf = lds + 6 * SLAB;                       // [2][SLAB]
+    double* Tbuf = lds + 128 * DL;                       // [2][256]
+    auto issueA = [&](int s) {
+        double* base = lds + (s & 3) * SLAB;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * wave + r;
+            slab_row_to_lds(A + 2 * lane + (long)(16 * s + row) * lda, base + row * GEMM_LDS_MC_LD);
+        }
+    };
+    auto issueL = [&](int s) {
+        double* base = Lbuf + (s & 1) * SLAB;
+        if (s < 7) {                                     // block 7 has no later block to update: only T16_7 is needed
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * wave + r;
+                slab_row_to_lds_sc1(L + 2 * lane + (long)(16 * s + row) * ldl, base + row * GEMM_LDS_MC_LD);
+            }
+        }
+        if (wave < 2)
+            slab_row_to_lds_sc1(T + (16 * s + 2 * (lane & 7)) + (long)(16 * s + 8 * wave + (lane >> 3)) * ldt, Tbuf + (s & 1) * 256 + 128 * wave);
+    };
+    auto rsrcX = __builtin_amdgcn_make_buffer_rsrc(A, 0, 0x7fffffff, 0x00020000);
+    ChainAcc V;
+    d4_t acc[9], c0[9];
+#pragma unroll
+    for (int p = 0; p < 9; ++p) acc[p] = d4_t{0.0, 0.0, 0.0, 0.0};
+    V.zero();
+    issueA(0); issueA(1); issueA(2);
+    if (stamp) stamp[5] = wall_clock64();
+    int issuedL = 0;
+    bool ok = true;
+    // xprog += 1 per wave and block once that wave's four columns of the block have drained (4 (s + 1): block s is in global
+    // memory): the owners of the tile below run the K loop of its last update behind these (stream_update_half)
+    int raised = 0;
+    auto raise = [&](int upto) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (raised < upto) {
+            if (lane == 0) __hip_atomic_fetch_add(xprog, upto - raised, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            raised = upto;
+        }
+    };
+    auto step = [&](auto S) {
+        constexpr int s = decltype(S)::value;
+        if (!ok) return;
+        // early: column block s was already published a step ago and requested then -- BEFORE that step's four stores of X_{s-1}.
+        // Memory operations complete in order: everything but those stores is waited for, and they drain behind this step (a
+        // solve that has fallen behind the factorisation would otherwise pay a write-through round trip per block).
+        const bool early = issuedL > s;
+        if (!early) {
+            if (!stream_wait(flag, 3 * (s + 1), abort_flag, timeout)) { ok = false; return; }
+            issueL(s);
+            issuedL = s + 1;
+        }
+        if (s == 7 && stamp) stamp[0] = wall_clock64();    // probes: the diagonal block has ended (on the other workgroup) a moment ago
+        if (early) ring_wait_barrier<4>();               // slab s of A and of L in LDS (every wave's part); slab s - 1 no longer read
+        else ring_wait_barrier<0>();
+        if (s == 7 && stamp) stamp[9] = wall_clock64();
+        if (s + 3 < 8) issueA(s + 3);
+        if (s + 1 < 8) {
+            int have = 0;
+            if (lane == 0) have = df_flag(flag) >= 3 * (s + 2) ? 1 : 0;
+            if (__builtin_amdgcn_readfirstlane(have)) {
+                issueL(s + 1);
+                issuedL = s + 2;
+            }
+        }
+        const double* la = lds + (s & 3) * SLAB;
+        const double* lb = Lbuf + (s & 1) * SLAB;
+        const double* tb = Tbuf + (s & 1) * 256;
+        double* xb = Xbuf + (s & 1) * SLAB;
+        double tf[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) tf[kk] = tb[fl + 16 * (4 * kk + fk)];
+        // both row blocks' X_s first (the slab the other waves wait for), then the later blocks' sums
+        d4_t xs[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            d4_t r;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r[q] = la[(fk + 4 * q) * GEMM_LDS_MC_LD + 16 * mi[a] + fl] - V.v[a][s][q];
+            d4_t x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) x = __builtin_amdgcn_mfma_f64_16x16x4f64(tf[kk], r[kk], x, 0, 0, 0);
+            xs[a] = x;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xb[(fk + 4 * q) * GEMM_LDS_MC_LD + 16 * mi[a] + fl] = x[q];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int c = s + 1; c < 8; ++c) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const double bf = lb[(fk + 4 * kk) * GEMM_LDS_MC_LD + 16 * c + fl];
+                    V.v[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf, xs[a][kk], V.v[a][c], 0, 0, 0);
+                }
+            }
+        }
+#ifndef SLS_EXP_NORAISE
+        if (s > 0) raise(s);                             // block s - 1: stored a step ago
+#endif
+        lds_barrier();                                   // X_s complete in its slab (every wave's rows)
+#ifndef SLS_EXP_NOSTORE
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                    // column 16 s + 4 q + wave of the tile: 64 lanes x 16 bytes
+            const int c = 4 * q + wave;
+            const d2_t v = *reinterpret_cast<const d2_t*>(xb + c * GEMM_LDS_MC_LD + 2 * lane);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rsrcX, (int)((2 * lane + (long)(16 * s + c) * lda) * 8), 0, 16);
+        }
+#endif
+#ifndef SLS_EXP_NOSYRK
+        if (wave == 0) syrk_slab<0>(acc, xb, lane);
+        else if (wave == 1) syrk_slab<1>(acc, xb, lane);
+        else if (wave == 2) syrk_slab<2>(acc, xb, lane);
+        else syrk_slab<3>(acc, xb, lane);
+#endif
+        if (stamp && (s == 0 || s == 3 || s == 6)) stamp[6 + s / 3] = wall_clock64();
+    };
+    step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
+    step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+    step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
+    if (!ok) return false;
+    raise(8);
+    if (stamp) stamp[12] = wall_clock64();
+    if (!ready()) return false;
+    if (wave == 0) syrk_load_c0<0>(c0, Csub, ldc, lane);
+    else if (wave == 1) syrk_load_c0<1>(c0, Csub, ldc, lane);
+    else if (wave == 2) syrk_load_c0<2>(c0, Csub, ldc, lane);
+    else syrk_load_c0<3>(c0, Csub, ldc, lane);
+    lds_barrier();                                       // every wave has read the last slab: the image may be written
+    if (wave == 0) syrk_to_image<0, true>(lds, acc, c0, lane);
+    else if (wave == 1) syrk_to_image<1, true>(lds, acc, c0, lane);
+    else if (wave == 2) syrk_to_image<2, true>(lds, acc, c0, lane);
+    else syrk_to_image<3, true>(lds, acc, c0, lane);
+    return true;
+}
+
+// The LAST update of half a sub-diagonal tile, C_{k+1,k}[:, 64 nhalf ..] -= L_{k+1,k-1} L_{k,k-1}^T, run BEHIND the chain's solve of
+// L_{k,k-1}: its K loop walks the 16-column blocks of both operands, and block s of L_{k,k-1} is in global memory when the solve
+// has finished its step s (xprog).  The tile is then complete one block's product + its write-back after the chain's tile -- not
+// a whole K = 128 product later (13 us: with the product L L^T folded into the solve that product had become the chain's step).
+// Same slabs, same fragment layout, same k order as gemm_tile_mc<2>: same bits; the tile's values are in registers before the
+// last block arrives.
+__device__ __forceinline__ bool stream_update_half(double* __restrict__ C, long ld, const double* __restrict__ A, const double* __restrict__ B,
+                                                   int nhalf, int* xprog, int* abort_flag, long long timeout, double* lds) {
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fl = lane & 15, fk = lane >> 4;
+    const int wm = (wave & 1) * 64, wn = 64 * nhalf + (wave >> 1) * 32;
+    constexpr int SLAB = GEMM_LDS_TILE;
+    double* Bbuf = lds + 4 * SLAB;
+    auto issueA = [&](int s) {
+        double* base = lds + (s & 3) * SLAB;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * wave + r;
+            slab_row_to_lds(A + 2 * lane + (long)(16 * s + row) * ld, base + row * GEMM_LDS_MC_LD);
+        }
+    };
+    auto issueB = [&](int s) {
+        double* base = Bbuf + (s & 1) * SLAB;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * wave + r;
+            slab_row_to_lds_sc1(B + 2 * lane + (long)(16 * s + row) * ld, base + row * GEMM_LDS_MC_LD);
+        }
+    };
+    d2_t cv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) cv[q] = *reinterpret_cast<const d2_t*>(C + 2 * lane + (long)(64 * nhalf + wave + 4 * q) * ld);
+    d4_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) acc[i][jj] = d4_t{0.0, 0.0, 0.0, 0.0};
+    issueA(0); issueA(1); issueA(2);
+    int issuedB = 0;
+    bool ok = true;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        if (issuedB <= s) {
+            if (!stream_wait(xprog, 4 * (s + 1), abort_flag, timeout)) { ok = false; break; }
+            issueB(s);
+            issuedB = s + 1;
+        }
+        ring_wait_barrier<0>();
+        if (s + 3 < 8) issueA(s + 3);
+        if (s + 1 < 8) {
+            int have = 0;
+            if (lane == 0) have = df_flag(xprog) >= 4 * (s + 2) ? 1 : 0;
+            if (__builtin_amdgcn_readfirstlane(have)) {
+                issueB(s + 1);
+                issuedB = s + 2;
+            }
+        }
+        const double* la = lds + (s & 3) * SLAB;
+        const double* lb = Bbuf + (s & 1) * SLAB;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            double fa[4], fb[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = la[(4 * kk + fk) * GEMM_LDS_MC_LD + wm + 16 * i + fl];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) fb[jj] = lb[(4 * kk + fk) * GEMM_LDS_MC_LD + wn + 16 * jj + fl];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[jj], fa[i], acc[i][jj], 0, 0, 0);
+        }
+    }
+    if (!ok) return false;
+    lds_barrier();                                       // the rings are no longer read: the image may be written
+    // tile_commit_half<1, true> with the tile's values already in registers
+    const int n0 = 64 * nhalf + (wave >> 1) * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lds[(wm + 16 * i + fl) + (n0 + 16 * jj + fk + 4 * r) * DL] = acc[i][jj][r];
+    lds_barrier();
+    auto rsrc = __builtin_amdgcn_make_buffer_rsrc(C, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int c = 64 * nhalf + wave + 4 * q;
+        const d2_t v = cv[q] - *reinterpret_cast<const d2_t*>(lds + 2 * lane + c * DL);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rsrc, (int)((2 * lane + (long)c * ld) * 8), 0, 16);
+    }
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1057,6 +1337,9 @@ __device__ __forceinline__ void potri_team(const PersistArgs& a, int b2, int G2,
     }
 }
 
+// FUSE: the streamed chain folds the next diagonal tile's update into its solve (stream_trsm_syrk; SLS_POTRF_FUSE_SYRK=0 launches the
+// other instantiation: two kernels rather than a run-time branch, whose two sets of hoisted addresses did not fit the registers)
+template <bool FUSE>
 __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
@@ -1080,6 +1363,7 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
     // comes ~6 us later and is only needed behind the solve
     int* diag_ready = a.sync + DF_FACT + 2 * nb + 2 * nb * nb;
     int* upd_done = diag_ready + nb;                    // [i + k nb]: the second half of tile (i, k) carries all its updates
+    int* xprog = upd_done + nb * nb;                    // [j]: 4 (s + 1) = the chain's tile (j+1, j) is in global memory up to column block s (FUSE)
     const int nchain = a.nchain;
     if (b < 2 && nchain == 2) {
         // ---- the chain, streamed form: TWO workgroups taking turns ----
@@ -1099,37 +1383,50 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             PK_STAMP(10);
             if (!pk_wait_count(chain_ready + j, 1 + a.split_sub, a)) return;   // tile (j+1, j) carries its owners' updates (steps < j)
             PK_STAMP(11);
-            {
-                ChainAcc ca;
-                if (!stream_trsm(ca, Asub, ld, Ajj, ld, Tjj, ld, factored + j, a.info + 1, a.timeout, lds)) return;
-                PK_STAMP(12);
-                PK_STAMP(0);                                   // diagonal block j has ended (on the other workgroup) a moment ago
-                chain_acc_to_image<true>(ca, lds);
-            }
-            int* ctl = reinterpret_cast<int*>(lds + 128 * DL);               // a word behind the image (the T16 buffers of the solve: dead)
-            if (threadIdx.x == 0) *ctl = df_flag(diag_ready + j) >= 1 ? 1 : 0;   // one decision for the workgroup, see below
-            lds_barrier();
-            chain_image_store_wt(Asub, ld, lds);
-            {
-                // The diagonal tile's owner finished its updates long since (its last one comes ~6 us after the sub-diagonal
-                // tile's, i.e. ~10 us before this point): a relaxed look at its flag, the full wait only if it is not up yet.
-                const int up = *ctl;
-                if (!up && !pk_wait_count(diag_ready + j, 1, a)) return;
-            }
-            // The product starts at once: the stores have left the image (it is only overwritten behind the product), and their
-            // drain -- 3.3 us for 128 KB of write-through stores + the 64 KB of loads above -- would sit on the chain's path.  The
-            // flag for the workers goes up behind the product's second slab, when the drain is over anyway.
-            PK_STAMP(1);
-            PK_STAMP(2);
             int* xflag = panel_done + (j + 1) + (long)j * nb;
-            // image <- A_{j+1,j+1} - L L^T on the lower blocks (the tile comes in the accumulator layout, agent-scope loads in flight
-            // behind the product; what stands above the diagonal blocks is never read by the factorisation)
-            chain_syrk_inplace(lds, [&](int sblk) {
-                if (sblk == 2) {
-                    df_publish_store(xflag);
-                    PK_STAMP(13);
+            if constexpr (FUSE) {
+                // solve, store and multiply in one pass (stream_trsm_syrk); the diagonal tile's owner finished its updates long since
+                // (its last one comes ~6 us after the sub-diagonal tile's): a relaxed look per wave, a spin only if it is not up yet
+                long long* stamp = (a.trace && threadIdx.x == 0) ? a.trace + 16 * j : nullptr;
+                if (!stream_trsm_syrk(Asub, ld, Ajj, ld, Tjj, ld, factored + j, a.info + 1, a.timeout, Anext, ld,
+                                      [&]() { return stream_wait(diag_ready + j, 1, a.info + 1, a.timeout); }, xprog + j, stamp, lds))
+                    return;
+                PK_STAMP(1);
+                PK_STAMP(2);
+                df_publish_store(xflag);                       // drains the last block's stores; the image is complete behind its barrier
+                PK_STAMP(13);
+            } else {
+                {
+                    ChainAcc ca;
+                    if (!stream_trsm(ca, Asub, ld, Ajj, ld, Tjj, ld, factored + j, a.info + 1, a.timeout, lds)) return;
+                    PK_STAMP(12);
+                    PK_STAMP(0);                                   // diagonal block j has ended (on the other workgroup) a moment ago
+                    chain_acc_to_image<true>(ca, lds);
                 }
-            }, Anext, ld);
+                int* ctl = reinterpret_cast<int*>(lds + 128 * DL);               // a word behind the image (the T16 buffers of the solve: dead)
+                if (threadIdx.x == 0) *ctl = df_flag(diag_ready + j) >= 1 ? 1 : 0;   // one decision for the workgroup, see below
+                lds_barrier();
+                chain_image_store_wt(Asub, ld, lds);
+                {
+                    // The diagonal tile's owner finished its updates long since (its last one comes ~6 us after the sub-diagonal
+                    // tile's, i.e. ~10 us before this point): a relaxed look at its flag, the full wait only if it is not up yet.
+                    const int up = *ctl;
+                    if (!up && !pk_wait_count(diag_ready + j, 1, a)) return;
+                }
+                // The product starts at once: the stores have left the image (it is only overwritten behind the product), and their
+                // drain -- 3.3 us for 128 KB of write-through stores + the 64 KB of loads above -- would sit on the chain's path.  The
+                // flag for the workers goes up behind the product's second slab, when the drain is over anyway.
+                PK_STAMP(1);
+                PK_STAMP(2);
+                // image <- A_{j+1,j+1} - L L^T on the lower blocks (the tile comes in the accumulator layout, agent-scope loads in flight
+                // behind the product; what stands above the diagonal blocks is never read by the factorisation)
+                chain_syrk_inplace(lds, [&](int sblk) {
+                    if (sblk == 2) {
+                        df_publish_store(xflag);
+                        PK_STAMP(13);
+                    }
+                }, Anext, ld);
+            }
             PK_STAMP(8);
             PK_STAMP(9);
             __syncthreads();
@@ -1248,7 +1545,12 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
                     const int j0 = d;
                     const int j1 = df_chunk_end(k, j0, target, nbo, a.near);
                     const int j = j0 + (l & 7);
-                    if (j < j1 && !(l >= 8 && i == k)) ok = df_flag(panel_done + (l < 8 ? i : k) + (long)j * nb) != 0;
+                    // the last update of a sub-diagonal half tile runs behind the chain's solve of its second operand (FUSE): the
+                    // first block of that tile instead of the whole
+                    const bool streamed = FUSE && nchain == 2 && i == k + 1 && SW(6, t) != 0 && j1 == target && j1 - j0 == 1;
+                    if (streamed && l >= 8) {
+                        if (l == 8) ok = df_flag(xprog + j0) >= 4;
+                    } else if (j < j1 && !(l >= 8 && i == k)) ok = df_flag(panel_done + (l < 8 ? i : k) + (long)j * nb) != 0;
                 } else if (i > k + 1 && SW(6, t) != 2) {
                     // the diagonal block (round-3 chain), or its first column block (3 = one arrival per publishing wave) in the streamed
                     // form, where the tile is solved block by block behind it; a tile with two owners: the other half
@@ -1288,6 +1590,25 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             const int j0 = d;
             const int j1 = df_chunk_end(k, j0, target, nbo, a.near);
             const int half = SW(6, t);
+            if (FUSE && nchain == 2 && half != 0 && i == k + 1 && j1 == target && j1 - j0 == 1) {
+                if (!stream_update_half(Cik, ld, a.A + (long)i * NB + (long)j0 * NB * ld, a.A + (long)k * NB + (long)j0 * NB * ld, half - 1,
+                                        xprog + j0, a.info + 1, a.timeout, lds))
+                    return;
+                df_publish_add(chain_ready + k);
+                if (a.trace && tid == 0 && k >= 1) {
+                    a.trace[16 * (k - 1) + 14 + 0] = half == 1 ? st_task0 : a.trace[16 * (k - 1) + 14];
+                    if (half == 1) a.trace[16 * (k - 1) + 15] = wall_clock64();
+                }
+                if (tid == 0) {
+                    SW(2, t) = j1;
+                    SW(3, t) = 1;
+                }
+                ++st_n_upd;
+                __syncthreads();
+                t_progress = wall_clock64();
+                if (a.trace) st_task += t_progress - st_task0;
+                continue;
+            }
             Acc acc;
             acc.zero();
             if (half == 0)
@@ -1336,7 +1657,7 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
         } else if (i > k + 1) {
             ++st_n_panel;
             if (nchain == 2) {
-                const bool stamp = a.trace && tid == 0 && i == k + 2;      // probes: the panel tile right below the chain's
+                const bool stamp = a.trace && tid == 0 && i == k + 2 && !FUSE;      // probes: the panel tile right below the chain (FUSE: the slots carry the solve.s own stamps)
                 if (stamp) a.trace[16 * k + 5] = st_task0;
                 ChainAcc ca;
                 if (!stream_trsm(ca, Cik, ld, a.A + (long)k * NB * (ld + 1), ld, a.Linv + (long)k * NB * (ld + 1), ld, factored + k,
@@ -1450,7 +1771,7 @@ int potrf_dataflow_nbo(int Np) {
 // ints of device scratch the dataflow form needs per problem
 size_t potrf_dataflow_sync_ints(int Np) {
     const size_t nb = Np / NB;
-    return DF_FACT + 3 * nb + 3 * nb * nb;           // factored, chain_ready, panel_done[nb][nb], xdone[nb][nb] (fused inverse), diag_ready, upd_done[nb][nb]
+    return DF_FACT + 4 * nb + 3 * nb * nb;           // factored, chain_ready, panel_done[nb][nb], xdone[nb][nb] (fused inverse), diag_ready, upd_done[nb][nb], xprog
 }
 // How many independent Np x Np factorisations share one launch well: a problem keeps the chip busy with about nb^2 / 14.5 workers
 // (its ~nb^3 / 6 tile tasks of ~20 us against a chain of nb steps of ~48 us); the rest of the CUs can factor other problems.
@@ -1470,12 +1791,18 @@ int potrf_dataflow_max_problems(int Np) {
 // false if the matrix is too large for it (N > 4096: the chip is busy with the factorisation itself) or too few CUs remain.
 static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double* Linv, int* info, int* sync, int nprob, long strideA,
                                        long stride_sync, bool block_inverses, long long* trace, const PotriFused* inv) {
-    ensure_dyn_lds((const void*)potrf_dataflow_kernel, DIAG_LDS_BYTES);
+    // Measured (round 6, N = 2048, profiles/r06_potrf_fused_chain.log): the fused solve takes the serial L L^T product (10.7 us) off
+    // the step, but the solve itself then carries 25 us of work per tile (16 without the product) against the 19.8 us of the
+    // diagonal block it follows, and the tile below reaches it 10-21 us after the block before it ended: 37-49 us per step against
+    // 35.7.  Off by default until the solve is under the diagonal block's time.
+    const bool fuse = tune_on(TUNE_POTRF_FUSE_SYRK, false);
+    ensure_dyn_lds((const void*)potrf_dataflow_kernel<true>, DIAG_LDS_BYTES);
+    ensure_dyn_lds((const void*)potrf_dataflow_kernel<false>, DIAG_LDS_BYTES);
     const int nb = Np / NB;
     PersistSerial& ps = persist_serial_of_current_device();
     if (ps.resident_per_cu < 0) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, potrf_dataflow_kernel, 256, DIAG_LDS_BYTES) != hipSuccess) n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, potrf_dataflow_kernel<true>, 256, DIAG_LDS_BYTES) != hipSuccess) n = 0;
         ps.resident_per_cu = n;
     }
     if (ps.resident_per_cu < 1 || nprob < 1 || nprob > 8) return false;
@@ -1543,7 +1870,8 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
     a.inv_ck = std::max(1, std::min(8, (int)tune(TUNE_POTRI_CK, nb > 16 ? 2 : 1)));
     {
         PersistSerialScope serial(ps, s);
-        hipLaunchKernelGGL(potrf_dataflow_kernel, dim3(Gp * nprob + G2), dim3(256), DIAG_LDS_BYTES, s, a);
+        if (fuse) hipLaunchKernelGGL(potrf_dataflow_kernel<true>, dim3(Gp * nprob + G2), dim3(256), DIAG_LDS_BYTES, s, a);
+        else hipLaunchKernelGGL(potrf_dataflow_kernel<false>, dim3(Gp * nprob + G2), dim3(256), DIAG_LDS_BYTES, s, a);
     }
     // T_jj for every diagonal block, off the factorisation's serial chain (callers that only need the factor skip it; the fused
     // inverse builds them itself)
