@@ -179,6 +179,9 @@ struct PersistArgs {
     // the update is a whole-tile product (14 + 3 + 21 us against 39): a row that falls behind once never catches up, and sooner
     // or later it is the sub-diagonal one.  The first half's owner solves the tile once the second half has reported (upd_done).
     int split_sub, split_band;
+    // fused inverse, hybrid pool: the factorisation's tiles (i, k) with i - k > hybrid_near are dealt over BOTH teams (an inverse
+    // workgroup runs its factorisation tasks first); -1: the inverse team owns no tile of the factorisation (round-4 form)
+    int hybrid_near;
 };
 #define PK_STAMP(slot) do { if (a.trace && threadIdx.x == 0) a.trace[16 * j + (slot)] = wall_clock64(); } while (0)
 
@@ -1343,12 +1346,14 @@ template <bool FUSE>
 __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
-    if (a.g1 > 0 && (int)blockIdx.x >= a.g1) {
+    const bool inv_wg = a.g1 > 0 && (int)blockIdx.x >= a.g1;      // a workgroup of the inverse's team (nprob == 1)
+    if (inv_wg && a.hybrid_near < 0) {
         potri_team(a, (int)blockIdx.x - a.g1, (int)gridDim.x - a.g1, lds, smem);
         return;
     }
     // several independent problems share the launch: this workgroup's problem, its rank inside it, the problem's buffers
-    const int G = a.g1 > 0 ? a.g1 : gridDim.x / a.nprob, q = blockIdx.x / G, b = blockIdx.x - q * G, nb = a.nb, nbo = a.nbo;
+    const int G = a.g1 > 0 ? a.g1 : gridDim.x / a.nprob, q = inv_wg ? 0 : blockIdx.x / G, b = inv_wg ? G : blockIdx.x - q * G, nb = a.nb, nbo = a.nbo;
+    const int b2 = (int)blockIdx.x - a.g1, G2 = (int)gridDim.x - a.g1;   // inverse team: this workgroup, the team's size
     a.A += q * a.strideA;
     a.Linv += q * a.strideA;
     a.sync += q * a.stride_sync;
@@ -1485,27 +1490,30 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
     auto SW = [&](int arr, int k) -> int& { return reinterpret_cast<int*>(lds + k * DL + 128)[arr]; };
     const int tid = threadIdx.x;
     if (tid == 0) {
-        // worker index, XCD by XCD
-        unsigned x;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
-        const int xcc = (int)(x & 7);
-        // the tile -> owner map must be a bijection: every worker's count increment is ordered before its arrival (release) and
-        // the counts are read behind the rendezvous (acquire)
-        const int rank = __hip_atomic_fetch_add(a.sync + 8 + xcc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(a.sync + 1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        int ok = pk_spin(a.sync + 1, G - nchain, a.info + 1, a.timeout) ? 1 : 0;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        int widx = rank;
-        for (int q = 0; q < xcc; ++q) widx += __hip_atomic_load(a.sync + 8 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int W = G - nchain;
-        int nt = 0;
-        if (ok) {
+        int ok = 1, widx = -1, nt = 0;
+        if (!inv_wg) {
+            // worker index, XCD by XCD
+            unsigned x;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+            const int xcc = (int)(x & 7);
+            // the tile -> owner map must be a bijection: every worker's count increment is ordered before its arrival (release) and
+            // the counts are read behind the rendezvous (acquire)
+            const int rank = __hip_atomic_fetch_add(a.sync + 8 + xcc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(a.sync + 1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            ok = pk_spin(a.sync + 1, G - nchain, a.info + 1, a.timeout) ? 1 : 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            widx = rank;
+            for (int q = 0; q < xcc; ++q) widx += __hip_atomic_load(a.sync + 8 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const bool hybrid = a.g1 > 0 && a.hybrid_near >= 0;
+        const int band = a.split_band;
+        if (ok && !hybrid) {
             // tiles in column-major order (without (0, 0)) dealt round-robin: even in total work and at every stage (a cyclic
             // PR x PC owner grid left 1.4x the mean work on some owners: 5.7 vs 5.0 ms at N = 8192, round 3)
             // split_band: column k carries extra items, the second halves of its tiles (k+1, k) .. (k+band, k)
             int k = 0;
             long off = 0;                                    // items before column k
-            const int band = a.split_band;
             auto cnt = [&](int kk) { return nb - kk + min(band, nb - 1 - kk); };
             for (long t = widx; nt < DF_MAXT; t += W) {
                 const long tt = t + 1;                       // skip (0, 0)
@@ -1517,24 +1525,67 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
                 SW(6, nt) = second ? 2 : (e >= 1 && e <= band ? 1 : 0);        // 0 whole tile, 1 / 2: columns 0-63 / 64-127
                 ++nt;
             }
+        } else if (ok) {
+            // hybrid pool: the same items in the same order, two round-robin deals -- the tiles near the diagonal (whose tasks sit on or
+            // next to the chain's path) over the factorisation's own workers, the others over both teams
+            const int me_near = inv_wg ? -1 : widx, me_far = inv_wg ? W + b2 : widx;
+            int cn = 0, cf = 0;
+            for (int k = 0; k < nb; ++k) {
+                const int c = nb - k + min(band, nb - 1 - k);
+                for (int e = k == 0 ? 1 : 0; e < c; ++e) {
+                    const bool second = e >= nb - k;
+                    const int i = second ? k + 1 + (e - (nb - k)) : k + e;
+                    bool mine;
+                    if (i - k > a.hybrid_near) { mine = cf == me_far; if (++cf == W + G2) cf = 0; }
+                    else { mine = cn == me_near; if (++cn == W) cn = 0; }
+                    if (mine && nt < DF_MAXT) {
+                        SW(0, nt) = i; SW(1, nt) = k; SW(2, nt) = 0; SW(3, nt) = 0;
+                        SW(6, nt) = second ? 2 : (e >= 1 && e <= band ? 1 : 0);
+                        ++nt;
+                    }
+                }
+            }
         }
         SW(5, 0) = ok ? nt : -1;
+        int nt2 = 0;
+        if (inv_wg) {
+            // the inverse's items, dealt as in potri_team (arrays 8 .. 14)
+            int turn = 0;
+            auto deal = [&](int type, int i, int j) {
+                if (turn == b2 && nt2 < DF_MAXT) {
+                    SW(8, nt2) = i; SW(9, nt2) = j; SW(10, nt2) = (type == 1 && j == i - 1 && a.inv_plast) ? 1 : 0; SW(11, nt2) = 0; SW(14, nt2) = type;
+                    ++nt2;
+                }
+                if (++turn == G2) turn = 0;
+            };
+            for (int r = 0; r < nb; ++r) {
+                deal(0, r, r);
+                if (r > 0 && a.inv_plast) deal(4, r, r - 1);
+                for (int j = 0; j < r; ++j) deal(1, r, j);
+            }
+            for (int r = 0; r < nb; ++r)
+                for (int j = 0; j <= r; ++j) deal(2, r, j);
+        }
+        SW(13, 0) = nt2;
     }
     __syncthreads();
-    const int nt = SW(5, 0);
-    if (nt <= 0) return;
-    int first = 0;
+    const int nt = SW(5, 0), nt2 = SW(13, 0);
+    if (nt < 0 || (nt == 0 && nt2 == 0)) return;
+    int first = 0, first2 = 0;
     long long t_progress = wall_clock64();
     const int slot = tid >> 4, l = tid & 15;
     // optional statistics (probes): ticks of the 100 MHz clock in tasks / in scheduling rounds that found work / idle, task counts
     long long st_task = 0, st_idle = 0, st_t0 = t_progress, st_n_upd = 0, st_n_panel = 0, st_rounds = 0, st_gemm = 0, st_rmw = 0;
+    long long st2_task = 0, st2_n = 0, st2_last = 0;           // probes: the inverse's tasks of this workgroup
     for (;;) {
         while (first < nt && SW(3, first)) ++first;            // uniform: every thread reads the same LDS words
-        if (first >= nt) break;
+        while (first2 < nt2 && SW(11, first2)) ++first2;
+        if (first >= nt && first2 >= nt2) break;
         const long long st_round0 = a.trace ? wall_clock64() : 0;
         ++st_rounds;
+        int sel = -1, sel2 = -1;
         // ---- which tasks have their inputs? 16 lanes per tile, one flag per lane ----
-        {
+        if (first < nt) {
             const int t = first + slot;
             bool valid = t < nt && !SW(3, t);
             bool ok = true;
@@ -1562,14 +1613,27 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             const unsigned long long m = __ballot(ok);
             const unsigned grp = (unsigned)(m >> (16 * ((tid >> 4) & 3))) & 0xffffu;
             if (l == 0) SW(4, slot) = (valid && grp == 0xffffu) ? 1 : 0;
-        }
-        __syncthreads();
-        int sel = -1;
+            __syncthreads();
 #pragma unroll
-        for (int q = DF_WIN - 1; q >= 0; --q)
-            if (SW(4, q)) sel = q;
-        __syncthreads();
-        if (sel < 0) {
+            for (int q = DF_WIN - 1; q >= 0; --q)
+                if (SW(4, q)) sel = q;
+            __syncthreads();
+        }
+        if (sel < 0 && first2 < nt2) {                         // nothing of the factorisation's is ready: the inverse's items (potri_team's round)
+            const int t = first2 + slot;
+            const bool valid = t < nt2 && !SW(11, t);
+            bool ok = true;
+            if (valid) ok = potri_item_ready(a, SW(14, t), SW(8, t), SW(9, t), SW(10, t), l);
+            const unsigned long long m = __ballot(ok);
+            const unsigned grp = (unsigned)(m >> (16 * ((tid >> 4) & 3))) & 0xffffu;
+            if (l == 0) SW(12, slot) = (valid && grp == 0xffffu) ? 1 : 0;
+            __syncthreads();
+#pragma unroll
+            for (int q = DF_WIN - 1; q >= 0; --q)
+                if (SW(12, q)) sel2 = q;
+            __syncthreads();
+        }
+        if (sel < 0 && sel2 < 0) {
             if (__hip_atomic_load(a.info + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
             if (wall_clock64() - t_progress > a.timeout) {
                 if (tid == 0) __hip_atomic_store(a.info + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1582,6 +1646,18 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
         if (tid < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // correct by the memory model, not only by first-touch reasoning
         __syncthreads();
         const long long st_task0 = a.trace ? wall_clock64() : 0;
+        if (sel < 0) {
+            const int t = first2 + sel2;
+            const PotriStep step = potri_item_task(a, SW(14, t), SW(8, t), SW(9, t), SW(10, t), lds, smem);
+            if (tid == 0) {
+                SW(10, t) = step.d;
+                if (step.done) SW(11, t) = 1;
+            }
+            __syncthreads();
+            t_progress = wall_clock64();
+            if (a.trace) { st2_task += t_progress - st_task0; ++st2_n; st2_last = t_progress; }
+            continue;
+        }
         const int t = first + sel;
         const int i = SW(0, t), k = SW(1, t), d = SW(2, t);
         const int target = i == k ? k - 1 : k;
@@ -1697,8 +1773,15 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
         if (a.trace) st_task += t_progress - st_task0;
     }
     if (a.trace && tid == 0) {
-        long long* o = a.trace + 16 * (long)nb + 16 * (long)(b - 1);
-        o[0] = st_task; o[1] = st_idle; o[2] = wall_clock64() - st_t0; o[3] = st_n_upd; o[4] = st_n_panel; o[5] = st_rounds; o[6] = nt; o[7] = st_gemm; o[8] = st_rmw;
+        if (inv_wg) {                                           // potri_team's record (o[6] < 0), busy time of both kinds of tasks
+            long long* o = a.trace + 16 * (long)nb + 16 * (long)(a.g1 - 1 + b2);
+            const long long t_end = wall_clock64();
+            o[0] = st_task + st2_task; o[2] = t_end - st_t0; o[3] = st2_n + st_n_upd + st_n_panel; o[6] = -(nt + nt2); o[9] = st_t0; o[10] = st2_last ? st2_last : t_end;
+            o[11] = st_task; o[12] = st_n_upd + st_n_panel;
+        } else {
+            long long* o = a.trace + 16 * (long)nb + 16 * (long)(b - 1);
+            o[0] = st_task; o[1] = st_idle; o[2] = wall_clock64() - st_t0; o[3] = st_n_upd; o[4] = st_n_panel; o[5] = st_rounds; o[6] = nt; o[7] = st_gemm; o[8] = st_rmw;
+        }
     }
 }
 
@@ -1837,7 +1920,7 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
         // the chip builds the inverse.  Measured (tools/probes/potri_scan.sh; ms, factor + inverse): N = 4096: 96 workers 2.12,
         // 80: 2.22, 112: 2.26, 136: 2.56, 48: 3.05 (separate launches: 2.62); N = 3072: 1.46-1.50 for 80-112 (1.92);
         // N = 2048: 0.84-0.86 for 80-112, 0.89 for 135 (1.18); same bits for every split
-        const int w1_dflt = std::min(tiles, std::max(3 * n_cu / 8, 3 * nb));
+        const int w1_dflt = std::min(tiles, std::max(3 * n_cu / 8, 3 * nb));   // (round-4 split; the hybrid pool's default below)
         const int W1 = std::max(1, std::min(tiles, (int)tune(TUNE_POTRI_W1, w1_dflt)));
         Gp = nchain + W1;
         G2 = n_cu * ps.resident_per_cu - Gp;
@@ -1863,6 +1946,7 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
     a.nchain = nchain;
     a.split_sub = split_sub;
     a.split_band = split_band;
+    a.hybrid_near = inv ? (int)tune(TUNE_POTRI_HYBRID, -1) : -1;
     // measured (ms, factor + inverse; two products per row -> one): N = 384: 0.209 -> 0.234, 1024: 0.405 -> 0.411, 2048: 0.759 -> 0.753,
     // 3072: 1.466 -> 1.32, 4096: 2.15 -> 2.15 (there the two teams are short of CUs, not of time on the wavefront)
     a.inv_plast = (int)tune(TUNE_POTRI_PLAST, nb >= 12 ? 1 : 0) != 0 ? 1 : 0;
