@@ -45,6 +45,11 @@ namespace sequential_line_search
         /// (their optima are this layer's parity anchors; SLS_MAP_FIT_TOL opts in, see host/device.hpp).
         void SetLocalSearchTolerances(double relative_func_tolerance, double relative_param_tolerance);
         void GetLocalSearchTolerances(double* relative_func_tolerance, double* relative_param_tolerance);
+        /// The same pair for the two MAP fits (GaussianProcessRegressor::PerformMapEstimation, PreferenceRegressor's).  Initial
+        /// values 0 / 0 (off) -- a DEVIATION from the reference, whose fits run under nloptutil::solve's 1e-6 defaults like every
+        /// other search: pass (1e-6, 1e-6) for the reference's evaluation counts (INTEGRATION.md 2 says why off is the default).
+        void SetMapFitTolerances(double relative_func_tolerance, double relative_param_tolerance);
+        void GetMapFitTolerances(double* relative_func_tolerance, double* relative_param_tolerance);
 
         /// Acquisition value at x (0 if the regressor holds no data).  `..._hyperparam` is the GP-UCB trade-off weight
         /// (ignored for EI).

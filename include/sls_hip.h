@@ -16,14 +16,23 @@
  *   - return 0 on success, <0 on error; sls_last_error() describes the last
  *     failure of the calling thread.  There is NO CPU fallback: every entry point
  *     runs hand-written gfx950 kernels and fails if no GPU is present.
- *   - a context owns one HIP stream and one lock: EVERY entry point that takes a
- *     context or a handle created from it holds that (recursive) lock for the whole
- *     call, so a context and its handles may be shared by any number of host threads
- *     -- the reference shares one const regressor across hardware_concurrency worker
- *     threads (src/acquisition-function.cpp:125-144) -- but their calls are SERIALISED
- *     in arrival order, not run concurrently.  Parallelism comes from batching (M
- *     points / S starts per call), not from concurrent callers; use one context per
- *     thread (or sls_multi, one per GPU) for independent streams of work.
+ *   - a context owns one HIP stream and one (recursive) lock; a context and its
+ *     handles may be shared by any number of host threads -- the reference shares one
+ *     const regressor across hardware_concurrency worker threads
+ *     (src/acquisition-function.cpp:125-144).  Two kinds of calls:
+ *       * const evaluations of at most 64 points on a small handle (N <= 512, D <= 128:
+ *         sls_gp_predict, sls_gp_predict_grad, sls_acq_eval) do NOT take the context's
+ *         lock: each borrows one of the context's evaluation slots (own stream, own
+ *         mapped result block) under a SHARED lock on the handle's fitted state and
+ *         runs concurrently with the others (SLS_EVAL_SLOTS=0 restores the lock);
+ *       * everything else -- fits, refits, sls_gp_append_point, sls_gp_set_sigma_mode,
+ *         maximisers, MAP fits, larger evaluations -- holds the context's lock for the
+ *         whole call (mutators also take the handle's state lock exclusively) and is
+ *         SERIALISED in arrival order.
+ *     A handle must outlive every call in flight on it: sls_gp_destroy waits for
+ *     the evaluations that hold its state lock, but a call that STARTS after the
+ *     destroy is a use after free, as with any C handle.  For independent streams of
+ *     large work use one context per thread (or sls_multi, one per GPU).
  */
 #ifndef SLS_HIP_H
 #define SLS_HIP_H
@@ -136,6 +145,10 @@ int sls_acq_eval(sls_gp* gp, int acq_type, double ucb_h, const double* Xs, int M
  * idx_out is the winning start's index plus start_index_offset (so that ranks sharding one global start set report
  * global indices).  x_stars (D x S) / y_stars (S) may be NULL. */
 typedef struct sls_lbfgs_opts {
+    /* sizeof(sls_lbfgs_opts) as the CALLER's header declares it (sls_lbfgs_default_opts fills it in).  The struct is caller-
+     * allocated and has grown once already (ftol_rel / xtol_rel, round 5): the library reads struct_size bytes and takes its
+     * defaults for members beyond them, and refuses a size it does not know (0, or larger than its own). */
+    int struct_size;
     int history;        /* L-BFGS memory m (1..8), default 6 */
     double c1;          /* Armijo constant, default 1e-4 */
     double shrink;      /* backtracking factor, default 0.5 */

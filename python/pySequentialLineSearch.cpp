@@ -87,6 +87,12 @@ PYBIND11_MODULE(pySequentialLineSearch, m)
         acquisition_func::GetLocalSearchTolerances(&f, &x);
         return std::make_pair(f, x);
     });
+    m.def("set_map_fit_tolerances", &acquisition_func::SetMapFitTolerances, "relative_func_tolerance"_a, "relative_param_tolerance"_a);
+    m.def("get_map_fit_tolerances", [] {
+        double f = 0.0, x = 0.0;
+        acquisition_func::GetMapFitTolerances(&f, &x);
+        return std::make_pair(f, x);
+    });
     m.def("set_devices", &device::SetDevices, "devices"_a);
     m.def("get_devices", [] { return device::Devices(); });
 

@@ -29,8 +29,12 @@ class SlsError(RuntimeError):
 
 
 class LbfgsOpts(C.Structure):
-    _fields_ = [("history", C.c_int), ("c1", C.c_double), ("shrink", C.c_double), ("gtol", C.c_double),
+    """sls_lbfgs_opts (include/sls_hip.h).  struct_size is filled in here; the positional arguments are the option members."""
+    _fields_ = [("struct_size", C.c_int), ("history", C.c_int), ("c1", C.c_double), ("shrink", C.c_double), ("gtol", C.c_double),
                 ("max_backtracks", C.c_int), ("ftol_rel", C.c_double), ("xtol_rel", C.c_double)]
+
+    def __init__(self, history=6, c1=1e-4, shrink=0.5, gtol=0.0, max_backtracks=20, ftol_rel=0.0, xtol_rel=0.0):
+        super().__init__(C.sizeof(LbfgsOpts), history, c1, shrink, gtol, max_backtracks, ftol_rel, xtol_rel)
 
 
 def lib():

@@ -1,4 +1,6 @@
 // C-ABI of libsls_hip (include/sls_hip.h): host orchestration of the gfx950 kernels.  No CPU fallback.
+#include <cstddef>
+#include <cstring>
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -412,6 +414,8 @@ struct sls_gp {
     std::vector<double> il_h, ypad_h;   // upload staging that lives with the handle: no synchronisation between the uploads and the fit
     bool host_stale = false;   // sls_gp_refit_dev replaced the device X / y: Xh / yh are refreshed before their next use
     DBuf X, y, inv_ell, XT, XaT, nx, L, Linv, Kinv, U, alpha, tvec, mu_data, scal, gemv_part, idx_buf;   // U = (L^-1)^T, needed by the fit only
+    const double* linv_clean_p = nullptr;   // the Linv buffer / leading dimension whose blocks above the diagonal are known to be zero
+    int linv_clean_np = 0;
     long* d_idx = nullptr;             // idx_buf's block (pooled: a hipMalloc / hipFree pair per handle synchronised the device)
     // what the host reads after a fit -- max mu, log|K_y|, arg max, the factorisation's two info words -- in a page-locked block the
     // last kernel of the fit writes directly (mapped): one synchronisation, no copies back (they were three blocking pageable copies)
@@ -502,7 +506,14 @@ static void gp_fit_device(sls_gp* g) {
         launch_gram_sym(c->stream, g->XT.p, Np, g->Dp, g->nx.p, Np, N, ks, g->b, g->L.p, true);
     }
     SLS_HIP(hipMemsetAsync(c->d_info, 0, 64, c->stream));
-    launch_fill(c->stream, g->Linv.p, (long)Np * Np, 0.0);
+    // L^-1 is read as a full matrix (gemv, the plain-product predict): its blocks above the diagonal must be zero.  Nothing ever
+    // writes them -- the factorisation, the inverse and the rank-1 growth touch blocks on and below the diagonal only -- so they are
+    // cleared when the buffer is new or its leading dimension changed, not on every refit (a 512 MB sweep, 91 us, at N = 8192).
+    if (g->linv_clean_p != g->Linv.p || g->linv_clean_np != Np) {
+        launch_fill(c->stream, g->Linv.p, (long)Np * Np, 0.0);
+        g->linv_clean_p = g->Linv.p;
+        g->linv_clean_np = Np;
+    }
     c->potrf_tick_rearm();
     int* df_sync = c->potrf_df_sync(Np);
     if (potri_fused_applies(Np, df_sync != nullptr)) {
@@ -632,6 +643,9 @@ extern "C" int sls_gp_destroy(sls_gp* gp) {
         std::unique_lock<std::recursive_mutex> lock_(c->mtx);
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
+        // evaluations that run on the context's slots without its lock (eval_in_slot) hold the state lock shared until their slot's
+        // stream has drained: taking it exclusively waits for them.  Released before the delete (it is a member).
+        { std::unique_lock<std::shared_mutex> drain_(gp->state_mtx); }
         delete gp;
     }
     slsk::ctx_release(c);
@@ -1151,7 +1165,21 @@ extern "C" int sls_acq_eval(sls_gp* g, int acq_type, double ucb_h, const double*
 
 // ---- multi-start maximiser -------------------------------------------------------------------------------------
 extern "C" void sls_lbfgs_default_opts(sls_lbfgs_opts* o) {
+    o->struct_size = (int)sizeof(sls_lbfgs_opts);
     o->history = 6; o->c1 = 1e-4; o->shrink = 0.5; o->gtol = 0.0; o->max_backtracks = 20; o->ftol_rel = 0.0; o->xtol_rel = 0.0;
+}
+// the caller's struct may be shorter than this library's (an older header): its struct_size bytes over the defaults
+static sls_lbfgs_opts read_lbfgs_opts(const sls_lbfgs_opts* in) {
+    sls_lbfgs_opts o;
+    sls_lbfgs_default_opts(&o);
+    if (!in) return o;
+    const int min_size = (int)(offsetof(sls_lbfgs_opts, max_backtracks) + sizeof(int));   // the members of the first version
+    SLS_REQUIRE(in->struct_size >= min_size && in->struct_size <= (int)sizeof(sls_lbfgs_opts),
+                "sls_lbfgs_opts.struct_size = %d: expected %d .. %d (call sls_lbfgs_default_opts first)", in->struct_size, min_size,
+                (int)sizeof(sls_lbfgs_opts));
+    memcpy(&o, in, (size_t)in->struct_size);
+    o.struct_size = (int)sizeof(sls_lbfgs_opts);
+    return o;
 }
 
 static void ensure_lbfgs(sls_gp* g, int Sp, int m) {
@@ -1194,8 +1222,7 @@ static void maximize_impl(sls_gp* g, sls_gp* gs, int acq_type, double ucb_h, con
     sls_ctx* c = g->ctx;
     SLS_REQUIRE(S >= 1 && n_local >= 1, "sls_acq_maximize: need S >= 1 and n_local >= 1");
     SLS_REQUIRE(acq_type == SLS_ACQ_EXPECTED_IMPROVEMENT || acq_type == SLS_ACQ_GP_UCB, "unknown acquisition type %d", acq_type);
-    sls_lbfgs_opts o;
-    if (opts_in) o = *opts_in; else sls_lbfgs_default_opts(&o);
+    const sls_lbfgs_opts o = read_lbfgs_opts(opts_in);
     SLS_REQUIRE(o.history >= 1 && o.history <= 8, "L-BFGS history must be in 1..8");
     const int Sp = round_up(S, 128), D = g->D;
     ensure_lbfgs(g, Sp, o.history);

@@ -113,7 +113,7 @@ struct sls_ctx {
     slsk::DBuf potrf_df;                 // flag tables of the dataflow form (grown on demand)
     int* potrf_df_sync(int Np);          // nullptr: single-launch form switched off for this context (no side effects)
     bool potrf_df_available(int Np) const;   // the same question without allocating the flag tables
-    bool potrf_single_pending = false;
+    bool potrf_single_pending = false;   // a single-launch factorisation was handed its flag tables since the last verdict
     // streams + device-mapped page-locked blocks lent to concurrent small evaluations (capi.hip: eval_in_slot), created on demand,
     // kept for the life of the context
     struct EvalSlot {
@@ -126,7 +126,7 @@ struct sls_ctx {
     std::mutex slot_mtx;
     std::condition_variable slot_cv;
     std::vector<std::unique_ptr<EvalSlot>> slots;
-    static constexpr int MAX_SLOTS = 16;   // a single-launch factorisation was handed its flag tables since the last verdict
+    static constexpr int MAX_SLOTS = 16;   // concurrent small evaluations per context; further callers wait for a free slot
 
     // page-locked host blocks (result blocks the small-problem kernels write directly, staging for uploads) handed out to the
     // handles of this context and taken back when a handle dies: hipHostMalloc + hipHostFree cost ~260 us per block (round 4, C3:

@@ -35,6 +35,29 @@ inline void ensure_dyn_lds(const void* fn, int bytes) {
     }
 }
 
+// Geometry of the CURRENT device, read once per device: compute units, and the XCDs (each with its own L2) they sit in.  HIP has no
+// attribute for the latter; gfx950 builds an XCD from 32 active CUs and hands out workgroups round-robin over a partition's XCDs
+// (SPX: 256 CUs = 8 XCDs; a CPX partition: 32 CUs = 1).  A CU count that is not a multiple of 32 is treated as one XCD.
+struct ChipGeometry {
+    int n_cu, n_xcd;
+};
+inline ChipGeometry chip_geometry() {
+    static std::mutex mtx;
+    static std::map<int, ChipGeometry> table;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mtx);
+    auto it = table.find(dev);
+    if (it != table.end()) return it->second;
+    int v = 0;
+    (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+    ChipGeometry g;
+    g.n_cu = v > 0 ? v : 64;
+    g.n_xcd = (g.n_cu % 32 == 0) ? g.n_cu / 32 : 1;
+    table[dev] = g;
+    return g;
+}
+
 struct KernelSpec {
     int kernel;   // SLS_KERNEL_*
     double a;     // signal variance theta[0]

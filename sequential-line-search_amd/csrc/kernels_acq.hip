@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256, 1) void acq_gemm_kernel(const double* __restri
                                                           int Sp, const double* __restrict__ Kinv, int Np,
                                                           double* __restrict__ P, double* __restrict__ kw_part,
                                                           double* __restrict__ cw_part, int* __restrict__ sync,
-                                                          int phase, int ntiles, int prio, int gate_every) {
+                                                          int phase, int ntiles, int prio, int gate_every, int nx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
     const int ntm = Sp / GEMM_BM, ntn = Np / GEMM_BN;
@@ -134,7 +134,8 @@ __global__ __launch_bounds__(256, 1) void acq_gemm_kernel(const double* __restri
         acq_tile<MATERN, false>(xcd_remap(blockIdx.x, ntiles), 0, ntm, ntn, Ks, Cs, ldk, Kinv, Np, P, kw_part, cw_part, lds);
         return;
     }
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    // nx: the device's XCDs (launch_acq_gemm reads the geometry from the device; workgroups go round-robin over them)
+    const int xcd = blockIdx.x % nx, slot = blockIdx.x / nx, slots = gridDim.x / nx;
     const int nchunks = (ntiles + slots - 1) / slots;
     // Slots s and s + slots/2 of an XCD share a CU (cu_probe.hip: all 256 pairs).  With `phase` the two halves are gated
     // separately and the upper half starts `phase` ticks (100 MHz) late, so the two workgroups of a CU never run their
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256, 1) void acq_gemm_kernel(const double* __restri
         __syncthreads();
     }
     int gen = 0;
-    for (int c = xcd; c < nchunks; c += 8, ++gen) {
+    for (int c = xcd; c < nchunks; c += nx, ++gen) {
         if (gen > 0 && phase >= 0 && gen % gate_every == 0) {   // phase < 0: persistent but ungated (SLS_PERSIST=2)
             if (threadIdx.x == 0) {
                 const int target = per_gen * gen;
@@ -215,7 +216,9 @@ int launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk,
     // 0.25 % faster than one workgroup per tile (4293 / 4298 -> 4285 / 4282 ms): no workgroup launch between tiles.
     // 2 = two per CU, generation-gated (the round-1 form).
     const int wg_per_cu = tune(TUNE_ACQ_WG_PER_CU, 1) == 2 ? 2 : 1;
-    const int cap = 256 * wg_per_cu;                                 // tiles the chip holds at a time
+    const ChipGeometry chip = chip_geometry();                       // from the device, not literals: a partitioned device has fewer CUs / XCDs
+    const int cap = chip.n_cu * wg_per_cu;                           // tiles the chip holds at a time (MI355X, SPX: 256 or 512)
+    const int nx = (chip.n_xcd <= 8 && cap % chip.n_xcd == 0) ? chip.n_xcd : 1;   // the gate table has 2 x 8 words
     const int lds_bytes = wg_per_cu == 1 ? 96 * 1024 : GEMM_LDS_BYTES;
     ensure_dyn_lds((const void*)acq_gemm_kernel<false>, lds_bytes);
     ensure_dyn_lds((const void*)acq_gemm_kernel<true>, lds_bytes);
@@ -241,10 +244,10 @@ int launch_acq_gemm(hipStream_t s, const double* Ks, const double* Cs, long ldk,
     if (nmain > 0) {
         if (matern)
             hipLaunchKernelGGL(acq_gemm_kernel<true>, dim3(grid), dim3(GEMM_THREADS), lds_bytes, s, Ks, Cs, ldk, Sp, Kinv, Np, P,
-                               kw_part, cw_part, sy, phase_k, nmain, prio, gate_every);
+                               kw_part, cw_part, sy, phase_k, nmain, prio, gate_every, nx);
         else
             hipLaunchKernelGGL(acq_gemm_kernel<false>, dim3(grid), dim3(GEMM_THREADS), lds_bytes, s, Ks, Cs, ldk, Sp, Kinv, Np, P,
-                               kw_part, cw_part, sy, phase_k, nmain, prio, gate_every);
+                               kw_part, cw_part, sy, phase_k, nmain, prio, gate_every, nx);
     }
     if (tail > 0) {
         if (matern)

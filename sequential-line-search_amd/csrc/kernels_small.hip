@@ -216,6 +216,13 @@ __device__ __forceinline__ SmallPts small_pts_stage(double* As, const double* __
     return p;
 }
 
+// May this evaluation use the norm expansion?  (uniform: every wave computes the same bound from the 1 / l in the scratch, zeros beyond D)
+__device__ __forceinline__ bool small_mc_form_ok(double* As, int D) {
+    const int l64 = threadIdx.x & 63;
+    const double ilm = wave_max(fmax(small_scratch(As, SC_INVL + l64), small_scratch(As, SC_INVL + 64 + l64)));
+    return ilm * ilm * (0.5 * D) * 2.3e-16 <= 1e-11;
+}
+
 // q_ij = sum_d ((x_id - x_jd) / l_d)^2 in dimension order, B dimensions' operands in flight at a time
 template <int B, class Pts>
 __device__ __forceinline__ double small_pair_q(const Pts& x, int D, int i, int j, double* As) {
@@ -304,7 +311,13 @@ __device__ __forceinline__ double small_build_factor(double* As, double* Ts, con
                 }
             });
     };
-    if (pts.lds) {
+    // The matrix-core form takes q_ij from the norm expansion |x~_i|^2 + |x~_j|^2 - 2 x~_i . x~_j, whose cancellation error is about
+    // eps (|x~_i|^2 + |x~_j|^2) <= eps D / (2 l_min^2) ABSOLUTE in q -- nothing at the usual length scales, but the DIRECT phase of the GP
+    // MAP fit takes l down to 1e-8, where near-duplicate points (normal late in a line search) would get q wrong by O(1) and the
+    // clamp at 0 would hide it.  Beyond 1e-11 the evaluation uses the direct differences (which are exact for near-duplicates):
+    // every wave forms the bound itself (two reads, one wave-wide maximum), so the branch is uniform.
+    const bool mc_form = pts.lds != 0 && small_mc_form_ok(As, D);
+    if (mc_form) {
         // Matrix-core form.  (1) The dot products x~_i . x~_j / l^2 of the lower tiles, one 16 x 16 tile per wave and trip, straight
         // into the image; the diagonal of a diagonal tile is |x~_i|^2 and goes to the scratch (SC_NX).  (2) q_ij from the norm
         // expansion and the kernel function per element.
@@ -601,7 +614,7 @@ __device__ __forceinline__ double small_grad(double* As, const SmallPts& pts, co
                                              double& e1, double& e2) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nb16 = (N + 15) >> 4;
-    const bool mm = pts.lds != 0;   // matrix-core contraction
+    const bool mm = pts.lds != 0 && small_mc_form_ok(As, D);   // matrix-core contraction (the same expansion, the same guard as the Gram pass)
     double sa = 0.0;
     if (want_grad) {
         // one batch of four slots, without branches around the loads: alpha_i, alpha_j, K^-1_ij of the four first

@@ -29,6 +29,7 @@ struct GemmDesc {
     int kmode;         // 0: [0,K)  1: [128 tn, K)  2: [0, 128 (tm+1))  3: [128 max(tm,tn), K)  4: [128 tm, K)
     int vb_stride, vb_off, vb_limit;   // tile row (vb_on_n: tile column) valid iff batch*vb_stride + vb_off + tm (tn) < vb_limit
     int vb_on_n;
+    int mirror;        // 1 (square lower-triangular outputs): tile (tm, tn), tm > tn, is also written transposed at (tn, tm)
 };
 
 // NJ = 4: one workgroup per 128 x 128 tile.  NJ = 2 (both operands M-contiguous only): two workgroups per tile, each the 64
@@ -83,6 +84,10 @@ __global__ __launch_bounds__(256, 2) void tri_gemm_kernel(GemmDesc g) {
                 double v = g.alpha * acc.v[i][j][r];
                 if (g.beta != 0.0) v += g.beta * *c;
                 *c = v;
+                // the mirror tile from the same registers (lauum: K^-1 is used as a full matrix; a separate pass over the finished
+                // matrix read and wrote N^2 / 2 elements again: 91 us at N = 8192).  Four consecutive columns per lane group and
+                // store, a full 128-byte line per row over r = 0 .. 3.
+                if (g.mirror && tm != tn) C[(long)(n0 + ncol0 + 16 * j + (lane >> 4) + 4 * r) + (long)(m0 + acc_m(i)) * g.ldc] = v;
             }
 }
 
@@ -117,7 +122,7 @@ static GemmDesc mkdesc(const double* A, long lda, const double* B, long ldb, dou
     g.B = B; g.ldb = ldb; g.strideB = 0;
     g.C = C; g.ldc = ldc; g.strideC = 0;
     g.mt = mt; g.nt = nt; g.K = K; g.alpha = alpha; g.beta = beta;
-    g.tri = 0; g.tri_off = 0; g.order = 0; g.kmode = 0; g.vb_stride = 0; g.vb_off = 0; g.vb_limit = 1 << 30; g.vb_on_n = 0;
+    g.tri = 0; g.tri_off = 0; g.order = 0; g.kmode = 0; g.vb_stride = 0; g.vb_off = 0; g.vb_limit = 1 << 30; g.vb_on_n = 0; g.mirror = 0;
     return g;
 }
 
@@ -258,20 +263,6 @@ void launch_trtri(hipStream_t s, const double* L, int Np, double* Linv, double* 
     }
 }
 
-__global__ __launch_bounds__(256) void symmetrize_kernel(double* __restrict__ A, int Np) {
-    // copy the lower triangle into the upper one through a 32x33 LDS tile (both sides coalesced)
-    __shared__ double tile[32][33];
-    const int bi = blockIdx.x, bj = blockIdx.y;
-    if (bj > bi) return;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-    for (int r = ty; r < 32; r += 8) tile[r][tx] = A[(long)(32 * bi + tx) + (long)(32 * bj + r) * Np];   // tile[c][r_in]
-    __syncthreads();
-    for (int r = ty; r < 32; r += 8) {
-        const int gi = 32 * bj + tx, gj = 32 * bi + r;   // transposed position
-        if (gi < gj) A[(long)gi + (long)gj * Np] = tile[tx][r];
-    }
-}
-
 // K^-1 = X^T X = U U^T with U = X^T (launch_trtri): lower tiles, A elem(m,k) = U[m + k ld], B elem(n,k) = U[n + k ld] (both
 // M-contiguous), k >= 128 max(tm,tn) = 128 tm.
 void launch_lauum(hipStream_t s, const double* U, int Np, double* Kinv) {
@@ -281,6 +272,7 @@ void launch_lauum(hipStream_t s, const double* U, int Np, double* Kinv) {
     g.tri = 1;
     g.kmode = 3;
     g.order = 1;            // rows from the top, longest k range first, no idle workgroups
+    g.mirror = 1;           // both triangles in one pass
     // small matrices leave most workgroup slots empty: half tiles double the count (SLS_LAUUM_N64=0/1 overrides)
     const int n64_env = (int)tune(TUNE_LAUUM_N64, -1);
     // measured inside the C5 evaluation (N = 4096): 3.41 -> 3.24 ms per evaluation with half tiles (the longest tile's k loop,
@@ -288,7 +280,6 @@ void launch_lauum(hipStream_t s, const double* U, int Np, double* Kinv) {
     const bool narrow = n64_env >= 0 ? n64_env != 0 : nb <= 32;
     if (narrow) launch_tri_gemm_mc_half(s, g, 1);
     else launch_tri_gemm<false, false>(s, g, 1);
-    hipLaunchKernelGGL(symmetrize_kernel, dim3(Np / 32, Np / 32), dim3(256), 0, s, Kinv, Np);
 }
 
 // A (SPD, lower triangle read) -> L in place, Linv = L^-1, U = Linv^T (blocks on and above the diagonal), Kinv = A^-1 (full).

@@ -99,6 +99,8 @@ namespace sequential_line_search
     } // namespace
     void acquisition_func::SetLocalSearchTolerances(double f, double x) { optim::SetSearchTolerances(f, x); }
     void acquisition_func::GetLocalSearchTolerances(double* f, double* x) { optim::SearchTolerances(f, x); }
+    void acquisition_func::SetMapFitTolerances(double f, double x) { optim::SetMapFitTolerances(f, x); }
+    void acquisition_func::GetMapFitTolerances(double* f, double* x) { optim::MapFitTolerances(f, x); }
 
     void acquisition_func::SetGlobalSearchStrategy(GlobalSearchStrategy strategy) { g_strategy.store(static_cast<int>(strategy)); }
     GlobalSearchStrategy acquisition_func::GetGlobalSearchStrategy()

@@ -198,14 +198,28 @@ namespace sequential_line_search
             if (x) *x = g_xtol_rel.load();
         }
 
+        namespace
+        {
+            std::atomic<double> g_map_ftol_rel{-1.0}, g_map_xtol_rel{-1.0};
+            void                InitMapTolerances()
+            {
+                if (g_map_ftol_rel.load() >= 0.0) return;
+                const char*  e = std::getenv("SLS_MAP_FIT_TOL");   // read once per process; off unless set
+                const double v = e ? std::max(0.0, std::atof(e)) : 0.0;
+                g_map_xtol_rel.store(v);
+                g_map_ftol_rel.store(v);
+            }
+        } // namespace
+        void SetMapFitTolerances(double f, double x)
+        {
+            g_map_xtol_rel.store(std::max(0.0, x));
+            g_map_ftol_rel.store(std::max(0.0, f));
+        }
         void MapFitTolerances(double* f, double* x)
         {
-            static const double v = [] {   // read once per process
-                const char* e = std::getenv("SLS_MAP_FIT_TOL");
-                return e ? std::max(0.0, std::atof(e)) : 0.0;
-            }();
-            if (f) *f = v;
-            if (x) *x = v;
+            InitMapTolerances();
+            if (f) *f = g_map_ftol_rel.load();
+            if (x) *x = g_map_xtol_rel.load();
         }
 
         std::vector<double> MaximizeBounded(const Objective& f, std::vector<double> x, const std::vector<double>& lo,

@@ -98,14 +98,19 @@ namespace sequential_line_search
                                             int* evals_used = nullptr, double ftol_rel = 0.0, double xtol_rel = 0.0);
 
         /// The relative tolerances every search of this layer runs with: nloptutil::solve's defaults relative_func_tolerance =
-        /// relative_param_tolerance = 1e-6, SLS_LOCAL_SEARCH_TOL=<v> sets both (0 = off).  One setting for
-        /// the acquisition maximiser's local searches and the MAP fits (acquisition_func::SetLocalSearchTolerances is its setter).
+        /// relative_param_tolerance = 1e-6, SLS_LOCAL_SEARCH_TOL=<v> sets both (0 = off).  The setting of the
+        /// acquisition maximiser's local searches ONLY (acquisition_func::SetLocalSearchTolerances is its setter); the MAP fits have
+        /// their own pair, below.
         void SetSearchTolerances(double ftol_rel, double xtol_rel);
         void SearchTolerances(double* ftol_rel, double* xtol_rel);
         /// The MAP fits do NOT take those by default: their optima are what pins this layer to independent implementations (scipy,
         /// tests/golden/map_optima*.npz), and NLopt's tests look at ONE step -- on the slow tail of the joint preference fit a step
         /// below 1e-6 still leaves 4e-4 of the objective on the table (tests/test_gpu_map_device.py).  SLS_MAP_FIT_TOL=<v> opts in
-        /// (both tolerances; what nloptutil::solve's defaults would do to the reference's fits is v = 1e-6).
+        /// (both tolerances; what nloptutil::solve's defaults would do to the reference's fits is v = 1e-6), and so does
+        /// SetMapFitTolerances (acquisition_func::SetMapFitTolerances / set_map_fit_tolerances in the Python module) at run time.
+        /// This is a deviation from the reference, where the same nloptutil::solve defaults apply to the TNEWTON MAP fits too:
+        /// INTEGRATION.md 2.
+        void SetMapFitTolerances(double ftol_rel, double xtol_rel);
         void MapFitTolerances(double* ftol_rel, double* xtol_rel);
 
         /// values[k] = f(xs[k]) for a whole batch of points (one device call per batch).

@@ -125,6 +125,38 @@ def test_matrix_core_form_and_direct_difference_form_agree(ctx, oracle, kernel, 
     np.testing.assert_allclose(fast[3], direct[3], rtol=1e-10, atol=1e-10 * max(1.0, np.abs(ggo).max()))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", [0, 1])
+@pytest.mark.parametrize("ell", [3e-3, 1e-5, 1e-8])
+def test_small_length_scales_with_near_duplicates_take_the_direct_form(ctx, oracle, kernel, ell):
+    """ADVICE (round 5): the matrix-core Gram pass expands q_ij = |x~_i|^2 + |x~_j|^2 - 2 x~_i . x~_j, whose cancellation error is
+    eps D / (2 l^2) absolute -- O(1) at the l = 1e-8 the DIRECT phase of the GP MAP fit visits, exactly where near-duplicate points
+    (late in a line search) have a small TRUE q.  Such evaluations must take the direct differences: the marginal likelihood and its
+    gradient with near-duplicates at small l agree with the oracle (which forms differences) and with SLS_SMALL_XLDS=0."""
+    rng = np.random.default_rng(11 + kernel)
+    M, D = 40, 6
+    X = rng.uniform(0, 1, (D, M))
+    X[:, 1] = X[:, 0] + ell * 0.3 * rng.normal(size=D)        # q ~ 0.5 at this length scale: the kernel value is O(1), not 0 or 1
+    X[:, 7] = X[:, 6] + ell * 1.0 * rng.normal(size=D)
+    y = rng.normal(size=M) * 0.3
+    hyp = np.concatenate([[0.7, 5e-3], np.full(D, ell)])
+
+    def run():
+        h = sls().Nll(ctx, X, kernel)
+        vg, gg = h.gp_objective(y, hyp)
+        h.close()
+        return vg, gg
+    fast = run()
+    with env_switch("SLS_SMALL_XLDS", 0):
+        direct = run()
+    vgo, ggo = oracle.gp_map_objective(kernel, X, y, hyp)
+    for vg, gg in (fast, direct):
+        assert abs(vg - vgo) <= 1e-8 * max(1.0, abs(vgo)), (vg, vgo)
+        np.testing.assert_allclose(gg, ggo, rtol=1e-6, atol=1e-8 * max(1.0, np.abs(ggo).max()))
+    assert fast[0] == direct[0]                                # the same arithmetic: the guard sent both down the direct path
+    np.testing.assert_array_equal(fast[1], direct[1])
+
+
 def test_device_btl_overflows_like_the_reference(ctx, oracle):
     """utils.hpp:25-29 has no max-subtraction: f / s > 709.78 makes exp() infinite and the likelihood inf / inf = NaN.  The device
     terms must do the same (not silently stabilise), like the oracle's restatement."""
