@@ -328,6 +328,12 @@ def main():
             ok = torch.tensor([1.0 if "comm" in box and "err" not in box else 0.0], dtype=torch.float64)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if ok.item() < 1.0:
+                if not args.same_device and os.environ.get("SLS_BENCH_ALLOW_GLOO_FALLBACK") != "1":
+                    # one rank per GPU over RCCL is what a multi-GPU bench line measures: without the communicator the run FAILS
+                    # (a line whose exchange silently went through gloo would be read as an xGMI number)
+                    raise SystemExit(f"[bench] rank {rank}: --backend nccl on distinct devices, but the RCCL communicator is unavailable "
+                                     f"({box.get('err', 'see other ranks')}); refusing to fall back to gloo "
+                                     "(SLS_BENCH_ALLOW_GLOO_FALLBACK=1 overrides, and labels the line)")
                 exchange = ("torch.distributed gloo all_gather (RCCL communicator unavailable on some rank: "
                             f"{box.get('err', 'see other ranks')})")
             else:
@@ -336,19 +342,25 @@ def main():
         else:
             exchange = "torch.distributed gloo all_gather (test mode)"
 
+    def exchange_once(r):
+        if comm is not None:
+            return comm.allgather_best(r["value"], r["index"], r["x"])
+        return sls.exchange_best(r["value"], r["index"], r["x"], device=xdev)
+
     def step():
+        t_a = time.perf_counter()
         gp.refit_dev(X_dev.data_ptr(), y_dev.data_ptr())
-        r = gp.acq_maximize_dev(starts_dev.data_ptr(), S_loc, args.n_local, sls.ACQ_EI, 1.0, offset=lo)
+        r = gp.acq_maximize_dev(starts_dev.data_ptr(), S_loc, args.n_local, sls.ACQ_EI, 1.0, offset=lo)   # returns the winner: synchronous
         issued[0] += gp.last_stats()["evals_issued"]
+        t_b = time.perf_counter()
+        t_local[0] += t_b - t_a
         if world > 1:                                   # the single exchange of the step
-            if comm is not None:
-                v, i, x = comm.allgather_best(r["value"], r["index"], r["x"])
-            else:
-                v, i, x = sls.exchange_best(r["value"], r["index"], r["x"], device=xdev)
+            v, i, x = exchange_once(r)
+            t_xchg[0] += time.perf_counter() - t_b      # includes waiting for the slowest rank
             return dict(value=v, index=i, x=x)
         return r
 
-    issued = [0]
+    issued, t_local, t_xchg = [0], [0.0], [0.0]
 
     def fence():
         torch.cuda.synchronize()
@@ -360,7 +372,7 @@ def main():
         step()
     ctx.prof_enable(True)
     ctx.prof_reset()
-    issued[0] = 0
+    issued[0], t_local[0], t_xchg[0] = 0, 0.0, 0.0
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -379,6 +391,28 @@ def main():
     names = ["gram", "potri", "potrf", "trtri", "lauum", "cross_gram", "acq_gemm", "grad_gemm", "finalize", "lbfgs"]
     prof = {n: ctx.prof_get(n) for n in names}
     ctx.prof_enable(False)
+    per_rank = None
+    if world > 1:
+        # What makes a scaling curve diagnosable from ONE line: every rank's own numbers, all-gathered over the rendezvous group
+        # (behind the timed region).  exchange_us: the collective alone, ranks aligned by a barrier in front of every repetition.
+        reps = 20
+        t_pure = 0.0
+        for _ in range(reps):
+            dist.barrier()
+            t_x = time.perf_counter()
+            exchange_once(res if "value" in res else dict(value=0.0, index=0, x=np.zeros(D)))
+            t_pure += time.perf_counter() - t_x
+        g_ms, g_n = prof["acq_gemm"]
+        mine = {"rank": rank, "device": local_rank, "starts": S_loc, "local_ms_per_step": t_local[0] / args.steps * 1e3,
+                "exchange_wait_us_per_step": t_xchg[0] / args.steps * 1e6, "exchange_us": t_pure / reps * 1e6,
+                "evals_issued_per_step": issued[0] / args.steps,
+                "acq_gemm_ms_per_step": g_ms / args.steps, "acq_gemm_launches_per_step": g_n / args.steps,
+                "acq_gemm_frac": (2.0 * N * N * issued[0] / (g_ms * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS) if g_ms > 0 else 0.0,
+                "fit_ms_per_step": sum(prof[n][0] for n in ("gram", "potri", "potrf", "trtri", "lauum")) / args.steps,
+                "potrf_fallbacks": int(ctx.prof_get("potrf_fallbacks")[1])}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        per_rank = sorted(gathered, key=lambda e: e["rank"])
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -424,6 +458,15 @@ def main():
             # the multi-launch schedule: 0 on a GPU this process has to itself
             "potrf_fallbacks": int(ctx.prof_get("potrf_fallbacks")[1]),
         }
+        if per_rank is not None:
+            loc = [e["local_ms_per_step"] for e in per_rank]
+            out["per_rank"] = per_rank
+            out["skew"] = {"local_ms_max": max(loc), "local_ms_min": min(loc), "max_minus_min_ms": max(loc) - min(loc),
+                           "slowest_rank": int(np.argmax(loc)), "exchange_us_max": max(e["exchange_us"] for e in per_rank),
+                           "note": "local = refit + this rank's shard of the maximisation (host clock around the synchronous calls); "
+                                   "exchange_wait includes waiting for the slowest rank, exchange_us is the collective alone"}
+            if args.backend == "nccl" and not args.same_device and os.environ.get("SLS_BENCH_ALLOW_GLOO_FALLBACK") != "1":
+                assert exchange.startswith("ncclAllGather inside libsls_hip"), exchange
         if args.same_device or args.backend != "nccl":
             out["config"]["test_mode"] = "ranks share GPU 0 over gloo: not a bench line"
         if world == 1 and not args.no_cpu_baseline:

@@ -182,6 +182,9 @@ struct PersistArgs {
     // fused inverse, hybrid pool: the factorisation's tiles (i, k) with i - k > hybrid_near are dealt over BOTH teams (an inverse
     // workgroup runs its factorisation tasks first); -1: the inverse team owns no tile of the factorisation (round-4 form)
     int hybrid_near;
+    // factorisation alone, large N: the tiles (i, k) with i - k <= band_near -- the ones whose updates the chain waits for -- have
+    // band_w workers of their own (the first band_w in XCD order), which own nothing else; 0: one deal over all workers
+    int band_w, band_near;
 };
 #define PK_STAMP(slot) do { if (a.trace && threadIdx.x == 0) a.trace[16 * j + (slot)] = wall_clock64(); } while (0)
 
@@ -1507,8 +1510,32 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             for (int q = 0; q < xcc; ++q) widx += __hip_atomic_load(a.sync + 8 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const bool hybrid = a.g1 > 0 && a.hybrid_near >= 0;
+        const bool banded = a.g1 == 0 && a.band_w > 0 && a.band_w < W;
         const int band = a.split_band;
-        if (ok && !hybrid) {
+        if (ok && banded) {
+            // At N = 8192 every worker is busy with 30 us updates of tiles far from the diagonal most of the time, and the chain's two
+            // tiles of the next step queue behind them: it stood still for 1.2 of the 4.1 ms (POTRF_BENCH_TRACE).  The band next to
+            // the diagonal therefore has owners that carry nothing else -- the first band_w workers in XCD order, i.e. the CUs around
+            // the chain's own, sharing its panels in one L2.
+            const int R = a.band_w;
+            const int me_near = widx < R ? widx : -1, me_far = widx >= R ? widx - R : -1;
+            int cn = 0, cf = 0;
+            for (int k = 0; k < nb; ++k) {
+                const int c = nb - k + min(band, nb - 1 - k);
+                for (int e = k == 0 ? 1 : 0; e < c; ++e) {
+                    const bool second = e >= nb - k;
+                    const int i = second ? k + 1 + (e - (nb - k)) : k + e;
+                    bool mine;
+                    if (i - k <= a.band_near) { mine = cn == me_near; if (++cn == R) cn = 0; }
+                    else { mine = cf == me_far; if (++cf == W - R) cf = 0; }
+                    if (mine && nt < DF_MAXT) {
+                        SW(0, nt) = i; SW(1, nt) = k; SW(2, nt) = 0; SW(3, nt) = 0;
+                        SW(6, nt) = second ? 2 : (e >= 1 && e <= band ? 1 : 0);
+                        ++nt;
+                    }
+                }
+            }
+        } else if (ok && !hybrid) {
             // tiles in column-major order (without (0, 0)) dealt round-robin: even in total work and at every stage (a cyclic
             // PR x PC owner grid left 1.4x the mean work on some owners: 5.7 vs 5.0 ms at N = 8192, round 3)
             // split_band: column k carries extra items, the second halves of its tiles (k+1, k) .. (k+band, k)
@@ -1849,7 +1876,8 @@ int potrf_dataflow_nbo(int Np) {
     // measured (tools/probes/df_scan2.sh, TRSM chain; ms): N = 8192: nbo 2: 4.31, 3: 4.83, 4: 5.15 (4.36 with near = 4), 8 + near 4:
     // 4.71; N = 16384 (the workers are the limit: fewer read-modify-write passes win): 2: 26.1, 4: 24.0, 8 + near 3: 23.6 (62
     // TFLOP/s = 0.79 of peak); N = 4096: 1: 1.69, 2: 1.83
-    return Np >= 16384 ? 8 : Np >= 8192 ? 2 : 1;
+    // round 6 (profiles/r06_potrf8192_scan.log): with the streamed chain at N = 8192: nbo 2: 4.09, 3 + near 2: 3.97, 4 + near 2: 4.24
+    return Np >= 16384 ? 8 : Np >= 8192 ? 3 : 1;
 }
 // ints of device scratch the dataflow form needs per problem
 size_t potrf_dataflow_sync_ints(int Np) {
@@ -1901,13 +1929,17 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
     // the workers are as busy as the chain (4.16 -> 4.10-4.17): the round-3 form stays from N > 5120
     // Several problems per launch are bound by their workers, not by their chains (8 value-only evaluations at N = 4096: 6.4 ms on
     // the round-3 chain, 7.3 ms streamed): the round-3 form there too.
-    const int nchain = (int)tune(TUNE_POTRF_STREAM, nb <= 40 && nprob == 1 ? SLS_POTRF_STREAM_DEFAULT : 0) != 0 && nb >= 4 ? 2 : 1;
+    // Round 6: N = 8192 .. 16 256 streamed as well, with WHOLE tiles (split 0: the half-tile owners were what made it slower there, 4.63 ms)
+    // and three-step update chunks: 4.10 -> 3.97 ms (profiles/r06_potrf8192_scan.log).  Dedicated owners for the band next to the
+    // diagonal (SLS_POTRF_BAND_W) were measured too and lose at every size of the band (4.2-9.4 ms, r06_potrf8192_band_scan.log).
+    const bool stream_dflt = nprob == 1 && (nb <= 40 || (Np >= 8192 && Np < 16384));
+    const int nchain = (int)tune(TUNE_POTRF_STREAM, stream_dflt ? SLS_POTRF_STREAM_DEFAULT : 0) != 0 && nb >= 4 ? 2 : 1;
     // SLS_POTRF_SPLIT = band: the tiles (i, k) with 1 <= i - k <= band have one owner per 64-column half (0: whole tiles only)
     // Measured (tools/probes: ms at N = 2048 / 3072 / 4096): factorisation alone: band 1: 0.655 / 0.992 / 1.363, 4: 0.645 / 0.999 / 1.353,
     // all: 0.654 / 1.000 / 1.345 -- what matters is that every row's cycle is shorter than the chain's step, the solving workgroup then finds
     // its tile 14-22 us before the diagonal block ends at EVERY step (before: -4 .. +6 us at every third one).  With the fused
     // inverse sharing the chip: band 1: 0.742 / 1.284 / 2.158, all: 0.733 / 1.344 / 2.518 (CUs are short from N = 3072).
-    const int split_band = nchain == 2 ? std::max(0, std::min(nb - 1, (int)tune(TUNE_POTRF_SPLIT, (nb <= 16 || !inv) ? nb : 1))) : 0;
+    const int split_band = nchain == 2 ? std::max(0, std::min(nb - 1, (int)tune(TUNE_POTRF_SPLIT, nb > 40 ? 0 : (nb <= 16 || !inv) ? nb : 1))) : 0;
     const int split_sub = split_band >= 1 ? 1 : 0;
     int n_second = 0;
     for (int kk = 0; kk < nb; ++kk) n_second += std::min(split_band, nb - 1 - kk);
@@ -1938,7 +1970,7 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
     a.timeout = (int)tune(TUNE_POTRF_TIMEOUT_TICKS, 20000000);   // 0.2 s of the 100 MHz wall clock (test hook: 1 makes every wait expire)
     a.trace = trace;
     a.nbo = potrf_dataflow_nbo(Np);
-    a.near = (int)tune(TUNE_POTRF_DNEAR, Np >= 16384 ? 3 : 0);
+    a.near = (int)tune(TUNE_POTRF_DNEAR, Np >= 16384 ? 3 : Np >= 8192 ? 2 : 0);
     a.nprob = nprob; a.strideA = strideA; a.stride_sync = stride_sync;
     a.g1 = inv ? Gp : 0;
     a.U = inv ? inv->U : nullptr;
@@ -1947,6 +1979,12 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
     a.split_sub = split_sub;
     a.split_band = split_band;
     a.hybrid_near = inv ? (int)tune(TUNE_POTRI_HYBRID, -1) : -1;
+    a.band_near = (int)tune(TUNE_POTRF_BAND, 2);
+    a.band_w = (!inv && nprob == 1) ? std::max(0, std::min(W - 1, (int)tune(TUNE_POTRF_BAND_W, 0))) : 0;
+    if (a.band_w > 0) {   // both deals must fit the per-worker tables
+        const int near_tiles = (a.band_near + 1) * nb + n_second, far_tiles = tiles - std::min(tiles, near_tiles);
+        if ((near_tiles + a.band_w - 1) / a.band_w > DF_MAXT || (far_tiles + (W - a.band_w) - 1) / (W - a.band_w) > DF_MAXT) a.band_w = 0;
+    }
     // measured (ms, factor + inverse; two products per row -> one): N = 384: 0.209 -> 0.234, 1024: 0.405 -> 0.411, 2048: 0.759 -> 0.753,
     // 3072: 1.466 -> 1.32, 4096: 2.15 -> 2.15 (there the two teams are short of CUs, not of time on the wavefront)
     a.inv_plast = (int)tune(TUNE_POTRI_PLAST, nb >= 12 ? 1 : 0) != 0 ? 1 : 0;

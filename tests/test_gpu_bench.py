@@ -22,7 +22,7 @@ REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 
 def run(cmd):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout
@@ -68,6 +68,44 @@ def test_bench_gpus_n_without_a_launcher_spawns_its_own_ranks():
     assert two["result"]["best_index"] == one["result"]["best_index"]
     assert two["result"]["best_value"] == one["result"]["best_value"]
     np.testing.assert_array_equal(two["result"]["best_x"], one["result"]["best_x"])
+
+
+@pytest.mark.gpu
+def test_eight_rank_dry_run_of_the_full_shard_shape():
+    """What the first 8-GPU lease will run, rehearsed on one GPU: 8 ranks through torch.distributed.run, each with the 8 192-start
+    shard of the full N = 8192, D = 64 workload (its chunk shape, tail split and global start offsets; three evaluations per start to
+    keep it short), the exchange over the rendezvous group.  The merged winner must be the single-rank winner over all 65 536
+    starts, and the one JSON line must carry what makes a scaling curve diagnosable: per-rank step time, per-rank acq_gemm
+    fraction, exchange time and the max - min skew (multi-start loop of src/acquisition-function.cpp:121-153)."""
+    full = ["--num-train", "8192", "--dims", "64", "--starts", "65536", "--n-local", "3", "--steps", "1", "--warmup", "1",
+            "--no-cpu-baseline", "--no-traffic"]
+    one = run([sys.executable, "bench.py", "--gpus", "1"] + full)
+    eight = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                 "--master-port", "29643", "bench.py", "--gpus", "8", "--backend", "gloo", "--same-device"] + full)
+    assert eight["n_gpus"] == 8 and eight["config"]["starts_per_gpu"] == 8192 and eight["config"]["candidate_chunk"] == 8192
+    assert "test_mode" in eight["config"] and eight["config"]["exchange"].startswith("torch.distributed gloo")
+    pr = eight["per_rank"]
+    assert [e["rank"] for e in pr] == list(range(8)) and all(e["starts"] == 8192 for e in pr)
+    for e in pr:
+        for k in ("local_ms_per_step", "exchange_wait_us_per_step", "exchange_us", "acq_gemm_frac", "acq_gemm_ms_per_step",
+                  "evals_issued_per_step", "fit_ms_per_step"):
+            assert k in e and e[k] >= 0, (k, e)
+        assert 0 < e["acq_gemm_frac"] < 1 and 0 < e["evals_issued_per_step"] <= 8192 * 3
+    sk = eight["skew"]
+    assert sk["max_minus_min_ms"] == pytest.approx(sk["local_ms_max"] - sk["local_ms_min"]) and 0 <= sk["slowest_rank"] < 8
+    assert abs(sum(e["evals_issued_per_step"] for e in pr) - eight["config"]["evals_issued_per_step"]) < 1e-6
+    assert eight["config"]["evals_issued_per_step"] == one["config"]["evals_issued_per_step"]      # a start's path does not depend on its shard
+    assert eight["result"]["best_index"] == one["result"]["best_index"]
+    assert eight["result"]["best_value"] == one["result"]["best_value"]
+    np.testing.assert_array_equal(eight["result"]["best_x"], one["result"]["best_x"])
+
+
+def test_nccl_on_distinct_devices_must_not_fall_back_silently():
+    """bench.py: with --backend nccl and one rank per device the exchange is RCCL or the run fails; only the same-device test mode
+    (and an explicit SLS_BENCH_ALLOW_GLOO_FALLBACK=1) may label a gloo exchange (CPU: the source says so)."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "refusing to fall back to gloo" in src and "SLS_BENCH_ALLOW_GLOO_FALLBACK" in src
+    assert 'assert exchange.startswith("ncclAllGather inside libsls_hip")' in src
 
 
 @pytest.mark.gpu
