@@ -94,6 +94,36 @@ def cpu_baseline(args, kernel_id):
     }
 
 
+def cpu_as_written(args, kernel_id, cores):
+    """BASELINE.md 5, mode 1: the reference's AS-WRITTEN call structure -- one NLopt callback = derivative then value
+    (src/acquisition-function.cpp:38-56), each recomputing PredictMaximumPointFromData = N x PredictMu with K^-1 y not cached
+    (src/regressor.cpp:29-43, src/acquisition-function.cpp:188): O(N^3) per evaluation.  Feasible only at small N: timed single-
+    threaded through the oracle's as-written entry points at N in {256, 512, 1024} (D as the workload's), a power law fitted and
+    EXTRAPOLATED to the workload's N; the reference's multi-start loop runs one evaluation per hardware thread, so the whole-machine
+    rate is cores / t.  Labelled extrapolated: it is context beside the measured hoisted port, never a measured number."""
+    from oracle import oracle_py as orc
+    os.environ["OMP_NUM_THREADS"] = "1"
+    rows = []
+    for N, reps in ((256, 3), (512, 2), (1024, 1)):
+        rng = np.random.default_rng(1234 + N)
+        X = np.asfortranarray(rng.uniform(0, 1, (args.d, N)))
+        y = np.exp(-np.sum((X - 0.4) ** 2, axis=0)) + 0.01 * rng.standard_normal(N)
+        theta = np.concatenate([[0.5], np.full(args.d, 0.5 * np.sqrt(max(args.d, 8) / 8.0))])
+        ref = orc.Regressor(X, y, theta, 0.005, kernel=kernel_id)
+        x = rng.uniform(0, 1, args.d)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ref.acq_derivative_as_written(x)
+            ref.acq_value_as_written(x)
+        rows.append({"N": N, "s_per_eval_1thread": (time.perf_counter() - t0) / reps, "reps": reps})
+    p, logc = np.polyfit(np.log([r["N"] for r in rows]), np.log([r["s_per_eval_1thread"] for r in rows]), 1)
+    t_n = float(np.exp(logc) * args.n ** p)
+    return {"kind": "port of the as-written call structure", "extrapolated": True, "measured": rows, "fit_exponent": float(p),
+            "N": args.n, "s_per_eval_1thread": t_n, "value": cores / t_n, "unit": "candidate-evals/s", "cores": cores,
+            "implied_step_seconds": args.starts * args.n_local * t_n / cores,
+            "note": "one evaluation per hardware thread (parallel-util's queue); power law through N = 256, 512, 1024 evaluated at the workload's N"}
+
+
 def parity_vs_oracle(sls, ctx, kernel_id, o):
     """The oracle numbers of the cpu_baseline leg (full N, 1024 starts x 2 evaluations, mu / sigma at 256 points) against
     the HIP path on the same inputs: maximum relative errors (north_star bar: 1e-6)."""
@@ -471,6 +501,7 @@ def main():
             out["config"]["test_mode"] = "ranks share GPU 0 over gloo: not a bench line"
         if world == 1 and not args.no_cpu_baseline:
             oracle_out, out["cpu_baseline"] = cpu_baseline(args, kernel_id)
+            out["cpu_baseline"]["as_written"] = cpu_as_written(args, kernel_id, os.cpu_count() or 1)
             # the oracle run is not thrown away: the same inputs go through the HIP path and the two are diffed
             out["parity"], out["parity_max_rel"] = parity_vs_oracle(sls, ctx, kernel_id, oracle_out)
         print(json.dumps(out))

@@ -1,6 +1,7 @@
 // C entry points into the host C++ layer for ctypes-driven tests and tools: the two MAP fits of the reference
 // (src/gaussian-process-regressor.cpp:274-299, src/preference-regressor.cpp:332-403) run through the restated classes
 // exactly as a C++ caller would run them; only plain pointers cross the boundary.  Column-major inputs as Eigen.
+#include <sequential-line-search/acquisition-function.hpp>
 #include <sequential-line-search/gaussian-process-regressor.hpp>
 #include <sequential-line-search/preference-regressor.hpp>
 
@@ -68,6 +69,40 @@ extern "C" int slsh_pref_map_fit(const double* X, int D, int M, const unsigned* 
     }
     catch (const std::exception& e)
     {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+/// The reference's default maximiser branch (src/acquisition-function.cpp:155-165: DIRECT, then ONE L-BFGS from its result) on a
+/// PreferenceRegressor with FIXED hyper-parameters (use_map = false; the goodness values are fitted), with the given relative
+/// tolerances for the local search (0 = run to the evaluation cap; the previous setting is restored).  out_x[D], *out_value = the
+/// acquisition value at out_x.  For the tests that hold the early stop to a bound where it picks the answer.
+extern "C" int slsh_find_next_point_direct(const double* X, int D, int M, const unsigned* prefs_flat, const int* offsets, int n_prefs,
+                                           double a, double r, double b, double prior_var, double btl_scale, int kernel, unsigned num_global,
+                                           unsigned num_local, double ftol_rel, double xtol_rel, double* out_x, double* out_value)
+{
+    double f0 = 0.0, x0 = 0.0;
+    acquisition_func::GetLocalSearchTolerances(&f0, &x0);
+    try
+    {
+        Eigen::MatrixXd Xm(D, M);
+        std::memcpy(Xm.data(), X, sizeof(double) * D * M);
+        std::vector<Preference> prefs;
+        for (int p = 0; p < n_prefs; ++p) prefs.emplace_back(std::vector<unsigned>(prefs_flat + offsets[p], prefs_flat + offsets[p + 1]));
+        PreferenceRegressor reg(Xm, prefs, false, a, r, b, prior_var, btl_scale, 100, KernelOf(kernel));
+        acquisition_func::SetLocalSearchTolerances(ftol_rel, xtol_rel);
+        double                v = 0.0;
+        const Eigen::VectorXd x = acquisition_func::FindNextPointDirect(reg, num_global, num_local, AcquisitionFuncType::ExpectedImprovement, 1.0, &v);
+        acquisition_func::SetLocalSearchTolerances(f0, x0);
+        for (int d = 0; d < D; ++d) out_x[d] = x(d);
+        *out_value = acquisition_func::CalcAcquisitionValue(reg, x, AcquisitionFuncType::ExpectedImprovement, 1.0);
+        (void)v;
+        return 0;
+    }
+    catch (const std::exception& e)
+    {
+        acquisition_func::SetLocalSearchTolerances(f0, x0);
         g_err = e.what();
         return -1;
     }

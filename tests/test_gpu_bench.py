@@ -96,8 +96,15 @@ def test_eight_rank_dry_run_of_the_full_shard_shape():
     assert abs(sum(e["evals_issued_per_step"] for e in pr) - eight["config"]["evals_issued_per_step"]) < 1e-6
     assert eight["config"]["evals_issued_per_step"] == one["config"]["evals_issued_per_step"]      # a start's path does not depend on its shard
     assert eight["result"]["best_index"] == one["result"]["best_index"]
-    assert eight["result"]["best_value"] == one["result"]["best_value"]
-    np.testing.assert_array_equal(eight["result"]["best_x"], one["result"]["best_x"])
+    if all(e["potrf_fallbacks"] == 0 for e in pr):
+        assert eight["result"]["best_value"] == one["result"]["best_value"]
+        np.testing.assert_array_equal(eight["result"]["best_x"], one["result"]["best_x"])
+    else:
+        # eight processes on ONE GPU: a rank whose single-launch Cholesky could not have all its workgroups resident repeated the fit
+        # on the multi-launch schedule, whose update chunks differ (nbo 4 against 3): the factor agrees to rounding, not in every bit.
+        # One rank per GPU (the real run) never takes that path.
+        assert eight["result"]["best_value"] == pytest.approx(one["result"]["best_value"], rel=1e-11)
+        np.testing.assert_allclose(eight["result"]["best_x"], one["result"]["best_x"], rtol=0, atol=1e-9)
 
 
 def test_nccl_on_distinct_devices_must_not_fall_back_silently():
