@@ -98,4 +98,6 @@ def test_single_start_branch_early_stop_against_run_to_cap(host):
     assert loss.max() <= EARLY_STOP_LOSS_BOUND, out["loss_rel_max"]
 
 
-EARLY_STOP_LOSS_BOUND = 1.0    # placeholder until measured
+# measured over the 60 seeds (MI355X, round 6): max 5.3e-6, median 7e-8, 90 % below 3.6e-7 of the capped run's value; the largest
+# move of the returned point 0.10 in one coordinate (a flat ridge of the acquisition function at N = 10), typically 1e-3
+EARLY_STOP_LOSS_BOUND = 2e-5
