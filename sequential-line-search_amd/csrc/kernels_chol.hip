@@ -185,6 +185,9 @@ struct PersistArgs {
     // factorisation alone, large N: the tiles (i, k) with i - k <= band_near -- the ones whose updates the chain waits for -- have
     // band_w workers of their own (the first band_w in XCD order), which own nothing else; 0: one deal over all workers
     int band_w, band_near;
+    // three-workgroup chain: the LAST update of every sub-diagonal half tile (the one that runs behind the chain's solve) is an item of its
+    // own, dealt over the first lu_w workers, which carry nothing else (0: it stays with the tile's owner)
+    int lu_w;
 };
 #define PK_STAMP(slot) do { if (a.trace && threadIdx.x == 0) a.trace[16 * j + (slot)] = wall_clock64(); } while (0)
 
@@ -769,7 +772,10 @@ __device__ __forceinline__ void chain_image_rsub(const double* __restrict__ C, l
 // On return the image holds Csub - X X^T on its lower 16 x 16 blocks (diag_block_factor<false>'s input, behind the caller's
 // barrier) and the tile X has been stored (the caller drains and raises the flag).
 // ready(): called once, uniformly, before the tile Csub is first read (its owner's last update must have landed); false = give up.
-template <class Ready>
+// SYRK = false: the solve alone (the three-workgroup chain: another workgroup forms the product from the published blocks,
+// stream_syrk_image); block s - 1 is then flagged at the TOP of step s, before the wait for the diagonal block's column block s --
+// block 6 must not wait for the diagonal block's end.
+template <bool SYRK, class Ready>
 __device__ __forceinline__ bool stream_trsm_syrk(double* __restrict__ A, long lda, const double* __restrict__ L, long ldl,
                                                  const double* __restrict__ T, long ldt, int* flag, int* abort_flag, long long timeout,
                                                  const double* __restrict__ Csub, long ldc, Ready&& ready, int* xprog, long long* stamp, double* lds) {
@@ -813,6 +819,7 @@ __device__ __forceinline__ bool stream_trsm_syrk(double* __restrict__ A, long ld
     issueA(0); issueA(1); issueA(2);
     if (stamp) stamp[5] = wall_clock64();
     int issuedL = 0;
+    int seen_raw = 0, seen_u = 0;                        // the diagonal block's publication count as last polled (lane 0) / uniform
     bool ok = true;
     // xprog += 1 per wave and block once that wave's four columns of the block have drained (4 (s + 1): block s is in global
     // memory): the owners of the tile below run the K loop of its last update behind these (stream_update_half)
@@ -824,30 +831,83 @@ __device__ __forceinline__ bool stream_trsm_syrk(double* __restrict__ A, long ld
             raised = upto;
         }
     };
+    auto store_block = [&](int sb) {                     // block sb from its slab: column 16 sb + 4 q + wave of the tile, 64 lanes x 16 bytes
+        const double* xs_ = Xbuf + (sb & 1) * SLAB;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = 4 * q + wave;
+            const d2_t v = *reinterpret_cast<const d2_t*>(xs_ + c * GEMM_LDS_MC_LD + 2 * lane);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rsrcX, (int)((2 * lane + (long)(16 * sb + c) * lda) * 8), 0, 16);
+        }
+    };
     auto step = [&](auto S) {
         constexpr int s = decltype(S)::value;
         if (!ok) return;
         // early: column block s was already published a step ago and requested then -- BEFORE that step's four stores of X_{s-1}.
         // Memory operations complete in order: everything but those stores is waited for, and they drain behind this step (a
         // solve that has fallen behind the factorisation would otherwise pay a write-through round trip per block).
-        const bool early = issuedL > s;
-        if (!early) {
+        if constexpr (!SYRK) {
+            // ---- the solve alone: every wait of this wave is placed by hand ----
+            // Memory operations of a wave complete in issue order; a step issues, behind its barrier:  g1 the NEXT column block of the
+            // diagonal block (if the poll of the step before saw it published), the poll for the step after, g2 the four stores of
+            // X_{s-1} (formed a step ago), g3 the A slab three steps ahead.  The next barrier needs g1 and the poll only: it waits
+            // until just g2 + g3 are outstanding -- the write-through round trip of the stores (~1.5 us) and the slab's latency stay
+            // behind the step's products.  (With one vmcnt(0) per step -- the compiler's, in front of the poll's result while LDS-
+            // direct loads were in flight -- a tile took 20 us for 7.7 us of products.)  Block s - 2 is flagged at the top of step s,
+            // behind g3 of the step before only.
+#ifdef SLS_COUNTED_MIXED_WAITS
+            constexpr int N_FLAG = s <= 5 ? 4 : 0;                              // g3 of step s - 1
+            constexpr int N_BAR = (s >= 2 ? 4 : 0) + (s <= 5 ? 4 : 0);          // g2 + g3 of step s - 1 (the flag's atomic, younger still, is not counted: conservative)
+#else
+            // MEASURED (round 6, POTRF_BENCH_STRESS): with the counted waits 1 of 300 launches at N = 2560 / 3072 produced a different
+            // factor -- stores and loads of a wave do NOT retire in one common order (a vmcnt(N) behind a mix of both says nothing
+            // about WHICH N are still out).  Every wait that has stores behind it is therefore a full drain.
+            constexpr int N_FLAG = 0, N_BAR = 0;
+#endif
+            if (s >= 2) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_FLAG) : "memory");
+                if (lane == 0) __hip_atomic_fetch_add(xprog, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // block s - 2: one arrival per wave
+            }
+            const bool early = issuedL > s;
+            if (!early) {
+                if (!stream_wait(flag, 3 * (s + 1), abort_flag, timeout)) { ok = false; return; }
+                issueL(s);
+                issuedL = s + 1;
+            }
+            if (s == 7 && stamp) stamp[0] = wall_clock64();
+            if (early) asm volatile("s_waitcnt vmcnt(%1) lgkmcnt(0)\n\ts_barrier" : "+v"(seen_raw) : "n"(N_BAR) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" : "+v"(seen_raw)::"memory");
+            const int seen = __builtin_amdgcn_readfirstlane(seen_raw);          // the diagonal block's count as polled a step ago
+            if (s + 1 < 8) {
+                if (seen >= 3 * (s + 2)) {
+                    issueL(s + 1);
+                    issuedL = s + 2;
+                }
+                if (lane == 0) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(seen_raw) : "v"(flag) : "memory");
+            }
+            if (s > 0) store_block(s - 1);
+            if (s + 3 < 8) issueA(s + 3);
+        } else {
+        if (SYRK && s > 0) {}
+        const bool early = SYRK && issuedL > s;
+        if (issuedL <= s) {
             if (!stream_wait(flag, 3 * (s + 1), abort_flag, timeout)) { ok = false; return; }
             issueL(s);
             issuedL = s + 1;
         }
         if (s == 7 && stamp) stamp[0] = wall_clock64();    // probes: the diagonal block has ended (on the other workgroup) a moment ago
+        if (s + 1 < 8 && seen_u < 3 * (s + 2) && lane == 0) seen_raw = df_flag(flag);
         if (early) ring_wait_barrier<4>();               // slab s of A and of L in LDS (every wave's part); slab s - 1 no longer read
         else ring_wait_barrier<0>();
         if (s == 7 && stamp) stamp[9] = wall_clock64();
         if (s + 3 < 8) issueA(s + 3);
         if (s + 1 < 8) {
-            int have = 0;
-            if (lane == 0) have = df_flag(flag) >= 3 * (s + 2) ? 1 : 0;
-            if (__builtin_amdgcn_readfirstlane(have)) {
+            seen_u = __builtin_amdgcn_readfirstlane(seen_raw);
+            if (seen_u >= 3 * (s + 2)) {
                 issueL(s + 1);
                 issuedL = s + 2;
             }
+        }
         }
         const double* la = lds + (s & 3) * SLAB;
         const double* lb = Lbuf + (s & 1) * SLAB;
@@ -881,24 +941,15 @@ __device__ __forceinline__ bool stream_trsm_syrk(double* __restrict__ A, long ld
                 }
             }
         }
-#ifndef SLS_EXP_NORAISE
-        if (s > 0) raise(s);                             // block s - 1: stored a step ago
-#endif
-        lds_barrier();                                   // X_s complete in its slab (every wave's rows)
-#ifndef SLS_EXP_NOSTORE
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {                    // column 16 s + 4 q + wave of the tile: 64 lanes x 16 bytes
-            const int c = 4 * q + wave;
-            const d2_t v = *reinterpret_cast<const d2_t*>(xb + c * GEMM_LDS_MC_LD + 2 * lane);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rsrcX, (int)((2 * lane + (long)(16 * s + c) * lda) * 8), 0, 16);
+        if (SYRK && s > 0) raise(s);                     // block s - 1: stored a step ago
+        if constexpr (SYRK) {
+            lds_barrier();                               // X_s complete in its slab (every wave's rows)
+            store_block(s);
+            if (wave == 0) syrk_slab<0>(acc, xb, lane);
+            else if (wave == 1) syrk_slab<1>(acc, xb, lane);
+            else if (wave == 2) syrk_slab<2>(acc, xb, lane);
+            else syrk_slab<3>(acc, xb, lane);
         }
-#endif
-#ifndef SLS_EXP_NOSYRK
-        if (wave == 0) syrk_slab<0>(acc, xb, lane);
-        else if (wave == 1) syrk_slab<1>(acc, xb, lane);
-        else if (wave == 2) syrk_slab<2>(acc, xb, lane);
-        else syrk_slab<3>(acc, xb, lane);
-#endif
         if (stamp && (s == 0 || s == 3 || s == 6)) stamp[6 + s / 3] = wall_clock64();
     };
     step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
@@ -906,13 +957,85 @@ __device__ __forceinline__ bool stream_trsm_syrk(double* __restrict__ A, long ld
     step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
     step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
     if (!ok) return false;
+    if constexpr (!SYRK) {
+        raised = 6;                                      // blocks 0 .. 5 were flagged inside the steps
+        raise(7);                                        // block 6: stored in step 7
+        lds_barrier();                                   // X_7 complete in its slab
+        store_block(7);
+    }
     raise(8);
     if (stamp) stamp[12] = wall_clock64();
-    if (!ready()) return false;
-    if (wave == 0) syrk_load_c0<0>(c0, Csub, ldc, lane);
-    else if (wave == 1) syrk_load_c0<1>(c0, Csub, ldc, lane);
-    else if (wave == 2) syrk_load_c0<2>(c0, Csub, ldc, lane);
-    else syrk_load_c0<3>(c0, Csub, ldc, lane);
+    if constexpr (SYRK) {
+        if (!ready()) return false;
+        if (wave == 0) syrk_load_c0<0>(c0, Csub, ldc, lane);
+        else if (wave == 1) syrk_load_c0<1>(c0, Csub, ldc, lane);
+        else if (wave == 2) syrk_load_c0<2>(c0, Csub, ldc, lane);
+        else syrk_load_c0<3>(c0, Csub, ldc, lane);
+        lds_barrier();                                       // every wave has read the last slab: the image may be written
+        if (wave == 0) syrk_to_image<0, true>(lds, acc, c0, lane);
+        else if (wave == 1) syrk_to_image<1, true>(lds, acc, c0, lane);
+        else if (wave == 2) syrk_to_image<2, true>(lds, acc, c0, lane);
+        else syrk_to_image<3, true>(lds, acc, c0, lane);
+    }
+    return true;
+}
+
+// The other half of the three-workgroup chain: A_{j,j} - X X^T for the NEXT diagonal block, accumulated from the 16-column blocks of
+// X = L_{j,j-1} as the solving workgroup publishes them (xprog: 4 (s + 1) = block s is in global memory), one slab of
+// chain_syrk_inplace's sum per block -- same deal, same k order, same single subtraction: same bits.  On return the image holds the
+// difference on its lower 16 x 16 blocks (diag_block_factor<false>'s input, behind the caller's barrier).  Behind the last block remain
+// one slab (36 products per wave) and the write-back.
+template <class Ready>
+__device__ __forceinline__ bool stream_syrk_image(const double* __restrict__ X, long ldx, int* xprog, int* abort_flag, long long timeout,
+                                                  const double* __restrict__ Csub, long ldc, Ready&& ready, long long* stamp, double* lds) {
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int SLAB = GEMM_LDS_TILE;
+    auto issue = [&](int s) {
+        double* base = lds + (s & 3) * SLAB;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * wave + r;
+            slab_row_to_lds_sc1(X + 2 * lane + (long)(16 * s + row) * ldx, base + row * GEMM_LDS_MC_LD);
+        }
+    };
+    d4_t acc[9], c0[9];
+#pragma unroll
+    for (int p = 0; p < 9; ++p) acc[p] = d4_t{0.0, 0.0, 0.0, 0.0};
+    int issued = 0;
+    bool ok = true;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        if (issued <= s) {
+            if (!stream_wait(xprog, 4 * (s + 1), abort_flag, timeout)) { ok = false; break; }
+            issue(s);
+            issued = s + 1;
+        }
+        if (s == 7 && stamp) stamp[0] = wall_clock64();    // probes: the last block of the tile has arrived
+        if (s == 6) {                                      // the tile the product is subtracted from: in flight behind the last two slabs
+            if (!ready()) { ok = false; break; }
+            if (wave == 0) syrk_load_c0<0>(c0, Csub, ldc, lane);
+            else if (wave == 1) syrk_load_c0<1>(c0, Csub, ldc, lane);
+            else if (wave == 2) syrk_load_c0<2>(c0, Csub, ldc, lane);
+            else syrk_load_c0<3>(c0, Csub, ldc, lane);
+        }
+        int seen = 0;
+        if (s + 1 < 8 && lane == 0) seen = df_flag(xprog);
+        ring_wait_barrier<0>();                          // slab s in LDS (every wave's rows); slab s - 1 no longer read
+        if (s + 1 < 8) {
+            if (__builtin_amdgcn_readfirstlane(seen) >= 4 * (s + 2)) {
+                issue(s + 1);
+                issued = s + 2;
+            }
+        }
+        const double* xb = lds + (s & 3) * SLAB;
+        if (wave == 0) syrk_slab<0>(acc, xb, lane);
+        else if (wave == 1) syrk_slab<1>(acc, xb, lane);
+        else if (wave == 2) syrk_slab<2>(acc, xb, lane);
+        else syrk_slab<3>(acc, xb, lane);
+    }
+    if (!ok) return false;
     lds_barrier();                                       // every wave has read the last slab: the image may be written
     if (wave == 0) syrk_to_image<0, true>(lds, acc, c0, lane);
     else if (wave == 1) syrk_to_image<1, true>(lds, acc, c0, lane);
@@ -928,60 +1051,65 @@ __device__ __forceinline__ bool stream_trsm_syrk(double* __restrict__ A, long ld
 // Same slabs, same fragment layout, same k order as gemm_tile_mc<2>: same bits; the tile's values are in registers before the
 // last block arrives.
 __device__ __forceinline__ bool stream_update_half(double* __restrict__ C, long ld, const double* __restrict__ A, const double* __restrict__ B,
-                                                   int nhalf, int* xprog, int* abort_flag, long long timeout, double* lds) {
+                                                   int nhalf, int* xprogA, int* xprog, int* abort_flag, long long timeout, double* lds) {
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane));
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fl = lane & 15, fk = lane >> 4;
     const int wm = (wave & 1) * 64, wn = 64 * nhalf + (wave >> 1) * 32;
     constexpr int SLAB = GEMM_LDS_TILE;
-    double* Bbuf = lds + 4 * SLAB;
-    auto issueA = [&](int s) {
-        double* base = lds + (s & 3) * SLAB;
+    // BOTH operands belong to the column the chain is busy with: L_{k,k-1} is the chain's own tile, L_{k+1,k-1} the tile right below it,
+    // solved by a worker behind the same diagonal block -- each publishes its 16-column blocks as they become final (xprog, xprogA)
+    // Four slots of (A slab, B slab): every block that is published is requested at once, up to two ahead of the one in work (the
+    // slot of block s + 3 is the one a slower wave may still be reading in step s - 1's place: this request runs in front of the barrier).  The
+    // two progress counters are polled ONCE per step, by loads issued behind the step's barrier and read at the top of the next step
+    // (their round trip, ~1 us each, stands behind the step's products: a loop that polled, loaded and multiplied one after the other
+    // took 4 us per block and ended 9 us behind its producers, which publish a block every 2.1 us).
+    auto issueAB = [&](int s) {
+        double* base = lds + (s & 3) * 2 * SLAB;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 4 * wave + r;
-            slab_row_to_lds(A + 2 * lane + (long)(16 * s + row) * ld, base + row * GEMM_LDS_MC_LD);
+            slab_row_to_lds_sc1(A + 2 * lane + (long)(16 * s + row) * ld, base + row * GEMM_LDS_MC_LD);
+            slab_row_to_lds_sc1(B + 2 * lane + (long)(16 * s + row) * ld, base + SLAB + row * GEMM_LDS_MC_LD);
         }
     };
-    auto issueB = [&](int s) {
-        double* base = Bbuf + (s & 1) * SLAB;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 4 * wave + r;
-            slab_row_to_lds_sc1(B + 2 * lane + (long)(16 * s + row) * ld, base + row * GEMM_LDS_MC_LD);
-        }
-    };
+    // (agent-scope loads: with the last update as an item of its own the tile's earlier updates were stored by another CU)
     d2_t cv[16];
+    auto rsrcC = __builtin_amdgcn_make_buffer_rsrc(C, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) cv[q] = *reinterpret_cast<const d2_t*>(C + 2 * lane + (long)(64 * nhalf + wave + 4 * q) * ld);
+    for (int q = 0; q < 16; ++q)
+        cv[q] = __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(rsrcC, (int)((2 * lane + (long)(64 * nhalf + wave + 4 * q) * ld) * 8), 0, 16));
     d4_t acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) acc[i][jj] = d4_t{0.0, 0.0, 0.0, 0.0};
-    issueA(0); issueA(1); issueA(2);
-    int issuedB = 0;
+    int issued = 0;
+    int pa = 0, pb = 0;                                  // the counters as polled (lane 0)
     bool ok = true;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        if (issuedB <= s) {
-            if (!stream_wait(xprog, 4 * (s + 1), abort_flag, timeout)) { ok = false; break; }
-            issueB(s);
-            issuedB = s + 1;
+        // everything this wave has in flight -- the polls of the step before and the slabs requested so far -- has landed
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pa), "+v"(pb)::"memory");
+        int pub = min(__builtin_amdgcn_readfirstlane(pa), __builtin_amdgcn_readfirstlane(pb)) >> 2;   // blocks of both tiles in global memory
+        bool fresh = false;
+        if (pub <= s) {                                  // block s itself is not there yet: wait for it (both counters)
+            if (!stream_wait(xprog, 4 * (s + 1), abort_flag, timeout) || !stream_wait(xprogA, 4 * (s + 1), abort_flag, timeout)) { ok = false; break; }
+            pub = s + 1;
         }
-        ring_wait_barrier<0>();
-        if (s + 3 < 8) issueA(s + 3);
-        if (s + 1 < 8) {
-            int have = 0;
-            if (lane == 0) have = df_flag(xprog) >= 4 * (s + 2) ? 1 : 0;
-            if (__builtin_amdgcn_readfirstlane(have)) {
-                issueB(s + 1);
-                issuedB = s + 2;
-            }
+        for (; issued < min(pub, s + 3); ++issued) {
+            issueAB(issued);
+            fresh = fresh || issued == s;
         }
-        const double* la = lds + (s & 3) * SLAB;
-        const double* lb = Bbuf + (s & 1) * SLAB;
+        if (fresh) ring_wait_barrier<0>();               // block s was requested just now
+        else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // landed (the wait above); younger slabs stay in flight
+        if (s + 1 < 8 && lane == 0) {
+            asm volatile("global_load_dword %0, %1, off sc1" : "=v"(pa) : "v"(xprogA) : "memory");
+            asm volatile("global_load_dword %0, %1, off sc1" : "=v"(pb) : "v"(xprog) : "memory");
+        }
+        const double* la = lds + (s & 3) * 2 * SLAB;
+        const double* lb = la + SLAB;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             double fa[4], fb[2];
@@ -1006,12 +1134,11 @@ __device__ __forceinline__ bool stream_update_half(double* __restrict__ C, long 
 #pragma unroll
             for (int r = 0; r < 4; ++r) lds[(wm + 16 * i + fl) + (n0 + 16 * jj + fk + 4 * r) * DL] = acc[i][jj][r];
     lds_barrier();
-    auto rsrc = __builtin_amdgcn_make_buffer_rsrc(C, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int c = 64 * nhalf + wave + 4 * q;
         const d2_t v = cv[q] - *reinterpret_cast<const d2_t*>(lds + 2 * lane + c * DL);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rsrc, (int)((2 * lane + (long)c * ld) * 8), 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rsrcC, (int)((2 * lane + (long)c * ld) * 8), 0, 16);
     }
     return true;
 }
@@ -1122,7 +1249,7 @@ __device__ __forceinline__ bool potri_item_ready(const PersistArgs& a, int type,
     const int cx = a.inv_cx, ck = a.inv_ck;
     bool ok = true;
     if (type == 0) {
-        if (l == 0) ok = df_flag(factored + i) >= (a.nchain == 2 ? 24 : 1);
+        if (l == 0) ok = df_flag(factored + i) >= (a.nchain >= 2 ? 24 : 1);
     } else if (type == 1) {
         // d: terms applied (k = j .. i - 1 - plast), then nterms -> Q pending, nterms + 1 -> last step pending (plast)
         const int nterms = i - j - a.inv_plast;
@@ -1372,7 +1499,55 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
     int* diag_ready = a.sync + DF_FACT + 2 * nb + 2 * nb * nb;
     int* upd_done = diag_ready + nb;                    // [i + k nb]: the second half of tile (i, k) carries all its updates
     int* xprog = upd_done + nb * nb;                    // [j]: 4 (s + 1) = the chain's tile (j+1, j) is in global memory up to column block s (FUSE)
+    int* xprog2 = xprog + nb;                           // [j]: the same for the tile (j+2, j) right below it (a worker's)
+    const bool lu_mode = FUSE && a.nchain == 3 && a.lu_w > 0;
+    // lu_mode: half h (1, 2) of tile (k+1, k) carries every update but the last: two words of upd_done that nothing else uses (the
+    // sub-diagonal and the diagonal position of column k)
+    auto pre_done = [&](int k, int h) -> int* { return upd_done + (h == 1 ? k + 1 : k) + (long)k * nb; };
     const int nchain = a.nchain;
+    if constexpr (FUSE) {
+        if (b < 3 && nchain == 3) {
+            // ---- the chain, THREE workgroups in rotation (round 6) ----
+            // While workgroup F factors diagonal block j (publishing its column blocks), S solves the panel tile (j+1, j) behind it
+            // block by block and stores every finished block at once (stream_trsm_syrk<false>), and Y accumulates A_{j+1,j+1} - X X^T
+            // from those blocks as they land (stream_syrk_image): when block j ends, what remains before block j+1 can start is the
+            // last block of X (eight products + its store), its arrival at Y and ONE slab of the product -- not the whole product
+            // (10.7 us on one CU in the two-workgroup form).  Y then factors block j+1 from its own LDS image, F becomes the next S, S the
+            // next Y.  Workgroup c: blocks c, c + 3, ... (Y, then F), then the solve of tile (j+2, j+1) behind block j+1.
+            for (int j = (b == 2 ? -1 : b); j <= nb - 1; j += 3) {
+                if (j >= 0) {
+                    double* Ajj = a.A + (long)j * NB * (ld + 1);
+                    double* Tjj = a.Linv + (long)j * NB * (ld + 1);
+                    if (j == 0) diag_block_factor<true>(Ajj, ld, Tjj, ld, a.info, 0, smem, factored + 0);
+                    else {
+                        long long* stamp = (a.trace && threadIdx.x == 0) ? a.trace + 16 * (j - 1) : nullptr;
+                        if (!stream_syrk_image(Ajj - (long)NB * ld, ld, xprog + (j - 1), a.info + 1, a.timeout, Ajj, ld,
+                                               [&]() { return stream_wait(diag_ready + (j - 1), 1, a.info + 1, a.timeout); }, stamp, lds))
+                            return;
+                        __syncthreads();
+                        if (stamp) stamp[3] = wall_clock64();
+                        diag_block_factor<false>(Ajj, ld, Tjj, ld, a.info, j * NB, smem, factored + j);
+                        if (stamp) stamp[4] = wall_clock64();
+                    }
+                }
+                const int k = j + 1;                                   // the solve of tile (k+1, k) behind diagonal block k
+                if (k + 1 <= nb - 1) {
+                    double* Akk = a.A + (long)k * NB * (ld + 1);
+                    double* Tkk = a.Linv + (long)k * NB * (ld + 1);
+                    long long* stamp = (a.trace && threadIdx.x == 0) ? a.trace + 16 * k : nullptr;
+                    if (stamp) stamp[10] = wall_clock64();
+                    if (!pk_wait_count(chain_ready + k, 1 + a.split_sub, a)) return;   // tile (k+1, k) carries its owners' updates
+                    if (stamp) stamp[11] = wall_clock64();
+                    if (!stream_trsm_syrk<false>(Akk + NB, ld, Akk, ld, Tkk, ld, factored + k, a.info + 1, a.timeout, (const double*)nullptr, 0L,
+                                                 []() { return true; }, xprog + k, (long long*)nullptr, lds))
+                        return;
+                    df_publish_store(panel_done + (k + 1) + (long)k * nb);    // the last block's stores have drained (raise(8)); the barrier frees the LDS
+                    if (stamp) stamp[13] = wall_clock64();
+                }
+            }
+            return;
+        }
+    }
     if (b < 2 && nchain == 2) {
         // ---- the chain, streamed form: TWO workgroups taking turns ----
         // Workgroup c factors the diagonal blocks j = c, c + 2, ... and publishes their column blocks while it does (StreamPublish).
@@ -1392,49 +1567,36 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             if (!pk_wait_count(chain_ready + j, 1 + a.split_sub, a)) return;   // tile (j+1, j) carries its owners' updates (steps < j)
             PK_STAMP(11);
             int* xflag = panel_done + (j + 1) + (long)j * nb;
-            if constexpr (FUSE) {
-                // solve, store and multiply in one pass (stream_trsm_syrk); the diagonal tile's owner finished its updates long since
-                // (its last one comes ~6 us after the sub-diagonal tile's): a relaxed look per wave, a spin only if it is not up yet
-                long long* stamp = (a.trace && threadIdx.x == 0) ? a.trace + 16 * j : nullptr;
-                if (!stream_trsm_syrk(Asub, ld, Ajj, ld, Tjj, ld, factored + j, a.info + 1, a.timeout, Anext, ld,
-                                      [&]() { return stream_wait(diag_ready + j, 1, a.info + 1, a.timeout); }, xprog + j, stamp, lds))
-                    return;
-                PK_STAMP(1);
-                PK_STAMP(2);
-                df_publish_store(xflag);                       // drains the last block's stores; the image is complete behind its barrier
-                PK_STAMP(13);
-            } else {
-                {
-                    ChainAcc ca;
-                    if (!stream_trsm(ca, Asub, ld, Ajj, ld, Tjj, ld, factored + j, a.info + 1, a.timeout, lds)) return;
-                    PK_STAMP(12);
-                    PK_STAMP(0);                                   // diagonal block j has ended (on the other workgroup) a moment ago
-                    chain_acc_to_image<true>(ca, lds);
-                }
-                int* ctl = reinterpret_cast<int*>(lds + 128 * DL);               // a word behind the image (the T16 buffers of the solve: dead)
-                if (threadIdx.x == 0) *ctl = df_flag(diag_ready + j) >= 1 ? 1 : 0;   // one decision for the workgroup, see below
-                lds_barrier();
-                chain_image_store_wt(Asub, ld, lds);
-                {
-                    // The diagonal tile's owner finished its updates long since (its last one comes ~6 us after the sub-diagonal
-                    // tile's, i.e. ~10 us before this point): a relaxed look at its flag, the full wait only if it is not up yet.
-                    const int up = *ctl;
-                    if (!up && !pk_wait_count(diag_ready + j, 1, a)) return;
-                }
-                // The product starts at once: the stores have left the image (it is only overwritten behind the product), and their
-                // drain -- 3.3 us for 128 KB of write-through stores + the 64 KB of loads above -- would sit on the chain's path.  The
-                // flag for the workers goes up behind the product's second slab, when the drain is over anyway.
-                PK_STAMP(1);
-                PK_STAMP(2);
-                // image <- A_{j+1,j+1} - L L^T on the lower blocks (the tile comes in the accumulator layout, agent-scope loads in flight
-                // behind the product; what stands above the diagonal blocks is never read by the factorisation)
-                chain_syrk_inplace(lds, [&](int sblk) {
-                    if (sblk == 2) {
-                        df_publish_store(xflag);
-                        PK_STAMP(13);
-                    }
-                }, Anext, ld);
+            {
+                ChainAcc ca;
+                if (!stream_trsm(ca, Asub, ld, Ajj, ld, Tjj, ld, factored + j, a.info + 1, a.timeout, lds)) return;
+                PK_STAMP(12);
+                PK_STAMP(0);                                   // diagonal block j has ended (on the other workgroup) a moment ago
+                chain_acc_to_image<true>(ca, lds);
             }
+            int* ctl = reinterpret_cast<int*>(lds + 128 * DL);               // a word behind the image (the T16 buffers of the solve: dead)
+            if (threadIdx.x == 0) *ctl = df_flag(diag_ready + j) >= 1 ? 1 : 0;   // one decision for the workgroup, see below
+            lds_barrier();
+            chain_image_store_wt(Asub, ld, lds);
+            {
+                // The diagonal tile's owner finished its updates long since (its last one comes ~6 us after the sub-diagonal
+                // tile's, i.e. ~10 us before this point): a relaxed look at its flag, the full wait only if it is not up yet.
+                const int up = *ctl;
+                if (!up && !pk_wait_count(diag_ready + j, 1, a)) return;
+            }
+            // The product starts at once: the stores have left the image (it is only overwritten behind the product), and their
+            // drain -- 3.3 us for 128 KB of write-through stores + the 64 KB of loads above -- would sit on the chain's path.  The
+            // flag for the workers goes up behind the product's second slab, when the drain is over anyway.
+            PK_STAMP(1);
+            PK_STAMP(2);
+            // image <- A_{j+1,j+1} - L L^T on the lower blocks (the tile comes in the accumulator layout, agent-scope loads in flight
+            // behind the product; what stands above the diagonal blocks is never read by the factorisation)
+            chain_syrk_inplace(lds, [&](int sblk) {
+                if (sblk == 2) {
+                    df_publish_store(xflag);
+                    PK_STAMP(13);
+                }
+            }, Anext, ld);
             PK_STAMP(8);
             PK_STAMP(9);
             __syncthreads();
@@ -1510,9 +1672,32 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             for (int q = 0; q < xcc; ++q) widx += __hip_atomic_load(a.sync + 8 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const bool hybrid = a.g1 > 0 && a.hybrid_near >= 0;
-        const bool banded = a.g1 == 0 && a.band_w > 0 && a.band_w < W;
+        const bool banded = !hybrid && a.band_w > 0 && a.band_w < W;
         const int band = a.split_band;
-        if (ok && banded) {
+        if (ok && lu_mode && a.lu_w < W) {
+            // the usual items in the usual order over the workers behind the first lu_w; the last updates of the sub-diagonal halves
+            // (type 3 / 4: columns 0-63 / 64-127 of tile (k+1, k), k >= 1) over those first lu_w
+            const int R = a.lu_w;
+            const int me_near = widx < R ? widx : -1, me_far = widx >= R ? widx - R : -1;
+            int cn = 0, cf = 0;
+            auto put = [&](int i, int k, int type) {
+                if (nt < DF_MAXT) { SW(0, nt) = i; SW(1, nt) = k; SW(2, nt) = 0; SW(3, nt) = 0; SW(6, nt) = type; ++nt; }
+            };
+            for (int k = 0; k < nb; ++k) {
+                const int c = nb - k + min(band, nb - 1 - k);
+                for (int e = k == 0 ? 1 : 0; e < c; ++e) {
+                    const bool second = e >= nb - k;
+                    const int i = second ? k + 1 + (e - (nb - k)) : k + e;
+                    if (cf == me_far) put(i, k, second ? 2 : (e >= 1 && e <= band ? 1 : 0));
+                    if (++cf == W - R) cf = 0;
+                }
+                if (k >= 1 && k + 1 <= nb - 1)
+                    for (int h = 1; h <= 2; ++h) {
+                        if (cn == me_near) put(k + 1, k, 2 + h);
+                        if (++cn == R) cn = 0;
+                    }
+            }
+        } else if (ok && banded) {
             // At N = 8192 every worker is busy with 30 us updates of tiles far from the diagonal most of the time, and the chain's two
             // tiles of the next step queue behind them: it stood still for 1.2 of the 4.1 ms (POTRF_BENCH_TRACE).  The band next to
             // the diagonal therefore has owners that carry nothing else -- the first band_w workers in XCD order, i.e. the CUs around
@@ -1617,22 +1802,29 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             bool valid = t < nt && !SW(3, t);
             bool ok = true;
             if (valid) {
-                const int i = SW(0, t), k = SW(1, t), d = SW(2, t);
-                const int target = i == k ? k - 1 : k;         // steps the owner applies (the chain applies step k-1 to (k, k))
-                if (d < target) {
+                const int i = SW(0, t), k = SW(1, t), d = SW(2, t), typ = SW(6, t);
+                // steps the owner applies (the chain applies step k-1 to (k, k); lu_mode: the last one of a sub-diagonal half is an item of its own)
+                const int target = i == k ? k - 1 : (lu_mode && i == k + 1 && k >= 1 && (typ == 1 || typ == 2)) ? k - 1 : k;
+                if (typ >= 3) {
+                    if (l == 0) ok = df_flag(pre_done(k, typ - 2)) != 0;
+                    else if (l == 1) ok = df_flag(xprog + k - 1) >= 4;
+                    else if (l == 2) ok = df_flag(xprog2 + k - 1) >= 4;
+                    if (a.trace && typ == 3 && l <= 2 && ok && a.trace[16 * (k - 1) + 5 + l] == 0) a.trace[16 * (k - 1) + 5 + l] = wall_clock64();   // probes: when each input was first seen
+                } else if (d < target) {
                     const int j0 = d;
                     const int j1 = df_chunk_end(k, j0, target, nbo, a.near);
                     const int j = j0 + (l & 7);
                     // the last update of a sub-diagonal half tile runs behind the chain's solve of its second operand (FUSE): the
                     // first block of that tile instead of the whole
-                    const bool streamed = FUSE && nchain == 2 && i == k + 1 && SW(6, t) != 0 && j1 == target && j1 - j0 == 1;
-                    if (streamed && l >= 8) {
+                    const bool streamed = FUSE && nchain == 3 && !lu_mode && i == k + 1 && SW(6, t) != 0 && j1 == target && j1 - j0 == 1;
+                    if (streamed) {
                         if (l == 8) ok = df_flag(xprog + j0) >= 4;
+                        else if (l == 0) ok = df_flag(xprog2 + j0) >= 4;
                     } else if (j < j1 && !(l >= 8 && i == k)) ok = df_flag(panel_done + (l < 8 ? i : k) + (long)j * nb) != 0;
                 } else if (i > k + 1 && SW(6, t) != 2) {
                     // the diagonal block (round-3 chain), or its first column block (3 = one arrival per publishing wave) in the streamed
                     // form, where the tile is solved block by block behind it; a tile with two owners: the other half
-                    const int need = nchain == 2 ? 3 : 1;
+                    const int need = nchain >= 2 ? 3 : 1;
                     if (l == 0) ok = df_flag(factored + k) >= need;
                     else if (l == 1 && SW(6, t) == 1) ok = df_flag(upd_done + i + (long)k * nb) != 0;
                 }
@@ -1686,16 +1878,29 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             continue;
         }
         const int t = first + sel;
-        const int i = SW(0, t), k = SW(1, t), d = SW(2, t);
-        const int target = i == k ? k - 1 : k;
+        const int i = SW(0, t), k = SW(1, t), d = SW(2, t), typ = SW(6, t);
+        const bool lu_sub = lu_mode && i == k + 1 && k >= 1 && (typ == 1 || typ == 2);   // a sub-diagonal half whose last update is somebody else's
+        const int target = i == k ? k - 1 : lu_sub ? k - 1 : k;
         double* Cik = a.A + (long)i * NB + (long)k * NB * ld;
-        if (d < target) {
+        if (typ >= 3) {
+            // the last update of half a sub-diagonal tile, behind the chain's solve of L_{k,k-1} and a worker's of L_{k+1,k-1}
+            if (!stream_update_half(Cik, ld, a.A + (long)i * NB + (long)(k - 1) * NB * ld, a.A + (long)k * NB + (long)(k - 1) * NB * ld, typ - 3,
+                                    xprog2 + (k - 1), xprog + (k - 1), a.info + 1, a.timeout, lds))
+                return;
+            df_publish_add(chain_ready + k);
+            if (a.trace && tid == 0) {
+                a.trace[16 * (k - 1) + 14 + 0] = typ == 3 ? st_task0 : a.trace[16 * (k - 1) + 14];
+                if (typ == 3) a.trace[16 * (k - 1) + 15] = wall_clock64();
+            }
+            if (tid == 0) SW(3, t) = 1;
+            ++st_n_upd;
+        } else if (d < target) {
             const int j0 = d;
             const int j1 = df_chunk_end(k, j0, target, nbo, a.near);
             const int half = SW(6, t);
-            if (FUSE && nchain == 2 && half != 0 && i == k + 1 && j1 == target && j1 - j0 == 1) {
+            if (FUSE && nchain == 3 && !lu_mode && half != 0 && i == k + 1 && j1 == target && j1 - j0 == 1) {
                 if (!stream_update_half(Cik, ld, a.A + (long)i * NB + (long)j0 * NB * ld, a.A + (long)k * NB + (long)j0 * NB * ld, half - 1,
-                                        xprog + j0, a.info + 1, a.timeout, lds))
+                                        xprog2 + j0, xprog + j0, a.info + 1, a.timeout, lds))
                     return;
                 df_publish_add(chain_ready + k);
                 if (a.trace && tid == 0 && k >= 1) {
@@ -1724,7 +1929,10 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             const bool last = j1 == target;
             const bool to_chain = last && i <= k + 1;         // (k+1, k) and (k, k) go to the chain after their last update
             if (half != 0) {                                  // a half of a sub-diagonal tile
-                if (to_chain) {
+                if (to_chain && lu_sub) {                     // every update but the last is in: over to the last update's owner
+                    tile_commit_half<1, true>(Cik, ld, acc, lds, half - 1);
+                    df_publish_store(pre_done(k, half));
+                } else if (to_chain) {
                     tile_commit_half<1, true>(Cik, ld, acc, lds, half - 1);
                     df_publish_add(chain_ready + k);
                     if (a.trace && tid == 0 && k >= 1) {      // probes: the last update of tile (k+1, k), first half: begin / end
@@ -1759,7 +1967,14 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             }
         } else if (i > k + 1) {
             ++st_n_panel;
-            if (nchain == 2) {
+            if (FUSE && nchain == 3 && i == k + 2) {
+                // the tile right below the chain's: its blocks leave as they become final and are counted (xprog2): the last update of
+                // tile (k+2, k+1) runs behind them and behind the chain's own tile (stream_update_half)
+                if (!stream_trsm_syrk<false>(Cik, ld, a.A + (long)k * NB * (ld + 1), ld, a.Linv + (long)k * NB * (ld + 1), ld, factored + k,
+                                             a.info + 1, a.timeout, (const double*)nullptr, 0L, []() { return true; }, xprog2 + k,
+                                             (long long*)nullptr, lds))
+                    return;
+            } else if (nchain >= 2) {
                 const bool stamp = a.trace && tid == 0 && i == k + 2 && !FUSE;      // probes: the panel tile right below the chain (FUSE: the slots carry the solve.s own stamps)
                 if (stamp) a.trace[16 * k + 5] = st_task0;
                 ChainAcc ca;
@@ -1789,9 +2004,10 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             df_publish_store(panel_done + i + (long)k * nb);
             if (tid == 0) SW(3, t) = 1;
         } else {
-            // no update to apply at all: tiles (1, 0) and (1, 1)
+            // no update to apply at all: tiles (1, 0) and (1, 1) (lu_mode: the halves of tile (2, 1), whose only update is the last one's owner's)
             if (tid == 0) {
-                __hip_atomic_fetch_add(i == k ? diag_ready + k - 1 : chain_ready + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lu_sub) __hip_atomic_store(pre_done(k, typ), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else __hip_atomic_fetch_add(i == k ? diag_ready + k - 1 : chain_ready + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 SW(3, t) = 1;
             }
         }
@@ -1882,7 +2098,7 @@ int potrf_dataflow_nbo(int Np) {
 // ints of device scratch the dataflow form needs per problem
 size_t potrf_dataflow_sync_ints(int Np) {
     const size_t nb = Np / NB;
-    return DF_FACT + 4 * nb + 3 * nb * nb;           // factored, chain_ready, panel_done[nb][nb], xdone[nb][nb] (fused inverse), diag_ready, upd_done[nb][nb], xprog
+    return DF_FACT + 5 * nb + 3 * nb * nb;           // factored, chain_ready, panel_done[nb][nb], xdone[nb][nb] (fused inverse), diag_ready, upd_done[nb][nb], xprog
 }
 // How many independent Np x Np factorisations share one launch well: a problem keeps the chip busy with about nb^2 / 14.5 workers
 // (its ~nb^3 / 6 tile tasks of ~20 us against a chain of nb steps of ~48 us); the rest of the CUs can factor other problems.
@@ -1902,11 +2118,15 @@ int potrf_dataflow_max_problems(int Np) {
 // false if the matrix is too large for it (N > 4096: the chip is busy with the factorisation itself) or too few CUs remain.
 static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double* Linv, int* info, int* sync, int nprob, long strideA,
                                        long stride_sync, bool block_inverses, long long* trace, const PotriFused* inv) {
-    // Measured (round 6, N = 2048, profiles/r06_potrf_fused_chain.log): the fused solve takes the serial L L^T product (10.7 us) off
-    // the step, but the solve itself then carries 25 us of work per tile (16 without the product) against the 19.8 us of the
-    // diagonal block it follows, and the tile below reaches it 10-21 us after the block before it ended: 37-49 us per step against
-    // 35.7.  Off by default until the solve is under the diagonal block's time.
-    const bool fuse = tune_on(TUNE_POTRF_FUSE_SYRK, false);
+    // SLS_POTRF_FUSE_SYRK: the chain as THREE workgroups in rotation (factor / solve / product), the product of the next diagonal tile
+    // accumulated from the solve's blocks as they are published instead of in one piece behind it.  Round 6, same box, two-workgroup
+    // chain -> three (ms, factor alone / factor + inverse; profiles/r06_potrf_chain3_ab.log): N = 1536: 0.447 / 0.523 -> 0.443 / 0.512,
+    // 2048: 0.584 / 0.693 -> 0.570 / 0.666, 2560: 0.757 / 1.046 -> 0.740 / 1.046, 3072: 0.917 / 1.280 -> 0.900 / 1.283, 4096: 1.289 /
+    // 2.160 -> 1.254 / 2.19.  The step's serial tail falls from 13 us to 2.3, but the solve now runs unthrottled for 17-20 us per tile
+    // and starts 9 us behind the diagonal block (the tile below the chain's needs the column before it complete): 33 us per step against
+    // 35.7.  On for 12 <= N / 128 <= 20, where it wins.  (The first form of this round, solve + product in ONE workgroup, lost: 37-49 us.)
+    const int nb_ = Np / NB;
+    const bool fuse = tune_on(TUNE_POTRF_FUSE_SYRK, nb_ >= 12 && nb_ <= 20);
     ensure_dyn_lds((const void*)potrf_dataflow_kernel<true>, DIAG_LDS_BYTES);
     ensure_dyn_lds((const void*)potrf_dataflow_kernel<false>, DIAG_LDS_BYTES);
     const int nb = Np / NB;
@@ -1933,13 +2153,14 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
     // and three-step update chunks: 4.10 -> 3.97 ms (profiles/r06_potrf8192_scan.log).  Dedicated owners for the band next to the
     // diagonal (SLS_POTRF_BAND_W) were measured too and lose at every size of the band (4.2-9.4 ms, r06_potrf8192_band_scan.log).
     const bool stream_dflt = nprob == 1 && (nb <= 40 || (Np >= 8192 && Np < 16384));
-    const int nchain = (int)tune(TUNE_POTRF_STREAM, stream_dflt ? SLS_POTRF_STREAM_DEFAULT : 0) != 0 && nb >= 4 ? 2 : 1;
+    // fuse (SLS_POTRF_FUSE_SYRK): three chain workgroups in rotation (factor / solve / product), see potrf_dataflow_kernel
+    const int nchain = (int)tune(TUNE_POTRF_STREAM, stream_dflt ? SLS_POTRF_STREAM_DEFAULT : 0) != 0 && nb >= 4 ? (fuse && nprob == 1 ? 3 : 2) : 1;
     // SLS_POTRF_SPLIT = band: the tiles (i, k) with 1 <= i - k <= band have one owner per 64-column half (0: whole tiles only)
     // Measured (tools/probes: ms at N = 2048 / 3072 / 4096): factorisation alone: band 1: 0.655 / 0.992 / 1.363, 4: 0.645 / 0.999 / 1.353,
     // all: 0.654 / 1.000 / 1.345 -- what matters is that every row's cycle is shorter than the chain's step, the solving workgroup then finds
     // its tile 14-22 us before the diagonal block ends at EVERY step (before: -4 .. +6 us at every third one).  With the fused
     // inverse sharing the chip: band 1: 0.742 / 1.284 / 2.158, all: 0.733 / 1.344 / 2.518 (CUs are short from N = 3072).
-    const int split_band = nchain == 2 ? std::max(0, std::min(nb - 1, (int)tune(TUNE_POTRF_SPLIT, nb > 40 ? 0 : (nb <= 16 || !inv) ? nb : 1))) : 0;
+    const int split_band = nchain >= 2 ? std::max(0, std::min(nb - 1, (int)tune(TUNE_POTRF_SPLIT, nb > 40 ? 0 : (nb <= 16 || !inv) ? nb : 1))) : 0;
     const int split_sub = split_band >= 1 ? 1 : 0;
     int n_second = 0;
     for (int kk = 0; kk < nb; ++kk) n_second += std::min(split_band, nb - 1 - kk);
@@ -1979,8 +2200,13 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
     a.split_sub = split_sub;
     a.split_band = split_band;
     a.hybrid_near = inv ? (int)tune(TUNE_POTRI_HYBRID, -1) : -1;
+    // three-workgroup chain: the diagonal and sub-diagonal tiles -- whose last updates run behind the chain's solve and decide when the
+    // next solve may start -- get owners that carry nothing else (a worker in the middle of a 10 us update of another tile would hold
+    // the chain up every other step)
     a.band_near = (int)tune(TUNE_POTRF_BAND, 2);
-    a.band_w = (!inv && nprob == 1) ? std::max(0, std::min(W - 1, (int)tune(TUNE_POTRF_BAND_W, 0))) : 0;
+    a.band_w = nprob == 1 ? std::max(0, std::min(W - 1, (int)tune(TUNE_POTRF_BAND_W, 0))) : 0;
+    a.lu_w = (nchain == 3 && split_sub) ? std::max(0, std::min(W - 1, (int)tune(TUNE_POTRF_LU_W, 6))) : 0;
+    if (a.lu_w > 0 && ((2 * nb + a.lu_w - 1) / a.lu_w > DF_MAXT || (tiles + (W - a.lu_w) - 1) / (W - a.lu_w) > DF_MAXT)) a.lu_w = 0;
     if (a.band_w > 0) {   // both deals must fit the per-worker tables
         const int near_tiles = (a.band_near + 1) * nb + n_second, far_tiles = tiles - std::min(tiles, near_tiles);
         if ((near_tiles + a.band_w - 1) / a.band_w > DF_MAXT || (far_tiles + (W - a.band_w) - 1) / (W - a.band_w) > DF_MAXT) a.band_w = 0;
