@@ -537,8 +537,8 @@ static void gp_fit_device(sls_gp* g) {
         }
     }
     // alpha = Linv^T (Linv y);  mu at the data points = y - b alpha;  x_best = first argmax  (regressor.cpp:29-43 hoisted)
-    launch_gemv_n(c->stream, g->Linv.p, Np, g->y.p, g->tvec.p, g->gemv_part.p);
-    launch_gemv_t(c->stream, g->Linv.p, Np, g->tvec.p, g->alpha.p);
+    launch_gemv_n(c->stream, g->Linv.p, Np, g->y.p, g->tvec.p, g->gemv_part.p, true);
+    launch_gemv_t(c->stream, g->Linv.p, Np, g->tvec.p, g->alpha.p, true);
     launch_scale_rows(c->stream, g->XT.p, g->alpha.p, g->XaT.p, Np, Np, g->Dcols);
     if (g->sigma_mode == 1) launch_transpose_full(c->stream, g->Linv.p, g->U.p, Np);   // every block of U = (L^-1)^T
     // mu at the data points, its first maximum, log|K_y| and the info words: one launch, results straight into the mapped block
@@ -1616,7 +1616,7 @@ extern "C" int sls_gp_append_point(sls_gp* g, const double* x, double y_new) {
     // Ks[n + i*128], n = 0 -> stride-128 gather into a dense vector (padding rows i >= N are 0)
     SLS_HIP(hipMemcpy2DAsync(kvec, 8, g->Ks.p, 128 * 8, 8, Np, hipMemcpyDeviceToDevice, c->stream));
     launch_gemv_n(c->stream, g->Kinv.p, Np, kvec, uvec, g->gemv_part.p);     // u = K^-1 k   (padding: identity block x 0 = 0)
-    launch_gemv_n(c->stream, g->Linv.p, Np, kvec, lvec, g->gemv_part.p);     // l = L^-1 k
+    launch_gemv_n(c->stream, g->Linv.p, Np, kvec, lvec, g->gemv_part.p, true);     // l = L^-1 k
     launch_append_dots(c->stream, kvec, uvec, lvec, g->y.p, N, scal);
     const double kappa = g->a + g->b;
     launch_append_update(c->stream, g->Kinv.p, g->L.p, g->Linv.p, g->alpha.p, Np, N, uvec, lvec, scal, kappa, y_new);

@@ -326,8 +326,8 @@ void launch_lauum(hipStream_t s, const double* U, int Np, double* Kinv);        
 // B (Np x Rp, ld = Np, Rp multiple of 128) <- (L L^T)^-1 B using the block inverses in Linv's diagonal
 void launch_potrs(hipStream_t s, const double* L, const double* Linv, int Np, double* B, int Rp);
 // y = A x; `part` is a caller-owned scratch of (Np/128) * Np doubles (per-chunk partial sums, reduced in fixed order)
-void launch_gemv_n(hipStream_t s, const double* A, int Np, const double* x, double* y, double* part);
-void launch_gemv_t(hipStream_t s, const double* A, int Np, const double* x, double* y);   // y = A^T x
+void launch_gemv_n(hipStream_t s, const double* A, int Np, const double* x, double* y, double* part, bool lower = false);   // lower: A is lower triangular (zeros above the diagonal are not read)
+void launch_gemv_t(hipStream_t s, const double* A, int Np, const double* x, double* y, bool lower = false);   // y = A^T x
 void launch_zero_upper(hipStream_t s, double* A, int Np);
 void launch_fill(hipStream_t s, double* p, long n, double v);
 // mu_data[i] = y[i] - b*alpha[i] (i<N); out: first argmax + value; logdet = 2 sum log L_ii (i<N)

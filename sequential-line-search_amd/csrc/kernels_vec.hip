@@ -9,11 +9,18 @@ namespace slsk {
 
 // y = A x (A column-major Np x Np): columns split into chunks over blockIdx.y so that the whole chip streams the matrix;
 // the per-chunk partials are summed in a fixed order by a second tiny kernel (deterministic).
+// lower: A is lower triangular (L^-1): a chunk of columns entirely to the right of this block's rows holds zeros only -- its partial sum
+// is written as the +0 the products would add up to, without reading the 256 x 128 zeros (half of the matrix: the fit's two products
+// with L^-1 streamed 2 x 512 MB at N = 8192 for 2 x 256 MB of content).  Same bits.
 __global__ __launch_bounds__(256) void gemv_n_partial_kernel(const double* __restrict__ A, int Np, const double* __restrict__ x,
-                                                             double* __restrict__ part, int cols_per_chunk) {
+                                                             double* __restrict__ part, int cols_per_chunk, int lower) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= Np) return;
     const int j0 = blockIdx.y * cols_per_chunk;
+    if (lower && j0 > (int)blockIdx.x * 256 + 255) {
+        part[(long)blockIdx.y * Np + i] = 0.0;
+        return;
+    }
     double s = 0.0;
 #pragma unroll 4
     for (int j = j0; j < j0 + cols_per_chunk; ++j) s += A[(long)i + (long)j * Np] * x[j];
@@ -27,26 +34,28 @@ __global__ __launch_bounds__(256) void gemv_n_reduce_kernel(const double* __rest
     for (int c = 0; c < chunks; ++c) s += part[(long)c * Np + i];
     y[i] = s;
 }
-void launch_gemv_n(hipStream_t s, const double* A, int Np, const double* x, double* y, double* part) {
+void launch_gemv_n(hipStream_t s, const double* A, int Np, const double* x, double* y, double* part, bool lower) {
     const int chunks = Np / 128;                 // 128 columns per chunk
-    hipLaunchKernelGGL(gemv_n_partial_kernel, dim3((Np + 255) / 256, chunks), dim3(256), 0, s, A, Np, x, part, 128);
+    hipLaunchKernelGGL(gemv_n_partial_kernel, dim3((Np + 255) / 256, chunks), dim3(256), 0, s, A, Np, x, part, 128, lower ? 1 : 0);
     hipLaunchKernelGGL(gemv_n_reduce_kernel, dim3((Np + 255) / 256), dim3(256), 0, s, part, Np, chunks, y);
 }
 
 // y_j = sum_i A[i,j] x_i : one wave per column, wave-shuffle reduction
+// lower: column j of a lower-triangular A is zero above row j: the wave starts at the 64-row group that holds the diagonal (the terms
+// left out are +0: same bits)
 __global__ __launch_bounds__(256) void gemv_t_kernel(const double* __restrict__ A, int Np, const double* __restrict__ x,
-                                                     double* __restrict__ y) {
+                                                     double* __restrict__ y, int lower) {
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= Np) return;
     double s = 0.0;
-    for (int i = lane; i < Np; i += 64) s += A[(long)i + (long)j * Np] * x[i];
+    for (int i = (lower ? (j & ~63) : 0) + lane; i < Np; i += 64) s += A[(long)i + (long)j * Np] * x[i];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (lane == 0) y[j] = s;
 }
-void launch_gemv_t(hipStream_t s, const double* A, int Np, const double* x, double* y) {
-    hipLaunchKernelGGL(gemv_t_kernel, dim3((Np + 3) / 4), dim3(256), 0, s, A, Np, x, y);
+void launch_gemv_t(hipStream_t s, const double* A, int Np, const double* x, double* y, bool lower) {
+    hipLaunchKernelGGL(gemv_t_kernel, dim3((Np + 3) / 4), dim3(256), 0, s, A, Np, x, y, lower ? 1 : 0);
 }
 
 __device__ __forceinline__ double block_sum256(double v, double* red) {
