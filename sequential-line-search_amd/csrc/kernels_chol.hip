@@ -188,6 +188,7 @@ struct PersistArgs {
     // three-workgroup chain: the LAST update of every sub-diagonal half tile (the one that runs behind the chain's solve) is an item of its
     // own, dealt over the first lu_w workers, which carry nothing else (0: it stays with the tile's owner)
     int lu_w;
+    int prio_band;      // workers: a ready task of a tile within this many blocks of the diagonal is taken before the others (0: list order)
 };
 #define PK_STAMP(slot) do { if (a.trace && threadIdx.x == 0) a.trace[16 * j + (slot)] = wall_clock64(); } while (0)
 
@@ -1831,11 +1832,19 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             }
             const unsigned long long m = __ballot(ok);
             const unsigned grp = (unsigned)(m >> (16 * ((tid >> 4) & 3))) & 0xffffu;
-            if (l == 0) SW(4, slot) = (valid && grp == 0xffffu) ? 1 : 0;
+            // 2: ready and within prio_band blocks of the diagonal (look-ahead: such a task goes first, whatever its place in the list)
+            if (l == 0) SW(4, slot) = (valid && grp == 0xffffu) ? ((a.prio_band > 0 && SW(0, t) - SW(1, t) <= a.prio_band) ? 2 : 1) : 0;
             __syncthreads();
 #pragma unroll
             for (int q = DF_WIN - 1; q >= 0; --q)
                 if (SW(4, q)) sel = q;
+            if (a.prio_band > 0) {
+                int sel2_ = -1;
+#pragma unroll
+                for (int q = DF_WIN - 1; q >= 0; --q)
+                    if (SW(4, q) == 2) sel2_ = q;
+                if (sel2_ >= 0) sel = sel2_;
+            }
             __syncthreads();
         }
         if (sel < 0 && first2 < nt2) {                         // nothing of the factorisation's is ready: the inverse's items (potri_team's round)
@@ -2203,6 +2212,7 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
     // three-workgroup chain: the diagonal and sub-diagonal tiles -- whose last updates run behind the chain's solve and decide when the
     // next solve may start -- get owners that carry nothing else (a worker in the middle of a 10 us update of another tile would hold
     // the chain up every other step)
+    a.prio_band = std::max(0, (int)tune(TUNE_POTRF_PRIO, 0));
     a.band_near = (int)tune(TUNE_POTRF_BAND, 2);
     a.band_w = nprob == 1 ? std::max(0, std::min(W - 1, (int)tune(TUNE_POTRF_BAND_W, 0))) : 0;
     a.lu_w = (nchain == 3 && split_sub) ? std::max(0, std::min(W - 1, (int)tune(TUNE_POTRF_LU_W, 6))) : 0;
