@@ -1,7 +1,7 @@
 mkdir -p gpurun_out/r06
-cd tools/probes
-for P in 0 1 2 3 4; do
-echo "== prio $P"
-(SLS_POTRF_PRIO=$P POTRF_BENCH_QUICK=1 POTRF_BENCH_POTRI=1 timeout 300 ./bin/potrf_bench 2048 3072 4096 8192) 2>&1 | grep -E "dataflow single|potri fused" | cut -c1-100
-done > ../../gpurun_out/r06/potrf_prio_scan.log 2>&1
-cat ../../gpurun_out/r06/potrf_prio_scan.log
+timeout 600 python bench.py --no-cpu-baseline --no-traffic --steps 2 --warmup 1 > gpurun_out/r06/bench_kmath.json 2>/dev/null
+python - <<'PY'
+import json
+j=json.loads(open('gpurun_out/r06/bench_kmath.json').read().strip().splitlines()[-1])
+print(j['ms_per_step'], j['roofline']['frac']); print(j['stage_ms_per_step']); print({k:round(v['frac'],3) for k,v in j['stage_rooflines'].items()})
+PY
