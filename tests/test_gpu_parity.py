@@ -4,6 +4,8 @@ Tolerance: BASELINE.json's north_star asks for 1e-6 relative in fp64; the assert
 (absolute floors only where the quantity itself underflows / cancels to ~0)."""
 import os
 
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -1097,6 +1099,32 @@ def test_gp_map_objective_batch_matches_single_evaluations(ctx, oracle, D, N):
         vo = np.array([oracle.gp_map_objective(kernel, X, y, xs[k])[0] for k in (0, 1, 2)])
         np.testing.assert_allclose(vb[:3], vo, rtol=1e-8)
         h.close()
+
+
+def test_lbfgs_opts_struct_size_versions(ctx, oracle):
+    """sls_lbfgs_opts is caller-allocated and has grown (ftol_rel / xtol_rel, round 5): struct_size says how much of it the caller's
+    header knows.  A struct of the FIRST version's size (up to max_backtracks) is accepted and the members beyond it take the
+    library's defaults (tolerances 0 = run to the cap: the same bits as no options at all); a size of 0 (a caller that never called
+    sls_lbfgs_default_opts) or one larger than the library's own struct is refused with an error, not read past its end."""
+    X, y, theta, b = synth_problem(oracle, 4, 60)
+    starts = synth_candidates(oracle, 4, 16)
+    gp = sls().GP(ctx, X, y, theta, b, 1)
+    L = sls().LbfgsOpts
+    full = L(6, 1e-4, 0.5, 0.0, 20, 0.0, 0.0)
+    assert full.struct_size == C.sizeof(L)
+    r_none = gp.acq_maximize(starts, 12)
+    r_full = gp.acq_maximize(starts, 12, opts=full)
+    assert np.array_equal(r_none["y_stars"], r_full["y_stars"])
+    old = L(6, 1e-4, 0.5, 0.0, 20, 123.0, 456.0)            # what sits behind the old struct's end must not be read
+    old.struct_size = L.max_backtracks.offset + C.sizeof(C.c_int)
+    r_old = gp.acq_maximize(starts, 12, opts=old)
+    assert np.array_equal(r_none["y_stars"], r_old["y_stars"]) and np.array_equal(r_none["x_stars"], r_old["x_stars"])
+    for bad in (0, C.sizeof(L) + 8, 4):
+        o = L()
+        o.struct_size = bad
+        with pytest.raises(sls().SlsError, match="struct_size"):
+            gp.acq_maximize(starts, 12, opts=o)
+    gp.close()
 
 
 @pytest.mark.parametrize("path,D,N,S", [("wave", 5, 40, 48), ("wave", 32, 61, 1), ("wave", 12, 200, 24), ("reg", 6, 300, 400), ("mem", 70, 256, 200)])

@@ -129,3 +129,20 @@ def test_build_specific_switches(pysls):
         pbo.determine_next_query(32, 10)
     assert len(pbo.get_current_options()) == 3
     pysls.set_global_search_strategy(before)
+
+
+def test_tolerance_setters_of_both_kinds_of_search(pysls):
+    """The local searches start with nloptutil::solve's 1e-6 / 1e-6, the MAP fits with 0 / 0 (off: the documented deviation,
+    INTEGRATION.md 2); both pairs have run-time setters (round 6 added the MAP fits': ADVICE), and a line search with the MAP fits
+    under the reference's tolerances still improves."""
+    assert pysls.get_local_search_tolerances() == (1e-6, 1e-6)
+    assert pysls.get_map_fit_tolerances() == (0.0, 0.0)
+    pysls.set_map_fit_tolerances(1e-6, 1e-6)
+    try:
+        assert pysls.get_map_fit_tolerances() == (1e-6, 1e-6)
+        optimizer = pysls.SequentialLineSearchOptimizer(num_dims=5)
+        res = run_line_search(optimizer, iters=8)
+        assert res[-1] < res[0], res
+    finally:
+        pysls.set_map_fit_tolerances(0.0, 0.0)
+    assert pysls.get_map_fit_tolerances() == (0.0, 0.0)
