@@ -182,6 +182,8 @@ struct PersistArgs {
     // fused inverse, hybrid pool: the factorisation's tiles (i, k) with i - k > hybrid_near are dealt over BOTH teams (an inverse
     // workgroup runs its factorisation tasks first); -1: the inverse team owns no tile of the factorisation (round-4 form)
     int hybrid_near;
+    int hybrid_kmax;    // ... only the tiles of the columns before this one (the factorisation's work is front-loaded)
+    int hybrid_rmin;    // ... and the K^-1 items of the rows from this one on go over both teams too (the inverse's work is back-loaded)
     // factorisation alone, large N: the tiles (i, k) with i - k <= band_near -- the ones whose updates the chain waits for -- have
     // band_w workers of their own (the first band_w in XCD order), which own nothing else; 0: one deal over all workers
     int band_w, band_near;
@@ -1749,7 +1751,7 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
                     const bool second = e >= nb - k;
                     const int i = second ? k + 1 + (e - (nb - k)) : k + e;
                     bool mine;
-                    if (i - k > a.hybrid_near) { mine = cf == me_far; if (++cf == W + G2) cf = 0; }
+                    if (i - k > a.hybrid_near && k < a.hybrid_kmax) { mine = cf == me_far; if (++cf == W + G2) cf = 0; }
                     else { mine = cn == me_near; if (++cn == W) cn = 0; }
                     if (mine && nt < DF_MAXT) {
                         SW(0, nt) = i; SW(1, nt) = k; SW(2, nt) = 0; SW(3, nt) = 0;
@@ -1761,14 +1763,20 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
         }
         SW(5, 0) = ok ? nt : -1;
         int nt2 = 0;
-        if (inv_wg) {
-            // the inverse's items, dealt as in potri_team (arrays 8 .. 14)
-            int turn = 0;
-            auto deal = [&](int type, int i, int j) {
-                if (turn == b2 && nt2 < DF_MAXT) {
+        if (inv_wg || (hybrid && ok)) {
+            // the inverse's items, dealt as in potri_team (arrays 8 .. 14).  Hybrid pool: the K^-1 items of the rows from hybrid_rmin on
+            // -- whose work arrives late, when the factorisation's workers have run out of tiles -- are dealt over BOTH teams
+            // (owner index: inverse workgroup b2, or G2 + the factorisation worker's index)
+            int turn = 0, turn2 = 0;
+            const int me1 = inv_wg ? b2 : -1, me2 = inv_wg ? b2 : G2 + widx;
+            auto put2 = [&](int type, int i, int j) {
+                if (nt2 < DF_MAXT) {
                     SW(8, nt2) = i; SW(9, nt2) = j; SW(10, nt2) = (type == 1 && j == i - 1 && a.inv_plast) ? 1 : 0; SW(11, nt2) = 0; SW(14, nt2) = type;
                     ++nt2;
                 }
+            };
+            auto deal = [&](int type, int i, int j) {
+                if (turn == me1) put2(type, i, j);
                 if (++turn == G2) turn = 0;
             };
             for (int r = 0; r < nb; ++r) {
@@ -1777,7 +1785,12 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
                 for (int j = 0; j < r; ++j) deal(1, r, j);
             }
             for (int r = 0; r < nb; ++r)
-                for (int j = 0; j <= r; ++j) deal(2, r, j);
+                for (int j = 0; j <= r; ++j) {
+                    if (hybrid && r >= a.hybrid_rmin) {
+                        if (turn2 == me2) put2(2, r, j);
+                        if (++turn2 == G2 + W) turn2 = 0;
+                    } else deal(2, r, j);
+                }
         }
         SW(13, 0) = nt2;
     }
@@ -2209,6 +2222,8 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
     a.split_sub = split_sub;
     a.split_band = split_band;
     a.hybrid_near = inv ? (int)tune(TUNE_POTRI_HYBRID, -1) : -1;
+    a.hybrid_kmax = (int)tune(TUNE_POTRI_HYB_KMAX, nb / 2);
+    a.hybrid_rmin = (int)tune(TUNE_POTRI_HYB_RMIN, nb / 2);
     // three-workgroup chain: the diagonal and sub-diagonal tiles -- whose last updates run behind the chain's solve and decide when the
     // next solve may start -- get owners that carry nothing else (a worker in the middle of a 10 us update of another tile would hold
     // the chain up every other step)
