@@ -56,6 +56,13 @@ namespace sequential_line_search
         double GetPreferenceValueStdev(const Eigen::VectorXd& point) const;
         double GetAcquisitionFuncValue(const Eigen::VectorXd& point) const;
 
+        /// Batched forms of the three accessors above (additions of this build: SURVEY.md 8(f3)): one query point per column of
+        /// `points` (D x M), ONE device pass each -- what the reference's GUI demo does pixel by pixel
+        /// (demos/bayesian_optimization_2d_gui/mainwidget.cpp:41-72).  Zeros while there is no data, like the scalar forms.
+        Eigen::VectorXd GetPreferenceValueMeans(const Eigen::MatrixXd& points) const;
+        Eigen::VectorXd GetPreferenceValueStdevs(const Eigen::MatrixXd& points) const;
+        Eigen::VectorXd GetAcquisitionFuncValues(const Eigen::MatrixXd& points) const;
+
         const Eigen::MatrixXd& GetRawDataPoints() const;
         void                   DampData(const std::string& directory_path) const;
 

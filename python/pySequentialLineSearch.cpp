@@ -131,6 +131,9 @@ PYBIND11_MODULE(pySequentialLineSearch, m)
         .def("get_preference_value_mean", &SequentialLineSearchOptimizer::GetPreferenceValueMean, "point"_a)
         .def("get_preference_value_stdev", &SequentialLineSearchOptimizer::GetPreferenceValueStdev, "point"_a)
         .def("get_acquisition_func_value", &SequentialLineSearchOptimizer::GetAcquisitionFuncValue, "point"_a)
+        .def("get_preference_value_means", &SequentialLineSearchOptimizer::GetPreferenceValueMeans, "points"_a)
+        .def("get_preference_value_stdevs", &SequentialLineSearchOptimizer::GetPreferenceValueStdevs, "points"_a)
+        .def("get_acquisition_func_values", &SequentialLineSearchOptimizer::GetAcquisitionFuncValues, "points"_a)
         .def("get_raw_data_points", &SequentialLineSearchOptimizer::GetRawDataPoints)
         .def("damp_data", &SequentialLineSearchOptimizer::DampData, "directory_path"_a)
         .def("set_gaussian_process_upper_confidence_bound_hyperparam",
@@ -155,6 +158,9 @@ PYBIND11_MODULE(pySequentialLineSearch, m)
         .def("get_preference_value_mean", &PreferentialBayesianOptimizer::GetPreferenceValueMean, "point"_a)
         .def("get_preference_value_stdev", &PreferentialBayesianOptimizer::GetPreferenceValueStdev, "point"_a)
         .def("get_acquisition_func_value", &PreferentialBayesianOptimizer::GetAcquisitionFuncValue, "point"_a)
+        .def("get_preference_value_means", &PreferentialBayesianOptimizer::GetPreferenceValueMeans, "points"_a)
+        .def("get_preference_value_stdevs", &PreferentialBayesianOptimizer::GetPreferenceValueStdevs, "points"_a)
+        .def("get_acquisition_func_values", &PreferentialBayesianOptimizer::GetAcquisitionFuncValues, "points"_a)
         .def("get_raw_data_points", &PreferentialBayesianOptimizer::GetRawDataPoints)
         .def("damp_data", &PreferentialBayesianOptimizer::DampData, "directory_path"_a)
         .def("set_gaussian_process_upper_confidence_bound_hyperparam",

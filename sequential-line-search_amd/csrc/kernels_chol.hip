@@ -663,7 +663,7 @@ struct NoSlabHook {
 // memory; its lower 16 x 16 blocks are loaded in the ACCUMULATOR layout -- agent-scope loads, in flight behind the product -- so
 // the subtraction happens in the write-back, without a pass of its own over the image).  The same single subtraction of the
 // complete sum: same bits as image <- product, image <- Csub - image.
-// The pieces of the product, shared by the in-place form below and by the form fused into the streamed solve (stream_trsm_syrk):
+// The pieces of the product, shared by the in-place form below and by the form that accumulates it from published blocks (stream_syrk_image):
 // the 3 x 3 deal, the tile the product is subtracted from in the accumulator layout, ONE slab of the sum, the write-back.
 template <int W>
 struct SyrkDeal {
@@ -762,28 +762,26 @@ __device__ __forceinline__ void chain_image_rsub(const double* __restrict__ C, l
     }
 }
 
-// ---- the streamed solve with the next diagonal tile's update folded in (round 6) -----------------------------
-// The chain's step used to be serial behind the solve: tile -> image -> global memory, THEN the 128 x 128 x 128 product L L^T on one
-// CU (10.7 us), THEN the diagonal block.  But L L^T = sum_s X_s X_s^T over the 16-column blocks of the panel tile, and block s is final at
-// step s of the solve -- while the workgroup is waiting for the other one to publish column block s + 1 of the diagonal block it is
-// still factoring.  So every finished block goes to an LDS slab (two of them, behind the solve's rings), from where it leaves for
-// global memory (whole 1 KB columns, write-through: the panel tile is stored BY the solve) and enters the product as ONE slab of
-// chain_syrk_inplace's sum -- same deal of the 36 lower blocks, same k order, same single subtraction from the tile at the end:
-// same bits.  Behind the last published block only remain: X_7 (eight products), its slab, one slab of the product (36 per wave)
-// and the write-back into the image.
+// ---- the streamed solve that PUBLISHES its blocks (round 6: the three-workgroup chain) -----------------------------------------
+// stream_trsm, with every finished 16-column block X_s leaving at once: to an LDS slab (two of them, behind the solve's rings), from
+// there to global memory (whole 1 KB columns, write-through: the tile is stored BY the solve, in place) and counted in `xprog` (+1 per
+// wave and block once that wave's four columns of it have drained: 4 (s + 1) = block s is in global memory).  Two consumers run
+// behind the counter: the workgroup that forms the next diagonal tile's A - X X^T slab by slab (stream_syrk_image), and the last
+// update of the tile below (stream_update_half).  Same arithmetic as stream_trsm: same bits.
+// Order of a step, behind its barrier: the next column block of the diagonal block (if the poll of the step before saw it
+// published), the poll for the step after (an inline-assembly load: the compiler puts a vmcnt(0) in front of a tracked load's
+// result while LDS-direct loads are in flight), the stores of X_{s-1} (formed a step ago), the A slab three steps ahead; block
+// s - 2 is counted at the top of step s.  Every wait is a FULL drain: counted waits (vmcnt(8): "everything older than the four
+// stores and the four slab rows") made 1 of 300 launches at N = 2560 / 3072 produce a different factor (POTRF_BENCH_STRESS) --
+// stores and loads of a wave do not retire in one common order on this chip, so a count behind a mix of both says nothing about
+// WHICH operations are still out.  Measured: 17-20 us per tile when the solve runs unthrottled (7.7 us of products).
 // LDS: A ring slabs 0-3, L slabs 4-5, X slabs 6-7 of the image area, T16 buffers behind it -- the whole 160 KB.
-// On return the image holds Csub - X X^T on its lower 16 x 16 blocks (diag_block_factor<false>'s input, behind the caller's
-// barrier) and the tile X has been stored (the caller drains and raises the flag).
-// ready(): called once, uniformly, before the tile Csub is first read (its owner's last update must have landed); false = give up.
-// SYRK = false: the solve alone (the three-workgroup chain: another workgroup forms the product from the published blocks,
-// stream_syrk_image); block s - 1 is then flagged at the TOP of step s, before the wait for the diagonal block's column block s --
-// block 6 must not wait for the diagonal block's end.
-template <bool SYRK, class Ready>
-__device__ __forceinline__ bool stream_trsm_syrk(double* __restrict__ A, long lda, const double* __restrict__ L, long ldl,
-                                                 const double* __restrict__ T, long ldt, int* flag, int* abort_flag, long long timeout,
-                                                 const double* __restrict__ Csub, long ldc, Ready&& ready, int* xprog, long long* stamp, double* lds) {
-    // `lane` is made opaque here: everything derived from it -- some 300 LDS / global offsets of the four waves' deals -- is otherwise
-    // hoisted out of the chain's loop over the diagonal blocks and kept (spilled) across it
+// The caller drains (raise(8) has) and raises the tile's own flag.
+__device__ __forceinline__ bool stream_trsm_publish(double* __restrict__ A, long lda, const double* __restrict__ L, long ldl,
+                                                    const double* __restrict__ T, long ldt, int* flag, int* abort_flag, long long timeout,
+                                                    int* xprog, double* lds) {
+    // `lane` is made opaque: the per-lane LDS / global offsets derived from it are otherwise hoisted out of the caller's loop over the
+    // diagonal blocks and kept (spilled) across it
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane));
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -814,26 +812,6 @@ __device__ __forceinline__ bool stream_trsm_syrk(double* __restrict__ A, long ld
             slab_row_to_lds_sc1(T + (16 * s + 2 * (lane & 7)) + (long)(16 * s + 8 * wave + (lane >> 3)) * ldt, Tbuf + (s & 1) * 256 + 128 * wave);
     };
     auto rsrcX = __builtin_amdgcn_make_buffer_rsrc(A, 0, 0x7fffffff, 0x00020000);
-    ChainAcc V;
-    d4_t acc[9], c0[9];
-#pragma unroll
-    for (int p = 0; p < 9; ++p) acc[p] = d4_t{0.0, 0.0, 0.0, 0.0};
-    V.zero();
-    issueA(0); issueA(1); issueA(2);
-    if (stamp) stamp[5] = wall_clock64();
-    int issuedL = 0;
-    int seen_raw = 0, seen_u = 0;                        // the diagonal block's publication count as last polled (lane 0) / uniform
-    bool ok = true;
-    // xprog += 1 per wave and block once that wave's four columns of the block have drained (4 (s + 1): block s is in global
-    // memory): the owners of the tile below run the K loop of its last update behind these (stream_update_half)
-    int raised = 0;
-    auto raise = [&](int upto) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (raised < upto) {
-            if (lane == 0) __hip_atomic_fetch_add(xprog, upto - raised, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            raised = upto;
-        }
-    };
     auto store_block = [&](int sb) {                     // block sb from its slab: column 16 sb + 4 q + wave of the tile, 64 lanes x 16 bytes
         const double* xs_ = Xbuf + (sb & 1) * SLAB;
 #pragma unroll
@@ -843,75 +821,36 @@ __device__ __forceinline__ bool stream_trsm_syrk(double* __restrict__ A, long ld
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rsrcX, (int)((2 * lane + (long)(16 * sb + c) * lda) * 8), 0, 16);
         }
     };
+    auto count_block = [&]() {                           // every operation of this wave has completed: one more block of it is out
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(xprog, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    ChainAcc V;
+    V.zero();
+    issueA(0); issueA(1); issueA(2);
+    int issuedL = 0;
+    int seen_raw = 0;                                    // the diagonal block's publication count as last polled (lane 0)
+    bool ok = true;
     auto step = [&](auto S) {
         constexpr int s = decltype(S)::value;
         if (!ok) return;
-        // early: column block s was already published a step ago and requested then -- BEFORE that step's four stores of X_{s-1}.
-        // Memory operations complete in order: everything but those stores is waited for, and they drain behind this step (a
-        // solve that has fallen behind the factorisation would otherwise pay a write-through round trip per block).
-        if constexpr (!SYRK) {
-            // ---- the solve alone: every wait of this wave is placed by hand ----
-            // Memory operations of a wave complete in issue order; a step issues, behind its barrier:  g1 the NEXT column block of the
-            // diagonal block (if the poll of the step before saw it published), the poll for the step after, g2 the four stores of
-            // X_{s-1} (formed a step ago), g3 the A slab three steps ahead.  The next barrier needs g1 and the poll only: it waits
-            // until just g2 + g3 are outstanding -- the write-through round trip of the stores (~1.5 us) and the slab's latency stay
-            // behind the step's products.  (With one vmcnt(0) per step -- the compiler's, in front of the poll's result while LDS-
-            // direct loads were in flight -- a tile took 20 us for 7.7 us of products.)  Block s - 2 is flagged at the top of step s,
-            // behind g3 of the step before only.
-#ifdef SLS_COUNTED_MIXED_WAITS
-            constexpr int N_FLAG = s <= 5 ? 4 : 0;                              // g3 of step s - 1
-            constexpr int N_BAR = (s >= 2 ? 4 : 0) + (s <= 5 ? 4 : 0);          // g2 + g3 of step s - 1 (the flag's atomic, younger still, is not counted: conservative)
-#else
-            // MEASURED (round 6, POTRF_BENCH_STRESS): with the counted waits 1 of 300 launches at N = 2560 / 3072 produced a different
-            // factor -- stores and loads of a wave do NOT retire in one common order (a vmcnt(N) behind a mix of both says nothing
-            // about WHICH N are still out).  Every wait that has stores behind it is therefore a full drain.
-            constexpr int N_FLAG = 0, N_BAR = 0;
-#endif
-            if (s >= 2) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_FLAG) : "memory");
-                if (lane == 0) __hip_atomic_fetch_add(xprog, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // block s - 2: one arrival per wave
-            }
-            const bool early = issuedL > s;
-            if (!early) {
-                if (!stream_wait(flag, 3 * (s + 1), abort_flag, timeout)) { ok = false; return; }
-                issueL(s);
-                issuedL = s + 1;
-            }
-            if (s == 7 && stamp) stamp[0] = wall_clock64();
-            if (early) asm volatile("s_waitcnt vmcnt(%1) lgkmcnt(0)\n\ts_barrier" : "+v"(seen_raw) : "n"(N_BAR) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" : "+v"(seen_raw)::"memory");
-            const int seen = __builtin_amdgcn_readfirstlane(seen_raw);          // the diagonal block's count as polled a step ago
-            if (s + 1 < 8) {
-                if (seen >= 3 * (s + 2)) {
-                    issueL(s + 1);
-                    issuedL = s + 2;
-                }
-                if (lane == 0) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(seen_raw) : "v"(flag) : "memory");
-            }
-            if (s > 0) store_block(s - 1);
-            if (s + 3 < 8) issueA(s + 3);
-        } else {
-        if (SYRK && s > 0) {}
-        const bool early = SYRK && issuedL > s;
+        if (s >= 2) count_block();                       // block s - 2: stored in the step before
         if (issuedL <= s) {
             if (!stream_wait(flag, 3 * (s + 1), abort_flag, timeout)) { ok = false; return; }
             issueL(s);
             issuedL = s + 1;
         }
-        if (s == 7 && stamp) stamp[0] = wall_clock64();    // probes: the diagonal block has ended (on the other workgroup) a moment ago
-        if (s + 1 < 8 && seen_u < 3 * (s + 2) && lane == 0) seen_raw = df_flag(flag);
-        if (early) ring_wait_barrier<4>();               // slab s of A and of L in LDS (every wave's part); slab s - 1 no longer read
-        else ring_wait_barrier<0>();
-        if (s == 7 && stamp) stamp[9] = wall_clock64();
-        if (s + 3 < 8) issueA(s + 3);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" : "+v"(seen_raw)::"memory");   // slab s of A and of L in LDS; X_{s-1} in its slab
+        const int seen = __builtin_amdgcn_readfirstlane(seen_raw);          // the diagonal block's count as polled a step ago
         if (s + 1 < 8) {
-            seen_u = __builtin_amdgcn_readfirstlane(seen_raw);
-            if (seen_u >= 3 * (s + 2)) {
+            if (seen >= 3 * (s + 2)) {
                 issueL(s + 1);
                 issuedL = s + 2;
             }
+            if (lane == 0) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(seen_raw) : "v"(flag) : "memory");
         }
-        }
+        if (s > 0) store_block(s - 1);
+        if (s + 3 < 8) issueA(s + 3);
         const double* la = lds + (s & 3) * SLAB;
         const double* lb = Lbuf + (s & 1) * SLAB;
         const double* tb = Tbuf + (s & 1) * 256;
@@ -919,7 +858,7 @@ __device__ __forceinline__ bool stream_trsm_syrk(double* __restrict__ A, long ld
         double tf[4];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) tf[kk] = tb[fl + 16 * (4 * kk + fk)];
-        // both row blocks' X_s first (the slab the other waves wait for), then the later blocks' sums
+        // both row blocks' X_s first (into the slab), then the later blocks' sums
         d4_t xs[2];
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
@@ -944,42 +883,16 @@ __device__ __forceinline__ bool stream_trsm_syrk(double* __restrict__ A, long ld
                 }
             }
         }
-        if (SYRK && s > 0) raise(s);                     // block s - 1: stored a step ago
-        if constexpr (SYRK) {
-            lds_barrier();                               // X_s complete in its slab (every wave's rows)
-            store_block(s);
-            if (wave == 0) syrk_slab<0>(acc, xb, lane);
-            else if (wave == 1) syrk_slab<1>(acc, xb, lane);
-            else if (wave == 2) syrk_slab<2>(acc, xb, lane);
-            else syrk_slab<3>(acc, xb, lane);
-        }
-        if (stamp && (s == 0 || s == 3 || s == 6)) stamp[6 + s / 3] = wall_clock64();
     };
     step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
     step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
     step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
     step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
     if (!ok) return false;
-    if constexpr (!SYRK) {
-        raised = 6;                                      // blocks 0 .. 5 were flagged inside the steps
-        raise(7);                                        // block 6: stored in step 7
-        lds_barrier();                                   // X_7 complete in its slab
-        store_block(7);
-    }
-    raise(8);
-    if (stamp) stamp[12] = wall_clock64();
-    if constexpr (SYRK) {
-        if (!ready()) return false;
-        if (wave == 0) syrk_load_c0<0>(c0, Csub, ldc, lane);
-        else if (wave == 1) syrk_load_c0<1>(c0, Csub, ldc, lane);
-        else if (wave == 2) syrk_load_c0<2>(c0, Csub, ldc, lane);
-        else syrk_load_c0<3>(c0, Csub, ldc, lane);
-        lds_barrier();                                       // every wave has read the last slab: the image may be written
-        if (wave == 0) syrk_to_image<0, true>(lds, acc, c0, lane);
-        else if (wave == 1) syrk_to_image<1, true>(lds, acc, c0, lane);
-        else if (wave == 2) syrk_to_image<2, true>(lds, acc, c0, lane);
-        else syrk_to_image<3, true>(lds, acc, c0, lane);
-    }
+    count_block();                                       // block 6: stored in step 7
+    lds_barrier();                                       // X_7 complete in its slab
+    store_block(7);
+    count_block();                                       // block 7: the tile is complete in global memory
     return true;
 }
 
@@ -1473,8 +1386,8 @@ __device__ __forceinline__ void potri_team(const PersistArgs& a, int b2, int G2,
     }
 }
 
-// FUSE: the streamed chain folds the next diagonal tile's update into its solve (stream_trsm_syrk; SLS_POTRF_FUSE_SYRK=0 launches the
-// other instantiation: two kernels rather than a run-time branch, whose two sets of hoisted addresses did not fit the registers)
+// FUSE: the instantiation that carries the three-workgroup chain and the streamed last updates (SLS_POTRF_FUSE_SYRK; two kernels
+// rather than a run-time branch: the two chain forms' hoisted per-lane addresses together did not fit the registers)
 template <bool FUSE>
 __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1512,7 +1425,7 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
         if (b < 3 && nchain == 3) {
             // ---- the chain, THREE workgroups in rotation (round 6) ----
             // While workgroup F factors diagonal block j (publishing its column blocks), S solves the panel tile (j+1, j) behind it
-            // block by block and stores every finished block at once (stream_trsm_syrk<false>), and Y accumulates A_{j+1,j+1} - X X^T
+            // block by block and stores every finished block at once (stream_trsm_publish), and Y accumulates A_{j+1,j+1} - X X^T
             // from those blocks as they land (stream_syrk_image): when block j ends, what remains before block j+1 can start is the
             // last block of X (eight products + its store), its arrival at Y and ONE slab of the product -- not the whole product
             // (10.7 us on one CU in the two-workgroup form).  Y then factors block j+1 from its own LDS image, F becomes the next S, S the
@@ -1541,9 +1454,7 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
                     if (stamp) stamp[10] = wall_clock64();
                     if (!pk_wait_count(chain_ready + k, 1 + a.split_sub, a)) return;   // tile (k+1, k) carries its owners' updates
                     if (stamp) stamp[11] = wall_clock64();
-                    if (!stream_trsm_syrk<false>(Akk + NB, ld, Akk, ld, Tkk, ld, factored + k, a.info + 1, a.timeout, (const double*)nullptr, 0L,
-                                                 []() { return true; }, xprog + k, (long long*)nullptr, lds))
-                        return;
+                    if (!stream_trsm_publish(Akk + NB, ld, Akk, ld, Tkk, ld, factored + k, a.info + 1, a.timeout, xprog + k, lds)) return;
                     df_publish_store(panel_done + (k + 1) + (long)k * nb);    // the last block's stores have drained (raise(8)); the barrier frees the LDS
                     if (stamp) stamp[13] = wall_clock64();
                 }
@@ -1992,9 +1903,8 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             if (FUSE && nchain == 3 && i == k + 2) {
                 // the tile right below the chain's: its blocks leave as they become final and are counted (xprog2): the last update of
                 // tile (k+2, k+1) runs behind them and behind the chain's own tile (stream_update_half)
-                if (!stream_trsm_syrk<false>(Cik, ld, a.A + (long)k * NB * (ld + 1), ld, a.Linv + (long)k * NB * (ld + 1), ld, factored + k,
-                                             a.info + 1, a.timeout, (const double*)nullptr, 0L, []() { return true; }, xprog2 + k,
-                                             (long long*)nullptr, lds))
+                if (!stream_trsm_publish(Cik, ld, a.A + (long)k * NB * (ld + 1), ld, a.Linv + (long)k * NB * (ld + 1), ld, factored + k, a.info + 1,
+                                         a.timeout, xprog2 + k, lds))
                     return;
             } else if (nchain >= 2) {
                 const bool stamp = a.trace && tid == 0 && i == k + 2 && !FUSE;      // probes: the panel tile right below the chain (FUSE: the slots carry the solve.s own stamps)

@@ -108,6 +108,25 @@ namespace sequential_line_search
                            : 0.0;
     }
 
+    Eigen::VectorXd PreferentialBayesianOptimizer::GetPreferenceValueMeans(const Eigen::MatrixXd& points) const
+    {
+        Eigen::VectorXd mu = Eigen::VectorXd::Zero(points.cols()), sigma;
+        if (m_regressor) m_regressor->PredictBatch(points, mu, sigma);
+        return mu;
+    }
+    Eigen::VectorXd PreferentialBayesianOptimizer::GetPreferenceValueStdevs(const Eigen::MatrixXd& points) const
+    {
+        Eigen::VectorXd mu, sigma = Eigen::VectorXd::Zero(points.cols());
+        if (m_regressor) m_regressor->PredictBatch(points, mu, sigma);
+        return sigma;
+    }
+    Eigen::VectorXd PreferentialBayesianOptimizer::GetAcquisitionFuncValues(const Eigen::MatrixXd& points) const
+    {
+        if (!m_regressor) return Eigen::VectorXd::Zero(points.cols());
+        return acquisition_func::CalcAcquisitionValues(*m_regressor, points, m_acquisition_func_type,
+                                                       m_gaussian_process_upper_confidence_bound_hyperparam);
+    }
+
     const Eigen::MatrixXd& PreferentialBayesianOptimizer::GetRawDataPoints() const { return m_data->GetX(); }
 
     void PreferentialBayesianOptimizer::DampData(const std::string& directory_path) const

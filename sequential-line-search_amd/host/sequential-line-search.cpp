@@ -127,6 +127,25 @@ namespace sequential_line_search
                            : 0.0;
     }
 
+    Eigen::VectorXd SequentialLineSearchOptimizer::GetPreferenceValueMeans(const Eigen::MatrixXd& points) const
+    {
+        Eigen::VectorXd mu = Eigen::VectorXd::Zero(points.cols()), sigma;
+        if (m_regressor) m_regressor->PredictBatch(points, mu, sigma);
+        return mu;
+    }
+    Eigen::VectorXd SequentialLineSearchOptimizer::GetPreferenceValueStdevs(const Eigen::MatrixXd& points) const
+    {
+        Eigen::VectorXd mu, sigma = Eigen::VectorXd::Zero(points.cols());
+        if (m_regressor) m_regressor->PredictBatch(points, mu, sigma);
+        return sigma;
+    }
+    Eigen::VectorXd SequentialLineSearchOptimizer::GetAcquisitionFuncValues(const Eigen::MatrixXd& points) const
+    {
+        if (!m_regressor) return Eigen::VectorXd::Zero(points.cols());
+        return acquisition_func::CalcAcquisitionValues(*m_regressor, points, m_acquisition_func_type,
+                                                       m_gaussian_process_upper_confidence_bound_hyperparam);
+    }
+
     const Eigen::MatrixXd& SequentialLineSearchOptimizer::GetRawDataPoints() const { return m_data->GetX(); }
 
     void SequentialLineSearchOptimizer::DampData(const std::string& directory_path) const

@@ -146,3 +146,28 @@ def test_tolerance_setters_of_both_kinds_of_search(pysls):
     finally:
         pysls.set_map_fit_tolerances(0.0, 0.0)
     assert pysls.get_map_fit_tolerances() == (0.0, 0.0)
+
+
+def test_batched_accessors_match_the_scalar_ones(pysls):
+    """SURVEY.md 8(f3): batched mean / deviation / acquisition value over the columns of a D x M matrix (one device pass each;
+    the reference's GUI demo calls the scalar forms pixel by pixel, demos/bayesian_optimization_2d_gui/mainwidget.cpp:41-72).
+    Same numbers as the scalar accessors, point by point, for both optimisers; zeros before any data."""
+    np.random.seed(3)
+    opt = pysls.SequentialLineSearchOptimizer(num_dims=5)
+    P = np.asfortranarray(np.random.uniform(0, 1, (5, 33)))
+    assert np.all(opt.get_preference_value_means(P) == 0.0) and np.all(opt.get_acquisition_func_values(P) == 0.0)
+    for _ in range(4):
+        opt.submit_feedback_data(simulated_slider_user(opt.get_slider_ends()))
+    pbo = pysls.PreferentialBayesianOptimizer(num_dims=5, num_options=3)
+    for _ in range(3):
+        o = pbo.get_current_options()
+        pbo.submit_feedback_data(int(np.argmax([simulated_objective(x) for x in o])))
+        pbo.determine_next_query(32, 10)
+    for obj in (opt, pbo):
+        mu, sg, av = obj.get_preference_value_means(P), obj.get_preference_value_stdevs(P), obj.get_acquisition_func_values(P)
+        assert mu.shape == sg.shape == av.shape == (33,)
+        for m in range(33):
+            x = P[:, m].copy()
+            assert mu[m] == pytest.approx(obj.get_preference_value_mean(x), rel=1e-9, abs=1e-12)
+            assert sg[m] == pytest.approx(obj.get_preference_value_stdev(x), rel=1e-7, abs=1e-10)
+            assert av[m] == pytest.approx(obj.get_acquisition_func_value(x), rel=1e-7, abs=1e-12)
