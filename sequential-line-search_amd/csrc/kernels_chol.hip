@@ -13,7 +13,9 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <tuple>
 #include <type_traits>
+#include <vector>
 
 #include "chol_diag.hpp"
 #include "gemm_f64.hpp"
@@ -191,6 +193,14 @@ struct PersistArgs {
     // own, dealt over the first lu_w workers, which carry nothing else (0: it stays with the tile's owner)
     int lu_w;
     int prio_band;      // workers: a ready task of a tile within this many blocks of the diagonal is taken before the others (0: list order)
+    // fused inverse, DYNAMIC pools (round 6): the items of both teams in ONE global order (the factorisation's tiles column by column,
+    // then the inverse's items in potri_team's order), item n in pool n mod pool_nx = the workgroups of one XCD; any workgroup of the
+    // pool claims the first item of the pool's list whose next task has its inputs (compare-and-swap on the item's state word) and
+    // runs that ONE task.  pool_items: {type, i, k or j, half or initial progress} per item (host-built, cached per device);
+    // pool_state: (progress << 2) | {0 free, 1 claimed, 2 done}, zeroed with the flag tables.  0 items: static ownership.
+    const int4* pool_items;
+    int pool_n, pool_nx, pool_keep;
+    int* pool_state;
 };
 #define PK_STAMP(slot) do { if (a.trace && threadIdx.x == 0) a.trace[16 * j + (slot)] = wall_clock64(); } while (0)
 
@@ -1307,6 +1317,84 @@ __device__ __forceinline__ PotriStep potri_item_task(const PersistArgs& a, int t
     return res;
 }
 
+// Dynamic pools: "has the NEXT task of this item its inputs?" for a scanner that looks at one item per THREAD: what fac_ready_lane /
+// potri_item_ready ask lane by lane, with all of an item's flag loads (at most four for chunks of up to two blocks) in flight at once
+// -- no arrays (dynamic indexing would put them into scratch memory), every case written out.  *lanes = true: the task's chunk is
+// longer than two blocks, the caller asks lane by lane.  it = {type, i, k or j, half}; type 0: a tile of the factorisation.
+template <bool FUSE>
+__device__ __forceinline__ bool pool_item_ready(const PersistArgs& a, const int4 it, int d, bool* lanes) {
+    const int nb = a.nb;
+    const int* factored = a.sync + DF_FACT;
+    const int* panel_done = a.sync + DF_FACT + 2 * nb;
+    const int* xdone = a.sync + DF_FACT + 2 * nb + nb * nb;
+    const int* upd_done = a.sync + DF_FACT + 3 * nb + 2 * nb * nb;
+    const int* xprog = upd_done + nb * nb;
+    const int* xprog2 = xprog + nb;
+    const int i = it.y, j = it.z;
+    *lanes = false;
+    // up to four flags, each with the value it must reach; unused ones point at a word that always passes
+    const int* p0 = nullptr; const int* p1 = nullptr; const int* p2 = nullptr; const int* p3 = nullptr;
+    int t0 = 1, t1 = 1, t2 = 1, t3 = 1;
+    if (it.x == 0) {
+        const int k = j, typ = it.w;
+        const int target = i == k ? k - 1 : k;
+        if (d < target) {
+            const int j0 = d, j1 = df_chunk_end(k, j0, target, a.nbo, a.near);
+            if (FUSE && a.nchain == 3 && i == k + 1 && typ != 0 && j1 == target && j1 - j0 == 1) {
+                p0 = xprog + j0; t0 = 4;
+                p1 = xprog2 + j0; t1 = 4;
+            } else if (j1 - j0 <= 2) {
+                p0 = panel_done + i + (long)j0 * nb;
+                if (i != k) p1 = panel_done + k + (long)j0 * nb;
+                if (j1 - j0 == 2) {
+                    p2 = panel_done + i + (long)(j0 + 1) * nb;
+                    if (i != k) p3 = panel_done + k + (long)(j0 + 1) * nb;
+                }
+            } else {
+                *lanes = true;
+                return false;
+            }
+        } else if (i > k + 1 && typ != 2) {
+            p0 = factored + k; t0 = a.nchain >= 2 ? 3 : 1;
+            if (typ == 1) p1 = upd_done + i + (long)k * nb;
+        }
+    } else if (it.x == 10) {
+        p0 = factored + i; t0 = a.nchain >= 2 ? 24 : 1;
+    } else if (it.x == 11) {
+        const int nterms = i - j - a.inv_plast;
+        if (d < nterms) {
+            const int k0 = j + d, k1 = min(k0 + a.inv_cx, j + nterms);
+            if (k1 - k0 > 2) { *lanes = true; return false; }
+            p0 = xdone + k0 + (long)j * nb;
+            p1 = panel_done + i + (long)k0 * nb;
+            if (k1 - k0 == 2) {
+                p2 = xdone + (k0 + 1) + (long)j * nb;
+                p3 = panel_done + i + (long)(k0 + 1) * nb;
+            }
+        } else if (d == nterms) {
+            p0 = xdone + i + (long)i * nb;
+        } else {
+            p0 = xdone + (i - 1) + (long)j * nb;
+            p1 = xdone + (i - 1) + (long)i * nb;
+        }
+    } else if (it.x == 14) {
+        p0 = xdone + i + (long)i * nb;
+        p1 = panel_done + i + (long)j * nb;
+    } else {
+        const int k0 = i + d, k1 = min(k0 + a.inv_ck, nb);
+        if (k1 - k0 > 2) { *lanes = true; return false; }
+        p0 = xdone + k0 + (long)i * nb;
+        p1 = xdone + k0 + (long)j * nb;
+        if (k1 - k0 == 2) {
+            p2 = xdone + (k0 + 1) + (long)i * nb;
+            p3 = xdone + (k0 + 1) + (long)j * nb;
+        }
+    }
+    const int v0 = p0 ? df_flag(p0) : 0x7fffffff, v1 = p1 ? df_flag(p1) : 0x7fffffff, v2 = p2 ? df_flag(p2) : 0x7fffffff,
+              v3 = p3 ? df_flag(p3) : 0x7fffffff;
+    return v0 >= t0 && v1 >= t1 && v2 >= t2 && v3 >= t3;
+}
+
 __device__ __forceinline__ void potri_team(const PersistArgs& a, int b2, int G2, double* lds, char* smem) {
     const int nb = a.nb;
     auto SW = [&](int arr, int k) -> int& { return reinterpret_cast<int*>(lds + k * DL + 128)[arr]; };
@@ -1393,7 +1481,8 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lds = reinterpret_cast<double*>(smem);
     const bool inv_wg = a.g1 > 0 && (int)blockIdx.x >= a.g1;      // a workgroup of the inverse's team (nprob == 1)
-    if (inv_wg && a.hybrid_near < 0) {
+    const bool pool = a.pool_n > 0;
+    if (inv_wg && !pool && a.hybrid_near < 0) {
         potri_team(a, (int)blockIdx.x - a.g1, (int)gridDim.x - a.g1, lds, smem);
         return;
     }
@@ -1571,7 +1660,24 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
     if (tid == 0) {
         const int W = G - nchain;
         int ok = 1, widx = -1, nt = 0;
-        if (!inv_wg) {
+        if (pool) {
+            // every workgroup outside the chain is a pool worker: which XCD it sits on decides its pool; all of them meet once so that
+            // every pool is known to have workers (a pool without any would never finish: give up, the caller repeats on the
+            // multi-launch schedule)
+            unsigned x;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+            const int mypool = (int)(x & 7) % a.pool_nx;
+            __hip_atomic_fetch_add(a.sync + 8 + mypool, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(a.sync + 1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            ok = pk_spin(a.sync + 1, (int)gridDim.x - nchain, a.info + 1, a.timeout) ? 1 : 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            for (int q = 0; ok && q < a.pool_nx; ++q)
+                if (__hip_atomic_load(a.sync + 8 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                    __hip_atomic_store(a.info + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = 0;
+                }
+            SW(7, 0) = mypool;
+        } else if (!inv_wg) {
             // worker index, XCD by XCD
             unsigned x;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
@@ -1585,10 +1691,12 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             widx = rank;
             for (int q = 0; q < xcc; ++q) widx += __hip_atomic_load(a.sync + 8 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        const bool hybrid = a.g1 > 0 && a.hybrid_near >= 0;
+        const bool hybrid = !pool && a.g1 > 0 && a.hybrid_near >= 0;
         const bool banded = !hybrid && a.band_w > 0 && a.band_w < W;
         const int band = a.split_band;
-        if (ok && lu_mode && a.lu_w < W) {
+        if (pool) {
+            // nothing is dealt: the lists are the pool's
+        } else if (ok && lu_mode && a.lu_w < W) {
             // the usual items in the usual order over the workers behind the first lu_w; the last updates of the sub-diagonal halves
             // (type 3 / 4: columns 0-63 / 64-127 of tile (k+1, k), k >= 1) over those first lu_w
             const int R = a.lu_w;
@@ -1674,7 +1782,7 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
         }
         SW(5, 0) = ok ? nt : -1;
         int nt2 = 0;
-        if (inv_wg || (hybrid && ok)) {
+        if (!pool && (inv_wg || (hybrid && ok))) {
             // the inverse's items, dealt as in potri_team (arrays 8 .. 14).  Hybrid pool: the K^-1 items of the rows from hybrid_rmin on
             // -- whose work arrives late, when the factorisation's workers have run out of tiles -- are dealt over BOTH teams
             // (owner index: inverse workgroup b2, or G2 + the factorisation worker's index)
@@ -1706,53 +1814,174 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
         SW(13, 0) = nt2;
     }
     __syncthreads();
-    const int nt = SW(5, 0), nt2 = SW(13, 0);
-    if (nt < 0 || (nt == 0 && nt2 == 0)) return;
+    int nt = SW(5, 0), nt2 = SW(13, 0);
+    if (nt < 0 || (!pool && nt == 0 && nt2 == 0)) return;
     int first = 0, first2 = 0;
+    // dynamic pool: this workgroup's pool, the length of its list, the first entry not yet seen finished, the item in hand
+    const int mypool = pool ? SW(7, 0) : 0;
+    const int pool_len = pool ? (a.pool_n - mypool + a.pool_nx - 1) / a.pool_nx : 0;
+    int pool_first = 0, claimed = -1;
     long long t_progress = wall_clock64();
     const int slot = tid >> 4, l = tid & 15;
     // optional statistics (probes): ticks of the 100 MHz clock in tasks / in scheduling rounds that found work / idle, task counts
     long long st_task = 0, st_idle = 0, st_t0 = t_progress, st_n_upd = 0, st_n_panel = 0, st_rounds = 0, st_gemm = 0, st_rmw = 0;
     long long st2_task = 0, st2_n = 0, st2_last = 0;           // probes: the inverse's tasks of this workgroup
+    // one lane's share of "has the next task of the factorisation's item (i, k) at progress d its inputs?" (16 lanes cover an item)
+    auto fac_ready_lane = [&](int i, int k, int d, int typ, int l) -> bool {
+        bool ok = true;
+        // steps the owner applies (the chain applies step k-1 to (k, k); lu_mode: the last one of a sub-diagonal half is an item of its own)
+        const int target = i == k ? k - 1 : (lu_mode && i == k + 1 && k >= 1 && (typ == 1 || typ == 2)) ? k - 1 : k;
+        if (typ >= 3) {
+            if (l == 0) ok = df_flag(pre_done(k, typ - 2)) != 0;
+            else if (l == 1) ok = df_flag(xprog + k - 1) >= 4;
+            else if (l == 2) ok = df_flag(xprog2 + k - 1) >= 4;
+        } else if (d < target) {
+            const int j0 = d;
+            const int j1 = df_chunk_end(k, j0, target, nbo, a.near);
+            const int j = j0 + (l & 7);
+            // the last update of a sub-diagonal half tile runs behind the chain's solve of its second operand (FUSE): the
+            // first block of that tile instead of the whole
+            const bool streamed = FUSE && nchain == 3 && !lu_mode && i == k + 1 && typ != 0 && j1 == target && j1 - j0 == 1;
+            if (streamed) {
+                if (l == 8) ok = df_flag(xprog + j0) >= 4;
+                else if (l == 0) ok = df_flag(xprog2 + j0) >= 4;
+            } else if (j < j1 && !(l >= 8 && i == k)) ok = df_flag(panel_done + (l < 8 ? i : k) + (long)j * nb) != 0;
+        } else if (i > k + 1 && typ != 2) {
+            // the diagonal block (round-3 chain), or its first column block (3 = one arrival per publishing wave) in the streamed
+            // form, where the tile is solved block by block behind it; a tile with two owners: the other half
+            const int need = nchain >= 2 ? 3 : 1;
+            if (l == 0) ok = df_flag(factored + k) >= need;
+            else if (l == 1 && typ == 1) ok = df_flag(upd_done + i + (long)k * nb) != 0;
+        }
+        return ok;
+    };
     for (;;) {
+        int sel = -1, sel2 = -1;
+        const long long st_round0 = a.trace ? wall_clock64() : 0;
+        ++st_rounds;
+        if (pool) {
+            // ---- dynamic pool: hand back the item of the last task, then claim the next one ----
+            if (claimed >= 0) {
+                // The item of the last task.  If it is not finished and its NEXT task has its inputs already, the workgroup keeps it
+                // and goes on (no hand-back, no scan, no claim: 4-5 us per task; the accumulation chains of the inverse run many
+                // chunks in a row late in the launch).  Otherwise: every store of the task has reached the XCD's L2 (the next
+                // workgroup to take the item sits on this XCD and reads through an invalidated L1), then ONE word says how far
+                // the item is.
+                const bool fac_item = nt == 1;
+                const int fin = fac_item ? SW(3, 0) : SW(11, 0), dd = fac_item ? SW(2, 0) : SW(10, 0);
+                bool go_on = false;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the next task, here or elsewhere, may read what any wave of this one stored)
+                if (!fin && a.pool_keep) {
+                    if (tid == 0) {
+                        const int4 it = fac_item ? int4{0, SW(0, 0), SW(1, 0), SW(6, 0)} : int4{SW(14, 0) + 10, SW(8, 0), SW(9, 0), 0};
+                        bool lanes = false;
+                        const bool r = pool_item_ready<FUSE>(a, it, dd, &lanes);
+                        SW(18, 1) = (r && !lanes) ? 1 : 0;
+                    }
+                    __syncthreads();
+                    go_on = SW(18, 1) != 0;
+                    __syncthreads();
+                }
+                if (go_on) {
+                    if (fac_item) sel = 0; else sel2 = 0;
+                } else {
+                    __syncthreads();
+                    if (tid == 0) __hip_atomic_store(a.pool_state + claimed, fin ? 2 : (dd << 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    claimed = -1;
+                }
+            }
+            if (claimed < 0) {
+            // one thread per entry of the pool's list, 256 entries from the first unfinished one: state word and item record, then ALL the
+            // flags the item's next task needs, in flight together
+            const int m = pool_first + tid;
+            int code = 2, w = 0, n = -1;                     // 2 finished (or beyond the end), 1 free and ready, 0 neither
+            int4 it = {0, 0, 0, 0};
+            if (m < pool_len) {
+                n = mypool + m * a.pool_nx;
+                w = __hip_atomic_load(a.pool_state + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                it = a.pool_items[n];
+                code = (w & 3) == 2 ? 2 : 0;
+                if ((w & 3) == 0) {
+                    const int d = w ? (w >> 2) : (it.x == 11 ? it.w : 0);      // an untouched X item starts at its initial progress
+                    bool lanes = false;
+                    bool ok = pool_item_ready<FUSE>(a, it, d, &lanes);
+                    if (!lanes) {
+                    } else if (it.x == 0) {
+                        ok = true;
+                        for (int q = 0; q < 16 && ok; ++q) ok = fac_ready_lane(it.y, it.z, d, it.w, q);
+                    } else {
+                        ok = true;
+                        for (int q = 0; q < 16 && ok; ++q) ok = potri_item_ready(a, it.x - 10, it.y, it.z, d, q);
+                    }
+                    code = ok ? 1 : 0;
+                }
+            }
+            // first entry that is not finished (the list's new start): per wave by ballot, over the waves in LDS
+            const unsigned long long b_nf = __ballot(code != 2);
+            unsigned long long b_rd = __ballot(code == 1);
+            const int wbase = tid & ~63;
+            if ((tid & 63) == 0) SW(16, tid >> 6) = b_nf ? wbase + __builtin_ctzll(b_nf) : 1 << 20;
+            __syncthreads();
+            const int f_nf = min(min(SW(16, 0), SW(16, 1)), min(SW(16, 2), SW(16, 3)));
+            if (f_nf >= (1 << 20)) {                         // the whole window is finished
+                __syncthreads();
+                pool_first += 256;
+                if (pool_first >= pool_len) break;           // ... and it was the last one: this pool is done
+                continue;
+            }
+            // claim the first ready entry; if another workgroup of the pool was faster, the next ready one of the same scan
+            bool got = false, any_ready = false;
+            for (;;) {
+                if ((tid & 63) == 0) SW(17, tid >> 6) = b_rd ? wbase + __builtin_ctzll(b_rd) : 1 << 20;
+                __syncthreads();
+                const int f_rd = min(min(SW(17, 0), SW(17, 1)), min(SW(17, 2), SW(17, 3)));
+                if (f_rd >= (1 << 20)) { __syncthreads(); break; }
+                any_ready = true;
+                if (tid == f_rd) {                           // the thread that looked at the entry claims it, with the word it saw
+                    int expect = w;
+                    const bool won = __hip_atomic_compare_exchange_strong(a.pool_state + n, &expect, w | 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                          __HIP_MEMORY_SCOPE_AGENT);
+                    SW(18, 0) = won ? n : -1;
+                    if (won) {
+                        const int d = w ? (w >> 2) : (it.x == 11 ? it.w : 0);
+                        if (it.x == 0) { SW(0, 0) = it.y; SW(1, 0) = it.z; SW(2, 0) = d; SW(3, 0) = 0; SW(6, 0) = it.w; SW(19, 0) = 1; }
+                        else { SW(8, 0) = it.y; SW(9, 0) = it.z; SW(10, 0) = d; SW(11, 0) = 0; SW(14, 0) = it.x - 10; SW(19, 0) = 0; }
+                    }
+                }
+                if ((f_rd & ~63) == wbase) b_rd &= ~(1ull << (f_rd & 63));   // not again in this scan
+                __syncthreads();
+                claimed = SW(18, 0);
+                __syncthreads();
+                if (claimed >= 0) { got = true; break; }
+            }
+            pool_first += f_nf;
+            if (got) {
+                if (SW(19, 0)) { nt = 1; nt2 = 0; first = 0; sel = 0; }
+                else { nt = 0; nt2 = 1; first2 = 0; sel2 = 0; }
+            } else {
+                if (__hip_atomic_load(a.info + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+                if (wall_clock64() - t_progress > a.timeout) {
+                    if (tid == 0) __hip_atomic_store(a.info + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return;
+                }
+                if (!any_ready) __builtin_amdgcn_s_sleep(32);   // nothing was ready (after lost races: look again at once)
+                if (a.trace) st_idle += wall_clock64() - st_round0;
+                continue;
+            }
+            }   // claimed < 0
+        } else {
         while (first < nt && SW(3, first)) ++first;            // uniform: every thread reads the same LDS words
         while (first2 < nt2 && SW(11, first2)) ++first2;
         if (first >= nt && first2 >= nt2) break;
-        const long long st_round0 = a.trace ? wall_clock64() : 0;
-        ++st_rounds;
-        int sel = -1, sel2 = -1;
         // ---- which tasks have their inputs? 16 lanes per tile, one flag per lane ----
         if (first < nt) {
             const int t = first + slot;
             bool valid = t < nt && !SW(3, t);
             bool ok = true;
             if (valid) {
-                const int i = SW(0, t), k = SW(1, t), d = SW(2, t), typ = SW(6, t);
-                // steps the owner applies (the chain applies step k-1 to (k, k); lu_mode: the last one of a sub-diagonal half is an item of its own)
-                const int target = i == k ? k - 1 : (lu_mode && i == k + 1 && k >= 1 && (typ == 1 || typ == 2)) ? k - 1 : k;
-                if (typ >= 3) {
-                    if (l == 0) ok = df_flag(pre_done(k, typ - 2)) != 0;
-                    else if (l == 1) ok = df_flag(xprog + k - 1) >= 4;
-                    else if (l == 2) ok = df_flag(xprog2 + k - 1) >= 4;
-                    if (a.trace && typ == 3 && l <= 2 && ok && a.trace[16 * (k - 1) + 5 + l] == 0) a.trace[16 * (k - 1) + 5 + l] = wall_clock64();   // probes: when each input was first seen
-                } else if (d < target) {
-                    const int j0 = d;
-                    const int j1 = df_chunk_end(k, j0, target, nbo, a.near);
-                    const int j = j0 + (l & 7);
-                    // the last update of a sub-diagonal half tile runs behind the chain's solve of its second operand (FUSE): the
-                    // first block of that tile instead of the whole
-                    const bool streamed = FUSE && nchain == 3 && !lu_mode && i == k + 1 && SW(6, t) != 0 && j1 == target && j1 - j0 == 1;
-                    if (streamed) {
-                        if (l == 8) ok = df_flag(xprog + j0) >= 4;
-                        else if (l == 0) ok = df_flag(xprog2 + j0) >= 4;
-                    } else if (j < j1 && !(l >= 8 && i == k)) ok = df_flag(panel_done + (l < 8 ? i : k) + (long)j * nb) != 0;
-                } else if (i > k + 1 && SW(6, t) != 2) {
-                    // the diagonal block (round-3 chain), or its first column block (3 = one arrival per publishing wave) in the streamed
-                    // form, where the tile is solved block by block behind it; a tile with two owners: the other half
-                    const int need = nchain >= 2 ? 3 : 1;
-                    if (l == 0) ok = df_flag(factored + k) >= need;
-                    else if (l == 1 && SW(6, t) == 1) ok = df_flag(upd_done + i + (long)k * nb) != 0;
-                }
+                ok = fac_ready_lane(SW(0, t), SW(1, t), SW(2, t), SW(6, t), l);
+                if (a.trace && SW(6, t) == 3 && l <= 2 && ok && a.trace[16 * (SW(1, t) - 1) + 5 + l] == 0)
+                    a.trace[16 * (SW(1, t) - 1) + 5 + l] = wall_clock64();   // probes: when each input of a last-update item was first seen
             }
             const unsigned long long m = __ballot(ok);
             const unsigned grp = (unsigned)(m >> (16 * ((tid >> 4) & 3))) & 0xffffu;
@@ -1795,6 +2024,7 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             if (a.trace) st_idle += wall_clock64() - st_round0;
             continue;
         }
+        }   // static lists
         if (tid < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // correct by the memory model, not only by first-touch reasoning
         __syncthreads();
         const long long st_task0 = a.trace ? wall_clock64() : 0;
@@ -2030,7 +2260,7 @@ int potrf_dataflow_nbo(int Np) {
 // ints of device scratch the dataflow form needs per problem
 size_t potrf_dataflow_sync_ints(int Np) {
     const size_t nb = Np / NB;
-    return DF_FACT + 5 * nb + 3 * nb * nb;           // factored, chain_ready, panel_done[nb][nb], xdone[nb][nb] (fused inverse), diag_ready, upd_done[nb][nb], xprog
+    return DF_FACT + 7 * nb + 5 * nb * nb;           // factored, chain_ready, panel_done[nb][nb], xdone[nb][nb] (fused inverse), diag_ready, upd_done[nb][nb], xprog, xprog2, pool_state[<= 2 nb^2 + 2 nb]
 }
 // How many independent Np x Np factorisations share one launch well: a problem keeps the chip busy with about nb^2 / 14.5 workers
 // (its ~nb^3 / 6 tile tasks of ~20 us against a chain of nb steps of ~48 us); the rest of the CUs can factor other problems.
@@ -2043,6 +2273,48 @@ int potrf_dataflow_max_problems(int Np) {
     const int per_problem = 1 + std::max(1, (int)(nb * (double)nb / 24.0));
     return std::max(1, std::min(8, ps.n_cu / per_problem));
 }
+// The dynamic pools' item table for an nb-block problem: the factorisation's tiles in the workers' order (column by column, halves
+// behind the whole tiles of their column), then the inverse's items in potri_team's order.  Built on the host once per (device, nb,
+// band, plast) and kept on the device.
+static const int4* pool_item_table(int nb, int band, int plast, int* n_items) {
+    static std::mutex mtx;
+    static std::map<std::tuple<int, int, int, int>, std::pair<int4*, int>> cache;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mtx);
+    const auto key = std::make_tuple(dev, nb, band, plast);
+    auto it = cache.find(key);
+    if (it != cache.end()) {
+        *n_items = it->second.second;
+        return it->second.first;
+    }
+    std::vector<int4> v;
+    for (int k = 0; k < nb; ++k) {
+        const int c = nb - k + std::min(band, nb - 1 - k);
+        for (int e = k == 0 ? 1 : 0; e < c; ++e) {
+            const bool second = e >= nb - k;
+            const int i = second ? k + 1 + (e - (nb - k)) : k + e;
+            v.push_back(int4{0, i, k, second ? 2 : (e >= 1 && e <= band ? 1 : 0)});
+        }
+    }
+    for (int r = 0; r < nb; ++r) {
+        v.push_back(int4{10, r, r, 0});
+        if (r > 0 && plast) v.push_back(int4{14, r, r - 1, 0});
+        for (int j = 0; j < r; ++j) v.push_back(int4{11, r, j, (j == r - 1 && plast) ? 1 : 0});
+    }
+    for (int r = 0; r < nb; ++r)
+        for (int j = 0; j <= r; ++j) v.push_back(int4{12, r, j, 0});
+    int4* d = nullptr;
+    if (hipMalloc(&d, v.size() * sizeof(int4)) != hipSuccess) {
+        *n_items = 0;
+        return nullptr;
+    }
+    (void)hipMemcpy(d, v.data(), v.size() * sizeof(int4), hipMemcpyHostToDevice);   // once per key: synchronous
+    cache[key] = {d, (int)v.size()};
+    *n_items = (int)v.size();
+    return d;
+}
+
 // nprob problems (A + q strideA, Linv + q strideA, sync + q stride_sync ints, info + 2 q) in one launch.
 // false: not applicable (too few blocks / too many tiles per worker / the kernel cannot be resident once per CU) -- the caller
 // uses another schedule.
@@ -2138,9 +2410,10 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
     // next solve may start -- get owners that carry nothing else (a worker in the middle of a 10 us update of another tile would hold
     // the chain up every other step)
     a.prio_band = std::max(0, (int)tune(TUNE_POTRF_PRIO, 0));
+    a.pool_items = nullptr; a.pool_n = 0; a.pool_nx = 1; a.pool_state = nullptr; a.pool_keep = (int)tune(TUNE_POTRI_POOL_KEEP, 1);
     a.band_near = (int)tune(TUNE_POTRF_BAND, 2);
     a.band_w = nprob == 1 ? std::max(0, std::min(W - 1, (int)tune(TUNE_POTRF_BAND_W, 0))) : 0;
-    a.lu_w = (nchain == 3 && split_sub) ? std::max(0, std::min(W - 1, (int)tune(TUNE_POTRF_LU_W, 6))) : 0;
+    a.lu_w = (nchain == 3 && split_sub) ? std::max(0, std::min(W - 1, (int)tune(TUNE_POTRF_LU_W, 0))) : 0;
     if (a.lu_w > 0 && ((2 * nb + a.lu_w - 1) / a.lu_w > DF_MAXT || (tiles + (W - a.lu_w) - 1) / (W - a.lu_w) > DF_MAXT)) a.lu_w = 0;
     if (a.band_w > 0) {   // both deals must fit the per-worker tables
         const int near_tiles = (a.band_near + 1) * nb + n_second, far_tiles = tiles - std::min(tiles, near_tiles);
@@ -2151,6 +2424,25 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
     a.inv_plast = (int)tune(TUNE_POTRI_PLAST, nb >= 12 ? 1 : 0) != 0 ? 1 : 0;
     a.inv_cx = std::max(1, std::min(8, (int)tune(TUNE_POTRI_CX, nb > 16 ? 2 : 1)));
     a.inv_ck = std::max(1, std::min(8, (int)tune(TUNE_POTRI_CK, nb > 16 ? 2 : 1)));
+    if (inv && tune_on(TUNE_POTRI_POOL, nb >= 22) && a.hybrid_near < 0) {
+        // dynamic pools, one per XCD (an item's tiles are then only ever touched through ONE L2: no coherence traffic beyond what the
+        // static form has).  Modelled before it was built (tools/potri_sched_sim.py, the measured task durations): static ownership
+        // 2017 us at N = 4096 (measured 2150), one pool per XCD 1330-1540 depending on the claim's cost.  Measured (ms, factor + inverse,
+        // static -> pools; profiles/r06_potri_pool.log): N = 2048: 0.67 -> 0.77, 2560: 1.06 -> 1.05, 3072: 1.29 -> 1.21, 3584: 1.65 -> 1.39,
+        // 4096: 2.16 -> 1.67-1.75.  A scan + claim costs 4-5 us per task, which the short chains of the small sizes cannot hide:
+        // on from N = 2816.
+        int n_items = 0;
+        const int4* tab = pool_item_table(nb, split_band, a.inv_plast, &n_items);
+        const ChipGeometry chip = chip_geometry();
+        if (tab && n_items > 0 && n_items <= 2 * nb * nb + 2 * nb) {
+            a.pool_items = tab;
+            a.pool_n = n_items;
+            a.pool_nx = std::max(1, std::min(8, chip.n_xcd));
+            a.pool_state = sync + DF_FACT + 5 * nb + 3 * nb * nb;   // behind xprog2: 2 nb^2 + 2 nb words (potrf_dataflow_sync_ints)
+            a.lu_w = 0;
+            a.band_w = 0;
+        }
+    }
     {
         PersistSerialScope serial(ps, s);
         if (fuse) hipLaunchKernelGGL(potrf_dataflow_kernel<true>, dim3(Gp * nprob + G2), dim3(256), DIAG_LDS_BYTES, s, a);
