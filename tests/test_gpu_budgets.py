@@ -58,7 +58,7 @@ def test_factor_and_inverse_device_time_budget(oracle):
     N = 4096 (kernels_chol.hip: streamed chain + fused inverse).  Measured: 0.74-0.78 ms at N = 2048 (first session of round 4:
     potrf 0.79 + trtri 0.27 + lauum 0.14 = 1.2 ms), 2.16-2.2 ms at N = 4096 (2.62)."""
     m = sls()
-    for N, budget in ((2048, 0.9), (4096, 2.7)):       # 1.25x the measured 0.68-0.70 / 2.15-2.2 ms (round 5)
+    for N, budget in ((2048, 0.9), (4096, 2.4)):       # 1.25x the measured 0.70-0.72 / 1.89 ms in this test (round 6: dynamic pools at 4096; round 5: 2.15-2.2)
         X, y, theta, b = synth_problem(oracle, 16, N)
         c = m.Context(0)
         m.GP(c, X, y, theta, b, 0).close()            # code objects, buffers
@@ -115,7 +115,7 @@ def test_c5_evaluation_and_batch_budget(ctx, oracle):
         ms_seq = best_of(lambda: h.gp_objective_batch(y, xs), 1, ctx.synchronize)
     h.close()
     record("budget", config="C5", ms_per_evaluation=ms_eval, batch8_ms=ms_batch, sequential8_ms=ms_seq, speedup=ms_seq / ms_batch)
-    assert ms_eval <= 3.2, ms_eval     # 1.25x the measured 2.5-2.6 ms
+    assert ms_eval <= 2.8, ms_eval     # 1.25x the measured 2.1-2.25 ms (round 6; round 5: 2.5-2.6)
     assert ms_seq / ms_batch >= 1.8, (ms_seq, ms_batch)
 
 
