@@ -1870,14 +1870,14 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
                 const bool fac_item = nt == 1;
                 const int fin = fac_item ? SW(3, 0) : SW(11, 0), dd = fac_item ? SW(2, 0) : SW(10, 0);
                 bool go_on = false;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the next task, here or elsewhere, may read what any wave of this one stored)
                 if (!fin && a.pool_keep) {
-                    if (tid == 0) {
+                    if (tid == 0) {                          // (its flag loads travel while the task's last stores drain)
                         const int4 it = fac_item ? int4{0, SW(0, 0), SW(1, 0), SW(6, 0)} : int4{SW(14, 0) + 10, SW(8, 0), SW(9, 0), 0};
                         bool lanes = false;
                         const bool r = pool_item_ready<FUSE>(a, it, dd, &lanes);
                         SW(18, 1) = (r && !lanes) ? 1 : 0;
                     }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next task, here or elsewhere, may read what any wave of this one stored
                     __syncthreads();
                     go_on = SW(18, 1) != 0;
                     __syncthreads();
@@ -1885,6 +1885,7 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
                 if (go_on) {
                     if (fac_item) sel = 0; else sel2 = 0;
                 } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
                     if (tid == 0) __hip_atomic_store(a.pool_state + claimed, fin ? 2 : (dd << 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     claimed = -1;
