@@ -181,7 +181,9 @@ def simulate(nb, W1, G2, dynamic, cx=2, ck=2, verbose=True, t_over=0.0):
             done_items += 1
         last = max(last, end)
         heapq.heappush(servers, [end, p])
+    chain_advance()
     chain_end = t_flag[("fact", nb - 1)]
+    last = max(last, chain_end)
     if verbose:
         nserv = sum(n_wg)
         print(f"nb={nb} {['static ', 'one pool', 'pool per team', 'static fact + pooled inv', 'pool per XCD'][dynamic]} W1={W1} G2={G2}: chain ends {chain_end:7.0f} us ({chain_end / nb:5.1f} per step), "
