@@ -200,6 +200,10 @@ struct PersistArgs {
     // pool_state: (progress << 2) | {0 free, 1 claimed, 2 done}, zeroed with the flag tables.  0 items: static ownership.
     const int4* pool_items;
     int pool_n, pool_nx, pool_keep;
+    // the tiles within pool_near blocks of the diagonal (the chain's feeders: their tasks are the ones whose start latency the chain
+    // feels) stay OUT of the pools: the first pool_near_w workgroups behind the chain own them statically and take nothing else
+    // (-1 / 0: everything is pooled)
+    int pool_near, pool_near_w;
     int* pool_state;
 };
 #define PK_STAMP(slot) do { if (a.trace && threadIdx.x == 0) a.trace[16 * j + (slot)] = wall_clock64(); } while (0)
@@ -1482,6 +1486,9 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
     double* lds = reinterpret_cast<double*>(smem);
     const bool inv_wg = a.g1 > 0 && (int)blockIdx.x >= a.g1;      // a workgroup of the inverse's team (nprob == 1)
     const bool pool = a.pool_n > 0;
+    const int b_lin = (int)blockIdx.x - a.nchain;                  // index among the workgroups outside the chain
+    const bool near_wg = pool && a.pool_near >= 0 && b_lin >= 0 && b_lin < a.pool_near_w;   // owns tiles next to the diagonal, statically
+    const bool pool_wg = pool && !near_wg;
     if (inv_wg && !pool && a.hybrid_near < 0) {
         potri_team(a, (int)blockIdx.x - a.g1, (int)gridDim.x - a.g1, lds, smem);
         return;
@@ -1667,7 +1674,7 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             unsigned x;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
             const int mypool = (int)(x & 7) % a.pool_nx;
-            __hip_atomic_fetch_add(a.sync + 8 + mypool, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (pool_wg) __hip_atomic_fetch_add(a.sync + 8 + mypool, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_add(a.sync + 1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             ok = pk_spin(a.sync + 1, (int)gridDim.x - nchain, a.info + 1, a.timeout) ? 1 : 0;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -1694,8 +1701,25 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
         const bool hybrid = !pool && a.g1 > 0 && a.hybrid_near >= 0;
         const bool banded = !hybrid && a.band_w > 0 && a.band_w < W;
         const int band = a.split_band;
-        if (pool) {
+        if (pool_wg) {
             // nothing is dealt: the lists are the pool's
+        } else if (near_wg) {
+            // the tiles next to the diagonal (and their second halves), round-robin over the near workers in the usual order
+            int cn = 0;
+            for (int k = 0; ok && k < nb; ++k) {
+                const int c = nb - k + min(band, nb - 1 - k);
+                for (int e = k == 0 ? 1 : 0; e < c; ++e) {
+                    const bool second = e >= nb - k;
+                    const int i = second ? k + 1 + (e - (nb - k)) : k + e;
+                    if (i - k > a.pool_near) continue;
+                    if (cn == b_lin && nt < DF_MAXT) {
+                        SW(0, nt) = i; SW(1, nt) = k; SW(2, nt) = 0; SW(3, nt) = 0;
+                        SW(6, nt) = second ? 2 : (e >= 1 && e <= band ? 1 : 0);
+                        ++nt;
+                    }
+                    if (++cn == a.pool_near_w) cn = 0;
+                }
+            }
         } else if (ok && lu_mode && a.lu_w < W) {
             // the usual items in the usual order over the workers behind the first lu_w; the last updates of the sub-diagonal halves
             // (type 3 / 4: columns 0-63 / 64-127 of tile (k+1, k), k >= 1) over those first lu_w
@@ -1815,11 +1839,11 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
     }
     __syncthreads();
     int nt = SW(5, 0), nt2 = SW(13, 0);
-    if (nt < 0 || (!pool && nt == 0 && nt2 == 0)) return;
+    if (nt < 0 || (!pool_wg && nt == 0 && nt2 == 0)) return;
     int first = 0, first2 = 0;
     // dynamic pool: this workgroup's pool, the length of its list, the first entry not yet seen finished, the item in hand
-    const int mypool = pool ? SW(7, 0) : 0;
-    const int pool_len = pool ? (a.pool_n - mypool + a.pool_nx - 1) / a.pool_nx : 0;
+    const int mypool = pool_wg ? SW(7, 0) : 0;
+    const int pool_len = pool_wg ? (a.pool_n - mypool + a.pool_nx - 1) / a.pool_nx : 0;
     int pool_first = 0, claimed = -1;
     long long t_progress = wall_clock64();
     const int slot = tid >> 4, l = tid & 15;
@@ -1859,7 +1883,7 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
         int sel = -1, sel2 = -1;
         const long long st_round0 = a.trace ? wall_clock64() : 0;
         ++st_rounds;
-        if (pool) {
+        if (pool_wg) {
             // ---- dynamic pool: hand back the item of the last task, then claim the next one ----
             if (claimed >= 0) {
                 // The item of the last task.  If it is not finished and its NEXT task has its inputs already, the workgroup keeps it
@@ -2277,13 +2301,13 @@ int potrf_dataflow_max_problems(int Np) {
 // The dynamic pools' item table for an nb-block problem: the factorisation's tiles in the workers' order (column by column, halves
 // behind the whole tiles of their column), then the inverse's items in potri_team's order.  Built on the host once per (device, nb,
 // band, plast) and kept on the device.
-static const int4* pool_item_table(int nb, int band, int plast, int* n_items) {
+static const int4* pool_item_table(int nb, int band, int plast, int near, int* n_items) {
     static std::mutex mtx;
-    static std::map<std::tuple<int, int, int, int>, std::pair<int4*, int>> cache;
+    static std::map<std::tuple<int, int, int, int, int>, std::pair<int4*, int>> cache;
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(mtx);
-    const auto key = std::make_tuple(dev, nb, band, plast);
+    const auto key = std::make_tuple(dev, nb, band, plast, near);
     auto it = cache.find(key);
     if (it != cache.end()) {
         *n_items = it->second.second;
@@ -2295,6 +2319,7 @@ static const int4* pool_item_table(int nb, int band, int plast, int* n_items) {
         for (int e = k == 0 ? 1 : 0; e < c; ++e) {
             const bool second = e >= nb - k;
             const int i = second ? k + 1 + (e - (nb - k)) : k + e;
+            if (i - k <= near) continue;                     // owned statically by the near workers
             v.push_back(int4{0, i, k, second ? 2 : (e >= 1 && e <= band ? 1 : 0)});
         }
     }
@@ -2411,7 +2436,7 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
     // next solve may start -- get owners that carry nothing else (a worker in the middle of a 10 us update of another tile would hold
     // the chain up every other step)
     a.prio_band = std::max(0, (int)tune(TUNE_POTRF_PRIO, 0));
-    a.pool_items = nullptr; a.pool_n = 0; a.pool_nx = 1; a.pool_state = nullptr; a.pool_keep = (int)tune(TUNE_POTRI_POOL_KEEP, 1);
+    a.pool_items = nullptr; a.pool_n = 0; a.pool_nx = 1; a.pool_state = nullptr; a.pool_near = -1; a.pool_near_w = 0; a.pool_keep = (int)tune(TUNE_POTRI_POOL_KEEP, 1);
     a.band_near = (int)tune(TUNE_POTRF_BAND, 2);
     a.band_w = nprob == 1 ? std::max(0, std::min(W - 1, (int)tune(TUNE_POTRF_BAND_W, 0))) : 0;
     a.lu_w = (nchain == 3 && split_sub) ? std::max(0, std::min(W - 1, (int)tune(TUNE_POTRF_LU_W, 0))) : 0;
@@ -2425,15 +2450,20 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
     a.inv_plast = (int)tune(TUNE_POTRI_PLAST, nb >= 12 ? 1 : 0) != 0 ? 1 : 0;
     a.inv_cx = std::max(1, std::min(8, (int)tune(TUNE_POTRI_CX, nb > 16 ? 2 : 1)));
     a.inv_ck = std::max(1, std::min(8, (int)tune(TUNE_POTRI_CK, nb > 16 ? 2 : 1)));
-    if (inv && tune_on(TUNE_POTRI_POOL, nb >= 22) && a.hybrid_near < 0) {
+    if (inv && tune_on(TUNE_POTRI_POOL, nb >= 19) && a.hybrid_near < 0) {
         // dynamic pools, one per XCD (an item's tiles are then only ever touched through ONE L2: no coherence traffic beyond what the
         // static form has).  Modelled before it was built (tools/potri_sched_sim.py, the measured task durations): static ownership
         // 2017 us at N = 4096 (measured 2150), one pool per XCD 1330-1540 depending on the claim's cost.  Measured (ms, factor + inverse,
         // static -> pools; profiles/r06_potri_pool.log): N = 2048: 0.67 -> 0.77, 2560: 1.06 -> 1.05, 3072: 1.29 -> 1.21, 3584: 1.65 -> 1.39,
-        // 4096: 2.16 -> 1.67-1.75.  A scan + claim costs 4-5 us per task, which the short chains of the small sizes cannot hide:
-        // on from N = 2816.
+        // 4096: 2.16 -> 1.65-1.75.  A scan + claim costs 4-5 us per task, which the short chains of the small sizes cannot hide: on
+        // from N = 2432.  Up to N = 3456 the DIAGONAL tiles (whose last update the chain's next block waits for) stay out of the
+        // pools, with 32 workgroups that own them statically and nothing else (ms, static / pools / pools + these; same box,
+        // profiles/r06_potri_pool.log): 2304: 0.880 / 0.912 / 0.879, 2560: 1.052 / 1.015 / 0.973, 3072: 1.300 / 1.209 / 1.170,
+        // 3584: 1.644 / 1.370 / 1.368, 4096: 2.159 / 1.653 / 1.758.
         int n_items = 0;
-        const int4* tab = pool_item_table(nb, split_band, a.inv_plast, &n_items);
+        a.pool_near = (int)tune(TUNE_POTRI_POOL_NEAR, nb <= 27 ? 0 : -1);
+        a.pool_near_w = a.pool_near >= 0 ? std::max(1, std::min(64, (int)tune(TUNE_POTRI_POOL_NEAR_W, 32))) : 0;
+        const int4* tab = pool_item_table(nb, split_band, a.inv_plast, a.pool_near, &n_items);
         const ChipGeometry chip = chip_geometry();
         if (tab && n_items > 0 && n_items <= 2 * nb * nb + 2 * nb) {
             a.pool_items = tab;
