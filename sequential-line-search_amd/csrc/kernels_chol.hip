@@ -1354,6 +1354,18 @@ __device__ __forceinline__ bool pool_item_ready(const PersistArgs& a, const int4
                     p2 = panel_done + i + (long)(j0 + 1) * nb;
                     if (i != k) p3 = panel_done + k + (long)(j0 + 1) * nb;
                 }
+            } else if (j1 - j0 <= 4) {                      // the update chunks of the large sizes (nbo 3, 4): eight flags, unrolled
+                int va[4], vb[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool use = q < j1 - j0;
+                    va[q] = use ? df_flag(panel_done + i + (long)(j0 + q) * nb) : 1;
+                    vb[q] = (use && i != k) ? df_flag(panel_done + k + (long)(j0 + q) * nb) : 1;
+                }
+                bool r = true;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) r = r && va[q] != 0 && vb[q] != 0;
+                return r;
             } else {
                 *lanes = true;
                 return false;
@@ -2301,13 +2313,13 @@ int potrf_dataflow_max_problems(int Np) {
 // The dynamic pools' item table for an nb-block problem: the factorisation's tiles in the workers' order (column by column, halves
 // behind the whole tiles of their column), then the inverse's items in potri_team's order.  Built on the host once per (device, nb,
 // band, plast) and kept on the device.
-static const int4* pool_item_table(int nb, int band, int plast, int near, int* n_items) {
+static const int4* pool_item_table(int nb, int band, int plast, int near, bool with_inverse, int* n_items) {
     static std::mutex mtx;
-    static std::map<std::tuple<int, int, int, int, int>, std::pair<int4*, int>> cache;
+    static std::map<std::tuple<int, int, int, int, int, int>, std::pair<int4*, int>> cache;
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(mtx);
-    const auto key = std::make_tuple(dev, nb, band, plast, near);
+    const auto key = std::make_tuple(dev, nb, band, plast, near, with_inverse ? 1 : 0);
     auto it = cache.find(key);
     if (it != cache.end()) {
         *n_items = it->second.second;
@@ -2323,12 +2335,12 @@ static const int4* pool_item_table(int nb, int band, int plast, int near, int* n
             v.push_back(int4{0, i, k, second ? 2 : (e >= 1 && e <= band ? 1 : 0)});
         }
     }
-    for (int r = 0; r < nb; ++r) {
+    for (int r = 0; with_inverse && r < nb; ++r) {
         v.push_back(int4{10, r, r, 0});
         if (r > 0 && plast) v.push_back(int4{14, r, r - 1, 0});
         for (int j = 0; j < r; ++j) v.push_back(int4{11, r, j, (j == r - 1 && plast) ? 1 : 0});
     }
-    for (int r = 0; r < nb; ++r)
+    for (int r = 0; with_inverse && r < nb; ++r)
         for (int j = 0; j <= r; ++j) v.push_back(int4{12, r, j, 0});
     int4* d = nullptr;
     if (hipMalloc(&d, v.size() * sizeof(int4)) != hipSuccess) {
@@ -2450,7 +2462,9 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
     a.inv_plast = (int)tune(TUNE_POTRI_PLAST, nb >= 12 ? 1 : 0) != 0 ? 1 : 0;
     a.inv_cx = std::max(1, std::min(8, (int)tune(TUNE_POTRI_CX, nb > 16 ? 2 : 1)));
     a.inv_ck = std::max(1, std::min(8, (int)tune(TUNE_POTRI_CK, nb > 16 ? 2 : 1)));
-    if (inv && tune_on(TUNE_POTRI_POOL, nb >= 19) && a.hybrid_near < 0) {
+    const bool pool_inv = inv && tune_on(TUNE_POTRI_POOL, nb >= 19) && a.hybrid_near < 0;
+    const bool pool_fac = !inv && nprob == 1 && tune_on(TUNE_POTRF_POOL, false);
+    if (pool_inv || pool_fac) {
         // dynamic pools, one per XCD (an item's tiles are then only ever touched through ONE L2: no coherence traffic beyond what the
         // static form has).  Modelled before it was built (tools/potri_sched_sim.py, the measured task durations): static ownership
         // 2017 us at N = 4096 (measured 2150), one pool per XCD 1330-1540 depending on the claim's cost.  Measured (ms, factor + inverse,
@@ -2461,9 +2475,9 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
         // profiles/r06_potri_pool.log): 2304: 0.880 / 0.912 / 0.879, 2560: 1.052 / 1.015 / 0.973, 3072: 1.300 / 1.209 / 1.170,
         // 3584: 1.644 / 1.370 / 1.368, 4096: 2.159 / 1.653 / 1.758.
         int n_items = 0;
-        a.pool_near = (int)tune(TUNE_POTRI_POOL_NEAR, nb <= 27 ? 0 : -1);
+        a.pool_near = (int)tune(TUNE_POTRI_POOL_NEAR, (inv && nb <= 27) ? 0 : -1);
         a.pool_near_w = a.pool_near >= 0 ? std::max(1, std::min(64, (int)tune(TUNE_POTRI_POOL_NEAR_W, 32))) : 0;
-        const int4* tab = pool_item_table(nb, split_band, a.inv_plast, a.pool_near, &n_items);
+        const int4* tab = pool_item_table(nb, split_band, a.inv_plast, a.pool_near, inv != nullptr, &n_items);
         const ChipGeometry chip = chip_geometry();
         if (tab && n_items > 0 && n_items <= 2 * nb * nb + 2 * nb) {
             a.pool_items = tab;
