@@ -328,7 +328,8 @@ def main():
         try_rccl = args.backend == "nccl" and (not args.same_device or os.environ.get("SLS_BENCH_TRY_RCCL_SAME_DEVICE") == "1")
         if try_rccl:
             # The communicator lives on its OWN context and is created (and tried once) on a watchdog thread: if RCCL's
-            # bootstrap cannot complete on this node the measurement still happens, over the rendezvous group, and says so.
+            # bootstrap cannot complete on this node every rank learns so (all_reduce below) and the run fails with the reason,
+            # instead of hanging in a collective; only the same-device test mode or an explicit override continues over gloo.
             import threading
             try:
                 uid = [sls.Comm.unique_id() if rank == 0 else None]

@@ -181,18 +181,6 @@ struct PersistArgs {
     // the update is a whole-tile product (14 + 3 + 21 us against 39): a row that falls behind once never catches up, and sooner
     // or later it is the sub-diagonal one.  The first half's owner solves the tile once the second half has reported (upd_done).
     int split_sub, split_band;
-    // fused inverse, hybrid pool: the factorisation's tiles (i, k) with i - k > hybrid_near are dealt over BOTH teams (an inverse
-    // workgroup runs its factorisation tasks first); -1: the inverse team owns no tile of the factorisation (round-4 form)
-    int hybrid_near;
-    int hybrid_kmax;    // ... only the tiles of the columns before this one (the factorisation's work is front-loaded)
-    int hybrid_rmin;    // ... and the K^-1 items of the rows from this one on go over both teams too (the inverse's work is back-loaded)
-    // factorisation alone, large N: the tiles (i, k) with i - k <= band_near -- the ones whose updates the chain waits for -- have
-    // band_w workers of their own (the first band_w in XCD order), which own nothing else; 0: one deal over all workers
-    int band_w, band_near;
-    // three-workgroup chain: the LAST update of every sub-diagonal half tile (the one that runs behind the chain's solve) is an item of its
-    // own, dealt over the first lu_w workers, which carry nothing else (0: it stays with the tile's owner)
-    int lu_w;
-    int prio_band;      // workers: a ready task of a tile within this many blocks of the diagonal is taken before the others (0: list order)
     // fused inverse, DYNAMIC pools (round 6): the items of both teams in ONE global order (the factorisation's tiles column by column,
     // then the inverse's items in potri_team's order), item n in pool n mod pool_nx = the workgroups of one XCD; any workgroup of the
     // pool claims the first item of the pool's list whose next task has its inputs (compare-and-swap on the item's state word) and
@@ -1501,13 +1489,13 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
     const int b_lin = (int)blockIdx.x - a.nchain;                  // index among the workgroups outside the chain
     const bool near_wg = pool && a.pool_near >= 0 && b_lin >= 0 && b_lin < a.pool_near_w;   // owns tiles next to the diagonal, statically
     const bool pool_wg = pool && !near_wg;
-    if (inv_wg && !pool && a.hybrid_near < 0) {
+    if (inv_wg && !pool) {
         potri_team(a, (int)blockIdx.x - a.g1, (int)gridDim.x - a.g1, lds, smem);
         return;
     }
     // several independent problems share the launch: this workgroup's problem, its rank inside it, the problem's buffers
     const int G = a.g1 > 0 ? a.g1 : gridDim.x / a.nprob, q = inv_wg ? 0 : blockIdx.x / G, b = inv_wg ? G : blockIdx.x - q * G, nb = a.nb, nbo = a.nbo;
-    const int b2 = (int)blockIdx.x - a.g1, G2 = (int)gridDim.x - a.g1;   // inverse team: this workgroup, the team's size
+    const int b2 = (int)blockIdx.x - a.g1;   // inverse team: this workgroup
     a.A += q * a.strideA;
     a.Linv += q * a.strideA;
     a.sync += q * a.stride_sync;
@@ -1524,10 +1512,6 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
     int* upd_done = diag_ready + nb;                    // [i + k nb]: the second half of tile (i, k) carries all its updates
     int* xprog = upd_done + nb * nb;                    // [j]: 4 (s + 1) = the chain's tile (j+1, j) is in global memory up to column block s (FUSE)
     int* xprog2 = xprog + nb;                           // [j]: the same for the tile (j+2, j) right below it (a worker's)
-    const bool lu_mode = FUSE && a.nchain == 3 && a.lu_w > 0;
-    // lu_mode: half h (1, 2) of tile (k+1, k) carries every update but the last: two words of upd_done that nothing else uses (the
-    // sub-diagonal and the diagonal position of column k)
-    auto pre_done = [&](int k, int h) -> int* { return upd_done + (h == 1 ? k + 1 : k) + (long)k * nb; };
     const int nchain = a.nchain;
     if constexpr (FUSE) {
         if (b < 3 && nchain == 3) {
@@ -1710,8 +1694,6 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             widx = rank;
             for (int q = 0; q < xcc; ++q) widx += __hip_atomic_load(a.sync + 8 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        const bool hybrid = !pool && a.g1 > 0 && a.hybrid_near >= 0;
-        const bool banded = !hybrid && a.band_w > 0 && a.band_w < W;
         const int band = a.split_band;
         if (pool_wg) {
             // nothing is dealt: the lists are the pool's
@@ -1732,53 +1714,7 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
                     if (++cn == a.pool_near_w) cn = 0;
                 }
             }
-        } else if (ok && lu_mode && a.lu_w < W) {
-            // the usual items in the usual order over the workers behind the first lu_w; the last updates of the sub-diagonal halves
-            // (type 3 / 4: columns 0-63 / 64-127 of tile (k+1, k), k >= 1) over those first lu_w
-            const int R = a.lu_w;
-            const int me_near = widx < R ? widx : -1, me_far = widx >= R ? widx - R : -1;
-            int cn = 0, cf = 0;
-            auto put = [&](int i, int k, int type) {
-                if (nt < DF_MAXT) { SW(0, nt) = i; SW(1, nt) = k; SW(2, nt) = 0; SW(3, nt) = 0; SW(6, nt) = type; ++nt; }
-            };
-            for (int k = 0; k < nb; ++k) {
-                const int c = nb - k + min(band, nb - 1 - k);
-                for (int e = k == 0 ? 1 : 0; e < c; ++e) {
-                    const bool second = e >= nb - k;
-                    const int i = second ? k + 1 + (e - (nb - k)) : k + e;
-                    if (cf == me_far) put(i, k, second ? 2 : (e >= 1 && e <= band ? 1 : 0));
-                    if (++cf == W - R) cf = 0;
-                }
-                if (k >= 1 && k + 1 <= nb - 1)
-                    for (int h = 1; h <= 2; ++h) {
-                        if (cn == me_near) put(k + 1, k, 2 + h);
-                        if (++cn == R) cn = 0;
-                    }
-            }
-        } else if (ok && banded) {
-            // At N = 8192 every worker is busy with 30 us updates of tiles far from the diagonal most of the time, and the chain's two
-            // tiles of the next step queue behind them: it stood still for 1.2 of the 4.1 ms (POTRF_BENCH_TRACE).  The band next to
-            // the diagonal therefore has owners that carry nothing else -- the first band_w workers in XCD order, i.e. the CUs around
-            // the chain's own, sharing its panels in one L2.
-            const int R = a.band_w;
-            const int me_near = widx < R ? widx : -1, me_far = widx >= R ? widx - R : -1;
-            int cn = 0, cf = 0;
-            for (int k = 0; k < nb; ++k) {
-                const int c = nb - k + min(band, nb - 1 - k);
-                for (int e = k == 0 ? 1 : 0; e < c; ++e) {
-                    const bool second = e >= nb - k;
-                    const int i = second ? k + 1 + (e - (nb - k)) : k + e;
-                    bool mine;
-                    if (i - k <= a.band_near) { mine = cn == me_near; if (++cn == R) cn = 0; }
-                    else { mine = cf == me_far; if (++cf == W - R) cf = 0; }
-                    if (mine && nt < DF_MAXT) {
-                        SW(0, nt) = i; SW(1, nt) = k; SW(2, nt) = 0; SW(3, nt) = 0;
-                        SW(6, nt) = second ? 2 : (e >= 1 && e <= band ? 1 : 0);
-                        ++nt;
-                    }
-                }
-            }
-        } else if (ok && !hybrid) {
+        } else if (ok) {
             // tiles in column-major order (without (0, 0)) dealt round-robin: even in total work and at every stage (a cyclic
             // PR x PC owner grid left 1.4x the mean work on some owners: 5.7 vs 5.0 ms at N = 8192, round 3)
             // split_band: column k carries extra items, the second halves of its tiles (k+1, k) .. (k+band, k)
@@ -1795,59 +1731,9 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
                 SW(6, nt) = second ? 2 : (e >= 1 && e <= band ? 1 : 0);        // 0 whole tile, 1 / 2: columns 0-63 / 64-127
                 ++nt;
             }
-        } else if (ok) {
-            // hybrid pool: the same items in the same order, two round-robin deals -- the tiles near the diagonal (whose tasks sit on or
-            // next to the chain's path) over the factorisation's own workers, the others over both teams
-            const int me_near = inv_wg ? -1 : widx, me_far = inv_wg ? W + b2 : widx;
-            int cn = 0, cf = 0;
-            for (int k = 0; k < nb; ++k) {
-                const int c = nb - k + min(band, nb - 1 - k);
-                for (int e = k == 0 ? 1 : 0; e < c; ++e) {
-                    const bool second = e >= nb - k;
-                    const int i = second ? k + 1 + (e - (nb - k)) : k + e;
-                    bool mine;
-                    if (i - k > a.hybrid_near && k < a.hybrid_kmax) { mine = cf == me_far; if (++cf == W + G2) cf = 0; }
-                    else { mine = cn == me_near; if (++cn == W) cn = 0; }
-                    if (mine && nt < DF_MAXT) {
-                        SW(0, nt) = i; SW(1, nt) = k; SW(2, nt) = 0; SW(3, nt) = 0;
-                        SW(6, nt) = second ? 2 : (e >= 1 && e <= band ? 1 : 0);
-                        ++nt;
-                    }
-                }
-            }
         }
         SW(5, 0) = ok ? nt : -1;
-        int nt2 = 0;
-        if (!pool && (inv_wg || (hybrid && ok))) {
-            // the inverse's items, dealt as in potri_team (arrays 8 .. 14).  Hybrid pool: the K^-1 items of the rows from hybrid_rmin on
-            // -- whose work arrives late, when the factorisation's workers have run out of tiles -- are dealt over BOTH teams
-            // (owner index: inverse workgroup b2, or G2 + the factorisation worker's index)
-            int turn = 0, turn2 = 0;
-            const int me1 = inv_wg ? b2 : -1, me2 = inv_wg ? b2 : G2 + widx;
-            auto put2 = [&](int type, int i, int j) {
-                if (nt2 < DF_MAXT) {
-                    SW(8, nt2) = i; SW(9, nt2) = j; SW(10, nt2) = (type == 1 && j == i - 1 && a.inv_plast) ? 1 : 0; SW(11, nt2) = 0; SW(14, nt2) = type;
-                    ++nt2;
-                }
-            };
-            auto deal = [&](int type, int i, int j) {
-                if (turn == me1) put2(type, i, j);
-                if (++turn == G2) turn = 0;
-            };
-            for (int r = 0; r < nb; ++r) {
-                deal(0, r, r);
-                if (r > 0 && a.inv_plast) deal(4, r, r - 1);
-                for (int j = 0; j < r; ++j) deal(1, r, j);
-            }
-            for (int r = 0; r < nb; ++r)
-                for (int j = 0; j <= r; ++j) {
-                    if (hybrid && r >= a.hybrid_rmin) {
-                        if (turn2 == me2) put2(2, r, j);
-                        if (++turn2 == G2 + W) turn2 = 0;
-                    } else deal(2, r, j);
-                }
-        }
-        SW(13, 0) = nt2;
+        SW(13, 0) = 0;   // the inverse's item tables (arrays 8 .. 14): slot 0 carries a pool's claimed item; nothing is dealt statically here
     }
     __syncthreads();
     int nt = SW(5, 0), nt2 = SW(13, 0);
@@ -1865,19 +1751,14 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
     // one lane's share of "has the next task of the factorisation's item (i, k) at progress d its inputs?" (16 lanes cover an item)
     auto fac_ready_lane = [&](int i, int k, int d, int typ, int l) -> bool {
         bool ok = true;
-        // steps the owner applies (the chain applies step k-1 to (k, k); lu_mode: the last one of a sub-diagonal half is an item of its own)
-        const int target = i == k ? k - 1 : (lu_mode && i == k + 1 && k >= 1 && (typ == 1 || typ == 2)) ? k - 1 : k;
-        if (typ >= 3) {
-            if (l == 0) ok = df_flag(pre_done(k, typ - 2)) != 0;
-            else if (l == 1) ok = df_flag(xprog + k - 1) >= 4;
-            else if (l == 2) ok = df_flag(xprog2 + k - 1) >= 4;
-        } else if (d < target) {
+        const int target = i == k ? k - 1 : k;   // steps the owner applies (the chain applies step k-1 to (k, k))
+        if (d < target) {
             const int j0 = d;
             const int j1 = df_chunk_end(k, j0, target, nbo, a.near);
             const int j = j0 + (l & 7);
             // the last update of a sub-diagonal half tile runs behind the chain's solve of its second operand (FUSE): the
             // first block of that tile instead of the whole
-            const bool streamed = FUSE && nchain == 3 && !lu_mode && i == k + 1 && typ != 0 && j1 == target && j1 - j0 == 1;
+            const bool streamed = FUSE && nchain == 3 && i == k + 1 && typ != 0 && j1 == target && j1 - j0 == 1;
             if (streamed) {
                 if (l == 8) ok = df_flag(xprog + j0) >= 4;
                 else if (l == 0) ok = df_flag(xprog2 + j0) >= 4;
@@ -2008,47 +1889,20 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             }   // claimed < 0
         } else {
         while (first < nt && SW(3, first)) ++first;            // uniform: every thread reads the same LDS words
-        while (first2 < nt2 && SW(11, first2)) ++first2;
-        if (first >= nt && first2 >= nt2) break;
+        if (first >= nt) break;
         // ---- which tasks have their inputs? 16 lanes per tile, one flag per lane ----
         if (first < nt) {
             const int t = first + slot;
             bool valid = t < nt && !SW(3, t);
             bool ok = true;
-            if (valid) {
-                ok = fac_ready_lane(SW(0, t), SW(1, t), SW(2, t), SW(6, t), l);
-                if (a.trace && SW(6, t) == 3 && l <= 2 && ok && a.trace[16 * (SW(1, t) - 1) + 5 + l] == 0)
-                    a.trace[16 * (SW(1, t) - 1) + 5 + l] = wall_clock64();   // probes: when each input of a last-update item was first seen
-            }
+            if (valid) ok = fac_ready_lane(SW(0, t), SW(1, t), SW(2, t), SW(6, t), l);
             const unsigned long long m = __ballot(ok);
             const unsigned grp = (unsigned)(m >> (16 * ((tid >> 4) & 3))) & 0xffffu;
-            // 2: ready and within prio_band blocks of the diagonal (look-ahead: such a task goes first, whatever its place in the list)
-            if (l == 0) SW(4, slot) = (valid && grp == 0xffffu) ? ((a.prio_band > 0 && SW(0, t) - SW(1, t) <= a.prio_band) ? 2 : 1) : 0;
+            if (l == 0) SW(4, slot) = (valid && grp == 0xffffu) ? 1 : 0;
             __syncthreads();
 #pragma unroll
             for (int q = DF_WIN - 1; q >= 0; --q)
                 if (SW(4, q)) sel = q;
-            if (a.prio_band > 0) {
-                int sel2_ = -1;
-#pragma unroll
-                for (int q = DF_WIN - 1; q >= 0; --q)
-                    if (SW(4, q) == 2) sel2_ = q;
-                if (sel2_ >= 0) sel = sel2_;
-            }
-            __syncthreads();
-        }
-        if (sel < 0 && first2 < nt2) {                         // nothing of the factorisation's is ready: the inverse's items (potri_team's round)
-            const int t = first2 + slot;
-            const bool valid = t < nt2 && !SW(11, t);
-            bool ok = true;
-            if (valid) ok = potri_item_ready(a, SW(14, t), SW(8, t), SW(9, t), SW(10, t), l);
-            const unsigned long long m = __ballot(ok);
-            const unsigned grp = (unsigned)(m >> (16 * ((tid >> 4) & 3))) & 0xffffu;
-            if (l == 0) SW(12, slot) = (valid && grp == 0xffffu) ? 1 : 0;
-            __syncthreads();
-#pragma unroll
-            for (int q = DF_WIN - 1; q >= 0; --q)
-                if (SW(12, q)) sel2 = q;
             __syncthreads();
         }
         if (sel < 0 && sel2 < 0) {
@@ -2078,27 +1932,14 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             continue;
         }
         const int t = first + sel;
-        const int i = SW(0, t), k = SW(1, t), d = SW(2, t), typ = SW(6, t);
-        const bool lu_sub = lu_mode && i == k + 1 && k >= 1 && (typ == 1 || typ == 2);   // a sub-diagonal half whose last update is somebody else's
-        const int target = i == k ? k - 1 : lu_sub ? k - 1 : k;
+        const int i = SW(0, t), k = SW(1, t), d = SW(2, t);
+        const int target = i == k ? k - 1 : k;
         double* Cik = a.A + (long)i * NB + (long)k * NB * ld;
-        if (typ >= 3) {
-            // the last update of half a sub-diagonal tile, behind the chain's solve of L_{k,k-1} and a worker's of L_{k+1,k-1}
-            if (!stream_update_half(Cik, ld, a.A + (long)i * NB + (long)(k - 1) * NB * ld, a.A + (long)k * NB + (long)(k - 1) * NB * ld, typ - 3,
-                                    xprog2 + (k - 1), xprog + (k - 1), a.info + 1, a.timeout, lds))
-                return;
-            df_publish_add(chain_ready + k);
-            if (a.trace && tid == 0) {
-                a.trace[16 * (k - 1) + 14 + 0] = typ == 3 ? st_task0 : a.trace[16 * (k - 1) + 14];
-                if (typ == 3) a.trace[16 * (k - 1) + 15] = wall_clock64();
-            }
-            if (tid == 0) SW(3, t) = 1;
-            ++st_n_upd;
-        } else if (d < target) {
+        if (d < target) {
             const int j0 = d;
             const int j1 = df_chunk_end(k, j0, target, nbo, a.near);
             const int half = SW(6, t);
-            if (FUSE && nchain == 3 && !lu_mode && half != 0 && i == k + 1 && j1 == target && j1 - j0 == 1) {
+            if (FUSE && nchain == 3 && half != 0 && i == k + 1 && j1 == target && j1 - j0 == 1) {
                 if (!stream_update_half(Cik, ld, a.A + (long)i * NB + (long)j0 * NB * ld, a.A + (long)k * NB + (long)j0 * NB * ld, half - 1,
                                         xprog2 + j0, xprog + j0, a.info + 1, a.timeout, lds))
                     return;
@@ -2129,10 +1970,7 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             const bool last = j1 == target;
             const bool to_chain = last && i <= k + 1;         // (k+1, k) and (k, k) go to the chain after their last update
             if (half != 0) {                                  // a half of a sub-diagonal tile
-                if (to_chain && lu_sub) {                     // every update but the last is in: over to the last update's owner
-                    tile_commit_half<1, true>(Cik, ld, acc, lds, half - 1);
-                    df_publish_store(pre_done(k, half));
-                } else if (to_chain) {
+                if (to_chain) {
                     tile_commit_half<1, true>(Cik, ld, acc, lds, half - 1);
                     df_publish_add(chain_ready + k);
                     if (a.trace && tid == 0 && k >= 1) {      // probes: the last update of tile (k+1, k), first half: begin / end
@@ -2203,10 +2041,9 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
             df_publish_store(panel_done + i + (long)k * nb);
             if (tid == 0) SW(3, t) = 1;
         } else {
-            // no update to apply at all: tiles (1, 0) and (1, 1) (lu_mode: the halves of tile (2, 1), whose only update is the last one's owner's)
+            // no update to apply at all: tiles (1, 0) and (1, 1)
             if (tid == 0) {
-                if (lu_sub) __hip_atomic_store(pre_done(k, typ), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else __hip_atomic_fetch_add(i == k ? diag_ready + k - 1 : chain_ready + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(i == k ? diag_ready + k - 1 : chain_ready + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 SW(3, t) = 1;
             }
         }
@@ -2393,7 +2230,7 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
     // the round-3 chain, 7.3 ms streamed): the round-3 form there too.
     // Round 6: N = 8192 .. 16 256 streamed as well, with WHOLE tiles (split 0: the half-tile owners were what made it slower there, 4.63 ms)
     // and three-step update chunks: 4.10 -> 3.97 ms (profiles/r06_potrf8192_scan.log).  Dedicated owners for the band next to the
-    // diagonal (SLS_POTRF_BAND_W) were measured too and lose at every size of the band (4.2-9.4 ms, r06_potrf8192_band_scan.log).
+    // diagonal (a switch since removed) were measured too and lose at every size of the band (4.2-9.4 ms, r06_potrf8192_band_scan.log).
     const bool stream_dflt = nprob == 1 && (nb <= 40 || (Np >= 8192 && Np < 16384));
     // fuse (SLS_POTRF_FUSE_SYRK): three chain workgroups in rotation (factor / solve / product), see potrf_dataflow_kernel
     const int nchain = (int)tune(TUNE_POTRF_STREAM, stream_dflt ? SLS_POTRF_STREAM_DEFAULT : 0) != 0 && nb >= 4 ? (fuse && nprob == 1 ? 3 : 2) : 1;
@@ -2415,7 +2252,7 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
         // the chip builds the inverse.  Measured (tools/probes/potri_scan.sh; ms, factor + inverse): N = 4096: 96 workers 2.12,
         // 80: 2.22, 112: 2.26, 136: 2.56, 48: 3.05 (separate launches: 2.62); N = 3072: 1.46-1.50 for 80-112 (1.92);
         // N = 2048: 0.84-0.86 for 80-112, 0.89 for 135 (1.18); same bits for every split
-        const int w1_dflt = std::min(tiles, std::max(3 * n_cu / 8, 3 * nb));   // (round-4 split; the hybrid pool's default below)
+        const int w1_dflt = std::min(tiles, std::max(3 * n_cu / 8, 3 * nb));   // (round-4 split)
         const int W1 = std::max(1, std::min(tiles, (int)tune(TUNE_POTRI_W1, w1_dflt)));
         Gp = nchain + W1;
         G2 = n_cu * ps.resident_per_cu - Gp;
@@ -2441,28 +2278,13 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
     a.nchain = nchain;
     a.split_sub = split_sub;
     a.split_band = split_band;
-    a.hybrid_near = inv ? (int)tune(TUNE_POTRI_HYBRID, -1) : -1;
-    a.hybrid_kmax = (int)tune(TUNE_POTRI_HYB_KMAX, nb / 2);
-    a.hybrid_rmin = (int)tune(TUNE_POTRI_HYB_RMIN, nb / 2);
-    // three-workgroup chain: the diagonal and sub-diagonal tiles -- whose last updates run behind the chain's solve and decide when the
-    // next solve may start -- get owners that carry nothing else (a worker in the middle of a 10 us update of another tile would hold
-    // the chain up every other step)
-    a.prio_band = std::max(0, (int)tune(TUNE_POTRF_PRIO, 0));
     a.pool_items = nullptr; a.pool_n = 0; a.pool_nx = 1; a.pool_state = nullptr; a.pool_near = -1; a.pool_near_w = 0; a.pool_keep = (int)tune(TUNE_POTRI_POOL_KEEP, 1);
-    a.band_near = (int)tune(TUNE_POTRF_BAND, 2);
-    a.band_w = nprob == 1 ? std::max(0, std::min(W - 1, (int)tune(TUNE_POTRF_BAND_W, 0))) : 0;
-    a.lu_w = (nchain == 3 && split_sub) ? std::max(0, std::min(W - 1, (int)tune(TUNE_POTRF_LU_W, 0))) : 0;
-    if (a.lu_w > 0 && ((2 * nb + a.lu_w - 1) / a.lu_w > DF_MAXT || (tiles + (W - a.lu_w) - 1) / (W - a.lu_w) > DF_MAXT)) a.lu_w = 0;
-    if (a.band_w > 0) {   // both deals must fit the per-worker tables
-        const int near_tiles = (a.band_near + 1) * nb + n_second, far_tiles = tiles - std::min(tiles, near_tiles);
-        if ((near_tiles + a.band_w - 1) / a.band_w > DF_MAXT || (far_tiles + (W - a.band_w) - 1) / (W - a.band_w) > DF_MAXT) a.band_w = 0;
-    }
     // measured (ms, factor + inverse; two products per row -> one): N = 384: 0.209 -> 0.234, 1024: 0.405 -> 0.411, 2048: 0.759 -> 0.753,
     // 3072: 1.466 -> 1.32, 4096: 2.15 -> 2.15 (there the two teams are short of CUs, not of time on the wavefront)
     a.inv_plast = (int)tune(TUNE_POTRI_PLAST, nb >= 12 ? 1 : 0) != 0 ? 1 : 0;
     a.inv_cx = std::max(1, std::min(8, (int)tune(TUNE_POTRI_CX, nb > 16 ? 2 : 1)));
     a.inv_ck = std::max(1, std::min(8, (int)tune(TUNE_POTRI_CK, nb > 16 ? 2 : 1)));
-    const bool pool_inv = inv && tune_on(TUNE_POTRI_POOL, nb >= 19) && a.hybrid_near < 0;
+    const bool pool_inv = inv && tune_on(TUNE_POTRI_POOL, nb >= 19);
     const bool pool_fac = !inv && nprob == 1 && tune_on(TUNE_POTRF_POOL, false);
     if (pool_inv || pool_fac) {
         // dynamic pools, one per XCD (an item's tiles are then only ever touched through ONE L2: no coherence traffic beyond what the
@@ -2484,8 +2306,6 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
             a.pool_n = n_items;
             a.pool_nx = std::max(1, std::min(8, chip.n_xcd));
             a.pool_state = sync + DF_FACT + 5 * nb + 3 * nb * nb;   // behind xprog2: 2 nb^2 + 2 nb words (potrf_dataflow_sync_ints)
-            a.lu_w = 0;
-            a.band_w = 0;
         }
     }
     {

@@ -13,7 +13,7 @@ namespace slsk {
     X(NLL_SMALL) X(SMALL_ZEROCOPY) X(NLL_BATCH) X(MAP_DEVICE) X(MAP_TRACE) X(SMALL_XLDS) X(MULTI_RCCL) X(PERSIST)                \
     X(ACQ_WG_PER_CU) X(GATE_PHASE) X(TAIL_SPLIT) X(LBFGS_REG) X(TRI_WG_PER_CU) X(POTRF_MODE) X(POTRF_DNBO) X(POTRF_NBO)          \
     X(LAUUM_N64) X(POTRI_FUSED) X(POTRF_STREAM) X(POTRF_SPLIT) X(POTRI_W1) X(POTRF_TIMEOUT_TICKS) X(POTRF_DNEAR) X(POTRI_PLAST)  \
-    X(POTRI_CX) X(POTRI_CK) X(WAVE_STAGE) X(WAVE_COOP) X(GRAD_SPLIT_TILES) X(EVAL_SLOTS) X(GATE_EVERY) X(POTRF_FUSE_SYRK) X(POTRI_HYBRID) X(POTRF_BAND_W) X(POTRF_BAND) X(POTRF_LU_W) X(POTRF_PRIO) X(POTRI_HYB_KMAX) X(POTRI_HYB_RMIN) X(POTRI_POOL) X(POTRF_POOL) X(POTRI_POOL_KEEP) X(POTRI_POOL_NEAR) X(POTRI_POOL_NEAR_W)
+    X(POTRI_CX) X(POTRI_CK) X(WAVE_STAGE) X(WAVE_COOP) X(GRAD_SPLIT_TILES) X(EVAL_SLOTS) X(GATE_EVERY) X(POTRF_FUSE_SYRK) X(POTRI_POOL) X(POTRF_POOL) X(POTRI_POOL_KEEP) X(POTRI_POOL_NEAR) X(POTRI_POOL_NEAR_W)
 enum TuneKey {
 #define SLS_TK(name) TUNE_##name,
     SLS_TUNING_KEYS(SLS_TK)
