@@ -26,6 +26,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# RCCL between processes needs dmabuf IPC on this host driver (hipIpcGetMemHandle fails otherwise); read by the HSA runtime when
+# it initialises, i.e. at the first HIP call below -- a launcher that did not export it still gets it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X dense fp64 matrix peak: 256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz
                                # (v_mfma_f64_16x16x4_f64 = 2048 FLOP / 64 clk / SIMD; MI355X_MICROARCH.md gives no
