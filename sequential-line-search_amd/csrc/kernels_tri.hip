@@ -240,7 +240,9 @@ void launch_trtri(hipStream_t s, const double* L, int Np, double* Linv, double* 
         const long pstride = (long)2 * h * NB * (ld + 1);
         const long off21 = (long)h * NB;          // block (S, F): rows of the second half, columns of the first
         const long off12 = (long)h * NB * ld;     // block (F, S)
-        const bool narrow = (long)h * h * pairs <= 512;   // fewer 128 x 128 tiles than workgroup slots: half tiles
+        // fewer 128 x 128 tiles than two per CU: half tiles (same bits).  Measured per level at N = 8192 (rocprofv3 kernel trace, us per
+        // product; half / whole tiles): 512 tiles (h = 16): 288 / 273; 256 tiles (h = 8): 110 / 117 (SLS_TRTRI_NARROW = the threshold)
+        const bool narrow = (long)h * h * pairs <= tune(TUNE_TRTRI_NARROW, 511);
         // W = U_FF * L_SF^T : A = U_FF (M-contig, k >= 128 tm), B elem(n,k) = L_SF[n + k ld] (M-contig); columns n in S
         GemmDesc g1 = mkdesc(U, ld, L + off21, ld, tmp + off12, ld, h, h, h * NB, 1.0, 0.0);
         g1.strideA = g1.strideB = g1.strideC = pstride;

@@ -12,7 +12,7 @@ namespace slsk {
     X(POOL_MB) X(FIT_SMALL) X(TRI_PREDICT) X(WAVE_PATH) X(IO_STAGE) X(EVAL_ZEROCOPY) X(WAVE_TRACE) X(COMPACT) \
     X(NLL_SMALL) X(SMALL_ZEROCOPY) X(NLL_BATCH) X(MAP_DEVICE) X(MAP_TRACE) X(SMALL_XLDS) X(MULTI_RCCL) X(PERSIST)                \
     X(ACQ_WG_PER_CU) X(GATE_PHASE) X(TAIL_SPLIT) X(LBFGS_REG) X(TRI_WG_PER_CU) X(POTRF_MODE) X(POTRF_DNBO) X(POTRF_NBO)          \
-    X(LAUUM_N64) X(POTRI_FUSED) X(POTRF_STREAM) X(POTRF_SPLIT) X(POTRI_W1) X(POTRF_TIMEOUT_TICKS) X(POTRF_DNEAR) X(POTRI_PLAST)  \
+    X(LAUUM_N64) X(TRTRI_NARROW) X(POTRI_FUSED) X(POTRF_STREAM) X(POTRF_SPLIT) X(POTRI_W1) X(POTRF_TIMEOUT_TICKS) X(POTRF_DNEAR) X(POTRI_PLAST)  \
     X(POTRI_CX) X(POTRI_CK) X(WAVE_STAGE) X(WAVE_COOP) X(GRAD_SPLIT_TILES) X(EVAL_SLOTS) X(GATE_EVERY) X(POTRF_FUSE_SYRK) X(POTRI_POOL) X(POTRF_POOL) X(POTRI_POOL_KEEP) X(POTRI_POOL_NEAR) X(POTRI_POOL_NEAR_W)
 enum TuneKey {
 #define SLS_TK(name) TUNE_##name,
