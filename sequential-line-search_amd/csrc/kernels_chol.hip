@@ -2284,8 +2284,10 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
     a.inv_plast = (int)tune(TUNE_POTRI_PLAST, nb >= 12 ? 1 : 0) != 0 ? 1 : 0;
     a.inv_cx = std::max(1, std::min(8, (int)tune(TUNE_POTRI_CX, nb > 16 ? 2 : 1)));
     a.inv_ck = std::max(1, std::min(8, (int)tune(TUNE_POTRI_CK, nb > 16 ? 2 : 1)));
-    const bool pool_inv = inv && tune_on(TUNE_POTRI_POOL, nb >= 19);
-    const bool pool_fac = !inv && nprob == 1 && tune_on(TUNE_POTRF_POOL, false);
+    const bool pool_inv = inv && tune_on(TUNE_POTRI_POOL, nb >= 19) && W + G2 >= 128;
+    // (a pool is served by the workgroups of ITS XCD only: a launch too small to put workers on every XCD -- found by the schedule test at
+    // nb = 3: six workgroups, the item of XCD 0's pool never ran and the launch gave up -- keeps the static deal)
+    const bool pool_fac = !inv && nprob == 1 && tune_on(TUNE_POTRF_POOL, false) && W >= 128;
     if (pool_inv || pool_fac) {
         // dynamic pools, one per XCD (an item's tiles are then only ever touched through ONE L2: no coherence traffic beyond what the
         // static form has).  Modelled before it was built (tools/potri_sched_sim.py, the measured task durations): static ownership
@@ -2310,7 +2312,9 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
     }
     {
         PersistSerialScope serial(ps, s);
-        if (fuse) hipLaunchKernelGGL(potrf_dataflow_kernel<true>, dim3(Gp * nprob + G2), dim3(256), DIAG_LDS_BYTES, s, a);
+        // the <true> instantiation carries ONLY the three-workgroup chain: a forced SLS_POTRF_FUSE_SYRK=1 where the chain is not streamed
+        // (fewer than four blocks, SLS_POTRF_STREAM=0, several problems per launch) takes the other one
+        if (nchain == 3) hipLaunchKernelGGL(potrf_dataflow_kernel<true>, dim3(Gp * nprob + G2), dim3(256), DIAG_LDS_BYTES, s, a);
         else hipLaunchKernelGGL(potrf_dataflow_kernel<false>, dim3(Gp * nprob + G2), dim3(256), DIAG_LDS_BYTES, s, a);
     }
     // T_jj for every diagonal block, off the factorisation's serial chain (callers that only need the factor skip it; the fused

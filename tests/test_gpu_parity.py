@@ -90,6 +90,10 @@ def test_potrf_schedules_agree(N, monkeypatch):
                       ("dataflow1_nosplit", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "1", "SLS_POTRF_SPLIT": "0"}),
                       ("dataflow1_band1", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "1", "SLS_POTRF_SPLIT": "1"}),
                       ("dataflow1_band3", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "1", "SLS_POTRF_SPLIT": "3"}),
+                      # round 6: the chain as three workgroups in rotation / two taking turns; the workers' tiles claimed from pools per XCD
+                      ("dataflow1_chain3", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "1", "SLS_POTRF_FUSE_SYRK": "1"}),
+                      ("dataflow1_chain2", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "1", "SLS_POTRF_FUSE_SYRK": "0"}),
+                      ("dataflow1_pool", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "1", "SLS_POTRF_POOL": "1"}),
                       ("dataflow2", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "2"}),
                       ("dataflow4near", {"SLS_POTRF_MODE": "3", "SLS_POTRF_DNBO": "4", "SLS_POTRF_DNEAR": "2"})):
         for k in [k for k in os.environ if k.startswith("SLS_POTRF_")]:
@@ -101,7 +105,7 @@ def test_potrf_schedules_agree(N, monkeypatch):
         bad = A.copy(); bad[N - 5, N - 5] = -1.0
         with pytest.raises(sls().SlsError):
             c.potrf(bad)
-        assert c.prof_get("potrf_fallbacks")[1] == 0
+        assert c.prof_get("potrf_fallbacks")[1] == 0, name
         c.close()
     L = np.linalg.cholesky(A)
     for name, v in res.items():
@@ -111,7 +115,8 @@ def test_potrf_schedules_agree(N, monkeypatch):
     close(res["dataflow2"], res["multi"], rtol=1e-12, atol=1e-13)
     close(res["dataflow4near"], res["multi"], rtol=1e-12, atol=1e-13)
     # ... and so do the follower workgroup, the streamed solves and the half-tile owners (same slabs, same MFMA order)
-    for name in ("dataflow1_nostream", "dataflow1_nosplit", "dataflow1_band1", "dataflow1_band3"):
+    for name in ("dataflow1_nostream", "dataflow1_nosplit", "dataflow1_band1", "dataflow1_band3", "dataflow1_chain3", "dataflow1_chain2",
+                 "dataflow1_pool"):
         assert np.array_equal(res[name], res["dataflow1"]), name
     close(res["multi2"], res["multi"], rtol=1e-12, atol=1e-13)
 
@@ -175,6 +180,71 @@ def test_fused_inverse_matches_separate_launches(oracle, N, D, monkeypatch):
     assert c.prof_get("potrf_fallbacks")[1] == 1
     close(Kg, s["Kinv"], rtol=1e-9, atol=1e-11 * scale)
     g.close(); c.close()
+
+
+@pytest.mark.parametrize("N,D", [(2500, 6), (3000, 9), (3600, 4)])
+def test_pools_chain_forms_and_static_teams_give_identical_bits(oracle, N, D, monkeypatch):
+    """Round 6's schedules of the fused factor + inverse (kernels_chol.hip): dynamic pools per XCD (default from N = 2432), with the
+    diagonal tiles owned statically beside them (default up to N = 3456) or pooled too, with and without keeping an item across
+    tasks; static teams (SLS_POTRI_POOL=0); the chain as three workgroups in rotation (default at N = 1536-2560) or two taking
+    turns.  Who runs a task, and when, never changes what it computes: the factor, K^-1 and alpha of every variant carry the bits of
+    the default (src/gaussian-process-regressor.cpp:159,211: one MatrixXd::inverse() in the reference)."""
+    m = sls()
+    X, y, theta, b = synth_problem(oracle, D, N)
+    knobs = ("SLS_POTRI_POOL", "SLS_POTRI_POOL_KEEP", "SLS_POTRI_POOL_NEAR", "SLS_POTRI_POOL_NEAR_W", "SLS_POTRF_FUSE_SYRK", "SLS_POTRI_W1")
+    out = {}
+    for name, env in (("default", {}), ("static", {"SLS_POTRI_POOL": "0"}), ("pool_nokeep", {"SLS_POTRI_POOL": "1", "SLS_POTRI_POOL_KEEP": "0"}),
+                      ("pool_all", {"SLS_POTRI_POOL": "1", "SLS_POTRI_POOL_NEAR": "-1"}),
+                      ("pool_near1", {"SLS_POTRI_POOL": "1", "SLS_POTRI_POOL_NEAR": "1", "SLS_POTRI_POOL_NEAR_W": "16"}),
+                      ("chain3", {"SLS_POTRF_FUSE_SYRK": "1"}), ("chain2", {"SLS_POTRF_FUSE_SYRK": "0"}),
+                      ("chain3_static", {"SLS_POTRF_FUSE_SYRK": "1", "SLS_POTRI_POOL": "0", "SLS_POTRI_W1": "90"})):
+        for k in knobs:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = m.Context(0)
+        c.prof_enable(True)
+        g = m.GP(c, X, y, theta, b, 1)
+        out[name] = dict(L=g.matrix(m.GP_CHOL_L), Kinv=g.matrix(m.GP_K_Y_INV), alpha=g.matrix(m.GP_ALPHA))
+        assert c.prof_get("potri")[1] == 1 and c.prof_get("potrf_fallbacks")[1] == 0, name     # ONE fused launch, which did not give up
+        g.close(); c.close()
+    ref = out["default"]
+    assert np.array_equal(ref["Kinv"], ref["Kinv"].T)
+    for name, v in out.items():
+        for key in ("L", "Kinv", "alpha"):
+            assert np.array_equal(v[key], ref[key]), (name, key, float(np.abs(v[key] - ref[key]).max()))
+    Lr = ref["L"]
+    A = Lr @ Lr.T
+    R = A @ ref["Kinv"] - np.eye(N)
+    assert np.abs(R).max() < 1e-9 * np.linalg.cond(A) ** 0.5 + 1e-10, np.abs(R).max()
+
+
+@pytest.mark.parametrize("N,D", [(2304, 5)])
+def test_separate_launch_inverse_switches_give_identical_bits(oracle, N, D, monkeypatch):
+    """potrf + trtri + lauum (the form of N > 4096, forced here with SLS_POTRI_FUSED=0): half or whole tiles per level of the
+    recursive doubling (SLS_TRTRI_NARROW), one or two workgroups per CU (SLS_TRI_WG_PER_CU), half-tile lauum (SLS_LAUUM_N64): same slabs,
+    same fragments, same k order -- identical bits (kernels_tri.hip)."""
+    m = sls()
+    X, y, theta, b = synth_problem(oracle, D, N)
+    knobs = ("SLS_POTRI_FUSED", "SLS_TRTRI_NARROW", "SLS_TRI_WG_PER_CU", "SLS_LAUUM_N64")
+    out = {}
+    for name, env in (("default", {}), ("all_whole", {"SLS_TRTRI_NARROW": "0", "SLS_LAUUM_N64": "0"}),
+                      ("all_half", {"SLS_TRTRI_NARROW": "100000", "SLS_LAUUM_N64": "1"}), ("wg1", {"SLS_TRI_WG_PER_CU": "1"}),
+                      ("wg2", {"SLS_TRI_WG_PER_CU": "2"})):
+        for k in knobs:
+            monkeypatch.delenv(k, raising=False)
+        monkeypatch.setenv("SLS_POTRI_FUSED", "0")
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = m.Context(0)
+        c.prof_enable(True)
+        g = m.GP(c, X, y, theta, b, 1)
+        out[name] = dict(L=g.matrix(m.GP_CHOL_L), Kinv=g.matrix(m.GP_K_Y_INV), alpha=g.matrix(m.GP_ALPHA))
+        assert c.prof_get("potri")[1] == 0, name
+        g.close(); c.close()
+    for name, v in out.items():
+        for key in ("L", "Kinv", "alpha"):
+            assert np.array_equal(v[key], out["default"][key]), (name, key)
 
 
 @pytest.mark.parametrize("N,D", [(700, 5), (2100, 12)])
