@@ -182,7 +182,7 @@ def test_fused_inverse_matches_separate_launches(oracle, N, D, monkeypatch):
     g.close(); c.close()
 
 
-@pytest.mark.parametrize("N,D", [(2500, 6), (3000, 9), (3600, 4)])
+@pytest.mark.parametrize("N,D", [(640, 3), (1500, 5), (2500, 6), (3000, 9), (3600, 4)])
 def test_pools_chain_forms_and_static_teams_give_identical_bits(oracle, N, D, monkeypatch):
     """Round 6's schedules of the fused factor + inverse (kernels_chol.hip): dynamic pools per XCD (default from N = 2432), with the
     diagonal tiles owned statically beside them (default up to N = 3456) or pooled too, with and without keeping an item across
