@@ -2301,6 +2301,12 @@ static bool launch_potrf_dataflow_impl(hipStream_t s, double* A, int Np, double*
         int n_items = 0;
         a.pool_near = (int)tune(TUNE_POTRI_POOL_NEAR, (inv && nb <= 27) ? 0 : -1);
         a.pool_near_w = a.pool_near >= 0 ? std::max(1, std::min(64, (int)tune(TUNE_POTRI_POOL_NEAR_W, 32))) : 0;
+        if (a.pool_near >= 0) {
+            // the statically owned tiles must fit their owners' tables (forced switches: a wide band over few owners would not)
+            long near_items = 0;
+            for (int kk = 0; kk < nb; ++kk) near_items += std::min(a.pool_near, nb - 1 - kk) + 1 + std::min(std::min(split_band, a.pool_near), nb - 1 - kk);
+            if ((near_items + a.pool_near_w - 1) / a.pool_near_w > DF_MAXT) { a.pool_near = -1; a.pool_near_w = 0; }
+        }
         const int4* tab = pool_item_table(nb, split_band, a.inv_plast, a.pool_near, inv != nullptr, &n_items);
         const ChipGeometry chip = chip_geometry();
         if (tab && n_items > 0 && n_items <= 2 * nb * nb + 2 * nb) {

@@ -196,6 +196,9 @@ def test_pools_chain_forms_and_static_teams_give_identical_bits(oracle, N, D, mo
     for name, env in (("default", {}), ("static", {"SLS_POTRI_POOL": "0"}), ("pool_nokeep", {"SLS_POTRI_POOL": "1", "SLS_POTRI_POOL_KEEP": "0"}),
                       ("pool_all", {"SLS_POTRI_POOL": "1", "SLS_POTRI_POOL_NEAR": "-1"}),
                       ("pool_near1", {"SLS_POTRI_POOL": "1", "SLS_POTRI_POOL_NEAR": "1", "SLS_POTRI_POOL_NEAR_W": "16"}),
+                      # a band too wide for ONE owner's table (the launcher then pools everything) / a wide band that fits two
+                      ("pool_near_wide1", {"SLS_POTRI_POOL": "1", "SLS_POTRI_POOL_NEAR": "8", "SLS_POTRI_POOL_NEAR_W": "1"}),
+                      ("pool_near_wide4", {"SLS_POTRI_POOL": "1", "SLS_POTRI_POOL_NEAR": "6", "SLS_POTRI_POOL_NEAR_W": "4"}),
                       ("chain3", {"SLS_POTRF_FUSE_SYRK": "1"}), ("chain2", {"SLS_POTRF_FUSE_SYRK": "0"}),
                       ("chain3_static", {"SLS_POTRF_FUSE_SYRK": "1", "SLS_POTRI_POOL": "0", "SLS_POTRI_W1": "90"})):
         for k in knobs:
