@@ -199,6 +199,9 @@ def test_pools_chain_forms_and_static_teams_give_identical_bits(oracle, N, D, mo
                       # a band too wide for ONE owner's table (the launcher then pools everything) / a wide band that fits two
                       ("pool_near_wide1", {"SLS_POTRI_POOL": "1", "SLS_POTRI_POOL_NEAR": "8", "SLS_POTRI_POOL_NEAR_W": "1"}),
                       ("pool_near_wide4", {"SLS_POTRI_POOL": "1", "SLS_POTRI_POOL_NEAR": "6", "SLS_POTRI_POOL_NEAR_W": "4"}),
+                      # fewer workgroups in the factorisation's team than owners of the diagonal tiles: some owners sit in the other team
+                      ("pool_small_team", {"SLS_POTRI_POOL": "1", "SLS_POTRI_W1": "7"}),
+                      ("pool_big_team", {"SLS_POTRI_POOL": "1", "SLS_POTRI_W1": "200"}),
                       ("chain3", {"SLS_POTRF_FUSE_SYRK": "1"}), ("chain2", {"SLS_POTRF_FUSE_SYRK": "0"}),
                       ("chain3_static", {"SLS_POTRF_FUSE_SYRK": "1", "SLS_POTRI_POOL": "0", "SLS_POTRI_W1": "90"})):
         for k in knobs:
