@@ -2,10 +2,8 @@
 
 Tolerance: BASELINE.json's north_star asks for 1e-6 relative in fp64; the assertions below use 1e-6 or tighter
 (absolute floors only where the quantity itself underflows / cancels to ~0)."""
-import os
-
 import ctypes as C
-
+import os
 import time
 
 import numpy as np
