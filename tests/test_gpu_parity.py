@@ -223,6 +223,18 @@ def test_pools_chain_forms_and_static_teams_give_identical_bits(oracle, N, D, mo
     A = Lr @ Lr.T
     R = A @ ref["Kinv"] - np.eye(N)
     assert np.abs(R).max() < 1e-9 * np.linalg.cond(A) ** 0.5 + 1e-10, np.abs(R).max()
+    # forced expiry of every device-side wait (pool scans included): the launch gives up, the fit is recomputed with separate launches
+    for k in knobs:
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("SLS_POTRF_TIMEOUT_TICKS", "1")
+    c = m.Context(0)
+    c.prof_enable(True)
+    g = m.GP(c, X, y, theta, b, 1)
+    Kg = g.matrix(m.GP_K_Y_INV)
+    assert c.prof_get("potrf_fallbacks")[1] == 1
+    close(Kg, ref["Kinv"], rtol=1e-9, atol=1e-11 * np.abs(ref["Kinv"]).max())
+    g.close(); c.close()
+    monkeypatch.delenv("SLS_POTRF_TIMEOUT_TICKS")
 
 
 @pytest.mark.parametrize("N", [640, 1500, 2500, 3000])
