@@ -86,14 +86,15 @@ def test_rccl_communicator_single_rank_allgather():
     comm.close(); ctx.close()
 
 
-def test_concurrent_contexts_on_one_device_do_not_fall_back(oracle):
+@pytest.mark.parametrize("N", [1500, 2700])      # static teams + three-workgroup chain / dynamic pools per XCD (round 6)
+def test_concurrent_contexts_on_one_device_do_not_fall_back(oracle, N):
     """Two host threads, one context each, on the SAME GPU, fitting at the same time (what sls_multi does with a repeated
     device, and what sls_hip.h recommends for multi-threaded callers).  The single-launch Cholesky needs every workgroup resident
     at once, so two of them in flight would starve each other into their bounded-wait fallback; launches are serialised per
     device instead: same bits as a lone fit, and no fallback recorded on either context."""
     import threading
     m = sls()
-    D, N = 6, 1500
+    D = 6
     X, y, theta, b = synth_problem(oracle, D, N)
     Xs = synth_candidates(oracle, D, 64)
     c0 = m.Context(0)
