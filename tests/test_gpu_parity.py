@@ -295,16 +295,17 @@ def test_separate_launch_inverse_switches_give_identical_bits(oracle, N, D, monk
             assert np.array_equal(v[key], out["default"][key]), (name, key)
 
 
-@pytest.mark.parametrize("N,D", [(700, 5), (2100, 12)])
+@pytest.mark.parametrize("N,D", [(700, 5), (2100, 12), (2700, 9), (3500, 4)])      # the last two: dynamic pools (with / without owned diagonal tiles)
 def test_fused_inverse_inside_the_map_objective(oracle, N, D, monkeypatch):
     """The GP MAP objective + gradient (sls_gp_nll_grad, src/gaussian-process-regressor.cpp:36-193) on the fused factor + inverse
-    launch against the same evaluation on separate launches."""
+    launch against the same evaluation on separate launches; with the pools switched off: the same bits."""
     m = sls()
     X, y, _, _ = synth_problem(oracle, D, N)
     x = np.concatenate([[0.6, 0.01], np.linspace(0.4, 0.9, D)])
     res = {}
-    for name, env in (("fused", {}), ("separate", {"SLS_POTRI_FUSED": "0"})):
+    for name, env in (("fused", {}), ("separate", {"SLS_POTRI_FUSED": "0"}), ("fused_static", {"SLS_POTRI_POOL": "0"})):
         monkeypatch.delenv("SLS_POTRI_FUSED", raising=False)
+        monkeypatch.delenv("SLS_POTRI_POOL", raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         c = m.Context(0)
@@ -312,6 +313,7 @@ def test_fused_inverse_inside_the_map_objective(oracle, N, D, monkeypatch):
         res[name] = h.gp_objective(y, x)
         assert c.prof_get("potrf_fallbacks")[1] == 0
         h.close(); c.close()
+    assert res["fused_static"][0] == res["fused"][0] and np.array_equal(res["fused_static"][1], res["fused"][1])
     np.testing.assert_allclose(res["fused"][0], res["separate"][0], rtol=1e-11)
     g0 = res["separate"][1]
     np.testing.assert_allclose(res["fused"][1], g0, rtol=1e-7, atol=1e-9 * np.abs(g0).max())
