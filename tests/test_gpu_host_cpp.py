@@ -78,3 +78,32 @@ def test_sequential_line_search_nd_c3_size():
     assert len(res) == 30
     assert res[-1] < res[0] and min(res[-5:]) < 0.8 * res[0], res
     assert all(np.isfinite(res))
+
+
+def test_host_layer_environment_switches():
+    """The host layer's process-wide settings (host/device.cpp; read once per process, hence one process each): the device(s) the lazily
+    created contexts live on, NLopt's relative tolerances for the local searches (default 1e-6, 0 = run to the cap) and for the MAP
+    fits (default off), the timing trace.  The scenario (D = 8, 8 iterations, the reference's use_MAP_hyperparams = true) must run under
+    each and end where the default run ends to within what a polished local search can move the slider's end point."""
+    def scenario(**env):
+        p = subprocess.run([os.path.join(BIN, "sequential_line_search_nd"), "8", "8", "1", "1"], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, **env))
+        assert p.returncode == 0, (env, p.stdout[-2000:] + p.stderr[-2000:])
+        res = [float(x) for x in re.findall(r"residual ([-\d.e]+)", p.stdout)]
+        assert len(res) == 8 and all(np.isfinite(res)), (env, p.stdout[-2000:])
+        return res, p.stderr
+    base, err = scenario()
+    assert "ms" not in err or "maximiser" not in err              # no timing trace unless asked for
+    for env in (dict(SLS_DEVICE="0"), dict(SLS_DEVICES="0,0"), dict(SLS_LOCAL_SEARCH_TOL="0"), dict(SLS_LOCAL_SEARCH_TOL="1e-9"),
+                dict(SLS_MAP_FIT_TOL="1e-6")):
+        res, _ = scenario(**env)
+        assert res[-1] < res[0], (env, res)
+        if "SLS_DEVICE" in env:                                   # the same computation on the same device: the same numbers
+            assert res == base, (env, res, base)
+        else:
+            assert abs(res[0] - base[0]) < 0.05 and res[-1] < 1.5 * base[-1] + 0.05, (env, res, base)
+    _, err = scenario(SLS_HOST_TIMING="1")
+    assert re.search(r"\d ms|ms \d|ms=", err), err[-1500:]        # stderr carries the per-call timing lines
+    p = subprocess.run([os.path.join(BIN, "sequential_line_search_nd"), "8", "2", "1", "1"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, SLS_DEVICE="7"))
+    assert p.returncode != 0 and ("device" in (p.stdout + p.stderr).lower())      # a device that is not there: a loud failure, no fallback
