@@ -57,3 +57,31 @@ def test_m0_is_not_live_across_the_saddr_load_statements():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_m0.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "kernels_acq.hip" in r.stdout and "kernels_chol.hip" in r.stdout
+
+
+def test_boundary_header_is_plain_c_and_links(tmp_path):
+    """The drop-in boundary is a C ABI: include/sls_hip.h must compile as C99 with -pedantic (no C++ in the signatures, no torch types),
+    and a plain C program that calls it must link against libsls_hip.so and -- here, without a GPU -- get the library's error code
+    and message back instead of a crash."""
+    import subprocess
+    src = tmp_path / "probe.c"
+    src.write_text('#include <stdio.h>\n#include "sls_hip.h"\n'
+                   'int main(void) {\n'
+                   '    sls_ctx* c = 0;\n'
+                   '    int rc = sls_ctx_create(0, &c);\n'
+                   '    printf("version %d rc %d msg %s\\n", sls_version(), rc, rc ? sls_last_error() : "ok");\n'
+                   '    if (c) sls_ctx_destroy(c);\n'
+                   '    return 0;\n}\n')
+    inc = os.path.join(ROOT, "include")
+    libdir = os.path.join(ROOT, "sequential-line-search_amd")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    exe = tmp_path / "probe"
+    r = subprocess.run(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-lsls_hip", "-Wl,-rpath," + libdir],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and re.search(r"version \d+ rc -?\d+ msg ", r.stdout), r.stdout + r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        assert " rc 0 " not in r.stdout and ("no HIP device" in r.stdout or "no CPU fallback" in r.stdout), r.stdout
