@@ -10,21 +10,33 @@ import heapq
 import sys
 
 
-def build(nb, cx, ck):
-    """items: list of dicts(kind, key, tasks=[(inputs, dur, outputs)]) in the kernel's global order; inputs/outputs are flag names."""
+def build(nb, cx, ck, nbo=1):
+    """items: list of dicts(kind, key, tasks=[(inputs, dur, outputs)]) in the kernel's global order; inputs/outputs are flag names.
+    nbo > 1 (large N): the factorisation's updates run in chunks of nbo steps (single steps for the tiles next to the diagonal), and a
+    chunk of n K = 128 units costs 4 + 14.8 n us (POTRF_BENCH_TRACE at N = 8192: 37.5 us for 2.37 units; 19.6 / 33 for one / two)."""
     fac, inv = [], []
     T_UPD, T_UPD2, T_SOLVE, T_T, T_P = 19.6, 33.0, 14.0, 25.0, 25.0
+
+    def dur(n):
+        return T_UPD if n == 1 else T_UPD2 if n == 2 else 4.0 + 14.8 * n
     for k in range(nb):
         for i in range(k, nb):
             if i == 0:
                 continue
             target = k - 1 if i == k else k
             tasks = []
-            for j in range(target):
+            step = 1 if i - k <= 2 else nbo
+            j = 0
+            while j < target:
+                e = min(j + step, target)
                 outs = []
-                if j == target - 1 and i <= k + 1:
+                if e == target and i <= k + 1:
                     outs = [("diag_ready", k - 1) if i == k else ("chain_ready", k)]
-                tasks.append(([("panel", i, j)] + ([("panel", k, j)] if i != k else []), T_UPD, outs))
+                ins = []
+                for q in range(j, e):
+                    ins += [("panel", i, q)] + ([("panel", k, q)] if i != k else [])
+                tasks.append((ins, dur(e - j), outs))
+                j = e
             if target == 0 and i <= k + 1:
                 tasks.append(([], 0.0, [("diag_ready", k - 1) if i == k else ("chain_ready", k)]))
             if i > k + 1:
@@ -43,7 +55,7 @@ def build(nb, cx, ck):
                 ins = []
                 for k in range(j + d, j + e):
                     ins += [("x", k, j), ("panel", r, k)]
-                tasks.append((ins, T_UPD if e - d == 1 else T_UPD2, []))
+                tasks.append((ins, dur(e - d), []))
                 d = e
             if nterms > 0:
                 tasks.append(([("x", r, r)], T_UPD, []))
@@ -58,14 +70,16 @@ def build(nb, cx, ck):
                 ins = []
                 for k in range(d, e):
                     ins += [("x", k, r), ("x", k, j)]
-                tasks.append((ins, T_UPD if e - d == 1 else T_UPD2, []))
+                tasks.append((ins, dur(e - d), []))
                 d = e
             inv.append(dict(key=("K", r, j), tasks=tasks))
     return fac, inv
 
 
-def simulate(nb, W1, G2, dynamic, cx=2, ck=2, verbose=True, t_over=0.0):
-    fac, inv = build(nb, cx, ck)
+def simulate(nb, W1, G2, dynamic, cx=2, ck=2, verbose=True, t_over=0.0, nbo=1, with_inverse=True):
+    fac, inv = build(nb, cx, ck, nbo)
+    if not with_inverse:
+        inv = []
     T_DIAG, T_SYRK, T_TAIL, T_STREAM = 19.5, 10.7, 3.0, 8.0
     t_flag = {}                     # flag -> time it was raised
     waiting = {}                    # flag -> list of callbacks
