@@ -10,11 +10,12 @@ import heapq
 import sys
 
 
-def build(nb, cx, ck, nbo=1):
+def build(nb, cx, ck, nbo=1, escort=None):
     """items: list of dicts(kind, key, tasks=[(inputs, dur, outputs)]) in the kernel's global order; inputs/outputs are flag names.
     nbo > 1 (large N): the factorisation's updates run in chunks of nbo steps (single steps for the tiles next to the diagonal), and a
     chunk of n K = 128 units costs 4 + 14.8 n us (POTRF_BENCH_TRACE at N = 8192: 37.5 us for 2.37 units; 19.6 / 33 for one / two)."""
     fac, inv = [], []
+    esc = []     # escort = (band, U): the last U updates (and the solve) of the tiles within `band` blocks of the diagonal are items of their own
     T_UPD, T_UPD2, T_SOLVE, T_T, T_P = 19.6, 33.0, 14.0, 25.0, 25.0
 
     def dur(n):
@@ -26,22 +27,40 @@ def build(nb, cx, ck, nbo=1):
             target = k - 1 if i == k else k
             tasks = []
             step = 1 if i - k <= 2 else nbo
+            split_at = target
+            if escort and i - k <= escort[0] and target > 0:
+                split_at = max(0, target - escort[1])
+                step = nbo if split_at > 0 else 1     # what stays with the owner is no longer urgent: full chunks
             j = 0
-            while j < target:
-                e = min(j + step, target)
+            while j < split_at:
+                e = min(j + step, split_at)
                 outs = []
                 if e == target and i <= k + 1:
                     outs = [("diag_ready", k - 1) if i == k else ("chain_ready", k)]
+                if e == split_at and split_at < target:
+                    outs = outs + [("pre", i, k)]
                 ins = []
                 for q in range(j, e):
                     ins += [("panel", i, q)] + ([("panel", k, q)] if i != k else [])
                 tasks.append((ins, dur(e - j), outs))
                 j = e
+            etasks = []
+            j = split_at
+            while j < target:
+                outs = []
+                if j + 1 == target and i <= k + 1:
+                    outs = [("diag_ready", k - 1) if i == k else ("chain_ready", k)]
+                ins = ([("pre", i, k)] if (j == split_at and split_at > 0) else []) + [("panel", i, j)] + ([("panel", k, j)] if i != k else [])
+                etasks.append((ins, dur(1), outs))
+                j += 1
             if target == 0 and i <= k + 1:
                 tasks.append(([], 0.0, [("diag_ready", k - 1) if i == k else ("chain_ready", k)]))
             if i > k + 1:
-                tasks.append(([("fact_start", k)], T_SOLVE, [("panel", i, k)], ("after_fact", k)))
-            fac.append(dict(key=("F", i, k), tasks=tasks))
+                (etasks if etasks else tasks).append(([("fact_start", k)], T_SOLVE, [("panel", i, k)], ("after_fact", k)))
+            if tasks:
+                fac.append(dict(key=("F", i, k), tasks=tasks))
+            if etasks:
+                esc.append(dict(key=("E", i, k), tasks=etasks))
     for r in range(nb):
         inv.append(dict(key=("T", r), tasks=[([("fact", r)], T_T, [("x", r, r)])]))
         if r > 0:
@@ -73,11 +92,18 @@ def build(nb, cx, ck, nbo=1):
                 tasks.append((ins, dur(e - d), []))
                 d = e
             inv.append(dict(key=("K", r, j), tasks=tasks))
-    return fac, inv
+    return (fac, inv, esc) if escort else (fac, inv)
 
 
-def simulate(nb, W1, G2, dynamic, cx=2, ck=2, verbose=True, t_over=0.0, nbo=1, with_inverse=True):
-    fac, inv = build(nb, cx, ck, nbo)
+def simulate(nb, W1, G2, dynamic, cx=2, ck=2, verbose=True, t_over=0.0, nbo=1, with_inverse=True, escort=None, n_escort=0):
+    """escort = (band, U), n_escort = E (static ownership only): E of the W1 workers own nothing but the last U updates (and the solves) of the
+    tiles within `band` blocks of the diagonal, dealt round-robin."""
+    esc = []
+    if escort:
+        fac, inv, esc = build(nb, cx, ck, nbo, escort)
+        W1 -= n_escort
+    else:
+        fac, inv = build(nb, cx, ck, nbo)
     if not with_inverse:
         inv = []
     T_DIAG, T_SYRK, T_TAIL, T_STREAM = 19.5, 10.7, 3.0, 8.0
@@ -112,13 +138,15 @@ def simulate(nb, W1, G2, dynamic, cx=2, ck=2, verbose=True, t_over=0.0, nbo=1, w
             pools[n % W1].append(n)
         n_wg = [1] * W1 + [G2]
     else:
-        pools = [[] for _ in range(W1 + G2)]
+        pools = [[] for _ in range(W1 + G2 + n_escort)]
         for n in range(len(fac)):
             pools[n % W1].append(n)
         for n in range(len(inv)):
             pools[W1 + n % G2].append(len(fac) + n)
-        n_wg = [1] * (W1 + G2)
-    items = fac + inv
+        for n in range(len(esc)):
+            pools[W1 + G2 + n % n_escort].append(len(fac) + len(inv) + n)
+        n_wg = [1] * (W1 + G2 + n_escort)
+    items = fac + inv + esc
     pos = [0] * len(items)
     # chain state
     chain = dict(j=0, free=T_DIAG)
