@@ -1748,6 +1748,7 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
     // optional statistics (probes): ticks of the 100 MHz clock in tasks / in scheduling rounds that found work / idle, task counts
     long long st_task = 0, st_idle = 0, st_t0 = t_progress, st_n_upd = 0, st_n_panel = 0, st_rounds = 0, st_gemm = 0, st_rmw = 0;
     long long st2_task = 0, st2_n = 0, st2_last = 0;           // probes: the inverse's tasks of this workgroup
+    long long st_lost = 0, st_lost_t = 0, st_cas = 0;          // probes (pools): rounds that saw ready items and lost every race, their ticks, claim attempts
     // one lane's share of "has the next task of the factorisation's item (i, k) at progress d its inputs?" (16 lanes cover an item)
     auto fac_ready_lane = [&](int i, int k, int d, int typ, int l) -> bool {
         bool ok = true;
@@ -1855,6 +1856,7 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
                 const int f_rd = min(min(SW(17, 0), SW(17, 1)), min(SW(17, 2), SW(17, 3)));
                 if (f_rd >= (1 << 20)) { __syncthreads(); break; }
                 any_ready = true;
+                ++st_cas;
                 if (tid == f_rd) {                           // the thread that looked at the entry claims it, with the word it saw
                     int expect = w;
                     const bool won = __hip_atomic_compare_exchange_strong(a.pool_state + n, &expect, w | 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
@@ -1883,7 +1885,11 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
                     return;
                 }
                 if (!any_ready) __builtin_amdgcn_s_sleep(32);   // nothing was ready (after lost races: look again at once)
-                if (a.trace) st_idle += wall_clock64() - st_round0;
+                if (a.trace) {
+                    const long long dt = wall_clock64() - st_round0;
+                    st_idle += dt;
+                    if (any_ready) { ++st_lost; st_lost_t += dt; }
+                }
                 continue;
             }
             }   // claimed < 0
@@ -2060,6 +2066,7 @@ __global__ __launch_bounds__(256) void potrf_dataflow_kernel(PersistArgs a) {
         } else {
             long long* o = a.trace + 16 * (long)nb + 16 * (long)(b - 1);
             o[0] = st_task; o[1] = st_idle; o[2] = wall_clock64() - st_t0; o[3] = st_n_upd; o[4] = st_n_panel; o[5] = st_rounds; o[6] = nt; o[7] = st_gemm; o[8] = st_rmw;
+            o[11] = st_lost; o[12] = st_lost_t; o[13] = st_cas;
         }
     }
 }

@@ -95,7 +95,7 @@ def build(nb, cx, ck, nbo=1, escort=None):
     return (fac, inv, esc) if escort else (fac, inv)
 
 
-def simulate(nb, W1, G2, dynamic, cx=2, ck=2, verbose=True, t_over=0.0, nbo=1, with_inverse=True, escort=None, n_escort=0):
+def simulate(nb, W1, G2, dynamic, cx=2, ck=2, verbose=True, t_over=0.0, nbo=1, with_inverse=True, escort=None, n_escort=0, order_c=0.0):
     """escort = (band, U), n_escort = E (static ownership only): E of the W1 workers own nothing but the last U updates (and the solves) of the
     tiles within `band` blocks of the diagonal, dealt round-robin."""
     esc = []
@@ -106,6 +106,10 @@ def simulate(nb, W1, G2, dynamic, cx=2, ck=2, verbose=True, t_over=0.0, nbo=1, w
         fac, inv = build(nb, cx, ck, nbo)
     if not with_inverse:
         inv = []
+    if order_c:
+        # list order by k + c (i - k) instead of column by column: what is near the diagonal in a LATER column goes before the stragglers
+        # far below the diagonal in an earlier one (stable: ties keep the column-major order)
+        fac.sort(key=lambda it: it["key"][2] + order_c * (it["key"][1] - it["key"][2]))
     T_DIAG, T_SYRK, T_TAIL, T_STREAM = 19.5, 10.7, 3.0, 8.0
     t_flag = {}                     # flag -> time it was raised
     waiting = {}                    # flag -> list of callbacks

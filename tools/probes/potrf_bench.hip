@@ -111,15 +111,17 @@ int main(int argc, char** argv) {
                 hipStreamSynchronize(s);
                 std::vector<long long> ht(trn); hipMemcpy(ht.data(), tr, ht.size() * 8, hipMemcpyDeviceToHost);
                 {   // worker statistics
-                    double task = 0, idle = 0, life = 0, tmax = 0, lmax = 0; long nu = 0, np_ = 0, rounds = 0; int nw = 0; double gsum = 0, rsum = 0;
+                    double task = 0, idle = 0, life = 0, tmax = 0, lmax = 0; long nu = 0, np_ = 0, rounds = 0; int nw = 0; double gsum = 0, rsum = 0; long lost = 0, cas = 0; double lost_t = 0;
                     for (int w = 0; w < 512; ++w) {
                         const long long* o = ht.data() + 16 * nb + 16 * w;
                         if (o[6] == 0) continue;
                         ++nw; task += o[0] / 100.0; idle += o[1] / 100.0; life += o[2] / 100.0; tmax = fmax(tmax, o[0] / 100.0); lmax = fmax(lmax, o[2] / 100.0);
                         nu += o[3]; np_ += o[4]; rounds += o[5]; gsum += o[7] / 100.0; rsum += o[8] / 100.0;
+                        lost += o[11]; lost_t += o[12] / 100.0; cas += o[13];
                     }
                     printf("  workers with tiles: %d; per worker (us): in tasks mean %.0f max %.0f, idle rounds mean %.0f, lifetime mean %.0f max %.0f; tasks: %ld updates %ld panels, %ld scheduling rounds; mean task %.1f us; update tasks: k loop %.1f us, C read-modify-write + drain %.1f us (wave 0, mean)\n",
                            nw, task / nw, tmax, idle / nw, life / nw, lmax, nu, np_, rounds, task / (nu + np_), gsum / nu, rsum / nu);
+                    if (cas) printf("  pools: %ld claim attempts for %ld tasks; %ld rounds saw ready items and lost every race (%.0f us per worker in them)\n", cas, nu + np_, lost, lost_t / nw);
                 }
                 printf("dataflow chain trace N=%d (us from the chain's step start): step | wait-for-tiles gemm1+signal gemm2 diag+signal | step start since step 0\n", Np);
                 double waited = 0.0;
